@@ -1,0 +1,290 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under cvids_amd/ imports this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+TRUNC_CONSTANT, TRUNC_INVERSE, TRUNC_QUADRATIC = 0, 1, 2
+COUNTER_NAMES = ["sdf", "col", "col_sat", "probe", "carved", "visited", "candidates", "created", "collected",
+                 "updated_chunks"]
+
+
+def build(force=False):
+    """Compile the oracle with the flags of oracle/Makefile (g++ only, no GPU needed)."""
+    src = os.path.join(_HERE, "chisel_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    f32p = C.POINTER(C.c_float)
+    u8p = C.POINTER(C.c_uint8)
+    i32p = C.POINTER(C.c_int)
+    vp = C.c_void_p
+    L.oc_create.restype = vp
+    L.oc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    L.oc_destroy.argtypes = [vp]
+    L.oc_reset.argtypes = [vp]
+    L.oc_set_integrator.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float]
+    L.oc_set_threads.argtypes = [vp, C.c_int]
+    L.oc_integrate_depth.argtypes = [vp, f32p, C.c_int, C.c_int, f32p] + [C.c_float] * 6
+    L.oc_integrate_depth_color.argtypes = ([vp, f32p, C.c_int, C.c_int, f32p] + [C.c_float] * 6 +
+                                           [u8p, C.c_int, C.c_int, C.c_int, f32p] + [C.c_float] * 4)
+    L.oc_get_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.oc_get_phase_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.oc_num_chunks.argtypes = [vp]
+    L.oc_list_chunks.argtypes = [vp, i32p]
+    L.oc_has_chunk.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.oc_get_chunk.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p, f32p, u8p]
+    L.oc_remove_chunk.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.oc_num_meshes_to_update.argtypes = [vp]
+    L.oc_list_meshes_to_update.argtypes = [vp, i32p]
+    L.oc_update_meshes.argtypes = [vp, C.c_int]
+    L.oc_num_meshes.argtypes = [vp]
+    L.oc_list_meshes.argtypes = [vp, i32p]
+    L.oc_mesh_size.argtypes = [vp, C.c_int, C.c_int, C.c_int, i32p, i32p]
+    L.oc_get_mesh.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
+    L.oc_save_ply.argtypes = [vp, C.c_char_p]
+    L.oc_get_sdf.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_double)]
+    L.oc_get_sdf_and_gradient.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_double), f32p]
+    L.oc_truncation.restype = C.c_float
+    L.oc_truncation.argtypes = [C.c_int, C.c_float, C.c_float]
+    L.oc_weight.restype = C.c_float
+    L.oc_weight.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.oc_dist_integrate.argtypes = [f32p, f32p, C.c_float, C.c_float]
+    L.oc_color_integrate.argtypes = [u8p] + [C.c_uint8] * 4
+    L.oc_color_at.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+    L.oc_chunk_hash.restype = C.c_uint64
+    L.oc_chunk_hash.argtypes = [C.c_int] * 3
+    L.oc_project_point.argtypes = [C.c_float] * 4 + [f32p, f32p]
+    L.oc_frustum.argtypes = [f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, f32p, f32p, f32p]
+    L.oc_candidates.restype = C.c_int
+    L.oc_candidates.argtypes = [vp, f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, i32p, C.c_int]
+    L.oc_mesh_cube.restype = C.c_int
+    L.oc_mesh_cube.argtypes = [f32p, f32p, C.c_float, f32p, f32p]
+    L.oc_triangle_table_row.argtypes = [C.c_int, i32p]
+    _lib = L
+    return L
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class OracleMap:
+    """chisel::Chisel + ProjectionIntegrator + ChunkManager of the reference, on the CPU."""
+
+    def __init__(self, chunk_size=16, resolution=0.02, use_color=False, threads=16):
+        self.L = lib()
+        cs = (chunk_size,) * 3 if isinstance(chunk_size, int) else tuple(chunk_size)
+        self.chunk_size = cs
+        self.V = cs[0] * cs[1] * cs[2]
+        self.resolution = float(resolution)
+        self.use_color = bool(use_color)
+        self.h = self.L.oc_create(cs[0], cs[1], cs[2], float(resolution), int(use_color))
+        self.L.oc_set_threads(self.h, threads)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oc_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.L.oc_reset(self.h)
+
+    def set_integrator(self, trunc_kind=TRUNC_INVERSE, trunc_param=2.0, weight=1.0, carving=True, carving_dist=0.05):
+        self.L.oc_set_integrator(self.h, trunc_kind, float(trunc_param), float(weight), int(carving), float(carving_dist))
+
+    def integrate_depth(self, depth, pose, intr, near=0.05, far=5.0):
+        d, dp = _f32(depth)
+        p, pp = _f32(np.asarray(pose)[:3, :4])
+        H, W = d.shape
+        fx, fy, cx, cy = intr
+        self.L.oc_integrate_depth(self.h, dp, W, H, pp, fx, fy, cx, cy, near, far)
+
+    def integrate_depth_color(self, depth, pose, intr, color, color_pose=None, color_intr=None, near=0.05, far=5.0):
+        d, dp = _f32(depth)
+        p, pp = _f32(np.asarray(pose)[:3, :4])
+        c, cp = _u8(color)
+        H, W = d.shape
+        CH, CW = c.shape[:2]
+        ch = 1 if c.ndim == 2 else c.shape[2]
+        cpose = pose if color_pose is None else color_pose
+        q, qp = _f32(np.asarray(cpose)[:3, :4])
+        fx, fy, cx, cy = intr
+        cfx, cfy, ccx, ccy = intr if color_intr is None else color_intr
+        self.L.oc_integrate_depth_color(self.h, dp, W, H, pp, fx, fy, cx, cy, near, far, cp, CW, CH, ch, qp,
+                                        cfx, cfy, ccx, ccy)
+
+    def counters(self):
+        out = (C.c_uint64 * len(COUNTER_NAMES))()
+        self.L.oc_get_counters(self.h, out)
+        return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def phase_ms(self):
+        out = (C.c_double * 4)()
+        self.L.oc_get_phase_ms(self.h, out)
+        return dict(zip(["intersect", "allocation", "integration", "garbage"], list(out)))
+
+    def num_chunks(self):
+        return self.L.oc_num_chunks(self.h)
+
+    def chunk_ids(self):
+        n = self.num_chunks()
+        ids = np.zeros((n, 3), dtype=np.int32)
+        if n:
+            self.L.oc_list_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)))
+        return ids
+
+    def has_chunk(self, cid):
+        return bool(self.L.oc_has_chunk(self.h, int(cid[0]), int(cid[1]), int(cid[2])))
+
+    def get_chunk(self, cid):
+        sdf = np.empty(self.V, np.float32)
+        w = np.empty(self.V, np.float32)
+        rgbw = np.zeros((self.V, 4), np.uint8)
+        ok = self.L.oc_get_chunk(self.h, int(cid[0]), int(cid[1]), int(cid[2]),
+                                 sdf.ctypes.data_as(C.POINTER(C.c_float)), w.ctypes.data_as(C.POINTER(C.c_float)),
+                                 rgbw.ctypes.data_as(C.POINTER(C.c_uint8)) if self.use_color else None)
+        if not ok:
+            return None
+        return sdf, w, (rgbw if self.use_color else None)
+
+    def remove_chunk(self, cid):
+        return bool(self.L.oc_remove_chunk(self.h, int(cid[0]), int(cid[1]), int(cid[2])))
+
+    def meshes_to_update(self):
+        n = self.L.oc_num_meshes_to_update(self.h)
+        ids = np.zeros((n, 3), dtype=np.int32)
+        if n:
+            self.L.oc_list_meshes_to_update(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)))
+        return ids
+
+    def update_meshes(self, force=True):
+        self.L.oc_update_meshes(self.h, int(force))
+
+    def mesh_ids(self):
+        n = self.L.oc_num_meshes(self.h)
+        ids = np.zeros((n, 3), dtype=np.int32)
+        if n:
+            self.L.oc_list_meshes(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)))
+        return ids
+
+    def get_mesh(self, cid):
+        nv, ng = C.c_int(0), C.c_int(0)
+        if not self.L.oc_mesh_size(self.h, int(cid[0]), int(cid[1]), int(cid[2]), C.byref(nv), C.byref(ng)):
+            return None
+        v = np.zeros((nv.value, 3), np.float32)
+        n = np.zeros((nv.value, 3), np.float32)
+        c = np.zeros((nv.value, 3), np.float32)
+        g = np.zeros((ng.value, 3), np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        self.L.oc_get_mesh(self.h, int(cid[0]), int(cid[1]), int(cid[2]), fp(v), fp(n), fp(c), fp(g))
+        return {"vertices": v, "normals": n, "colors": c if self.use_color else None, "grids": g}
+
+    def save_ply(self, path):
+        return bool(self.L.oc_save_ply(self.h, str(path).encode()))
+
+    def get_sdf(self, pos):
+        d = C.c_double(0)
+        ok = self.L.oc_get_sdf(self.h, float(pos[0]), float(pos[1]), float(pos[2]), C.byref(d))
+        return (bool(ok), d.value)
+
+    def get_sdf_and_gradient(self, pos):
+        d = C.c_double(0)
+        g = np.zeros(3, np.float32)
+        ok = self.L.oc_get_sdf_and_gradient(self.h, float(pos[0]), float(pos[1]), float(pos[2]), C.byref(d),
+                                            g.ctypes.data_as(C.POINTER(C.c_float)))
+        return (bool(ok), d.value, g)
+
+    def candidates(self, pose, intr, W, H, near=0.05, far=5.0, max_ids=4_000_000):
+        p, pp = _f32(np.asarray(pose)[:3, :4])
+        ids = np.zeros((max_ids, 3), np.int32)
+        n = self.L.oc_candidates(self.h, pp, near, far, intr[1], intr[3], W, H, ids.ctypes.data_as(C.POINTER(C.c_int)), max_ids)
+        return ids[:min(n, max_ids)].copy()
+
+    def fields(self):
+        """dict chunk-id tuple -> (sdf, w, rgbw)"""
+        return {tuple(int(v) for v in cid): self.get_chunk(cid) for cid in self.chunk_ids()}
+
+
+# ---- scalar KAT helpers ------------------------------------------------------------------------
+def truncation(kind, param, depth):
+    return float(lib().oc_truncation(kind, float(param), float(depth)))
+
+
+def weight(w, sd, trunc):
+    return float(lib().oc_weight(float(w), float(sd), float(trunc)))
+
+
+def dist_integrate(sdf, w, d, wu):
+    a, b = C.c_float(sdf), C.c_float(w)
+    lib().oc_dist_integrate(C.byref(a), C.byref(b), float(d), float(wu))
+    return a.value, b.value
+
+
+def color_integrate(rgbw, r, g, b, wu):
+    buf = (C.c_uint8 * 4)(*rgbw)
+    lib().oc_color_integrate(buf, r, g, b, wu)
+    return tuple(buf)
+
+
+def color_at(data, width, channels, row, col):
+    d, dp = _u8(data)
+    out = (C.c_uint8 * 4)()
+    lib().oc_color_at(dp, width, channels, row, col, out)
+    return tuple(out)
+
+
+def chunk_hash(x, y, z):
+    return int(lib().oc_chunk_hash(x, y, z))
+
+
+def frustum(pose, near, far, fy, cy, W, H):
+    p, pp = _f32(np.asarray(pose)[:3, :4])
+    corners = np.zeros((8, 3), np.float32)
+    planes = np.zeros((6, 4), np.float32)
+    aabb = np.zeros(6, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    lib().oc_frustum(pp, near, far, fy, cy, W, H, fp(corners), fp(planes), fp(aabb))
+    return corners, planes, aabb
+
+
+def mesh_cube(sdf8, origin, res):
+    s, sp = _f32(sdf8)
+    o, op = _f32(origin)
+    v = np.zeros((15, 3), np.float32)
+    n = np.zeros((15, 3), np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    k = lib().oc_mesh_cube(sp, op, float(res), fp(v), fp(n))
+    return v[:k].copy(), n[:k].copy()
+
+
+def triangle_table():
+    t = np.zeros((256, 16), np.int32)
+    for i in range(256):
+        lib().oc_triangle_table_row(i, t[i].ctypes.data_as(C.POINTER(C.c_int)))
+    return t
