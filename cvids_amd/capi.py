@@ -1,0 +1,135 @@
+"""ctypes bindings of include/chisel_hip.h (the drop-in C ABI)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libchisel_hip.so")
+
+NUM_COUNTERS = 9
+COUNTER_NAMES = ["sdf", "col", "col_sat", "probe", "carved", "work_chunks", "new_chunks", "updated_chunks", "frames"]
+NUM_KERNELS = 4
+KERNEL_NAMES = ["pyramid", "cull", "integrate", "mesh"]
+TRUNC_CONSTANT, TRUNC_INVERSE, TRUNC_QUADRATIC = 0, 1, 2
+STATUS = {0: "OK", 1: "ERR_INVALID", 2: "ERR_HIP", 3: "ERR_POOL_FULL", 4: "ERR_NOT_FOUND", 5: "ERR_UNSUPPORTED", 6: "ERR_IO"}
+
+
+class ChiselHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("chisel_hip: %s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("chunk_size", C.c_int * 3), ("voxel_resolution", C.c_float), ("use_color", C.c_int),
+                ("device_id", C.c_int), ("max_chunks", C.c_int64), ("n_shards", C.c_int), ("shard_rank", C.c_int),
+                ("shard_block", C.c_int)]
+
+
+class Integrator(C.Structure):
+    _fields_ = [("truncator_kind", C.c_int), ("truncator_param", C.c_float), ("weight", C.c_float),
+                ("carving_enabled", C.c_int), ("carving_dist", C.c_float)]
+
+
+class DepthFrame(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("on_device", C.c_int),
+                ("pose", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("near_plane", C.c_float), ("far_plane", C.c_float)]
+
+
+class ColorFrame(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("channels", C.c_int),
+                ("on_device", C.c_int), ("pose", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float)]
+
+
+# every symbol include/chisel_hip.h declares (tests/test_abi.py checks the header against this list)
+EXPORTS = [
+    "chisel_hip_abi_version", "chisel_hip_last_error", "chisel_hip_device_count", "chisel_hip_create",
+    "chisel_hip_destroy", "chisel_hip_reset", "chisel_hip_set_integrator", "chisel_hip_set_stream",
+    "chisel_hip_synchronize", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
+    "chisel_hip_integrate_batch", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
+    "chisel_hip_list_chunks", "chisel_hip_has_chunk", "chisel_hip_download_chunk", "chisel_hip_upload_chunk",
+    "chisel_hip_meshes_to_update", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
+    "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
+    "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner",
+]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of cvids_amd/csrc (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if not force and os.path.exists(_LIB):
+        newest = max(os.path.getmtime(os.path.join(src_dir, f)) for f in os.listdir(src_dir))
+        newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "chisel_hip.h")))
+        if os.path.getmtime(_LIB) >= newest:
+            return _LIB
+    subprocess.check_call(["make", "-C", src_dir])
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """Load libchisel_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise ChiselHipError(2, "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(there is no CPU fallback)" % _LIB)
+    # torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in one process do not
+    # work ("No HIP GPUs are available" in whichever comes second), so when torch is installed let it load its
+    # runtime first; libchisel_hip.so then binds to that copy.  A C++ host without torch uses /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(_LIB)
+    vp, i32p, f32p, u8p, i64p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
+    L.chisel_hip_last_error.restype = C.c_char_p
+    L.chisel_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.chisel_hip_destroy.argtypes = [vp]
+    L.chisel_hip_reset.argtypes = [vp]
+    L.chisel_hip_set_integrator.argtypes = [vp, C.POINTER(Integrator)]
+    L.chisel_hip_set_stream.argtypes = [vp, vp]
+    L.chisel_hip_synchronize.argtypes = [vp]
+    L.chisel_hip_integrate_depth.argtypes = [vp, C.POINTER(DepthFrame)]
+    L.chisel_hip_integrate_depth_color.argtypes = [vp, C.POINTER(DepthFrame), C.POINTER(ColorFrame)]
+    L.chisel_hip_integrate_batch.argtypes = [vp, C.c_int, C.POINTER(DepthFrame), C.POINTER(ColorFrame)]
+    L.chisel_hip_garbage_collect.argtypes = [vp, i32p, C.c_int]
+    L.chisel_hip_update_meshes.argtypes = [vp, C.c_int]
+    L.chisel_hip_num_chunks.argtypes = [vp, i64p]
+    L.chisel_hip_list_chunks.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.chisel_hip_has_chunk.argtypes = [vp, i32p, i32p]
+    L.chisel_hip_download_chunk.argtypes = [vp, i32p, f32p, f32p, u8p]
+    L.chisel_hip_upload_chunk.argtypes = [vp, i32p, f32p, f32p, u8p]
+    L.chisel_hip_meshes_to_update.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.chisel_hip_num_meshes.argtypes = [vp, i64p]
+    L.chisel_hip_list_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.chisel_hip_mesh_size.argtypes = [vp, i32p, i64p, i64p]
+    L.chisel_hip_download_mesh.argtypes = [vp, i32p, f32p, f32p, f32p, f32p]
+    L.chisel_hip_get_sdf.argtypes = [vp, f32p, C.POINTER(C.c_double), i32p]
+    L.chisel_hip_get_sdf_and_gradient.argtypes = [vp, f32p, C.POINTER(C.c_double), f32p, i32p]
+    L.chisel_hip_save_ply.argtypes = [vp, C.c_char_p]
+    L.chisel_hip_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+    L.chisel_hip_set_profiling.argtypes = [vp, C.c_int]
+    L.chisel_hip_get_profile.argtypes = [vp, C.POINTER(C.c_double), i64p, C.c_int]
+    L.chisel_hip_chunk_owner.argtypes = [i32p, C.c_int, C.c_int]
+    L.chisel_hip_kat_truncation.argtypes = [C.c_int, C.c_float, f32p, C.c_int, f32p, f32p]
+    L.chisel_hip_kat_dist.argtypes = [f32p, C.c_int, f32p]
+    L.chisel_hip_kat_color.argtypes = [u8p, C.c_int, u8p]
+    L.chisel_hip_debug_frustum_range.argtypes = [f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                 C.c_int, C.c_float, i32p, i32p, f32p, f32p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise ChiselHipError(rc, load_library().chisel_hip_last_error().decode(errors="replace"))

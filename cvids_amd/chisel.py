@@ -1,0 +1,316 @@
+"""Host-side mirror of the reference's operator interface for the TSDF path, over the C ABI.
+
+Names and argument meaning follow OpenChisel (open_chisel/include/open_chisel/*.h) so the parity
+tests read like the reference's call sites (chisel_ros/src/ChiselServer.cpp:480-516):
+
+    chisel = Chisel((16, 16, 16), 0.01, use_color=True)
+    integrator = ProjectionIntegrator(InverseTruncator(1.0), ConstantWeighter(1), 0.05, True)
+    chisel.IntegrateDepthScanColor(integrator, depth, pose, camera, color, pose, camera)
+    chisel.UpdateMeshes()
+
+Images may be numpy arrays (host, copied in by the library) or torch CUDA tensors (used in place).
+Every call goes to libchisel_hip.so; nothing is computed in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import ColorFrame, Config, DepthFrame, Integrator, check
+
+
+# ---- strategy objects (truncation/*.h, weighting/ConstantWeighter.h) ---------------------------------
+class ConstantTruncator:
+    kind = capi.TRUNC_CONSTANT
+
+    def __init__(self, value):
+        self.param = float(value)
+
+
+class InverseTruncator:
+    kind = capi.TRUNC_INVERSE
+
+    def __init__(self, scale):
+        self.param = float(scale)
+
+
+class QuadraticTruncator:
+    kind = capi.TRUNC_QUADRATIC
+
+    def __init__(self, scale):
+        self.param = float(scale)
+
+
+class ConstantWeighter:
+    def __init__(self, weight):
+        self.weight = float(weight)
+
+
+class PinholeCamera:
+    """camera/PinholeCamera.h:35-69 + Intrinsics.h:40-47"""
+
+    def __init__(self, fx, fy, cx, cy, width, height, near_plane=0.05, far_plane=5.0):
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        self.width, self.height = int(width), int(height)
+        self.near_plane, self.far_plane = float(near_plane), float(far_plane)
+
+
+class ProjectionIntegrator:
+    """ProjectionIntegrator.h:43-44, 185-217 (centroids are implicit: the kernel recomputes them)."""
+
+    def __init__(self, truncator=None, weighter=None, carving_dist=0.05, enable_carving=True):
+        self.truncator = truncator or InverseTruncator(8.0)
+        self.weighter = weighter or ConstantWeighter(1.0)
+        self.carving_dist = float(carving_dist)
+        self.enable_carving = bool(enable_carving)
+
+    def SetTruncator(self, t):
+        self.truncator = t
+
+    def SetWeighter(self, w):
+        self.weighter = w
+
+    def SetCarvingDist(self, d):
+        self.carving_dist = float(d)
+
+    def SetCarvingEnabled(self, e):
+        self.enable_carving = bool(e)
+
+    def _struct(self):
+        return Integrator(self.truncator.kind, self.truncator.param, self.weighter.weight, int(self.enable_carving),
+                          self.carving_dist)
+
+
+def _image_pointer(img, np_dtype):
+    """-> (address, on_device, keepalive) for a numpy array or a torch tensor."""
+    if isinstance(img, np.ndarray):
+        a = np.ascontiguousarray(img, dtype=np_dtype)
+        return a.ctypes.data, 0, a
+    # torch tensor
+    t = img.contiguous()
+    if t.is_cuda:
+        return t.data_ptr(), 1, t
+    a = np.ascontiguousarray(t.numpy(), dtype=np_dtype)
+    return a.ctypes.data, 0, a
+
+
+def _pose12(pose):
+    p = np.ascontiguousarray(np.asarray(pose, dtype=np.float32)[:3, :4]).reshape(12)
+    return (C.c_float * 12)(*p.tolist())
+
+
+def depth_frame(depth, pose, camera):
+    addr, dev, keep = _image_pointer(depth, np.float32)
+    H, W = depth.shape[-2], depth.shape[-1]
+    f = DepthFrame(addr, W, H, dev, _pose12(pose), camera.fx, camera.fy, camera.cx, camera.cy, camera.near_plane,
+                   camera.far_plane)
+    return f, keep
+
+
+def color_frame(color, pose, camera):
+    addr, dev, keep = _image_pointer(color, np.uint8)
+    shp = tuple(color.shape)
+    H, W = shp[0], shp[1]
+    ch = 1 if len(shp) == 2 else shp[2]
+    f = ColorFrame(addr, W, H, ch, dev, _pose12(pose), camera.fx, camera.fy, camera.cx, camera.cy)
+    return f, keep
+
+
+class Chisel:
+    """chisel::Chisel (Chisel.h:38-230) + the ChunkManager queries its callers use."""
+
+    def __init__(self, chunk_size=(16, 16, 16), voxel_resolution=0.03, use_color=False, device_id=-1, max_chunks=0,
+                 n_shards=1, shard_rank=0, shard_block=0):
+        self.L = capi.load_library()
+        cs = (chunk_size,) * 3 if isinstance(chunk_size, int) else tuple(int(v) for v in chunk_size)
+        self.chunk_size = cs
+        self.V = cs[0] * cs[1] * cs[2]
+        self.voxel_resolution = float(voxel_resolution)
+        self.use_color = bool(use_color)
+        cfg = Config((C.c_int * 3)(*cs), float(voxel_resolution), int(use_color), int(device_id), int(max_chunks),
+                     int(n_shards), int(shard_rank), int(shard_block))
+        self.h = C.c_void_p()
+        check(self.L.chisel_hip_create(C.byref(cfg), C.byref(self.h)))
+        self._integrator = None
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.chisel_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Chisel.h ---------------------------------------------------------------------------------
+    def _use(self, integrator):
+        s = integrator._struct()
+        check(self.L.chisel_hip_set_integrator(self.h, C.byref(s)))
+
+    def IntegrateDepthScan(self, integrator, depth_image, extrinsic, camera):
+        self._use(integrator)
+        f, keep = depth_frame(depth_image, extrinsic, camera)
+        check(self.L.chisel_hip_integrate_depth(self.h, C.byref(f)))
+        self._keep = [keep]
+
+    def IntegrateDepthScanColor(self, integrator, depth_image, depth_extrinsic, depth_camera, color_image,
+                                color_extrinsic, color_camera):
+        self._use(integrator)
+        f, k1 = depth_frame(depth_image, depth_extrinsic, depth_camera)
+        c, k2 = color_frame(color_image, color_extrinsic, color_camera)
+        check(self.L.chisel_hip_integrate_depth_color(self.h, C.byref(f), C.byref(c)))
+        self._keep = [k1, k2]
+
+    def IntegrateBatch(self, integrator, frames, colors=None):
+        """frames: list of (depth, pose, camera); colors: list of (color, pose, camera) or None."""
+        self._use(integrator)
+        n = len(frames)
+        fa = (DepthFrame * n)()
+        keep = []
+        for i, (d, p, cam) in enumerate(frames):
+            fa[i], k = depth_frame(d, p, cam)
+            keep.append(k)
+        ca = None
+        if colors is not None:
+            ca = (ColorFrame * n)()
+            for i, (c, p, cam) in enumerate(colors):
+                ca[i], k = color_frame(c, p, cam)
+                keep.append(k)
+        check(self.L.chisel_hip_integrate_batch(self.h, n, fa, ca))
+        self._keep = keep
+
+    def GarbageCollect(self, chunk_ids):
+        ids = np.ascontiguousarray(np.asarray(chunk_ids, dtype=np.int32).reshape(-1, 3))
+        check(self.L.chisel_hip_garbage_collect(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), len(ids)))
+
+    def UpdateMeshes(self, force=False):
+        check(self.L.chisel_hip_update_meshes(self.h, int(force)))
+
+    def Reset(self):
+        check(self.L.chisel_hip_reset(self.h))
+
+    def SaveAllMeshesToPLY(self, filename):
+        rc = self.L.chisel_hip_save_ply(self.h, str(filename).encode())
+        if rc == 6:
+            return False
+        check(rc)
+        return True
+
+    def GetMeshesToUpdate(self):
+        n = C.c_int64(0)
+        check(self.L.chisel_hip_meshes_to_update(self.h, None, 0, C.byref(n)))
+        ids = np.zeros((n.value, 3), np.int32)
+        if n.value:
+            check(self.L.chisel_hip_meshes_to_update(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n.value, C.byref(n)))
+        return ids
+
+    # ---- ChunkManager.h -----------------------------------------------------------------------------
+    def synchronize(self):
+        check(self.L.chisel_hip_synchronize(self.h))
+
+    def set_stream(self, hip_stream):
+        check(self.L.chisel_hip_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def NumChunks(self):
+        n = C.c_int64(0)
+        check(self.L.chisel_hip_num_chunks(self.h, C.byref(n)))
+        return n.value
+
+    def GetChunkIDs(self):
+        n = C.c_int64(0)
+        check(self.L.chisel_hip_list_chunks(self.h, None, 0, C.byref(n)))
+        ids = np.zeros((n.value, 3), np.int32)
+        if n.value:
+            check(self.L.chisel_hip_list_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n.value, C.byref(n)))
+        return ids
+
+    def HasChunk(self, cid):
+        cid = (C.c_int * 3)(*[int(v) for v in cid])
+        out = C.c_int(0)
+        check(self.L.chisel_hip_has_chunk(self.h, cid, C.byref(out)))
+        return bool(out.value)
+
+    def GetChunk(self, cid):
+        """-> (sdf[V], weight[V], rgbw[V,4] or None); raises KeyError like ChunkMap::at."""
+        cid_c = (C.c_int * 3)(*[int(v) for v in cid])
+        sdf = np.empty(self.V, np.float32)
+        w = np.empty(self.V, np.float32)
+        rgbw = np.empty((self.V, 4), np.uint8) if self.use_color else None
+        rc = self.L.chisel_hip_download_chunk(self.h, cid_c, sdf.ctypes.data_as(C.POINTER(C.c_float)),
+                                              w.ctypes.data_as(C.POINTER(C.c_float)),
+                                              rgbw.ctypes.data_as(C.POINTER(C.c_uint8)) if rgbw is not None else None)
+        if rc == 4:
+            raise KeyError(tuple(int(v) for v in cid))
+        check(rc)
+        return sdf, w, rgbw
+
+    def AddChunk(self, cid, sdf, weight, rgbw=None):
+        cid_c = (C.c_int * 3)(*[int(v) for v in cid])
+        s = np.ascontiguousarray(sdf, np.float32)
+        w = np.ascontiguousarray(weight, np.float32)
+        c = np.ascontiguousarray(rgbw, np.uint8) if rgbw is not None else None
+        check(self.L.chisel_hip_upload_chunk(self.h, cid_c, s.ctypes.data_as(C.POINTER(C.c_float)),
+                                             w.ctypes.data_as(C.POINTER(C.c_float)),
+                                             c.ctypes.data_as(C.POINTER(C.c_uint8)) if c is not None else None))
+
+    def fields(self):
+        return {tuple(int(v) for v in cid): self.GetChunk(cid) for cid in self.GetChunkIDs()}
+
+    def GetMeshIDs(self):
+        n = C.c_int64(0)
+        check(self.L.chisel_hip_list_meshes(self.h, None, 0, C.byref(n)))
+        ids = np.zeros((n.value, 3), np.int32)
+        if n.value:
+            check(self.L.chisel_hip_list_meshes(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n.value, C.byref(n)))
+        return ids
+
+    def GetMesh(self, cid):
+        cid_c = (C.c_int * 3)(*[int(v) for v in cid])
+        nv, ng = C.c_int64(0), C.c_int64(0)
+        rc = self.L.chisel_hip_mesh_size(self.h, cid_c, C.byref(nv), C.byref(ng))
+        if rc == 4:
+            raise KeyError(tuple(int(v) for v in cid))
+        check(rc)
+        v = np.zeros((nv.value, 3), np.float32)
+        n = np.zeros((nv.value, 3), np.float32)
+        c = np.zeros((nv.value, 3), np.float32) if self.use_color else None
+        g = np.zeros((ng.value, 3), np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+        check(self.L.chisel_hip_download_mesh(self.h, cid_c, fp(v), fp(n), fp(c), fp(g)))
+        return {"vertices": v, "normals": n, "colors": c, "grids": g}
+
+    def GetSDF(self, pos):
+        p = (C.c_float * 3)(*[float(v) for v in pos])
+        d, found = C.c_double(0), C.c_int(0)
+        check(self.L.chisel_hip_get_sdf(self.h, p, C.byref(d), C.byref(found)))
+        return bool(found.value), d.value
+
+    def GetSDFAndGradient(self, pos):
+        p = (C.c_float * 3)(*[float(v) for v in pos])
+        g = (C.c_float * 3)()
+        d, found = C.c_double(0), C.c_int(0)
+        check(self.L.chisel_hip_get_sdf_and_gradient(self.h, p, C.byref(d), g, C.byref(found)))
+        return bool(found.value), d.value, np.array(list(g), np.float32)
+
+    # ---- measurement ----------------------------------------------------------------------------------
+    def counters(self, reset=False):
+        out = (C.c_uint64 * capi.NUM_COUNTERS)()
+        check(self.L.chisel_hip_get_counters(self.h, out, int(reset)))
+        return dict(zip(capi.COUNTER_NAMES, [int(v) for v in out]))
+
+    def set_profiling(self, enable):
+        check(self.L.chisel_hip_set_profiling(self.h, int(enable)))
+
+    def profile(self, reset=False):
+        ms = (C.c_double * capi.NUM_KERNELS)()
+        n = (C.c_int64 * capi.NUM_KERNELS)()
+        check(self.L.chisel_hip_get_profile(self.h, ms, n, int(reset)))
+        return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(capi.KERNEL_NAMES)}
+
+
+def chunk_owner(cid, n_shards, shard_block=2):
+    c = (C.c_int * 3)(*[int(v) for v in cid])
+    return capi.load_library().chisel_hip_chunk_owner(c, int(n_shards), int(shard_block))

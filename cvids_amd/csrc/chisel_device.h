@@ -1,0 +1,186 @@
+// chisel_device.h -- structures shared by the host API (chisel_hip.hip) and the gfx950 kernels.
+//
+// HBM layout of one map (all arrays are hipMalloc'ed once at create time, sized by max_chunks = C):
+//   sdf   float [C][V]    V = N^3 voxels of a chunk, index (z*N + y)*N + x (Chunk.h:81-84): x-rows are
+//   wgt   float [C][V]    contiguous, so a wave64 reading 4 voxels/lane covers 256 consecutive voxels
+//   rgbw  uchar4[C][V]    = 1 KiB per plane per instruction (fully coalesced).  DistVoxel / ColorVoxel
+//                         payloads (8 B + 4 B) without the reference's vptr padding (16 B + 16 B).
+//   hash_keys uint64[Hc]  open-addressing table keyed by the packed chunk id, probe = linear,
+//   hash_vals int32 [Hc]  home bucket = the reference's ChunkHasher (ChunkManager.h:40-52) & (Hc-1)
+//   slot_key  uint64[C]   packed id of the chunk living in a slot (EMPTY when free)
+//   slot_dirty uint32[C]  "updated since the last mesh recompute" (Chisel.h:175-189 marks 27 neighbours
+//                         on the host; here the mark is per slot and the neighbourhood is expanded later)
+//   free_list int32 [C], free_top: stack of free slots
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chisel_hip {
+
+constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
+constexpr int ID_BIAS = 1 << 20;  // chunk ids in [-2^20, 2^20)
+
+__host__ __device__ inline uint64_t pack_id(int x, int y, int z) {
+    return (uint64_t)(uint32_t)(x + ID_BIAS) | ((uint64_t)(uint32_t)(y + ID_BIAS) << 21) |
+           ((uint64_t)(uint32_t)(z + ID_BIAS) << 42);
+}
+__host__ __device__ inline void unpack_id(uint64_t k, int &x, int &y, int &z) {
+    x = (int)(k & 0x1FFFFF) - ID_BIAS;
+    y = (int)((k >> 21) & 0x1FFFFF) - ID_BIAS;
+    z = (int)((k >> 42) & 0x1FFFFF) - ID_BIAS;
+}
+// ChunkHasher (ChunkManager.h:40-52): size_t arithmetic on sign-extended ints; third prime 8349279 (sic)
+__host__ __device__ inline uint64_t chunk_hash(int x, int y, int z) {
+    return ((uint64_t)(int64_t)x * 73856093ull) ^ ((uint64_t)(int64_t)y * 19349663ull) ^
+           ((uint64_t)(int64_t)z * 8349279ull);
+}
+__host__ __device__ inline int floor_div(int a, int b) {
+    int q = a / b, r = a % b;
+    return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
+}
+// spatial ownership for the multi-GPU shard: pure function of the chunk id
+__host__ __device__ inline int chunk_owner(int x, int y, int z, int n_shards, int shard_block) {
+    if (n_shards <= 1) return 0;
+    int bx = floor_div(x, shard_block), by = floor_div(y, shard_block), bz = floor_div(z, shard_block);
+    int h = (bx + 3 * by + 5 * bz) % n_shards;
+    return h < 0 ? h + n_shards : h;
+}
+
+struct MapView {
+    float *sdf;
+    float *wgt;
+    uchar4 *rgbw;            // null without colour
+    uint64_t *hash_keys;
+    int *hash_vals;
+    uint64_t hash_mask;      // capacity - 1 (power of two)
+    uint64_t *slot_key;
+    uint32_t *slot_dirty;
+    int *free_list;
+    int *free_top;
+    unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS
+    int *error_flag;         // != 0: pool / hash exhausted
+    int max_chunks;
+};
+
+// depth min/max pyramid: level l (PYR_L0 <= l <= PYR_L1) has ceil(W/2^l) x ceil(H/2^l) texels of
+// (min, max) over the valid pixels of a 2^l x 2^l block; (+inf, -inf) when the block has none.
+constexpr int PYR_L0 = 2, PYR_L1 = 6, PYR_LEVELS = PYR_L1 - PYR_L0 + 1;
+struct PyramidView {
+    float2 *data;
+    int off[PYR_LEVELS];
+    int w[PYR_LEVELS];
+    int h[PYR_LEVELS];
+};
+
+struct CameraParams {
+    float R[9];  // camera->world rotation, row-major (Transform::linear())
+    float t[3];  // Transform::translation()
+    float fx, fy, cx, cy;
+    int W, H;
+};
+
+struct FrameParams {
+    CameraParams cam;
+    const float *depth;
+    CameraParams ccam;       // colour camera (IntegrateColor only)
+    const uint8_t *color;
+    int color_channels;
+    // ProjectionIntegrator state
+    int trunc_kind;
+    float trunc_param;
+    float weight;
+    int carving;
+    float carving_dist;
+    // derived constants
+    float res;               // Chunk::GetVoxelResolutionMeters
+    float half_res;          // ChunkManager.cpp:52  (res * 0.5f)
+    float diag;              // ProjectionIntegrator.h:58  2.0 * sqrt(3.0f) * res  (double, narrowed)
+    float max_depth;         // 50 (Integrate :74) or 100 (IntegrateColor :141)
+    // reference candidate enumeration (ChunkManager.cpp:182-212): ids range_min .. range_min+range_dim-1
+    int range_min[3];
+    int range_dim[3];
+    float planes[24];        // far, near, top, bottom, left, right: normal xyz + distance (Frustum.cpp:43)
+    // sharding
+    int n_shards, shard_rank, shard_block;
+};
+
+struct WorkItem {
+    int x, y, z;             // chunk id
+    int slot;                // pool slot, -1 = not resident (allocate if any voxel is updated)
+    short u0, v0, u1, v1;    // conservative pixel bounding box of the chunk (inclusive), depth camera
+    int flags;
+    int pad;
+};
+constexpr int WI_INBAND = 1;   // some voxel may take the in-band branch
+constexpr int WI_CARVE = 2;    // some voxel of this resident chunk may take the carve test
+constexpr int WI_TILE = 4;     // u0..v1 is a valid bounding box (else: gather from the whole image)
+
+// ---- strategy arithmetic (devirtualised Truncator / Weighter) -------------------------------------
+// InverseTruncator.h:48-52
+constexpr float kBaseLine = 0.10;
+constexpr float kFocal = 471.27;
+constexpr float kDepSample = 1.0f / (kBaseLine * kFocal);
+// QuadraticTruncator.h:65-67
+constexpr float kQuadTerm = 0.0019 * 10;
+constexpr float kLinTerm = 0.00152 * 10;
+constexpr float kConstTerm = 0.001504 * 10;
+
+__host__ __device__ inline float truncation_distance(int kind, float param, float reading) {
+    if (kind == 1) {  // InverseTruncator.h:42-46: float inv = 1.0 / reading (double divide narrowed == fp32 divide)
+        float inv_reading = 1.0f / reading;
+        return (kDepSample / (inv_reading * inv_reading)) * param;
+    } else if (kind == 0) {  // ConstantTruncator.h:48-51
+        return param;
+    } else {  // QuadraticTruncator.h:42-45: double arithmetic via pow(reading, 2)
+        double r = (double)reading;
+        double v = (double)kQuadTerm * (r * r) + (double)(kLinTerm * reading) + (double)kConstTerm;
+        v = v < 0 ? -v : v;
+        return (float)(v * (double)param);
+    }
+}
+// ConstantWeighter.h:43-46
+__host__ __device__ inline float constant_weight(float weight, float truncation) { return weight / (5 * truncation); }
+// DistVoxel::Integrate DistVoxel.h:52-60
+__host__ __device__ inline void dist_integrate(float &sdf, float &w, float distUpdate, float weightUpdate) {
+    float newDist = (w * sdf + weightUpdate * distUpdate) / (weightUpdate + w);
+    sdf = newDist;
+    w = w + weightUpdate;
+}
+// ColorVoxel::Integrate ColorVoxel.h:65-85 (one channel)
+__host__ __device__ inline uint8_t color_channel(uint8_t old, uint8_t weight, uint8_t nw, uint8_t weightUpdate) {
+    float oldc = (float)old;
+    float upd = ((float)((float)(int)weight * oldc + (float)((int)weightUpdate * (int)nw))) / (float)((int)weightUpdate + (int)weight);
+    upd = fminf(fmaxf(upd, 0.0f), 255.0f);
+    return (uint8_t)upd;
+}
+__host__ __device__ inline uchar4 color_integrate(uchar4 c, uint8_t r, uint8_t g, uint8_t b, uint8_t wu) {
+    if ((int)c.w >= 255 - (int)wu) return c;
+    uchar4 o;
+    o.x = color_channel(c.x, c.w, r, wu);
+    o.y = color_channel(c.y, c.w, g, wu);
+    o.z = color_channel(c.z, c.w, b, wu);
+    o.w = (uint8_t)(c.w + wu);
+    return o;
+}
+// ColorImage::At ColorImage.h:72-107 -> (red, green, blue)
+__device__ inline void color_at(const uint8_t *data, int idx, int channels, uint8_t &r, uint8_t &g, uint8_t &b) {
+    const uint8_t *p = data + (size_t)idx * channels;
+    if (channels == 1) {
+        r = g = b = p[0];
+    } else if (channels == 2) {
+        r = p[0];
+        g = b = p[1];
+    } else {  // 3 = BGR, 4 = BGRA
+        r = p[2];
+        g = p[1];
+        b = p[0];
+    }
+}
+
+// thresholds the reference compares in double against fp32 values, folded to fp32 (exactly equivalent):
+//   sdf < 1e-5 (double)  <=>  sdf < kSdfCarveThr,  kSdfCarveThr = smallest float >= 1e-5
+//   (ProjectionIntegrator.h:90,168)
+__host__ __device__ inline bool sdf_below_carve_threshold(float sdf) { return (double)sdf < 1e-5; }
+
+}  // namespace chisel_hip

@@ -1,0 +1,725 @@
+// chisel_hip.hip -- host side of libchisel_hip.so: the C ABI of include/chisel_hip.h on top of the
+// gfx950 kernels in kernels_*.h.  No CPU fallback: every entry point either runs on the GPU or fails
+// with CHISEL_HIP_ERR_HIP.
+#include "../../include/chisel_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "chisel_device.h"
+#include "host_frustum.h"
+#include "kernels_cull.h"
+#include "kernels_integrate.h"
+#include "kernels_map.h"
+#include "kernels_mesh.h"
+
+using namespace chisel_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(CHISEL_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+struct IdHash {
+    size_t operator()(uint64_t k) const { return (size_t)(k * 0x9E3779B97F4A7C15ull); }
+};
+
+struct HostMesh {  // mesh/Mesh.h:54-58 (indices are implicit 0..n-1)
+    std::vector<float> vertices, normals, colors, grids;
+};
+
+struct ProfEvent {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct chisel_hip_map {
+    chisel_hip_config cfg;
+    int N = 0, V = 0;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    MapView view{};
+    uint64_t hash_capacity = 0;
+    chisel_hip_integrator integ{CHISEL_HIP_TRUNC_INVERSE, 8.0f, 1.0f, 1, 0.05f};  // ChiselNode.cpp:54-64 defaults
+    // per-frame device buffers
+    WorkItem *items = nullptr;
+    int items_capacity = 0;
+    int *work_count = nullptr;
+    float2 *pyr_data = nullptr;
+    int pyr_w = 0, pyr_h = 0;
+    PyramidView pyr{};
+    float *depth_stage = nullptr;
+    size_t depth_stage_elems = 0;
+    uint8_t *color_stage = nullptr;
+    size_t color_stage_bytes = 0;
+    // scratch for queries
+    int *scratch_i = nullptr;   // device ints
+    size_t scratch_i_elems = 0;
+    // meshing state
+    int update_meshes_calls = 0;                                       // Chisel.cpp:53 "static int cnt"
+    std::unordered_map<uint64_t, HostMesh, IdHash> meshes;             // ChunkManager::allMeshes
+    std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
+    MeshBuffers mesh_buf{};
+    // profiling
+    bool profiling = false;
+    std::vector<ProfEvent> prof_live;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0};
+    int64_t prof_launches[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int ensure_scratch(chisel_hip_map *m, size_t elems) {
+    if (elems <= m->scratch_i_elems) return CHISEL_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->scratch_i) HIP_TRY(hipFree(m->scratch_i));
+    m->scratch_i = nullptr;
+    size_t n = std::max<size_t>(elems, 1024);
+    HIP_TRY(hipMalloc(&m->scratch_i, n * sizeof(int)));
+    m->scratch_i_elems = n;
+    return CHISEL_HIP_OK;
+}
+
+hipEvent_t take_event(chisel_hip_map *m) {
+    if (!m->event_pool.empty()) {
+        hipEvent_t e = m->event_pool.back();
+        m->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    chisel_hip_map *m;
+    int k;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(chisel_hip_map *m_, int k_) : m(m_), k(k_) {
+        if (m->profiling) {
+            a = take_event(m);
+            b = take_event(m);
+            (void)hipEventRecord(a, m->stream);
+        }
+    }
+    ~ProfScope() {
+        if (m->profiling) {
+            (void)hipEventRecord(b, m->stream);
+            m->prof_live.push_back(ProfEvent{k, a, b});
+        }
+    }
+};
+int drain_profile(chisel_hip_map *m) {
+    if (m->prof_live.empty()) return CHISEL_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (const ProfEvent &p : m->prof_live) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            m->prof_ms[p.kernel] += ms;
+            m->prof_launches[p.kernel] += 1;
+        }
+        m->event_pool.push_back(p.start);
+        m->event_pool.push_back(p.stop);
+    }
+    m->prof_live.clear();
+    return CHISEL_HIP_OK;
+}
+
+int check_device_error(chisel_hip_map *m) {
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (flag != 0)
+        return fail(CHISEL_HIP_ERR_POOL_FULL, flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
+                                                        : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
+    return CHISEL_HIP_OK;
+}
+
+void fill_camera(CameraParams &c, const float *pose, float fx, float fy, float cx, float cy, int W, int H) {
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) c.R[3 * r + k] = pose[4 * r + k];
+        c.t[r] = pose[4 * r + 3];
+    }
+    c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy; c.W = W; c.H = H;
+}
+
+int ensure_pyramid(chisel_hip_map *m, int W, int H) {
+    if (m->pyr_data && m->pyr_w == W && m->pyr_h == H) return CHISEL_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->pyr_data) HIP_TRY(hipFree(m->pyr_data));
+    m->pyr_data = nullptr;
+    int off = 0;
+    for (int l = 0; l < PYR_LEVELS; l++) {
+        int s = PYR_L0 + l;
+        m->pyr.w[l] = (W + (1 << s) - 1) >> s;
+        m->pyr.h[l] = (H + (1 << s) - 1) >> s;
+        m->pyr.off[l] = off;
+        off += m->pyr.w[l] * m->pyr.h[l];
+    }
+    HIP_TRY(hipMalloc(&m->pyr_data, (size_t)off * sizeof(float2)));
+    m->pyr.data = m->pyr_data;
+    m->pyr_w = W;
+    m->pyr_h = H;
+    return CHISEL_HIP_OK;
+}
+
+template <int N>
+int launch_frame(chisel_hip_map *m, const FrameParams &P, bool color) {
+    using G = Geom<N>;
+    const int total = P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
+    {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID);
+        dim3 grid((P.cam.W + 63) / 64, (P.cam.H + 63) / 64);
+        hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, m->stream, P.depth, P.cam.W, P.cam.H, P.max_depth,
+                           m->pyr, m->work_count);
+    }
+    {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_CULL);
+        hipLaunchKernelGGL(cull_kernel<N>, dim3((total + 255) / 256), dim3(256), 0, m->stream, P, m->view, m->pyr, m->items,
+                           m->work_count, m->items_capacity);
+    }
+    {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
+        const int grid = std::max(1, std::min(total, 256 * 8));
+        if (color)
+            hipLaunchKernelGGL((integrate_kernel<N, true>), dim3(grid), dim3(G::BLOCK), 0, m->stream, P, m->view, m->items,
+                               m->work_count, m->items_capacity);
+        else
+            hipLaunchKernelGGL((integrate_kernel<N, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, P, m->view, m->items,
+                               m->work_count, m->items_capacity);
+    }
+    HIP_TRY(hipGetLastError());
+    return CHISEL_HIP_OK;
+}
+
+int integrate_one(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
+    if (!f || !f->depth || f->width <= 0 || f->height <= 0) return fail(CHISEL_HIP_ERR_INVALID, "bad depth frame");
+    if (f->width > 32767 || f->height > 32767) return fail(CHISEL_HIP_ERR_INVALID, "image larger than 32767 pixels per side");
+    if (c && (!c->color || c->channels < 1 || c->channels > 4 || c->width <= 0 || c->height <= 0))
+        return fail(CHISEL_HIP_ERR_INVALID, "bad colour frame");
+    if (c && !m->cfg.use_color)
+        return fail(CHISEL_HIP_ERR_INVALID, "map was created without colour voxels (Chunk::GetColorVoxelMutable would throw)");
+    HIP_TRY(hipSetDevice(m->device));
+
+    FrameParams P;
+    memset(&P, 0, sizeof(P));
+    fill_camera(P.cam, f->pose, f->fx, f->fy, f->cx, f->cy, f->width, f->height);
+    // depth image
+    const size_t npx = (size_t)f->width * f->height;
+    if (f->on_device) {
+        P.depth = f->depth;
+    } else {
+        if (npx > m->depth_stage_elems) {
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (m->depth_stage) HIP_TRY(hipFree(m->depth_stage));
+            m->depth_stage = nullptr;
+            HIP_TRY(hipMalloc(&m->depth_stage, npx * sizeof(float)));
+            m->depth_stage_elems = npx;
+        }
+        HIP_TRY(hipMemcpyAsync(m->depth_stage, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        P.depth = m->depth_stage;
+    }
+    if (c) {
+        fill_camera(P.ccam, c->pose, c->fx, c->fy, c->cx, c->cy, c->width, c->height);
+        P.color_channels = c->channels;
+        const size_t nb = (size_t)c->width * c->height * c->channels;
+        if (c->on_device) {
+            P.color = c->color;
+        } else {
+            if (nb > m->color_stage_bytes) {
+                HIP_TRY(hipStreamSynchronize(m->stream));
+                if (m->color_stage) HIP_TRY(hipFree(m->color_stage));
+                m->color_stage = nullptr;
+                HIP_TRY(hipMalloc(&m->color_stage, nb));
+                m->color_stage_bytes = nb;
+            }
+            HIP_TRY(hipMemcpyAsync(m->color_stage, c->color, nb, hipMemcpyHostToDevice, m->stream));
+            P.color = m->color_stage;
+        }
+    }
+    P.trunc_kind = m->integ.truncator_kind;
+    P.trunc_param = m->integ.truncator_param;
+    P.weight = m->integ.weight;
+    P.carving = m->integ.carving_enabled ? 1 : 0;
+    P.carving_dist = m->integ.carving_dist;
+    P.res = m->cfg.voxel_resolution;
+    P.half_res = m->cfg.voxel_resolution * 0.5f;                                           // ChunkManager.cpp:52
+    P.diag = (float)(2.0 * ::sqrt((double)3.0f) * (double)m->cfg.voxel_resolution);        // ProjectionIntegrator.h:58,109
+    P.max_depth = c ? 100.0f : 50.0f;
+    hostmath::FrustumRange fr = hostmath::frustum_range(f->pose, f->near_plane, f->far_plane, f->fy, f->cy, f->width,
+                                                        f->height, m->N, m->cfg.voxel_resolution);
+    for (int k = 0; k < 3; k++) {
+        P.range_min[k] = fr.range_min[k];
+        P.range_dim[k] = fr.range_dim[k];
+        if (fr.range_dim[k] <= 0 || fr.range_min[k] < -ID_BIAS + 2 || fr.range_min[k] + fr.range_dim[k] > ID_BIAS - 2)
+            return fail(CHISEL_HIP_ERR_INVALID, "frustum outside the addressable chunk-id range (pose not finite?)");
+    }
+    memcpy(P.planes, fr.planes, sizeof(P.planes));
+    const double total_d = (double)P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
+    if (total_d > 2.0e8) return fail(CHISEL_HIP_ERR_INVALID, "frustum covers more than 2e8 chunks: far plane / resolution mismatch");
+    const int total = (int)total_d;
+    P.n_shards = m->cfg.n_shards;
+    P.shard_rank = m->cfg.shard_rank;
+    P.shard_block = m->cfg.shard_block;
+
+    if (total > m->items_capacity) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (m->items) HIP_TRY(hipFree(m->items));
+        m->items = nullptr;
+        int cap = std::max(total, 4096);
+        HIP_TRY(hipMalloc(&m->items, (size_t)cap * sizeof(WorkItem)));
+        m->items_capacity = cap;
+    }
+    int rc = ensure_pyramid(m, f->width, f->height);
+    if (rc) return rc;
+    const bool color = c != nullptr;
+    switch (m->N) {
+        case 8: return launch_frame<8>(m, P, color);
+        case 16: return launch_frame<16>(m, P, color);
+        case 32: return launch_frame<32>(m, P, color);
+    }
+    return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chunk size");
+}
+
+// ids of dirty slots -> host vector (packed keys)
+int fetch_listed(chisel_hip_map *m, bool dirty_only, std::vector<int> &ids, std::vector<int> *slots) {
+    int rc = ensure_scratch(m, (size_t)m->view.max_chunks * 4 + 16);
+    if (rc) return rc;
+    int *d_count = m->scratch_i;
+    int *d_ids = m->scratch_i + 16;
+    int *d_slots = d_ids + (size_t)m->view.max_chunks * 3;
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), m->stream));
+    const int blocks = (m->view.max_chunks + 255) / 256;
+    if (dirty_only)
+        hipLaunchKernelGGL(list_slots_kernel<true>, dim3(blocks), dim3(256), 0, m->stream, m->view, d_ids, d_slots,
+                           m->view.max_chunks, d_count);
+    else
+        hipLaunchKernelGGL(list_slots_kernel<false>, dim3(blocks), dim3(256), 0, m->stream, m->view, d_ids, d_slots,
+                           m->view.max_chunks, d_count);
+    int count = 0;
+    HIP_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    ids.resize((size_t)count * 3);
+    if (slots) slots->resize(count);
+    if (count) {
+        HIP_TRY(hipMemcpy(ids.data(), d_ids, (size_t)count * 3 * sizeof(int), hipMemcpyDeviceToHost));
+        if (slots) HIP_TRY(hipMemcpy(slots->data(), d_slots, (size_t)count * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return CHISEL_HIP_OK;
+}
+
+int lookup_slots(chisel_hip_map *m, const int *ids, int n, std::vector<int> &slots) {
+    slots.assign(n, -1);
+    if (n == 0) return CHISEL_HIP_OK;
+    int rc = ensure_scratch(m, (size_t)n * 4);
+    if (rc) return rc;
+    int *d_ids = m->scratch_i, *d_slots = m->scratch_i + (size_t)n * 3;
+    HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, m->view, d_ids, n, d_slots);
+    HIP_TRY(hipMemcpyAsync(slots.data(), d_slots, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHISEL_HIP_OK;
+}
+
+void expand27(const std::vector<int> &ids, std::unordered_set<uint64_t, IdHash> &out) {
+    for (size_t i = 0; i + 2 < ids.size(); i += 3)
+        for (int dx = -1; dx <= 1; dx++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dz = -1; dz <= 1; dz++) out.insert(pack_id(ids[i] + dx, ids[i + 1] + dy, ids[i + 2] + dz));
+}
+
+}  // namespace
+
+#include "host_mesh.h"
+
+extern "C" {
+
+int chisel_hip_abi_version(void) { return CHISEL_HIP_ABI_VERSION; }
+const char *chisel_hip_last_error(void) { return g_last_error.c_str(); }
+
+int chisel_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strstr(p.gcnArchName, "gfx950")) ok++;
+    }
+    return ok;
+}
+
+int chisel_hip_chunk_owner(const int id[3], int n_shards, int shard_block) {
+    return chunk_owner(id[0], id[1], id[2], n_shards < 1 ? 1 : n_shards, shard_block < 1 ? 2 : shard_block);
+}
+
+int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
+    if (!cfg || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int N = cfg->chunk_size[0];
+    if (cfg->chunk_size[1] != N || cfg->chunk_size[2] != N || (N != 8 && N != 16 && N != 32))
+        return fail(CHISEL_HIP_ERR_UNSUPPORTED,
+                    "chunk_size must be cubic 8, 16 or 32 (the reference's Chunk::GetVoxelID, Chunk.h:81-84, is only valid for cubic chunks)");
+    if (!(cfg->voxel_resolution > 0.0f)) return fail(CHISEL_HIP_ERR_INVALID, "voxel_resolution must be > 0");
+    const int n_shards = cfg->n_shards < 1 ? 1 : cfg->n_shards;
+    if (cfg->shard_rank < 0 || cfg->shard_rank >= n_shards) return fail(CHISEL_HIP_ERR_INVALID, "shard_rank out of range");
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(CHISEL_HIP_ERR_HIP, "no HIP device visible: libchisel_hip has no CPU path");
+    int dev = cfg->device_id;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(CHISEL_HIP_ERR_INVALID, "device_id out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(CHISEL_HIP_ERR_HIP, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 (MI355X) only");
+    HIP_TRY(hipSetDevice(dev));
+
+    chisel_hip_map *m = new chisel_hip_map();
+    m->cfg = *cfg;
+    m->cfg.n_shards = n_shards;
+    m->cfg.shard_block = cfg->shard_block < 1 ? 2 : cfg->shard_block;
+    m->N = N;
+    m->V = N * N * N;
+    m->device = dev;
+    const size_t bytes_per_chunk = (size_t)m->V * (8 + (cfg->use_color ? 4 : 0));
+    int64_t C = cfg->max_chunks;
+    if (C <= 0) C = (int64_t)((6ull << 30) / bytes_per_chunk);
+    if (C > (1 << 30)) C = 1 << 30;
+    m->cfg.max_chunks = C;
+    uint64_t hc = 1024;
+    while (hc < (uint64_t)C * 2) hc <<= 1;
+    m->hash_capacity = hc;
+
+    auto cleanup = [&](int rc) {
+        chisel_hip_destroy(m);
+        return rc;
+    };
+#define HIP_TRY_C(expr)                                                                                       \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return cleanup(fail(CHISEL_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)));      \
+    } while (0)
+    HIP_TRY_C(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+    m->stream = m->own_stream;
+    MapView &v = m->view;
+    v.max_chunks = (int)C;
+    v.hash_mask = hc - 1;
+    HIP_TRY_C(hipMalloc(&v.sdf, (size_t)C * m->V * sizeof(float)));
+    HIP_TRY_C(hipMalloc(&v.wgt, (size_t)C * m->V * sizeof(float)));
+    if (cfg->use_color) HIP_TRY_C(hipMalloc(&v.rgbw, (size_t)C * m->V * sizeof(uchar4)));
+    HIP_TRY_C(hipMalloc(&v.hash_keys, hc * sizeof(uint64_t)));
+    HIP_TRY_C(hipMalloc(&v.hash_vals, hc * sizeof(int)));
+    HIP_TRY_C(hipMalloc(&v.slot_key, (size_t)C * sizeof(uint64_t)));
+    HIP_TRY_C(hipMalloc(&v.slot_dirty, (size_t)C * sizeof(uint32_t)));
+    HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
+    HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
+    HIP_TRY_C(hipMalloc(&v.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc(&v.error_flag, sizeof(int)));
+    HIP_TRY_C(hipMalloc(&m->work_count, sizeof(int)));
+    HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
+    HIP_TRY_C(hipMemsetAsync(m->work_count, 0, sizeof(int), m->stream));
+    hipLaunchKernelGGL(reset_map_kernel, dim3(1024), dim3(256), 0, m->stream, m->view);
+    HIP_TRY_C(hipGetLastError());
+    HIP_TRY_C(hipStreamSynchronize(m->stream));
+#undef HIP_TRY_C
+    *out = m;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_destroy(chisel_hip_map *m) {
+    if (!m) return CHISEL_HIP_OK;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    MapView &v = m->view;
+    void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
+                    v.counters, v.error_flag, m->work_count, m->items, m->pyr_data, m->depth_stage, m->color_stage,
+                    m->scratch_i};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    free_mesh_buffers(m->mesh_buf);
+    for (const ProfEvent &p : m->prof_live) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    for (hipEvent_t e : m->event_pool) (void)hipEventDestroy(e);
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    delete m;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_reset(chisel_hip_map *m) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    HIP_TRY(hipSetDevice(m->device));
+    hipLaunchKernelGGL(reset_map_kernel, dim3(1024), dim3(256), 0, m->stream, m->view);
+    HIP_TRY(hipGetLastError());
+    m->meshes.clear();
+    m->pending_mesh_ids.clear();
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_set_integrator(chisel_hip_map *m, const chisel_hip_integrator *in) {
+    if (!m || !in) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (in->truncator_kind < 0 || in->truncator_kind > 2) return fail(CHISEL_HIP_ERR_INVALID, "unknown truncator kind");
+    m->integ = *in;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_set_stream(chisel_hip_map *m, void *s) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->stream = s ? (hipStream_t)s : m->own_stream;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_synchronize(chisel_hip_map *m) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    HIP_TRY(hipSetDevice(m->device));
+    return check_device_error(m);
+}
+
+int chisel_hip_integrate_depth(chisel_hip_map *m, const chisel_hip_depth_frame *f) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    return integrate_one(m, f, nullptr);
+}
+
+int chisel_hip_integrate_depth_color(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
+    if (!m || !c) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    return integrate_one(m, f, c);
+}
+
+int chisel_hip_integrate_batch(chisel_hip_map *m, int n, const chisel_hip_depth_frame *frames,
+                               const chisel_hip_color_frame *colors) {
+    if (!m || n < 0 || (n > 0 && !frames)) return fail(CHISEL_HIP_ERR_INVALID, "bad batch");
+    for (int i = 0; i < n; i++) {
+        // host-resident images share one staging buffer: the copy of frame i+1 is stream-ordered after frame i's kernels
+        int rc = integrate_one(m, &frames[i], colors ? &colors[i] : nullptr);
+        if (rc) return rc;
+    }
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
+    if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
+    if (n == 0) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    // keep the reference's meshesToUpdate entries of chunks that disappear (Chisel.h:228 lives on the host)
+    std::vector<int> dirty;
+    int rc = fetch_listed(m, true, dirty, nullptr);
+    if (rc) return rc;
+    if (!dirty.empty()) {
+        std::unordered_set<uint64_t, IdHash> doomed;
+        for (int i = 0; i < n; i++) doomed.insert(pack_id(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
+        std::vector<int> gone;
+        for (size_t i = 0; i + 2 < dirty.size(); i += 3)
+            if (doomed.count(pack_id(dirty[i], dirty[i + 1], dirty[i + 2]))) {
+                gone.push_back(dirty[i]); gone.push_back(dirty[i + 1]); gone.push_back(dirty[i + 2]);
+            }
+        expand27(gone, m->pending_mesh_ids);
+    }
+    rc = ensure_scratch(m, (size_t)n * 3 + 16);
+    if (rc) return rc;
+    int *d_cnt = m->scratch_i, *d_ids = m->scratch_i + 16;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), m->stream));
+    HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(remove_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, m->view, d_ids, n, d_cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_num_chunks(chisel_hip_map *m, int64_t *out) {
+    if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_device_error(m);
+    if (rc) return rc;
+    int top = 0;
+    HIP_TRY(hipMemcpy(&top, m->view.free_top, sizeof(int), hipMemcpyDeviceToHost));
+    *out = (int64_t)m->view.max_chunks - top;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_list_chunks(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_device_error(m);
+    if (rc) return rc;
+    std::vector<int> all;
+    rc = fetch_listed(m, false, all, nullptr);
+    if (rc) return rc;
+    *count = (int64_t)all.size() / 3;
+    if (ids && max_ids > 0) memcpy(ids, all.data(), (size_t)std::min<int64_t>(*count, max_ids) * 3 * sizeof(int));
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_has_chunk(chisel_hip_map *m, const int id[3], int *out) {
+    if (!m || !id || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    std::vector<int> slots;
+    int rc = lookup_slots(m, id, 1, slots);
+    if (rc) return rc;
+    *out = slots[0] >= 0 ? 1 : 0;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_download_chunk(chisel_hip_map *m, const int id[3], float *sdf, float *weight, uint8_t *rgbw) {
+    if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_device_error(m);
+    if (rc) return rc;
+    std::vector<int> slots;
+    rc = lookup_slots(m, id, 1, slots);
+    if (rc) return rc;
+    if (slots[0] < 0) return fail(CHISEL_HIP_ERR_NOT_FOUND, "chunk not resident (ChunkManager::GetChunk would throw std::out_of_range)");
+    const size_t off = (size_t)slots[0] * m->V;
+    if (sdf) HIP_TRY(hipMemcpy(sdf, m->view.sdf + off, (size_t)m->V * sizeof(float), hipMemcpyDeviceToHost));
+    if (weight) HIP_TRY(hipMemcpy(weight, m->view.wgt + off, (size_t)m->V * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgbw) {
+        if (!m->view.rgbw) return fail(CHISEL_HIP_ERR_INVALID, "map has no colour voxels");
+        HIP_TRY(hipMemcpy(rgbw, m->view.rgbw + off, (size_t)m->V * 4, hipMemcpyDeviceToHost));
+    }
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf, const float *weight, const uint8_t *rgbw) {
+    if (!m || !id || !sdf || !weight) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)
+        return fail(CHISEL_HIP_ERR_INVALID, "chunk belongs to another shard");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = ensure_scratch(m, 16);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ensure_chunk_kernel, dim3(1), dim3(1), 0, m->stream, m->view, id[0], id[1], id[2], m->scratch_i);
+    int slot = -1;
+    HIP_TRY(hipMemcpyAsync(&slot, m->scratch_i, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (slot < 0) return check_device_error(m) ? CHISEL_HIP_ERR_POOL_FULL : fail(CHISEL_HIP_ERR_POOL_FULL, "no slot");
+    const size_t off = (size_t)slot * m->V;
+    HIP_TRY(hipMemcpy(m->view.sdf + off, sdf, (size_t)m->V * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->view.wgt + off, weight, (size_t)m->V * sizeof(float), hipMemcpyHostToDevice));
+    if (m->view.rgbw) {
+        if (rgbw) HIP_TRY(hipMemcpy(m->view.rgbw + off, rgbw, (size_t)m->V * 4, hipMemcpyHostToDevice));
+        else HIP_TRY(hipMemset(m->view.rgbw + off, 0, (size_t)m->V * 4));
+    }
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_meshes_to_update(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    std::vector<int> dirty;
+    int rc = fetch_listed(m, true, dirty, nullptr);
+    if (rc) return rc;
+    std::unordered_set<uint64_t, IdHash> all(m->pending_mesh_ids);
+    expand27(dirty, all);
+    *count = (int64_t)all.size();
+    if (ids) {
+        int64_t k = 0;
+        for (uint64_t key : all) {
+            if (k >= max_ids) break;
+            unpack_id(key, ids[3 * k], ids[3 * k + 1], ids[3 * k + 2]);
+            k++;
+        }
+    }
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters) {
+    if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpyAsync(out, m->view.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, m->stream));
+    if (reset_counters) HIP_TRY(hipMemsetAsync(m->view.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(uint64_t), m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_set_profiling(chisel_hip_map *m, int enable) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    int rc = drain_profile(m);
+    m->profiling = enable != 0;
+    return rc;
+}
+
+int chisel_hip_get_profile(chisel_hip_map *m, double *ms_total, int64_t *launches, int reset_profile) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    int rc = drain_profile(m);
+    if (rc) return rc;
+    for (int k = 0; k < CHISEL_HIP_NUM_KERNELS; k++) {
+        if (ms_total) ms_total[k] = m->prof_ms[k];
+        if (launches) launches[k] = m->prof_launches[k];
+        if (reset_profile) {
+            m->prof_ms[k] = 0;
+            m->prof_launches[k] = 0;
+        }
+    }
+    return CHISEL_HIP_OK;
+}
+
+// ---- known-answer entry points (tests only; not part of the reference surface) -------------------------
+int chisel_hip_kat_truncation(int kind, float param, const float *depths, int n, float *trunc, float *weight1) {
+    float *d_in = nullptr, *d_t = nullptr, *d_w = nullptr;
+    HIP_TRY(hipMalloc(&d_in, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&d_t, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&d_w, n * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_in, depths, n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kat_truncation_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, kind, param, d_in, n, d_t, d_w);
+    HIP_TRY(hipMemcpy(trunc, d_t, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(weight1, d_w, n * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_t); (void)hipFree(d_w);
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_kat_dist(const float *ops, int n, float *out) {
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, n * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc(&d_out, n * 2 * sizeof(float)));
+    HIP_TRY(hipMemcpy(d_in, ops, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kat_dist_kernel, dim3(1), dim3(64), 0, 0, d_in, n, d_out);
+    HIP_TRY(hipMemcpy(out, d_out, n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_kat_color(const uint8_t *ops, int n, uint8_t *out) {
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, n * 4));
+    HIP_TRY(hipMalloc(&d_out, n * 4));
+    HIP_TRY(hipMemcpy(d_in, ops, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kat_color_kernel, dim3(1), dim3(64), 0, 0, d_in, n, d_out);
+    HIP_TRY(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return CHISEL_HIP_OK;
+}
+// host-side frustum arithmetic of the product (host_frustum.h), for CPU-only tests against the oracle
+int chisel_hip_debug_frustum_range(const float *pose, float near_plane, float far_plane, float fy, float cy, int W, int H,
+                                   int chunk_n, float res, int *range_min3, int *range_dim3, float *planes24, float *corners24) {
+    hostmath::FrustumRange fr = hostmath::frustum_range(pose, near_plane, far_plane, fy, cy, W, H, chunk_n, res);
+    memcpy(range_min3, fr.range_min, sizeof(fr.range_min));
+    memcpy(range_dim3, fr.range_dim, sizeof(fr.range_dim));
+    if (planes24) memcpy(planes24, fr.planes, sizeof(fr.planes));
+    if (corners24) memcpy(corners24, fr.corners, sizeof(fr.corners));
+    return CHISEL_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+// kernels_map.h -- chunk-hash / pool maintenance and small query kernels.
+//
+// Device-side counterpart of ChunkManager's unordered_map bookkeeping (ChunkManager.h:67-122):
+// CreateChunk happens inside integrate_kernel; everything else (Reset, RemoveChunk / GarbageCollect,
+// HasChunk / GetChunk lookups, GetChunks enumeration) lives here.
+#pragma once
+#include "chisel_device.h"
+
+namespace chisel_hip {
+
+// Chisel::Reset / ChunkManager::Reset (Chisel.cpp:44-48, ChunkManager.cpp:176-180) and initial state
+__global__ void reset_map_kernel(MapView M) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = gid; i <= M.hash_mask; i += stride) M.hash_keys[i] = KEY_EMPTY;
+    for (uint64_t i = gid; i < (uint64_t)M.max_chunks; i += stride) {
+        M.slot_key[i] = KEY_EMPTY;
+        M.slot_dirty[i] = 0;
+        M.free_list[i] = M.max_chunks - 1 - (int)i;  // slot 0 is popped first
+    }
+    if (gid == 0) {
+        *M.free_top = M.max_chunks;
+        *M.error_flag = 0;
+    }
+}
+
+__device__ inline int hash_find(const MapView &M, int x, int y, int z, uint64_t *where = nullptr) {
+    const uint64_t key = pack_id(x, y, z);
+    const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+    for (uint64_t i = 0; i <= M.hash_mask; i++) {
+        const uint64_t idx = (h + i) & M.hash_mask;
+        const uint64_t k = M.hash_keys[idx];
+        if (k == key) {
+            if (where) *where = idx;
+            return M.hash_vals[idx];
+        }
+        if (k == KEY_EMPTY) break;
+    }
+    return -1;
+}
+
+// HasChunk / GetChunk (ChunkManager.h:79-87): slot per id, -1 when absent
+__global__ void lookup_kernel(MapView M, const int *ids, int n, int *slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = hash_find(M, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+}
+
+// RemoveChunk(ChunkID) (ChunkManager.h:99-108) for a list: Chisel::GarbageCollect (Chisel.cpp:61-67).
+// Never runs concurrently with integrate_kernel (same stream), so pushes and pops do not interleave.
+__global__ void remove_chunks_kernel(MapView M, const int *ids, int n, int *n_removed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t where = 0;
+    const int slot = hash_find(M, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2], &where);
+    if (slot < 0) return;
+    // duplicates in the list: only the thread that swaps the key out frees the slot
+    const uint64_t key = pack_id(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+    if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) != key) return;
+    M.slot_key[slot] = KEY_EMPTY;
+    M.slot_dirty[slot] = 0;
+    const int pos = atomicAdd(M.free_top, 1);
+    M.free_list[pos] = slot;
+    atomicAdd(n_removed, 1);
+}
+
+// create-or-find for chisel_hip_upload_chunk (ChunkManager::AddChunk ChunkManager.h:89-92); one thread
+__global__ void ensure_chunk_kernel(MapView M, int x, int y, int z, int *out_slot) {
+    int slot = hash_find(M, x, y, z);
+    if (slot < 0) {
+        int top = atomicSub(M.free_top, 1) - 1;
+        if (top < 0) {
+            atomicAdd(M.free_top, 1);
+            atomicExch(M.error_flag, 1);
+        } else {
+            slot = M.free_list[top];
+            const uint64_t key = pack_id(x, y, z);
+            const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+            bool placed = false;
+            for (uint64_t i = 0; i <= M.hash_mask && !placed; i++) {
+                const uint64_t idx = (h + i) & M.hash_mask;
+                const uint64_t cur = M.hash_keys[idx];
+                if (cur == KEY_EMPTY || cur == KEY_TOMB) {
+                    M.hash_keys[idx] = key;
+                    M.hash_vals[idx] = slot;
+                    placed = true;
+                }
+            }
+            if (placed) {
+                M.slot_key[slot] = key;
+            } else {
+                atomicExch(M.error_flag, 2);
+                slot = -1;
+            }
+        }
+    }
+    *out_slot = slot;
+}
+
+// enumerate resident chunks (GetChunks()) or the dirty ones: ballot compaction over the slot table
+template <bool DIRTY_ONLY>
+__global__ void list_slots_kernel(MapView M, int *ids, int *slots, int max_out, int *count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    uint64_t key = KEY_EMPTY;
+    if (i < M.max_chunks) {
+        key = M.slot_key[i];
+        keep = key != KEY_EMPTY && (!DIRTY_ONLY || M.slot_dirty[i] != 0);
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = (int)__builtin_ctzll(mask);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, leader);
+    if (keep) {
+        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < max_out) {
+            int x, y, z;
+            unpack_id(key, x, y, z);
+            ids[3 * pos] = x;
+            ids[3 * pos + 1] = y;
+            ids[3 * pos + 2] = z;
+            if (slots) slots[pos] = i;
+        }
+    }
+}
+
+__global__ void clear_dirty_kernel(MapView M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M.max_chunks) M.slot_dirty[i] = 0;
+}
+
+// ---- known-answer kernels: the device arithmetic against the reference-built golden vectors ----------
+__global__ void kat_truncation_kernel(int kind, float param, const float *depths, int n, float *trunc, float *weight1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float t = truncation_distance(kind, param, depths[i]);
+        trunc[i] = t;
+        weight1[i] = constant_weight(1.0f, t);
+    }
+}
+// ops: n x (op, d, wu): op 0 = carve, 1 = integrate; out: n x (sdf, w)
+__global__ void kat_dist_kernel(const float *ops, int n, float *out) {
+    if (blockIdx.x || threadIdx.x) return;
+    float sdf = 99999.0f, w = 0.0f;
+    for (int i = 0; i < n; i++) {
+        if (ops[3 * i] == 0.0f) {
+            sdf = 99999.0f;
+            w = 0.0f;
+        } else {
+            dist_integrate(sdf, w, ops[3 * i + 1], ops[3 * i + 2]);
+        }
+        out[2 * i] = sdf;
+        out[2 * i + 1] = w;
+    }
+}
+// ops: n x (r, g, b, wu) bytes; out: n x (r, g, b, w)
+__global__ void kat_color_kernel(const uint8_t *ops, int n, uint8_t *out) {
+    if (blockIdx.x || threadIdx.x) return;
+    uchar4 c = make_uchar4(0, 0, 0, 0);
+    for (int i = 0; i < n; i++) {
+        c = color_integrate(c, ops[4 * i], ops[4 * i + 1], ops[4 * i + 2], ops[4 * i + 3]);
+        out[4 * i] = c.x;
+        out[4 * i + 1] = c.y;
+        out[4 * i + 2] = c.z;
+        out[4 * i + 3] = c.w;
+    }
+}
+
+}  // namespace chisel_hip

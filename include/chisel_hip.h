@@ -1,0 +1,193 @@
+/*
+ * chisel_hip.h -- C ABI of libchisel_hip.so, the MI355X (gfx950) dense-TSDF backend that replaces the
+ * CPU hot path of the OpenChisel library vendored in z619850002/CVIDS.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, no Eigen / torch / STL types.  Every entry point
+ * names the reference interface it replaces (paths relative to OpenChisel/open_chisel/ in the
+ * reference tree).  The C++ facade in cvids_amd/open_chisel/ re-creates the reference's class
+ * surface (chisel::Chisel, ProjectionIntegrator, ChunkManager, Chunk, Mesh) on top of this ABI;
+ * INTEGRATION.md shows the binding a CVIDS maintainer adds.
+ *
+ * Conventions
+ *   - all functions return a chisel_hip_status (0 = OK) unless documented otherwise;
+ *     chisel_hip_last_error() gives the message of the calling thread's last failure.
+ *   - poses are camera->world rigid transforms, row-major 3x4 [R|t] (the `Transform` /
+ *     Eigen::Affine3f the reference passes; optical frame: z forward, x right, y down).
+ *   - chunk ids are int[3] (chisel::ChunkID = Eigen::Vector3i); voxel i of a chunk is
+ *     (z*N + y)*N + x (Chunk.h:81-84).
+ *   - integrate calls are asynchronous on the map's HIP stream; every query / download
+ *     synchronises first, so the observable behaviour is the reference's synchronous one.
+ *   - image pointers may be host or device memory (`on_device`); device images must stay valid
+ *     until the map's stream has consumed them (chisel_hip_synchronize).
+ */
+#ifndef CHISEL_HIP_H_
+#define CHISEL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHISEL_HIP_ABI_VERSION 1
+
+typedef struct chisel_hip_map chisel_hip_map; /* opaque: one TSDF map (or one shard of it) on one GPU */
+
+typedef enum {
+    CHISEL_HIP_OK = 0,
+    CHISEL_HIP_ERR_INVALID = 1,     /* bad argument (null, non-cubic chunk, bad channel count ...)        */
+    CHISEL_HIP_ERR_HIP = 2,         /* a HIP runtime call failed / no gfx950 device                        */
+    CHISEL_HIP_ERR_POOL_FULL = 3,   /* chunk pool or hash exhausted: raise chisel_hip_config.max_chunks    */
+    CHISEL_HIP_ERR_NOT_FOUND = 4,   /* chunk / mesh absent (the reference throws std::out_of_range)        */
+    CHISEL_HIP_ERR_UNSUPPORTED = 5, /* feature outside the supported envelope                             */
+    CHISEL_HIP_ERR_IO = 6           /* file could not be written                                          */
+} chisel_hip_status;
+
+/* truncation/{ConstantTruncator.h:48-51, InverseTruncator.h:42-53, QuadraticTruncator.h:42-67} */
+typedef enum {
+    CHISEL_HIP_TRUNC_CONSTANT = 0,  /* param = truncation distance [m]  */
+    CHISEL_HIP_TRUNC_INVERSE = 1,   /* param = scalingFactor (the one ChiselNode.cpp:98 instantiates) */
+    CHISEL_HIP_TRUNC_QUADRATIC = 2  /* param = scalingFactor */
+} chisel_hip_truncator_kind;
+
+/* Chisel::Chisel(const Eigen::Vector3i& chunkSize, float voxelResolution, bool useColor) Chisel.h:41,
+ * ChunkManager::ChunkManager(...) ChunkManager.cpp:44-48 */
+typedef struct {
+    int chunk_size[3];       /* voxels per chunk edge; must be cubic: 8, 16 or 32                      */
+    float voxel_resolution;  /* metres                                                                  */
+    int use_color;           /* allocate RGBW voxels (ColorVoxel.h:95-98)                               */
+    int device_id;           /* HIP device ordinal, -1 = current device                                 */
+    int64_t max_chunks;      /* chunk-pool capacity, 0 = default (about 6 GiB of voxel payload)         */
+    int n_shards;            /* spatial sharding of the chunk hash over GPUs: number of shards (>=1)    */
+    int shard_rank;          /* this map's shard, 0 <= shard_rank < n_shards                            */
+    int shard_block;         /* ownership super-block edge in chunks, 0 = default (2)                   */
+} chisel_hip_config;
+
+/* ProjectionIntegrator(truncator, weighter, carvingDist, enableCarving, centroids) ProjectionIntegrator.h:43-44;
+ * ChiselServer::SetupProjectionIntegrator chisel_ros/src/ChiselServer.cpp:480-487 */
+typedef struct {
+    int truncator_kind;      /* chisel_hip_truncator_kind                                               */
+    float truncator_param;
+    float weight;            /* ConstantWeighter(weight) weighting/ConstantWeighter.h:35-46            */
+    int carving_enabled;     /* ProjectionIntegrator::SetCarvingEnabled                                 */
+    float carving_dist;      /* ProjectionIntegrator::SetCarvingDist                                    */
+} chisel_hip_integrator;
+
+/* DepthImage<float> (camera/DepthImage.h:33-103) + PinholeCamera (camera/PinholeCamera.h:35-69) + Transform */
+typedef struct {
+    const float *depth;      /* width*height row-major fp32 metres, NaN = invalid                       */
+    int width, height;
+    int on_device;           /* 0: host pointer (copied in), 1: device pointer (used in place)          */
+    float pose[12];
+    float fx, fy, cx, cy;    /* Intrinsics.h:40-47                                                      */
+    float near_plane, far_plane;
+} chisel_hip_depth_frame;
+
+/* ColorImage<uint8_t> (camera/ColorImage.h:38-134): 1 = mono, 2, 3 = BGR, 4 = BGRA */
+typedef struct {
+    const uint8_t *color;
+    int width, height, channels;
+    int on_device;
+    float pose[12];
+    float fx, fy, cx, cy;
+} chisel_hip_color_frame;
+
+/* per-map accumulated voxel counters; index into the array of chisel_hip_get_counters */
+enum {
+    CHISEL_HIP_CNT_SDF = 0,       /* DistVoxel::Integrate executions                                    */
+    CHISEL_HIP_CNT_COL = 1,       /* ColorVoxel::Integrate executions                                   */
+    CHISEL_HIP_CNT_COL_SAT = 2,   /* in band, on the colour image, colour weight already >= 8           */
+    CHISEL_HIP_CNT_PROBE = 3,     /* voxels of resident chunks that took the carve test                 */
+    CHISEL_HIP_CNT_CARVED = 4,    /* Carve() / weight decay executions                                  */
+    CHISEL_HIP_CNT_WORK_CHUNKS = 5, /* chunks the integration kernel visited                            */
+    CHISEL_HIP_CNT_NEW_CHUNKS = 6,  /* chunks allocated                                                 */
+    CHISEL_HIP_CNT_UPDATED_CHUNKS = 7, /* chunks whose integration reported "updated"                   */
+    CHISEL_HIP_CNT_FRAMES = 8,
+    CHISEL_HIP_NUM_COUNTERS = 9
+};
+
+/* kernels timed by the built-in hipEvent profiler (chisel_hip_set_profiling) */
+enum {
+    CHISEL_HIP_KERNEL_PYRAMID = 0,   /* depth min/max pyramid                                           */
+    CHISEL_HIP_KERNEL_CULL = 1,      /* candidate enumeration + hash lookup + compaction                 */
+    CHISEL_HIP_KERNEL_INTEGRATE = 2, /* projective SDF/weight/colour integration (+ allocation)          */
+    CHISEL_HIP_KERNEL_MESH = 3,      /* marching cubes (count + emit)                                   */
+    CHISEL_HIP_NUM_KERNELS = 4
+};
+
+/* ---- life cycle ------------------------------------------------------------------------------------- */
+int chisel_hip_abi_version(void);
+const char *chisel_hip_last_error(void);
+/* number of visible gfx950 devices (0 when there is none) */
+int chisel_hip_device_count(void);
+/* Chisel::Chisel Chisel.h:41 */
+int chisel_hip_create(const chisel_hip_config *config, chisel_hip_map **out);
+int chisel_hip_destroy(chisel_hip_map *map);
+/* Chisel::Reset Chisel.cpp:44-48 (+ ChunkManager::Reset ChunkManager.cpp:176-180) */
+int chisel_hip_reset(chisel_hip_map *map);
+/* ProjectionIntegrator setters ProjectionIntegrator.h:185-217 */
+int chisel_hip_set_integrator(chisel_hip_map *map, const chisel_hip_integrator *integrator);
+/* run the map's kernels on a caller-owned hipStream_t (NULL = the map's own stream) */
+int chisel_hip_set_stream(chisel_hip_map *map, void *hip_stream);
+int chisel_hip_synchronize(chisel_hip_map *map);
+
+/* ---- the hot path ------------------------------------------------------------------------------------ */
+/* Chisel::IntegrateDepthScan<float> Chisel.h:59-112 -> ProjectionIntegrator::Integrate ProjectionIntegrator.h:51-99
+ * (candidate enumeration ChunkManager.cpp:182-212, allocation :171-174, GarbageCollect Chisel.cpp:61-67) */
+int chisel_hip_integrate_depth(chisel_hip_map *map, const chisel_hip_depth_frame *frame);
+/* Chisel::IntegrateDepthScanColor<float,uint8_t> Chisel.h:114-213 -> IntegrateColor ProjectionIntegrator.h:101-183 */
+int chisel_hip_integrate_depth_color(chisel_hip_map *map, const chisel_hip_depth_frame *frame,
+                                     const chisel_hip_color_frame *color);
+/* n frames in order (frame k+1 sees frame k's result, as n successive calls would); colors may be NULL */
+int chisel_hip_integrate_batch(chisel_hip_map *map, int n, const chisel_hip_depth_frame *frames,
+                               const chisel_hip_color_frame *colors);
+/* Chisel::GarbageCollect(const ChunkIDList&) Chisel.cpp:61-67 / ChunkManager::RemoveChunk(ChunkID) ChunkManager.h:99-108 */
+int chisel_hip_garbage_collect(chisel_hip_map *map, const int *chunk_ids_xyz, int n);
+/* Chisel::UpdateMeshes Chisel.cpp:50-59 (recompute on every 10th call unless force) ->
+ * ChunkManager::RecomputeMeshes ChunkManager.cpp:130-169 */
+int chisel_hip_update_meshes(chisel_hip_map *map, int force);
+
+/* ---- queries (each synchronises) --------------------------------------------------------------------- */
+/* ChunkManager::GetChunks().size() ChunkManager.h:67-70 */
+int chisel_hip_num_chunks(chisel_hip_map *map, int64_t *out);
+/* ids of all resident chunks, 3 ints each; writes min(count, max_ids) ids, *count = total */
+int chisel_hip_list_chunks(chisel_hip_map *map, int *ids_xyz, int64_t max_ids, int64_t *count);
+/* ChunkManager::HasChunk ChunkManager.h:79-82 */
+int chisel_hip_has_chunk(chisel_hip_map *map, const int id_xyz[3], int *out);
+/* Chunk::GetVoxels / GetColorVoxels Chunk.h:66,117-120: N^3 sdf, N^3 weight, 4*N^3 rgbw (may be NULL) */
+int chisel_hip_download_chunk(chisel_hip_map *map, const int id_xyz[3], float *sdf, float *weight, uint8_t *rgbw);
+/* inverse of download (ChunkManager::AddChunk ChunkManager.h:89-92 with caller-filled voxels) */
+int chisel_hip_upload_chunk(chisel_hip_map *map, const int id_xyz[3], const float *sdf, const float *weight,
+                            const uint8_t *rgbw);
+/* Chisel::GetMeshesToUpdate Chisel.h:220-223: ids flagged since the last recompute (27-neighbourhoods) */
+int chisel_hip_meshes_to_update(chisel_hip_map *map, int *ids_xyz, int64_t max_ids, int64_t *count);
+/* ChunkManager::GetAllMeshes ChunkManager.h:163-166 */
+int chisel_hip_num_meshes(chisel_hip_map *map, int64_t *out);
+int chisel_hip_list_meshes(chisel_hip_map *map, int *ids_xyz, int64_t max_ids, int64_t *count);
+/* Mesh (mesh/Mesh.h:54-58) sizes of one chunk's mesh: vertices (= normals = colors = indices), grids */
+int chisel_hip_mesh_size(chisel_hip_map *map, const int id_xyz[3], int64_t *n_vertices, int64_t *n_grids);
+/* 3 floats per vertex / grid; any pointer may be NULL; indices are 0..n_vertices-1 (MarchingCubes.h:92-94) */
+int chisel_hip_download_mesh(chisel_hip_map *map, const int id_xyz[3], float *vertices, float *normals,
+                             float *colors, float *grids);
+/* ChunkManager::GetSDF ChunkManager.cpp:476-499 ; *found = 0 when the reference returns false */
+int chisel_hip_get_sdf(chisel_hip_map *map, const float pos[3], double *dist, int *found);
+/* ChunkManager::GetSDFAndGradient ChunkManager.cpp:449-474 */
+int chisel_hip_get_sdf_and_gradient(chisel_hip_map *map, const float pos[3], double *dist, float grad[3], int *found);
+/* Chisel::SaveAllMeshesToPLY Chisel.cpp:69-105 + SaveMeshPLYASCII io/PLY.cpp:29-88 */
+int chisel_hip_save_ply(chisel_hip_map *map, const char *path);
+
+/* ---- measurement ------------------------------------------------------------------------------------ */
+/* accumulated since creation / last reset_counters; out has CHISEL_HIP_NUM_COUNTERS entries */
+int chisel_hip_get_counters(chisel_hip_map *map, uint64_t *out, int reset_counters);
+/* hipEvent pairs around every kernel launch on the map's stream (off by default) */
+int chisel_hip_set_profiling(chisel_hip_map *map, int enable);
+/* total milliseconds and launch counts per CHISEL_HIP_KERNEL_* since enabled / last reset */
+int chisel_hip_get_profile(chisel_hip_map *map, double *ms_total, int64_t *launches, int reset_profile);
+/* owner shard of a chunk id under (n_shards, shard_block); pure function, same on every rank */
+int chisel_hip_chunk_owner(const int id_xyz[3], int n_shards, int shard_block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHISEL_HIP_H_ */

@@ -1,0 +1,66 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/chisel_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "chisel_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(chisel_hip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(hip_lib):
+    from cvids_amd import capi
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(hip_lib, s), "libchisel_hip.so does not export %s" % s
+    assert sorted(capi.EXPORTS) == syms, "cvids_amd/capi.py EXPORTS out of sync with include/chisel_hip.h"
+    assert hip_lib.chisel_hip_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from cvids_amd import capi
+    # sizes implied by the field lists of include/chisel_hip.h on LP64
+    assert ctypes.sizeof(capi.Config) == 48
+    assert ctypes.sizeof(capi.Integrator) == 20
+    assert ctypes.sizeof(capi.DepthFrame) == 96
+    assert ctypes.sizeof(capi.ColorFrame) == 88
+
+
+def test_create_fails_loudly_without_gpu(hip_lib):
+    """No CPU fallback: on a box without a gfx950 device create() must fail, not emulate."""
+    from cvids_amd import capi
+    if hip_lib.chisel_hip_device_count() > 0:
+        pytest.skip("a gfx950 device is present")
+    from cvids_amd.chisel import Chisel
+    with pytest.raises(capi.ChiselHipError):
+        Chisel((16, 16, 16), 0.02, False)
+
+
+def test_invalid_config_rejected(hip_lib):
+    from cvids_amd import capi
+    from cvids_amd.chisel import Chisel
+    with pytest.raises(capi.ChiselHipError) as e:
+        Chisel((16, 16, 8), 0.02, False)
+    assert e.value.code == 5
+
+
+def test_chunk_owner_is_a_partition(hip_lib):
+    from cvids_amd.chisel import chunk_owner
+    for n in (1, 2, 4, 8):
+        seen = set()
+        for x in range(-5, 6):
+            for y in range(-5, 6):
+                for z in range(-5, 6):
+                    o = chunk_owner((x, y, z), n, 2)
+                    assert 0 <= o < n
+                    seen.add(o)
+        assert seen == set(range(n))
+    # 2x2x2 super-blocks share an owner
+    assert len({chunk_owner((2 + dx, 4 + dy, -6 + dz), 8, 2) for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)}) == 1

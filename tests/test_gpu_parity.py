@@ -1,0 +1,283 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): SDF and weight within 1e-4 absolute of the CPU reference.  The kernels
+reproduce the reference's fp32 operation order, so these tests demand BIT-EXACT sdf / weight / colour and
+identical voxel counters; ATOL below documents the contractual tolerance and is only used at full size.
+"""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from cvids_amd import synth
+from tests.common import compare_fields, make_frames, small_camera
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def f32(hexstr):
+    return struct.unpack("<f", struct.pack("<I", int(hexstr, 16)))[0]
+
+
+def _mk(oracle_mod, N, res, color, trunc=("inverse", 2.0), weight=1.0, carving=True, carving_dist=0.05, max_chunks=4096):
+    from cvids_amd import chisel as ch
+    kinds = {"constant": (0, ch.ConstantTruncator), "inverse": (1, ch.InverseTruncator), "quadratic": (2, ch.QuadraticTruncator)}
+    k, cls = kinds[trunc[0]]
+    om = oracle_mod.OracleMap(N, res, color)
+    om.set_integrator(k, trunc[1], weight, carving, carving_dist)
+    gm = ch.Chisel((N, N, N), res, color, max_chunks=max_chunks)
+    integ = ch.ProjectionIntegrator(cls(trunc[1]), ch.ConstantWeighter(weight), carving_dist, carving)
+    return om, gm, integ
+
+
+def _run(om, gm, integ, frames, cam, color_img=None, check_each=True, atol=0.0):
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    for i, (depth, pose) in enumerate(frames):
+        if color_img is None:
+            om.integrate_depth(depth, pose, intr, cam.near_plane, cam.far_plane)
+            gm.IntegrateDepthScan(integ, depth, pose, cam)
+        else:
+            om.integrate_depth_color(depth, pose, intr, color_img, near=cam.near_plane, far=cam.far_plane)
+            gm.IntegrateDepthScanColor(integ, depth, pose, cam, color_img, pose, cam)
+        oc = om.counters()
+        gc = gm.counters(reset=True)
+        for k in ("sdf", "col", "col_sat", "probe", "carved", "updated_chunks"):
+            assert oc[k] == gc[k], "frame %d counter %s: oracle %d gpu %d" % (i, k, oc[k], gc[k])
+        if check_each or i == len(frames) - 1:
+            assert om.num_chunks() == gm.NumChunks(), "frame %d: chunk count" % i
+            compare_fields(om.fields(), gm.fields(), om.V, om.use_color, atol=atol, what="frame %d" % i)
+            assert sorted(map(tuple, om.meshes_to_update().tolist())) == sorted(map(tuple, gm.GetMeshesToUpdate().tolist()))
+
+
+# ---- device arithmetic against the reference-built golden vectors ---------------------------------------
+def test_device_kat_truncators(hip_lib):
+    import ctypes as C
+    kat = json.load(open(os.path.join(HERE, "golden", "ref_kat.json")))
+    depths = np.array([f32(h) for h in kat["depths"]], np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    kinds = {"constant": 0, "inverse": 1, "quadratic": 2}
+    for key, vals in kat["truncation"].items():
+        name, phex = key.rsplit("_", 1)
+        exp = np.array([int(v, 16) for v in vals], np.uint32)
+        t = np.zeros_like(depths)
+        w = np.zeros_like(depths)
+        if name in kinds:
+            assert hip_lib.chisel_hip_kat_truncation(kinds[name], f32(phex), fp(depths), len(depths), fp(t), fp(w)) == 0
+            got = t.view(np.uint32)
+        elif name == "weight1_inverse":
+            assert hip_lib.chisel_hip_kat_truncation(1, f32(phex), fp(depths), len(depths), fp(t), fp(w)) == 0
+            got = w.view(np.uint32)
+        else:
+            continue
+        nan = np.isnan(exp.view(np.float32))
+        assert np.array_equal(np.isnan(got.view(np.float32)), nan), key
+        assert np.array_equal(got[~nan], exp[~nan]), key
+
+
+def test_device_kat_voxels(hip_lib):
+    import ctypes as C
+    kat = json.load(open(os.path.join(HERE, "golden", "ref_kat.json")))
+    for seq in kat["dist_sequences"]:
+        ops = np.array([[0.0 if s[0] == "c" else 1.0, f32(s[1]) if s[0] == "i" else 0.0, f32(s[2]) if s[0] == "i" else 0.0]
+                        for s in seq["steps"]], np.float32)
+        exp = np.array([[int(s[3], 16), int(s[4], 16)] for s in seq["steps"]], np.uint32)
+        out = np.zeros((len(ops), 2), np.float32)
+        assert hip_lib.chisel_hip_kat_dist(ops.ctypes.data_as(C.POINTER(C.c_float)), len(ops), out.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        got = out.view(np.uint32)
+        nan = np.isnan(exp.view(np.float32))
+        assert np.array_equal(np.isnan(out), nan)
+        assert np.array_equal(got[~nan], exp[~nan])
+    for seq in kat["color_sequences"]:
+        a = np.array(seq, np.uint8)
+        ops = np.ascontiguousarray(a[:, :4])
+        out = np.zeros_like(ops)
+        assert hip_lib.chisel_hip_kat_color(ops.ctypes.data_as(C.POINTER(C.c_uint8)), len(ops), out.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+        assert np.array_equal(out, a[:, 4:])
+
+
+# ---- frame-level parity ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["wall", "sphere_room", "box_room"])
+def test_depth_only_stream(oracle_mod, scene):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False)
+    cam = small_camera(64, 48)
+    _run(om, gm, integ, make_frames(scene, 4, 64, 48), cam)
+    assert gm.NumChunks() > 50
+
+
+@pytest.mark.parametrize("channels", [1, 3, 4])
+def test_color_stream(oracle_mod, channels):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True)
+    cam = small_camera(64, 48)
+    color = synth.render_color(64, 48, channels)
+    _run(om, gm, integ, make_frames("sphere_room", 12, 64, 48), cam, color_img=color)  # > 8 frames: colour weight saturates
+
+
+@pytest.mark.parametrize("N,res,W,H", [(16, 0.04, 96, 72), (32, 0.02, 64, 48), (8, 0.10, 160, 120)])
+def test_chunk_sizes(oracle_mod, N, res, W, H):
+    om, gm, integ = _mk(oracle_mod, N, res, True, max_chunks=2048)
+    cam = small_camera(W, H)
+    _run(om, gm, integ, make_frames("box_room", 3, W, H), cam, color_img=synth.render_color(W, H, 3))
+
+
+@pytest.mark.parametrize("trunc", [("constant", 0.12), ("quadratic", 1.5), ("inverse", 0.7)])
+@pytest.mark.parametrize("color", [False, True])
+def test_truncators(oracle_mod, trunc, color):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, color, trunc=trunc, weight=2.0)
+    cam = small_camera(64, 48)
+    _run(om, gm, integ, make_frames("sphere_room", 3, 64, 48), cam, color_img=synth.render_color(64, 48, 3) if color else None)
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_carving_moves_surface(oracle_mod, color):
+    """Integrate a near wall, then a far one along the same rays: the old surface is carved / decayed."""
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, color, carving=True, carving_dist=0.0)
+    cam = small_camera(64, 48)
+    pose = synth.pose_yaw(0.0)
+    near_wall = np.full((48, 64), 1.2, np.float32)
+    far_wall = np.full((48, 64), 2.4, np.float32)
+    frames = [(near_wall, pose)] * 7 + [(far_wall, pose)] * 4
+    _run(om, gm, integ, frames, cam, color_img=synth.render_color(64, 48, 3) if color else None)
+    # carving really happened in this scenario
+    om2, gm2, integ2 = _mk(oracle_mod, 8, 0.05, color, carving=True, carving_dist=0.0)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    carved = 0
+    for d, p in frames:
+        if color:
+            om2.integrate_depth_color(d, p, intr, synth.render_color(64, 48, 3))
+        else:
+            om2.integrate_depth(d, p, intr)
+        carved += om2.counters()["carved"]
+    assert carved > 1000
+
+
+def test_carving_disabled(oracle_mod):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False, carving=False)
+    cam = small_camera(64, 48)
+    pose = synth.pose_yaw(0.0)
+    frames = [(np.full((48, 64), 1.2, np.float32), pose)] * 2 + [(np.full((48, 64), 2.4, np.float32), pose)] * 2
+    _run(om, gm, integ, frames, cam)
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_invalid_pixels(oracle_mod, color):
+    """NaN, zero, negative, > 50 m / > 100 m, +-inf depth: every special value the reference tolerates."""
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, color)
+    cam = small_camera(64, 48)
+    rng = np.random.default_rng(7)
+    frames = []
+    for depth, pose in make_frames("sphere_room", 3, 64, 48, nan_fraction=0.05):
+        d = depth.copy()
+        sel = rng.random(d.shape)
+        d[sel < 0.03] = 0.0
+        d[(sel >= 0.03) & (sel < 0.05)] = -0.7
+        d[(sel >= 0.05) & (sel < 0.07)] = 75.0
+        d[(sel >= 0.07) & (sel < 0.09)] = 150.0
+        d[(sel >= 0.09) & (sel < 0.10)] = np.inf
+        d[(sel >= 0.10) & (sel < 0.11)] = -np.inf
+        frames.append((d, pose))
+    _run(om, gm, integ, frames, cam, color_img=synth.render_color(64, 48, 3) if color else None)
+
+
+def test_all_invalid_and_empty_map(oracle_mod):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False)
+    cam = small_camera(64, 48)
+    _run(om, gm, integ, [(np.full((48, 64), np.nan, np.float32), synth.pose_yaw(10.0))], cam)
+    assert gm.NumChunks() == 0 and len(gm.GetChunkIDs()) == 0
+    with pytest.raises(KeyError):
+        gm.GetChunk((0, 0, 0))
+    assert not gm.HasChunk((0, 0, 0))
+
+
+def test_far_plane_limits_candidates(oracle_mod):
+    """Depth beyond the far plane: the reference never enumerates those chunks; neither may the GPU."""
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False)
+    cam = small_camera(64, 48, far=1.5)
+    _run(om, gm, integ, make_frames("sphere_room", 2, 64, 48), cam)
+
+
+def test_moving_camera_noise_multi_agent(oracle_mod):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    cam = small_camera(64, 48)
+    frames = make_frames("sphere_room", 3, 64, 48, agents=4, noise=True, nan_fraction=0.02)
+    _run(om, gm, integ, frames, cam, color_img=synth.render_color(64, 48, 3), check_each=False)
+
+
+def test_ragged_image_sizes(oracle_mod):
+    """Width not a multiple of 4 / 64: pyramid edge tiles and the unaligned depth path."""
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False)
+    cam = small_camera(67, 45)
+    _run(om, gm, integ, make_frames("box_room", 2, 67, 45), cam)
+
+
+def test_reset_and_garbage_collect(oracle_mod):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False)
+    cam = small_camera(64, 48)
+    frames = make_frames("wall", 2, 64, 48)
+    _run(om, gm, integ, frames, cam)
+    ids = gm.GetChunkIDs()
+    victims = ids[:: 3]
+    gm.GarbageCollect(victims)
+    for v in victims:
+        om.remove_chunk(v)
+    gm.GarbageCollect(victims[:2])  # removing twice is a no-op (ChunkManager.h:99-108 returns false)
+    assert gm.NumChunks() == om.num_chunks()
+    compare_fields(om.fields(), gm.fields(), om.V, False)
+    _run(om, gm, integ, make_frames("wall", 2, 64, 48, start=2), cam)  # freed slots and tombstones are reused
+    gm.Reset()
+    om.reset()
+    assert gm.NumChunks() == 0
+    _run(om, gm, integ, frames, cam)
+
+
+def test_pool_exhaustion_is_reported(oracle_mod):
+    from cvids_amd import capi
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False, max_chunks=16)
+    cam = small_camera(64, 48)
+    depth, pose = make_frames("sphere_room", 1, 64, 48)[0]
+    gm.IntegrateDepthScan(integ, depth, pose, cam)
+    with pytest.raises(capi.ChiselHipError) as e:
+        gm.synchronize()
+    assert e.value.code == 3
+
+
+def test_device_resident_frames_and_batch(oracle_mod):
+    """Frames already in HBM (torch tensors) through integrate_batch == frame-by-frame host frames."""
+    import torch
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True)
+    cam = small_camera(64, 48)
+    frames = make_frames("sphere_room", 5, 64, 48)
+    color = synth.render_color(64, 48, 3)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color)
+    dev = torch.device("cuda:0")
+    d_dev = [torch.from_numpy(d).to(dev) for d, _ in frames]
+    c_dev = torch.from_numpy(color).to(dev)
+    torch.cuda.synchronize()
+    gm.IntegrateBatch(integ, [(d_dev[i], frames[i][1], cam) for i in range(5)], [(c_dev, frames[i][1], cam) for i in range(5)])
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
+def test_upload_download_roundtrip(oracle_mod):
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True)
+    rng = np.random.default_rng(3)
+    sdf = rng.normal(size=512).astype(np.float32)
+    w = rng.random(512).astype(np.float32)
+    rgbw = rng.integers(0, 256, (512, 4)).astype(np.uint8)
+    gm.AddChunk((3, -2, 7), sdf, w, rgbw)
+    s2, w2, c2 = gm.GetChunk((3, -2, 7))
+    assert np.array_equal(sdf, s2) and np.array_equal(w, w2) and np.array_equal(rgbw, c2)
+    assert gm.HasChunk((3, -2, 7)) and gm.NumChunks() == 1
+
+
+@pytest.mark.parametrize("color", [False, True])
+def test_full_size_frame_2cm(oracle_mod, color):
+    """BASELINE configs[0]/[1]: one 640x480 frame at 2 cm, chunk 16 (the oracle needs ~1 GB and a few seconds)."""
+    om, gm, integ = _mk(oracle_mod, 16, 0.02, color, max_chunks=16384)
+    cam = small_camera(640, 480)
+    frames = make_frames("sphere_room", 2, 640, 480, nan_fraction=0.02)
+    _run(om, gm, integ, frames, cam, color_img=synth.render_color(640, 480, 3) if color else None, check_each=False, atol=0.0)
