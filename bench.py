@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- depth frames/s integrated into the TSDF (+ Mvoxel-updates/s), 640x480 @ 1 cm.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one depth(+colour) frame pushed through the hot path (pyramid -> cull -> integrate kernels;
+with --mesh-every M also a marching-cubes recompute every M-th frame, the reference cadence is 10).
+Frames are synthetic (cvids_amd.synth: sphere room, 0.5 deg + 1 cm per frame) and already resident in
+HBM when the timed region starts.  N > 1: one process per GPU, the chunk hash is sharded spatially
+(chisel_hip_config.n_shards), every frame is RCCL-broadcast from the GPU that ingested it and each rank
+integrates the chunks it owns -> total work is fixed: "scaling": "strong".
+
+One JSON line on rank 0.  `roofline` prices the integration kernel: algorithmic bytes per frame
+(DESIGN.md "Measurement": 16 B per integrated voxel + 8 B per carve probe + 8 B per carve + colour
+bytes + the images once) divided by the kernel's mean duration from hipEvents recorded on the map's
+stream during a second, instrumented pass over the same frames from the same initial map state.
+`cpu_baseline` = the oracle (oracle/liboracle.so: the reference algorithm restated, "faithful mode",
+16 threads as the reference hard-codes) on a bounded sample of the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "depth frames/sec integrated + Mvoxel-updates/sec, 640x480 @ 1 cm, 1/2/4/8 GPU"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--res", type=float, default=0.01)
+    ap.add_argument("--chunk", type=int, default=16)
+    ap.add_argument("--scene", default="sphere_room")
+    ap.add_argument("--no-color", action="store_true", help="depth-only path (IntegrateDepthScan)")
+    ap.add_argument("--agents", type=int, default=1)
+    ap.add_argument("--trunc-scale", type=float, default=None, help="InverseTruncator scale (default: 100*res)")
+    ap.add_argument("--mesh-every", type=int, default=0, help="UpdateMeshes(force) every M frames inside the timed region")
+    ap.add_argument("--max-chunks", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(cnt, n_frames, W, H, channels):
+    """B = 16 N_sdf + 8 N_col + 4 N_colsat + 8 N_probe + 8 N_carved + (4 + C) W H per frame."""
+    b = 16 * cnt["sdf"] + 8 * cnt["col"] + 4 * cnt["col_sat"] + 8 * cnt["probe"] + 8 * cnt["carved"]
+    b += n_frames * (4 + channels) * W * H
+    return b
+
+
+def cpu_baseline(args, frames, color_img, intr, scale):
+    import oracle
+    om = oracle.OracleMap(args.chunk, args.res, not args.no_color, threads=16)
+    om.set_integrator(oracle.TRUNC_INVERSE, scale, 1.0, True, 0.05)
+    n = min(args.cpu_frames, len(frames))
+    upd = 0
+    t0 = time.perf_counter()
+    for depth, pose in frames[:n]:
+        if args.no_color:
+            om.integrate_depth(depth, pose, intr, 0.05, 5.0)
+        else:
+            om.integrate_depth_color(depth, pose, intr, color_img, near=0.05, far=5.0)
+        c = om.counters()
+        upd += c["sdf"] + c["carved"]
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 16 if not args.no_color else 1, "kind": "port",
+            "host_cpus": os.cpu_count(), "mvoxel_updates_per_s": upd / dt / 1e6,
+            "sample": "first %d frames of the same stream (oracle faithful mode: %d candidate chunks visited per frame, %s), %.1f s"
+                      % (n, c["candidates"], "16 std::threads as Chisel.h:150" if not args.no_color else "serial as Chisel.h:71", dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from cvids_amd import synth
+    from cvids_amd.chisel import Chisel, ConstantWeighter, InverseTruncator, PinholeCamera, ProjectionIntegrator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus), file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H = args.width, args.height
+    intr = synth.intrinsics(W, H)
+    cam = PinholeCamera(*intr, W, H, 0.05, 5.0)
+    scale = args.trunc_scale if args.trunc_scale is not None else 100.0 * args.res  # 2.0 @2 cm, 1.0 @1 cm, 0.5 @0.5 cm
+    integ = ProjectionIntegrator(InverseTruncator(scale), ConstantWeighter(1.0), 0.05, True)
+    use_color = not args.no_color
+    channels = 3 if use_color else 0
+    total = args.warmup + args.steps
+    n_traj = (total + args.agents - 1) // args.agents
+    frames = list(synth.stream(args.scene, n_traj, W, H, agents=args.agents))[:total]
+    color_img = synth.render_color(W, H, 3) if use_color else None
+
+    # frame i is ingested by rank (i % agents) % world: its pixels live in that rank's HBM before timing starts
+    root_of = [(i % args.agents) % world for i in range(total)]
+    d_dev = [torch.from_numpy(frames[i][0]).to(dev) if (world == 1 or root_of[i] == rank) else None for i in range(total)]
+    c_dev = torch.from_numpy(color_img).to(dev) if use_color else None  # static colour pattern, resident on every rank
+    recv = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+
+    def new_map():
+        m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
+                   n_shards=world, shard_rank=rank)
+        m.set_stream(torch.cuda.current_stream().cuda_stream)  # RCCL -> integrate ordering comes from the stream
+        return m
+
+    def run(m, lo, hi):
+        pending = None
+        for i in range(lo, hi):
+            if world > 1:
+                buf = recv[i & 1]
+                if root_of[i] == rank:
+                    buf.copy_(d_dev[i], non_blocking=True)
+                dist.broadcast(buf, src=root_of[i])
+                depth = buf
+            else:
+                depth = d_dev[i]
+            pose = frames[i][1]
+            if use_color:
+                m.IntegrateDepthScanColor(integ, depth, pose, cam, c_dev, pose, cam)
+            else:
+                m.IntegrateDepthScan(integ, depth, pose, cam)
+            if args.mesh_every and (i + 1) % args.mesh_every == 0:
+                m.UpdateMeshes(force=True)
+        return pending
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- pass A: the timed region ---------------------------------------------------------------------
+    m = new_map()
+    run(m, 0, args.warmup)
+    m.synchronize()
+    m.counters(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    run(m, args.warmup, total)
+    fence()
+    dt = time.perf_counter() - t0
+    m.synchronize()  # surfaces pool exhaustion
+    cnt = m.counters()
+    n_chunks = m.NumChunks()
+    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+    vals = torch.tensor([cnt["sdf"] + cnt["carved"], cnt["sdf"], cnt["col"], cnt["col_sat"], cnt["probe"], cnt["carved"],
+                         cnt["work_chunks"], n_chunks], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+    dt = float(t_all.item())
+    vals = [float(v) for v in vals.tolist()]
+    m.close()
+
+    # ---- pass B: same frames from the same initial state, hipEvents around every kernel ---------------------
+    roof = None
+    if not args.no_roofline:
+        m = new_map()
+        run(m, 0, args.warmup)
+        m.synchronize()
+        m.counters(reset=True)
+        m.set_profiling(True)
+        fence()
+        t1 = time.perf_counter()
+        run(m, args.warmup, total)
+        fence()
+        dt_b = time.perf_counter() - t1
+        prof = m.profile()
+        cb = m.counters()
+        m.set_profiling(False)
+        m.close()
+        k = prof["integrate"]
+        avg_ms = k["ms"] / max(k["launches"], 1)
+        bytes_per_launch = algorithmic_bytes(cb, args.steps, W, H, channels) / max(k["launches"], 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "integrate_kernel<%d,%s>" % (args.chunk, "true" if use_color else "false"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "avg_kernel_us": avg_ms * 1e3, "launches": k["launches"],
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "other_kernels_us": {n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "mesh")
+                                     if prof[n]["launches"]},
+                "instrumented_ms_per_step": dt_b / args.steps * 1e3,
+                "note": "rank 0 shard; traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by tools/profile.sh into profiles/"}
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mvoxel_updates_per_s": vals[0] / dt / 1e6,
+            "config": {"workload": "%dx%d %s stream (%s, %d agent%s), %g cm voxels, chunk %d^3, InverseTruncator(%g), carving 0.05 m, "
+                                   "projective TSDF integration%s" % (W, H, "depth+BGR colour" if use_color else "depth-only",
+                                                                        args.scene, args.agents, "" if args.agents == 1 else "s",
+                                                                        args.res * 100, args.chunk, scale,
+                                                                        (" + marching cubes every %d frames" % args.mesh_every) if args.mesh_every else ""),
+                       "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color,
+                       "parallelism": "spatial chunk-hash shards x%d, RCCL frame broadcast" % world if world > 1 else "1 GPU"},
+            "per_frame": {"voxel_updates": vals[0] / args.steps, "n_sdf": vals[1] / args.steps, "n_col": vals[2] / args.steps,
+                          "n_probe": vals[4] / args.steps, "n_carved": vals[5] / args.steps,
+                          "work_chunks": vals[6] / args.steps, "resident_chunks_end": vals[7]},
+        }
+        if roof:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, frames[args.warmup:], color_img, intr, scale)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

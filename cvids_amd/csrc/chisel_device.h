@@ -20,6 +20,7 @@ namespace chisel_hip {
 constexpr uint64_t KEY_EMPTY = ~0ull;
 constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
 constexpr int ID_BIAS = 1 << 20;  // chunk ids in [-2^20, 2^20)
+constexpr int INTEGRATE_MAX_GRID = 2048;  // 256 CUs x 8 workgroups
 
 __host__ __device__ inline uint64_t pack_id(int x, int y, int z) {
     return (uint64_t)(uint32_t)(x + ID_BIAS) | ((uint64_t)(uint32_t)(y + ID_BIAS) << 21) |
@@ -58,7 +59,8 @@ struct MapView {
     uint32_t *slot_dirty;
     int *free_list;
     int *free_top;
-    unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS
+    unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS (filled by reduce_counters_kernel)
+    unsigned long long *block_counters;  // [INTEGRATE_MAX_GRID][16] per-workgroup partial sums
     int *error_flag;         // != 0: pool / hash exhausted
     int max_chunks;
 };

@@ -203,7 +203,7 @@ int launch_frame(chisel_hip_map *m, const FrameParams &P, bool color) {
     }
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
-        const int grid = std::max(1, std::min(total, 256 * 8));
+        const int grid = std::max(1, std::min(total, INTEGRATE_MAX_GRID));
         if (color)
             hipLaunchKernelGGL((integrate_kernel<N, true>), dim3(grid), dim3(G::BLOCK), 0, m->stream, P, m->view, m->items,
                                m->work_count, m->items_capacity);
@@ -439,6 +439,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 16 * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 16 * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMalloc(&v.error_flag, sizeof(int)));
     HIP_TRY_C(hipMalloc(&m->work_count, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
@@ -457,7 +459,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.error_flag, m->work_count, m->items, m->pyr_data, m->depth_stage, m->color_stage,
+                    v.counters, v.block_counters, v.error_flag, m->work_count, m->items, m->pyr_data, m->depth_stage, m->color_stage,
                     m->scratch_i};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -650,8 +652,10 @@ int chisel_hip_meshes_to_update(chisel_hip_map *m, int *ids, int64_t max_ids, in
 int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters) {
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
+    hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, m->stream, m->view, INTEGRATE_MAX_GRID);
     HIP_TRY(hipMemcpyAsync(out, m->view.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, m->stream));
-    if (reset_counters) HIP_TRY(hipMemsetAsync(m->view.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(uint64_t), m->stream));
+    if (reset_counters)
+        HIP_TRY(hipMemsetAsync(m->view.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 16 * sizeof(unsigned long long), m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHISEL_HIP_OK;
 }

@@ -327,22 +327,48 @@ __global__ __launch_bounds__(Geom<N>::BLOCK) void integrate_kernel(FrameParams P
         }
     }
 
-    // ---- counters: wave reduction, one atomic per counter per wave --------------------------------
+    // ---- counters: block reduction in LDS, then a plain read-modify-write of this block's private row.
+    // (Same-address atomics run at ~90 per microsecond on this part: a few thousand of them per frame would
+    // cost more than the integration itself.  Rows are summed lazily by reduce_counters_kernel.)
+    __syncthreads();
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_tile);
+    if (tid < 8) s_cnt[tid] = 0;
+    __syncthreads();
     unsigned vals[5] = {tally.sdf, tally.col, tally.colsat, tally.probe, tally.carved};
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         unsigned v = vals[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if ((tid & 63) == 0 && v) atomicAdd(&M.counters[k], (unsigned long long)v);
+        if ((tid & 63) == 0 && v) atomicAdd(&s_cnt[k], v);  // LDS atomic, <= 4 per counter
     }
+    __syncthreads();
     if (tid == 0) {
-        if (n_new) atomicAdd(&M.counters[6], (unsigned long long)n_new);
-        if (n_updated) atomicAdd(&M.counters[7], (unsigned long long)n_updated);
+        unsigned long long *row = M.block_counters + (size_t)blockIdx.x * 16;
+        for (int k = 0; k < 5; k++) row[k] += s_cnt[k];
+        row[6] += n_new;
+        row[7] += n_updated;
         if (blockIdx.x == 0) {
-            atomicAdd(&M.counters[5], (unsigned long long)n_items);
-            atomicAdd(&M.counters[8], 1ull);
+            row[5] += (unsigned long long)n_items;
+            row[8] += 1ull;
         }
+    }
+}
+
+// sums the per-block rows into counters[] (CHISEL_HIP_NUM_COUNTERS = 9 entries); one block of 256 threads
+__global__ void reduce_counters_kernel(MapView M, int n_rows) {
+    __shared__ unsigned long long s[256];
+    for (int k = 0; k < 9; k++) {
+        unsigned long long v = 0;
+        for (int r = threadIdx.x; r < n_rows; r += 256) v += M.block_counters[(size_t)r * 16 + k];
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) M.counters[k] = s[0];
+        __syncthreads();
     }
 }
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel trace + PMC passes) into the summary committed under profiles/."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    return name.split("(")[0].replace("chisel_hip::", "").replace("void ", "")[:70]
+
+
+def main(out):
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, out))
+        rows = list(csv.DictReader(open(f)))
+        for r in rows[:12]:
+            print("  %-70s calls %7s  total %12s ns  avg %12s ns  pct %s" % (short(r.get("Name", "")), r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+    # our own per-kernel average from the trace (skipping nothing: includes warm-up frames)
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        agg = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        print("== kernel trace durations:", os.path.relpath(f, out))
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:12]:
+            v2 = sorted(v)
+            print("  %-70s n %6d  avg %9.2f us  p50 %9.2f us  p90 %9.2f us" % (k, len(v), sum(v) / len(v) / 1e3, v2[len(v2) // 2] / 1e3, v2[int(len(v2) * 0.9)] / 1e3))
+    for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
+            agg = defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == ctr:
+                    agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+            print("== %s per dispatch (counter units: KiB per rocprofv3 definition):" % ctr, os.path.relpath(f, out))
+            for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:12]:
+                print("  %-70s n %6d  avg %12.1f  total %14.1f" % (k, len(v), sum(v) / len(v), sum(v)))
+    for name in ("bench_plain.json", "bench_trace.json"):
+        p = os.path.join(out, name)
+        if os.path.exists(p):
+            print("== %s: %s" % (name, open(p).read().strip()[:3000]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
