@@ -4,7 +4,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libchisel_hip.so")
+# CHISEL_HIP_LIB selects a diagnostic build (e.g. libchisel_hip_stamps.so); the default is the product library
+_LIB = os.path.join(_HERE, os.environ.get("CHISEL_HIP_LIB", "libchisel_hip.so"))
 
 NUM_COUNTERS = 9
 COUNTER_NAMES = ["sdf", "col", "col_sat", "probe", "carved", "work_chunks", "new_chunks", "updated_chunks", "frames"]

@@ -11,6 +11,10 @@
 //   slot_dirty uint32[C]  "updated since the last mesh recompute" (Chisel.h:175-189 marks 27 neighbours
 //                         on the host; here the mark is per slot and the neighbourhood is expanded later)
 //   free_list int32 [C], free_top: stack of free slots
+// Invariant: every FREE slot holds default voxels (sdf 99999, weight 0, rgbw 0 -- DistVoxel.cpp:27-31,
+// ColorVoxel.cpp:27-31).  reset_map_kernel and remove_chunks_kernel restore it, so allocating a chunk
+// (ChunkManager::CreateChunk) writes nothing but the hash entry and integration writes only the
+// voxels that change.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,7 +24,7 @@ namespace chisel_hip {
 constexpr uint64_t KEY_EMPTY = ~0ull;
 constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
 constexpr int ID_BIAS = 1 << 20;  // chunk ids in [-2^20, 2^20)
-constexpr int INTEGRATE_MAX_GRID = 2048;  // 256 CUs x 8 workgroups
+constexpr int INTEGRATE_MAX_GRID = 4096;  // rows of per-workgroup counters (largest persistent grid)
 
 __host__ __device__ inline uint64_t pack_id(int x, int y, int z) {
     return (uint64_t)(uint32_t)(x + ID_BIAS) | ((uint64_t)(uint32_t)(y + ID_BIAS) << 21) |
@@ -63,6 +67,7 @@ struct MapView {
     unsigned long long *block_counters;  // [INTEGRATE_MAX_GRID][16] per-workgroup partial sums
     int *error_flag;         // != 0: pool / hash exhausted
     int max_chunks;
+    unsigned long long *stamps;  // diagnostic builds (-DCHISEL_STAMPS) only: [workgroup][8] s_memrealtime stamps
 };
 
 // depth min/max pyramid: level l (PYR_L0 <= l <= PYR_L1) has ceil(W/2^l) x ceil(H/2^l) texels of
@@ -82,40 +87,89 @@ struct CameraParams {
     int W, H;
 };
 
-struct FrameParams {
-    CameraParams cam;
-    const float *depth;
-    CameraParams ccam;       // colour camera (IntegrateColor only)
-    const uint8_t *color;
-    int color_channels;
-    // ProjectionIntegrator state
+// One launch set (pyramid -> cull -> integrate) handles up to KMAX frames, applied to every voxel in
+// frame order.  All per-frame constants travel in the kernel-argument segment (scalar loads).
+constexpr int KMAX = 8;
+
+// ProjectionIntegrator state + map constants, identical for every frame of a batch
+struct IntegratorParams {
     int trunc_kind;
     float trunc_param;
     float weight;
     int carving;
     float carving_dist;
-    // derived constants
     float res;               // Chunk::GetVoxelResolutionMeters
     float half_res;          // ChunkManager.cpp:52  (res * 0.5f)
     float diag;              // ProjectionIntegrator.h:58  2.0 * sqrt(3.0f) * res  (double, narrowed)
     float max_depth;         // 50 (Integrate :74) or 100 (IntegrateColor :141)
-    // reference candidate enumeration (ChunkManager.cpp:182-212): ids range_min .. range_min+range_dim-1
+    int n_shards, shard_rank, shard_block;
+};
+
+// pixel record of one depth pixel: x = depth reading (NaN when the reference skips the pixel: NaN depth,
+// depth > max_depth), y = truncator->GetTruncationDistance(depth).  Built once per frame by
+// depth_pyramid_kernel so the per-voxel loop does no truncator arithmetic.
+typedef float2 PixelRec;
+
+// per-frame arguments of the integration kernel
+struct FrameCam {
+    CameraParams cam;
+    CameraParams ccam;       // colour camera (IntegrateColor only)
+    const PixelRec *rec;     // W x H records of this frame
+    const uint8_t *color;
+    int color_channels;
+    int same_cam;            // colour camera == depth camera bit for bit: reuse the depth projection
+};
+struct IntegrateParams {
+    IntegratorParams ip;
+    int n_frames;
+    FrameCam f[KMAX];
+};
+
+// per-frame arguments of the cull kernel: the reference's candidate enumeration of that frame
+// (ChunkManager.cpp:182-212): ids range_min .. range_min+range_dim-1, and the six frustum planes
+struct CullFrame {
+    CameraParams cam;
     int range_min[3];
     int range_dim[3];
     float planes[24];        // far, near, top, bottom, left, right: normal xyz + distance (Frustum.cpp:43)
-    // sharding
-    int n_shards, shard_rank, shard_block;
+};
+struct CullParams {
+    IntegratorParams ip;
+    int n_frames;
+    int range_min[3];        // union of the frames' ranges: one thread per chunk id of it
+    int range_dim[3];
+    int pyr_stride;          // texels between two frames' pyramids
+    CullFrame f[KMAX];
+};
+
+// per-frame arguments of the pyramid / pixel-record kernel
+struct PyramidParams {
+    IntegratorParams ip;
+    int W, H;
+    int rec_stride;          // records between two frames
+    int pyr_stride;
+    PixelRec *rec;
+    const float *depth[KMAX];
 };
 
 struct WorkItem {
     int x, y, z;             // chunk id
-    int slot;                // pool slot, -1 = not resident (allocate if any voxel is updated)
+    int slot;                // pool slot, -1 = not resident (allocated if any voxel is integrated)
+    unsigned frame_mask;     // frames of the batch that may touch this chunk
+    int any_flags;           // OR of the frames' FrameBox flags
+    int pad[2];
+};
+struct FrameBox {            // one per (work item, frame)
     short u0, v0, u1, v1;    // conservative pixel bounding box of the chunk (inclusive), depth camera
     int flags;
+    unsigned magic;          // ceil(2^32 / (u1 - u0 + 1)): division by the tile width in the staging loop
+    // conservative camera-z bounds from the depth range under the box: a voxel can be in band only if
+    // z_near < z < z_far and can take the carve test only if z < z_carve (-inf when carving is off)
+    float z_near, z_far, z_carve;
     int pad;
 };
 constexpr int WI_INBAND = 1;   // some voxel may take the in-band branch
-constexpr int WI_CARVE = 2;    // some voxel of this resident chunk may take the carve test
+constexpr int WI_CARVE = 2;    // some voxel may take the carve test (only matters while the chunk is resident)
 constexpr int WI_TILE = 4;     // u0..v1 is a valid bounding box (else: gather from the whole image)
 
 // ---- strategy arithmetic (devirtualised Truncator / Weighter) -------------------------------------

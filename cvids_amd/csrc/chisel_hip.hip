@@ -62,18 +62,21 @@ struct chisel_hip_map {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     MapView view{};
+    MapView *view_dev = nullptr;  // device-resident copy of `view` (cold fields are read from here by the kernels)
     uint64_t hash_capacity = 0;
     chisel_hip_integrator integ{CHISEL_HIP_TRUNC_INVERSE, 8.0f, 1.0f, 1, 0.05f};  // ChiselNode.cpp:54-64 defaults
-    // per-frame device buffers
+    // per-batch device buffers (a batch = up to KMAX frames handled by one pyramid -> cull -> integrate launch set)
     WorkItem *items = nullptr;
+    FrameBox *boxes = nullptr;           // [items_capacity][KMAX]
     int items_capacity = 0;
     int *work_count = nullptr;
-    float2 *pyr_data = nullptr;
-    int pyr_w = 0, pyr_h = 0;
+    float2 *pyr_data = nullptr;          // [KMAX][pyr_stride]
+    PixelRec *rec_data = nullptr;        // [KMAX][W*H]
+    int pyr_w = 0, pyr_h = 0, pyr_stride = 0;
     PyramidView pyr{};
-    float *depth_stage = nullptr;
+    float *depth_stage = nullptr;        // [KMAX][depth_stage_elems]: host frames are copied here
     size_t depth_stage_elems = 0;
-    uint8_t *color_stage = nullptr;
+    uint8_t *color_stage = nullptr;      // [KMAX][color_stage_bytes]
     size_t color_stage_bytes = 0;
     // scratch for queries
     int *scratch_i = nullptr;   // device ints
@@ -82,6 +85,7 @@ struct chisel_hip_map {
     int update_meshes_calls = 0;                                       // Chisel.cpp:53 "static int cnt"
     std::unordered_map<uint64_t, HostMesh, IdHash> meshes;             // ChunkManager::allMeshes
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
+    int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
     MeshBuffers mesh_buf{};
     // profiling
     bool profiling = false;
@@ -170,7 +174,9 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
     if (m->pyr_data && m->pyr_w == W && m->pyr_h == H) return CHISEL_HIP_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (m->pyr_data) HIP_TRY(hipFree(m->pyr_data));
+    if (m->rec_data) HIP_TRY(hipFree(m->rec_data));
     m->pyr_data = nullptr;
+    m->rec_data = nullptr;
     int off = 0;
     for (int l = 0; l < PYR_LEVELS; l++) {
         int s = PYR_L0 + l;
@@ -179,7 +185,9 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
         m->pyr.off[l] = off;
         off += m->pyr.w[l] * m->pyr.h[l];
     }
-    HIP_TRY(hipMalloc(&m->pyr_data, (size_t)off * sizeof(float2)));
+    m->pyr_stride = off;
+    HIP_TRY(hipMalloc(&m->pyr_data, (size_t)off * KMAX * sizeof(float2)));
+    HIP_TRY(hipMalloc(&m->rec_data, (size_t)W * H * KMAX * sizeof(PixelRec)));
     m->pyr.data = m->pyr_data;
     m->pyr_w = W;
     m->pyr_h = H;
@@ -187,121 +195,193 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
 }
 
 template <int N>
-int launch_frame(chisel_hip_map *m, const FrameParams &P, bool color) {
+int launch_group(chisel_hip_map *m, const PyramidParams &PP, const CullParams &CP, const IntegrateParams &IP, bool color) {
     using G = Geom<N>;
-    const int total = P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
+    const int total = CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2];
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID);
-        dim3 grid((P.cam.W + 63) / 64, (P.cam.H + 63) / 64);
-        hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, m->stream, P.depth, P.cam.W, P.cam.H, P.max_depth,
-                           m->pyr, m->work_count);
+        dim3 grid((PP.W + 63) / 64, (PP.H + 63) / 64, IP.n_frames);
+        hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, m->stream, PP, m->pyr, m->work_count);
     }
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_CULL);
-        hipLaunchKernelGGL(cull_kernel<N>, dim3((total + 255) / 256), dim3(256), 0, m->stream, P, m->view, m->pyr, m->items,
-                           m->work_count, m->items_capacity);
+        hipLaunchKernelGGL(cull_kernel<N>, dim3((total + 255) / 256), dim3(256), 0, m->stream, CP, m->view, m->pyr, m->items,
+                           m->boxes, m->work_count, m->items_capacity);
     }
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
-        const int grid = std::max(1, std::min(total, INTEGRATE_MAX_GRID));
-        if (color)
-            hipLaunchKernelGGL((integrate_kernel<N, true>), dim3(grid), dim3(G::BLOCK), 0, m->stream, P, m->view, m->items,
-                               m->work_count, m->items_capacity);
+        const int grid = std::max(1, std::min(total, G::GRID));
+        bool same_cam = color;
+        for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
+        if (color && same_cam)  // CVIDS: depth and colour share one camera (sample.launch:19-20)
+            hipLaunchKernelGGL((integrate_kernel<N, true, true>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
+                               m->items, m->boxes, m->work_count, m->items_capacity);
+        else if (color)
+            hipLaunchKernelGGL((integrate_kernel<N, true, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
+                               m->items, m->boxes, m->work_count, m->items_capacity);
         else
-            hipLaunchKernelGGL((integrate_kernel<N, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, P, m->view, m->items,
-                               m->work_count, m->items_capacity);
+            hipLaunchKernelGGL((integrate_kernel<N, false, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
+                               m->items, m->boxes, m->work_count, m->items_capacity);
     }
     HIP_TRY(hipGetLastError());
     return CHISEL_HIP_OK;
 }
 
-int integrate_one(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
+int check_frame(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
     if (!f || !f->depth || f->width <= 0 || f->height <= 0) return fail(CHISEL_HIP_ERR_INVALID, "bad depth frame");
     if (f->width > 32767 || f->height > 32767) return fail(CHISEL_HIP_ERR_INVALID, "image larger than 32767 pixels per side");
     if (c && (!c->color || c->channels < 1 || c->channels > 4 || c->width <= 0 || c->height <= 0))
         return fail(CHISEL_HIP_ERR_INVALID, "bad colour frame");
     if (c && !m->cfg.use_color)
         return fail(CHISEL_HIP_ERR_INVALID, "map was created without colour voxels (Chunk::GetColorVoxelMutable would throw)");
+    return CHISEL_HIP_OK;
+}
+
+// n <= KMAX frames of one image size, all with or all without colour, in one launch set
+int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors) {
     HIP_TRY(hipSetDevice(m->device));
+    const int W = frames[0].width, H = frames[0].height;
+    const size_t npx = (size_t)W * H;
+    const bool color = colors != nullptr;
+    int rc = ensure_pyramid(m, W, H);
+    if (rc) return rc;
 
-    FrameParams P;
-    memset(&P, 0, sizeof(P));
-    fill_camera(P.cam, f->pose, f->fx, f->fy, f->cx, f->cy, f->width, f->height);
-    // depth image
-    const size_t npx = (size_t)f->width * f->height;
-    if (f->on_device) {
-        P.depth = f->depth;
-    } else {
-        if (npx > m->depth_stage_elems) {
-            HIP_TRY(hipStreamSynchronize(m->stream));
-            if (m->depth_stage) HIP_TRY(hipFree(m->depth_stage));
-            m->depth_stage = nullptr;
-            HIP_TRY(hipMalloc(&m->depth_stage, npx * sizeof(float)));
-            m->depth_stage_elems = npx;
+    PyramidParams PP;
+    CullParams CP;
+    IntegrateParams IP;
+    memset(&PP, 0, sizeof(PP));
+    memset(&CP, 0, sizeof(CP));
+    memset(&IP, 0, sizeof(IP));
+    IntegratorParams ip;
+    ip.trunc_kind = m->integ.truncator_kind;
+    ip.trunc_param = m->integ.truncator_param;
+    ip.weight = m->integ.weight;
+    ip.carving = m->integ.carving_enabled ? 1 : 0;
+    ip.carving_dist = m->integ.carving_dist;
+    ip.res = m->cfg.voxel_resolution;
+    ip.half_res = m->cfg.voxel_resolution * 0.5f;                                           // ChunkManager.cpp:52
+    ip.diag = (float)(2.0 * ::sqrt((double)3.0f) * (double)m->cfg.voxel_resolution);        // ProjectionIntegrator.h:58,109
+    ip.max_depth = color ? 100.0f : 50.0f;
+    ip.n_shards = m->cfg.n_shards;
+    ip.shard_rank = m->cfg.shard_rank;
+    ip.shard_block = m->cfg.shard_block;
+    PP.ip = CP.ip = IP.ip = ip;
+    PP.W = W;
+    PP.H = H;
+    PP.rec_stride = (int)npx;
+    PP.pyr_stride = m->pyr_stride;
+    PP.rec = m->rec_data;
+    CP.n_frames = IP.n_frames = n;
+    CP.pyr_stride = m->pyr_stride;
+
+    // host-resident images: grow the staging rings first (a reallocation must not race with queued copies)
+    bool any_host_depth = false, any_host_color = false;
+    size_t color_bytes = 0;
+    for (int k = 0; k < n; k++) {
+        any_host_depth |= !frames[k].on_device;
+        if (color) {
+            any_host_color |= !colors[k].on_device;
+            color_bytes = std::max(color_bytes, (size_t)colors[k].width * colors[k].height * colors[k].channels);
         }
-        HIP_TRY(hipMemcpyAsync(m->depth_stage, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, m->stream));
-        P.depth = m->depth_stage;
     }
-    if (c) {
-        fill_camera(P.ccam, c->pose, c->fx, c->fy, c->cx, c->cy, c->width, c->height);
-        P.color_channels = c->channels;
-        const size_t nb = (size_t)c->width * c->height * c->channels;
-        if (c->on_device) {
-            P.color = c->color;
+    if (any_host_depth && npx > m->depth_stage_elems) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (m->depth_stage) HIP_TRY(hipFree(m->depth_stage));
+        m->depth_stage = nullptr;
+        HIP_TRY(hipMalloc(&m->depth_stage, npx * KMAX * sizeof(float)));
+        m->depth_stage_elems = npx;
+    }
+    if (any_host_color && color_bytes > m->color_stage_bytes) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (m->color_stage) HIP_TRY(hipFree(m->color_stage));
+        m->color_stage = nullptr;
+        HIP_TRY(hipMalloc(&m->color_stage, color_bytes * KMAX));
+        m->color_stage_bytes = color_bytes;
+    }
+
+    int umin[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, umax[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (int k = 0; k < n; k++) {
+        const chisel_hip_depth_frame *f = &frames[k];
+        FrameCam &F = IP.f[k];
+        fill_camera(F.cam, f->pose, f->fx, f->fy, f->cx, f->cy, W, H);
+        CP.f[k].cam = F.cam;
+        if (f->on_device) {
+            PP.depth[k] = f->depth;
         } else {
-            if (nb > m->color_stage_bytes) {
-                HIP_TRY(hipStreamSynchronize(m->stream));
-                if (m->color_stage) HIP_TRY(hipFree(m->color_stage));
-                m->color_stage = nullptr;
-                HIP_TRY(hipMalloc(&m->color_stage, nb));
-                m->color_stage_bytes = nb;
-            }
-            HIP_TRY(hipMemcpyAsync(m->color_stage, c->color, nb, hipMemcpyHostToDevice, m->stream));
-            P.color = m->color_stage;
+            float *dst = m->depth_stage + (size_t)k * m->depth_stage_elems;
+            HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, m->stream));
+            PP.depth[k] = dst;
         }
+        F.rec = m->rec_data + (size_t)k * npx;
+        if (color) {
+            const chisel_hip_color_frame *c = &colors[k];
+            fill_camera(F.ccam, c->pose, c->fx, c->fy, c->cx, c->cy, c->width, c->height);
+            F.color_channels = c->channels;
+            F.same_cam = memcmp(&F.cam, &F.ccam, sizeof(CameraParams)) == 0 ? 1 : 0;
+            if (c->on_device) {
+                F.color = c->color;
+            } else {
+                uint8_t *dst = m->color_stage + (size_t)k * m->color_stage_bytes;
+                HIP_TRY(hipMemcpyAsync(dst, c->color, (size_t)c->width * c->height * c->channels, hipMemcpyHostToDevice, m->stream));
+                F.color = dst;
+            }
+        }
+        hostmath::FrustumRange fr = hostmath::frustum_range(f->pose, f->near_plane, f->far_plane, f->fy, f->cy, W, H, m->N,
+                                                            m->cfg.voxel_resolution);
+        for (int a = 0; a < 3; a++) {
+            CP.f[k].range_min[a] = fr.range_min[a];
+            CP.f[k].range_dim[a] = fr.range_dim[a];
+            if (fr.range_dim[a] <= 0 || fr.range_min[a] < -ID_BIAS + 2 || fr.range_min[a] + fr.range_dim[a] > ID_BIAS - 2)
+                return fail(CHISEL_HIP_ERR_INVALID, "frustum outside the addressable chunk-id range (pose not finite?)");
+            umin[a] = std::min(umin[a], fr.range_min[a]);
+            umax[a] = std::max(umax[a], fr.range_min[a] + fr.range_dim[a]);
+        }
+        memcpy(CP.f[k].planes, fr.planes, sizeof(fr.planes));
     }
-    P.trunc_kind = m->integ.truncator_kind;
-    P.trunc_param = m->integ.truncator_param;
-    P.weight = m->integ.weight;
-    P.carving = m->integ.carving_enabled ? 1 : 0;
-    P.carving_dist = m->integ.carving_dist;
-    P.res = m->cfg.voxel_resolution;
-    P.half_res = m->cfg.voxel_resolution * 0.5f;                                           // ChunkManager.cpp:52
-    P.diag = (float)(2.0 * ::sqrt((double)3.0f) * (double)m->cfg.voxel_resolution);        // ProjectionIntegrator.h:58,109
-    P.max_depth = c ? 100.0f : 50.0f;
-    hostmath::FrustumRange fr = hostmath::frustum_range(f->pose, f->near_plane, f->far_plane, f->fy, f->cy, f->width,
-                                                        f->height, m->N, m->cfg.voxel_resolution);
-    for (int k = 0; k < 3; k++) {
-        P.range_min[k] = fr.range_min[k];
-        P.range_dim[k] = fr.range_dim[k];
-        if (fr.range_dim[k] <= 0 || fr.range_min[k] < -ID_BIAS + 2 || fr.range_min[k] + fr.range_dim[k] > ID_BIAS - 2)
-            return fail(CHISEL_HIP_ERR_INVALID, "frustum outside the addressable chunk-id range (pose not finite?)");
+    double total_d = 1.0;
+    for (int a = 0; a < 3; a++) {
+        CP.range_min[a] = umin[a];
+        CP.range_dim[a] = umax[a] - umin[a];
+        total_d *= (double)CP.range_dim[a];
     }
-    memcpy(P.planes, fr.planes, sizeof(P.planes));
-    const double total_d = (double)P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
-    if (total_d > 2.0e8) return fail(CHISEL_HIP_ERR_INVALID, "frustum covers more than 2e8 chunks: far plane / resolution mismatch");
+    if (total_d > 2.0e8) return fail(CHISEL_HIP_ERR_INVALID, "frusta cover more than 2e8 chunks: far plane / resolution mismatch");
     const int total = (int)total_d;
-    P.n_shards = m->cfg.n_shards;
-    P.shard_rank = m->cfg.shard_rank;
-    P.shard_block = m->cfg.shard_block;
-
     if (total > m->items_capacity) {
         HIP_TRY(hipStreamSynchronize(m->stream));
         if (m->items) HIP_TRY(hipFree(m->items));
+        if (m->boxes) HIP_TRY(hipFree(m->boxes));
         m->items = nullptr;
+        m->boxes = nullptr;
         int cap = std::max(total, 4096);
         HIP_TRY(hipMalloc(&m->items, (size_t)cap * sizeof(WorkItem)));
+        HIP_TRY(hipMalloc(&m->boxes, (size_t)cap * KMAX * sizeof(FrameBox)));
         m->items_capacity = cap;
     }
-    int rc = ensure_pyramid(m, f->width, f->height);
-    if (rc) return rc;
-    const bool color = c != nullptr;
     switch (m->N) {
-        case 8: return launch_frame<8>(m, P, color);
-        case 16: return launch_frame<16>(m, P, color);
-        case 32: return launch_frame<32>(m, P, color);
+        case 8: return launch_group<8>(m, PP, CP, IP, color);
+        case 16: return launch_group<16>(m, PP, CP, IP, color);
+        case 32: return launch_group<32>(m, PP, CP, IP, color);
     }
     return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chunk size");
+}
+
+// frames in order; consecutive frames of equal image size are grouped KMAX at a time
+int integrate_frames(chisel_hip_map *m, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors,
+                     int max_group) {
+    for (int i = 0; i < n; i++) {
+        int rc = check_frame(m, &frames[i], colors ? &colors[i] : nullptr);
+        if (rc) return rc;
+    }
+    const int kmax = std::max(1, std::min(max_group, KMAX));
+    int i = 0;
+    while (i < n) {
+        int g = 1;
+        while (i + g < n && g < kmax && frames[i + g].width == frames[i].width && frames[i + g].height == frames[i].height) g++;
+        int rc = integrate_group(m, g, frames + i, colors ? colors + i : nullptr);
+        if (rc) return rc;
+        i += g;
+    }
+    return CHISEL_HIP_OK;
 }
 
 // ids of dirty slots -> host vector (packed keys)
@@ -445,7 +525,9 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&m->work_count, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMemsetAsync(m->work_count, 0, sizeof(int), m->stream));
-    hipLaunchKernelGGL(reset_map_kernel, dim3(1024), dim3(256), 0, m->stream, m->view);
+    HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));
+    HIP_TRY_C(hipMemcpyAsync(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
     HIP_TRY_C(hipGetLastError());
     HIP_TRY_C(hipStreamSynchronize(m->stream));
 #undef HIP_TRY_C
@@ -459,7 +541,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.block_counters, v.error_flag, m->work_count, m->items, m->pyr_data, m->depth_stage, m->color_stage,
+                    v.counters, v.block_counters, v.error_flag, v.stamps, m->view_dev, m->work_count, m->items, m->boxes, m->pyr_data, m->rec_data, m->depth_stage, m->color_stage,
                     m->scratch_i};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -477,7 +559,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
 int chisel_hip_reset(chisel_hip_map *m) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
-    hipLaunchKernelGGL(reset_map_kernel, dim3(1024), dim3(256), 0, m->stream, m->view);
+    hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
     HIP_TRY(hipGetLastError());
     m->meshes.clear();
     m->pending_mesh_ids.clear();
@@ -506,23 +588,18 @@ int chisel_hip_synchronize(chisel_hip_map *m) {
 
 int chisel_hip_integrate_depth(chisel_hip_map *m, const chisel_hip_depth_frame *f) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
-    return integrate_one(m, f, nullptr);
+    return integrate_frames(m, 1, f, nullptr, 1);
 }
 
 int chisel_hip_integrate_depth_color(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
     if (!m || !c) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
-    return integrate_one(m, f, c);
+    return integrate_frames(m, 1, f, c, 1);
 }
 
 int chisel_hip_integrate_batch(chisel_hip_map *m, int n, const chisel_hip_depth_frame *frames,
                                const chisel_hip_color_frame *colors) {
     if (!m || n < 0 || (n > 0 && !frames)) return fail(CHISEL_HIP_ERR_INVALID, "bad batch");
-    for (int i = 0; i < n; i++) {
-        // host-resident images share one staging buffer: the copy of frame i+1 is stream-ordered after frame i's kernels
-        int rc = integrate_one(m, &frames[i], colors ? &colors[i] : nullptr);
-        if (rc) return rc;
-    }
-    return CHISEL_HIP_OK;
+    return integrate_frames(m, n, frames, colors, m->batch_frames);
 }
 
 int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
@@ -548,7 +625,7 @@ int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
     int *d_cnt = m->scratch_i, *d_ids = m->scratch_i + 16;
     HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), m->stream));
     HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(remove_chunks_kernel, dim3((n + 255) / 256), dim3(256), 0, m->stream, m->view, d_ids, n, d_cnt);
+    hipLaunchKernelGGL(remove_chunks_kernel, dim3(n), dim3(256), 0, m->stream, m->view, d_ids, n, d_cnt, m->V);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHISEL_HIP_OK;
@@ -713,6 +790,23 @@ int chisel_hip_kat_color(const uint8_t *ops, int n, uint8_t *out) {
     hipLaunchKernelGGL(kat_color_kernel, dim3(1), dim3(64), 0, 0, d_in, n, d_out);
     HIP_TRY(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(d_in); (void)hipFree(d_out);
+    return CHISEL_HIP_OK;
+}
+// diagnostic builds (-DCHISEL_STAMPS): allocate / read back the per-workgroup stamp buffer of integrate_kernel
+int chisel_hip_debug_stamps(chisel_hip_map *m, unsigned long long *out, int n_groups) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const size_t bytes = (size_t)INTEGRATE_MAX_GRID * 8 * sizeof(unsigned long long);
+    if (!m->view.stamps) {
+        HIP_TRY(hipMalloc(&m->view.stamps, bytes));
+        HIP_TRY(hipMemset(m->view.stamps, 0, bytes));
+        HIP_TRY(hipMemcpy(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice));
+    }
+    if (out) {
+        HIP_TRY(hipMemcpy(out, m->view.stamps, (size_t)std::min(n_groups, INTEGRATE_MAX_GRID) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(m->view.stamps, 0, bytes));
+    }
     return CHISEL_HIP_OK;
 }
 // host-side frustum arithmetic of the product (host_frustum.h), for CPU-only tests against the oracle

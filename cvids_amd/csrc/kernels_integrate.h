@@ -3,17 +3,25 @@
 // Replaces ProjectionIntegrator::Integrate<float> (ProjectionIntegrator.h:51-99) and
 // ::IntegrateColor<float,uint8_t> (:101-183) plus the allocate-everything / erase-untouched protocol of
 // Chisel::IntegrateDepthScan[Color] (Chisel.h:77-108, 133-143, 202-207):
-//   - one workgroup per work-list chunk (grid-stride over the device-resident list, no host round trip);
-//   - a lane owns 4 consecutive x voxels, so every voxel-plane access of a wave is one contiguous
-//     1 KiB segment (float4 per lane) and sdf/weight/colour are only read for quads that can change
-//     and only written for quads that did change;
-//   - the depth pixels under the chunk are staged once in LDS (the chunk's conservative pixel box
-//     from the cull kernel) and gathered from there; boxes too large for the tile buffer fall back
-//     to gathers from global memory (near-camera chunks);
-//   - a chunk that is not resident is first classified without touching memory; only if some voxel
-//     is updated does thread 0 pop a pool slot and insert the id into the hash, and the chunk is
-//     then written in full -- the outcome of the reference's "create, integrate, erase if untouched"
-//     without ever allocating the ~98 % of candidates that stay untouched;
+//   - one workgroup per work-list chunk (persistent grid, grid-stride over the device-resident list,
+//     no host round trip);
+//   - a lane owns quads of 4 consecutive x voxels, so every voxel-plane access of a wave is one
+//     contiguous 1 KiB segment (float4 per lane); sdf/weight/colour are read only for quads whose
+//     camera-z interval can meet the depth band or the carve region of the pixels under the chunk
+//     (bounds from the cull kernel; the reads are issued before the tile is staged so both overlap)
+//     and written only for quads that did change;
+//   - the pixel records (depth, truncation distance: built once per frame by depth_pyramid_kernel) under
+//     the chunk are staged in LDS (the chunk's conservative pixel box from the cull kernel) and
+//     gathered from there; boxes too large for the tile buffer fall back to gathers from global
+//     memory (near-camera chunks);
+//   - a launch applies up to KMAX frames: for chunks of <= 4096 voxels the voxel state stays in
+//     registers from its first use to the end of the batch (read once, written once, frames applied in
+//     order per voxel -- DistVoxel::Integrate is order dependent); 32^3 chunks are streamed slab by
+//     slab per frame;
+//   - a chunk that is not resident is allocated (thread 0 pops a pool slot and inserts the id into the
+//     hash) only once some voxel of it is integrated: the outcome of the reference's "create,
+//     integrate, erase if untouched" without ever allocating the ~98 % of candidates that stay
+//     untouched.  Free slots hold default voxels, so nothing else needs writing;
 //   - per-voxel arithmetic follows the reference operation by operation in fp32 (compiled with
 //     -ffp-contract=off, IEEE divide), 3-term sums in Eigen's a0 + (a1 + a2) order.
 #pragma once
@@ -21,338 +29,500 @@
 
 namespace chisel_hip {
 
-constexpr int TILE_MAX_PIXELS = 4096;  // 16 KiB depth tile in LDS per workgroup
+#ifndef INTEGRATE_MIN_WAVES
+#define INTEGRATE_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for (1 = no constraint)
+#endif
+#ifndef INTEGRATE_QPT
+#define INTEGRATE_QPT 4        // quads (of 4 voxels) per thread; 1024 / QPT threads per 16^3 chunk
+#endif
 
 struct Tally {
     unsigned sdf, col, colsat, probe, carved;
 };
 
 struct TileCtx {
-    const float *tile;   // LDS
-    int u0, v0, tw, th;  // tile origin / size; tw == 0: no tile
+    const PixelRec *rec;   // the frame's full record image (global)
+    int u0, v0, tw, th;    // origin / size of the box staged in LDS; tw == 0: nothing staged
+    // camera-z bounds from the cull kernel (conservative): a voxel can be in band only if z_near < z < z_far and
+    // can take the carve test only if z < z_carve
+    float z_near, z_far, z_carve;
 };
-
-// classification of one voxel against the depth image: 0 = untouched, 1 = in band, 2 = carve test
-// Out: sd (surfaceDist), wu (weight update), cpix (colour pixel index or -1)
-template <bool COLOR>
-__device__ inline int classify_voxel(const FrameParams &P, const TileCtx &T, float pcx, float pcy, float pcz, float vx,
-                                     float vy, float vz, float &sd, float &wu, int &cpix) {
-    const CameraParams &C = P.cam;
-    // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45)
-    const float invZ = 1.0f / pcz;
-    const float u = C.fx * pcx * invZ + C.cx;
-    const float v = C.fy * pcy * invZ + C.cy;
-    // IsPointOnImage (PinholeCamera.cpp:61-64) || z < 0 (ProjectionIntegrator.h:68 / :126)
-    const bool on = (u >= 0.0f) && (v >= 0.0f) && (u < (float)C.W) && (v < (float)C.H) && !(pcz < 0.0f);
-    cpix = -1;
-    sd = 0.0f;
-    wu = 1.0f;
-    if (!on) return 0;
-    const int iu = (int)u, iv = (int)v;  // truncating lookup (:72 / :131)
-    float depth;
-    const int tu = iu - T.u0, tv = iv - T.v0;
-    if ((unsigned)tu < (unsigned)T.tw && (unsigned)tv < (unsigned)T.th) {
-        depth = T.tile[tv * T.tw + tu];
-    } else {
-        depth = P.depth[(size_t)iv * C.W + iu];  // DepthAt(row, col) DepthImage.h:72-76
-    }
-    if (COLOR) {
-        if (depth != depth) return 0;  // :134
-    } else {
-        if (depth > 50.0f) return 0;  // :74
-    }
-    const float truncation = truncation_distance(P.trunc_kind, P.trunc_param, depth);
-    const float surfaceDist = depth - pcz;
-    if (COLOR) {
-        if (depth > 100.0f) return 0;  // :141
-    }
-    sd = surfaceDist;
-    if (fabsf(surfaceDist) < truncation + P.diag) {
-        if (COLOR) {
-            // colour camera projection (:146-147); voxel centre (vx,vy,vz) is in world coordinates
-            const CameraParams &K = P.ccam;
-            const float dx = vx - K.t[0], dy = vy - K.t[1], dz = vz - K.t[2];
-            const float qx = K.R[0] * dx + (K.R[3] * dy + K.R[6] * dz);
-            const float qy = K.R[1] * dx + (K.R[4] * dy + K.R[7] * dz);
-            const float qz = K.R[2] * dx + (K.R[5] * dy + K.R[8] * dz);
-            const float iq = 1.0f / qz;
-            const float cu = K.fx * qx * iq + K.cx;
-            const float cv = K.fy * qy * iq + K.cy;
-            if ((cu >= 0.0f) && (cv >= 0.0f) && (cu < (float)K.W) && (cv < (float)K.H)) cpix = (int)cv * K.W + (int)cu;
-            wu = constant_weight(P.weight, truncation);  // :161-162
-        }
-        return 1;
-    }
-    if (P.carving && surfaceDist > truncation + P.carving_dist) return 2;
-    return 0;
-}
 
 template <int N>
 struct Geom {
     static constexpr int V = N * N * N;
-    static constexpr int QX = N / 4;              // quads per x-row
+    static constexpr int QX = N / 4;                                   // quads per x-row
     static constexpr int QUADS = V / 4;
-    static constexpr int BLOCK = (QUADS < 256) ? QUADS : 256;
-    static constexpr int PASSES = QUADS / BLOCK;
-    static constexpr int PPI = (PASSES < 4) ? PASSES : 4;  // passes in flight per iteration
-    static constexpr int ITERS = PASSES / PPI;
+    static constexpr int LAYER_QUADS = QX * N;                         // quads per z-layer
+    static constexpr int SLAB_QUADS = (N == 8) ? 128 : 1024;           // quads a workgroup holds at a time
+    static constexpr int QPT = (N == 8 && INTEGRATE_QPT > 2) ? 2 : INTEGRATE_QPT;  // quads per thread: same x, y, different z
+    static constexpr int BLOCK = SLAB_QUADS / QPT;
+    static constexpr int PASSES = QUADS / SLAB_QUADS;                  // 1 (8^3, 16^3) or 8 (32^3)
+    static constexpr int TILE_PIXELS = (N == 8) ? 1024 : 4096;         // record tile in LDS per workgroup (8 / 32 KiB)
+    static constexpr int GRID = (N == 8) ? 4096 : ((BLOCK > 512) ? 512 : 1024);  // persistent grid: about what fits the chip at once
+    static_assert(BLOCK % LAYER_QUADS == 0, "a thread's quads must share x and y");
+    static_assert(GRID <= INTEGRATE_MAX_GRID, "per-workgroup counter rows");
 };
 
-// camera-space position of the 4 voxels of quad q, exactly as the reference computes it:
-//   voxelCenter = centroids[i] + origin            (ChunkManager.cpp:61: Vec3(x,y,z)*res + half; ProjectionIntegrator.h:63)
-//   inCamera    = R^T * (voxelCenter - t)          (:64), row i of R^T summed as a0 + (a1 + a2)
+// colour-camera pixel of a voxel centre given in world coordinates (ProjectionIntegrator.h:146-149); -1 = off the image
+__device__ inline int color_pixel(const CameraParams &K, float vx, float vy, float vz) {
+    const float dx = vx - K.t[0], dy = vy - K.t[1], dz = vz - K.t[2];
+    const float qx = K.R[0] * dx + (K.R[3] * dy + K.R[6] * dz);
+    const float qy = K.R[1] * dx + (K.R[4] * dy + K.R[7] * dz);
+    const float qz = K.R[2] * dx + (K.R[5] * dy + K.R[8] * dz);
+    const float iq = 1.0f / qz;
+    const float cu = K.fx * qx * iq + K.cx;
+    const float cv = K.fy * qy * iq + K.cy;
+    if ((cu >= 0.0f) && (cv >= 0.0f) && (cu < (float)K.W) && (cv < (float)K.H)) return (int)cv * K.W + (int)cu;
+    return -1;
+}
+
+// voxel state a thread holds in registers: QPT quads at the same (x, y) in different z-layers
+template <int QPT>
+struct ThreadState {
+    float wx[4], wy;          // world coordinates of the voxel centres shared by the thread's quads
+    float wz[QPT];
+    float s[QPT][4], w[QPT][4];
+    unsigned c[QPT][4];
+    unsigned have, havec;     // bit p: sdf/weight (colour) of quad p hold the chunk's values (read, or defaults of a new chunk)
+    unsigned dchg, cchg;      // bit p: sdf/weight (colour) of quad p differ from memory
+};
+
+// voxelCenter = centroids[i] + origin (ChunkManager.cpp:61: Vec3(x,y,z)*res + half; ProjectionIntegrator.h:63)
 template <int N>
-__device__ inline void quad_geometry(const FrameParams &P, float ox, float oy, float oz, int q, float (&pcx)[4],
-                                     float (&pcy)[4], float (&pcz)[4], float (&wx)[4], float &wy, float &wz) {
+__device__ inline void thread_place(const IntegratorParams &ip, float ox, float oy, float oz, int q0, ThreadState<Geom<N>::QPT> &S) {
     using G = Geom<N>;
-    const CameraParams &C = P.cam;
-    const int xq = q % G::QX, y = (q / G::QX) % N, z = q / (G::QX * N);
-    wy = ((float)y * P.res + P.half_res) + oy;
-    wz = ((float)z * P.res + P.half_res) + oz;
-    const float dy = wy - C.t[1], dz = wz - C.t[2];
-    const float s0 = C.R[3] * dy + C.R[6] * dz;
-    const float s1 = C.R[4] * dy + C.R[7] * dz;
-    const float s2 = C.R[5] * dy + C.R[8] * dz;
+    const int xq = q0 % G::QX, y = (q0 / G::QX) % N, z0 = q0 / G::LAYER_QUADS;
+    S.wy = ((float)y * ip.res + ip.half_res) + oy;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int x = xq * 4 + j;
-        wx[j] = ((float)x * P.res + P.half_res) + ox;
-        const float dx = wx[j] - C.t[0];
-        pcx[j] = C.R[0] * dx + s0;
-        pcy[j] = C.R[1] * dx + s1;
-        pcz[j] = C.R[2] * dx + s2;
-    }
+    for (int j = 0; j < 4; j++) S.wx[j] = ((float)(xq * 4 + j) * ip.res + ip.half_res) + ox;
+#pragma unroll
+    for (int p = 0; p < G::QPT; p++) S.wz[p] = ((float)(z0 + p * (G::BLOCK / G::LAYER_QUADS)) * ip.res + ip.half_res) + oz;
+}
+
+// default voxels: DistVoxel() DistVoxel.cpp:27-31, ColorVoxel() ColorVoxel.cpp:27-31
+template <int QPT>
+__device__ inline void thread_defaults(ThreadState<QPT> &S, bool existed) {
+#pragma unroll
+    for (int p = 0; p < QPT; p++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            S.s[p][j] = 99999.0f;
+            S.w[p][j] = 0.0f;
+            S.c[p][j] = 0u;
+        }
+    S.have = S.havec = existed ? 0u : ~0u;  // a chunk without a slot has default voxels: nothing to read
+    S.dchg = S.cchg = 0u;
 }
 
 template <int N, bool COLOR>
-__global__ __launch_bounds__(Geom<N>::BLOCK) void integrate_kernel(FrameParams P, MapView M, const WorkItem *items,
-                                                                    const int *work_count, int max_items) {
+__device__ inline void thread_store(const ThreadState<Geom<N>::QPT> &S, float *sdf_base, float *wgt_base, uchar4 *col_base, int q0) {
     using G = Geom<N>;
-    __shared__ float s_tile[TILE_MAX_PIXELS];
-    __shared__ int s_flag[2];
+#pragma unroll
+    for (int p = 0; p < G::QPT; p++) {
+        const int q = q0 + p * G::BLOCK;
+        if (S.dchg & (1u << p)) {
+            *reinterpret_cast<float4 *>(sdf_base + 4 * q) = make_float4(S.s[p][0], S.s[p][1], S.s[p][2], S.s[p][3]);
+            *reinterpret_cast<float4 *>(wgt_base + 4 * q) = make_float4(S.w[p][0], S.w[p][1], S.w[p][2], S.w[p][3]);
+        }
+        if (COLOR && (S.cchg & (1u << p)))
+            *reinterpret_cast<uint4 *>(col_base + 4 * q) = make_uint4(S.c[p][0], S.c[p][1], S.c[p][2], S.c[p][3]);
+    }
+}
+
+// Step 1 of a frame, before the tile is staged: camera z of the thread's voxels (three additions, no
+// division) against the depth interval of the pixels under the chunk.  Sets bit p of `need` when quad p can be
+// touched by this frame and issues the reads of its state if the registers do not hold it yet, so that the
+// voxel traffic overlaps the staging of the tile.
+template <int N, bool COLOR>
+__device__ inline unsigned prefetch_frame(const FrameCam &F, const TileCtx &T, ThreadState<Geom<N>::QPT> &S, const float *sdf_base,
+                                          const float *wgt_base, const uchar4 *col_base, int q0) {
+    using G = Geom<N>;
+    const CameraParams &C = F.cam;
+    const float ay2 = C.R[5] * (S.wy - C.t[1]);
+    float ax2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ax2[j] = C.R[2] * (S.wx[j] - C.t[0]);
+    unsigned need = 0;
+#pragma unroll
+    for (int p = 0; p < G::QPT; p++) {
+        const float s2 = ay2 + C.R[8] * (S.wz[p] - C.t[2]);
+        const float z0 = ax2[0] + s2, z1 = ax2[1] + s2, z2 = ax2[2] + s2, z3 = ax2[3] + s2;
+        const float zlo = fminf(fminf(z0, z1), fminf(z2, z3));
+        const float zhi = fmaxf(fmaxf(z0, z1), fmaxf(z2, z3));
+        const bool may_band = (zhi > T.z_near) & (zlo < T.z_far);
+        const bool may_carve = zlo < T.z_carve;
+        if (may_band | may_carve) {
+            need |= 1u << p;
+            const int q = q0 + p * G::BLOCK;
+            if (!(S.have & (1u << p))) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(sdf_base + 4 * q);
+                const float4 w4 = *reinterpret_cast<const float4 *>(wgt_base + 4 * q);
+                S.s[p][0] = s4.x; S.s[p][1] = s4.y; S.s[p][2] = s4.z; S.s[p][3] = s4.w;
+                S.w[p][0] = w4.x; S.w[p][1] = w4.y; S.w[p][2] = w4.z; S.w[p][3] = w4.w;
+                S.have |= 1u << p;
+            }
+            if (COLOR && may_band && !(S.havec & (1u << p))) {
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(col_base + 4 * q);
+                S.c[p][0] = c4.x; S.c[p][1] = c4.y; S.c[p][2] = c4.z; S.c[p][3] = c4.w;
+                S.havec |= 1u << p;
+            }
+        }
+    }
+    return need;
+}
+
+// Step 2 of a frame, after the tile is staged: apply the frame to the quads of `need`.  `resident`: the
+// reference's map holds the chunk before this frame (only the probe counter depends on it).  Returns bit 0:
+// some voxel integrated (in band), bit 1: something changed (the reference's `updated`).
+//
+// Per quad the four voxels are classified branch-free so that their dependency chains (IEEE reciprocal ->
+// pixel -> LDS record -> band tests) overlap; the update is predicated per quad, not per voxel.
+template <int N, bool COLOR, bool SAMECAM>
+__device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F, const TileCtx &T, const PixelRec *s_tile,
+                                  unsigned need, bool resident, ThreadState<Geom<N>::QPT> &S, Tally &tally) {
+    using G = Geom<N>;
+    const CameraParams &C = F.cam;
+    // inCamera = R^T * (voxelCenter - t) (ProjectionIntegrator.h:64), row i of R^T summed as a0 + (a1 + a2);
+    // the products that do not depend on z are shared by the thread's quads
+    const float dy = S.wy - C.t[1];
+    const float ay0 = C.R[3] * dy, ay1 = C.R[4] * dy, ay2 = C.R[5] * dy;
+    float ax0[4], ax1[4], ax2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float dx = S.wx[j] - C.t[0];
+        ax0[j] = C.R[0] * dx;
+        ax1[j] = C.R[1] * dx;
+        ax2[j] = C.R[2] * dx;
+    }
+    int ret = 0;
+#pragma unroll
+    for (int p = 0; p < G::QPT; p++) {
+        if (!(need & (1u << p))) continue;
+        const float dz = S.wz[p] - C.t[2];
+        const float s0 = ay0 + C.R[6] * dz;
+        const float s1 = ay1 + C.R[7] * dz;
+        const float s2 = ay2 + C.R[8] * dz;
+        bool on[4], band[4], carve[4];
+        int iu[4], iv[4], tidx[4];
+        float pcz[4];
+        bool any_out = false;
+        PixelRec r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float pcx = ax0[j] + s0, pcy = ax1[j] + s1;
+            pcz[j] = ax2[j] + s2;
+            // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45)
+            const float invZ = 1.0f / pcz[j];
+            const float u = C.fx * pcx * invZ + C.cx;
+            const float v = C.fy * pcy * invZ + C.cy;
+            // IsPointOnImage (PinholeCamera.cpp:61-64): 0 <= u < W && 0 <= v < H, and not z < 0 (ProjectionIntegrator.h:68 /
+            // :126).  z == +-0 or NaN gives u, v = +-inf / NaN, which fail the image test, so "z > 0" is the same
+            // predicate; for u not NaN, floor(u) in [0, W) <=> 0 <= u < W, and there floor(u) == (int)u (:72 / :131).
+            iu[j] = (int)floorf(u);
+            iv[j] = (int)floorf(v);
+            on[j] = (pcz[j] > 0.0f) & ((unsigned)iu[j] < (unsigned)C.W) & ((unsigned)iv[j] < (unsigned)C.H) & (u == u) & (v == v);
+            const int tu = iu[j] - T.u0, tv = iv[j] - T.v0;
+            const bool in_tile = ((unsigned)tu < (unsigned)T.tw) & ((unsigned)tv < (unsigned)T.th);
+            tidx[j] = in_tile ? tv * T.tw + tu : 0;
+            any_out |= on[j] & !in_tile;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = s_tile[tidx[j]];
+        // pixels outside the staged box (no box: near-camera chunks; otherwise never, the box is conservative)
+        if (any_out) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int tu = iu[j] - T.u0, tv = iv[j] - T.v0;
+                const bool in_tile = ((unsigned)tu < (unsigned)T.tw) & ((unsigned)tv < (unsigned)T.th);
+                if (on[j] & !in_tile) r[j] = T.rec[iv[j] * C.W + iu[j]];  // DepthAt(row, col) DepthImage.h:72-76
+            }
+        }
+        float sd[4];
+        bool any_band = false, any_carve = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail
+            sd[j] = r[j].x - pcz[j];                                                                 // surfaceDist :79 / :139
+            band[j] = on[j] & (fabsf(sd[j]) < r[j].y + ip.diag);                                     // :81 / :144
+            carve[j] = on[j] & !band[j] & (ip.carving != 0) & (sd[j] > r[j].y + ip.carving_dist);    // :86 / :164
+            any_band |= band[j];
+            any_carve |= carve[j];
+            tally.sdf += band[j];
+            tally.probe += carve[j] & resident;
+        }
+        if (any_band) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float wu = 1.0f;                                      // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84
+                if (COLOR) wu = constant_weight(ip.weight, r[j].y);  // IntegrateColor: weighter->GetWeight(.., truncation) :161-162
+                float ns = S.s[p][j], nw = S.w[p][j];
+                dist_integrate(ns, nw, sd[j], wu);
+                S.s[p][j] = band[j] ? ns : S.s[p][j];
+                S.w[p][j] = band[j] ? nw : S.w[p][j];
+            }
+            S.dchg |= 1u << p;
+            ret |= 3;
+            if (COLOR) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int cpix = SAMECAM ? (iv[j] * C.W + iu[j]) : (band[j] ? color_pixel(F.ccam, S.wx[j], S.wy, S.wz[p]) : -1);
+                    const bool has = band[j] & (cpix >= 0);
+                    const bool fresh_col = has & ((S.c[p][j] >> 24) < 8u);  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
+                    tally.colsat += has & !fresh_col;
+                    tally.col += fresh_col;
+                    if (fresh_col) {
+                        uchar4 cv = *reinterpret_cast<uchar4 *>(&S.c[p][j]);
+                        uint8_t cr, cg, cb;
+                        color_at(F.color, cpix, F.color_channels, cr, cg, cb);
+                        cv = color_integrate(cv, cr, cg, cb, 1);
+                        S.c[p][j] = *reinterpret_cast<unsigned *>(&cv);
+                        S.cchg |= 1u << p;
+                    }
+                }
+            }
+        }
+        if (any_carve) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool hit = carve[j] & (S.w[p][j] > 0.0f) & sdf_below_carve_threshold(S.s[p][j]);
+                tally.carved += hit;
+                if (hit) {
+                    if (COLOR && !(S.w[p][j] < 5.0f)) {  // :166-177: decay
+                        S.w[p][j] = S.w[p][j] - 1.0f;
+                    } else {                            // :88-95 / :170 Carve() == Reset()
+                        S.s[p][j] = 99999.0f;
+                        S.w[p][j] = 0.0f;
+                    }
+                    S.dchg |= 1u << p;
+                    ret |= 2;
+                }
+            }
+        }
+    }
+    return ret;
+}
+
+// ChunkManager::CreateChunk (ChunkManager.cpp:171-174) on the device; one thread.  Returns the slot or -1.
+// Takes the MapView from device memory so that its hash / free-list pointers do not occupy scalar registers
+// in the integration loop.
+__device__ __attribute__((noinline)) int create_chunk(const MapView *__restrict__ Mc, int x, int y, int z) {
+    const MapView M = *Mc;
+    int s = -1;
+    const int top = atomicSub(M.free_top, 1) - 1;
+    if (top < 0) {
+        atomicAdd(M.free_top, 1);
+        atomicExch(M.error_flag, 1);
+        return -1;
+    }
+    s = M.free_list[top];
+    const uint64_t key = pack_id(x, y, z);
+    const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+    for (uint64_t i = 0; i <= M.hash_mask; i++) {
+        const uint64_t idx = (h + i) & M.hash_mask;
+        const uint64_t cur = M.hash_keys[idx];
+        if (cur == KEY_EMPTY || cur == KEY_TOMB) {
+            if (atomicCAS((unsigned long long *)&M.hash_keys[idx], (unsigned long long)cur, (unsigned long long)key) == cur) {
+                M.hash_vals[idx] = s;
+                M.slot_key[s] = key;
+                return s;
+            }
+        }
+    }
+    atomicExch(M.error_flag, 2);
+    return -1;
+}
+
+// stage the pixel records of box (u0, v0, tw x th) of `rec` (row stride W) into LDS, 4 loads in flight per lane;
+// magic = ceil(2^32 / tw): row = floor(idx / tw) for idx < 2^16
+template <int BLOCK>
+__device__ inline void stage_tile(PixelRec *s_tile, const PixelRec *__restrict__ rec, int W, int u0, int v0, int tw, int npx,
+                                  unsigned magic, int tid) {
+    const PixelRec *src = rec + (size_t)v0 * W + u0;
+    for (int base = 0; base < npx; base += 4 * BLOCK) {
+        PixelRec v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = base + i * BLOCK + tid;
+            if (idx < npx) {
+                const int row = (int)__umulhi((unsigned)idx, magic);
+                v[i] = src[row * W + (idx - row * tw)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = base + i * BLOCK + tid;
+            if (idx < npx) s_tile[idx] = v[i];
+        }
+    }
+}
+
+template <int N, bool COLOR, bool SAMECAM>
+__global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate_kernel(IntegrateParams P, MapView M,
+                                                                                         const MapView *__restrict__ Mc,
+                                                                                         const WorkItem *__restrict__ items,
+                                                                                         const FrameBox *__restrict__ boxes,
+                                                                                         const int *__restrict__ work_count,
+                                                                                         int max_items) {
+    using G = Geom<N>;
+    __shared__ PixelRec s_tile[G::TILE_PIXELS];
+    __shared__ int s_flags[4];  // [2 * parity + 0]: a voxel was integrated this frame, [+1]: something changed this frame
     __shared__ int s_slot;
     const int tid = threadIdx.x;
+#ifdef CHISEL_STAMPS
+#define STAMP(i) do { if (tid == 0 && M.stamps) M.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+    STAMP(0);
+#ifdef CHISEL_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
     int n_items = *work_count;
     if (n_items > max_items) n_items = max_items;
+    STAMP(1);
+    if ((int)blockIdx.x >= n_items && blockIdx.x != 0) return;  // nothing to do, nothing to count (block 0 counts the frames)
     Tally tally = {0, 0, 0, 0, 0};
     unsigned n_new = 0, n_updated = 0;
+    const IntegratorParams &ip = P.ip;
 
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
         const WorkItem wi = items[it];
+        if (it == (int)blockIdx.x) STAMP(2);
+        const int cxi = __builtin_amdgcn_readfirstlane(wi.x), cyi = __builtin_amdgcn_readfirstlane(wi.y),
+                  czi = __builtin_amdgcn_readfirstlane(wi.z);
+        int slot = __builtin_amdgcn_readfirstlane(wi.slot);
+        unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
         // Chunk origin (Chunk.cpp:43): numVoxels * ID (int) * resolution
-        const float ox = (float)(N * wi.x) * P.res, oy = (float)(N * wi.y) * P.res, oz = (float)(N * wi.z) * P.res;
-        __syncthreads();  // previous item's tile / flags fully consumed
-        if (tid < 2) s_flag[tid] = 0;
-        // ---- stage the depth pixels under the chunk in LDS -------------------------------------
-        TileCtx T;
-        T.tile = s_tile;
-        T.u0 = wi.u0;
-        T.v0 = wi.v0;
-        T.tw = 0;
-        T.th = 0;
-        if (wi.flags & WI_TILE) {
-            const int tw = wi.u1 - wi.u0 + 1, th = wi.v1 - wi.v0 + 1;
-            if (tw * th <= TILE_MAX_PIXELS) {
-                T.tw = tw;
-                T.th = th;
-                for (int r = tid / 64; r < th; r += G::BLOCK / 64) {  // one wave per tile row: coalesced row segments
-                    const float *src = P.depth + (size_t)(wi.v0 + r) * P.cam.W + wi.u0;
-                    for (int c = tid & 63; c < tw; c += 64) s_tile[r * tw + c] = src[c];
-                }
-            }
-        }
-        __syncthreads();
+        const float ox = (float)(N * cxi) * ip.res, oy = (float)(N * cyi) * ip.res, oz = (float)(N * czi) * ip.res;
+        const bool existed = slot >= 0;  // memory of `slot` holds this chunk's voxels
+        bool resident = existed;         // the reference's map contains the chunk before the current frame
+        bool updated_any = false;
+        __syncthreads();  // previous item's tile / flags / s_slot fully consumed
+        if (tid < 4) s_flags[tid] = 0;
 
-        int slot = wi.slot;
-        const bool fresh = slot < 0;
-        if (fresh) {
-            // ---- classification only: would any voxel be integrated? (carving cannot touch w == 0 voxels)
-            bool any = false;
-            for (int pass = 0; pass < G::PASSES; pass++) {
-                const int q = pass * G::BLOCK + tid;
-                float pcx[4], pcy[4], pcz[4], wx[4], wy, wz;
-                quad_geometry<N>(P, ox, oy, oz, q, pcx, pcy, pcz, wx, wy, wz);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float sd, wu;
-                    int cpix;
-                    any |= classify_voxel<COLOR>(P, T, pcx[j], pcy[j], pcz[j], wx[j], wy, wz, sd, wu, cpix) == 1;
-                }
-                if ((pass & 3) == 3 || pass == G::PASSES - 1) {
-                    if (__syncthreads_or(any)) {
-                        any = true;
-                        break;
-                    }
+        ThreadState<G::QPT> S;
+        thread_defaults(S, existed);
+        if (G::PASSES == 1) thread_place<N>(ip, ox, oy, oz, tid, S);
+        const size_t base0 = (size_t)(existed ? slot : 0) * G::V;
+
+        int parity = 0;
+        while (mask) {
+            const int k = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const FrameCam &F = P.f[k];
+            const FrameBox fb = boxes[(size_t)it * P.n_frames + k];
+            const int flags = __builtin_amdgcn_readfirstlane(fb.flags);
+            TileCtx T;
+            T.rec = F.rec;
+            T.u0 = __builtin_amdgcn_readfirstlane((int)fb.u0);
+            T.v0 = __builtin_amdgcn_readfirstlane((int)fb.v0);
+            T.tw = 0;
+            T.th = 0;
+            T.z_near = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_near)));
+            T.z_far = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_far)));
+            T.z_carve = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_carve)));
+            // ---- register-resident chunk: which quads can this frame touch?  Their state is requested now ------
+            unsigned need = 0;
+            if (G::PASSES == 1)
+                need = prefetch_frame<N, COLOR>(F, T, S, M.sdf + base0, M.wgt + base0, COLOR ? (M.rgbw + base0) : nullptr, tid);
+            // ---- stage the pixel records under the chunk in LDS ------------------------------------
+            if (flags & WI_TILE) {
+                const int tw = __builtin_amdgcn_readfirstlane((int)fb.u1) - T.u0 + 1;
+                const int th = __builtin_amdgcn_readfirstlane((int)fb.v1) - T.v0 + 1;
+                if (tw * th <= G::TILE_PIXELS) {
+                    T.tw = tw;
+                    T.th = th;
+                    stage_tile<G::BLOCK>(s_tile, F.rec, F.cam.W, T.u0, T.v0, tw, tw * th,
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)fb.magic), tid);
                 }
             }
-            if (!any) continue;  // block-uniform: the reference would create and then erase this chunk
+            __syncthreads();  // [B] tile visible; flags of the other parity are free to be reset
+            if (it == (int)blockIdx.x) STAMP(3);
             if (tid == 0) {
-                // ChunkManager::CreateChunk (ChunkManager.cpp:171-174) on the device
-                int s = -1;
-                int top = atomicSub(M.free_top, 1) - 1;
-                if (top < 0) {
-                    atomicAdd(M.free_top, 1);
-                    atomicExch(M.error_flag, 1);
-                } else {
-                    s = M.free_list[top];
-                    const uint64_t key = pack_id(wi.x, wi.y, wi.z);
-                    const uint64_t h = chunk_hash(wi.x, wi.y, wi.z) & M.hash_mask;
-                    bool placed = false;
-                    for (uint64_t i = 0; i <= M.hash_mask && !placed; i++) {
-                        const uint64_t idx = (h + i) & M.hash_mask;
-                        const uint64_t cur = M.hash_keys[idx];
-                        if (cur == KEY_EMPTY || cur == KEY_TOMB) {
-                            if (atomicCAS((unsigned long long *)&M.hash_keys[idx], (unsigned long long)cur,
-                                          (unsigned long long)key) == cur) {
-                                M.hash_vals[idx] = s;
-                                placed = true;
-                            }
+                s_flags[2 * (parity ^ 1)] = 0;
+                s_flags[2 * (parity ^ 1) + 1] = 0;
+            }
+            int t_ret = 0;
+            if (G::PASSES == 1) {
+                t_ret = apply_frame<N, COLOR, SAMECAM>(ip, F, T, s_tile, need, resident, S, tally);
+            } else {
+                // streamed chunk (32^3): slab by slab, state re-read per frame; a chunk that does not exist yet is
+                // created by the first slab that integrates a voxel
+                for (int pass = 0; pass < G::PASSES; pass++) {
+                    const int q0 = pass * G::SLAB_QUADS + tid;
+                    const size_t base = (size_t)(slot >= 0 ? slot : 0) * G::V;
+                    thread_defaults(S, slot >= 0);
+                    thread_place<N>(ip, ox, oy, oz, q0, S);
+                    need = prefetch_frame<N, COLOR>(F, T, S, M.sdf + base, M.wgt + base, COLOR ? (M.rgbw + base) : nullptr, q0);
+                    const int p_ret = apply_frame<N, COLOR, SAMECAM>(ip, F, T, s_tile, need, resident, S, tally);
+                    t_ret |= p_ret;
+                    if (slot < 0) {  // block-uniform
+                        if (__syncthreads_or(p_ret & 1)) {
+                            if (tid == 0) s_slot = create_chunk(Mc, cxi, cyi, czi);
+                            __syncthreads();
+                            slot = s_slot;
+                            if (slot >= 0) n_new += (tid == 0);
                         }
                     }
-                    if (!placed) {
-                        atomicExch(M.error_flag, 2);
-                        s = -1;
-                    } else {
-                        M.slot_key[s] = key;
-                    }
+                    if (slot >= 0)
+                        thread_store<N, COLOR>(S, M.sdf + (size_t)slot * G::V, M.wgt + (size_t)slot * G::V,
+                                               COLOR ? (M.rgbw + (size_t)slot * G::V) : nullptr, q0);
                 }
-                s_slot = s;
             }
-            __syncthreads();
-            slot = s_slot;
-            if (slot < 0) continue;
-            n_new += (tid == 0);
+            if (t_ret & 1) s_flags[2 * parity] = 1;      // benign race: every writer stores 1
+            if (t_ret & 2) s_flags[2 * parity + 1] = 1;
+            __syncthreads();  // [C] flags complete; tile consumed
+            if (it == (int)blockIdx.x) STAMP(4);
+            const bool f_in = s_flags[2 * parity] != 0, f_ch = s_flags[2 * parity + 1] != 0;
+            resident |= f_in;
+            updated_any |= f_ch;
+            n_updated += (tid == 0 && f_ch);  // "needsUpdate" of the chunk for this frame (Chisel.h:85 / :167)
+            parity ^= 1;
         }
 
-        float *sdf_base = M.sdf + (size_t)slot * G::V;
-        float *wgt_base = M.wgt + (size_t)slot * G::V;
-        uchar4 *col_base = COLOR ? (M.rgbw + (size_t)slot * G::V) : nullptr;
-        bool updated = false;
-
-        for (int iter = 0; iter < G::ITERS; iter++) {
-            // ---- phase A: geometry + depth gather + classification for PPI quads -----------------
-            unsigned cls[G::PPI];          // 2 bits per voxel
-            float sd[G::PPI][4], wu[G::PPI][4];
-            int cpix[G::PPI][4];
-#pragma unroll
-            for (int p = 0; p < G::PPI; p++) {
-                const int q = (iter * G::PPI + p) * G::BLOCK + tid;
-                float pcx[4], pcy[4], pcz[4], wx[4], wy, wz;
-                quad_geometry<N>(P, ox, oy, oz, q, pcx, pcy, pcz, wx, wy, wz);
-                cls[p] = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    int c = classify_voxel<COLOR>(P, T, pcx[j], pcy[j], pcz[j], wx[j], wy, wz, sd[p][j], wu[p][j], cpix[p][j]);
-                    cls[p] |= (unsigned)c << (2 * j);
-                }
+        if (G::PASSES == 1) {
+            if (!existed) {
+                if (!resident) continue;  // block-uniform: the reference creates and then erases this chunk in every frame
+                if (tid == 0) s_slot = create_chunk(Mc, cxi, cyi, czi);
+                __syncthreads();
+                slot = s_slot;
+                if (slot < 0) continue;
+                n_new += (tid == 0);
             }
-            // ---- phase B: load voxel state only where something can change ----------------------
-            float4 s4[G::PPI], w4[G::PPI];
-            uint4 c4[G::PPI];
-#pragma unroll
-            for (int p = 0; p < G::PPI; p++) {
-                const int q = (iter * G::PPI + p) * G::BLOCK + tid;
-                s4[p] = make_float4(99999.0f, 99999.0f, 99999.0f, 99999.0f);  // DistVoxel() DistVoxel.cpp:27-31
-                w4[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                c4[p] = make_uint4(0u, 0u, 0u, 0u);                           // ColorVoxel() ColorVoxel.cpp:27-31
-                if (!fresh && cls[p] != 0) {
-                    s4[p] = *reinterpret_cast<const float4 *>(sdf_base + 4 * q);
-                    w4[p] = *reinterpret_cast<const float4 *>(wgt_base + 4 * q);
-                    if (COLOR && (cls[p] & 0x55u)) c4[p] = *reinterpret_cast<const uint4 *>(col_base + 4 * q);
-                }
-            }
-            // ---- phase C: update + write back ----------------------------------------------------
-#pragma unroll
-            for (int p = 0; p < G::PPI; p++) {
-                const int q = (iter * G::PPI + p) * G::BLOCK + tid;
-                float s[4] = {s4[p].x, s4[p].y, s4[p].z, s4[p].w};
-                float w[4] = {w4[p].x, w4[p].y, w4[p].z, w4[p].w};
-                unsigned cw[4] = {c4[p].x, c4[p].y, c4[p].z, c4[p].w};
-                bool dchg = false, cchg = false;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int c = (cls[p] >> (2 * j)) & 3;
-                    if (c == 1) {
-                        if (COLOR) {
-                            if (cpix[p][j] >= 0) {
-                                uchar4 cv = *reinterpret_cast<uchar4 *>(&cw[j]);
-                                if (cv.w < 8) {  // ProjectionIntegrator.h:152
-                                    uint8_t r, g, b;
-                                    color_at(P.color, cpix[p][j], P.color_channels, r, g, b);
-                                    cv = color_integrate(cv, r, g, b, 1);
-                                    cw[j] = *reinterpret_cast<unsigned *>(&cv);
-                                    cchg = true;
-                                    tally.col++;
-                                } else {
-                                    tally.colsat++;
-                                }
-                            }
-                        }
-                        dist_integrate(s[j], w[j], sd[p][j], COLOR ? wu[p][j] : 1.0f);
-                        dchg = true;
-                        tally.sdf++;
-                    } else if (c == 2) {
-                        if (!fresh) tally.probe++;
-                        if (w[j] > 0.0f && sdf_below_carve_threshold(s[j])) {
-                            if (COLOR) {  // :166-177
-                                if (w[j] < 5.0f) {
-                                    s[j] = 99999.0f;
-                                    w[j] = 0.0f;
-                                } else {
-                                    w[j] = w[j] - 1.0f;
-                                }
-                            } else {  // :88-95 Carve() == Reset()
-                                s[j] = 99999.0f;
-                                w[j] = 0.0f;
-                            }
-                            dchg = true;
-                            tally.carved++;
-                        }
-                    }
-                }
-                updated |= dchg;
-                if (dchg || fresh) {
-                    *reinterpret_cast<float4 *>(sdf_base + 4 * q) = make_float4(s[0], s[1], s[2], s[3]);
-                    *reinterpret_cast<float4 *>(wgt_base + 4 * q) = make_float4(w[0], w[1], w[2], w[3]);
-                }
-                if (COLOR && (cchg || fresh)) *reinterpret_cast<uint4 *>(col_base + 4 * q) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-            }
+            thread_store<N, COLOR>(S, M.sdf + (size_t)slot * G::V, M.wgt + (size_t)slot * G::V,
+                                   COLOR ? (M.rgbw + (size_t)slot * G::V) : nullptr, tid);
         }
-        // ---- "needsUpdate" of the chunk (Chisel.h:85 / :167): mark the slot dirty for the mesher
-        if (updated) s_flag[1] = 1;  // benign race: every writer stores 1
-        __syncthreads();
-        if (tid == 0 && s_flag[1]) {
-            M.slot_dirty[slot] = 1;
-            n_updated++;
-        }
+        // mark the slot for the mesher (Chisel.h:175-189 marks the 27-neighbourhood on the host)
+        if (tid == 0 && updated_any && slot >= 0) M.slot_dirty[slot] = 1;
+        if (it == (int)blockIdx.x) STAMP(5);
     }
 
-    // ---- counters: block reduction in LDS, then a plain read-modify-write of this block's private row.
-    // (Same-address atomics run at ~90 per microsecond on this part: a few thousand of them per frame would
-    // cost more than the integration itself.  Rows are summed lazily by reduce_counters_kernel.)
-    __syncthreads();
-    unsigned *s_cnt = reinterpret_cast<unsigned *>(s_tile);
-    if (tid < 8) s_cnt[tid] = 0;
-    __syncthreads();
+    // ---- counters: wave reduction, then one no-return atomic per wave and counter into this block's private row
+    // (no same-address contention across blocks: those run at ~90 per microsecond on this part; rows are summed
+    // lazily by reduce_counters_kernel).  Nothing waits for the atomics.
+    unsigned long long *row = M.block_counters + (size_t)blockIdx.x * 16;
     unsigned vals[5] = {tally.sdf, tally.col, tally.colsat, tally.probe, tally.carved};
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         unsigned v = vals[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if ((tid & 63) == 0 && v) atomicAdd(&s_cnt[k], v);  // LDS atomic, <= 4 per counter
+        if ((tid & 63) == 0 && v) atomicAdd(&row[k], (unsigned long long)v);
     }
-    __syncthreads();
     if (tid == 0) {
-        unsigned long long *row = M.block_counters + (size_t)blockIdx.x * 16;
-        for (int k = 0; k < 5; k++) row[k] += s_cnt[k];
-        row[6] += n_new;
-        row[7] += n_updated;
+        if (n_new) atomicAdd(&row[6], (unsigned long long)n_new);
+        if (n_updated) atomicAdd(&row[7], (unsigned long long)n_updated);
         if (blockIdx.x == 0) {
-            row[5] += (unsigned long long)n_items;
-            row[8] += 1ull;
+            atomicAdd(&row[5], (unsigned long long)n_items);
+            atomicAdd(&row[8], (unsigned long long)P.n_frames);
         }
     }
+    STAMP(6);
+#ifdef CHISEL_STAMPS
+    if (tid == 0 && M.stamps) M.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;  // shader-clock cycles
+#endif
+#undef STAMP
 }
 
 // sums the per-block rows into counters[] (CHISEL_HIP_NUM_COUNTERS = 9 entries); one block of 256 threads

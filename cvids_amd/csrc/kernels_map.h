@@ -8,8 +8,22 @@
 
 namespace chisel_hip {
 
-// Chisel::Reset / ChunkManager::Reset (Chisel.cpp:44-48, ChunkManager.cpp:176-180) and initial state
-__global__ void reset_map_kernel(MapView M) {
+// default voxels of V-voxel chunk `slot` (DistVoxel() DistVoxel.cpp:27-31, ColorVoxel() ColorVoxel.cpp:27-31);
+// called by every thread of a workgroup
+__device__ inline void fill_default_chunk(const MapView &M, int slot, int V) {
+    float4 *s4 = reinterpret_cast<float4 *>(M.sdf + (size_t)slot * V);
+    float4 *w4 = reinterpret_cast<float4 *>(M.wgt + (size_t)slot * V);
+    uint4 *c4 = M.rgbw ? reinterpret_cast<uint4 *>(M.rgbw + (size_t)slot * V) : nullptr;
+    for (int i = threadIdx.x; i < V / 4; i += blockDim.x) {
+        s4[i] = make_float4(99999.0f, 99999.0f, 99999.0f, 99999.0f);
+        w4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c4) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// Chisel::Reset / ChunkManager::Reset (Chisel.cpp:44-48, ChunkManager.cpp:176-180) and initial state:
+// empty hash, full free list, default voxels in every slot (the pool invariant of chisel_device.h)
+__global__ void reset_map_kernel(MapView M, int V) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = gid; i <= M.hash_mask; i += stride) M.hash_keys[i] = KEY_EMPTY;
@@ -17,6 +31,15 @@ __global__ void reset_map_kernel(MapView M) {
         M.slot_key[i] = KEY_EMPTY;
         M.slot_dirty[i] = 0;
         M.free_list[i] = M.max_chunks - 1 - (int)i;  // slot 0 is popped first
+    }
+    const uint64_t quads = (uint64_t)M.max_chunks * (uint64_t)(V / 4);
+    float4 *s4 = reinterpret_cast<float4 *>(M.sdf);
+    float4 *w4 = reinterpret_cast<float4 *>(M.wgt);
+    uint4 *c4 = reinterpret_cast<uint4 *>(M.rgbw);
+    for (uint64_t i = gid; i < quads; i += stride) {
+        s4[i] = make_float4(99999.0f, 99999.0f, 99999.0f, 99999.0f);
+        w4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c4) c4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (gid == 0) {
         *M.free_top = M.max_chunks;
@@ -46,21 +69,36 @@ __global__ void lookup_kernel(MapView M, const int *ids, int n, int *slots) {
 }
 
 // RemoveChunk(ChunkID) (ChunkManager.h:99-108) for a list: Chisel::GarbageCollect (Chisel.cpp:61-67).
-// Never runs concurrently with integrate_kernel (same stream), so pushes and pops do not interleave.
-__global__ void remove_chunks_kernel(MapView M, const int *ids, int n, int *n_removed) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t where = 0;
-    const int slot = hash_find(M, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2], &where);
+// One workgroup per id: thread 0 unlinks the chunk, then the whole group restores default voxels in the
+// freed slot (pool invariant).  Never runs concurrently with integrate_kernel (same stream).
+__global__ __launch_bounds__(256) void remove_chunks_kernel(MapView M, const int *ids, int n, int *n_removed, int V) {
+    __shared__ int s_slot;
+    const int i = blockIdx.x;
+    if (threadIdx.x == 0) {
+        s_slot = -1;
+        uint64_t where = 0;
+        const int slot = hash_find(M, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2], &where);
+        if (slot >= 0) {
+            // duplicates in the list: only the group that swaps the key out frees the slot
+            const uint64_t key = pack_id(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+            if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) == key) {
+                M.slot_key[slot] = KEY_EMPTY;
+                M.slot_dirty[slot] = 0;
+                s_slot = slot;
+            }
+        }
+    }
+    __syncthreads();
+    const int slot = s_slot;
     if (slot < 0) return;
-    // duplicates in the list: only the thread that swaps the key out frees the slot
-    const uint64_t key = pack_id(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
-    if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) != key) return;
-    M.slot_key[slot] = KEY_EMPTY;
-    M.slot_dirty[slot] = 0;
-    const int pos = atomicAdd(M.free_top, 1);
-    M.free_list[pos] = slot;
-    atomicAdd(n_removed, 1);
+    fill_default_chunk(M, slot, V);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int pos = atomicAdd(M.free_top, 1);
+        M.free_list[pos] = slot;
+        atomicAdd(n_removed, 1);
+    }
 }
 
 // create-or-find for chisel_hip_upload_chunk (ChunkManager::AddChunk ChunkManager.h:89-92); one thread

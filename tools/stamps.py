@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Timeline of integrate_kernel from s_memrealtime stamps (diagnostic build: make -C cvids_amd/csrc stamps).
+
+    CHISEL_HIP_LIB=libchisel_hip_stamps.so python3 tools/stamps.py [--frames 30] [--batch 1]
+Stamps per workgroup (100 MHz ticks): 0 entry, 1 work_count read, 2 item read, 3 tile staged (last frame),
+4 frame applied (last frame), 5 item stored, 6 exit.  Only the first item of each workgroup is stamped.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--res", type=float, default=0.01)
+    ap.add_argument("--no-color", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from cvids_amd import capi, synth
+    from cvids_amd.chisel import Chisel, ConstantWeighter, InverseTruncator, PinholeCamera, ProjectionIntegrator
+    W, H = 640, 480
+    intr = synth.intrinsics(W, H)
+    cam = PinholeCamera(*intr, W, H, 0.05, 5.0)
+    integ = ProjectionIntegrator(InverseTruncator(100 * args.res), ConstantWeighter(1.0), 0.05, True)
+    frames = list(synth.stream("sphere_room", args.frames, W, H))
+    dev = torch.device("cuda:0")
+    d_dev = [torch.from_numpy(d).to(dev) for d, _ in frames]
+    c_dev = torch.from_numpy(synth.render_color(W, H, 3)).to(dev)
+    m = Chisel((16,) * 3, args.res, not args.no_color)
+    L = m.L
+    L.chisel_hip_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    G = 2048
+    buf = np.zeros((G, 8), np.uint64)
+    ptr = buf.ctypes.data_as(C.POINTER(C.c_uint64))
+    n_warm = args.frames - args.batch
+    for i in range(n_warm):
+        if args.no_color:
+            m.IntegrateDepthScan(integ, d_dev[i], frames[i][1], cam)
+        else:
+            m.IntegrateDepthScanColor(integ, d_dev[i], frames[i][1], cam, c_dev, frames[i][1], cam)
+    m.synchronize()
+    capi.check(L.chisel_hip_debug_stamps(m.h, None, 0))
+    fr = [(d_dev[i], frames[i][1], cam) for i in range(n_warm, args.frames)]
+    co = None if args.no_color else [(c_dev, frames[i][1], cam) for i in range(n_warm, args.frames)]
+    m.IntegrateBatch(integ, fr, co)
+    m.synchronize()
+    capi.check(L.chisel_hip_debug_stamps(m.h, ptr, G))
+    s = buf.astype(np.int64)
+    live = s[:, 0] > 0
+    t0 = s[live, 0].min()
+    print("workgroups that ran: %d; with an item: %d" % (live.sum(), (s[:, 2] > 0).sum()))
+    us = lambda a: (a - t0) / 100.0
+    for name, col in (("entry", 0), ("work_count read", 1), ("item read", 2), ("tile staged", 3), ("frame applied", 4),
+                      ("item stored", 5), ("exit", 6)):
+        v = s[:, col][s[:, col] > 0]
+        if len(v):
+            x = us(v)
+            print("  %-16s n %5d  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, len(v), x.min(), np.median(x), np.percentile(x, 90), x.max()))
+    w = s[:, 2] > 0
+    for a, b, name in ((0, 1, "entry->count"), (1, 2, "count->item"), (2, 3, "item->tile"), (3, 4, "tile->applied"), (4, 5, "applied->stored"), (5, 6, "stored->exit")):
+        ok = w & (s[:, a] > 0) & (s[:, b] > 0)
+        d = (s[ok, b] - s[ok, a]) / 100.0
+        if len(d):
+            print("  d %-16s p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, np.median(d), np.percentile(d, 90), d.max()))
+    ok = w & (s[:, 7] > 0) & (s[:, 6] > s[:, 0])
+    if ok.any():
+        mhz = s[ok, 7] / ((s[ok, 6] - s[ok, 0]) / 100.0)
+        print("  shader clock during the kernel: p50 %.0f MHz (min %.0f, max %.0f)" % (np.median(mhz), mhz.min(), mhz.max()))
+    print("counters:", m.counters())
+
+
+if __name__ == "__main__":
+    main()
