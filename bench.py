@@ -7,8 +7,10 @@
 A step = one depth(+colour) frame pushed through the hot path (pyramid -> cull -> integrate kernels;
 with --mesh-every M also a marching-cubes recompute every M-th frame, the reference cadence is 10).
 Frames are synthetic (cvids_amd.synth: sphere room, 0.5 deg + 1 cm per frame) and already resident in
-HBM when the timed region starts.  N > 1: one process per GPU, the chunk hash is sharded spatially
-(chisel_hip_config.n_shards), every frame is RCCL-broadcast from the GPU that ingested it and each rank
+HBM when the timed region starts.  Frames are handed to the library --batch at a time
+(chisel_hip_integrate_batch: one launch set applies them to every voxel in frame order; --batch 1 is the
+reference's frame-by-frame call pattern).  N > 1: one process per GPU, the chunk hash is sharded spatially
+(chisel_hip_config.n_shards), every batch is RCCL-broadcast from the GPU that ingested it and each rank
 integrates the chunks it owns -> total work is fixed: "scaling": "strong".
 
 One JSON line on rank 0.  `roofline` prices the integration kernel: algorithmic bytes per frame
@@ -47,6 +49,7 @@ def parse():
     ap.add_argument("--agents", type=int, default=1)
     ap.add_argument("--trunc-scale", type=float, default=None, help="InverseTruncator scale (default: 100*res)")
     ap.add_argument("--mesh-every", type=int, default=0, help="UpdateMeshes(force) every M frames inside the timed region")
+    ap.add_argument("--batch", type=int, default=8, help="frames per chisel_hip_integrate_batch call (<= 8 share one launch set)")
     ap.add_argument("--max-chunks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
@@ -114,37 +117,57 @@ def main():
     frames = list(synth.stream(args.scene, n_traj, W, H, agents=args.agents))[:total]
     color_img = synth.render_color(W, H, 3) if use_color else None
 
-    # frame i is ingested by rank (i % agents) % world: its pixels live in that rank's HBM before timing starts
-    root_of = [(i % args.agents) % world for i in range(total)]
-    d_dev = [torch.from_numpy(frames[i][0]).to(dev) if (world == 1 or root_of[i] == rank) else None for i in range(total)]
+    # frames are ingested a batch at a time: batch b by rank b % world, its pixels live in that rank's HBM before timing starts
+    import ctypes as C
+    from cvids_amd import capi
+    from cvids_amd.chisel import color_frame, depth_frame
+    K = max(1, args.batch)
+    bounds = [(lo, min(lo + K, args.warmup)) for lo in range(0, args.warmup, K)] + \
+             [(lo, min(lo + K, total)) for lo in range(args.warmup, total, K)]
+    root_of = [b % world for b in range(len(bounds))]
+    stack = [torch.from_numpy(np.stack([frames[i][0] for i in range(lo, hi)])).to(dev) if (world == 1 or root_of[b] == rank) else None
+             for b, (lo, hi) in enumerate(bounds)]
     c_dev = torch.from_numpy(color_img).to(dev) if use_color else None  # static colour pattern, resident on every rank
-    recv = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    recv = [torch.empty((K, H, W), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+
+    # the C structs of every batch are built once, outside the timed region (device addresses are fixed)
+    keep = []
+    calls = []
+    for b, (lo, hi) in enumerate(bounds):
+        n = hi - lo
+        src = stack[b] if world == 1 else recv[b & 1]
+        fa = (capi.DepthFrame * n)()
+        ca = (capi.ColorFrame * n)() if use_color else None
+        for j in range(n):
+            fa[j], k1 = depth_frame(src[j], frames[lo + j][1], cam)
+            keep.append(k1)
+            if use_color:
+                ca[j], k2 = color_frame(c_dev, frames[lo + j][1], cam)
+                keep.append(k2)
+        calls.append((n, fa, ca))
+    first_timed = next(b for b, (lo, hi) in enumerate(bounds) if lo >= args.warmup) if args.steps else len(bounds)
 
     def new_map():
         m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
                    n_shards=world, shard_rank=rank)
         m.set_stream(torch.cuda.current_stream().cuda_stream)  # RCCL -> integrate ordering comes from the stream
+        m._use(integ)
         return m
 
-    def run(m, lo, hi):
-        pending = None
-        for i in range(lo, hi):
+    def run(m, b_lo, b_hi):
+        L, h = m.L, m.h
+        for b in range(b_lo, b_hi):
+            n, fa, ca = calls[b]
             if world > 1:
-                buf = recv[i & 1]
-                if root_of[i] == rank:
-                    buf.copy_(d_dev[i], non_blocking=True)
-                dist.broadcast(buf, src=root_of[i])
-                depth = buf
-            else:
-                depth = d_dev[i]
-            pose = frames[i][1]
-            if use_color:
-                m.IntegrateDepthScanColor(integ, depth, pose, cam, c_dev, pose, cam)
-            else:
-                m.IntegrateDepthScan(integ, depth, pose, cam)
-            if args.mesh_every and (i + 1) % args.mesh_every == 0:
+                buf = recv[b & 1]
+                if root_of[b] == rank:
+                    buf[:n].copy_(stack[b], non_blocking=True)
+                dist.broadcast(buf, src=root_of[b])
+            rc = L.chisel_hip_integrate_batch(h, n, fa, ca)
+            if rc:
+                capi.check(rc)
+            if args.mesh_every and (bounds[b][1] // args.mesh_every) > (bounds[b][0] // args.mesh_every):
                 m.UpdateMeshes(force=True)
-        return pending
 
     def fence():
         if world > 1:
@@ -153,12 +176,12 @@ def main():
 
     # ---- pass A: the timed region ---------------------------------------------------------------------
     m = new_map()
-    run(m, 0, args.warmup)
+    run(m, 0, first_timed)
     m.synchronize()
     m.counters(reset=True)
     fence()
     t0 = time.perf_counter()
-    run(m, args.warmup, total)
+    run(m, first_timed, len(bounds))
     fence()
     dt = time.perf_counter() - t0
     m.synchronize()  # surfaces pool exhaustion
@@ -178,13 +201,13 @@ def main():
     roof = None
     if not args.no_roofline:
         m = new_map()
-        run(m, 0, args.warmup)
+        run(m, 0, first_timed)
         m.synchronize()
         m.counters(reset=True)
         m.set_profiling(True)
         fence()
         t1 = time.perf_counter()
-        run(m, args.warmup, total)
+        run(m, first_timed, len(bounds))
         fence()
         dt_b = time.perf_counter() - t1
         prof = m.profile()
@@ -197,7 +220,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roof = {"bound": "hbm", "kernel": "integrate_kernel<%d,%s>" % (args.chunk, "true" if use_color else "false"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "avg_kernel_us": avg_ms * 1e3, "launches": k["launches"],
+                "traffic": None, "avg_kernel_us": avg_ms * 1e3, "launches": k["launches"], "frames_per_launch": args.steps / max(k["launches"], 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "other_kernels_us": {n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "mesh")
                                      if prof[n]["launches"]},
@@ -215,7 +238,7 @@ def main():
                                                                         args.scene, args.agents, "" if args.agents == 1 else "s",
                                                                         args.res * 100, args.chunk, scale,
                                                                         (" + marching cubes every %d frames" % args.mesh_every) if args.mesh_every else ""),
-                       "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color,
+                       "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color, "frames_per_call": K,
                        "parallelism": "spatial chunk-hash shards x%d, RCCL frame broadcast" % world if world > 1 else "1 GPU"},
             "per_frame": {"voxel_updates": vals[0] / args.steps, "n_sdf": vals[1] / args.steps, "n_col": vals[2] / args.steps,
                           "n_probe": vals[4] / args.steps, "n_carved": vals[5] / args.steps,

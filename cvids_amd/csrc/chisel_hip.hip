@@ -205,8 +205,19 @@ int launch_group(chisel_hip_map *m, const PyramidParams &PP, const CullParams &C
     }
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_CULL);
-        hipLaunchKernelGGL(cull_kernel<N>, dim3((total + 255) / 256), dim3(256), 0, m->stream, CP, m->view, m->pyr, m->items,
-                           m->boxes, m->work_count, m->items_capacity);
+        const dim3 cgrid((total + 63) / 64);
+        if (IP.n_frames <= 1)
+            hipLaunchKernelGGL((cull_kernel<N, 1>), cgrid, dim3(64), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
+                               m->work_count, m->items_capacity);
+        else if (IP.n_frames <= 2)
+            hipLaunchKernelGGL((cull_kernel<N, 2>), cgrid, dim3(128), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
+                               m->work_count, m->items_capacity);
+        else if (IP.n_frames <= 4)
+            hipLaunchKernelGGL((cull_kernel<N, 4>), cgrid, dim3(256), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
+                               m->work_count, m->items_capacity);
+        else
+            hipLaunchKernelGGL((cull_kernel<N, 8>), cgrid, dim3(512), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
+                               m->work_count, m->items_capacity);
     }
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
@@ -519,8 +530,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long)));
-    HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 16 * sizeof(unsigned long long)));
-    HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 16 * sizeof(unsigned long long), m->stream));
+    HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMalloc(&v.error_flag, sizeof(int)));
     HIP_TRY_C(hipMalloc(&m->work_count, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
@@ -732,7 +743,7 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, m->stream, m->view, INTEGRATE_MAX_GRID);
     HIP_TRY(hipMemcpyAsync(out, m->view.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, m->stream));
     if (reset_counters)
-        HIP_TRY(hipMemsetAsync(m->view.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 16 * sizeof(unsigned long long), m->stream));
+        HIP_TRY(hipMemsetAsync(m->view.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHISEL_HIP_OK;
 }
@@ -797,14 +808,14 @@ int chisel_hip_debug_stamps(chisel_hip_map *m, unsigned long long *out, int n_gr
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    const size_t bytes = (size_t)INTEGRATE_MAX_GRID * 8 * sizeof(unsigned long long);
+    const size_t bytes = (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long);
     if (!m->view.stamps) {
         HIP_TRY(hipMalloc(&m->view.stamps, bytes));
         HIP_TRY(hipMemset(m->view.stamps, 0, bytes));
         HIP_TRY(hipMemcpy(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice));
     }
     if (out) {
-        HIP_TRY(hipMemcpy(out, m->view.stamps, (size_t)std::min(n_groups, INTEGRATE_MAX_GRID) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, m->view.stamps, (size_t)std::min(n_groups, INTEGRATE_MAX_GRID) * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(m->view.stamps, 0, bytes));
     }
     return CHISEL_HIP_OK;

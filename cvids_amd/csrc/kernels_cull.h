@@ -6,8 +6,8 @@
 //
 //   depth_pyramid_kernel : per frame: pixel records (depth, truncation distance) and the min/max of
 //                          the valid depth over 4x4 .. 64x64 pixel blocks
-//   cull_kernel          : one thread per chunk id of the union of the frames' candidate ranges; for
-//                          every frame keeps the chunk only if (a) the reference would enumerate it
+//   cull_kernel          : one thread per (chunk id of the union of the frames' candidate ranges, frame): keeps
+//                          the pair only if (a) the reference would enumerate it
 //                          (same range + same plane test), (b) this shard owns it, (c) a conservative
 //                          projection/depth-range test cannot rule out that one of its voxels is
 //                          updated or carved; looks the survivors up in the chunk hash and compacts
@@ -161,8 +161,58 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
         if (__fadd_rn(dotv, dd) > 0.0f) hit = true;
     }
     if (!hit) return 0;
-    // conservative camera-space bounds of the box (voxel centres lie strictly inside it)
     const CameraParams &C = F.cam;
+    // ---- cheap reject with the bounding sphere of the box (most candidates are empty space): one camera-space
+    // point instead of eight corners, approximate reciprocals, every bound widened accordingly ---------------
+    {
+        const float hx = 0.5f * ext;
+        const float rad = hx * 1.7320508f * 1.001f + 1e-6f;
+        const float wx = (bminx + hx) - C.t[0], wy = (bminy + hx) - C.t[1], wz = (bminz + hx) - C.t[2];
+        const float px = C.R[0] * wx + C.R[3] * wy + C.R[6] * wz;
+        const float py = C.R[1] * wx + C.R[4] * wy + C.R[7] * wz;
+        const float pz = C.R[2] * wx + C.R[5] * wy + C.R[8] * wz;
+        const float slack = 1e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + rad);
+        const float zs1 = pz + rad + slack;
+        if (zs1 < 0.0f) return 0;  // every voxel has z < 0 (ProjectionIntegrator.h:68)
+        const float zs0 = pz - rad - slack;
+        int su0 = 0, sv0 = 0, su1 = C.W - 1, sv1 = C.H - 1;
+        if (zs0 > 0.25f * ip.res) {
+            // camera-space box [px +- rad] x [py +- rad] x [zs0, zs1] projects inside these bounds
+            const float i0 = __builtin_amdgcn_rcpf(zs0) * 1.00001f, i1 = __builtin_amdgcn_rcpf(zs1) * 0.99999f;
+            const float xl = px - rad - slack, xh = px + rad + slack, yl = py - rad - slack, yh = py + rad + slack;
+            const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
+            const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
+            const float fu0 = floorf(ul) - 3.0f, fu1 = floorf(uh) + 3.0f, fv0 = floorf(vl) - 3.0f, fv1 = floorf(vh) + 3.0f;
+            if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1)) return 0;  // off the image
+            su0 = (int)fmaxf(fu0, 0.0f); sv0 = (int)fmaxf(fv0, 0.0f);
+            su1 = (int)fminf(fu1, (float)(C.W - 1)); sv1 = (int)fminf(fv1, (float)(C.H - 1));
+        }
+        float dmin = INFINITY, dmax = -INFINITY;
+        int l = PYR_LEVELS - 1;
+#pragma unroll
+        for (int k = PYR_LEVELS - 2; k >= 0; k--) {
+            int sft = PYR_L0 + k;
+            if (((su1 >> sft) - (su0 >> sft)) <= 2 && ((sv1 >> sft) - (sv0 >> sft)) <= 2) l = k;
+        }
+        const int sft = PYR_L0 + l;
+        const float2 *lvl = pdata + pyr.off[l];
+        const int lw = pyr.w[l];
+        for (int ty = (sv0 >> sft); ty <= (sv1 >> sft); ty++)
+            for (int tx = (su0 >> sft); tx <= (su1 >> sft); tx++) {
+                float2 t = lvl[ty * lw + tx];
+                dmin = fminf(dmin, t.x);
+                dmax = fmaxf(dmax, t.y);
+            }
+        if (!(dmin <= dmax)) return 0;  // no valid depth under the chunk
+        float tmin, tmax;
+        truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
+        const float zlo = fmaxf(zs0, 0.0f) - slack;
+        const float band = tmax + ip.diag;
+        const bool inband = (dmin - band < zs1) && (dmax + band > zlo);
+        const bool carve = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
+        if (!inband && !carve) return 0;
+    }
+    // ---- survivors: conservative camera-space bounds of the box itself (voxel centres lie strictly inside it)
     float zmin = INFINITY, zmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
     bool any_behind = false;
     const float zeps = 0.25f * ip.res;
@@ -239,39 +289,45 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
     return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0);
 }
 
-template <int N>
-__global__ __launch_bounds__(256) void cull_kernel(CullParams P, MapView M, PyramidView pyr, WorkItem *items, FrameBox *boxes,
-                                                    int *work_count, int max_items) {
+// One wave per frame of the batch over the same 64 chunk ids (block = 64 * KL threads, KL = frames rounded up to a
+// power of two): every per-frame constant is wave-uniform (scalar loads), the per-frame verdicts meet in LDS.
+template <int N, int KL>
+__global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, PyramidView pyr, WorkItem *items, FrameBox *boxes,
+                                                        int *work_count, int max_items) {
+    __shared__ int s_flags[KL][64];
+    __shared__ int s_pos[64];
+    const int lane = threadIdx.x & 63;
+    const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's frame
     const int total = P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    bool keep = false;
-    WorkItem wi;
-    FrameBox fb[KMAX];
-    unsigned mask = 0;
-    bool want_carve = false, want_inband = false;
-    if (gid < total) {
+    const int c = blockIdx.x * 64 + lane;
+    int cx = 0, cy = 0, cz = 0;
+    FrameBox fb;
+    fb.flags = 0;
+    int fl = 0;
+    if (c < total) {
         // reference order: x outer, y, z inner (ChunkManager.cpp:195-199)
-        const int iz = gid % P.range_dim[2];
-        const int iy = (gid / P.range_dim[2]) % P.range_dim[1];
-        const int ix = gid / (P.range_dim[2] * P.range_dim[1]);
-        const int cx = P.range_min[0] + ix, cy = P.range_min[1] + iy, cz = P.range_min[2] + iz;
-        if (chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank) {
+        const int iz = c % P.range_dim[2];
+        const int iy = (c / P.range_dim[2]) % P.range_dim[1];
+        const int ix = c / (P.range_dim[2] * P.range_dim[1]);
+        cx = P.range_min[0] + ix; cy = P.range_min[1] + iy; cz = P.range_min[2] + iz;
+        if (k < P.n_frames && chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank)
+            fl = cull_chunk_frame<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, cx, cy, cz, fb);
+    }
+    fb.flags = fl;
+    s_flags[k][lane] = fl;
+    __syncthreads();
+    if (k == 0) {
+        // ---- merge the frames of each chunk, look the survivors up, compact ------------------------------------
+        int f[KL];
+        int any = 0;
 #pragma unroll
-            for (int k = 0; k < KMAX; k++) {
-                fb[k].flags = 0;
-                fb[k].magic = 0;
-                fb[k].z_near = fb[k].z_far = fb[k].z_carve = 0.0f;
-                fb[k].pad = 0;
-                fb[k].u0 = fb[k].v0 = fb[k].u1 = fb[k].v1 = 0;
-                if (k < P.n_frames) {
-                    const int fl = cull_chunk_frame<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, cx, cy, cz, fb[k]);
-                    fb[k].flags = fl;
-                    want_inband |= (fl & WI_INBAND) != 0;
-                    want_carve |= (fl & WI_CARVE) != 0;
-                }
-            }
+        for (int j = 0; j < KL; j++) {
+            f[j] = s_flags[j][lane];
+            any |= f[j];
         }
-        if (want_inband || want_carve) {
+        bool keep = false;
+        WorkItem wi;
+        if (any & (WI_INBAND | WI_CARVE)) {
             // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82)
             const uint64_t key = pack_id(cx, cy, cz);
             const uint64_t h = chunk_hash(cx, cy, cz) & M.hash_mask;
@@ -287,39 +343,47 @@ __global__ __launch_bounds__(256) void cull_kernel(CullParams P, MapView M, Pyra
             // a frame can only matter if it may integrate, or may carve a chunk that is resident by then
             // (resident now, or created by an earlier frame of this batch)
             bool resident = slot >= 0;
+            unsigned mask = 0;
+            int anyf = 0;
 #pragma unroll
-            for (int k = 0; k < KMAX; k++) {
-                const int fl = fb[k].flags;
-                if ((fl & WI_INBAND) || ((fl & WI_CARVE) && resident)) mask |= 1u << k;
-                resident |= (fl & WI_INBAND) != 0;
+            for (int j = 0; j < KL; j++) {
+                if ((f[j] & WI_INBAND) || ((f[j] & WI_CARVE) && resident)) {
+                    mask |= 1u << j;
+                    anyf |= f[j];
+                }
+                resident |= (f[j] & WI_INBAND) != 0;
             }
             keep = mask != 0;
             wi.x = cx; wi.y = cy; wi.z = cz;
             wi.slot = slot;
             wi.frame_mask = mask;
-            wi.any_flags = 0;
-#pragma unroll
-            for (int k = 0; k < KMAX; k++)
-                if (mask & (1u << k)) wi.any_flags |= fb[k].flags;
+            wi.any_flags = anyf;
             wi.pad[0] = wi.pad[1] = 0;
         }
-    }
-    // wave64 compaction: ballot + prefix popcount, one atomic per wave
-    const unsigned long long bal = __ballot(keep);
-    if (bal) {
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(work_count, __popcll(bal));
-        base = __shfl(base, (int)__builtin_ctzll(bal));
-        if (keep) {
-            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < max_items) {
-                items[pos] = wi;
-#pragma unroll
-                for (int k = 0; k < KMAX; k++)
-                    if (k < P.n_frames) boxes[(size_t)pos * P.n_frames + k] = fb[k];
+        // wave64 compaction: ballot + prefix popcount, one atomic per wave
+        const unsigned long long bal = __ballot(keep);
+        int pos = -1;
+        if (bal) {
+            int base = 0;
+            if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(work_count, __popcll(bal));
+            base = __shfl(base, (int)__builtin_ctzll(bal));
+            if (keep) {
+                pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < max_items) items[pos] = wi; else pos = -1;
             }
         }
+        s_pos[lane] = pos;
+    }
+    __syncthreads();
+    const int pos = s_pos[lane];
+    if (pos >= 0 && k < P.n_frames) {
+        if (fl == 0) {  // frames that cannot touch the chunk: a well-defined empty box
+            fb.u0 = fb.v0 = fb.u1 = fb.v1 = 0;
+            fb.magic = 0;
+            fb.z_near = fb.z_far = fb.z_carve = 0.0f;
+            fb.pad = 0;
+        }
+        boxes[(size_t)pos * P.n_frames + k] = fb;
     }
 }
 

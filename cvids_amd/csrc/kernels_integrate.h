@@ -30,15 +30,25 @@
 namespace chisel_hip {
 
 #ifndef INTEGRATE_MIN_WAVES
-#define INTEGRATE_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for (1 = no constraint)
+#define INTEGRATE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for: two 512-thread workgroups per CU
 #endif
 #ifndef INTEGRATE_QPT
-#define INTEGRATE_QPT 4        // quads (of 4 voxels) per thread; 1024 / QPT threads per 16^3 chunk
+#define INTEGRATE_QPT 2        // quads (of 4 voxels) per thread; 1024 / QPT threads per 16^3 chunk
 #endif
 
 struct Tally {
     unsigned sdf, col, colsat, probe, carved;
+#ifdef CHISEL_STAMPS
+    unsigned long long cyc[6];  // shader cycles of wave phases: geometry+project, record fetch, band tests, integrate, colour, carve
+#endif
 };
+#ifdef CHISEL_STAMPS
+#define PHASE_BEGIN() unsigned long long ph_t = __builtin_amdgcn_s_memtime()
+#define PHASE_END(i) do { unsigned long long ph_n = __builtin_amdgcn_s_memtime(); tally.cyc[i] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#else
+#define PHASE_BEGIN() do { } while (0)
+#define PHASE_END(i) do { } while (0)
+#endif
 
 struct TileCtx {
     const PixelRec *rec;   // the frame's full record image (global)
@@ -58,8 +68,11 @@ struct Geom {
     static constexpr int QPT = (N == 8 && INTEGRATE_QPT > 2) ? 2 : INTEGRATE_QPT;  // quads per thread: same x, y, different z
     static constexpr int BLOCK = SLAB_QUADS / QPT;
     static constexpr int PASSES = QUADS / SLAB_QUADS;                  // 1 (8^3, 16^3) or 8 (32^3)
-    static constexpr int TILE_PIXELS = (N == 8) ? 1024 : 4096;         // record tile in LDS per workgroup (8 / 32 KiB)
+    // record tile in LDS per workgroup (16 / 32 KiB).  Larger boxes belong to near-camera chunks whose voxels map to
+    // distinct pixels: staging the whole box would move more bytes than gathering the records from L2 directly.
+    static constexpr int TILE_PIXELS = (N == 8) ? 2048 : 4096;
     static constexpr int GRID = (N == 8) ? 4096 : ((BLOCK > 512) ? 512 : 1024);  // persistent grid: about what fits the chip at once
+    static constexpr int MIN_WAVES = (N == 8) ? 1 : INTEGRATE_MIN_WAVES;
     static_assert(BLOCK % LAYER_QUADS == 0, "a thread's quads must share x and y");
     static_assert(GRID <= INTEGRATE_MAX_GRID, "per-workgroup counter rows");
 };
@@ -82,11 +95,14 @@ template <int QPT>
 struct ThreadState {
     float wx[4], wy;          // world coordinates of the voxel centres shared by the thread's quads
     float wz[QPT];
-    float s[QPT][4], w[QPT][4];
-    unsigned c[QPT][4];
+    float4 s4[QPT], w4[QPT];  // sdf / weight of the quads, kept as the 16-byte tuples the loads and stores move
+    uint4 c4[QPT];            // packed RGBW
     unsigned have, havec;     // bit p: sdf/weight (colour) of quad p hold the chunk's values (read, or defaults of a new chunk)
     unsigned dchg, cchg;      // bit p: sdf/weight (colour) of quad p differ from memory
 };
+
+__device__ inline float &f4(float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+__device__ inline unsigned &u4(uint4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 // voxelCenter = centroids[i] + origin (ChunkManager.cpp:61: Vec3(x,y,z)*res + half; ProjectionIntegrator.h:63)
 template <int N>
@@ -104,13 +120,11 @@ __device__ inline void thread_place(const IntegratorParams &ip, float ox, float 
 template <int QPT>
 __device__ inline void thread_defaults(ThreadState<QPT> &S, bool existed) {
 #pragma unroll
-    for (int p = 0; p < QPT; p++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            S.s[p][j] = 99999.0f;
-            S.w[p][j] = 0.0f;
-            S.c[p][j] = 0u;
-        }
+    for (int p = 0; p < QPT; p++) {
+        S.s4[p] = make_float4(99999.0f, 99999.0f, 99999.0f, 99999.0f);
+        S.w4[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        S.c4[p] = make_uint4(0u, 0u, 0u, 0u);
+    }
     S.have = S.havec = existed ? 0u : ~0u;  // a chunk without a slot has default voxels: nothing to read
     S.dchg = S.cchg = 0u;
 }
@@ -122,11 +136,10 @@ __device__ inline void thread_store(const ThreadState<Geom<N>::QPT> &S, float *s
     for (int p = 0; p < G::QPT; p++) {
         const int q = q0 + p * G::BLOCK;
         if (S.dchg & (1u << p)) {
-            *reinterpret_cast<float4 *>(sdf_base + 4 * q) = make_float4(S.s[p][0], S.s[p][1], S.s[p][2], S.s[p][3]);
-            *reinterpret_cast<float4 *>(wgt_base + 4 * q) = make_float4(S.w[p][0], S.w[p][1], S.w[p][2], S.w[p][3]);
+            *reinterpret_cast<float4 *>(sdf_base + 4 * q) = S.s4[p];
+            *reinterpret_cast<float4 *>(wgt_base + 4 * q) = S.w4[p];
         }
-        if (COLOR && (S.cchg & (1u << p)))
-            *reinterpret_cast<uint4 *>(col_base + 4 * q) = make_uint4(S.c[p][0], S.c[p][1], S.c[p][2], S.c[p][3]);
+        if (COLOR && (S.cchg & (1u << p))) *reinterpret_cast<uint4 *>(col_base + 4 * q) = S.c4[p];
     }
 }
 
@@ -156,15 +169,12 @@ __device__ inline unsigned prefetch_frame(const FrameCam &F, const TileCtx &T, T
             need |= 1u << p;
             const int q = q0 + p * G::BLOCK;
             if (!(S.have & (1u << p))) {
-                const float4 s4 = *reinterpret_cast<const float4 *>(sdf_base + 4 * q);
-                const float4 w4 = *reinterpret_cast<const float4 *>(wgt_base + 4 * q);
-                S.s[p][0] = s4.x; S.s[p][1] = s4.y; S.s[p][2] = s4.z; S.s[p][3] = s4.w;
-                S.w[p][0] = w4.x; S.w[p][1] = w4.y; S.w[p][2] = w4.z; S.w[p][3] = w4.w;
+                S.s4[p] = *reinterpret_cast<const float4 *>(sdf_base + 4 * q);  // straight into the state tuple: no use, no wait
+                S.w4[p] = *reinterpret_cast<const float4 *>(wgt_base + 4 * q);
                 S.have |= 1u << p;
             }
             if (COLOR && may_band && !(S.havec & (1u << p))) {
-                const uint4 c4 = *reinterpret_cast<const uint4 *>(col_base + 4 * q);
-                S.c[p][0] = c4.x; S.c[p][1] = c4.y; S.c[p][2] = c4.z; S.c[p][3] = c4.w;
+                S.c4[p] = *reinterpret_cast<const uint4 *>(col_base + 4 * q);
                 S.havec |= 1u << p;
             }
         }
@@ -196,108 +206,140 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
         ax2[j] = C.R[2] * dx;
     }
     int ret = 0;
+    constexpr int QG = (G::QPT < 2) ? 1 : 2;  // quads whose record fetches are in flight together
 #pragma unroll
-    for (int p = 0; p < G::QPT; p++) {
-        if (!(need & (1u << p))) continue;
-        const float dz = S.wz[p] - C.t[2];
-        const float s0 = ay0 + C.R[6] * dz;
-        const float s1 = ay1 + C.R[7] * dz;
-        const float s2 = ay2 + C.R[8] * dz;
-        bool on[4], band[4], carve[4];
-        int iu[4], iv[4], tidx[4];
-        float pcz[4];
+    for (int g = 0; g < G::QPT; g += QG) {
+        if (!((need >> g) & ((1u << QG) - 1u))) continue;
+        bool on[QG][4], band[QG][4], carve[QG][4];
+        int iu[QG][4], iv[QG][4], tidx[QG][4];
+        float pcz[QG][4];
         bool any_out = false;
-        PixelRec r[4];
+        PixelRec r[QG][4];
+        PHASE_BEGIN();
+        // ---- phase A: geometry + projection -> pixel of every voxel of the group ------------------------------
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float pcx = ax0[j] + s0, pcy = ax1[j] + s1;
-            pcz[j] = ax2[j] + s2;
-            // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45)
-            const float invZ = 1.0f / pcz[j];
-            const float u = C.fx * pcx * invZ + C.cx;
-            const float v = C.fy * pcy * invZ + C.cy;
-            // IsPointOnImage (PinholeCamera.cpp:61-64): 0 <= u < W && 0 <= v < H, and not z < 0 (ProjectionIntegrator.h:68 /
-            // :126).  z == +-0 or NaN gives u, v = +-inf / NaN, which fail the image test, so "z > 0" is the same
-            // predicate; for u not NaN, floor(u) in [0, W) <=> 0 <= u < W, and there floor(u) == (int)u (:72 / :131).
-            iu[j] = (int)floorf(u);
-            iv[j] = (int)floorf(v);
-            on[j] = (pcz[j] > 0.0f) & ((unsigned)iu[j] < (unsigned)C.W) & ((unsigned)iv[j] < (unsigned)C.H) & (u == u) & (v == v);
-            const int tu = iu[j] - T.u0, tv = iv[j] - T.v0;
-            const bool in_tile = ((unsigned)tu < (unsigned)T.tw) & ((unsigned)tv < (unsigned)T.th);
-            tidx[j] = in_tile ? tv * T.tw + tu : 0;
-            any_out |= on[j] & !in_tile;
+        for (int e = 0; e < QG; e++) {
+            const int p = g + e;
+            const bool wanted = (need >> p) & 1u;
+            const float dz = S.wz[p] - C.t[2];
+            const float s0 = ay0 + C.R[6] * dz;
+            const float s1 = ay1 + C.R[7] * dz;
+            const float s2 = ay2 + C.R[8] * dz;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float pcx = ax0[j] + s0, pcy = ax1[j] + s1;
+                pcz[e][j] = ax2[j] + s2;
+                // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45)
+                const float invZ = 1.0f / pcz[e][j];
+                const float u = C.fx * pcx * invZ + C.cx;
+                const float v = C.fy * pcy * invZ + C.cy;
+                // IsPointOnImage (PinholeCamera.cpp:61-64): 0 <= u < W && 0 <= v < H, and not z < 0 (ProjectionIntegrator.h:68 /
+                // :126).  z == +-0 or NaN gives u, v = +-inf / NaN, which fail the image test, so "z > 0" is the same
+                // predicate; for u not NaN, floor(u) in [0, W) <=> 0 <= u < W, and there floor(u) == (int)u (:72 / :131).
+                iu[e][j] = (int)floorf(u);
+                iv[e][j] = (int)floorf(v);
+                on[e][j] = wanted & (pcz[e][j] > 0.0f) & ((unsigned)iu[e][j] < (unsigned)C.W) & ((unsigned)iv[e][j] < (unsigned)C.H) &
+                           (u == u) & (v == v);
+                const int tu = iu[e][j] - T.u0, tv = iv[e][j] - T.v0;
+                const bool in_tile = ((unsigned)tu < (unsigned)T.tw) & ((unsigned)tv < (unsigned)T.th);
+                tidx[e][j] = in_tile ? tv * T.tw + tu : 0;
+                any_out |= on[e][j] & !in_tile;
+            }
         }
+        PHASE_END(0);
+        // ---- phase B: records of all voxels of the group, in flight together -----------------------------------
 #pragma unroll
-        for (int j = 0; j < 4; j++) r[j] = s_tile[tidx[j]];
-        // pixels outside the staged box (no box: near-camera chunks; otherwise never, the box is conservative)
+        for (int e = 0; e < QG; e++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) r[e][j] = s_tile[tidx[e][j]];
+        // pixels outside the staged box (box too large for LDS: near-camera chunks; otherwise never, the box is conservative)
         if (any_out) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int tu = iu[j] - T.u0, tv = iv[j] - T.v0;
-                const bool in_tile = ((unsigned)tu < (unsigned)T.tw) & ((unsigned)tv < (unsigned)T.th);
-                if (on[j] & !in_tile) r[j] = T.rec[iv[j] * C.W + iu[j]];  // DepthAt(row, col) DepthImage.h:72-76
-            }
-        }
-        float sd[4];
-        bool any_band = false, any_carve = false;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail
-            sd[j] = r[j].x - pcz[j];                                                                 // surfaceDist :79 / :139
-            band[j] = on[j] & (fabsf(sd[j]) < r[j].y + ip.diag);                                     // :81 / :144
-            carve[j] = on[j] & !band[j] & (ip.carving != 0) & (sd[j] > r[j].y + ip.carving_dist);    // :86 / :164
-            any_band |= band[j];
-            any_carve |= carve[j];
-            tally.sdf += band[j];
-            tally.probe += carve[j] & resident;
-        }
-        if (any_band) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float wu = 1.0f;                                      // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84
-                if (COLOR) wu = constant_weight(ip.weight, r[j].y);  // IntegrateColor: weighter->GetWeight(.., truncation) :161-162
-                float ns = S.s[p][j], nw = S.w[p][j];
-                dist_integrate(ns, nw, sd[j], wu);
-                S.s[p][j] = band[j] ? ns : S.s[p][j];
-                S.w[p][j] = band[j] ? nw : S.w[p][j];
-            }
-            S.dchg |= 1u << p;
-            ret |= 3;
-            if (COLOR) {
+            for (int e = 0; e < QG; e++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int cpix = SAMECAM ? (iv[j] * C.W + iu[j]) : (band[j] ? color_pixel(F.ccam, S.wx[j], S.wy, S.wz[p]) : -1);
-                    const bool has = band[j] & (cpix >= 0);
-                    const bool fresh_col = has & ((S.c[p][j] >> 24) < 8u);  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
-                    tally.colsat += has & !fresh_col;
-                    tally.col += fresh_col;
-                    if (fresh_col) {
-                        uchar4 cv = *reinterpret_cast<uchar4 *>(&S.c[p][j]);
-                        uint8_t cr, cg, cb;
-                        color_at(F.color, cpix, F.color_channels, cr, cg, cb);
-                        cv = color_integrate(cv, cr, cg, cb, 1);
-                        S.c[p][j] = *reinterpret_cast<unsigned *>(&cv);
-                        S.cchg |= 1u << p;
-                    }
+                    const int tu = iu[e][j] - T.u0, tv = iv[e][j] - T.v0;
+                    const bool in_tile = ((unsigned)tu < (unsigned)T.tw) & ((unsigned)tv < (unsigned)T.th);
+                    const int gi = (on[e][j] & !in_tile) ? iv[e][j] * C.W + iu[e][j] : 0;  // DepthAt(row, col) DepthImage.h:72-76
+                    const PixelRec gr = T.rec[gi];                                          // unconditional: all loads in flight
+                    if (on[e][j] & !in_tile) r[e][j] = gr;
                 }
-            }
         }
-        if (any_carve) {
+#ifdef CHISEL_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        PHASE_END(1);
+        // ---- phase C: band tests and updates, quad by quad ------------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < QG; e++) {
+            const int p = g + e;
+            float sd[4];
+            bool any_band = false, any_carve = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool hit = carve[j] & (S.w[p][j] > 0.0f) & sdf_below_carve_threshold(S.s[p][j]);
-                tally.carved += hit;
-                if (hit) {
-                    if (COLOR && !(S.w[p][j] < 5.0f)) {  // :166-177: decay
-                        S.w[p][j] = S.w[p][j] - 1.0f;
-                    } else {                            // :88-95 / :170 Carve() == Reset()
-                        S.s[p][j] = 99999.0f;
-                        S.w[p][j] = 0.0f;
+                // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail
+                sd[j] = r[e][j].x - pcz[e][j];                                                                   // surfaceDist :79 / :139
+                band[e][j] = on[e][j] & (fabsf(sd[j]) < r[e][j].y + ip.diag);                                    // :81 / :144
+                carve[e][j] = on[e][j] & !band[e][j] & (ip.carving != 0) & (sd[j] > r[e][j].y + ip.carving_dist);  // :86 / :164
+                any_band |= band[e][j];
+                any_carve |= carve[e][j];
+                tally.sdf += band[e][j];
+                tally.probe += carve[e][j] & resident;
+            }
+            PHASE_END(2);
+            if (any_band) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float wu = 1.0f;                                         // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84
+                    if (COLOR) wu = constant_weight(ip.weight, r[e][j].y);  // IntegrateColor: weighter->GetWeight(.., truncation) :161-162
+                    float ns = f4(S.s4[p], j), nw = f4(S.w4[p], j);
+                    dist_integrate(ns, nw, sd[j], wu);
+                    f4(S.s4[p], j) = band[e][j] ? ns : f4(S.s4[p], j);
+                    f4(S.w4[p], j) = band[e][j] ? nw : f4(S.w4[p], j);
+                }
+                S.dchg |= 1u << p;
+                ret |= 3;
+                PHASE_END(3);
+                if (COLOR) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int cpix = SAMECAM ? (iv[e][j] * C.W + iu[e][j])
+                                                 : (band[e][j] ? color_pixel(F.ccam, S.wx[j], S.wy, S.wz[p]) : -1);
+                        const bool has = band[e][j] & (cpix >= 0);
+                        const bool fresh_col = has & ((u4(S.c4[p], j) >> 24) < 8u);  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
+                        if (!SAMECAM) tally.colsat += has & !fresh_col;  // one camera: every in-band voxel has a colour pixel, colsat = sdf - col
+                        tally.col += fresh_col;
+                        if (fresh_col) {
+                            unsigned cbits = u4(S.c4[p], j);
+                            uchar4 cv = *reinterpret_cast<uchar4 *>(&cbits);
+                            uint8_t cr, cg, cb;
+                            color_at(F.color, cpix, F.color_channels, cr, cg, cb);
+                            cv = color_integrate(cv, cr, cg, cb, 1);
+                            u4(S.c4[p], j) = *reinterpret_cast<unsigned *>(&cv);
+                            S.cchg |= 1u << p;
+                        }
                     }
-                    S.dchg |= 1u << p;
-                    ret |= 2;
                 }
             }
+            PHASE_END(4);
+            if (any_carve) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool hit = carve[e][j] && (f4(S.w4[p], j) > 0.0f) && sdf_below_carve_threshold(f4(S.s4[p], j));
+                    tally.carved += hit;
+                    if (hit) {
+                        if (COLOR && !(f4(S.w4[p], j) < 5.0f)) {  // :166-177: decay
+                            f4(S.w4[p], j) = f4(S.w4[p], j) - 1.0f;
+                        } else {                                 // :88-95 / :170 Carve() == Reset()
+                            f4(S.s4[p], j) = 99999.0f;
+                            f4(S.w4[p], j) = 0.0f;
+                        }
+                        S.dchg |= 1u << p;
+                        ret |= 2;
+                    }
+                }
+            }
+            PHASE_END(5);
         }
     }
     return ret;
@@ -335,19 +377,23 @@ __device__ __attribute__((noinline)) int create_chunk(const MapView *__restrict_
 
 // stage the pixel records of box (u0, v0, tw x th) of `rec` (row stride W) into LDS, 4 loads in flight per lane;
 // magic = ceil(2^32 / tw): row = floor(idx / tw) for idx < 2^16
-template <int BLOCK>
+template <int BLOCK, int TILE>
 __device__ inline void stage_tile(PixelRec *s_tile, const PixelRec *__restrict__ rec, int W, int u0, int v0, int tw, int npx,
                                   unsigned magic, int tid) {
     const PixelRec *src = rec + (size_t)v0 * W + u0;
-    for (int base = 0; base < npx; base += 4 * BLOCK) {
+    // fully unrolled (a rolled loop makes the compiler drain every outstanding load at its header, including the
+    // voxel-state reads issued just before); the loads are unconditional (index clamped into the box) so that
+    // four are in flight together
+#pragma unroll
+    for (int b = 0; b < (TILE + 4 * BLOCK - 1) / (4 * BLOCK); b++) {
+        const int base = b * 4 * BLOCK;
+        if (base >= npx) break;
         PixelRec v[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int idx = base + i * BLOCK + tid;
-            if (idx < npx) {
-                const int row = (int)__umulhi((unsigned)idx, magic);
-                v[i] = src[row * W + (idx - row * tw)];
-            }
+            const int idx = min(base + i * BLOCK + tid, npx - 1);
+            const int row = (int)__umulhi((unsigned)idx, magic);
+            v[i] = src[row * W + (idx - row * tw)];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -358,7 +404,7 @@ __device__ inline void stage_tile(PixelRec *s_tile, const PixelRec *__restrict__
 }
 
 template <int N, bool COLOR, bool SAMECAM>
-__global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate_kernel(IntegrateParams P, MapView M,
+__global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_kernel(IntegrateParams P, MapView M,
                                                                                          const MapView *__restrict__ Mc,
                                                                                          const WorkItem *__restrict__ items,
                                                                                          const FrameBox *__restrict__ boxes,
@@ -370,7 +416,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate
     __shared__ int s_slot;
     const int tid = threadIdx.x;
 #ifdef CHISEL_STAMPS
-#define STAMP(i) do { if (tid == 0 && M.stamps) M.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP(i) do { if (tid == 0 && M.stamps) M.stamps[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -382,7 +428,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate
     if (n_items > max_items) n_items = max_items;
     STAMP(1);
     if ((int)blockIdx.x >= n_items && blockIdx.x != 0) return;  // nothing to do, nothing to count (block 0 counts the frames)
-    Tally tally = {0, 0, 0, 0, 0};
+    Tally tally = {};
     unsigned n_new = 0, n_updated = 0;
     const IntegratorParams &ip = P.ip;
 
@@ -426,6 +472,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate
             unsigned need = 0;
             if (G::PASSES == 1)
                 need = prefetch_frame<N, COLOR>(F, T, S, M.sdf + base0, M.wgt + base0, COLOR ? (M.rgbw + base0) : nullptr, tid);
+            if (it == (int)blockIdx.x) STAMP(16);
             // ---- stage the pixel records under the chunk in LDS ------------------------------------
             if (flags & WI_TILE) {
                 const int tw = __builtin_amdgcn_readfirstlane((int)fb.u1) - T.u0 + 1;
@@ -433,12 +480,19 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate
                 if (tw * th <= G::TILE_PIXELS) {
                     T.tw = tw;
                     T.th = th;
-                    stage_tile<G::BLOCK>(s_tile, F.rec, F.cam.W, T.u0, T.v0, tw, tw * th,
+                    stage_tile<G::BLOCK, G::TILE_PIXELS>(s_tile, F.rec, F.cam.W, T.u0, T.v0, tw, tw * th,
                                          (unsigned)__builtin_amdgcn_readfirstlane((int)fb.magic), tid);
                 }
             }
+            if (it == (int)blockIdx.x) STAMP(17);
             __syncthreads();  // [B] tile visible; flags of the other parity are free to be reset
             if (it == (int)blockIdx.x) STAMP(3);
+#ifdef CHISEL_STAMPS
+            if (it == (int)blockIdx.x && tid == 0 && M.stamps) {
+                M.stamps[(size_t)blockIdx.x * 32 + 14] = (unsigned long long)(T.tw * T.th);
+                M.stamps[(size_t)blockIdx.x * 32 + 15] = (unsigned long long)flags | ((unsigned long long)(fb.u1 - fb.u0 + 1) << 8) | ((unsigned long long)(fb.v1 - fb.v0 + 1) << 24) | ((unsigned long long)__popc(need) << 40);
+            }
+#endif
             if (tid == 0) {
                 s_flags[2 * (parity ^ 1)] = 0;
                 s_flags[2 * (parity ^ 1) + 1] = 0;
@@ -502,7 +556,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate
     // (no same-address contention across blocks: those run at ~90 per microsecond on this part; rows are summed
     // lazily by reduce_counters_kernel).  Nothing waits for the atomics.
     unsigned long long *row = M.block_counters + (size_t)blockIdx.x * 16;
-    unsigned vals[5] = {tally.sdf, tally.col, tally.colsat, tally.probe, tally.carved};
+    unsigned vals[5] = {tally.sdf, tally.col, (COLOR && SAMECAM) ? (tally.sdf - tally.col) : tally.colsat, tally.probe, tally.carved};
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         unsigned v = vals[k];
@@ -520,7 +574,10 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, INTEGRATE_MIN_WAVES) void integrate
     }
     STAMP(6);
 #ifdef CHISEL_STAMPS
-    if (tid == 0 && M.stamps) M.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;  // shader-clock cycles
+    if (tid == 0 && M.stamps) {
+        M.stamps[(size_t)blockIdx.x * 32 + 7] = __builtin_amdgcn_s_memtime() - clk0;  // shader-clock cycles
+        for (int k = 0; k < 6; k++) M.stamps[(size_t)blockIdx.x * 32 + 8 + k] = tally.cyc[k];
+    }
 #endif
 #undef STAMP
 }

@@ -262,6 +262,65 @@ def test_device_resident_frames_and_batch(oracle_mod):
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+def _run_batched(om, gm, integ, frames, cam, color_img, batch):
+    """oracle frame by frame, HIP path `batch` frames per chisel_hip_integrate_batch call; compare after every call"""
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    for lo in range(0, len(frames), batch):
+        part = frames[lo:lo + batch]
+        tot = dict(sdf=0, col=0, col_sat=0, probe=0, carved=0, updated_chunks=0)
+        for depth, pose in part:
+            if color_img is None:
+                om.integrate_depth(depth, pose, intr, cam.near_plane, cam.far_plane)
+            else:
+                om.integrate_depth_color(depth, pose, intr, color_img, near=cam.near_plane, far=cam.far_plane)
+            oc = om.counters()
+            for k in tot:
+                tot[k] += oc[k]
+        gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], None if color_img is None else [(color_img, p, cam) for _, p in part])
+        gc = gm.counters(reset=True)
+        for k in tot:
+            assert tot[k] == gc[k], "frames %d..: counter %s: oracle %d gpu %d" % (lo, k, tot[k], gc[k])
+        assert om.num_chunks() == gm.NumChunks()
+        compare_fields(om.fields(), gm.fields(), om.V, om.use_color, what="frames %d.." % lo)
+        assert sorted(map(tuple, om.meshes_to_update().tolist())) == sorted(map(tuple, gm.GetMeshesToUpdate().tolist()))
+
+
+@pytest.mark.parametrize("batch", [2, 3, 8, 11])
+@pytest.mark.parametrize("color", [False, True])
+def test_batched_launch_equals_frame_by_frame(oracle_mod, batch, color):
+    """K frames in one launch set (voxel state kept in registers across frames) == the reference's frame-by-frame result,
+    including chunks created by one frame of the batch and carved / probed by a later one."""
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, color, carving=True, carving_dist=0.0, max_chunks=8192)
+    cam = small_camera(64, 48)
+    pose = synth.pose_yaw(0.0)
+    near_wall = np.full((48, 64), 1.2, np.float32)
+    far_wall = np.full((48, 64), 2.4, np.float32)
+    frames = [(near_wall, pose)] * 6 + [(far_wall, pose)] * 5 + make_frames("sphere_room", 6, 64, 48, agents=2, nan_fraction=0.02)
+    _run_batched(om, gm, integ, frames, cam, synth.render_color(64, 48, 3) if color else None, batch)
+
+
+@pytest.mark.parametrize("N,res,W,H", [(16, 0.04, 96, 72), (32, 0.02, 64, 48)])
+def test_batched_launch_chunk_sizes(oracle_mod, N, res, W, H):
+    om, gm, integ = _mk(oracle_mod, N, res, True, max_chunks=2048)
+    cam = small_camera(W, H)
+    _run_batched(om, gm, integ, make_frames("box_room", 8, W, H), cam, synth.render_color(W, H, 3), 4)
+
+
+def test_batch_mixed_image_sizes(oracle_mod):
+    """a batch whose frames differ in size is split into launch sets of equal size, order preserved"""
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, False)
+    intr_a, intr_b = synth.intrinsics(64, 48), synth.intrinsics(80, 60)
+    from cvids_amd.chisel import PinholeCamera
+    cam_a, cam_b = PinholeCamera(*intr_a, 64, 48), PinholeCamera(*intr_b, 80, 60)
+    fa = make_frames("sphere_room", 2, 64, 48)
+    fb = make_frames("sphere_room", 2, 80, 60, start=2)
+    seq = [(fa[0], cam_a, intr_a), (fb[0], cam_b, intr_b), (fb[1], cam_b, intr_b), (fa[1], cam_a, intr_a)]
+    for (d, p), cam, intr in seq:
+        om.integrate_depth(d, p, intr, cam.near_plane, cam.far_plane)
+    gm.IntegrateBatch(integ, [(d, p, cam) for (d, p), cam, _ in seq])
+    compare_fields(om.fields(), gm.fields(), om.V, False)
+
+
 def test_upload_download_roundtrip(oracle_mod):
     om, gm, integ = _mk(oracle_mod, 8, 0.05, True)
     rng = np.random.default_rng(3)

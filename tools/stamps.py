@@ -37,7 +37,7 @@ def main():
     L = m.L
     L.chisel_hip_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
     G = 2048
-    buf = np.zeros((G, 8), np.uint64)
+    buf = np.zeros((G, 32), np.uint64)
     ptr = buf.ctypes.data_as(C.POINTER(C.c_uint64))
     n_warm = args.frames - args.batch
     for i in range(n_warm):
@@ -64,7 +64,7 @@ def main():
             x = us(v)
             print("  %-16s n %5d  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, len(v), x.min(), np.median(x), np.percentile(x, 90), x.max()))
     w = s[:, 2] > 0
-    for a, b, name in ((0, 1, "entry->count"), (1, 2, "count->item"), (2, 3, "item->tile"), (3, 4, "tile->applied"), (4, 5, "applied->stored"), (5, 6, "stored->exit")):
+    for a, b, name in ((0, 1, "entry->count"), (1, 2, "count->item"), (2, 16, "item->prefetched"), (16, 17, "prefetched->staged(t0)"), (17, 3, "staged(t0)->barrier"), (3, 4, "tile->applied"), (4, 5, "applied->stored"), (5, 6, "stored->exit")):
         ok = w & (s[:, a] > 0) & (s[:, b] > 0)
         d = (s[ok, b] - s[ok, a]) / 100.0
         if len(d):
@@ -73,6 +73,16 @@ def main():
     if ok.any():
         mhz = s[ok, 7] / ((s[ok, 6] - s[ok, 0]) / 100.0)
         print("  shader clock during the kernel: p50 %.0f MHz (min %.0f, max %.0f)" % (np.median(mhz), mhz.min(), mhz.max()))
+    names = ["geometry+project", "record fetch", "band tests", "integrate", "colour", "carve"]
+    for k, nm in enumerate(names):
+        v = s[w, 8 + k]
+        print("  wave-0 cycles %-18s p50 %8.0f  p90 %8.0f  max %8.0f" % (nm, np.median(v), np.percentile(v, 90), v.max()))
+    tp = s[w, 14]
+    fl = s[w, 15]
+    bw, bh, nq = (fl >> 8) & 0xffff, (fl >> 24) & 0xffff, (fl >> 40) & 0xff
+    print("  staged tile pixels: p50 %d p90 %d max %d; items without a staged tile: %d of %d; flags inband %d carve %d tile %d" % (
+        np.median(tp), np.percentile(tp, 90), tp.max(), (tp == 0).sum(), len(tp), ((fl & 1) > 0).sum(), ((fl & 2) > 0).sum(), ((fl & 4) > 0).sum()))
+    print("  box w p50 %d max %d, h p50 %d max %d; needed quads of thread 0: p50 %d" % (np.median(bw), bw.max(), np.median(bh), bh.max(), np.median(nq)))
     print("counters:", m.counters())
 
 
