@@ -182,6 +182,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     run(m, first_timed, len(bounds))
+    t_issue = time.perf_counter() - t0  # host time to enqueue everything (no synchronisation yet)
     fence()
     dt = time.perf_counter() - t0
     m.synchronize()  # surfaces pool exhaustion
@@ -232,7 +233,7 @@ def main():
             "metric": METRIC, "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "mvoxel_updates_per_s": vals[0] / dt / 1e6,
+            "mvoxel_updates_per_s": vals[0] / dt / 1e6, "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "config": {"workload": "%dx%d %s stream (%s, %d agent%s), %g cm voxels, chunk %d^3, InverseTruncator(%g), carving 0.05 m, "
                                    "projective TSDF integration%s" % (W, H, "depth+BGR colour" if use_color else "depth-only",
                                                                         args.scene, args.agents, "" if args.agents == 1 else "s",

@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -47,6 +49,27 @@ struct IdHash {
 struct HostMesh {  // mesh/Mesh.h:54-58 (indices are implicit 0..n-1)
     std::vector<float> vertices, normals, colors, grids;
 };
+
+// host-side phase timer (CHISEL_HIP_HOST_TIMING=1): where does an integrate call spend its host time?
+struct HostTimer {
+    bool on = getenv("CHISEL_HIP_HOST_TIMING") != nullptr;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long calls = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int i) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+    ~HostTimer() {
+        if (on && calls)
+            fprintf(stderr, "chisel_hip host us/group: setup %.2f frames %.2f alloc %.2f pyramid-launch %.2f cull-launch %.2f integrate-launch %.2f (groups %ld)\n",
+                    acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls, acc[4] / calls, acc[5] / calls, calls);
+    }
+};
+HostTimer g_host_timer;
 
 struct ProfEvent {
     int kernel;
@@ -198,11 +221,13 @@ template <int N>
 int launch_group(chisel_hip_map *m, const PyramidParams &PP, const CullParams &CP, const IntegrateParams &IP, bool color) {
     using G = Geom<N>;
     const int total = CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2];
+    g_host_timer.lap(2);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID);
         dim3 grid((PP.W + 63) / 64, (PP.H + 63) / 64, IP.n_frames);
         hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, m->stream, PP, m->pyr, m->work_count);
     }
+    g_host_timer.lap(3);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_CULL);
         const dim3 cgrid((total + 63) / 64);
@@ -219,6 +244,7 @@ int launch_group(chisel_hip_map *m, const PyramidParams &PP, const CullParams &C
             hipLaunchKernelGGL((cull_kernel<N, 8>), cgrid, dim3(512), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
                                m->work_count, m->items_capacity);
     }
+    g_host_timer.lap(4);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
         const int grid = std::max(1, std::min(total, G::GRID));
@@ -235,6 +261,8 @@ int launch_group(chisel_hip_map *m, const PyramidParams &PP, const CullParams &C
                                m->items, m->boxes, m->work_count, m->items_capacity);
     }
     HIP_TRY(hipGetLastError());
+    g_host_timer.lap(5);
+    g_host_timer.calls++;
     return CHISEL_HIP_OK;
 }
 
@@ -250,6 +278,7 @@ int check_frame(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel
 
 // n <= KMAX frames of one image size, all with or all without colour, in one launch set
 int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors) {
+    g_host_timer.start();
     HIP_TRY(hipSetDevice(m->device));
     const int W = frames[0].width, H = frames[0].height;
     const size_t npx = (size_t)W * H;
@@ -310,6 +339,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         m->color_stage_bytes = color_bytes;
     }
 
+    g_host_timer.lap(0);
     int umin[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, umax[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
     for (int k = 0; k < n; k++) {
         const chisel_hip_depth_frame *f = &frames[k];
@@ -349,6 +379,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         }
         memcpy(CP.f[k].planes, fr.planes, sizeof(fr.planes));
     }
+    g_host_timer.lap(1);
     double total_d = 1.0;
     for (int a = 0; a < 3; a++) {
         CP.range_min[a] = umin[a];
@@ -363,7 +394,9 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         if (m->boxes) HIP_TRY(hipFree(m->boxes));
         m->items = nullptr;
         m->boxes = nullptr;
-        int cap = std::max(total, 4096);
+        // geometric growth: the candidate range changes with every pose, a reallocation (stream sync) must stay rare
+        int cap = std::max(1 << 17, m->items_capacity);
+        while (cap < total) cap *= 2;
         HIP_TRY(hipMalloc(&m->items, (size_t)cap * sizeof(WorkItem)));
         HIP_TRY(hipMalloc(&m->boxes, (size_t)cap * KMAX * sizeof(FrameBox)));
         m->items_capacity = cap;
