@@ -1,11 +1,287 @@
 // host_mesh.h -- mesh-side entry points of the C ABI (included by chisel_hip.hip).
-extern "C" {
-int chisel_hip_update_meshes(chisel_hip_map *m, int force) { (void)m; (void)force; return fail(CHISEL_HIP_ERR_UNSUPPORTED, "mesh extraction not built yet"); }
-int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) { if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null"); *out = (int64_t)m->meshes.size(); return CHISEL_HIP_OK; }
-int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) { (void)ids; (void)max_ids; if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null"); *count = 0; return CHISEL_HIP_OK; }
-int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_t *ng) { (void)m; (void)id; (void)nv; (void)ng; return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh"); }
-int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float *n, float *c, float *g) { (void)m; (void)id; (void)v; (void)n; (void)c; (void)g; return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh"); }
-int chisel_hip_get_sdf(chisel_hip_map *m, const float pos[3], double *dist, int *found) { (void)m; (void)pos; (void)dist; (void)found; return fail(CHISEL_HIP_ERR_UNSUPPORTED, "not built yet"); }
-int chisel_hip_get_sdf_and_gradient(chisel_hip_map *m, const float pos[3], double *dist, float grad[3], int *found) { (void)m; (void)pos; (void)dist; (void)grad; (void)found; return fail(CHISEL_HIP_ERR_UNSUPPORTED, "not built yet"); }
-int chisel_hip_save_ply(chisel_hip_map *m, const char *path) { (void)m; (void)path; return fail(CHISEL_HIP_ERR_UNSUPPORTED, "not built yet"); }
+//
+// Chisel::UpdateMeshes (Chisel.cpp:50-59) -> ChunkManager::RecomputeMeshes (ChunkManager.cpp:130-169): the ids flagged
+// since the last recompute are meshed on the GPU (kernels_mesh.h: jobs -> count -> host prefix sum -> emit into one
+// arena -> one D2H) and the results are kept on the host as the reference keeps ChunkManager::allMeshes.
+namespace {
+
+MeshParams mesh_params(const chisel_hip_map *m) {
+    MeshParams P;
+    P.res = m->cfg.voxel_resolution;
+    P.half_res = m->cfg.voxel_resolution * 0.5f;                    // ChunkManager.cpp:52
+    P.rf_chunk = 1.0f / ((float)m->N * m->cfg.voxel_resolution);    // ChunkManager.h:138-140
+    P.rf_voxel = 1.0f / m->cfg.voxel_resolution;                    // Chunk.cpp:74
+    P.use_color = m->cfg.use_color ? 1 : 0;
+    return P;
 }
+
+template <int N>
+void launch_mesh_count(chisel_hip_map *m, int n) {
+    hipLaunchKernelGGL(mesh_count_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, m->mesh_buf.jobs, m->mesh_buf.counts);
+}
+template <int N>
+void launch_mesh_emit(chisel_hip_map *m, int n, const MeshParams &P, float *v, float *nr, float *c, float *g) {
+    hipLaunchKernelGGL(mesh_emit_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, P, m->mesh_buf.jobs,
+                       m->mesh_buf.counts + 2 * (size_t)m->mesh_buf.capacity, v, nr, c, g);
+}
+
+int recompute_meshes(chisel_hip_map *m, const std::vector<int> &ids) {
+    const int n = (int)(ids.size() / 3);
+    if (n == 0) return CHISEL_HIP_OK;
+    MeshBuffers &B = m->mesh_buf;
+    if (n > B.capacity) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (B.jobs) HIP_TRY(hipFree(B.jobs));
+        if (B.ids) HIP_TRY(hipFree(B.ids));
+        if (B.counts) HIP_TRY(hipFree(B.counts));
+        B.jobs = nullptr; B.ids = nullptr; B.counts = nullptr;
+        int cap = std::max(4096, B.capacity);
+        while (cap < n) cap *= 2;
+        HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
+        HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
+        HIP_TRY(hipMalloc(&B.counts, (size_t)cap * 4 * sizeof(int)));
+        B.capacity = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(B.ids, ids.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(mesh_jobs_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, m->stream, m->view, B.ids, n, B.jobs);
+    {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+        switch (m->N) {
+            case 8: launch_mesh_count<8>(m, n); break;
+            case 16: launch_mesh_count<16>(m, n); break;
+            case 32: launch_mesh_count<32>(m, n); break;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<int> counts((size_t)n * 2), offsets((size_t)n * 2);
+    std::vector<MeshJob> jobs(n);
+    HIP_TRY(hipMemcpyAsync(counts.data(), B.counts, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(jobs.data(), B.jobs, (size_t)n * sizeof(MeshJob), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    size_t nv = 0, ng = 0;
+    for (int j = 0; j < n; j++) {
+        offsets[2 * j] = (int)nv;
+        offsets[2 * j + 1] = (int)ng;
+        nv += (size_t)counts[2 * j];
+        ng += (size_t)counts[2 * j + 1];
+        if (nv > 0x7fffffffull / 3) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^31 / 3 mesh vertices in one recompute");
+    }
+    const bool color = m->cfg.use_color != 0;
+    const size_t need = nv * 3 * (color ? 3 : 2) + ng * 3;
+    std::vector<float> host(need);
+    if (need) {
+        if (need > B.arena_floats) {
+            if (B.arena) HIP_TRY(hipFree(B.arena));
+            B.arena = nullptr;
+            size_t cap = std::max<size_t>(B.arena_floats, 1u << 22);
+            while (cap < need) cap *= 2;
+            HIP_TRY(hipMalloc(&B.arena, cap * sizeof(float)));
+            B.arena_floats = cap;
+        }
+        float *d_v = B.arena, *d_n = d_v + nv * 3, *d_c = d_n + nv * 3, *d_g = d_c + (color ? nv * 3 : 0);
+        HIP_TRY(hipMemcpyAsync(B.counts + 2 * (size_t)B.capacity, offsets.data(), (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        const MeshParams P = mesh_params(m);
+        {
+            ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+            switch (m->N) {
+                case 8: launch_mesh_emit<8>(m, n, P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 16: launch_mesh_emit<16>(m, n, P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 32: launch_mesh_emit<32>(m, n, P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host.data(), B.arena, need * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    const float *h_v = host.data(), *h_n = h_v + nv * 3, *h_c = h_n + nv * 3, *h_g = h_c + (color ? nv * 3 : 0);
+    for (int j = 0; j < n; j++) {
+        if (jobs[j].nslot[0] < 0) continue;  // RecomputeMesh: "if (!HasChunk(chunkID)) return" (ChunkManager.cpp:93-96)
+        const uint64_t key = pack_id(jobs[j].x, jobs[j].y, jobs[j].z);
+        const size_t cv = (size_t)counts[2 * j], cg = (size_t)counts[2 * j + 1];
+        auto it = m->meshes.find(key);
+        // the reference regenerates an existing Mesh object in place (it may become empty) and inserts a new one
+        // only when it has grids (ChunkManager.cpp:101-127)
+        if (it == m->meshes.end()) {
+            if (cg == 0) continue;
+            it = m->meshes.emplace(key, HostMesh()).first;
+        }
+        HostMesh &hm = it->second;
+        hm.vertices.assign(h_v + 3 * (size_t)offsets[2 * j], h_v + 3 * ((size_t)offsets[2 * j] + cv));
+        hm.normals.assign(h_n + 3 * (size_t)offsets[2 * j], h_n + 3 * ((size_t)offsets[2 * j] + cv));
+        if (color) hm.colors.assign(h_c + 3 * (size_t)offsets[2 * j], h_c + 3 * ((size_t)offsets[2 * j] + cv));
+        else hm.colors.clear();
+        hm.grids.assign(h_g + 3 * (size_t)offsets[2 * j + 1], h_g + 3 * ((size_t)offsets[2 * j + 1] + cg));
+    }
+    return CHISEL_HIP_OK;
+}
+
+int query_sdf(chisel_hip_map *m, const float pos[3], int with_gradient, double *dist, float *grad, int *found) {
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->mesh_buf.query) HIP_TRY(hipMalloc(&m->mesh_buf.query, 8 * sizeof(double)));
+    const MeshParams P = mesh_params(m);
+    switch (m->N) {
+        case 8: hipLaunchKernelGGL(query_sdf_kernel<8>, dim3(1), dim3(1), 0, m->stream, m->view, P, pos[0], pos[1], pos[2], with_gradient, m->mesh_buf.query); break;
+        case 16: hipLaunchKernelGGL(query_sdf_kernel<16>, dim3(1), dim3(1), 0, m->stream, m->view, P, pos[0], pos[1], pos[2], with_gradient, m->mesh_buf.query); break;
+        case 32: hipLaunchKernelGGL(query_sdf_kernel<32>, dim3(1), dim3(1), 0, m->stream, m->view, P, pos[0], pos[1], pos[2], with_gradient, m->mesh_buf.query); break;
+    }
+    double out[5];
+    HIP_TRY(hipMemcpyAsync(out, m->mesh_buf.query, sizeof(out), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (dist) *dist = out[0];
+    if (grad) {
+        grad[0] = (float)out[1];
+        grad[1] = (float)out[2];
+        grad[2] = (float)out[3];
+    }
+    if (found) *found = out[4] != 0.0 ? 1 : 0;
+    return CHISEL_HIP_OK;
+}
+
+// ids of all meshes, sorted (x, then y, then z) so that every listing / export is deterministic
+std::vector<uint64_t> sorted_mesh_keys(const chisel_hip_map *m) {
+    std::vector<uint64_t> keys;
+    keys.reserve(m->meshes.size());
+    for (const auto &kv : m->meshes) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end(), [](uint64_t a, uint64_t b) {
+        int ax, ay, az, bx, by, bz;
+        unpack_id(a, ax, ay, az);
+        unpack_id(b, bx, by, bz);
+        if (ax != bx) return ax < bx;
+        if (ay != by) return ay < by;
+        return az < bz;
+    });
+    return keys;
+}
+
+}  // namespace
+
+extern "C" {
+
+int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    if (m->cfg.n_shards > 1)
+        return fail(CHISEL_HIP_ERR_UNSUPPORTED, "meshing a sharded map needs the neighbour shards' border voxels: not built yet");
+    HIP_TRY(hipSetDevice(m->device));
+    // Chisel.cpp:53-58: "static int cnt = 0; if (cnt++ % 10 == 0)" -- the recompute runs on every 10th call
+    if (!force && (m->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;
+    int rc = check_device_error(m);
+    if (rc) return rc;
+    std::vector<int> dirty;
+    rc = fetch_listed(m, true, dirty, nullptr);
+    if (rc) return rc;
+    std::unordered_set<uint64_t, IdHash> all(m->pending_mesh_ids);
+    expand27(dirty, all);
+    std::vector<int> ids;
+    ids.reserve(all.size() * 3);
+    for (uint64_t key : all) {
+        int x, y, z;
+        unpack_id(key, x, y, z);
+        ids.push_back(x); ids.push_back(y); ids.push_back(z);
+    }
+    rc = recompute_meshes(m, ids);
+    if (rc) return rc;
+    // meshesToUpdate.clear() (Chisel.cpp:57)
+    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    HIP_TRY(hipGetLastError());
+    m->pending_mesh_ids.clear();
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) {
+    if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    *out = (int64_t)m->meshes.size();
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    const std::vector<uint64_t> keys = sorted_mesh_keys(m);
+    *count = (int64_t)keys.size();
+    if (ids)
+        for (int64_t k = 0; k < std::min<int64_t>(*count, max_ids); k++) unpack_id(keys[k], ids[3 * k], ids[3 * k + 1], ids[3 * k + 2]);
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_t *ng) {
+    if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    auto it = m->meshes.find(pack_id(id[0], id[1], id[2]));
+    if (it == m->meshes.end()) return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh for this chunk (ChunkManager::GetMesh would throw std::out_of_range)");
+    if (nv) *nv = (int64_t)it->second.vertices.size() / 3;
+    if (ng) *ng = (int64_t)it->second.grids.size() / 3;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float *n, float *c, float *g) {
+    if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    auto it = m->meshes.find(pack_id(id[0], id[1], id[2]));
+    if (it == m->meshes.end()) return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh for this chunk (ChunkManager::GetMesh would throw std::out_of_range)");
+    const HostMesh &hm = it->second;
+    if (v && !hm.vertices.empty()) memcpy(v, hm.vertices.data(), hm.vertices.size() * sizeof(float));
+    if (n && !hm.normals.empty()) memcpy(n, hm.normals.data(), hm.normals.size() * sizeof(float));
+    if (c && !hm.colors.empty()) memcpy(c, hm.colors.data(), hm.colors.size() * sizeof(float));
+    if (g && !hm.grids.empty()) memcpy(g, hm.grids.data(), hm.grids.size() * sizeof(float));
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_get_sdf(chisel_hip_map *m, const float pos[3], double *dist, int *found) {
+    if (!m || !pos) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    return query_sdf(m, pos, 0, dist, nullptr, found);
+}
+
+int chisel_hip_get_sdf_and_gradient(chisel_hip_map *m, const float pos[3], double *dist, float grad[3], int *found) {
+    if (!m || !pos) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    return query_sdf(m, pos, 1, dist, grad, found);
+}
+
+// Chisel::SaveAllMeshesToPLY (Chisel.cpp:69-105) + SaveMeshPLYASCII (io/PLY.cpp:29-88): same text format, same number
+// formatting (operator<< of float / int).  The reference concatenates the meshes in the iteration order of its
+// std::unordered_map (unspecified); here chunks are written in ascending id order.
+int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
+    if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    std::ofstream stream(path);
+    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    const std::vector<uint64_t> keys = sorted_mesh_keys(m);
+    size_t numPoints = 0;
+    bool any_color = false;
+    for (uint64_t k : keys) {
+        const HostMesh &hm = m->meshes.at(k);
+        numPoints += hm.vertices.size() / 3;
+        any_color = any_color || !hm.colors.empty();
+    }
+    stream << "ply" << std::endl;
+    stream << "format ascii 1.0" << std::endl;
+    stream << "element vertex " << numPoints << std::endl;
+    stream << "property float x" << std::endl;
+    stream << "property float y" << std::endl;
+    stream << "property float z" << std::endl;
+    if (any_color) {
+        stream << "property uchar red" << std::endl;
+        stream << "property uchar green" << std::endl;
+        stream << "property uchar blue" << std::endl;
+    }
+    stream << "element face " << numPoints / 3 << std::endl;
+    stream << "property list uchar int vertex_index" << std::endl;
+    stream << "end_header" << std::endl;
+    for (uint64_t k : keys) {
+        const HostMesh &hm = m->meshes.at(k);
+        for (size_t i = 0; i + 2 < hm.vertices.size(); i += 3) {
+            stream << hm.vertices[i] << " " << hm.vertices[i + 1] << " " << hm.vertices[i + 2];
+            if (any_color) {
+                const int r = static_cast<int>(hm.colors[i] * 255.0f);
+                const int g = static_cast<int>(hm.colors[i + 1] * 255.0f);
+                const int b = static_cast<int>(hm.colors[i + 2] * 255.0f);
+                stream << " " << r << " " << g << " " << b;
+            }
+            stream << std::endl;
+        }
+    }
+    for (size_t i = 0; i < numPoints; i += 3) {
+        stream << "3 ";
+        for (int j = 0; j < 3; j++) stream << (i + j) << " ";
+        stream << std::endl;
+    }
+    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("write failed: ") + path);
+    return CHISEL_HIP_OK;
+}
+
+}  // extern "C"
