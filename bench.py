@@ -10,7 +10,8 @@ Frames are synthetic (cvids_amd.synth: sphere room, 0.5 deg + 1 cm per frame) an
 HBM when the timed region starts.  Frames are handed to the library --batch at a time
 (chisel_hip_integrate_batch: one launch set applies them to every voxel in frame order; --batch 1 is the
 reference's frame-by-frame call pattern).  N > 1: one process per GPU, the chunk hash is sharded spatially
-(chisel_hip_config.n_shards), every batch is RCCL-broadcast from the GPU that ingested it and each rank
+(chisel_hip_config.n_shards); the frames of a batch are ingested round-robin (frame j on rank j * N / batch) and one
+RCCL all-gather per batch hands every rank the whole batch (cvids_amd.sharded.FrameExchange), then each rank
 integrates the chunks it owns -> total work is fixed: "scaling": "strong".
 
 One JSON line on rank 0.  `roofline` prices the integration kernel: algorithmic bytes per frame
@@ -54,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (functional check of the N > 1 logic on one GPU)")
     return ap.parse_args()
 
 
@@ -99,11 +101,16 @@ def main():
         if world == 1 and args.gpus > 1:
             print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus), file=sys.stderr)
             sys.exit(2)
+    if args.dist_backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)  # functional check: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     W, H = args.width, args.height
     intr = synth.intrinsics(W, H)
@@ -117,25 +124,36 @@ def main():
     frames = list(synth.stream(args.scene, n_traj, W, H, agents=args.agents))[:total]
     color_img = synth.render_color(W, H, 3) if use_color else None
 
-    # frames are ingested a batch at a time: batch b by rank b % world, its pixels live in that rank's HBM before timing starts
+    # frames are handed over a batch at a time; with N ranks frame j of a batch is ingested by rank j * N / K and its
+    # pixels live in that rank's HBM before timing starts
     import ctypes as C
     from cvids_amd import capi
     from cvids_amd.chisel import color_frame, depth_frame
+    from cvids_amd.sharded import FrameExchange, frames_of_rank, pack_meta
     K = max(1, args.batch)
+    if world > 1 and (K % world or args.warmup % K or args.steps % K):
+        K = max(world, (K // world) * world)
+        args.warmup = (args.warmup // K) * K
+        args.steps = max(K, (args.steps // K) * K)
+        total = args.warmup + args.steps
+        frames = frames[:total] if len(frames) >= total else list(synth.stream(args.scene, total, W, H, agents=args.agents))[:total]
     bounds = [(lo, min(lo + K, args.warmup)) for lo in range(0, args.warmup, K)] + \
              [(lo, min(lo + K, total)) for lo in range(args.warmup, total, K)]
-    root_of = [b % world for b in range(len(bounds))]
-    stack = [torch.from_numpy(np.stack([frames[i][0] for i in range(lo, hi)])).to(dev) if (world == 1 or root_of[b] == rank) else None
-             for b, (lo, hi) in enumerate(bounds)]
     c_dev = torch.from_numpy(color_img).to(dev) if use_color else None  # static colour pattern, resident on every rank
-    recv = [torch.empty((K, H, W), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+    xch = FrameExchange(W, H, K, dev, dist, channels=0) if world > 1 else None
+    if world == 1:
+        stack = [torch.from_numpy(np.stack([frames[i][0] for i in range(lo, hi)])).to(dev) for lo, hi in bounds]
+    else:
+        mine = frames_of_rank(K, world, rank)
+        stack = [torch.from_numpy(np.stack([frames[lo + j][0] for j in mine])).to(dev) for lo, hi in bounds]
+        meta = [torch.from_numpy(np.stack([pack_meta(frames[lo + j][1], cam) for j in mine])).to(dev) for lo, hi in bounds]
 
     # the C structs of every batch are built once, outside the timed region (device addresses are fixed)
     keep = []
     calls = []
     for b, (lo, hi) in enumerate(bounds):
         n = hi - lo
-        src = stack[b] if world == 1 else recv[b & 1]
+        src = stack[b] if world == 1 else xch.depth_view(b & 1)
         fa = (capi.DepthFrame * n)()
         ca = (capi.ColorFrame * n)() if use_color else None
         for j in range(n):
@@ -159,10 +177,7 @@ def main():
         for b in range(b_lo, b_hi):
             n, fa, ca = calls[b]
             if world > 1:
-                buf = recv[b & 1]
-                if root_of[b] == rank:
-                    buf[:n].copy_(stack[b], non_blocking=True)
-                dist.broadcast(buf, src=root_of[b])
+                xch.exchange(stack[b], meta[b])  # RCCL all-gather on the stream the kernels run on
             rc = L.chisel_hip_integrate_batch(h, n, fa, ca)
             if rc:
                 capi.check(rc)
@@ -240,7 +255,7 @@ def main():
                                                                         args.res * 100, args.chunk, scale,
                                                                         (" + marching cubes every %d frames" % args.mesh_every) if args.mesh_every else ""),
                        "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color, "frames_per_call": K,
-                       "parallelism": "spatial chunk-hash shards x%d, RCCL frame broadcast" % world if world > 1 else "1 GPU"},
+                       "parallelism": "spatial chunk-hash shards x%d, RCCL all-gather of each %d-frame batch" % (world, K) if world > 1 else "1 GPU"},
             "per_frame": {"voxel_updates": vals[0] / args.steps, "n_sdf": vals[1] / args.steps, "n_col": vals[2] / args.steps,
                           "n_probe": vals[4] / args.steps, "n_carved": vals[5] / args.steps,
                           "work_chunks": vals[6] / args.steps, "resident_chunks_end": vals[7]},

@@ -1,0 +1,136 @@
+"""Spatially sharded TSDF map: one process per GPU, every process owns the chunks `chunk_owner(id) == rank`.
+
+Voxels have exactly one owner and an update depends only on (the voxel, the frame, the pose), so the shards never
+exchange voxel data and no reduction exists on this path.  The only exchange step is the frame
+payload: every rank needs every depth(+colour) frame.  Frames are ingested round-robin -- frame j of a batch enters
+on rank j * world / K -- and one `all_gather` per batch hands every rank the whole batch: with K a multiple of the
+world size each GPU sends K/world frames over all of its xGMI links at once instead of one root pushing K frames
+through its own links (RCCL `ncclAllGather`; `gloo` in the CPU tests).  Poses / intrinsics travel the same way as
+a small float tensor.
+
+Nothing here computes on voxels: integration is `Chisel.IntegrateBatch` of the local shard (libchisel_hip.so).
+The local map is injected (`local_map`) so the distribution logic is testable on CPU with a recording stand-in.
+"""
+import numpy as np
+
+META_FLOATS = 20  # pose 12 + fx, fy, cx, cy + near, far + 2 spare
+
+
+def pack_meta(pose, camera):
+    m = np.zeros(META_FLOATS, np.float32)
+    m[:12] = np.asarray(pose, np.float32)[:3, :4].reshape(12)
+    m[12:18] = (camera.fx, camera.fy, camera.cx, camera.cy, camera.near_plane, camera.far_plane)
+    return m
+
+
+def unpack_meta(m, width, height):
+    from .chisel import PinholeCamera
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :4] = np.asarray(m[:12], np.float32).reshape(3, 4)
+    cam = PinholeCamera(float(m[12]), float(m[13]), float(m[14]), float(m[15]), width, height, float(m[16]), float(m[17]))
+    return pose, cam
+
+
+def frames_of_rank(n_frames, world, rank):
+    """indices (within a batch of n_frames) that `rank` ingests: contiguous blocks, so that all_gather output order is frame order"""
+    if n_frames % world:
+        raise ValueError("batch of %d frames does not split over %d ranks" % (n_frames, world))
+    per = n_frames // world
+    return list(range(rank * per, (rank + 1) * per))
+
+
+class FrameExchange:
+    """all_gather of one batch: every rank contributes the frames it ingested, every rank receives all of them in order.
+
+    One collective per batch: a frame travels as one fp32 row [H*W depth | META_PAD metadata] (colour, when exchanged,
+    as a second uint8 collective)."""
+
+    META_PAD = 32  # floats per frame after the pixels: keeps every frame's depth 16-byte aligned
+
+    def __init__(self, width, height, batch, device, dist_module=None, channels=0):
+        import torch
+        self.torch = torch
+        self.dist = dist_module
+        self.world = dist_module.get_world_size() if dist_module is not None else 1
+        self.rank = dist_module.get_rank() if dist_module is not None else 0
+        if batch % self.world:
+            raise ValueError("batch %d must be a multiple of the world size %d" % (batch, self.world))
+        self.batch, self.per = batch, batch // self.world
+        self.W, self.H, self.C = width, height, channels
+        self.row = width * height + self.META_PAD
+        # double-buffered on both sides: the kernels of batch b may still read buffer b & 1 while batch b+1 arrives
+        self.recv = [torch.zeros((batch, self.row), dtype=torch.float32, device=device) for _ in range(2)]
+        self.send = [torch.zeros((self.per, self.row), dtype=torch.float32, device=device) for _ in range(2)]
+        self.color = [torch.empty((batch, height, width, channels), dtype=torch.uint8, device=device) for _ in range(2)] if channels else None
+        self.turn = 0
+
+    def depth_view(self, b):
+        return self.recv[b][:, :self.W * self.H].unflatten(1, (self.H, self.W))
+
+    def meta_view(self, b):
+        return self.recv[b][:, self.W * self.H:self.W * self.H + META_FLOATS]
+
+    def exchange(self, local_depth, local_meta, local_color=None):
+        """local_*: this rank's `per` frames ([per, H, W] float32, [per, META_FLOATS], [per, H, W, C] uint8)."""
+        b = self.turn & 1
+        self.turn += 1
+        s = self.send[b]
+        s[:, :self.W * self.H].copy_(local_depth.reshape(self.per, -1), non_blocking=True)
+        s[:, self.W * self.H:self.W * self.H + META_FLOATS].copy_(local_meta, non_blocking=True)
+        if self.world == 1:
+            self.recv[b].copy_(s, non_blocking=True)
+            if self.C:
+                self.color[b].copy_(local_color, non_blocking=True)
+        elif self.dist.get_backend() == "gloo" and s.is_cuda:
+            # functional check only (gloo has no device all-gather): bounce through the host
+            host = self.torch.empty(self.recv[b].shape, dtype=self.torch.float32)
+            self.dist.all_gather_into_tensor(host.view(-1), s.cpu().view(-1))
+            self.recv[b].copy_(host)
+            if self.C:
+                hc = self.torch.empty(self.color[b].shape, dtype=self.torch.uint8)
+                self.dist.all_gather_into_tensor(hc.view(-1), local_color.contiguous().cpu().view(-1))
+                self.color[b].copy_(hc)
+        else:
+            self.dist.all_gather_into_tensor(self.recv[b].view(-1), s.view(-1))
+            if self.C:
+                self.dist.all_gather_into_tensor(self.color[b].view(-1), local_color.contiguous().view(-1))
+        return self.depth_view(b), self.meta_view(b), (self.color[b] if self.C else None)
+
+
+class ShardedChisel:
+    """chisel::Chisel surface over the shards of one node (only what the sharded path changes)."""
+
+    def __init__(self, local_map, exchange, integrator):
+        self.map = local_map
+        self.x = exchange
+        self.integrator = integrator
+
+    def IntegrateBatch(self, local_depth, local_poses, local_cameras, local_color=None):
+        """Every rank passes the frames it ingested (x.per of them); all ranks integrate the whole batch in frame order."""
+        torch = self.x.torch
+        meta = torch.from_numpy(np.stack([pack_meta(p, c) for p, c in zip(local_poses, local_cameras)])).to(local_depth.device)
+        depth, meta_all, color = self.x.exchange(local_depth, meta, local_color)
+        meta_host = meta_all.cpu().numpy()
+        frames, colors = [], ([] if color is not None else None)
+        for j in range(self.x.batch):
+            pose, cam = unpack_meta(meta_host[j], self.x.W, self.x.H)
+            frames.append((depth[j], pose, cam))
+            if color is not None:
+                colors.append((color[j], pose, cam))
+        self.map.IntegrateBatch(self.integrator, frames, colors)
+        return frames
+
+    def NumChunks(self):
+        torch, dist = self.x.torch, self.x.dist
+        n = torch.tensor([self.map.NumChunks()], dtype=torch.int64, device=self.x.recv[0].device)
+        if self.x.world > 1:
+            dist.all_reduce(n)
+        return int(n.item())
+
+    def GatherChunkIDs(self):
+        ids = np.asarray(self.map.GetChunkIDs(), np.int32).reshape(-1, 3)
+        if self.x.world == 1:
+            return ids
+        out = [None] * self.x.world
+        self.x.dist.all_gather_object(out, ids)
+        return np.concatenate(out, axis=0)

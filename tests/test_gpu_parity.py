@@ -321,6 +321,39 @@ def test_batch_mixed_image_sizes(oracle_mod):
     compare_fields(om.fields(), gm.fields(), om.V, False)
 
 
+@pytest.mark.parametrize("n_shards", [2, 4, 8])
+def test_spatial_shards_reproduce_the_unsharded_map(oracle_mod, n_shards):
+    """every voxel has one owner -> the union of the shards' chunks is bit-identical to one map (and to the
+    oracle); the shards are disjoint and each holds only chunks it owns.  All shards live on this one GPU here."""
+    from cvids_amd import chisel as ch
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    shards = [ch.Chisel((8, 8, 8), 0.05, True, max_chunks=8192, n_shards=n_shards, shard_rank=r) for r in range(n_shards)]
+    cam = small_camera(64, 48)
+    color = synth.render_color(64, 48, 3)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    frames = make_frames("sphere_room", 6, 64, 48, agents=2, nan_fraction=0.02)
+    for lo in range(0, len(frames), 4):
+        part = frames[lo:lo + 4]
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color)
+        for s_ in shards:
+            s_.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+    union = {}
+    tot = dict(sdf=0, col=0, probe=0)
+    for r, s_ in enumerate(shards):
+        f = s_.fields()
+        assert not (set(f) & set(union)), "shards overlap"
+        for cid in f:
+            assert ch.chunk_owner(cid, n_shards, 2) == r
+        union.update(f)
+        c = s_.counters()
+        for k in tot:
+            tot[k] += c[k]
+    compare_fields(om.fields(), union, om.V, True, what="%d shards" % n_shards)
+    assert len(union) == om.num_chunks()
+    assert min(len(s_.fields()) for s_ in shards) > 0
+
+
 def test_upload_download_roundtrip(oracle_mod):
     om, gm, integ = _mk(oracle_mod, 8, 0.05, True)
     rng = np.random.default_rng(3)

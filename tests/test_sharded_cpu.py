@@ -1,0 +1,125 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the sharded path's host logic: frame exchange, ownership, gathers.
+
+No GPU: the local shard map is a recording stand-in (tests only), the ownership function is the product's
+(chisel_hip_chunk_owner is a pure host function of libchisel_hip.so)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from cvids_amd import synth
+
+W, H, K = 32, 24, 4
+
+
+class RecordingMap:
+    """Stands in for cvids_amd.chisel.Chisel: records what IntegrateBatch received, owns ids by the product's ownership function."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.calls = rank, world, []
+
+    def IntegrateBatch(self, integrator, frames, colors=None):
+        self.calls.append(([(np.asarray(d.cpu()).copy(), np.asarray(p).copy(), (c.fx, c.fy, c.cx, c.cy, c.near_plane, c.far_plane, c.width, c.height))
+                            for d, p, c in frames],
+                           None if colors is None else [np.asarray(c.cpu()).copy() for c, _, _ in colors]))
+
+    def NumChunks(self):
+        return len(self.GetChunkIDs())
+
+    def GetChunkIDs(self):
+        from cvids_amd.chisel import chunk_owner
+        ids = [(x, y, z) for x in range(-3, 3) for y in range(-2, 2) for z in range(0, 4)]
+        return np.array([i for i in ids if chunk_owner(i, self.world, 2) == self.rank], np.int32).reshape(-1, 3)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, with_color, out):
+    import torch
+    import torch.distributed as dist
+    from cvids_amd.chisel import PinholeCamera
+    from cvids_amd.sharded import FrameExchange, ShardedChisel, frames_of_rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        intr = synth.intrinsics(W, H)
+        cam = PinholeCamera(*intr, W, H, 0.05, 5.0)
+        frames = list(synth.stream("sphere_room", 2 * K, W, H))
+        color = synth.render_color(W, H, 3)
+        x = FrameExchange(W, H, K, torch.device("cpu"), dist, channels=3 if with_color else 0)
+        local = RecordingMap(rank, world)
+        sm = ShardedChisel(local, x, integrator=None)
+        for b in range(2):
+            mine = [b * K + j for j in frames_of_rank(K, world, rank)]
+            depth = torch.from_numpy(np.stack([frames[i][0] for i in mine]))
+            col = torch.from_numpy(np.stack([color + np.uint8(i) for i in mine])) if with_color else None
+            sm.IntegrateBatch(depth, [frames[i][1] for i in mine], [cam] * len(mine), col)
+        # every rank must have received all frames of both batches, in frame order, bit for bit
+        for b in range(2):
+            got, gotc = local.calls[b]
+            assert len(got) == K
+            for j in range(K):
+                d, p, c = got[j]
+                assert np.array_equal(d.view(np.uint32), frames[b * K + j][0].view(np.uint32))
+                assert np.array_equal(p[:3], np.asarray(frames[b * K + j][1])[:3])
+                f32 = lambda v: float(np.float32(v))  # the payload carries fp32, like the C ABI's chisel_hip_depth_frame
+                assert c == (f32(cam.fx), f32(cam.fy), f32(cam.cx), f32(cam.cy), f32(cam.near_plane), f32(cam.far_plane), W, H)
+                if with_color:
+                    assert np.array_equal(gotc[j], color + np.uint8(b * K + j))
+        n_total = sm.NumChunks()
+        ids = sm.GatherChunkIDs()
+        out.put((rank, n_total, sorted(map(tuple, ids.tolist())), len(local.GetChunkIDs())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_color", [False, True])
+def test_frame_exchange_and_gathers_world2(hip_lib, with_color):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, with_color, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    all_ids = sorted((x, y, z) for x in range(-3, 3) for y in range(-2, 2) for z in range(0, 4))
+    for rank, n_total, ids, n_local in res:
+        assert n_total == len(all_ids) and ids == all_ids  # the shards partition the id set: complete and disjoint
+    assert res[0][3] + res[1][3] == len(all_ids) and min(res[0][3], res[1][3]) > len(all_ids) // 4  # and roughly balanced
+
+
+def test_ownership_is_a_partition(hip_lib):
+    from cvids_amd.chisel import chunk_owner
+    rng = np.random.default_rng(5)
+    ids = rng.integers(-500, 500, (4000, 3))
+    for world in (1, 2, 4, 8):
+        owners = np.array([chunk_owner(i, world, 2) for i in ids])
+        assert owners.min() >= 0 and owners.max() < world
+        if world > 1:
+            counts = np.bincount(owners, minlength=world)
+            assert counts.min() > 0.6 * len(ids) / world  # no starved shard
+    # super-blocks: the 2x2x2 chunks of one block share an owner
+    for base in ((0, 0, 0), (-2, 4, -6), (10, -8, 2)):
+        o = {chunk_owner((base[0] + a, base[1] + b, base[2] + c), 8, 2) for a in (0, 1) for b in (0, 1) for c in (0, 1)}
+        assert len(o) == 1
+
+
+def test_frames_of_rank():
+    from cvids_amd.sharded import frames_of_rank
+    for world in (1, 2, 4, 8):
+        got = sum((frames_of_rank(8, world, r) for r in range(world)), [])
+        assert got == list(range(8))
+    with pytest.raises(ValueError):
+        frames_of_rank(6, 4, 0)
