@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-frames", action="store_true", help="hand host (pageable) depth buffers to the library: the PCIe-inclusive rate (never `value`)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (functional check of the N > 1 logic on one GPU)")
     return ap.parse_args()
 
@@ -157,7 +158,7 @@ def main():
         fa = (capi.DepthFrame * n)()
         ca = (capi.ColorFrame * n)() if use_color else None
         for j in range(n):
-            fa[j], k1 = depth_frame(src[j], frames[lo + j][1], cam)
+            fa[j], k1 = depth_frame(frames[lo + j][0] if (args.host_frames and world == 1) else src[j], frames[lo + j][1], cam)
             keep.append(k1)
             if use_color:
                 ca[j], k2 = color_frame(c_dev, frames[lo + j][1], cam)
@@ -247,7 +248,7 @@ def main():
         out = {
             "metric": METRIC, "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host depth buffers: PCIe-inclusive)" if args.host_frames else ""),
             "mvoxel_updates_per_s": vals[0] / dt / 1e6, "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "config": {"workload": "%dx%d %s stream (%s, %d agent%s), %g cm voxels, chunk %d^3, InverseTruncator(%g), carving 0.05 m, "
                                    "projective TSDF integration%s" % (W, H, "depth+BGR colour" if use_color else "depth-only",

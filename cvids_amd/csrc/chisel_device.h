@@ -162,7 +162,7 @@ struct WorkItem {
 struct FrameBox {            // one per (work item, frame)
     short u0, v0, u1, v1;    // conservative pixel bounding box of the chunk (inclusive), depth camera
     int flags;
-    unsigned magic;          // ceil(2^32 / (u1 - u0 + 1)): division by the tile width in the staging loop
+    unsigned magic;          // ceil(2^32 / ((u1 - u0 + 1) / 2)): division by the tile width in record pairs (staging loop)
     // conservative camera-z bounds from the depth range under the box: a voxel can be in band only if
     // z_near < z < z_far and can take the carve test only if z < z_carve (-inf when carving is off)
     float z_near, z_far, z_carve;

@@ -284,8 +284,18 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
     fb.z_far = dmax + band + zslack;
     fb.z_carve = ip.carving ? (dmax - (tmin + ip.carving_dist - 1e-6f) + zslack) : -INFINITY;
     fb.pad = 0;
+    // the integration kernel stages the box with 16-byte LDS-DMA transfers (two records): even start, even width
+    if (tile && !(C.W & 1)) {
+        u0 &= ~1;
+        u1 |= 1;
+    } else {
+        tile = false;
+    }
     fb.u0 = (short)u0; fb.v0 = (short)v0; fb.u1 = (short)u1; fb.v1 = (short)v1;
-    fb.magic = (unsigned)((0x100000000ull + (unsigned long long)(u1 - u0)) / (unsigned long long)(u1 - u0 + 1));
+    {
+        const unsigned long long half_w = (unsigned long long)((u1 - u0 + 1) >> 1);
+        fb.magic = half_w ? (unsigned)((0x100000000ull + half_w - 1ull) / half_w) : 0u;  // ceil(2^32 / (width / 2))
+    }
     return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0);
 }
 

@@ -375,30 +375,24 @@ __device__ __attribute__((noinline)) int create_chunk(const MapView *__restrict_
     return -1;
 }
 
-// stage the pixel records of box (u0, v0, tw x th) of `rec` (row stride W) into LDS, 4 loads in flight per lane;
-// magic = ceil(2^32 / tw): row = floor(idx / tw) for idx < 2^16
-template <int BLOCK, int TILE>
-__device__ inline void stage_tile(PixelRec *s_tile, const PixelRec *__restrict__ rec, int W, int u0, int v0, int tw, int npx,
-                                  unsigned magic, int tid) {
-    const PixelRec *src = rec + (size_t)v0 * W + u0;
-    // fully unrolled (a rolled loop makes the compiler drain every outstanding load at its header, including the
-    // voxel-state reads issued just before); the loads are unconditional (index clamped into the box) so that
-    // four are in flight together
-#pragma unroll
-    for (int b = 0; b < (TILE + 4 * BLOCK - 1) / (4 * BLOCK); b++) {
-        const int base = b * 4 * BLOCK;
-        if (base >= npx) break;
-        PixelRec v[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = min(base + i * BLOCK + tid, npx - 1);
-            const int row = (int)__umulhi((unsigned)idx, magic);
-            v[i] = src[row * W + (idx - row * tw)];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int idx = base + i * BLOCK + tid;
-            if (idx < npx) s_tile[idx] = v[i];
+// Stage the pixel records of box (u0, v0, tw x th) of `rec` (row stride W) into the LDS tile with LDS-DMA
+// (global_load_lds_dwordx4: 16 bytes = two records per lane, no register staging, asynchronous: the transfer of the
+// next frame's tile runs under the current frame's arithmetic).  u0 and tw are even (cull kernel), so a record pair
+// never straddles a row and every source address is 16-byte aligned.  magic = ceil(2^32 / (tw / 2)).
+// Completion: the issuing wave's vmcnt, then a workgroup barrier before other waves read the tile.
+template <int BLOCK>
+__device__ inline void issue_tile_dma(PixelRec *lds_tile, const PixelRec *__restrict__ rec, int W, int u0, int v0, int tw, int npx,
+                                      unsigned magic, int tid) {
+    const int npairs = npx >> 1, tw2 = tw >> 1;
+    const int lane = tid & 63;
+    const PixelRec *src0 = rec + (size_t)v0 * W + u0;
+    for (int base = (tid & ~63); base < npairs; base += BLOCK) {  // wave-uniform trip count
+        const int pp = base + lane;
+        if (pp < npairs) {
+            const int row = (int)__umulhi((unsigned)pp, magic);
+            const PixelRec *src = src0 + (size_t)row * W + 2 * (pp - row * tw2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(lds_tile + 2 * base), 16, 0, 0);
         }
     }
 }
@@ -411,9 +405,10 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                                                                                          const int *__restrict__ work_count,
                                                                                          int max_items) {
     using G = Geom<N>;
-    __shared__ PixelRec s_tile[G::TILE_PIXELS];
+    __shared__ __attribute__((aligned(16))) PixelRec s_tiles[2][G::TILE_PIXELS];  // double buffer: the next frame's tile lands while this one is used
     __shared__ int s_flags[4];  // [2 * parity + 0]: a voxel was integrated this frame, [+1]: something changed this frame
     __shared__ int s_slot;
+    __shared__ unsigned s_changed;  // resident chunks: bit k = frame k changed some voxel (gathered once per item)
     const int tid = threadIdx.x;
 #ifdef CHISEL_STAMPS
 #define STAMP(i) do { if (tid == 0 && M.stamps) M.stamps[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -446,21 +441,23 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
         bool updated_any = false;
         __syncthreads();  // previous item's tile / flags / s_slot fully consumed
         if (tid < 4) s_flags[tid] = 0;
+        if (tid == 0) s_changed = 0u;
+        // A chunk that already exists is "resident" for every frame, so its waves need no per-frame agreement: they
+        // run through the batch independently (a barrier only where a staged tile must become visible) and report the
+        // frames that changed something once, at the end.  New chunks keep the per-frame hand-shake below.
+        const bool free_running = existed && (G::PASSES == 1);
+        unsigned lane_changed = 0u;
 
         ThreadState<G::QPT> S;
         thread_defaults(S, existed);
         if (G::PASSES == 1) thread_place<N>(ip, ox, oy, oz, tid, S);
         const size_t base0 = (size_t)(existed ? slot : 0) * G::V;
 
-        int parity = 0;
-        while (mask) {
-            const int k = __builtin_ctz(mask);
-            mask &= mask - 1;
-            const FrameCam &F = P.f[k];
+        // ---- frame loop, software pipelined: tile of frame k+1 in flight (LDS-DMA) while frame k is applied --------
+        auto frame_ctx = [&](int k, TileCtx &T, unsigned &magic, int &flags) {
             const FrameBox fb = boxes[(size_t)it * P.n_frames + k];
-            const int flags = __builtin_amdgcn_readfirstlane(fb.flags);
-            TileCtx T;
-            T.rec = F.rec;
+            flags = __builtin_amdgcn_readfirstlane(fb.flags);
+            T.rec = P.f[k].rec;
             T.u0 = __builtin_amdgcn_readfirstlane((int)fb.u0);
             T.v0 = __builtin_amdgcn_readfirstlane((int)fb.v0);
             T.tw = 0;
@@ -468,34 +465,60 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
             T.z_near = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_near)));
             T.z_far = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_far)));
             T.z_carve = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_carve)));
-            // ---- register-resident chunk: which quads can this frame touch?  Their state is requested now ------
-            unsigned need = 0;
-            if (G::PASSES == 1)
-                need = prefetch_frame<N, COLOR>(F, T, S, M.sdf + base0, M.wgt + base0, COLOR ? (M.rgbw + base0) : nullptr, tid);
-            if (it == (int)blockIdx.x) STAMP(16);
-            // ---- stage the pixel records under the chunk in LDS ------------------------------------
+            magic = (unsigned)__builtin_amdgcn_readfirstlane((int)fb.magic);
             if (flags & WI_TILE) {
                 const int tw = __builtin_amdgcn_readfirstlane((int)fb.u1) - T.u0 + 1;
                 const int th = __builtin_amdgcn_readfirstlane((int)fb.v1) - T.v0 + 1;
                 if (tw * th <= G::TILE_PIXELS) {
                     T.tw = tw;
                     T.th = th;
-                    stage_tile<G::BLOCK, G::TILE_PIXELS>(s_tile, F.rec, F.cam.W, T.u0, T.v0, tw, tw * th,
-                                         (unsigned)__builtin_amdgcn_readfirstlane((int)fb.magic), tid);
                 }
             }
+        };
+        int parity = 0;
+        TileCtx T;
+        unsigned magic;
+        int flags;
+        int k = __builtin_ctz(mask);
+        mask &= mask - 1;
+        frame_ctx(k, T, magic, flags);
+        if (T.tw) issue_tile_dma<G::BLOCK>(s_tiles[0], T.rec, P.f[k].cam.W, T.u0, T.v0, T.tw, T.tw * T.th, magic, tid);
+        while (true) {
+            const FrameCam &F = P.f[k];
+            PixelRec *s_tile = s_tiles[parity];
+            // ---- register-resident chunk: which quads can this frame touch?  Their state is requested now ------
+            unsigned need = 0;
+            if (G::PASSES == 1)
+                need = prefetch_frame<N, COLOR>(F, T, S, M.sdf + base0, M.wgt + base0, COLOR ? (M.rgbw + base0) : nullptr, tid);
+            if (it == (int)blockIdx.x) STAMP(16);
+            if (T.tw || !free_running) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed (and its voxel reads)
+                __syncthreads();  // [B] tile visible to every wave; the other buffer and the other parity's flags are free
+            }
             if (it == (int)blockIdx.x) STAMP(17);
-            __syncthreads();  // [B] tile visible; flags of the other parity are free to be reset
             if (it == (int)blockIdx.x) STAMP(3);
 #ifdef CHISEL_STAMPS
             if (it == (int)blockIdx.x && tid == 0 && M.stamps) {
                 M.stamps[(size_t)blockIdx.x * 32 + 14] = (unsigned long long)(T.tw * T.th);
-                M.stamps[(size_t)blockIdx.x * 32 + 15] = (unsigned long long)flags | ((unsigned long long)(fb.u1 - fb.u0 + 1) << 8) | ((unsigned long long)(fb.v1 - fb.v0 + 1) << 24) | ((unsigned long long)__popc(need) << 40);
+                M.stamps[(size_t)blockIdx.x * 32 + 15] = (unsigned long long)flags | ((unsigned long long)__popc(need) << 40);
             }
 #endif
             if (tid == 0) {
                 s_flags[2 * (parity ^ 1)] = 0;
                 s_flags[2 * (parity ^ 1) + 1] = 0;
+            }
+            // next frame: its tile starts to move now
+            const bool more = mask != 0;
+            int k_next = 0, flags_next = 0;
+            unsigned magic_next = 0;
+            TileCtx T_next;
+            if (more) {
+                k_next = __builtin_ctz(mask);
+                mask &= mask - 1;
+                frame_ctx(k_next, T_next, magic_next, flags_next);
+                if (T_next.tw)
+                    issue_tile_dma<G::BLOCK>(s_tiles[parity ^ 1], T_next.rec, P.f[k_next].cam.W, T_next.u0, T_next.v0, T_next.tw,
+                                             T_next.tw * T_next.th, magic_next, tid);
             }
             int t_ret = 0;
             if (G::PASSES == 1) {
@@ -524,17 +547,37 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                                                COLOR ? (M.rgbw + (size_t)slot * G::V) : nullptr, q0);
                 }
             }
-            if (t_ret & 1) s_flags[2 * parity] = 1;      // benign race: every writer stores 1
-            if (t_ret & 2) s_flags[2 * parity + 1] = 1;
-            __syncthreads();  // [C] flags complete; tile consumed
+            if (free_running) {
+                lane_changed |= (t_ret & 2) ? (1u << k) : 0u;
+            } else {
+                if (t_ret & 1) s_flags[2 * parity] = 1;      // benign race: every writer stores 1
+                if (t_ret & 2) s_flags[2 * parity + 1] = 1;
+                __syncthreads();  // [C] flags complete; tile consumed
+                const bool f_in = s_flags[2 * parity] != 0, f_ch = s_flags[2 * parity + 1] != 0;
+                resident |= f_in;
+                updated_any |= f_ch;
+                n_updated += (tid == 0 && f_ch);  // "needsUpdate" of the chunk for this frame (Chisel.h:85 / :167)
+            }
             if (it == (int)blockIdx.x) STAMP(4);
-            const bool f_in = s_flags[2 * parity] != 0, f_ch = s_flags[2 * parity + 1] != 0;
-            resident |= f_in;
-            updated_any |= f_ch;
-            n_updated += (tid == 0 && f_ch);  // "needsUpdate" of the chunk for this frame (Chisel.h:85 / :167)
             parity ^= 1;
+            if (!more) break;
+            k = k_next;
+            T = T_next;
+            magic = magic_next;
+            flags = flags_next;
         }
 
+        if (free_running) {
+            // frames that changed something, over all lanes of the workgroup
+            unsigned wmask = 0u;
+            for (int bit = 0; bit < P.n_frames; bit++)
+                if (__any((int)((lane_changed >> bit) & 1u))) wmask |= 1u << bit;
+            if ((tid & 63) == 0 && wmask) atomicOr(&s_changed, wmask);
+            __syncthreads();
+            const unsigned word = s_changed;
+            updated_any = word != 0u;
+            n_updated += (tid == 0) ? (unsigned)__popc(word) : 0u;  // "needsUpdate" per frame (Chisel.h:85 / :167)
+        }
         if (G::PASSES == 1) {
             if (!existed) {
                 if (!resident) continue;  // block-uniform: the reference creates and then erases this chunk in every frame
