@@ -203,12 +203,17 @@ __host__ __device__ inline void dist_integrate(float &sdf, float &w, float distU
     sdf = newDist;
     w = w + weightUpdate;
 }
-// ColorVoxel::Integrate ColorVoxel.h:65-85 (one channel)
+// ColorVoxel::Integrate ColorVoxel.h:65-85 (one channel):
+//   sat_0^255( ((float)weight * old + (float)(weightUpdate * new)) / (float)(weightUpdate + weight) ) truncated to uint8.
+// Numerator and denominator are small integers, exact in fp32, and the correctly rounded quotient of integers x / d can
+// only reach an integer when x / d is one (the nearest miss is 1/d away, d <= 510), so the truncated result is the
+// integer quotient: no fp32 division needed (checked exhaustively for every x, d in tests/test_oracle_kat.py).
 __host__ __device__ inline uint8_t color_channel(uint8_t old, uint8_t weight, uint8_t nw, uint8_t weightUpdate) {
-    float oldc = (float)old;
-    float upd = ((float)((float)(int)weight * oldc + (float)((int)weightUpdate * (int)nw))) / (float)((int)weightUpdate + (int)weight);
-    upd = fminf(fmaxf(upd, 0.0f), 255.0f);
-    return (uint8_t)upd;
+    const unsigned x = (unsigned)weight * (unsigned)old + (unsigned)weightUpdate * (unsigned)nw;
+    const unsigned d = (unsigned)weightUpdate + (unsigned)weight;
+    if (d == 0u) return 0;  // 0 / 0 = NaN: fminf(fmaxf(NaN, 0), 255) = 0
+    const unsigned q = x / d;
+    return (uint8_t)(q > 255u ? 255u : q);
 }
 __host__ __device__ inline uchar4 color_integrate(uchar4 c, uint8_t r, uint8_t g, uint8_t b, uint8_t wu) {
     if ((int)c.w >= 255 - (int)wu) return c;
@@ -237,6 +242,7 @@ __device__ inline void color_at(const uint8_t *data, int idx, int channels, uint
 // thresholds the reference compares in double against fp32 values, folded to fp32 (exactly equivalent):
 //   sdf < 1e-5 (double)  <=>  sdf < kSdfCarveThr,  kSdfCarveThr = smallest float >= 1e-5
 //   (ProjectionIntegrator.h:90,168)
-__host__ __device__ inline bool sdf_below_carve_threshold(float sdf) { return (double)sdf < 1e-5; }
+// (float)1e-5 = 9.99999974737875e-06 is the largest float below the double 1e-5, so the double comparison is "<=" on it
+__host__ __device__ inline bool sdf_below_carve_threshold(float sdf) { return sdf <= 1e-5f; }
 
 }  // namespace chisel_hip

@@ -486,6 +486,16 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
         while (true) {
             const FrameCam &F = P.f[k];
             PixelRec *s_tile = s_tiles[parity];
+            // next frame's scalars are requested first: their latency hides under this frame's vector work
+            const bool more = mask != 0;
+            int k_next = 0, flags_next = 0;
+            unsigned magic_next = 0;
+            TileCtx T_next;
+            if (more) {
+                k_next = __builtin_ctz(mask);
+                mask &= mask - 1;
+                frame_ctx(k_next, T_next, magic_next, flags_next);
+            }
             // ---- register-resident chunk: which quads can this frame touch?  Their state is requested now ------
             unsigned need = 0;
             if (G::PASSES == 1)
@@ -508,18 +518,9 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                 s_flags[2 * (parity ^ 1) + 1] = 0;
             }
             // next frame: its tile starts to move now
-            const bool more = mask != 0;
-            int k_next = 0, flags_next = 0;
-            unsigned magic_next = 0;
-            TileCtx T_next;
-            if (more) {
-                k_next = __builtin_ctz(mask);
-                mask &= mask - 1;
-                frame_ctx(k_next, T_next, magic_next, flags_next);
-                if (T_next.tw)
-                    issue_tile_dma<G::BLOCK>(s_tiles[parity ^ 1], T_next.rec, P.f[k_next].cam.W, T_next.u0, T_next.v0, T_next.tw,
-                                             T_next.tw * T_next.th, magic_next, tid);
-            }
+            if (more && T_next.tw)
+                issue_tile_dma<G::BLOCK>(s_tiles[parity ^ 1], T_next.rec, P.f[k_next].cam.W, T_next.u0, T_next.v0, T_next.tw,
+                                         T_next.tw * T_next.th, magic_next, tid);
             int t_ret = 0;
             if (G::PASSES == 1) {
                 t_ret = apply_frame<N, COLOR, SAMECAM>(ip, F, T, s_tile, need, resident, S, tally);
