@@ -137,10 +137,58 @@ __device__ inline void truncation_range(int kind, float param, float d0, float d
     tmax += slack;
 }
 
+// min / max of the valid depth over pixel box (u0, v0) .. (u1, v1): the finest pyramid level that covers the box with
+// at most 3 x 3 texels, read as nine unconditional (clamped, possibly repeated) loads so that they are in flight together
+__device__ inline void pyramid_minmax(const PyramidView &pyr, const float2 *__restrict__ pdata, float2 whole, int u0, int v0, int u1,
+                                      int v1, float &dmin, float &dmax) {
+    int l = PYR_LEVELS - 1;
+#pragma unroll
+    for (int k = PYR_LEVELS - 2; k >= 0; k--) {
+        const int s = PYR_L0 + k;
+        if (((u1 >> s) - (u0 >> s)) <= 2 && ((v1 >> s) - (v0 >> s)) <= 2) l = k;
+    }
+    const int s = PYR_L0 + l;
+    const float2 *lvl = pdata + pyr.off[l];
+    const int lw = pyr.w[l];
+    const int tx0 = u0 >> s, ty0 = v0 >> s, tx1 = u1 >> s, ty1 = v1 >> s;
+    dmin = INFINITY;
+    dmax = -INFINITY;
+    if (tx1 - tx0 <= 2 && ty1 - ty0 <= 2) {
+        float2 t[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) t[i] = lvl[min(ty0 + i / 3, ty1) * lw + min(tx0 + i % 3, tx1)];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            dmin = fminf(dmin, t[i].x);
+            dmax = fmaxf(dmax, t[i].y);
+        }
+    } else {  // box wider than 3 texels of the coarsest level (near-camera chunks): the extrema of the whole image
+        dmin = whole.x;
+        dmax = whole.y;
+    }
+}
+
+// min / max of the valid depth over the whole image of one frame: a wave reduces the coarsest level (<= a few hundred texels)
+__device__ inline float2 whole_image_minmax(const PyramidView &pyr, const float2 *__restrict__ pdata) {
+    const int L = PYR_LEVELS - 1, n = pyr.w[L] * pyr.h[L];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = (int)(threadIdx.x & 63); i < n; i += 64) {
+        const float2 t = pdata[pyr.off[L] + i];
+        mn = fminf(mn, t.x);
+        mx = fmaxf(mx, t.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    return make_float2(mn, mx);
+}
+
 // the per-frame test of one chunk; returns the FrameBox flags (0: this frame cannot touch the chunk)
 template <int N>
 __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFrame &F, const PyramidView &pyr,
-                                       const float2 *__restrict__ pdata, int cx, int cy, int cz, FrameBox &fb) {
+                                       const float2 *__restrict__ pdata, float2 whole, int cx, int cy, int cz, FrameBox &fb) {
     // the reference enumerates ids range_min .. range_min + range_dim - 1 (ChunkManager.cpp:189-199)
     if ((unsigned)(cx - F.range_min[0]) >= (unsigned)F.range_dim[0] || (unsigned)(cy - F.range_min[1]) >= (unsigned)F.range_dim[1] ||
         (unsigned)(cz - F.range_min[2]) >= (unsigned)F.range_dim[2])
@@ -187,22 +235,8 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
             su0 = (int)fmaxf(fu0, 0.0f); sv0 = (int)fmaxf(fv0, 0.0f);
             su1 = (int)fminf(fu1, (float)(C.W - 1)); sv1 = (int)fminf(fv1, (float)(C.H - 1));
         }
-        float dmin = INFINITY, dmax = -INFINITY;
-        int l = PYR_LEVELS - 1;
-#pragma unroll
-        for (int k = PYR_LEVELS - 2; k >= 0; k--) {
-            int sft = PYR_L0 + k;
-            if (((su1 >> sft) - (su0 >> sft)) <= 2 && ((sv1 >> sft) - (sv0 >> sft)) <= 2) l = k;
-        }
-        const int sft = PYR_L0 + l;
-        const float2 *lvl = pdata + pyr.off[l];
-        const int lw = pyr.w[l];
-        for (int ty = (sv0 >> sft); ty <= (sv1 >> sft); ty++)
-            for (int tx = (su0 >> sft); tx <= (su1 >> sft); tx++) {
-                float2 t = lvl[ty * lw + tx];
-                dmin = fminf(dmin, t.x);
-                dmax = fmaxf(dmax, t.y);
-            }
+        float dmin, dmax;
+        pyramid_minmax(pyr, pdata, whole, su0, sv0, su1, sv1, dmin, dmax);
         if (!(dmin <= dmax)) return 0;  // no valid depth under the chunk
         float tmin, tmax;
         truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
@@ -250,26 +284,9 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
         u1 = (int)fminf(fu1, (float)(C.W - 1)); v1 = (int)fminf(fv1, (float)(C.H - 1));
         tile = true;
     }
-    // depth extrema over the pixel box from the pyramid: the finest level that covers it with <= 3x3 texels
-    float dmin = INFINITY, dmax = -INFINITY;
-    int l = PYR_LEVELS - 1;
-#pragma unroll
-    for (int k = PYR_LEVELS - 2; k >= 0; k--) {
-        int s = PYR_L0 + k;
-        if (((u1 >> s) - (u0 >> s)) <= 2 && ((v1 >> s) - (v0 >> s)) <= 2) l = k;
-    }
-    {
-        // (at the coarsest level the loop may cover more than 3x3 texels: near-camera chunks only)
-        const int s = PYR_L0 + l;
-        const float2 *lvl = pdata + pyr.off[l];
-        const int lw = pyr.w[l];
-        for (int ty = (v0 >> s); ty <= (v1 >> s); ty++)
-            for (int tx = (u0 >> s); tx <= (u1 >> s); tx++) {
-                float2 t = lvl[ty * lw + tx];
-                dmin = fminf(dmin, t.x);
-                dmax = fmaxf(dmax, t.y);
-            }
-    }
+    // depth extrema over the pixel box from the pyramid
+    float dmin, dmax;
+    pyramid_minmax(pyr, pdata, whole, u0, v0, u1, v1, dmin, dmax);
     if (!(dmin <= dmax)) return 0;  // no valid depth under the chunk
     float tmin, tmax;
     truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
@@ -308,12 +325,19 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, 
     __shared__ int s_pos[64];
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's frame
+#ifdef CHISEL_STAMPS
+#define CSTAMP(i) do { if (threadIdx.x == 0 && M.stamps && blockIdx.x < INTEGRATE_MAX_GRID) M.stamps[(size_t)blockIdx.x * 32 + 26 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+    CSTAMP(0);
     const int total = P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
     const int c = blockIdx.x * 64 + lane;
     int cx = 0, cy = 0, cz = 0;
     FrameBox fb;
     fb.flags = 0;
     int fl = 0;
+    const float2 whole = (k < P.n_frames) ? whole_image_minmax(pyr, pyr.data + (size_t)k * P.pyr_stride) : make_float2(INFINITY, -INFINITY);
     if (c < total) {
         // reference order: x outer, y, z inner (ChunkManager.cpp:195-199)
         const int iz = c % P.range_dim[2];
@@ -321,11 +345,13 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, 
         const int ix = c / (P.range_dim[2] * P.range_dim[1]);
         cx = P.range_min[0] + ix; cy = P.range_min[1] + iy; cz = P.range_min[2] + iz;
         if (k < P.n_frames && chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank)
-            fl = cull_chunk_frame<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, cx, cy, cz, fb);
+            fl = cull_chunk_frame<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, whole, cx, cy, cz, fb);
     }
     fb.flags = fl;
     s_flags[k][lane] = fl;
+    CSTAMP(1);
     __syncthreads();
+    CSTAMP(2);
     if (k == 0) {
         // ---- merge the frames of each chunk, look the survivors up, compact ------------------------------------
         int f[KL];
@@ -384,7 +410,9 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, 
         }
         s_pos[lane] = pos;
     }
+    CSTAMP(3);
     __syncthreads();
+    CSTAMP(4);
     const int pos = s_pos[lane];
     if (pos >= 0 && k < P.n_frames) {
         if (fl == 0) {  // frames that cannot touch the chunk: a well-defined empty box
@@ -395,6 +423,8 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, 
         }
         boxes[(size_t)pos * P.n_frames + k] = fb;
     }
+    CSTAMP(5);
+#undef CSTAMP
 }
 
 }  // namespace chisel_hip

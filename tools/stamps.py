@@ -83,6 +83,16 @@ def main():
     print("  staged tile pixels: p50 %d p90 %d max %d; items without a staged tile: %d of %d; flags inband %d carve %d tile %d" % (
         np.median(tp), np.percentile(tp, 90), tp.max(), (tp == 0).sum(), len(tp), ((fl & 1) > 0).sum(), ((fl & 2) > 0).sum(), ((fl & 4) > 0).sum()))
     print("  box w p50 %d max %d, h p50 %d max %d; needed quads of thread 0: p50 %d" % (np.median(bw), bw.max(), np.median(bh), bh.max(), np.median(nq)))
+    cs = s[:, 26:32]
+    cl = cs[:, 0] > 0
+    if cl.any():
+        c0 = cs[cl, 0].min()
+        print("cull kernel blocks stamped: %d" % cl.sum())
+        for name, col in (("entry", 0), ("own frame judged (wave 0)", 1), ("after barrier 1", 2), ("merged+compacted", 3), ("after barrier 2", 4), ("exit", 5)):
+            v = cs[cl, col]
+            v = v[v > 0]
+            x = (v - c0) / 100.0
+            print("  cull %-26s n %5d  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, len(v), x.min(), np.median(x), np.percentile(x, 90), x.max()))
     print("counters:", m.counters())
 
 
