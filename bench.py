@@ -67,6 +67,26 @@ def algorithmic_bytes(cnt, n_frames, W, H, channels):
     return b
 
 
+def pmc_traffic(kernel_key, frames_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (tools/profile.sh -> profiles/*_digest.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs).  FETCH_SIZE is doubled
+    as MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte requests at 64 bytes); None when no digest fits."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_digest.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        k = d.get("kernels", {}).get(kernel_key)
+        if k and "fetch_kib" in k and "write_kib" in k and d.get("frames_per_launch", frames_per_launch) == frames_per_launch:
+            best = (f, k)
+    if not best:
+        return None, None
+    f, k = best
+    return (2.0 * k["fetch_kib"] + k["write_kib"]) * 1024.0, os.path.relpath(f, ROOT)
+
+
 def cpu_baseline(args, frames, color_img, intr, scale):
     import oracle
     om = oracle.OracleMap(args.chunk, args.res, not args.no_color, threads=16)
@@ -235,9 +255,11 @@ def main():
         avg_ms = k["ms"] / max(k["launches"], 1)
         bytes_per_launch = algorithmic_bytes(cb, args.steps, W, H, channels) / max(k["launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "integrate_kernel<%d,%s>" % (args.chunk, "true" if use_color else "false"),
+        kernel_key = "integrate_kernel<%d, %s, %s>" % (args.chunk, "true" if use_color else "false", "true" if use_color else "false")
+        traffic, traffic_src = pmc_traffic(kernel_key, args.steps / max(k["launches"], 1)) if world == 1 else (None, None)
+        roof = {"bound": "hbm", "kernel": kernel_key,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "avg_kernel_us": avg_ms * 1e3, "launches": k["launches"], "frames_per_launch": args.steps / max(k["launches"], 1),
+                "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_us": avg_ms * 1e3, "launches": k["launches"], "frames_per_launch": args.steps / max(k["launches"], 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "other_kernels_us": {n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "mesh")
                                      if prof[n]["launches"]},

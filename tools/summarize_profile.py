@@ -35,6 +35,22 @@ def main(out):
             print("== %s per dispatch (counter units: KiB per rocprofv3 definition):" % ctr, os.path.relpath(f, out))
             for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:12]:
                 print("  %-70s n %6d  avg %12.1f  total %14.1f" % (k, len(v), sum(v) / len(v), sum(v)))
+    # machine-readable digest next to the text: per kernel average duration and PMC bytes per dispatch
+    digest = {"kernels": {}}
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            digest["kernels"].setdefault(short(r["Name"]), {})["avg_us"] = float(r["AverageNs"]) / 1e3
+            digest["kernels"][short(r["Name"])]["calls"] = int(r["Calls"])
+    for tag, ctr, key in (("pmc_fetch", "FETCH_SIZE", "fetch_kib"), ("pmc_write", "WRITE_SIZE", "write_kib")):
+        for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
+            agg = defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == ctr:
+                    agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                digest["kernels"].setdefault(k, {})[key] = sum(v) / len(v)
+    import json
+    json.dump(digest, open(os.path.join(out, "digest.json"), "w"), indent=1, sort_keys=True)
     for name in ("bench_plain.json", "bench_trace.json"):
         p = os.path.join(out, name)
         if os.path.exists(p):
