@@ -1,0 +1,362 @@
+// open_chisel/Chisel.h -- the reference's class surface (chisel::Chisel, ProjectionIntegrator, ChunkManager, Chunk,
+// DistVoxel, ColorVoxel, Mesh) as thin host facades over the C ABI of libchisel_hip.so (include/chisel_hip.h).
+//
+// Same names, signatures, argument meaning and error behaviour as OpenChisel/open_chisel/include/open_chisel/*.h so
+// that chisel_ros::ChiselServer (chisel_ros/src/ChiselServer.cpp) compiles against these headers unchanged:
+//   - voxels and meshes live in HBM; ChunkManager::GetChunks() / GetChunk() / GetAllMeshes() materialise host
+//     mirrors lazily and the mirrors are invalidated by every integrate / update call;
+//   - GetChunk / GetMesh of an absent id throw std::out_of_range like the reference's unordered_map::at
+//     (ChunkManager.h:84-87, 171-178); bool results stay bool; C-ABI failures other than NOT_FOUND become
+//     std::runtime_error carrying chisel_hip_last_error().
+// Nothing is computed here: every call forwards to the C ABI.
+#ifndef CHISEL_HIP_FACADE_CHISEL_H_
+#define CHISEL_HIP_FACADE_CHISEL_H_
+#include <chisel_hip.h>
+
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "camera/PinholeCamera.h"
+#include "geometry/Geometry.h"
+#include "mesh/Mesh.h"
+#include "truncation/Truncator.h"
+#include "weighting/Weighter.h"
+
+namespace chisel {
+
+typedef Eigen::Vector3i ChunkID;
+#ifdef CHISEL_HIP_HAVE_EIGEN
+typedef std::vector<ChunkID, Eigen::aligned_allocator<ChunkID>> ChunkIDList;
+#else
+typedef std::vector<ChunkID> ChunkIDList;
+#endif
+struct ChunkHasher {  // ChunkManager.h:40-52
+    static constexpr size_t p1 = 73856093, p2 = 19349663, p3 = 8349279;
+    std::size_t operator()(const ChunkID &key) const { return (key(0) * p1 ^ key(1) * p2 ^ key(2) * p3); }
+};
+
+class DistVoxel {  // DistVoxel.h:33-77 (payload only: the update rules run in integrate_kernel)
+  public:
+    float GetSDF() const { return sdf; }
+    float GetWeight() const { return weight; }
+    void SetSDF(float v) { sdf = v; }
+    void SetWeight(float v) { weight = v; }
+    float sdf = 99999.0f, weight = 0.0f;
+};
+class ColorVoxel {  // ColorVoxel.h:33-100
+  public:
+    uint8_t GetRed() const { return red; }
+    uint8_t GetGreen() const { return green; }
+    uint8_t GetBlue() const { return blue; }
+    uint8_t GetWeight() const { return weight; }
+    uint8_t red = 0, green = 0, blue = 0, weight = 0;
+};
+
+class Chunk {  // Chunk.h:47-140: a host mirror of one device-resident chunk
+  public:
+    Chunk(const ChunkID &id, const Eigen::Vector3i &nv, float res, bool color)
+        : ID(id), numVoxels(nv), voxelResolutionMeters(res), voxels((size_t)nv(0) * nv(1) * nv(2)) {
+        if (color) colors.resize(voxels.size());
+        origin = Vec3(nv(0) * id(0) * res, nv(1) * id(1) * res, nv(2) * id(2) * res);  // Chunk.cpp:43
+    }
+    const ChunkID &GetID() const { return ID; }
+    const Eigen::Vector3i &GetNumVoxels() const { return numVoxels; }
+    float GetVoxelResolutionMeters() const { return voxelResolutionMeters; }
+    size_t GetTotalNumVoxels() const { return voxels.size(); }
+    bool HasColors() const { return !colors.empty(); }
+    bool HasVoxels() const { return !voxels.empty(); }
+    const std::vector<DistVoxel> &GetVoxels() const { return voxels; }
+    const std::vector<ColorVoxel> &GetColorVoxels() const { return colors; }
+    size_t GetVoxelID(int x, int y, int z) const { return (z * numVoxels(2) + y) * numVoxels(0) + x; }  // Chunk.h:81-84 (sic)
+    const DistVoxel &GetDistVoxel(size_t i) const { return voxels.at(i); }
+    const ColorVoxel &GetColorVoxel(size_t i) const { return colors.at(i); }
+    const Vec3 &GetOrigin() const { return origin; }
+  protected:
+    friend class ChunkManager;
+    ChunkID ID;
+    Eigen::Vector3i numVoxels;
+    float voxelResolutionMeters;
+    std::vector<DistVoxel> voxels;
+    std::vector<ColorVoxel> colors;
+    Vec3 origin;
+};
+typedef std::shared_ptr<Chunk> ChunkPtr;
+typedef std::shared_ptr<const Chunk> ChunkConstPtr;
+typedef std::unordered_map<ChunkID, ChunkPtr, ChunkHasher> ChunkMap;
+typedef std::unordered_map<ChunkID, bool, ChunkHasher> ChunkSet;
+typedef std::unordered_map<ChunkID, MeshPtr, ChunkHasher> MeshMap;
+
+inline void hip_check(int rc) {
+    if (rc != CHISEL_HIP_OK) throw std::runtime_error(std::string("chisel_hip: ") + chisel_hip_last_error());
+}
+
+class ProjectionIntegrator {  // ProjectionIntegrator.h:36-232 (Integrate / IntegrateColor per chunk run on the GPU)
+  public:
+    ProjectionIntegrator() : carvingDist(0), enableVoxelCarving(false) {}
+    ProjectionIntegrator(const TruncatorPtr &t, const WeighterPtr &w, float carvingDist_, bool enableCarving, const Vec3List &centroids_)
+        : truncator(t), weighter(w), carvingDist(carvingDist_), enableVoxelCarving(enableCarving), centroids(centroids_) {}
+    const TruncatorPtr &GetTruncator() const { return truncator; }
+    void SetTruncator(const TruncatorPtr &v) { truncator = v; }
+    const WeighterPtr &GetWeighter() const { return weighter; }
+    void SetWeighter(const WeighterPtr &v) { weighter = v; }
+    float GetCarvingDist() const { return carvingDist; }
+    bool IsCarvingEnabled() const { return enableVoxelCarving; }
+    void SetCarvingDist(float d) { carvingDist = d; }
+    void SetCarvingEnabled(bool e) { enableVoxelCarving = e; }
+    void SetCentroids(const Vec3List &c) { centroids = c; }  // kept for source compatibility: the kernels recompute centroids
+    chisel_hip_integrator HipStruct() const {
+        chisel_hip_integrator s;
+        s.truncator_kind = truncator ? truncator->HipKind() : CHISEL_HIP_TRUNC_INVERSE;
+        s.truncator_param = truncator ? truncator->HipParam() : 8.0f;
+        s.weight = weighter ? weighter->HipWeight() : 1.0f;
+        s.carving_enabled = enableVoxelCarving ? 1 : 0;
+        s.carving_dist = carvingDist;
+        return s;
+    }
+  protected:
+    TruncatorPtr truncator;
+    WeighterPtr weighter;
+    float carvingDist;
+    bool enableVoxelCarving;
+    Vec3List centroids;
+};
+
+class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
+  public:
+    ChunkManager() {}
+    ChunkManager(chisel_hip_map *m, const Eigen::Vector3i &cs, float res, bool color) : map(m), chunkSize(cs), voxelResolutionMeters(res), useColor(color) {
+        // CacheCentroids (ChunkManager.cpp:50-70)
+        const float half = res * 0.5f;
+        for (int z = 0; z < cs(2); z++)
+            for (int y = 0; y < cs(1); y++)
+                for (int x = 0; x < cs(0); x++) centroids.push_back(Vec3(x * res + half, y * res + half, z * res + half));
+    }
+    const Eigen::Vector3i &GetChunkSize() const { return chunkSize; }
+    float GetResolution() const { return voxelResolutionMeters; }
+    const Vec3List &GetCentroids() const { return centroids; }
+    bool HasChunk(const ChunkID &id) const {
+        const int v[3] = {id(0), id(1), id(2)};
+        int out = 0;
+        hip_check(chisel_hip_has_chunk(map, v, &out));
+        return out != 0;
+    }
+    bool HasChunk(int x, int y, int z) const { return HasChunk(ChunkID(x, y, z)); }
+    ChunkPtr GetChunk(const ChunkID &id) const {  // throws std::out_of_range like chunks.at(id) (ChunkManager.h:84-87)
+        const int v[3] = {id(0), id(1), id(2)};
+        const size_t V = (size_t)chunkSize(0) * chunkSize(1) * chunkSize(2);
+        std::vector<float> sdf(V), w(V);
+        std::vector<uint8_t> rgbw(useColor ? V * 4 : 0);
+        const int rc = chisel_hip_download_chunk(map, v, sdf.data(), w.data(), useColor ? rgbw.data() : nullptr);
+        if (rc == CHISEL_HIP_ERR_NOT_FOUND) throw std::out_of_range("ChunkManager::GetChunk");
+        hip_check(rc);
+        ChunkPtr c = std::make_shared<Chunk>(id, chunkSize, voxelResolutionMeters, useColor);
+        for (size_t i = 0; i < V; i++) {
+            c->voxels[i].sdf = sdf[i];
+            c->voxels[i].weight = w[i];
+            if (useColor) {
+                c->colors[i].red = rgbw[4 * i];
+                c->colors[i].green = rgbw[4 * i + 1];
+                c->colors[i].blue = rgbw[4 * i + 2];
+                c->colors[i].weight = rgbw[4 * i + 3];
+            }
+        }
+        return c;
+    }
+    // ids of all chunks; voxels are downloaded on demand by GetChunk (ChiselServer only walks the keys: ChiselServer.cpp:594-603)
+    const ChunkMap &GetChunks() const {
+        int64_t n = 0;
+        hip_check(chisel_hip_list_chunks(map, nullptr, 0, &n));
+        std::vector<int> ids((size_t)n * 3);
+        if (n) hip_check(chisel_hip_list_chunks(map, ids.data(), n, &n));
+        chunks.clear();
+        for (int64_t i = 0; i < n; i++) chunks[ChunkID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2])] = ChunkPtr();
+        return chunks;
+    }
+    const MeshMap &GetAllMeshes() const {
+        int64_t n = 0;
+        hip_check(chisel_hip_list_meshes(map, nullptr, 0, &n));
+        std::vector<int> ids((size_t)n * 3);
+        if (n) hip_check(chisel_hip_list_meshes(map, ids.data(), n, &n));
+        allMeshes.clear();
+        for (int64_t i = 0; i < n; i++) {
+            const ChunkID id(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+            allMeshes[id] = GetMesh(id);
+        }
+        return allMeshes;
+    }
+    bool HasMesh(const ChunkID &id) const {
+        const int v[3] = {id(0), id(1), id(2)};
+        int64_t nv = 0, ng = 0;
+        return chisel_hip_mesh_size(map, v, &nv, &ng) == CHISEL_HIP_OK;
+    }
+    MeshPtr GetMesh(const ChunkID &id) const {  // throws std::out_of_range like allMeshes.at(id) (ChunkManager.h:171-178)
+        const int v[3] = {id(0), id(1), id(2)};
+        int64_t nv = 0, ng = 0;
+        const int rc = chisel_hip_mesh_size(map, v, &nv, &ng);
+        if (rc == CHISEL_HIP_ERR_NOT_FOUND) throw std::out_of_range("ChunkManager::GetMesh");
+        hip_check(rc);
+        std::vector<float> ve((size_t)nv * 3), no((size_t)nv * 3), co(useColor ? (size_t)nv * 3 : 0), gr((size_t)ng * 3);
+        hip_check(chisel_hip_download_mesh(map, v, ve.data(), no.data(), useColor ? co.data() : nullptr, gr.data()));
+        MeshPtr mesh = std::make_shared<Mesh>();
+        for (int64_t i = 0; i < nv; i++) {
+            mesh->vertices.push_back(Vec3(ve[3 * i], ve[3 * i + 1], ve[3 * i + 2]));
+            mesh->normals.push_back(Vec3(no[3 * i], no[3 * i + 1], no[3 * i + 2]));
+            if (useColor) mesh->colors.push_back(Vec3(co[3 * i], co[3 * i + 1], co[3 * i + 2]));
+            mesh->indices.push_back((size_t)i);  // MarchingCubes.h:92-94: sequential
+        }
+        for (int64_t i = 0; i < ng; i++) mesh->grids.push_back(Vec3(gr[3 * i], gr[3 * i + 1], gr[3 * i + 2]));
+        return mesh;
+    }
+    bool RemoveChunk(const ChunkID &id) {  // ChunkManager.h:99-108
+        if (!HasChunk(id)) return false;
+        const int v[3] = {id(0), id(1), id(2)};
+        hip_check(chisel_hip_garbage_collect(map, v, 1));
+        return true;
+    }
+    bool GetSDF(const Vec3 &pos, double *dist) const {  // ChunkManager.cpp:476-499
+        const float p[3] = {pos(0), pos(1), pos(2)};
+        int found = 0;
+        hip_check(chisel_hip_get_sdf(map, p, dist, &found));
+        return found != 0;
+    }
+    bool GetSDFAndGradient(const Vec3 &pos, double *dist, Vec3 *grad) const {  // ChunkManager.cpp:449-474
+        const float p[3] = {pos(0), pos(1), pos(2)};
+        float g[3] = {0, 0, 0};
+        int found = 0;
+        hip_check(chisel_hip_get_sdf_and_gradient(map, p, dist, g, &found));
+        if (found && grad) *grad = Vec3(g[0], g[1], g[2]);
+        return found != 0;
+    }
+    void Reset() { hip_check(chisel_hip_reset(map)); }  // ChunkManager.cpp:176-180
+  protected:
+    chisel_hip_map *map = nullptr;
+    Eigen::Vector3i chunkSize;
+    float voxelResolutionMeters = 0.0f;
+    bool useColor = false;
+    Vec3List centroids;
+    mutable ChunkMap chunks;    // host mirrors, rebuilt on request
+    mutable MeshMap allMeshes;
+};
+
+class Chisel {  // Chisel.h:38-230
+  public:
+    Chisel() : map(nullptr) {}
+    Chisel(const Eigen::Vector3i &chunkSize, float voxelResolution, bool useColor) : map(nullptr) {
+        chisel_hip_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
+        for (int k = 0; k < 3; k++) cfg.chunk_size[k] = chunkSize(k);
+        cfg.voxel_resolution = voxelResolution;
+        cfg.use_color = useColor ? 1 : 0;
+        cfg.device_id = -1;
+        cfg.n_shards = 1;
+        hip_check(chisel_hip_create(&cfg, &map));
+        chunkManager = ChunkManager(map, chunkSize, voxelResolution, useColor);
+    }
+    virtual ~Chisel() {
+        if (map) chisel_hip_destroy(map);
+    }
+    Chisel(const Chisel &) = delete;
+    Chisel &operator=(const Chisel &) = delete;
+
+    const ChunkManager &GetChunkManager() const { return chunkManager; }
+    ChunkManager &GetMutableChunkManager() { return chunkManager; }
+
+    template <class DataType>
+    void IntegrateDepthScan(const ProjectionIntegrator &integrator, const std::shared_ptr<const DepthImage<DataType>> &depthImage,
+                            const Transform &extrinsic, const PinholeCamera &camera) {  // Chisel.h:59-112
+        static_assert(sizeof(DataType) == sizeof(float), "DepthImage<float>: convert 16UC1 millimetres on the caller's side as Conversions.h:140-150 does");
+        const chisel_hip_integrator in = integrator.HipStruct();
+        hip_check(chisel_hip_set_integrator(map, &in));
+        chisel_hip_depth_frame f = DepthFrame(*depthImage, extrinsic, camera);
+        hip_check(chisel_hip_integrate_depth(map, &f));
+        hip_check(chisel_hip_synchronize(map));  // the reference returns with every voxel update visible
+    }
+    template <class DataType, class ColorType>
+    void IntegrateDepthScanColor(const ProjectionIntegrator &integrator, const std::shared_ptr<const DepthImage<DataType>> &depthImage,
+                                 const Transform &depthExtrinsic, const PinholeCamera &depthCamera,
+                                 const std::shared_ptr<const ColorImage<ColorType>> &colorImage, const Transform &colorExtrinsic,
+                                 const PinholeCamera &colorCamera) {  // Chisel.h:114-213
+        static_assert(sizeof(DataType) == sizeof(float) && sizeof(ColorType) == 1, "DepthImage<float>, ColorImage<uint8_t>");
+        const chisel_hip_integrator in = integrator.HipStruct();
+        hip_check(chisel_hip_set_integrator(map, &in));
+        chisel_hip_depth_frame f = DepthFrame(*depthImage, depthExtrinsic, depthCamera);
+        chisel_hip_color_frame c;
+        std::memset(&c, 0, sizeof(c));
+        c.color = reinterpret_cast<const uint8_t *>(colorImage->GetData());
+        c.width = colorImage->GetWidth();
+        c.height = colorImage->GetHeight();
+        c.channels = colorImage->GetNumChannels();
+        Pose12(colorExtrinsic, c.pose);
+        c.fx = colorCamera.GetIntrinsics().GetFx();
+        c.fy = colorCamera.GetIntrinsics().GetFy();
+        c.cx = colorCamera.GetIntrinsics().GetCx();
+        c.cy = colorCamera.GetIntrinsics().GetCy();
+        hip_check(chisel_hip_integrate_depth_color(map, &f, &c));
+        hip_check(chisel_hip_synchronize(map));
+    }
+    void UpdateMeshes() { hip_check(chisel_hip_update_meshes(map, 0)); }  // Chisel.cpp:50-59 (every 10th call recomputes)
+    void GarbageCollect(const ChunkIDList &chunks) {  // Chisel.cpp:61-67
+        std::vector<int> ids;
+        for (const ChunkID &c : chunks) {
+            ids.push_back(c(0)); ids.push_back(c(1)); ids.push_back(c(2));
+        }
+        hip_check(chisel_hip_garbage_collect(map, ids.data(), (int)chunks.size()));
+    }
+    bool SaveAllMeshesToPLY(const std::string &filename) {  // Chisel.cpp:69-105
+        const int rc = chisel_hip_save_ply(map, filename.c_str());
+        if (rc == CHISEL_HIP_ERR_IO) return false;
+        hip_check(rc);
+        return true;
+    }
+    void Reset() {  // Chisel.cpp:44-48
+        hip_check(chisel_hip_reset(map));
+        meshesToUpdate.clear();
+    }
+    const ChunkSet &GetMeshesToUpdate() const {  // Chisel.h:220-223
+        int64_t n = 0;
+        hip_check(chisel_hip_meshes_to_update(map, nullptr, 0, &n));
+        std::vector<int> ids((size_t)n * 3);
+        if (n) hip_check(chisel_hip_meshes_to_update(map, ids.data(), n, &n));
+        meshesToUpdate.clear();
+        for (int64_t i = 0; i < n; i++) meshesToUpdate[ChunkID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2])] = true;
+        return meshesToUpdate;
+    }
+    chisel_hip_map *HipMap() const { return map; }
+
+  protected:
+    static void Pose12(const Transform &T, float out[12]) {
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) out[4 * r + c] = T.linear()(r, c);
+            out[4 * r + 3] = T.translation()(r);
+        }
+    }
+    template <class DataType>
+    static chisel_hip_depth_frame DepthFrame(const DepthImage<DataType> &img, const Transform &T, const PinholeCamera &cam) {
+        chisel_hip_depth_frame f;
+        std::memset(&f, 0, sizeof(f));
+        f.depth = reinterpret_cast<const float *>(img.GetData());
+        f.width = img.GetWidth();
+        f.height = img.GetHeight();
+        f.on_device = 0;
+        Pose12(T, f.pose);
+        f.fx = cam.GetIntrinsics().GetFx();
+        f.fy = cam.GetIntrinsics().GetFy();
+        f.cx = cam.GetIntrinsics().GetCx();
+        f.cy = cam.GetIntrinsics().GetCy();
+        f.near_plane = cam.GetNearPlane();
+        f.far_plane = cam.GetFarPlane();
+        return f;
+    }
+    chisel_hip_map *map;
+    ChunkManager chunkManager;
+    mutable ChunkSet meshesToUpdate;
+};
+typedef std::shared_ptr<Chisel> ChiselPtr;
+typedef std::shared_ptr<const Chisel> ChiselConstPtr;
+
+}  // namespace chisel
+#endif
