@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="frames per chisel_hip_integrate_batch call (<= 8 share one launch set)")
     ap.add_argument("--max-chunks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same stream the CPU oracle is timed on (about 1 s each at 1 cm)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-frames", action="store_true", help="hand host (pageable) depth buffers to the library: the PCIe-inclusive rate (never `value`)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (functional check of the N > 1 logic on one GPU)")
@@ -152,12 +152,8 @@ def main():
     from cvids_amd.chisel import color_frame, depth_frame
     from cvids_amd.sharded import FrameExchange, frames_of_rank, pack_meta
     K = max(1, args.batch)
-    if world > 1 and (K % world or args.warmup % K or args.steps % K):
-        K = max(world, (K // world) * world)
-        args.warmup = (args.warmup // K) * K
-        args.steps = max(K, (args.steps // K) * K)
-        total = args.warmup + args.steps
-        frames = frames[:total] if len(frames) >= total else list(synth.stream(args.scene, total, W, H, agents=args.agents))[:total]
+    if world > 1 and K % world:
+        K = max(world, (K // world) * world)  # every rank contributes K / world frame slots to each all-gather
     bounds = [(lo, min(lo + K, args.warmup)) for lo in range(0, args.warmup, K)] + \
              [(lo, min(lo + K, total)) for lo in range(args.warmup, total, K)]
     c_dev = torch.from_numpy(color_img).to(dev) if use_color else None  # static colour pattern, resident on every rank
@@ -165,9 +161,11 @@ def main():
     if world == 1:
         stack = [torch.from_numpy(np.stack([frames[i][0] for i in range(lo, hi)])).to(dev) for lo, hi in bounds]
     else:
+        # a short (last) batch leaves the trailing slots empty: the collective always moves K slots, only hi - lo are integrated
         mine = frames_of_rank(K, world, rank)
-        stack = [torch.from_numpy(np.stack([frames[lo + j][0] for j in mine])).to(dev) for lo, hi in bounds]
-        meta = [torch.from_numpy(np.stack([pack_meta(frames[lo + j][1], cam) for j in mine])).to(dev) for lo, hi in bounds]
+        blank = np.zeros((H, W), np.float32)
+        stack = [torch.from_numpy(np.stack([frames[lo + j][0] if lo + j < hi else blank for j in mine])).to(dev) for lo, hi in bounds]
+        meta = [torch.from_numpy(np.stack([pack_meta(frames[min(lo + j, hi - 1)][1], cam) for j in mine])).to(dev) for lo, hi in bounds]
 
     # the C structs of every batch are built once, outside the timed region (device addresses are fixed)
     keep = []
@@ -198,7 +196,7 @@ def main():
         for b in range(b_lo, b_hi):
             n, fa, ca = calls[b]
             if world > 1:
-                xch.exchange(stack[b], meta[b])  # RCCL all-gather on the stream the kernels run on
+                xch.exchange(stack[b], meta[b], buffer=b & 1)  # RCCL all-gather, ordered before the kernels on this stream
             rc = L.chisel_hip_integrate_batch(h, n, fa, ca)
             if rc:
                 capi.check(rc)
@@ -285,7 +283,7 @@ def main():
         }
         if roof:
             out["roofline"] = roof
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, frames[args.warmup:], color_img, intr, scale)
         print(json.dumps(out), flush=True)
     if world > 1:

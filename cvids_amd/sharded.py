@@ -70,9 +70,10 @@ class FrameExchange:
     def meta_view(self, b):
         return self.recv[b][:, self.W * self.H:self.W * self.H + META_FLOATS]
 
-    def exchange(self, local_depth, local_meta, local_color=None):
-        """local_*: this rank's `per` frames ([per, H, W] float32, [per, META_FLOATS], [per, H, W, C] uint8)."""
-        b = self.turn & 1
+    def exchange(self, local_depth, local_meta, local_color=None, buffer=None):
+        """local_*: this rank's `per` frame slots ([per, H, W] float32, [per, META_FLOATS], [per, H, W, C] uint8).
+        `buffer` (0 / 1) selects the receive buffer; by default the two alternate."""
+        b = (self.turn & 1) if buffer is None else (buffer & 1)
         self.turn += 1
         s = self.send[b]
         s[:, :self.W * self.H].copy_(local_depth.reshape(self.per, -1), non_blocking=True)
