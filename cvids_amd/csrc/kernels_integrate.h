@@ -32,6 +32,12 @@ namespace chisel_hip {
 #ifndef INTEGRATE_MIN_WAVES
 #define INTEGRATE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for: two 512-thread workgroups per CU
 #endif
+#ifndef INTEGRATE_TILE
+#define INTEGRATE_TILE 4096    // pixel records per LDS tile buffer (two buffers of 8 bytes per record)
+#endif
+#ifndef INTEGRATE_QG
+#define INTEGRATE_QG 1         // quads of a thread whose pixel-record fetches are in flight together (2: more ILP, more registers)
+#endif
 #ifndef INTEGRATE_QPT
 #define INTEGRATE_QPT 2        // quads (of 4 voxels) per thread; 1024 / QPT threads per 16^3 chunk
 #endif
@@ -70,8 +76,8 @@ struct Geom {
     static constexpr int PASSES = QUADS / SLAB_QUADS;                  // 1 (8^3, 16^3) or 8 (32^3)
     // record tile in LDS per workgroup (16 / 32 KiB).  Larger boxes belong to near-camera chunks whose voxels map to
     // distinct pixels: staging the whole box would move more bytes than gathering the records from L2 directly.
-    static constexpr int TILE_PIXELS = (N == 8) ? 2048 : 4096;
-    static constexpr int GRID = (N == 8) ? 4096 : ((BLOCK > 512) ? 512 : 1024);  // persistent grid: about what fits the chip at once
+    static constexpr int TILE_PIXELS = (N == 8) ? 2048 : INTEGRATE_TILE;
+    static constexpr int GRID = (N == 8) ? 4096 : ((BLOCK > 512) ? 512 : 1024);  // >= what is resident at once  // persistent grid: about what fits the chip at once
     static constexpr int MIN_WAVES = (N == 8) ? 1 : INTEGRATE_MIN_WAVES;
     static_assert(BLOCK % LAYER_QUADS == 0, "a thread's quads must share x and y");
     static_assert(GRID <= INTEGRATE_MAX_GRID, "per-workgroup counter rows");
@@ -206,7 +212,7 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
         ax2[j] = C.R[2] * dx;
     }
     int ret = 0;
-    constexpr int QG = (G::QPT < 2) ? 1 : 2;  // quads whose record fetches are in flight together
+    constexpr int QG = (G::QPT < INTEGRATE_QG) ? G::QPT : INTEGRATE_QG;  // quads whose record fetches are in flight together
 #pragma unroll
     for (int g = 0; g < G::QPT; g += QG) {
         if (!((need >> g) & ((1u << QG) - 1u))) continue;
