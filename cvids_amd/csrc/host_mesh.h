@@ -21,28 +21,68 @@ void launch_mesh_count(chisel_hip_map *m, int n) {
 }
 template <int N>
 void launch_mesh_emit(chisel_hip_map *m, int n, const MeshParams &P, float *v, float *nr, float *c, float *g) {
-    hipLaunchKernelGGL(mesh_emit_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, P, m->mesh_buf.jobs,
-                       m->mesh_buf.counts + 2 * (size_t)m->mesh_buf.capacity, v, nr, c, g);
+    const int *offsets = m->mesh_buf.counts + 2 * (size_t)m->mesh_buf.capacity;
+    hipLaunchKernelGGL(mesh_emit_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, P, m->mesh_buf.jobs, offsets, v, nr, g);
+    hipLaunchKernelGGL(mesh_shade_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, P, m->mesh_buf.jobs, offsets,
+                       m->mesh_buf.counts, v, nr, c);
 }
 
-int recompute_meshes(chisel_hip_map *m, const std::vector<int> &ids) {
-    const int n = (int)(ids.size() / 3);
+int ensure_mesh_jobs(chisel_hip_map *m, int n) {
+    MeshBuffers &B = m->mesh_buf;
+    if (n <= B.capacity) return CHISEL_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (B.jobs) HIP_TRY(hipFree(B.jobs));
+    if (B.ids) HIP_TRY(hipFree(B.ids));
+    if (B.counts) HIP_TRY(hipFree(B.counts));
+    B.jobs = nullptr; B.ids = nullptr; B.counts = nullptr;
+    int cap = std::max(4096, B.capacity);
+    while (cap < n) cap *= 2;
+    HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
+    HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
+    HIP_TRY(hipMalloc(&B.counts, (size_t)cap * 4 * sizeof(int)));
+    B.capacity = cap;
+    return CHISEL_HIP_OK;
+}
+
+// ids of the resident chunks to mesh, built on the device: the 27-neighbourhoods of the dirty slots, de-duplicated
+// through one flag per slot, plus `extra` host-side ids (neighbourhoods of chunks that were removed while dirty)
+int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra, int *n_out) {
+    MeshBuffers &B = m->mesh_buf;
+    const int C = m->view.max_chunks;
+    int rc = ensure_mesh_jobs(m, C);  // worst case: every resident chunk
+    if (rc) return rc;
+    if (!B.flags) {
+        HIP_TRY(hipMalloc(&B.flags, (size_t)C * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(B.flags, 0, (size_t)C * sizeof(unsigned), m->stream));
+    }
+    rc = ensure_scratch(m, 16);
+    if (rc) return rc;
+    int *d_count = m->scratch_i;
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), m->stream));
+    const long long threads = (long long)C * 27;
+    hipLaunchKernelGGL(mesh_mark_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, m->view, B.flags);
+    if (!extra.empty()) {
+        // (rare) ids kept on the host: flag the ones that are resident
+        const int ne = (int)(extra.size() / 3);
+        std::vector<int> slots;
+        rc = lookup_slots(m, extra.data(), ne, slots);
+        if (rc) return rc;
+        std::vector<unsigned> one(1, 1u);
+        for (int i = 0; i < ne; i++)
+            if (slots[i] >= 0) HIP_TRY(hipMemcpyAsync(B.flags + slots[i], one.data(), sizeof(unsigned), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    hipLaunchKernelGGL(mesh_collect_kernel, dim3((C + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, B.ids, d_count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(n_out, d_count, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHISEL_HIP_OK;
+}
+
+// meshes of the n chunks whose ids sit in mesh_buf.ids (device)
+int recompute_meshes(chisel_hip_map *m, int n) {
     if (n == 0) return CHISEL_HIP_OK;
     MeshBuffers &B = m->mesh_buf;
-    if (n > B.capacity) {
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        if (B.jobs) HIP_TRY(hipFree(B.jobs));
-        if (B.ids) HIP_TRY(hipFree(B.ids));
-        if (B.counts) HIP_TRY(hipFree(B.counts));
-        B.jobs = nullptr; B.ids = nullptr; B.counts = nullptr;
-        int cap = std::max(4096, B.capacity);
-        while (cap < n) cap *= 2;
-        HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
-        HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
-        HIP_TRY(hipMalloc(&B.counts, (size_t)cap * 4 * sizeof(int)));
-        B.capacity = cap;
-    }
-    HIP_TRY(hipMemcpyAsync(B.ids, ids.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(mesh_jobs_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, m->stream, m->view, B.ids, n, B.jobs);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
@@ -166,19 +206,17 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
     if (!force && (m->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;
     int rc = check_device_error(m);
     if (rc) return rc;
-    std::vector<int> dirty;
-    rc = fetch_listed(m, true, dirty, nullptr);
-    if (rc) return rc;
-    std::unordered_set<uint64_t, IdHash> all(m->pending_mesh_ids);
-    expand27(dirty, all);
-    std::vector<int> ids;
-    ids.reserve(all.size() * 3);
-    for (uint64_t key : all) {
+    std::vector<int> extra;
+    extra.reserve(m->pending_mesh_ids.size() * 3);
+    for (uint64_t key : m->pending_mesh_ids) {
         int x, y, z;
         unpack_id(key, x, y, z);
-        ids.push_back(x); ids.push_back(y); ids.push_back(z);
+        extra.push_back(x); extra.push_back(y); extra.push_back(z);
     }
-    rc = recompute_meshes(m, ids);
+    int n = 0;
+    rc = collect_mesh_ids(m, extra, &n);
+    if (rc) return rc;
+    rc = recompute_meshes(m, n);
     if (rc) return rc;
     // meshesToUpdate.clear() (Chisel.cpp:57)
     hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);

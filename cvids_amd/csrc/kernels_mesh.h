@@ -11,7 +11,8 @@
 // vertex / normal / colour / grid arrays of a chunk are element-for-element the reference's:
 //   mesh_jobs_kernel   : slots of the chunk and of its 7 "+" neighbours (the corners a border cube needs)
 //   mesh_count_kernel  : vertices and grids per chunk (case table popcount + block scan)
-//   mesh_emit_kernel   : same scan, then vertices, face normals, gradient normals and colours into one arena
+//   mesh_emit_kernel   : same scan, then vertices and face normals into one arena
+//   mesh_shade_kernel  : one thread per vertex: gradient normals and colours
 // A cube is meshed only when all 8 corner voxels have weight > 0.5 and every chunk they live in exists
 // (:271-276, :316-357); an absent neighbour simply reads as weight 0.
 #pragma once
@@ -208,6 +209,51 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
     return mk3(out[0], out[1], out[2]);
 }
 
+// meshesToUpdate on the device (Chisel.h:175-189 marks the 27-neighbourhood of every updated chunk): one thread per
+// (slot, neighbour offset); a resident neighbour of a dirty chunk gets its mesh flag set.  Ids of the neighbourhood
+// that are not resident have no chunk to mesh (RecomputeMesh returns at once: ChunkManager.cpp:93-96).
+__global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = t / 27, o = t % 27;
+    if (slot >= M.max_chunks || !M.slot_dirty[slot]) return;
+    const uint64_t key = M.slot_key[slot];
+    if (key == KEY_EMPTY) return;
+    int x, y, z;
+    unpack_id(key, x, y, z);
+    const int ns = (o == 13) ? slot : hash_find(M, x + o % 3 - 1, y + (o / 3) % 3 - 1, z + o / 9 - 1);
+    if (ns >= 0) mesh_flag[ns] = 1u;
+}
+
+// compaction of the flagged slots into the id list of the jobs (ballot + prefix popcount); clears the flags
+__global__ void mesh_collect_kernel(MapView M, unsigned *mesh_flag, int *ids, int *count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    uint64_t key = KEY_EMPTY;
+    if (i < M.max_chunks) {
+        keep = mesh_flag[i] != 0u;
+        if (keep) {
+            mesh_flag[i] = 0u;
+            key = M.slot_key[i];
+            keep = key != KEY_EMPTY;
+        }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = (int)__builtin_ctzll(mask);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, leader);
+    if (keep) {
+        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+        int x, y, z;
+        unpack_id(key, x, y, z);
+        ids[3 * pos] = x;
+        ids[3 * pos + 1] = y;
+        ids[3 * pos + 2] = z;
+    }
+}
+
 // slots of each listed chunk and its 7 "+" neighbours; one thread per (job, neighbour)
 __global__ void mesh_jobs_kernel(MapView M, const int *ids, int n, MeshJob *jobs) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,20 +280,45 @@ __device__ inline float2 corner_voxel(const MapView &M, const int (&nslot)[8], i
     return make_float2(M.sdf[off], M.wgt[off]);
 }
 
+// The (N+1)^3 corner voxels a chunk's cubes read -- the chunk plus one layer of its "+" neighbours -- staged once in
+// LDS as (sdf, weight) pairs (39 KiB for 16^3 chunks): every voxel is fetched from HBM once per kernel instead of
+// once per cube corner (8x).  32^3 chunks (287 KiB) do not fit and read their corners through L2.
+template <int N>
+struct CornerTile {
+    static constexpr bool STAGED = (N <= 16);
+    static constexpr int E = N + 1;
+    static constexpr int SIZE = STAGED ? E * E * E : 1;
+};
+
+template <int N>
+__device__ inline void stage_corners(const MapView &M, const int (&nslot)[8], float2 *s_vox) {
+    if (!CornerTile<N>::STAGED) return;
+    constexpr int E = N + 1;
+    for (int i = threadIdx.x; i < E * E * E; i += blockDim.x) {
+        const int cx = i % E, cy = (i / E) % E, cz = i / (E * E);
+        s_vox[i] = corner_voxel<N>(M, nslot, cx, cy, cz);
+    }
+    __syncthreads();
+}
+
 // cube (x, y, z): corner sdf values and the case index; false when a corner is unobserved (weight <= 0.5)
 template <int N>
-__device__ inline bool cube_config(const MapView &M, const int (&nslot)[8], int x, int y, int z, float (&s)[8], int &index) {
+__device__ inline bool cube_config(const MapView &M, const int (&nslot)[8], const float2 *s_vox, int x, int y, int z, float (&s)[8],
+                                   int &index) {
     // cubeIndexOffsets (ChunkManager.cpp:67-69)
     const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+    constexpr int E = N + 1;
     index = 0;
+    bool observed = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const float2 v = corner_voxel<N>(M, nslot, x + ox[i], y + oy[i], z + oz[i]);
-        if (v.y <= 0.5f) return false;  // :271 / :352
+        const float2 v = CornerTile<N>::STAGED ? s_vox[((z + oz[i]) * E + (y + oy[i])) * E + (x + ox[i])]
+                                               : corner_voxel<N>(M, nslot, x + ox[i], y + oy[i], z + oz[i]);
+        observed = observed && (v.y > 0.5f);  // :271 / :352 "weight <= 0.5 -> not observed"
         s[i] = v.x;
         index |= (v.x < 0.0f) ? (1 << i) : 0;  // MarchingCubes::CalculateVertexConfiguration MarchingCubes.h:108-118
     }
-    return true;
+    return observed;
 }
 
 // exclusive block scan of (a, b) pairs over BLOCK threads; returns this thread's offsets, totals in (ta, tb)
@@ -291,6 +362,7 @@ template <int N>
 __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const MeshJob *jobs, int *counts) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nslot[8];
+    __shared__ float2 s_vox[CornerTile<N>::SIZE];
     constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
     const MeshJob &job = jobs[blockIdx.x];
     if (threadIdx.x < 8) s_nslot[threadIdx.x] = job.nslot[threadIdx.x];
@@ -298,6 +370,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     int nslot[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) nslot[i] = s_nslot[i];
+    if (nslot[0] >= 0) stage_corners<N>(M, nslot, s_vox);  // block-uniform
     int nv = 0, ng = 0;
     if (nslot[0] >= 0) {
         for (int k = 0; k < CPT; k++) {
@@ -306,7 +379,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
             int x, y, z, index;
             float s[8];
             cube_of_rank<N>(r, x, y, z);
-            if (cube_config<N>(M, nslot, x, y, z, s, index)) {
+            if (cube_config<N>(M, nslot, s_vox, x, y, z, s, index)) {
                 const int c = c_mc_counts[index];
                 nv += c;
                 ng += (c != 0);  // IsOccupied (MarchingCubes.h:41-45)
@@ -333,9 +406,10 @@ __device__ inline f3v interpolate_vertex(f3v v1, f3v v2, float sdf1, float sdf2)
 // offsets[2*j], offsets[2*j+1]: first vertex / grid of job j in the arena (3 floats per entry)
 template <int N>
 __global__ __launch_bounds__(MESH_BLOCK) void mesh_emit_kernel(MapView M, MeshParams P, const MeshJob *jobs, const int *offsets,
-                                                                float *vertices, float *normals, float *colors, float *grids) {
+                                                                float *vertices, float *normals, float *grids) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nslot[8];
+    __shared__ float2 s_vox[CornerTile<N>::SIZE];
     constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
     const MeshJob &job = jobs[blockIdx.x];
     if (threadIdx.x < 8) s_nslot[threadIdx.x] = job.nslot[threadIdx.x];
@@ -343,6 +417,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_emit_kernel(MapView M, MeshPa
     int nslot[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) nslot[i] = s_nslot[i];
+    if (nslot[0] >= 0) stage_corners<N>(M, nslot, s_vox);  // block-uniform
     const int jx = job.x, jy = job.y, jz = job.z;
     // pass 1: this thread's share of the counts
     int nv = 0, ng = 0;
@@ -353,7 +428,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_emit_kernel(MapView M, MeshPa
             int x, y, z, index;
             float s[8];
             cube_of_rank<N>(r, x, y, z);
-            if (cube_config<N>(M, nslot, x, y, z, s, index)) {
+            if (cube_config<N>(M, nslot, s_vox, x, y, z, s, index)) {
                 const int c = c_mc_counts[index];
                 nv += c;
                 ng += (c != 0);
@@ -373,7 +448,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_emit_kernel(MapView M, MeshPa
         int x, y, z, index;
         float s[8];
         cube_of_rank<N>(r, x, y, z);
-        if (!cube_config<N>(M, nslot, x, y, z, s, index)) continue;
+        if (!cube_config<N>(M, nslot, s_vox, x, y, z, s, index)) continue;
         const unsigned long long row = c_mc_cases[index];
         if ((row & 0xF) == 0xF) continue;
         // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
@@ -401,25 +476,45 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_emit_kernel(MapView M, MeshPa
                 vertices[3 * vpos] = p[a].x;
                 vertices[3 * vpos + 1] = p[a].y;
                 vertices[3 * vpos + 2] = p[a].z;
-                // ComputeNormalsFromGradients (ChunkManager.cpp:609-626): the face normal stays when a lookup fails
-                f3v nrm = fn;
-                double dist;
-                f3v grad;
-                if (get_sdf_and_gradient<N>(M, P, p[a], jx, jy, jz, nslot[0], dist, grad)) {
-                    const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
-                    if ((double)mag > 1e-12) nrm = scl3(grad, 1.0f / mag);
-                }
-                normals[3 * vpos] = nrm.x;
-                normals[3 * vpos + 1] = nrm.y;
-                normals[3 * vpos + 2] = nrm.z;
-                if (P.use_color) {
-                    const f3v col = interpolate_color<N>(M, P, p[a], jx, jy, jz, nslot[0]);
-                    colors[3 * vpos] = col.x;
-                    colors[3 * vpos + 1] = col.y;
-                    colors[3 * vpos + 2] = col.z;
-                }
+                normals[3 * vpos] = fn.x;
+                normals[3 * vpos + 1] = fn.y;
+                normals[3 * vpos + 2] = fn.z;
                 vpos++;
             }
+        }
+    }
+}
+
+// Second half of RecomputeMesh, one thread per VERTEX (the per-cube loop above leaves most lanes idle: few cubes carry
+// triangles): ComputeNormalsFromGradients (ChunkManager.cpp:609-626: the face normal stays when a lookup fails) and
+// ColorizeMesh (:628-639).  Reads the vertices mesh_emit_kernel wrote (kernel boundary = visibility).
+template <int N>
+__global__ __launch_bounds__(MESH_BLOCK) void mesh_shade_kernel(MapView M, MeshParams P, const MeshJob *jobs, const int *offsets,
+                                                                 const int *counts, const float *vertices, float *normals, float *colors) {
+    const MeshJob &job = jobs[blockIdx.x];
+    const int nv = counts[2 * blockIdx.x];
+    if (nv == 0) return;
+    const size_t base = (size_t)offsets[2 * blockIdx.x];
+    const int jx = job.x, jy = job.y, jz = job.z, jslot = job.nslot[0];
+    for (int v = threadIdx.x; v < nv; v += MESH_BLOCK) {
+        const size_t i = base + v;
+        const f3v p = mk3(vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]);
+        double dist;
+        f3v grad;
+        if (get_sdf_and_gradient<N>(M, P, p, jx, jy, jz, jslot, dist, grad)) {
+            const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
+            if ((double)mag > 1e-12) {
+                const f3v nrm = scl3(grad, 1.0f / mag);
+                normals[3 * i] = nrm.x;
+                normals[3 * i + 1] = nrm.y;
+                normals[3 * i + 2] = nrm.z;
+            }
+        }
+        if (P.use_color) {
+            const f3v col = interpolate_color<N>(M, P, p, jx, jy, jz, jslot);
+            colors[3 * i] = col.x;
+            colors[3 * i + 1] = col.y;
+            colors[3 * i + 2] = col.z;
         }
     }
 }
@@ -446,6 +541,7 @@ struct MeshBuffers {
     int *ids = nullptr;
     int *counts = nullptr;   // [2 * capacity] counts, then [2 * capacity] offsets
     int capacity = 0;        // jobs
+    unsigned *flags = nullptr;  // [max_chunks] "mesh this slot"
     float *arena = nullptr;  // vertices | normals | colors | grids
     size_t arena_floats = 0;
     double *query = nullptr;
@@ -455,6 +551,7 @@ inline void free_mesh_buffers(MeshBuffers &b) {
     if (b.ids) (void)hipFree(b.ids);
     if (b.counts) (void)hipFree(b.counts);
     if (b.arena) (void)hipFree(b.arena);
+    if (b.flags) (void)hipFree(b.flags);
     if (b.query) (void)hipFree(b.query);
     b = MeshBuffers();
 }
