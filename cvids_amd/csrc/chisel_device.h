@@ -224,6 +224,21 @@ __host__ __device__ inline uchar4 color_integrate(uchar4 c, uint8_t r, uint8_t g
     o.w = (uint8_t)(c.w + wu);
     return o;
 }
+// color_integrate for weightUpdate == 1 and weight < 8 (the only call of the integrator: ProjectionIntegrator.h:152-157), with
+// the new colour given as a packed word, red in bits 0-7, green 8-15, blue 16-23.  The integer quotient x / d, d = weight + 1
+// in 1..8, x = weight * old + new <= 255 d, is taken without a division: (x + 0.5) / d lies at least 1/16 away from every
+// integer, the reciprocal is good to 1 ulp and x + 0.5 < 2^12, so truncating (x + 0.5) * rcp(d) gives floor(x / d)
+// (checked against color_integrate for every (weight, old, new) in tests/test_oracle_kat.py).
+__device__ inline unsigned color_integrate_fresh(unsigned c, unsigned rgb) {
+    const unsigned w = c >> 24;
+    const float wf = (float)w;
+    const float r = __builtin_amdgcn_rcpf(wf + 1.0f);
+    const float x0 = __builtin_fmaf(wf, (float)(c & 0xffu), (float)(rgb & 0xffu) + 0.5f);
+    const float x1 = __builtin_fmaf(wf, (float)((c >> 8) & 0xffu), (float)((rgb >> 8) & 0xffu) + 0.5f);
+    const float x2 = __builtin_fmaf(wf, (float)((c >> 16) & 0xffu), (float)((rgb >> 16) & 0xffu) + 0.5f);
+    const unsigned q0 = (unsigned)(x0 * r), q1 = (unsigned)(x1 * r), q2 = (unsigned)(x2 * r);
+    return q0 | (q1 << 8) | (q2 << 16) | ((w + 1u) << 24);
+}
 // ColorImage::At ColorImage.h:72-107 -> (red, green, blue)
 __device__ inline void color_at(const uint8_t *data, int idx, int channels, uint8_t &r, uint8_t &g, uint8_t &b) {
     const uint8_t *p = data + (size_t)idx * channels;
@@ -237,6 +252,20 @@ __device__ inline void color_at(const uint8_t *data, int idx, int channels, uint
         g = p[1];
         b = p[0];
     }
+}
+// ColorImage::At of 3 / 4 channel images as one 4-byte gather: color_gather() requests the pixel's bytes (byte address
+// channels * idx is not aligned; the last pixel of a 3-channel image is read from 1 byte lower so that no byte past the image
+// is touched), color_word() turns them into red | green << 8 | blue << 16 once they are needed.  image_bytes = W * H * channels.
+typedef unsigned __attribute__((aligned(1))) unaligned_u32;
+__device__ inline unsigned color_gather(const uint8_t *data, int idx, int channels, unsigned image_bytes, unsigned &shift) {
+    const unsigned b = (unsigned)idx * (unsigned)channels;
+    const unsigned lo = (b + 4u > image_bytes) ? image_bytes - 4u : b;
+    shift = (b - lo) * 8u;
+    return *reinterpret_cast<const unaligned_u32 *>(data + lo);
+}
+__device__ inline unsigned color_word(unsigned raw, unsigned shift) {
+    const unsigned v = raw >> shift;  // B | G << 8 | R << 16 (| A << 24)
+    return ((v >> 16) & 0xffu) | (v & 0xff00u) | ((v & 0xffu) << 16);
 }
 
 // thresholds the reference compares in double against fp32 values, folded to fp32 (exactly equivalent):

@@ -836,6 +836,15 @@ int chisel_hip_kat_color(const uint8_t *ops, int n, uint8_t *out) {
     (void)hipFree(d_in); (void)hipFree(d_out);
     return CHISEL_HIP_OK;
 }
+int chisel_hip_kat_color_fresh(unsigned *mismatches) {
+    unsigned *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(kat_color_fresh_kernel, dim3(8 * 256 * 256 / 256), dim3(256), 0, 0, d);
+    HIP_TRY(hipMemcpy(mismatches, d, sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return CHISEL_HIP_OK;
+}
 // diagnostic builds (-DCHISEL_STAMPS): allocate / read back the per-workgroup stamp buffer of integrate_kernel
 int chisel_hip_debug_stamps(chisel_hip_map *m, unsigned long long *out, int n_groups) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");

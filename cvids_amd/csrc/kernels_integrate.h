@@ -45,13 +45,17 @@ namespace chisel_hip {
 struct Tally {
     unsigned sdf, col, colsat, probe, carved;
 #ifdef CHISEL_STAMPS
-    unsigned long long cyc[6];  // shader cycles of wave phases: geometry+project, record fetch, band tests, integrate, colour, carve
+    unsigned long long cyc[6];  // shader cycles of wave 0 in the frame loop: scalars + z tests, tile wait + barrier, apply, hand-shake, item prologue; [5] = iterations
+    unsigned lanes[4];          // lanes that entered: the projection of a quad, the band update, the colour update, the carve test
+    float wave64[4];            // 64 / (lanes of the wave that entered together): sums to 64 per wave-level execution
 #endif
 };
 #ifdef CHISEL_STAMPS
-#define PHASE_BEGIN() unsigned long long ph_t = __builtin_amdgcn_s_memtime()
-#define PHASE_END(i) do { unsigned long long ph_n = __builtin_amdgcn_s_memtime(); tally.cyc[i] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#define PHASE_BEGIN() do { } while (0)
+#define PHASE_END(i) do { } while (0)
+#define REGION(i) do { tally.lanes[i] += 1u; tally.wave64[i] += 64.0f / (float)__popcll(__ballot(1)); } while (0)
 #else
+#define REGION(i) do { } while (0)
 #define PHASE_BEGIN() do { } while (0)
 #define PHASE_END(i) do { } while (0)
 #endif
@@ -221,6 +225,7 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
         float pcz[QG][4];
         bool any_out = false;
         PixelRec r[QG][4];
+        REGION(0);
         PHASE_BEGIN();
         // ---- phase A: geometry + projection -> pixel of every voxel of the group ------------------------------
 #pragma unroll
@@ -271,9 +276,6 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
                     if (on[e][j] & !in_tile) r[e][j] = gr;
                 }
         }
-#ifdef CHISEL_STAMPS
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         PHASE_END(1);
         // ---- phase C: band tests and updates, quad by quad ------------------------------------------------------
 #pragma unroll
@@ -294,6 +296,30 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
             }
             PHASE_END(2);
             if (any_band) {
+                REGION(1);
+                // colour first: the pixels of the in-band voxels whose colour weight is below 8 are requested now (one 4-byte
+                // gather per voxel, all in flight) and consumed after the sdf arithmetic
+                bool fresh[4];
+                unsigned cw[4], csh[4];
+                int cpix[4];
+                bool any_fresh = false;
+                const bool word_gather = COLOR && F.color_channels >= 3;  // wave-uniform
+                if (COLOR) {
+                    const unsigned image_bytes = (unsigned)(F.ccam.W * F.ccam.H * F.color_channels);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        cpix[j] = SAMECAM ? (iv[e][j] * C.W + iu[e][j]) : (band[e][j] ? color_pixel(F.ccam, S.wx[j], S.wy, S.wz[p]) : -1);
+                        const bool has = band[e][j] & (cpix[j] >= 0);
+                        fresh[j] = has & ((u4(S.c4[p], j) >> 24) < 8u);  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
+                        if (!SAMECAM) tally.colsat += has & !fresh[j];  // one camera: every in-band voxel has a colour pixel, colsat = sdf - col
+                        tally.col += fresh[j];
+                        any_fresh |= fresh[j];
+                    }
+                    if (word_gather && any_fresh) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) cw[j] = color_gather(F.color, fresh[j] ? cpix[j] : 0, F.color_channels, image_bytes, csh[j]);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float wu = 1.0f;                                         // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84
@@ -306,29 +332,33 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
                 S.dchg |= 1u << p;
                 ret |= 3;
                 PHASE_END(3);
-                if (COLOR) {
+                if (COLOR && any_fresh) {
+                    REGION(2);
+                    if (word_gather) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int cpix = SAMECAM ? (iv[e][j] * C.W + iu[e][j])
-                                                 : (band[e][j] ? color_pixel(F.ccam, S.wx[j], S.wy, S.wz[p]) : -1);
-                        const bool has = band[e][j] & (cpix >= 0);
-                        const bool fresh_col = has & ((u4(S.c4[p], j) >> 24) < 8u);  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
-                        if (!SAMECAM) tally.colsat += has & !fresh_col;  // one camera: every in-band voxel has a colour pixel, colsat = sdf - col
-                        tally.col += fresh_col;
-                        if (fresh_col) {
-                            unsigned cbits = u4(S.c4[p], j);
-                            uchar4 cv = *reinterpret_cast<uchar4 *>(&cbits);
-                            uint8_t cr, cg, cb;
-                            color_at(F.color, cpix, F.color_channels, cr, cg, cb);
-                            cv = color_integrate(cv, cr, cg, cb, 1);
-                            u4(S.c4[p], j) = *reinterpret_cast<unsigned *>(&cv);
-                            S.cchg |= 1u << p;
+                        for (int j = 0; j < 4; j++) {
+                            const unsigned nc = color_integrate_fresh(u4(S.c4[p], j), color_word(cw[j], csh[j]));
+                            u4(S.c4[p], j) = fresh[j] ? nc : u4(S.c4[p], j);
+                        }
+                    } else {  // 1 / 2 channel images
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (fresh[j]) {
+                                unsigned cbits = u4(S.c4[p], j);
+                                uchar4 cv = *reinterpret_cast<uchar4 *>(&cbits);
+                                uint8_t cr, cg, cb;
+                                color_at(F.color, cpix[j], F.color_channels, cr, cg, cb);
+                                cv = color_integrate(cv, cr, cg, cb, 1);
+                                u4(S.c4[p], j) = *reinterpret_cast<unsigned *>(&cv);
+                            }
                         }
                     }
+                    S.cchg |= 1u << p;
                 }
             }
             PHASE_END(4);
             if (any_carve) {
+                REGION(3);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const bool hit = carve[e][j] && (f4(S.w4[p], j) > 0.0f) && sdf_below_carve_threshold(f4(S.s4[p], j));
@@ -445,6 +475,12 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
         const bool existed = slot >= 0;  // memory of `slot` holds this chunk's voxels
         bool resident = existed;         // the reference's map contains the chunk before the current frame
         bool updated_any = false;
+#ifdef CHISEL_STAMPS
+        unsigned long long lt = __builtin_amdgcn_s_memtime();
+#define LOOPT(i) do { const unsigned long long ln = __builtin_amdgcn_s_memtime(); tally.cyc[i] += ln - lt; lt = ln; } while (0)
+#else
+#define LOOPT(i) do { } while (0)
+#endif
         __syncthreads();  // previous item's tile / flags / s_slot fully consumed
         if (tid < 4) s_flags[tid] = 0;
         if (tid == 0) s_changed = 0u;
@@ -489,6 +525,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
         mask &= mask - 1;
         frame_ctx(k, T, magic, flags);
         if (T.tw) issue_tile_dma<G::BLOCK>(s_tiles[0], T.rec, P.f[k].cam.W, T.u0, T.v0, T.tw, T.tw * T.th, magic, tid);
+        LOOPT(4);
         while (true) {
             const FrameCam &F = P.f[k];
             PixelRec *s_tile = s_tiles[parity];
@@ -507,10 +544,12 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
             if (G::PASSES == 1)
                 need = prefetch_frame<N, COLOR>(F, T, S, M.sdf + base0, M.wgt + base0, COLOR ? (M.rgbw + base0) : nullptr, tid);
             if (it == (int)blockIdx.x) STAMP(16);
+            LOOPT(0);
             if (T.tw || !free_running) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed (and its voxel reads)
                 __syncthreads();  // [B] tile visible to every wave; the other buffer and the other parity's flags are free
             }
+            LOOPT(1);
             if (it == (int)blockIdx.x) STAMP(17);
             if (it == (int)blockIdx.x) STAMP(3);
 #ifdef CHISEL_STAMPS
@@ -554,6 +593,10 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                                                COLOR ? (M.rgbw + (size_t)slot * G::V) : nullptr, q0);
                 }
             }
+            LOOPT(2);
+#ifdef CHISEL_STAMPS
+            tally.cyc[5] += 1;
+#endif
             if (free_running) {
                 lane_changed |= (t_ret & 2) ? (1u << k) : 0u;
             } else {
@@ -565,6 +608,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                 updated_any |= f_ch;
                 n_updated += (tid == 0 && f_ch);  // "needsUpdate" of the chunk for this frame (Chisel.h:85 / :167)
             }
+            LOOPT(3);
             if (it == (int)blockIdx.x) STAMP(4);
             parity ^= 1;
             if (!more) break;
@@ -624,12 +668,27 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
     }
     STAMP(6);
 #ifdef CHISEL_STAMPS
+    if (M.stamps) {
+        for (int k = 0; k < 4; k++) {
+            unsigned a = tally.lanes[k];
+            float b = tally.wave64[k];
+            for (int o = 32; o > 0; o >>= 1) {
+                a += __shfl_down(a, o);
+                b += __shfl_down(b, o);
+            }
+            if ((tid & 63) == 0) {
+                atomicAdd(&M.stamps[(size_t)blockIdx.x * 32 + 18 + k], (unsigned long long)a);
+                atomicAdd(&M.stamps[(size_t)blockIdx.x * 32 + 22 + k], (unsigned long long)(b + 0.5f));
+            }
+        }
+    }
     if (tid == 0 && M.stamps) {
         M.stamps[(size_t)blockIdx.x * 32 + 7] = __builtin_amdgcn_s_memtime() - clk0;  // shader-clock cycles
         for (int k = 0; k < 6; k++) M.stamps[(size_t)blockIdx.x * 32 + 8 + k] = tally.cyc[k];
     }
 #endif
 #undef STAMP
+#undef LOOPT
 }
 
 // sums the per-block rows into counters[] (CHISEL_HIP_NUM_COUNTERS = 9 entries); one block of 256 threads

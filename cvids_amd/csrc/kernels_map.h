@@ -205,5 +205,19 @@ __global__ void kat_color_kernel(const uint8_t *ops, int n, uint8_t *out) {
         out[4 * i + 3] = c.w;
     }
 }
+// exhaustive: color_integrate_fresh (division-free, packed) against color_integrate for every weight < 8, old and new channel
+// value (the three channels carry old, 255 - old and old ^ 0x5a; new likewise); counts the words that differ
+__global__ void kat_color_fresh_kernel(unsigned *mismatches) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;  // 8 * 256 * 256 cases
+    const unsigned w = i >> 16, o = (i >> 8) & 0xffu, n = i & 0xffu;
+    if (w >= 8u) return;
+    const uchar4 c = make_uchar4((uint8_t)o, (uint8_t)(255u - o), (uint8_t)(o ^ 0x5au), (uint8_t)w);
+    const uint8_t r = (uint8_t)n, g = (uint8_t)(255u - n), b = (uint8_t)(n ^ 0x5au);
+    const uchar4 want = color_integrate(c, r, g, b, 1);
+    const unsigned got = color_integrate_fresh((unsigned)c.x | ((unsigned)c.y << 8) | ((unsigned)c.z << 16) | ((unsigned)c.w << 24),
+                                               (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16));
+    const unsigned want_bits = (unsigned)want.x | ((unsigned)want.y << 8) | ((unsigned)want.z << 16) | ((unsigned)want.w << 24);
+    if (got != want_bits) atomicAdd(mismatches, 1u);
+}
 
 }  // namespace chisel_hip

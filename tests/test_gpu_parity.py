@@ -99,6 +99,16 @@ def test_device_kat_voxels(hip_lib):
         assert np.array_equal(out, a[:, 4:])
 
 
+def test_device_color_fast_path_exhaustive(hip_lib):
+    """the division-free colour update of the integration kernel == ColorVoxel::Integrate arithmetic for every
+    (weight < 8, old, new) -- 524288 words checked on the device against the integer-quotient form that
+    tests/test_oracle_kat.py pins to the reference's float expression"""
+    import ctypes as C
+    bad = C.c_uint(12345)
+    assert hip_lib.chisel_hip_kat_color_fresh(C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 # ---- frame-level parity ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("scene", ["wall", "sphere_room", "box_room"])
 def test_depth_only_stream(oracle_mod, scene):

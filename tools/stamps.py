@@ -73,16 +73,22 @@ def main():
     if ok.any():
         mhz = s[ok, 7] / ((s[ok, 6] - s[ok, 0]) / 100.0)
         print("  shader clock during the kernel: p50 %.0f MHz (min %.0f, max %.0f)" % (np.median(mhz), mhz.min(), mhz.max()))
-    names = ["geometry+project", "record fetch", "band tests", "integrate", "colour", "carve"]
+    names = ["scalars + z tests", "tile wait + barrier", "dma issue + apply", "hand-shake", "item prologue"]
+    it_n = np.maximum(1, s[w, 13]).astype(float)
     for k, nm in enumerate(names):
-        v = s[w, 8 + k]
-        print("  wave-0 cycles %-18s p50 %8.0f  p90 %8.0f  max %8.0f" % (nm, np.median(v), np.percentile(v, 90), v.max()))
+        v = s[w, 8 + k] / (it_n if k < 4 else 1.0)
+        print("  wave-0 cycles per frame iteration: %-20s mean %8.0f  p50 %8.0f  p90 %8.0f" % (nm, v.mean(), np.median(v), np.percentile(v, 90)))
+    print("  frame iterations per workgroup: mean %.1f" % it_n.mean())
     tp = s[w, 14]
     fl = s[w, 15]
     bw, bh, nq = (fl >> 8) & 0xffff, (fl >> 24) & 0xffff, (fl >> 40) & 0xff
     print("  staged tile pixels: p50 %d p90 %d max %d; items without a staged tile: %d of %d; flags inband %d carve %d tile %d" % (
         np.median(tp), np.percentile(tp, 90), tp.max(), (tp == 0).sum(), len(tp), ((fl & 1) > 0).sum(), ((fl & 2) > 0).sum(), ((fl & 4) > 0).sum()))
     print("  box w p50 %d max %d, h p50 %d max %d; needed quads of thread 0: p50 %d" % (np.median(bw), bw.max(), np.median(bh), bh.max(), np.median(nq)))
+    ln = s[live, 18:22].sum(axis=0).astype(float)
+    wv = s[live, 22:26].sum(axis=0).astype(float) / 64.0
+    for k, nm in enumerate(("quad projection", "band update", "colour update", "carve test")):
+        print("  wave executions of %-16s %9.0f  lanes that wanted it %11.0f  = %.1f %% of the lanes" % (nm, wv[k], ln[k], 100.0 * ln[k] / max(1.0, 64.0 * wv[k])))
     cs = s[:, 26:32]
     cl = cs[:, 0] > 0
     if cl.any():
