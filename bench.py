@@ -259,7 +259,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_us": avg_ms * 1e3, "launches": k["launches"], "frames_per_launch": args.steps / max(k["launches"], 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "other_kernels_us": {n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "mesh")
+                "other_kernels_us": {n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "resolve", "mesh")
                                      if prof[n]["launches"]},
                 "instrumented_ms_per_step": dt_b / args.steps * 1e3,
                 "note": "rank 0 shard; traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by tools/profile.sh into profiles/"}

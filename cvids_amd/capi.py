@@ -9,8 +9,8 @@ _LIB = os.path.join(_HERE, os.environ.get("CHISEL_HIP_LIB", "libchisel_hip.so"))
 
 NUM_COUNTERS = 9
 COUNTER_NAMES = ["sdf", "col", "col_sat", "probe", "carved", "work_chunks", "new_chunks", "updated_chunks", "frames"]
-NUM_KERNELS = 4
-KERNEL_NAMES = ["pyramid", "cull", "integrate", "mesh"]
+NUM_KERNELS = 5
+KERNEL_NAMES = ["pyramid", "cull", "integrate", "mesh", "resolve"]
 TRUNC_CONSTANT, TRUNC_INVERSE, TRUNC_QUADRATIC = 0, 1, 2
 STATUS = {0: "OK", 1: "ERR_INVALID", 2: "ERR_HIP", 3: "ERR_POOL_FULL", 4: "ERR_NOT_FOUND", 5: "ERR_UNSUPPORTED", 6: "ERR_IO"}
 

@@ -152,13 +152,21 @@ struct PyramidParams {
     const float *depth[KMAX];
 };
 
+// A candidate (written by cull_kernel: geometry only, the map is not consulted) and a work item (written by
+// resolve_kernel: the candidates that can change the map, with their pool slot) share this layout.
 struct WorkItem {
     int x, y, z;             // chunk id
-    int slot;                // pool slot, -1 = not resident (allocated if any voxel is integrated)
-    unsigned frame_mask;     // frames of the batch that may touch this chunk
-    int any_flags;           // OR of the frames' FrameBox flags
-    int pad[2];
+    int slot;                // pool slot, -1 = not resident (allocated if any voxel is integrated); candidates: -1;
+                             // SLOT_LOOKUP = the previous batch may be creating this chunk: the integration kernel looks it up
+    unsigned frame_mask;     // work item: frames of the batch that may touch this chunk
+                             // candidate: bits 0-7 frames that may integrate, bits 8-15 frames that may carve
+    int box;                 // row of the FrameBox array that holds this chunk's boxes (its candidate index)
+    unsigned inband_mask;    // work item: frames that may integrate (used when slot == SLOT_LOOKUP)
+    int pad;
 };
+constexpr int SLOT_LOOKUP = -2;
+// chunks the previous batch may create (open-addressing set of packed ids, one per batch buffer set)
+constexpr unsigned PENDING_CAPACITY = 1u << 14;
 struct FrameBox {            // one per (work item, frame)
     short u0, v0, u1, v1;    // conservative pixel bounding box of the chunk (inclusive), depth camera
     int flags;

@@ -88,18 +88,35 @@ struct chisel_hip_map {
     MapView *view_dev = nullptr;  // device-resident copy of `view` (cold fields are read from here by the kernels)
     uint64_t hash_capacity = 0;
     chisel_hip_integrator integ{CHISEL_HIP_TRUNC_INVERSE, 8.0f, 1.0f, 1, 0.05f};  // ChiselNode.cpp:54-64 defaults
-    // per-batch device buffers (a batch = up to KMAX frames handled by one pyramid -> cull -> integrate launch set)
-    WorkItem *items = nullptr;
-    FrameBox *boxes = nullptr;           // [items_capacity][KMAX]
+    // A batch (up to KMAX frames) is handled by one launch set in two halves:
+    //   front (auxiliary stream): host->device staging, depth_pyramid_kernel, cull_kernel (these read the frames only),
+    //         resolve_kernel (reads the chunk hash; tolerates the previous batch's insertions, see kernels_cull.h)
+    //   back  (the map's stream): integrate_kernel
+    // The front of batch b+1 runs while the back of batch b is still executing, so every buffer the front writes
+    // exists twice (sets alternate per batch); events order the halves.
+    struct BatchSet {
+        float2 *pyr_data = nullptr;      // [KMAX][pyr_stride]
+        PixelRec *rec_data = nullptr;    // [KMAX][W*H]
+        float *depth_stage = nullptr;    // [KMAX][depth_stage_elems]: host frames are copied here
+        uint8_t *color_stage = nullptr;  // [KMAX][color_stage_bytes]
+        WorkItem *cands = nullptr;       // [items_capacity]
+        FrameBox *boxes = nullptr;       // [items_capacity][KMAX]
+        int *cand_count = nullptr;       // [0] candidates, [1] work items, [2] pending-set overflow flag
+        WorkItem *items = nullptr;       // [items_capacity]: the work-list
+        uint64_t *pending = nullptr;     // [PENDING_CAPACITY]: chunks this batch may create
+        hipEvent_t front_done = nullptr;  // recorded on aux after the set's resolve
+        hipEvent_t back_done = nullptr;   // recorded on the map's stream after the set's integration
+    } sets[2];
+    hipStream_t aux = nullptr;
+    hipEvent_t call_event = nullptr;     // caller-provided stream: orders the front after the caller's producers
+    hipEvent_t mutation_event = nullptr; // map changed outside the integration path (reset, upload): the next front waits
+    bool mutation_pending = false;
+    bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
+    unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b & 1]
     int items_capacity = 0;
-    int *work_count = nullptr;
-    float2 *pyr_data = nullptr;          // [KMAX][pyr_stride]
-    PixelRec *rec_data = nullptr;        // [KMAX][W*H]
     int pyr_w = 0, pyr_h = 0, pyr_stride = 0;
-    PyramidView pyr{};
-    float *depth_stage = nullptr;        // [KMAX][depth_stage_elems]: host frames are copied here
+    PyramidView pyr{};                   // level geometry; .data is set per batch
     size_t depth_stage_elems = 0;
-    uint8_t *color_stage = nullptr;      // [KMAX][color_stage_bytes]
     size_t color_stage_bytes = 0;
     // scratch for queries
     int *scratch_i = nullptr;   // device ints
@@ -114,11 +131,25 @@ struct chisel_hip_map {
     bool profiling = false;
     std::vector<ProfEvent> prof_live;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0};
-    int64_t prof_launches[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0};
+    double prof_ms[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0, 0};
+    int64_t prof_launches[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0, 0};
 };
 
 namespace {
+
+// everything queued by the map, on both of its streams (needed before a batch buffer is reallocated)
+int sync_all(chisel_hip_map *m) {
+    if (m->aux) HIP_TRY(hipStreamSynchronize(m->aux));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->aux) HIP_TRY(hipStreamSynchronize(m->aux));
+    return CHISEL_HIP_OK;
+}
+
+// the chunk hash was changed on the map's stream outside the integration path: the next batch's front half must see it
+hipError_t note_map_mutation(chisel_hip_map *m) {
+    m->mutation_pending = true;
+    return hipEventRecord(m->mutation_event, m->stream);
+}
 
 int ensure_scratch(chisel_hip_map *m, size_t elems) {
     if (elems <= m->scratch_i_elems) return CHISEL_HIP_OK;
@@ -144,24 +175,26 @@ hipEvent_t take_event(chisel_hip_map *m) {
 struct ProfScope {
     chisel_hip_map *m;
     int k;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(chisel_hip_map *m_, int k_) : m(m_), k(k_) {
+    ProfScope(chisel_hip_map *m_, int k_, hipStream_t st_ = nullptr) : m(m_), k(k_), st(st_ ? st_ : m_->stream) {
         if (m->profiling) {
             a = take_event(m);
             b = take_event(m);
-            (void)hipEventRecord(a, m->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~ProfScope() {
         if (m->profiling) {
-            (void)hipEventRecord(b, m->stream);
+            (void)hipEventRecord(b, st);
             m->prof_live.push_back(ProfEvent{k, a, b});
         }
     }
 };
 int drain_profile(chisel_hip_map *m) {
     if (m->prof_live.empty()) return CHISEL_HIP_OK;
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    int rc_sync = sync_all(m);
+    if (rc_sync) return rc_sync;
     for (const ProfEvent &p : m->prof_live) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
@@ -194,12 +227,9 @@ void fill_camera(CameraParams &c, const float *pose, float fx, float fy, float c
 }
 
 int ensure_pyramid(chisel_hip_map *m, int W, int H) {
-    if (m->pyr_data && m->pyr_w == W && m->pyr_h == H) return CHISEL_HIP_OK;
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->pyr_data) HIP_TRY(hipFree(m->pyr_data));
-    if (m->rec_data) HIP_TRY(hipFree(m->rec_data));
-    m->pyr_data = nullptr;
-    m->rec_data = nullptr;
+    if (m->sets[0].pyr_data && m->pyr_w == W && m->pyr_h == H) return CHISEL_HIP_OK;
+    int rc = sync_all(m);
+    if (rc) return rc;
     int off = 0;
     for (int l = 0; l < PYR_LEVELS; l++) {
         int s = PYR_L0 + l;
@@ -209,42 +239,64 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
         off += m->pyr.w[l] * m->pyr.h[l];
     }
     m->pyr_stride = off;
-    HIP_TRY(hipMalloc(&m->pyr_data, (size_t)off * KMAX * sizeof(float2)));
-    HIP_TRY(hipMalloc(&m->rec_data, (size_t)W * H * KMAX * sizeof(PixelRec)));
-    m->pyr.data = m->pyr_data;
+    for (auto &bs : m->sets) {
+        if (bs.pyr_data) HIP_TRY(hipFree(bs.pyr_data));
+        if (bs.rec_data) HIP_TRY(hipFree(bs.rec_data));
+        bs.pyr_data = nullptr;
+        bs.rec_data = nullptr;
+        HIP_TRY(hipMalloc(&bs.pyr_data, (size_t)off * KMAX * sizeof(float2)));
+        HIP_TRY(hipMalloc(&bs.rec_data, (size_t)W * H * KMAX * sizeof(PixelRec)));
+    }
+    m->pyr.data = nullptr;
     m->pyr_w = W;
     m->pyr_h = H;
     return CHISEL_HIP_OK;
 }
 
+// The launch set of one batch.  Front half on the auxiliary stream, back half on the map's stream (see BatchSet).
 template <int N>
-int launch_group(chisel_hip_map *m, const PyramidParams &PP, const CullParams &CP, const IntegrateParams &IP, bool color) {
+int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidParams &PP, const CullParams &CP, const IntegrateParams &IP,
+                 bool color) {
     using G = Geom<N>;
     const int total = CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2];
     g_host_timer.lap(2);
+    PyramidView pyr = m->pyr;
+    pyr.data = bs.pyr_data;
     {
-        ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID);
+        ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID, m->aux);
         dim3 grid((PP.W + 63) / 64, (PP.H + 63) / 64, IP.n_frames);
-        hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, m->stream, PP, m->pyr, m->work_count);
+        hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, m->aux, PP, pyr, bs.cand_count, bs.pending);
     }
     g_host_timer.lap(3);
     {
-        ProfScope ps(m, CHISEL_HIP_KERNEL_CULL);
+        ProfScope ps(m, CHISEL_HIP_KERNEL_CULL, m->aux);
         const dim3 cgrid((total + 63) / 64);
         if (IP.n_frames <= 1)
-            hipLaunchKernelGGL((cull_kernel<N, 1>), cgrid, dim3(64), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
-                               m->work_count, m->items_capacity);
+            hipLaunchKernelGGL((cull_kernel<N, 1>), cgrid, dim3(64), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
+                               m->items_capacity, m->view.stamps);
         else if (IP.n_frames <= 2)
-            hipLaunchKernelGGL((cull_kernel<N, 2>), cgrid, dim3(128), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
-                               m->work_count, m->items_capacity);
+            hipLaunchKernelGGL((cull_kernel<N, 2>), cgrid, dim3(128), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
+                               m->items_capacity, m->view.stamps);
         else if (IP.n_frames <= 4)
-            hipLaunchKernelGGL((cull_kernel<N, 4>), cgrid, dim3(256), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
-                               m->work_count, m->items_capacity);
+            hipLaunchKernelGGL((cull_kernel<N, 4>), cgrid, dim3(256), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
+                               m->items_capacity, m->view.stamps);
         else
-            hipLaunchKernelGGL((cull_kernel<N, 8>), cgrid, dim3(512), 0, m->stream, CP, m->view, m->pyr, m->items, m->boxes,
-                               m->work_count, m->items_capacity);
+            hipLaunchKernelGGL((cull_kernel<N, 8>), cgrid, dim3(512), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
+                               m->items_capacity, m->view.stamps);
     }
+    {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, m->aux);
+        chisel_hip_map::BatchSet *prev = (m->batch_seq || m->force_uncertain) ? &m->sets[(m->batch_seq + 1u) & 1u] : nullptr;
+        const int *prev_overflow = m->force_uncertain ? m->sets[0].cand_count + 3 : (prev ? prev->cand_count + 2 : nullptr);  // [3] holds 1
+        hipLaunchKernelGGL(resolve_kernel, dim3((total + 255) / 256), dim3(256), 0, m->aux, m->view, bs.cands, bs.cand_count,
+                           m->items_capacity, IP.n_frames, bs.items, bs.cand_count + 1, prev ? prev->pending : nullptr,
+                           prev_overflow, bs.pending, bs.cand_count + 2);
+    }
+    HIP_TRY(hipEventRecord(bs.front_done, m->aux));
     g_host_timer.lap(4);
+    // ---- back half: the map's stream
+    HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
+    int *wc = bs.cand_count + 1;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
         const int grid = std::max(1, std::min(total, G::GRID));
@@ -252,15 +304,17 @@ int launch_group(chisel_hip_map *m, const PyramidParams &PP, const CullParams &C
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
         if (color && same_cam)  // CVIDS: depth and colour share one camera (sample.launch:19-20)
             hipLaunchKernelGGL((integrate_kernel<N, true, true>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               m->items, m->boxes, m->work_count, m->items_capacity);
+                               bs.items, bs.boxes, wc, m->items_capacity);
         else if (color)
             hipLaunchKernelGGL((integrate_kernel<N, true, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               m->items, m->boxes, m->work_count, m->items_capacity);
+                               bs.items, bs.boxes, wc, m->items_capacity);
         else
             hipLaunchKernelGGL((integrate_kernel<N, false, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               m->items, m->boxes, m->work_count, m->items_capacity);
+                               bs.items, bs.boxes, wc, m->items_capacity);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(bs.back_done, m->stream));
+    m->batch_seq++;
     g_host_timer.lap(5);
     g_host_timer.calls++;
     return CHISEL_HIP_OK;
@@ -308,9 +362,10 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     PP.ip = CP.ip = IP.ip = ip;
     PP.W = W;
     PP.H = H;
+    chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq & 1u];
     PP.rec_stride = (int)npx;
     PP.pyr_stride = m->pyr_stride;
-    PP.rec = m->rec_data;
+    PP.rec = bs.rec_data;
     CP.n_frames = IP.n_frames = n;
     CP.pyr_stride = m->pyr_stride;
 
@@ -325,18 +380,35 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         }
     }
     if (any_host_depth && npx > m->depth_stage_elems) {
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        if (m->depth_stage) HIP_TRY(hipFree(m->depth_stage));
-        m->depth_stage = nullptr;
-        HIP_TRY(hipMalloc(&m->depth_stage, npx * KMAX * sizeof(float)));
+        rc = sync_all(m);
+        if (rc) return rc;
+        for (auto &b2 : m->sets) {
+            if (b2.depth_stage) HIP_TRY(hipFree(b2.depth_stage));
+            b2.depth_stage = nullptr;
+            HIP_TRY(hipMalloc(&b2.depth_stage, npx * KMAX * sizeof(float)));
+        }
         m->depth_stage_elems = npx;
     }
     if (any_host_color && color_bytes > m->color_stage_bytes) {
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        if (m->color_stage) HIP_TRY(hipFree(m->color_stage));
-        m->color_stage = nullptr;
-        HIP_TRY(hipMalloc(&m->color_stage, color_bytes * KMAX));
+        rc = sync_all(m);
+        if (rc) return rc;
+        for (auto &b2 : m->sets) {
+            if (b2.color_stage) HIP_TRY(hipFree(b2.color_stage));
+            b2.color_stage = nullptr;
+            HIP_TRY(hipMalloc(&b2.color_stage, color_bytes * KMAX));
+        }
         m->color_stage_bytes = color_bytes;
+    }
+    // the front half may start as soon as the batch that last used this buffer set has been integrated; a stream given
+    // by the caller additionally orders it after whatever the caller queued there (the producers of device frames)
+    HIP_TRY(hipStreamWaitEvent(m->aux, bs.back_done, 0));
+    if (m->stream != m->own_stream) {
+        HIP_TRY(hipEventRecord(m->call_event, m->stream));
+        HIP_TRY(hipStreamWaitEvent(m->aux, m->call_event, 0));
+    }
+    if (m->mutation_pending) {
+        HIP_TRY(hipStreamWaitEvent(m->aux, m->mutation_event, 0));
+        m->mutation_pending = false;
     }
 
     g_host_timer.lap(0);
@@ -349,11 +421,11 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         if (f->on_device) {
             PP.depth[k] = f->depth;
         } else {
-            float *dst = m->depth_stage + (size_t)k * m->depth_stage_elems;
-            HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, m->stream));
+            float *dst = bs.depth_stage + (size_t)k * m->depth_stage_elems;
+            HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, m->aux));
             PP.depth[k] = dst;
         }
-        F.rec = m->rec_data + (size_t)k * npx;
+        F.rec = bs.rec_data + (size_t)k * npx;
         if (color) {
             const chisel_hip_color_frame *c = &colors[k];
             fill_camera(F.ccam, c->pose, c->fx, c->fy, c->cx, c->cy, c->width, c->height);
@@ -362,8 +434,8 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
             if (c->on_device) {
                 F.color = c->color;
             } else {
-                uint8_t *dst = m->color_stage + (size_t)k * m->color_stage_bytes;
-                HIP_TRY(hipMemcpyAsync(dst, c->color, (size_t)c->width * c->height * c->channels, hipMemcpyHostToDevice, m->stream));
+                uint8_t *dst = bs.color_stage + (size_t)k * m->color_stage_bytes;
+                HIP_TRY(hipMemcpyAsync(dst, c->color, (size_t)c->width * c->height * c->channels, hipMemcpyHostToDevice, m->aux));
                 F.color = dst;
             }
         }
@@ -389,22 +461,28 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     if (total_d > 2.0e8) return fail(CHISEL_HIP_ERR_INVALID, "frusta cover more than 2e8 chunks: far plane / resolution mismatch");
     const int total = (int)total_d;
     if (total > m->items_capacity) {
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        if (m->items) HIP_TRY(hipFree(m->items));
-        if (m->boxes) HIP_TRY(hipFree(m->boxes));
-        m->items = nullptr;
-        m->boxes = nullptr;
+        rc = sync_all(m);
+        if (rc) return rc;
         // geometric growth: the candidate range changes with every pose, a reallocation (stream sync) must stay rare
         int cap = std::max(1 << 17, m->items_capacity);
         while (cap < total) cap *= 2;
-        HIP_TRY(hipMalloc(&m->items, (size_t)cap * sizeof(WorkItem)));
-        HIP_TRY(hipMalloc(&m->boxes, (size_t)cap * KMAX * sizeof(FrameBox)));
+        for (auto &b2 : m->sets) {
+            if (b2.cands) HIP_TRY(hipFree(b2.cands));
+            if (b2.boxes) HIP_TRY(hipFree(b2.boxes));
+            if (b2.items) HIP_TRY(hipFree(b2.items));
+            b2.cands = nullptr;
+            b2.boxes = nullptr;
+            b2.items = nullptr;
+            HIP_TRY(hipMalloc(&b2.cands, (size_t)cap * sizeof(WorkItem)));
+            HIP_TRY(hipMalloc(&b2.items, (size_t)cap * sizeof(WorkItem)));
+            HIP_TRY(hipMalloc(&b2.boxes, (size_t)cap * KMAX * sizeof(FrameBox)));
+        }
         m->items_capacity = cap;
     }
     switch (m->N) {
-        case 8: return launch_group<8>(m, PP, CP, IP, color);
-        case 16: return launch_group<16>(m, PP, CP, IP, color);
-        case 32: return launch_group<32>(m, PP, CP, IP, color);
+        case 8: return launch_group<8>(m, bs, PP, CP, IP, color);
+        case 16: return launch_group<16>(m, bs, PP, CP, IP, color);
+        case 32: return launch_group<32>(m, bs, PP, CP, IP, color);
     }
     return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chunk size");
 }
@@ -549,7 +627,28 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
             return cleanup(fail(CHISEL_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)));      \
     } while (0)
     HIP_TRY_C(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+    {
+        // the front half is short and feeds the long integration kernel of the next batch: let its workgroups go first
+        int least = 0, greatest = 0;
+        HIP_TRY_C(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY_C(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, greatest));
+    }
     m->stream = m->own_stream;
+    HIP_TRY_C(hipEventCreateWithFlags(&m->call_event, hipEventDisableTiming));
+    for (auto &bs : m->sets) {
+        HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));
+        HIP_TRY_C(hipEventCreateWithFlags(&bs.back_done, hipEventDisableTiming));
+        HIP_TRY_C(hipMalloc(&bs.cand_count, 4 * sizeof(int)));
+        HIP_TRY_C(hipMemsetAsync(bs.cand_count, 0, 4 * sizeof(int), m->own_stream));
+        HIP_TRY_C(hipMalloc(&bs.pending, (size_t)PENDING_CAPACITY * sizeof(uint64_t)));
+        HIP_TRY_C(hipMemsetAsync(bs.pending, 0xff, (size_t)PENDING_CAPACITY * sizeof(uint64_t), m->own_stream));
+    }
+    HIP_TRY_C(hipEventCreateWithFlags(&m->mutation_event, hipEventDisableTiming));
+    m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
+    {
+        const int one = 1;
+        HIP_TRY_C(hipMemcpyAsync(m->sets[0].cand_count + 3, &one, sizeof(int), hipMemcpyHostToDevice, m->own_stream));
+    }
     MapView &v = m->view;
     v.max_chunks = (int)C;
     v.hash_mask = hc - 1;
@@ -566,9 +665,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMalloc(&v.error_flag, sizeof(int)));
-    HIP_TRY_C(hipMalloc(&m->work_count, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
-    HIP_TRY_C(hipMemsetAsync(m->work_count, 0, sizeof(int), m->stream));
     HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));
     HIP_TRY_C(hipMemcpyAsync(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
@@ -582,13 +679,22 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
 int chisel_hip_destroy(chisel_hip_map *m) {
     if (!m) return CHISEL_HIP_OK;
     (void)hipSetDevice(m->device);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->stream) (void)sync_all(m);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.block_counters, v.error_flag, v.stamps, m->view_dev, m->work_count, m->items, m->boxes, m->pyr_data, m->rec_data, m->depth_stage, m->color_stage,
-                    m->scratch_i};
+                    v.counters, v.block_counters, v.error_flag, v.stamps, m->view_dev, m->scratch_i};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto &bs : m->sets) {
+        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.pending};
+        for (void *p : bp)
+            if (p) (void)hipFree(p);
+        if (bs.front_done) (void)hipEventDestroy(bs.front_done);
+        if (bs.back_done) (void)hipEventDestroy(bs.back_done);
+    }
+    if (m->call_event) (void)hipEventDestroy(m->call_event);
+    if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
+    if (m->aux) (void)hipStreamDestroy(m->aux);
     free_mesh_buffers(m->mesh_buf);
     for (const ProfEvent &p : m->prof_live) {
         (void)hipEventDestroy(p.start);
@@ -605,6 +711,7 @@ int chisel_hip_reset(chisel_hip_map *m) {
     HIP_TRY(hipSetDevice(m->device));
     hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(note_map_mutation(m));
     m->meshes.clear();
     m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;
@@ -619,7 +726,8 @@ int chisel_hip_set_integrator(chisel_hip_map *m, const chisel_hip_integrator *in
 
 int chisel_hip_set_stream(chisel_hip_map *m, void *s) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    int rc = sync_all(m);
+    if (rc) return rc;
     m->stream = s ? (hipStream_t)s : m->own_stream;
     return CHISEL_HIP_OK;
 }

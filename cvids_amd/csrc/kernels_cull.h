@@ -10,9 +10,16 @@
 //                          the pair only if (a) the reference would enumerate it
 //                          (same range + same plane test), (b) this shard owns it, (c) a conservative
 //                          projection/depth-range test cannot rule out that one of its voxels is
-//                          updated or carved; looks the survivors up in the chunk hash and compacts
-//                          them into the work-list with a wave ballot + prefix popcount (one atomic
-//                          per wave).
+//                          updated or carved; compacts the surviving candidates with a wave ballot +
+//                          prefix popcount (one atomic per wave).  Reads the frames only, never the map,
+//                          so it runs (with the pyramid) on the auxiliary stream while the previous
+//                          batch is still being integrated.
+//   resolve_kernel       : one thread per candidate: chunk-hash lookup (ChunkManager::HasChunk), drops the
+//                          candidates that could only carve a chunk that is not resident, compacts the
+//                          rest into the work-list.  Also runs while the previous batch is being
+//                          integrated: the chunks that batch may still create are known (its work items
+//                          without a slot, kept in a small "pending" set), and a candidate found there is
+//                          passed on with slot = SLOT_LOOKUP for the integration kernel to look up itself.
 //
 // Dropping a (chunk, frame) pair is parity-safe only when no voxel of the chunk can change in that
 // frame: untouched new chunks are erased again by the reference (Chisel.h:202-207) and untouched
@@ -38,7 +45,8 @@ __device__ inline PixelRec make_record(const IntegratorParams &ip, float d) {
 }
 
 // grid: (ceil(W/64), ceil(H/64), n_frames), block 256: thread = one 4x4 pixel block of a 64x64 tile
-__global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, PyramidView pyr, int *work_count) {
+// Also resets the batch's counters ([0] candidates, [1] work items, [2] pending-set overflow) and empties its pending set.
+__global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, PyramidView pyr, int *counts, uint64_t *pending) {
     __shared__ float2 red[256];
     const int tid = threadIdx.x;
     const int k = blockIdx.z;
@@ -49,7 +57,11 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
     const float max_depth = P.ip.max_depth;
     const int bx = tid & 15, by = tid >> 4;
     const int px0 = blockIdx.x * 64 + bx * 4, py0 = blockIdx.y * 64 + by * 4;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && k == 0 && tid == 0) *work_count = 0;  // consumed by cull_kernel (next launch)
+    {  // consumed by cull_kernel / resolve_kernel (next launches)
+        const unsigned gid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256u + tid;
+        if (gid < 3u) counts[gid] = 0;
+        for (unsigned i = gid; i < PENDING_CAPACITY; i += gridDim.x * gridDim.y * gridDim.z * 256u) pending[i] = KEY_EMPTY;
+    }
     float mn = INFINITY, mx = -INFINITY;
     if (px0 < W && py0 < H) {
         const bool vec = ((W & 3) == 0) && (px0 + 3 < W);
@@ -319,14 +331,14 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
 // One wave per frame of the batch over the same 64 chunk ids (block = 64 * KL threads, KL = frames rounded up to a
 // power of two): every per-frame constant is wave-uniform (scalar loads), the per-frame verdicts meet in LDS.
 template <int N, int KL>
-__global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, PyramidView pyr, WorkItem *items, FrameBox *boxes,
-                                                        int *work_count, int max_items) {
+__global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *cand_count,
+                                                        int max_cands, unsigned long long *stamps) {
     __shared__ int s_flags[KL][64];
     __shared__ int s_pos[64];
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's frame
 #ifdef CHISEL_STAMPS
-#define CSTAMP(i) do { if (threadIdx.x == 0 && M.stamps && blockIdx.x < INTEGRATE_MAX_GRID) M.stamps[(size_t)blockIdx.x * 32 + 26 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CSTAMP(i) do { if (threadIdx.x == 0 && stamps && blockIdx.x < INTEGRATE_MAX_GRID) stamps[(size_t)blockIdx.x * 32 + 26 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
@@ -353,59 +365,36 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, 
     __syncthreads();
     CSTAMP(2);
     if (k == 0) {
-        // ---- merge the frames of each chunk, look the survivors up, compact ------------------------------------
-        int f[KL];
-        int any = 0;
+        // ---- merge the frames of each chunk, compact the candidates ----------------------------------------------
+        unsigned inband = 0, carve = 0;
 #pragma unroll
         for (int j = 0; j < KL; j++) {
-            f[j] = s_flags[j][lane];
-            any |= f[j];
+            const int f = s_flags[j][lane];
+            inband |= (f & WI_INBAND) ? (1u << j) : 0u;
+            carve |= (f & WI_CARVE) ? (1u << j) : 0u;
         }
-        bool keep = false;
-        WorkItem wi;
-        if (any & (WI_INBAND | WI_CARVE)) {
-            // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82)
-            const uint64_t key = pack_id(cx, cy, cz);
-            const uint64_t h = chunk_hash(cx, cy, cz) & M.hash_mask;
-            int slot = -1;
-            for (uint64_t i = 0; i <= M.hash_mask; i++) {
-                const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
-                if (kk == key) {
-                    slot = M.hash_vals[(h + i) & M.hash_mask];
-                    break;
-                }
-                if (kk == KEY_EMPTY) break;
-            }
-            // a frame can only matter if it may integrate, or may carve a chunk that is resident by then
-            // (resident now, or created by an earlier frame of this batch)
-            bool resident = slot >= 0;
-            unsigned mask = 0;
-            int anyf = 0;
-#pragma unroll
-            for (int j = 0; j < KL; j++) {
-                if ((f[j] & WI_INBAND) || ((f[j] & WI_CARVE) && resident)) {
-                    mask |= 1u << j;
-                    anyf |= f[j];
-                }
-                resident |= (f[j] & WI_INBAND) != 0;
-            }
-            keep = mask != 0;
-            wi.x = cx; wi.y = cy; wi.z = cz;
-            wi.slot = slot;
-            wi.frame_mask = mask;
-            wi.any_flags = anyf;
-            wi.pad[0] = wi.pad[1] = 0;
-        }
+        const bool keep = (inband | carve) != 0u;
         // wave64 compaction: ballot + prefix popcount, one atomic per wave
         const unsigned long long bal = __ballot(keep);
         int pos = -1;
         if (bal) {
             int base = 0;
-            if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(work_count, __popcll(bal));
+            if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(cand_count, __popcll(bal));
             base = __shfl(base, (int)__builtin_ctzll(bal));
             if (keep) {
                 pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pos < max_items) items[pos] = wi; else pos = -1;
+                if (pos < max_cands) {
+                    WorkItem wi;
+                    wi.x = cx; wi.y = cy; wi.z = cz;
+                    wi.slot = -1;
+                    wi.frame_mask = inband | (carve << 8);
+                    wi.box = pos;
+                    wi.inband_mask = inband;
+                    wi.pad = 0;
+                    cands[pos] = wi;
+                } else {
+                    pos = -1;
+                }
             }
         }
         s_pos[lane] = pos;
@@ -425,6 +414,86 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, MapView M, 
     }
     CSTAMP(5);
 #undef CSTAMP
+}
+
+__device__ inline bool pending_contains(const uint64_t *__restrict__ set, uint64_t key, uint64_t h) {
+    for (unsigned i = 0; i < PENDING_CAPACITY; i++) {
+        const uint64_t k = set[(h + i) & (PENDING_CAPACITY - 1)];
+        if (k == key) return true;
+        if (k == KEY_EMPTY) return false;
+    }
+    return false;
+}
+__device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
+    for (unsigned i = 0; i < PENDING_CAPACITY / 2; i++) {  // give up on a crowded table: the caller raises the overflow flag
+        unsigned long long *p = (unsigned long long *)&set[(h + i) & (PENDING_CAPACITY - 1)];
+        const unsigned long long cur = atomicCAS(p, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+        if (cur == KEY_EMPTY || cur == key) return true;
+    }
+    return false;
+}
+
+// Candidates -> work-list.  One thread per candidate; block 256.
+//   prev_pending / prev_overflow : the chunks the previous batch may create (nullptr: there is none in flight).  The
+//                                  chunk hash is read while that batch may still be inserting exactly those chunks, so
+//                                  for them the lookup result is ignored and the item is marked SLOT_LOOKUP; every
+//                                  other key of the hash is stable (inserted before, removal never overlaps a batch).
+//   my_pending / my_overflow     : receives the chunks this batch may create.
+__global__ __launch_bounds__(256) void resolve_kernel(MapView M, const WorkItem *__restrict__ cands, const int *__restrict__ cand_count,
+                                                       int max_cands, int n_frames, WorkItem *__restrict__ items, int *work_count,
+                                                       const uint64_t *__restrict__ prev_pending, const int *__restrict__ prev_overflow,
+                                                       uint64_t *my_pending, int *my_overflow) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    int n = *cand_count;
+    if (n > max_cands) n = max_cands;
+    const bool all_uncertain = prev_overflow && *prev_overflow != 0;  // pending set of the previous batch incomplete
+    bool keep = false;
+    WorkItem wi;
+    if (c < n) {
+        wi = cands[c];
+        const uint64_t key = pack_id(wi.x, wi.y, wi.z);
+        const uint64_t h0 = chunk_hash(wi.x, wi.y, wi.z);
+        // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82)
+        const uint64_t h = h0 & M.hash_mask;
+        int slot = -1;
+        for (uint64_t i = 0; i <= M.hash_mask; i++) {
+            const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
+            if (kk == key) {
+                slot = M.hash_vals[(h + i) & M.hash_mask];
+                break;
+            }
+            if (kk == KEY_EMPTY) break;
+        }
+        const unsigned inband = wi.frame_mask & 0xffu, carve = (wi.frame_mask >> 8) & 0xffu;
+        const bool uncertain = prev_pending && (all_uncertain ? (slot < 0) : pending_contains(prev_pending, key, h0));
+        unsigned mask = 0;
+        if (uncertain) {
+            slot = SLOT_LOOKUP;
+            mask = inband | carve;
+        } else {
+            // a frame can only matter if it may integrate, or may carve a chunk that is resident by then
+            // (resident now, or created by an earlier frame of this batch)
+            bool resident = slot >= 0;
+            for (int j = 0; j < n_frames; j++) {
+                const bool in = (inband >> j) & 1u;
+                if (in || (((carve >> j) & 1u) && resident)) mask |= 1u << j;
+                resident |= in;
+            }
+        }
+        keep = mask != 0;
+        wi.slot = slot;
+        wi.frame_mask = mask;
+        wi.inband_mask = inband;
+        if (keep && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(my_overflow, 1);
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (bal) {
+        int base = 0;
+        if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(work_count, __popcll(bal));
+        base = __shfl(base, (int)__builtin_ctzll(bal));
+        if (keep) items[base + __popcll(bal & ((1ull << lane) - 1ull))] = wi;  // items holds max_cands entries
+    }
 }
 
 }  // namespace chisel_hip

@@ -411,6 +411,20 @@ __device__ __attribute__((noinline)) int create_chunk(const MapView *__restrict_
     return -1;
 }
 
+// ChunkManager::HasChunk on the device for a work item marked SLOT_LOOKUP; one thread.  Returns the slot or -1.
+__device__ __attribute__((noinline)) int find_chunk(const MapView *__restrict__ Mc, int x, int y, int z) {
+    const MapView M = *Mc;
+    const uint64_t key = pack_id(x, y, z);
+    const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+    for (uint64_t i = 0; i <= M.hash_mask; i++) {
+        const uint64_t idx = (h + i) & M.hash_mask;
+        const uint64_t k = M.hash_keys[idx];
+        if (k == key) return M.hash_vals[idx];
+        if (k == KEY_EMPTY) break;
+    }
+    return -1;
+}
+
 // Stage the pixel records of box (u0, v0, tw x th) of `rec` (row stride W) into the LDS tile with LDS-DMA
 // (global_load_lds_dwordx4: 16 bytes = two records per lane, no register staging, asynchronous: the transfer of the
 // next frame's tile runs under the current frame's arithmetic).  u0 and tw are even (cull kernel), so a record pair
@@ -470,6 +484,20 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                   czi = __builtin_amdgcn_readfirstlane(wi.z);
         int slot = __builtin_amdgcn_readfirstlane(wi.slot);
         unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
+        const int box_row = __builtin_amdgcn_readfirstlane(wi.box);
+        if (slot == SLOT_LOOKUP) {
+            // the previous batch may have created this chunk while the work-list was built: it has finished now
+            __syncthreads();  // s_slot of the previous item consumed
+            if (tid == 0) s_slot = find_chunk(Mc, cxi, cyi, czi);
+            __syncthreads();
+            slot = s_slot;
+            if (slot < 0) {
+                // not resident: frames before the first one that may integrate could only carve, i.e. do nothing
+                const unsigned inband = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.inband_mask);
+                if (inband == 0u) continue;
+                mask &= ~((1u << __builtin_ctz(inband)) - 1u);
+            }
+        }
         // Chunk origin (Chunk.cpp:43): numVoxels * ID (int) * resolution
         const float ox = (float)(N * cxi) * ip.res, oy = (float)(N * cyi) * ip.res, oz = (float)(N * czi) * ip.res;
         const bool existed = slot >= 0;  // memory of `slot` holds this chunk's voxels
@@ -497,7 +525,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
 
         // ---- frame loop, software pipelined: tile of frame k+1 in flight (LDS-DMA) while frame k is applied --------
         auto frame_ctx = [&](int k, TileCtx &T, unsigned &magic, int &flags) {
-            const FrameBox fb = boxes[(size_t)it * P.n_frames + k];
+            const FrameBox fb = boxes[(size_t)box_row * P.n_frames + k];
             flags = __builtin_amdgcn_readfirstlane(fb.flags);
             T.rec = P.f[k].rec;
             T.u0 = __builtin_amdgcn_readfirstlane((int)fb.u0);

@@ -110,10 +110,11 @@ enum {
 /* kernels timed by the built-in hipEvent profiler (chisel_hip_set_profiling) */
 enum {
     CHISEL_HIP_KERNEL_PYRAMID = 0,   /* depth min/max pyramid                                           */
-    CHISEL_HIP_KERNEL_CULL = 1,      /* candidate enumeration + hash lookup + compaction                 */
+    CHISEL_HIP_KERNEL_CULL = 1,      /* candidate enumeration + conservative culling + compaction        */
     CHISEL_HIP_KERNEL_INTEGRATE = 2, /* projective SDF/weight/colour integration (+ allocation)          */
     CHISEL_HIP_KERNEL_MESH = 3,      /* marching cubes (count + emit)                                   */
-    CHISEL_HIP_NUM_KERNELS = 4
+    CHISEL_HIP_KERNEL_RESOLVE = 4,   /* hash lookup of the candidates -> work-list                       */
+    CHISEL_HIP_NUM_KERNELS = 5
 };
 
 /* ---- life cycle ------------------------------------------------------------------------------------- */

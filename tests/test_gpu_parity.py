@@ -309,6 +309,42 @@ def test_batched_launch_equals_frame_by_frame(oracle_mod, batch, color):
     _run_batched(om, gm, integ, frames, cam, synth.render_color(64, 48, 3) if color else None, batch)
 
 
+@pytest.mark.parametrize("batch", [1, 2, 8])
+@pytest.mark.parametrize("force_lookup", [False, True])
+def test_back_to_back_batches_pipeline(oracle_mod, batch, force_lookup, monkeypatch):
+    """Batches issued without any synchronisation in between: the work-list of batch b+1 is built on the auxiliary stream
+    while batch b is still being integrated, so chunks batch b creates reach batch b+1 as SLOT_LOOKUP items (looked up by
+    the integration kernel).  Walls that appear, move away (carving what the previous batch created) and come back.
+    force_lookup: the conservative mode used when a pending set overflows -- every candidate without a slot is looked up."""
+    if force_lookup:
+        monkeypatch.setenv("CHISEL_HIP_FORCE_UNCERTAIN", "1")
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, carving=True, carving_dist=0.0, max_chunks=8192)
+    monkeypatch.delenv("CHISEL_HIP_FORCE_UNCERTAIN", raising=False)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+    pose = synth.pose_yaw(0.0)
+    walls = [np.full((48, 64), d, np.float32) for d in (1.2, 2.4, 1.7, 1.2)]
+    frames = []
+    for w in walls:
+        frames += [(w, pose)] * 3
+    frames += make_frames("sphere_room", 10, 64, 48, agents=2, nan_fraction=0.02)
+    tot = dict(sdf=0, col=0, col_sat=0, probe=0, carved=0, updated_chunks=0)
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        oc = om.counters()
+        for k in tot:
+            tot[k] += oc[k]
+    for lo in range(0, len(frames), batch):
+        part = frames[lo:lo + batch]
+        gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])  # asynchronous
+    gc = gm.counters(reset=True)
+    for k in tot:
+        assert tot[k] == gc[k], "counter %s: oracle %d gpu %d" % (k, tot[k], gc[k])
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
 @pytest.mark.parametrize("N,res,W,H", [(16, 0.04, 96, 72), (32, 0.02, 64, 48)])
 def test_batched_launch_chunk_sizes(oracle_mod, N, res, W, H):
     om, gm, integ = _mk(oracle_mod, N, res, True, max_chunks=2048)
