@@ -101,7 +101,7 @@ struct chisel_hip_map {
         uint8_t *color_stage = nullptr;  // [KMAX][color_stage_bytes]
         WorkItem *cands = nullptr;       // [items_capacity]
         FrameBox *boxes = nullptr;       // [items_capacity][KMAX]
-        int *cand_count = nullptr;       // [0] candidates, [1] work items, [2] pending-set overflow flag
+        int *cand_count = nullptr;       // [COUNT_INTS] device counters of the batch (COUNT_* in kernels_cull.h)
         WorkItem *items = nullptr;       // [items_capacity]: the work-list
         uint64_t *pending = nullptr;     // [PENDING_CAPACITY]: chunks this batch may create
         hipEvent_t front_done = nullptr;  // recorded on aux after the set's resolve
@@ -287,16 +287,17 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, m->aux);
         chisel_hip_map::BatchSet *prev = (m->batch_seq || m->force_uncertain) ? &m->sets[(m->batch_seq + 1u) & 1u] : nullptr;
-        const int *prev_overflow = m->force_uncertain ? m->sets[0].cand_count + 3 : (prev ? prev->cand_count + 2 : nullptr);  // [3] holds 1
-        hipLaunchKernelGGL(resolve_kernel, dim3((total + 255) / 256), dim3(256), 0, m->aux, m->view, bs.cands, bs.cand_count,
-                           m->items_capacity, IP.n_frames, bs.items, bs.cand_count + 1, prev ? prev->pending : nullptr,
-                           prev_overflow, bs.pending, bs.cand_count + 2);
+        const int *prev_overflow = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : (prev ? prev->cand_count + COUNT_OVERFLOW : nullptr);
+        const dim3 rgrid((total + 255) / 256);
+        hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, m->aux, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
+                           prev ? prev->pending : nullptr, prev_overflow, bs.pending);
+        hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, m->aux, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items);
     }
     HIP_TRY(hipEventRecord(bs.front_done, m->aux));
     g_host_timer.lap(4);
     // ---- back half: the map's stream
     HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
-    int *wc = bs.cand_count + 1;
+    int *wc = bs.cand_count + COUNT_ITEMS;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
         const int grid = std::max(1, std::min(total, G::GRID));
@@ -627,7 +628,9 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
             return cleanup(fail(CHISEL_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)));      \
     } while (0)
     HIP_TRY_C(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
-    {
+    if (getenv("CHISEL_HIP_SERIAL")) {
+        m->aux = m->own_stream;  // diagnostic: both halves on one stream, nothing overlaps
+    } else {
         // the front half is short and feeds the long integration kernel of the next batch: let its workgroups go first
         int least = 0, greatest = 0;
         HIP_TRY_C(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -638,8 +641,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     for (auto &bs : m->sets) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));
         HIP_TRY_C(hipEventCreateWithFlags(&bs.back_done, hipEventDisableTiming));
-        HIP_TRY_C(hipMalloc(&bs.cand_count, 4 * sizeof(int)));
-        HIP_TRY_C(hipMemsetAsync(bs.cand_count, 0, 4 * sizeof(int), m->own_stream));
+        HIP_TRY_C(hipMalloc(&bs.cand_count, COUNT_INTS * sizeof(int)));
+        HIP_TRY_C(hipMemsetAsync(bs.cand_count, 0, COUNT_INTS * sizeof(int), m->own_stream));
         HIP_TRY_C(hipMalloc(&bs.pending, (size_t)PENDING_CAPACITY * sizeof(uint64_t)));
         HIP_TRY_C(hipMemsetAsync(bs.pending, 0xff, (size_t)PENDING_CAPACITY * sizeof(uint64_t), m->own_stream));
     }
@@ -647,7 +650,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
     {
         const int one = 1;
-        HIP_TRY_C(hipMemcpyAsync(m->sets[0].cand_count + 3, &one, sizeof(int), hipMemcpyHostToDevice, m->own_stream));
+        HIP_TRY_C(hipMemcpyAsync(m->sets[0].cand_count + COUNT_ONE, &one, sizeof(int), hipMemcpyHostToDevice, m->own_stream));
     }
     MapView &v = m->view;
     v.max_chunks = (int)C;
@@ -694,7 +697,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     }
     if (m->call_event) (void)hipEventDestroy(m->call_event);
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
-    if (m->aux) (void)hipStreamDestroy(m->aux);
+    if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
     free_mesh_buffers(m->mesh_buf);
     for (const ProfEvent &p : m->prof_live) {
         (void)hipEventDestroy(p.start);

@@ -30,6 +30,10 @@
 
 namespace chisel_hip {
 
+// per-batch device counters: candidates, work items, pending-set overflow flag, a constant 1, work items per cost class,
+// placement cursors per cost class
+constexpr int COUNT_CANDS = 0, COUNT_ITEMS = 1, COUNT_OVERFLOW = 2, COUNT_ONE = 3, COUNT_CLASS0 = 4, COUNT_CURSOR0 = 12, COUNT_INTS = 20;
+
 __device__ inline bool depth_valid(float d, float max_depth) {
     // NaN never updates (Integrate: every comparison false; IntegrateColor: isnan skip :134); d > max_depth is
     // skipped (:74 / :141); +-inf cannot satisfy |sd| < t+diag nor sd > t+cd for any of the truncators.
@@ -45,7 +49,7 @@ __device__ inline PixelRec make_record(const IntegratorParams &ip, float d) {
 }
 
 // grid: (ceil(W/64), ceil(H/64), n_frames), block 256: thread = one 4x4 pixel block of a 64x64 tile
-// Also resets the batch's counters ([0] candidates, [1] work items, [2] pending-set overflow) and empties its pending set.
+// Also resets the batch's counters (COUNT_* below) and empties its pending set.
 __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, PyramidView pyr, int *counts, uint64_t *pending) {
     __shared__ float2 red[256];
     const int tid = threadIdx.x;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
     const int px0 = blockIdx.x * 64 + bx * 4, py0 = blockIdx.y * 64 + by * 4;
     {  // consumed by cull_kernel / resolve_kernel (next launches)
         const unsigned gid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256u + tid;
-        if (gid < 3u) counts[gid] = 0;
+        if (gid < (unsigned)COUNT_INTS && gid != (unsigned)COUNT_ONE) counts[gid] = 0;
         for (unsigned i = gid; i < PENDING_CAPACITY; i += gridDim.x * gridDim.y * gridDim.z * 256u) pending[i] = KEY_EMPTY;
     }
     float mn = INFINITY, mx = -INFINITY;
@@ -433,25 +437,33 @@ __device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
     return false;
 }
 
-// Candidates -> work-list.  One thread per candidate; block 256.
+// Candidates -> work-list, in two passes over the candidates (both on the auxiliary stream, one thread per candidate,
+// block 256).
+//   resolve_kernel : hash lookup, frame mask; the verdict is written back into the candidate (frame_mask == 0: dropped)
+//                    and counted per cost class in counts[COUNT_CLASS0 + class].
+//   order_kernel   : places the surviving candidates into the work-list class by class, most expensive first (class =
+//                    8 - number of frames that touch the chunk): the integration kernel's last workgroups then run the
+//                    short items, which shortens the stretch where the chip drains.
 //   prev_pending / prev_overflow : the chunks the previous batch may create (nullptr: there is none in flight).  The
 //                                  chunk hash is read while that batch may still be inserting exactly those chunks, so
 //                                  for them the lookup result is ignored and the item is marked SLOT_LOOKUP; every
 //                                  other key of the hash is stable (inserted before, removal never overlaps a batch).
-//   my_pending / my_overflow     : receives the chunks this batch may create.
-__global__ __launch_bounds__(256) void resolve_kernel(MapView M, const WorkItem *__restrict__ cands, const int *__restrict__ cand_count,
-                                                       int max_cands, int n_frames, WorkItem *__restrict__ items, int *work_count,
-                                                       const uint64_t *__restrict__ prev_pending, const int *__restrict__ prev_overflow,
-                                                       uint64_t *my_pending, int *my_overflow) {
+//   my_pending / counts[COUNT_OVERFLOW] : receives the chunks this batch may create.
+
+// `counts_in` is `counts` again, read-only: the values read through it were written by earlier kernels, and a read-only
+// pointer lets them travel through the scalar cache instead of every wave asking the same L2 line.
+__global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
+                                                       int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
+                                                       const int *__restrict__ prev_overflow, uint64_t *my_pending) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    int n = *cand_count;
+    int n = counts_in[COUNT_CANDS];
     if (n > max_cands) n = max_cands;
+    if ((int)(blockIdx.x * 256) >= n) return;
     const bool all_uncertain = prev_overflow && *prev_overflow != 0;  // pending set of the previous batch incomplete
-    bool keep = false;
-    WorkItem wi;
+    int cls = -1;
     if (c < n) {
-        wi = cands[c];
+        WorkItem wi = cands[c];
         const uint64_t key = pack_id(wi.x, wi.y, wi.z);
         const uint64_t h0 = chunk_hash(wi.x, wi.y, wi.z);
         // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82)
@@ -481,18 +493,56 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, const WorkItem 
                 resident |= in;
             }
         }
-        keep = mask != 0;
-        wi.slot = slot;
-        wi.frame_mask = mask;
-        wi.inband_mask = inband;
-        if (keep && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(my_overflow, 1);
+        cands[c].slot = slot;
+        cands[c].frame_mask = mask;
+        if (mask) cls = 8 - __popc(mask);
+        if (mask && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(&counts[COUNT_OVERFLOW], 1);
     }
-    const unsigned long long bal = __ballot(keep);
-    if (bal) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const unsigned long long bal = __ballot(cls == k);
+        if (bal && lane == (int)__builtin_ctzll(bal)) atomicAdd(&counts[COUNT_CLASS0 + k], __popcll(bal));
+    }
+}
+
+__global__ __launch_bounds__(256) void order_kernel(const WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
+                                                     int max_cands, WorkItem *__restrict__ items) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    int n = counts_in[COUNT_CANDS];
+    if (n > max_cands) n = max_cands;
+    if ((int)(blockIdx.x * 256) >= n && blockIdx.x != 0) return;
+    int start[8];
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        start[k] = total;
+        total += counts_in[COUNT_CLASS0 + k];
+    }
+    if (c == 0) counts[COUNT_ITEMS] = total;
+    WorkItem wi;
+    int cls = -1;
+    if (c < n) {
+        wi = cands[c];
+        if (wi.frame_mask) cls = 8 - __popc(wi.frame_mask);
+    }
+    // one returning atomic per (wave, class), all of a wave's classes in the same instruction: the first lane of each class
+    // reserves the range for its class
+    unsigned long long mine = 0;  // lanes of this wave in my class
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const unsigned long long bal = __ballot(cls == k);
+        if (cls == k) mine = bal;
+    }
+    if (cls >= 0) {
+        const int leader = (int)__builtin_ctzll(mine);
         int base = 0;
-        if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(work_count, __popcll(bal));
-        base = __shfl(base, (int)__builtin_ctzll(bal));
-        if (keep) items[base + __popcll(bal & ((1ull << lane) - 1ull))] = wi;  // items holds max_cands entries
+        if (lane == leader) base = atomicAdd(&counts[COUNT_CURSOR0 + cls], __popcll(mine));
+        base = __shfl(base, leader);
+        int first = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) first = (cls == k) ? start[k] : first;
+        items[first + base + __popcll(mine & ((1ull << lane) - 1ull))] = wi;  // items holds max_cands entries
     }
 }
 

@@ -63,6 +63,15 @@ def main():
         if len(v):
             x = us(v)
             print("  %-16s n %5d  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, len(v), x.min(), np.median(x), np.percentile(x, 90), x.max()))
+    ex = s[live, 6]
+    en = s[live, 0]
+    dur = (ex.max() - t0) / 100.0
+    busy = ((ex - en) / 100.0).sum()
+    # resident workgroups at once: 2 per CU (register file), 256 CUs
+    print("  kernel (first entry -> last exit) %.1f us; workgroup-time %.0f us = %.1f %% of 512 slots x kernel" % (dur, busy, 100.0 * busy / (512 * dur)))
+    order = np.sort(us(ex))
+    print("  workgroups still running at 50/60/70/80/90 %% of the kernel: %s" % ", ".join(
+        "%d" % (ex > t0 + f * (ex.max() - t0)).sum() for f in (0.5, 0.6, 0.7, 0.8, 0.9)))
     w = s[:, 2] > 0
     for a, b, name in ((0, 1, "entry->count"), (1, 2, "count->item"), (2, 16, "item->prefetched"), (16, 17, "prefetched->staged(t0)"), (17, 3, "staged(t0)->barrier"), (3, 4, "tile->applied"), (4, 5, "applied->stored"), (5, 6, "stored->exit")):
         ok = w & (s[:, a] > 0) & (s[:, b] > 0)
