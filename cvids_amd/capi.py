@@ -126,6 +126,7 @@ def load_library():
     L.chisel_hip_kat_dist.argtypes = [f32p, C.c_int, f32p]
     L.chisel_hip_kat_color.argtypes = [u8p, C.c_int, u8p]
     L.chisel_hip_kat_color_fresh.argtypes = [C.POINTER(C.c_uint)]
+    L.chisel_hip_kat_reciprocal.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
     L.chisel_hip_debug_frustum_range.argtypes = [f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                                  C.c_int, C.c_float, i32p, i32p, f32p, f32p]
     _lib = L

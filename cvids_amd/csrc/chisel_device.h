@@ -179,6 +179,7 @@ struct FrameBox {            // one per (work item, frame)
 constexpr int WI_INBAND = 1;   // some voxel may take the in-band branch
 constexpr int WI_CARVE = 2;    // some voxel may take the carve test (only matters while the chunk is resident)
 constexpr int WI_TILE = 4;     // u0..v1 is a valid bounding box (else: gather from the whole image)
+constexpr int WI_FASTZ = 8;    // camera z of every voxel of the chunk lies in [FASTZ_MIN, FASTZ_MAX]: reciprocal_in_range() applies
 
 // ---- strategy arithmetic (devirtualised Truncator / Weighter) -------------------------------------
 // InverseTruncator.h:48-52
@@ -203,6 +204,17 @@ __host__ __device__ inline float truncation_distance(int kind, float param, floa
         return (float)(v * (double)param);
     }
 }
+// 1.0f / z, correctly rounded, for z in [2^-40, 2^40]: the hardware reciprocal (1 ulp) refined by one Newton step whose
+// residual is exact thanks to the fused multiply-add.  Checked against the IEEE division for EVERY float of that range on
+// the device (chisel_hip_kat_reciprocal, tests/test_gpu_parity.py; the bare v_rcp_f32 fails that test, one step passes).
+// Three instructions instead of the eleven of the general division sequence, which also has to scale denormal and huge
+// operands; the callers establish the range (cull_kernel: WI_FASTZ).
+__device__ inline float reciprocal_in_range(float z) {
+    const float r = __builtin_amdgcn_rcpf(z);
+    return __builtin_fmaf(__builtin_fmaf(-z, r, 1.0f), r, r);
+}
+constexpr float FASTZ_MIN = 9.094947017729282e-13f;  // 2^-40
+constexpr float FASTZ_MAX = 1099511627776.0f;        // 2^40
 // ConstantWeighter.h:43-46
 __host__ __device__ inline float constant_weight(float weight, float truncation) { return weight / (5 * truncation); }
 // DistVoxel::Integrate DistVoxel.h:52-60

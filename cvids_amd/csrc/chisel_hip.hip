@@ -46,8 +46,22 @@ struct IdHash {
     size_t operator()(uint64_t k) const { return (size_t)(k * 0x9E3779B97F4A7C15ull); }
 };
 
-struct HostMesh {  // mesh/Mesh.h:54-58 (indices are implicit 0..n-1)
-    std::vector<float> vertices, normals, colors, grids;
+// ChunkManager::allMeshes lives on the device: every recompute emits the meshes of its chunks into one arena
+// (vertices | normals | colors | grids, 3 floats per entry) and a chunk's mesh is a window of it (mesh/Mesh.h:54-58;
+// indices are implicit 0..n-1).  An arena is copied to the host when a caller first reads one of its meshes and is
+// released when no chunk points into it any more (every one of its chunks has been meshed again since).
+struct MeshArena {
+    float *dev = nullptr;
+    size_t nv = 0, ng = 0;     // vertices / grids of the whole arena
+    bool color = false;
+    int live = 0;              // meshes of the map that point into this arena
+    std::vector<float> host;   // lazily filled copy
+    bool host_valid = false;
+    size_t floats() const { return nv * 3 * (color ? 3 : 2) + ng * 3; }
+};
+struct MeshRef {
+    int arena = -1;            // -1: empty mesh
+    size_t v_off = 0, n_v = 0, g_off = 0, n_g = 0;
 };
 
 // host-side phase timer (CHISEL_HIP_HOST_TIMING=1): where does an integrate call spend its host time?
@@ -123,7 +137,8 @@ struct chisel_hip_map {
     size_t scratch_i_elems = 0;
     // meshing state
     int update_meshes_calls = 0;                                       // Chisel.cpp:53 "static int cnt"
-    std::unordered_map<uint64_t, HostMesh, IdHash> meshes;             // ChunkManager::allMeshes
+    std::unordered_map<uint64_t, MeshRef, IdHash> meshes;              // ChunkManager::allMeshes
+    std::vector<MeshArena> arenas;
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
     MeshBuffers mesh_buf{};
@@ -698,6 +713,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->call_event) (void)hipEventDestroy(m->call_event);
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
+    clear_meshes(m);
     free_mesh_buffers(m->mesh_buf);
     for (const ProfEvent &p : m->prof_live) {
         (void)hipEventDestroy(p.start);
@@ -715,7 +731,7 @@ int chisel_hip_reset(chisel_hip_map *m) {
     hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
     HIP_TRY(hipGetLastError());
     HIP_TRY(note_map_mutation(m));
-    m->meshes.clear();
+    clear_meshes(m);
     m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;
 }
@@ -954,6 +970,24 @@ int chisel_hip_kat_color_fresh(unsigned *mismatches) {
     hipLaunchKernelGGL(kat_color_fresh_kernel, dim3(8 * 256 * 256 / 256), dim3(256), 0, 0, d);
     HIP_TRY(hipMemcpy(mismatches, d, sizeof(unsigned), hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_kat_reciprocal(unsigned long long *mismatches, unsigned *example_bits) {
+    unsigned long long *d = nullptr;
+    unsigned *e = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&e, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(e, 0, sizeof(unsigned)));
+    unsigned lo, hi;
+    const float fmin = FASTZ_MIN, fmax = FASTZ_MAX;
+    memcpy(&lo, &fmin, 4);
+    memcpy(&hi, &fmax, 4);
+    hipLaunchKernelGGL(kat_reciprocal_kernel, dim3(4096), dim3(256), 0, 0, lo, (unsigned long long)(hi - lo) + 1ull, d, e);
+    HIP_TRY(hipMemcpy(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(example_bits, e, sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    (void)hipFree(e);
     return CHISEL_HIP_OK;
 }
 // diagnostic builds (-DCHISEL_STAMPS): allocate / read back the per-workgroup stamp buffer of integrate_kernel

@@ -2,7 +2,8 @@
 //
 // Chisel::UpdateMeshes (Chisel.cpp:50-59) -> ChunkManager::RecomputeMeshes (ChunkManager.cpp:130-169): the ids flagged
 // since the last recompute are meshed on the GPU (kernels_mesh.h: jobs -> count -> host prefix sum -> emit into one
-// arena -> one D2H) and the results are kept on the host as the reference keeps ChunkManager::allMeshes.
+// arena).  The arena stays in HBM (MeshArena in chisel_hip.hip); only the per-chunk sizes travel to the host, the vertex
+// data follows when a caller asks for a mesh.
 namespace {
 
 MeshParams mesh_params(const chisel_hip_map *m) {
@@ -17,14 +18,17 @@ MeshParams mesh_params(const chisel_hip_map *m) {
 
 template <int N>
 void launch_mesh_count(chisel_hip_map *m, int n) {
-    hipLaunchKernelGGL(mesh_count_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, m->mesh_buf.jobs, m->mesh_buf.counts);
+    MeshBuffers &B = m->mesh_buf;
+    int *bases = B.counts + 2 * (size_t)B.capacity, *totals = B.counts + 4 * (size_t)B.capacity;
+    hipLaunchKernelGGL(mesh_count_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, B.counts, bases, totals, B.tris,
+                       B.tri_capacity);
 }
 template <int N>
-void launch_mesh_emit(chisel_hip_map *m, int n, const MeshParams &P, float *v, float *nr, float *c, float *g) {
-    const int *offsets = m->mesh_buf.counts + 2 * (size_t)m->mesh_buf.capacity;
-    hipLaunchKernelGGL(mesh_emit_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, P, m->mesh_buf.jobs, offsets, v, nr, g);
-    hipLaunchKernelGGL(mesh_shade_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, P, m->mesh_buf.jobs, offsets,
-                       m->mesh_buf.counts, v, nr, c);
+void launch_mesh_triangles(chisel_hip_map *m, int n_tris, const MeshParams &P, float *v, float *nr, float *c, float *g) {
+    MeshBuffers &B = m->mesh_buf;
+    const int *bases = B.counts + 2 * (size_t)B.capacity;
+    hipLaunchKernelGGL(mesh_triangle_kernel<N>, dim3((n_tris + MESH_TRI_BLOCK - 1) / MESH_TRI_BLOCK), dim3(MESH_TRI_BLOCK), 0, m->stream, m->view, P, B.jobs,
+                       bases, B.tris, n_tris, v, nr, P.use_color ? c : nullptr, g);
 }
 
 int ensure_mesh_jobs(chisel_hip_map *m, int n) {
@@ -39,7 +43,7 @@ int ensure_mesh_jobs(chisel_hip_map *m, int n) {
     while (cap < n) cap *= 2;
     HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
     HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
-    HIP_TRY(hipMalloc(&B.counts, (size_t)cap * 4 * sizeof(int)));
+    HIP_TRY(hipMalloc(&B.counts, ((size_t)cap * 4 + 8) * sizeof(int)));
     B.capacity = cap;
     return CHISEL_HIP_OK;
 }
@@ -79,63 +83,107 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra, int *n_ou
     return CHISEL_HIP_OK;
 }
 
+void free_arena(chisel_hip_map *m, MeshArena &A) {
+    // the stream may still be reading it (a copy in flight): stream-ordered release
+    if (A.dev) {
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipFree(A.dev);
+    }
+    A = MeshArena();
+}
+void release_mesh_ref(chisel_hip_map *m, MeshRef &ref) {
+    if (ref.arena >= 0) {
+        MeshArena &A = m->arenas[ref.arena];
+        if (--A.live == 0) free_arena(m, A);
+    }
+    ref = MeshRef();
+}
+void clear_meshes(chisel_hip_map *m) {
+    for (MeshArena &A : m->arenas) free_arena(m, A);
+    m->arenas.clear();
+    m->meshes.clear();
+}
+
 // meshes of the n chunks whose ids sit in mesh_buf.ids (device)
 int recompute_meshes(chisel_hip_map *m, int n) {
     if (n == 0) return CHISEL_HIP_OK;
     MeshBuffers &B = m->mesh_buf;
-    hipLaunchKernelGGL(mesh_jobs_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, m->stream, m->view, B.ids, n, B.jobs);
-    {
-        ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
-        switch (m->N) {
-            case 8: launch_mesh_count<8>(m, n); break;
-            case 16: launch_mesh_count<16>(m, n); break;
-            case 32: launch_mesh_count<32>(m, n); break;
-        }
-    }
-    HIP_TRY(hipGetLastError());
-    std::vector<int> counts((size_t)n * 2), offsets((size_t)n * 2);
+    hipLaunchKernelGGL(mesh_jobs_kernel, dim3((n * 32 + 255) / 256), dim3(256), 0, m->stream, m->view, B.ids, n, B.jobs);
+    std::vector<int> counts((size_t)n * 2), bases((size_t)n * 2);
     std::vector<MeshJob> jobs(n);
-    HIP_TRY(hipMemcpyAsync(counts.data(), B.counts, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(jobs.data(), B.jobs, (size_t)n * sizeof(MeshJob), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    size_t nv = 0, ng = 0;
-    for (int j = 0; j < n; j++) {
-        offsets[2 * j] = (int)nv;
-        offsets[2 * j + 1] = (int)ng;
-        nv += (size_t)counts[2 * j];
-        ng += (size_t)counts[2 * j + 1];
-        if (nv > 0x7fffffffull / 3) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^31 / 3 mesh vertices in one recompute");
-    }
-    const bool color = m->cfg.use_color != 0;
-    const size_t need = nv * 3 * (color ? 3 : 2) + ng * 3;
-    std::vector<float> host(need);
-    if (need) {
-        if (need > B.arena_floats) {
-            if (B.arena) HIP_TRY(hipFree(B.arena));
-            B.arena = nullptr;
-            size_t cap = std::max<size_t>(B.arena_floats, 1u << 22);
-            while (cap < need) cap *= 2;
-            HIP_TRY(hipMalloc(&B.arena, cap * sizeof(float)));
-            B.arena_floats = cap;
+    int totals[4] = {0, 0, 0, 0};
+    for (int attempt = 0;; attempt++) {
+        if (!B.tris) {
+            B.tri_capacity = std::max(B.tri_capacity, 1 << 20);
+            HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
         }
-        float *d_v = B.arena, *d_n = d_v + nv * 3, *d_c = d_n + nv * 3, *d_g = d_c + (color ? nv * 3 : 0);
-        HIP_TRY(hipMemcpyAsync(B.counts + 2 * (size_t)B.capacity, offsets.data(), (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, m->stream));
-        const MeshParams P = mesh_params(m);
+        int *d_totals = B.counts + 4 * (size_t)B.capacity;
+        HIP_TRY(hipMemsetAsync(d_totals, 0, 4 * sizeof(int), m->stream));
         {
             ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
             switch (m->N) {
-                case 8: launch_mesh_emit<8>(m, n, P, d_v, d_n, color ? d_c : nullptr, d_g); break;
-                case 16: launch_mesh_emit<16>(m, n, P, d_v, d_n, color ? d_c : nullptr, d_g); break;
-                case 32: launch_mesh_emit<32>(m, n, P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 8: launch_mesh_count<8>(m, n); break;
+                case 16: launch_mesh_count<16>(m, n); break;
+                case 32: launch_mesh_count<32>(m, n); break;
             }
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host.data(), B.arena, need * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(counts.data(), B.counts, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(bases.data(), B.counts + 2 * (size_t)B.capacity, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        if (attempt == 0) HIP_TRY(hipMemcpyAsync(jobs.data(), B.jobs, (size_t)n * sizeof(MeshJob), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
+        if (!totals[2]) break;
+        // the triangle list was too small: grow it to what this batch needs and list again
+        if (attempt > 0) return fail(CHISEL_HIP_ERR_HIP, "mesh triangle list overflow after growing it");
+        HIP_TRY(hipFree(B.tris));
+        B.tris = nullptr;
+        while (B.tri_capacity < totals[0]) B.tri_capacity *= 2;
     }
-    const float *h_v = host.data(), *h_n = h_v + nv * 3, *h_c = h_n + nv * 3, *h_g = h_c + (color ? nv * 3 : 0);
+    if ((size_t)totals[0] > 0x7fffffffull / 9) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^31 / 9 mesh triangles in one recompute");
+    const size_t nv = (size_t)totals[0] * 3, ng = (size_t)totals[1];
+    std::vector<int> offsets((size_t)n * 2);
     for (int j = 0; j < n; j++) {
-        if (jobs[j].nslot[0] < 0) continue;  // RecomputeMesh: "if (!HasChunk(chunkID)) return" (ChunkManager.cpp:93-96)
+        offsets[2 * j] = 3 * bases[2 * j];      // first vertex of the job in the arena
+        offsets[2 * j + 1] = bases[2 * j + 1];  // first grid entry
+    }
+    const bool color = m->cfg.use_color != 0;
+    if (g_host_timer.on) {
+        int with_tris = 0;
+        for (int j = 0; j < n; j++) with_tris += counts[2 * j] != 0;
+        fprintf(stderr, "chisel_hip mesh recompute: %d jobs, %d with triangles, %zu vertices, %zu grids\n", n, with_tris, nv, ng);
+    }
+    int arena_id = -1;
+    if (nv + ng) {
+        // a free arena record, or a new one
+        for (size_t i = 0; i < m->arenas.size() && arena_id < 0; i++)
+            if (!m->arenas[i].dev) arena_id = (int)i;
+        if (arena_id < 0) {
+            m->arenas.emplace_back();
+            arena_id = (int)m->arenas.size() - 1;
+        }
+        MeshArena &A = m->arenas[arena_id];
+        A.nv = nv;
+        A.ng = ng;
+        A.color = color;
+        A.live = 0;
+        A.host.clear();
+        A.host_valid = false;
+        HIP_TRY(hipMalloc(&A.dev, A.floats() * sizeof(float)));
+        float *d_v = A.dev, *d_n = d_v + nv * 3, *d_c = d_n + nv * 3, *d_g = d_c + (color ? nv * 3 : 0);
+        const MeshParams P = mesh_params(m);
+        if (totals[0]) {
+            ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+            switch (m->N) {
+                case 8: launch_mesh_triangles<8>(m, totals[0], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 16: launch_mesh_triangles<16>(m, totals[0], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 32: launch_mesh_triangles<32>(m, totals[0], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    for (int j = 0; j < n; j++) {
+        if (jobs[j].nb[NB_SELF] < 0) continue;  // RecomputeMesh: "if (!HasChunk(chunkID)) return" (ChunkManager.cpp:93-96)
         const uint64_t key = pack_id(jobs[j].x, jobs[j].y, jobs[j].z);
         const size_t cv = (size_t)counts[2 * j], cg = (size_t)counts[2 * j + 1];
         auto it = m->meshes.find(key);
@@ -143,15 +191,53 @@ int recompute_meshes(chisel_hip_map *m, int n) {
         // only when it has grids (ChunkManager.cpp:101-127)
         if (it == m->meshes.end()) {
             if (cg == 0) continue;
-            it = m->meshes.emplace(key, HostMesh()).first;
+            it = m->meshes.emplace(key, MeshRef()).first;
         }
-        HostMesh &hm = it->second;
-        hm.vertices.assign(h_v + 3 * (size_t)offsets[2 * j], h_v + 3 * ((size_t)offsets[2 * j] + cv));
-        hm.normals.assign(h_n + 3 * (size_t)offsets[2 * j], h_n + 3 * ((size_t)offsets[2 * j] + cv));
-        if (color) hm.colors.assign(h_c + 3 * (size_t)offsets[2 * j], h_c + 3 * ((size_t)offsets[2 * j] + cv));
-        else hm.colors.clear();
-        hm.grids.assign(h_g + 3 * (size_t)offsets[2 * j + 1], h_g + 3 * ((size_t)offsets[2 * j + 1] + cg));
+        MeshRef &ref = it->second;
+        release_mesh_ref(m, ref);
+        if (cv + cg) {
+            ref.arena = arena_id;
+            ref.v_off = (size_t)offsets[2 * j];
+            ref.n_v = cv;
+            ref.g_off = (size_t)offsets[2 * j + 1];
+            ref.n_g = cg;
+            m->arenas[arena_id].live++;
+        }
     }
+    if (arena_id >= 0 && m->arenas[arena_id].live == 0) free_arena(m, m->arenas[arena_id]);
+    return CHISEL_HIP_OK;
+}
+
+// host copy of an arena, made on first use
+int arena_on_host(chisel_hip_map *m, MeshArena &A) {
+    if (A.host_valid) return CHISEL_HIP_OK;
+    A.host.resize(A.floats());
+    if (!A.host.empty()) {
+        HIP_TRY(hipMemcpyAsync(A.host.data(), A.dev, A.floats() * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    A.host_valid = true;
+    return CHISEL_HIP_OK;
+}
+
+// pointers to the four arrays of one mesh in its arena's host copy (nullptr for an empty mesh)
+struct MeshView {
+    const float *v = nullptr, *n = nullptr, *c = nullptr, *g = nullptr;
+    size_t n_v = 0, n_g = 0;
+};
+int view_mesh(chisel_hip_map *m, const MeshRef &ref, MeshView &out) {
+    out = MeshView();
+    if (ref.arena < 0) return CHISEL_HIP_OK;
+    MeshArena &A = m->arenas[ref.arena];
+    int rc = arena_on_host(m, A);
+    if (rc) return rc;
+    const float *base = A.host.data();
+    out.v = base + 3 * ref.v_off;
+    out.n = base + 3 * A.nv + 3 * ref.v_off;
+    out.c = A.color ? base + 6 * A.nv + 3 * ref.v_off : nullptr;
+    out.g = base + 3 * A.nv * (A.color ? 3 : 2) + 3 * ref.g_off;
+    out.n_v = ref.n_v;
+    out.n_g = ref.n_g;
     return CHISEL_HIP_OK;
 }
 
@@ -244,8 +330,8 @@ int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     auto it = m->meshes.find(pack_id(id[0], id[1], id[2]));
     if (it == m->meshes.end()) return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh for this chunk (ChunkManager::GetMesh would throw std::out_of_range)");
-    if (nv) *nv = (int64_t)it->second.vertices.size() / 3;
-    if (ng) *ng = (int64_t)it->second.grids.size() / 3;
+    if (nv) *nv = (int64_t)it->second.n_v;
+    if (ng) *ng = (int64_t)it->second.n_g;
     return CHISEL_HIP_OK;
 }
 
@@ -253,11 +339,14 @@ int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     auto it = m->meshes.find(pack_id(id[0], id[1], id[2]));
     if (it == m->meshes.end()) return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh for this chunk (ChunkManager::GetMesh would throw std::out_of_range)");
-    const HostMesh &hm = it->second;
-    if (v && !hm.vertices.empty()) memcpy(v, hm.vertices.data(), hm.vertices.size() * sizeof(float));
-    if (n && !hm.normals.empty()) memcpy(n, hm.normals.data(), hm.normals.size() * sizeof(float));
-    if (c && !hm.colors.empty()) memcpy(c, hm.colors.data(), hm.colors.size() * sizeof(float));
-    if (g && !hm.grids.empty()) memcpy(g, hm.grids.data(), hm.grids.size() * sizeof(float));
+    HIP_TRY(hipSetDevice(m->device));
+    MeshView mv;
+    int rc = view_mesh(m, it->second, mv);
+    if (rc) return rc;
+    if (v && mv.n_v) memcpy(v, mv.v, mv.n_v * 3 * sizeof(float));
+    if (n && mv.n_v) memcpy(n, mv.n, mv.n_v * 3 * sizeof(float));
+    if (c && mv.n_v && mv.c) memcpy(c, mv.c, mv.n_v * 3 * sizeof(float));
+    if (g && mv.n_g) memcpy(g, mv.g, mv.n_g * 3 * sizeof(float));
     return CHISEL_HIP_OK;
 }
 
@@ -278,13 +367,16 @@ int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
     if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     std::ofstream stream(path);
     if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    HIP_TRY(hipSetDevice(m->device));
     const std::vector<uint64_t> keys = sorted_mesh_keys(m);
     size_t numPoints = 0;
     bool any_color = false;
-    for (uint64_t k : keys) {
-        const HostMesh &hm = m->meshes.at(k);
-        numPoints += hm.vertices.size() / 3;
-        any_color = any_color || !hm.colors.empty();
+    std::vector<MeshView> views(keys.size());
+    for (size_t i = 0; i < keys.size(); i++) {
+        int rc = view_mesh(m, m->meshes.at(keys[i]), views[i]);
+        if (rc) return rc;
+        numPoints += views[i].n_v;
+        any_color = any_color || (views[i].n_v && views[i].c);
     }
     stream << "ply" << std::endl;
     stream << "format ascii 1.0" << std::endl;
@@ -300,14 +392,13 @@ int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
     stream << "element face " << numPoints / 3 << std::endl;
     stream << "property list uchar int vertex_index" << std::endl;
     stream << "end_header" << std::endl;
-    for (uint64_t k : keys) {
-        const HostMesh &hm = m->meshes.at(k);
-        for (size_t i = 0; i + 2 < hm.vertices.size(); i += 3) {
-            stream << hm.vertices[i] << " " << hm.vertices[i + 1] << " " << hm.vertices[i + 2];
+    for (const MeshView &mv : views) {
+        for (size_t i = 0; i + 2 < mv.n_v * 3; i += 3) {
+            stream << mv.v[i] << " " << mv.v[i + 1] << " " << mv.v[i + 2];
             if (any_color) {
-                const int r = static_cast<int>(hm.colors[i] * 255.0f);
-                const int g = static_cast<int>(hm.colors[i + 1] * 255.0f);
-                const int b = static_cast<int>(hm.colors[i + 2] * 255.0f);
+                const int r = static_cast<int>(mv.c[i] * 255.0f);
+                const int g = static_cast<int>(mv.c[i + 1] * 255.0f);
+                const int b = static_cast<int>(mv.c[i + 2] * 255.0f);
                 stream << " " << r << " " << g << " " << b;
             }
             stream << std::endl;

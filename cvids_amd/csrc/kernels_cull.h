@@ -329,7 +329,12 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
         const unsigned long long half_w = (unsigned long long)((u1 - u0 + 1) >> 1);
         fb.magic = half_w ? (unsigned)((0x100000000ull + half_w - 1ull) / half_w) : 0u;  // ceil(2^32 / (width / 2))
     }
-    return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0);
+    // all corners at least a quarter voxel in front of the camera: every voxel centre's camera z lies between the corner
+    // extrema (widened by the slack above), so the short reciprocal of the projection is exact for this chunk.  The
+    // kernel's own z carries the rounding of three products of magnitude <= mag: keep well clear of it.
+    const float mag = fabsf(C.t[0]) + fabsf(C.t[1]) + fabsf(C.t[2]) + fabsf(bminx) + fabsf(bminy) + fabsf(bminz) + 3.0f * ext;
+    const bool fastz = !any_behind && (zmin >= FASTZ_MIN + 1e-5f * mag) && (zmax <= FASTZ_MAX);
+    return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0);
 }
 
 // One wave per frame of the batch over the same 64 chunk ids (block = 64 * KL threads, KL = frames rounded up to a

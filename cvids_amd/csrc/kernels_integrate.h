@@ -66,6 +66,7 @@ struct TileCtx {
     // camera-z bounds from the cull kernel (conservative): a voxel can be in band only if z_near < z < z_far and
     // can take the carve test only if z < z_carve
     float z_near, z_far, z_carve;
+    bool fastz;            // every voxel's camera z is in the range of reciprocal_in_range() (WI_FASTZ)
 };
 
 template <int N>
@@ -241,7 +242,7 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
                 const float pcx = ax0[j] + s0, pcy = ax1[j] + s1;
                 pcz[e][j] = ax2[j] + s2;
                 // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45)
-                const float invZ = 1.0f / pcz[e][j];
+                const float invZ = T.fastz ? reciprocal_in_range(pcz[e][j]) : 1.0f / pcz[e][j];
                 const float u = C.fx * pcx * invZ + C.cx;
                 const float v = C.fy * pcy * invZ + C.cy;
                 // IsPointOnImage (PinholeCamera.cpp:61-64): 0 <= u < W && 0 <= v < H, and not z < 0 (ProjectionIntegrator.h:68 /
@@ -253,7 +254,7 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
                            (u == u) & (v == v);
                 const int tu = iu[e][j] - T.u0, tv = iv[e][j] - T.v0;
                 const bool in_tile = ((unsigned)tu < (unsigned)T.tw) & ((unsigned)tv < (unsigned)T.th);
-                tidx[e][j] = in_tile ? tv * T.tw + tu : 0;
+                tidx[e][j] = in_tile ? (int)__umul24((unsigned)tv, (unsigned)T.tw) + tu : 0;  // both below 2^12
                 any_out |= on[e][j] & !in_tile;
             }
         }
@@ -262,7 +263,11 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
 #pragma unroll
         for (int e = 0; e < QG; e++)
 #pragma unroll
+#ifdef CHISEL_ABLATE_LDS
+            for (int j = 0; j < 4; j++) r[e][j] = make_float2(pcz[e][j] + 0.01f, 0.05f);  // diagnostic: no gather
+#else
             for (int j = 0; j < 4; j++) r[e][j] = s_tile[tidx[e][j]];
+#endif
         // pixels outside the staged box (box too large for LDS: near-camera chunks; otherwise never, the box is conservative)
         if (any_out) {
 #pragma unroll
@@ -323,9 +328,18 @@ __device__ inline int apply_frame(const IntegratorParams &ip, const FrameCam &F,
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float wu = 1.0f;                                         // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84
+#ifdef CHISEL_ABLATE_DIV
+                    if (COLOR) wu = ip.weight * __builtin_amdgcn_rcpf(5 * r[e][j].y);
+#else
                     if (COLOR) wu = constant_weight(ip.weight, r[e][j].y);  // IntegrateColor: weighter->GetWeight(.., truncation) :161-162
+#endif
                     float ns = f4(S.s4[p], j), nw = f4(S.w4[p], j);
+#ifdef CHISEL_ABLATE_DIV
+                    ns = (nw * ns + wu * sd[j]) * __builtin_amdgcn_rcpf(wu + nw);
+                    nw = nw + wu;
+#else
                     dist_integrate(ns, nw, sd[j], wu);
+#endif
                     f4(S.s4[p], j) = band[e][j] ? ns : f4(S.s4[p], j);
                     f4(S.w4[p], j) = band[e][j] ? nw : f4(S.w4[p], j);
                 }
@@ -433,6 +447,9 @@ __device__ __attribute__((noinline)) int find_chunk(const MapView *__restrict__ 
 template <int BLOCK>
 __device__ inline void issue_tile_dma(PixelRec *lds_tile, const PixelRec *__restrict__ rec, int W, int u0, int v0, int tw, int npx,
                                       unsigned magic, int tid) {
+#ifdef CHISEL_ABLATE_DMA
+    return;
+#endif
     const int npairs = npx >> 1, tw2 = tw >> 1;
     const int lane = tid & 63;
     const PixelRec *src0 = rec + (size_t)v0 * W + u0;
@@ -532,6 +549,7 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
             T.v0 = __builtin_amdgcn_readfirstlane((int)fb.v0);
             T.tw = 0;
             T.th = 0;
+            T.fastz = (flags & WI_FASTZ) != 0;
             T.z_near = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_near)));
             T.z_far = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_far)));
             T.z_carve = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_carve)));
@@ -575,7 +593,9 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
             LOOPT(0);
             if (T.tw || !free_running) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed (and its voxel reads)
+#ifndef CHISEL_ABLATE_BARRIER
                 __syncthreads();  // [B] tile visible to every wave; the other buffer and the other parity's flags are free
+#endif
             }
             LOOPT(1);
             if (it == (int)blockIdx.x) STAMP(17);
@@ -596,7 +616,11 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                                          T_next.tw * T_next.th, magic_next, tid);
             int t_ret = 0;
             if (G::PASSES == 1) {
+#ifdef CHISEL_ABLATE_APPLY
+                t_ret = need ? 3 : 0;
+#else
                 t_ret = apply_frame<N, COLOR, SAMECAM>(ip, F, T, s_tile, need, resident, S, tally);
+#endif
             } else {
                 // streamed chunk (32^3): slab by slab, state re-read per frame; a chunk that does not exist yet is
                 // created by the first slab that integrates a voxel

@@ -219,5 +219,21 @@ __global__ void kat_color_fresh_kernel(unsigned *mismatches) {
     const unsigned want_bits = (unsigned)want.x | ((unsigned)want.y << 8) | ((unsigned)want.z << 16) | ((unsigned)want.w << 24);
     if (got != want_bits) atomicAdd(mismatches, 1u);
 }
+// exhaustive: reciprocal_in_range(z) against the IEEE division 1.0f / z for every float in [FASTZ_MIN, FASTZ_MAX]
+// (81 binades x 2^23 mantissas); counts the mismatches and keeps one offending input
+__global__ void kat_reciprocal_kernel(unsigned first_bits, unsigned long long n, unsigned long long *mismatches, unsigned *example) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float z = __uint_as_float(first_bits + (unsigned)i);
+        const float want = 1.0f / z;
+        const float got = reciprocal_in_range(z);
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            bad++;
+            *example = first_bits + (unsigned)i;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 
 }  // namespace chisel_hip

@@ -10,9 +10,9 @@
 // traversal order* (interior cubes, then the max-x, max-y and max-z planes: ChunkManager.cpp:395-441), so the
 // vertex / normal / colour / grid arrays of a chunk are element-for-element the reference's:
 //   mesh_jobs_kernel   : slots of the chunk and of its 7 "+" neighbours (the corners a border cube needs)
-//   mesh_count_kernel  : vertices and grids per chunk (case table popcount + block scan)
-//   mesh_emit_kernel   : same scan, then vertices and face normals into one arena
-//   mesh_shade_kernel  : one thread per vertex: gradient normals and colours
+//   mesh_count_kernel    : per chunk: vertices and grids (case table popcount + block scan), the chunk's range in the
+//                          batch and the list of its triangles
+//   mesh_triangle_kernel : one thread per triangle: vertices, gradient normals and colours into one arena
 // A cube is meshed only when all 8 corner voxels have weight > 0.5 and every chunk they live in exists
 // (:271-276, :316-357); an absent neighbour simply reads as weight 0.
 #pragma once
@@ -28,9 +28,11 @@ __constant__ unsigned char c_mc_edges[12] = CHISEL_MC_EDGE_CORNERS;
 
 struct MeshJob {
     int x, y, z;     // chunk id
-    int nslot[8];    // pool slot of chunk id + (b&1, b>>1&1, b>>2&1); [0] = the chunk itself; -1 = absent
-    int pad;
+    int nb[27];      // pool slots of the 27-neighbourhood: nb[(dz+1)*9 + (dy+1)*3 + (dx+1)], [13] = the chunk itself; -1 = absent.
+                     // Cube corners need the 7 "+" neighbours, the gradient / colour lookups of border vertices any of the 26.
+    int pad[2];
 };
+constexpr int NB_SELF = 13;
 
 struct MeshParams {
     float res;        // voxelResolutionMeters
@@ -91,14 +93,18 @@ __device__ inline void id_at(const MeshParams &P, f3v pos, int &ix, int &iy, int
     iz = (int)floorf(pos.z * P.rf_chunk);
 }
 
-// slot of the chunk containing `pos` (GetChunkAt ChunkManager.h:147-161); `hint`: a chunk whose slot is already known
+// slot of the chunk containing `pos` (GetChunkAt ChunkManager.h:147-161); (hx, hy, hz) / nb: a chunk whose 27-neighbourhood
+// slots are already known (MeshJob::nb; nullptr: none) -- a hash probe only for chunks further away
 template <int N>
-__device__ inline int chunk_at(const MapView &M, const MeshParams &P, f3v pos, int hx, int hy, int hz, int hslot, f3v &origin) {
+__device__ inline int chunk_at(const MapView &M, const MeshParams &P, f3v pos, int hx, int hy, int hz, const int *nb, f3v &origin) {
     int ix, iy, iz;
     id_at(P, pos, ix, iy, iz);
     // Chunk origin (Chunk.cpp:43): numVoxels * ID (int) * resolution
     origin = mk3((float)(N * ix) * P.res, (float)(N * iy) * P.res, (float)(N * iz) * P.res);
-    if (ix == hx && iy == hy && iz == hz) return hslot;  // (callers without a hint pass hx = INT_MAX)
+    if (nb) {
+        const unsigned dx = (unsigned)(ix - hx + 1), dy = (unsigned)(iy - hy + 1), dz = (unsigned)(iz - hz + 1);
+        if (dx < 3u && dy < 3u && dz < 3u) return nb[(dz * 3u + dy) * 3u + dx];
+    }
     if (ix < -ID_BIAS + 2 || ix > ID_BIAS - 2 || iy < -ID_BIAS + 2 || iy > ID_BIAS - 2 || iz < -ID_BIAS + 2 || iz > ID_BIAS - 2) return -1;
     return hash_find(M, ix, iy, iz);
 }
@@ -106,9 +112,9 @@ __device__ inline int chunk_at(const MapView &M, const MeshParams &P, f3v pos, i
 // ChunkManager::GetSDF (ChunkManager.cpp:476-499).  Note the reference only range-checks the linear voxel id,
 // not the coordinates (Chunk::GetVoxelID Chunk.h:81-84): reproduced.
 template <int N>
-__device__ inline bool get_sdf(const MapView &M, const MeshParams &P, f3v posf, int hx, int hy, int hz, int hslot, double &dist) {
+__device__ inline bool get_sdf(const MapView &M, const MeshParams &P, f3v posf, int hx, int hy, int hz, const int *nb, double &dist) {
     f3v origin;
-    const int slot = chunk_at<N>(M, P, posf, hx, hy, hz, hslot, origin);
+    const int slot = chunk_at<N>(M, P, posf, hx, hy, hz, nb, origin);
     if (slot < 0) return false;
     const f3v rel = sub3(posf, origin);
     const int cx = (int)floorf(rel.x * P.rf_voxel), cy = (int)floorf(rel.y * P.rf_voxel), cz = (int)floorf(rel.z * P.rf_voxel);
@@ -123,29 +129,49 @@ __device__ inline bool get_sdf(const MapView &M, const MeshParams &P, f3v posf, 
     return false;
 }
 
-// ChunkManager::GetSDFAndGradient (ChunkManager.cpp:449-474)
+// ChunkManager::GetSDFAndGradient (ChunkManager.cpp:449-474).  The reference makes the seven GetSDF calls one after
+// the other and gives up at the first failure; here the seven voxel addresses are resolved first and their weights and
+// distances requested together (14 independent loads instead of a chain of 14), then judged in the reference's order.
 template <int N>
-__device__ inline bool get_sdf_and_gradient(const MapView &M, const MeshParams &P, f3v pos, int hx, int hy, int hz, int hslot,
+__device__ inline bool get_sdf_and_gradient(const MapView &M, const MeshParams &P, f3v pos, int hx, int hy, int hz, const int *nb,
                                             double &dist, f3v &grad) {
     const float r = P.res;
     const f3v posf = mk3(floorf(pos.x / r) * r + r / 2.0f, floorf(pos.y / r) * r + r / 2.0f, floorf(pos.z / r) * r + r / 2.0f);
-    if (!get_sdf<N>(M, P, posf, hx, hy, hz, hslot, dist)) return false;
-    double xp, yp, zp, xm, ym, zm;
-    if (!get_sdf<N>(M, P, add3(posf, mk3(r, 0, 0)), hx, hy, hz, hslot, xp)) return false;
-    if (!get_sdf<N>(M, P, add3(posf, mk3(0, r, 0)), hx, hy, hz, hslot, yp)) return false;
-    if (!get_sdf<N>(M, P, add3(posf, mk3(0, 0, r)), hx, hy, hz, hslot, zp)) return false;
-    if (!get_sdf<N>(M, P, sub3(posf, mk3(r, 0, 0)), hx, hy, hz, hslot, xm)) return false;
-    if (!get_sdf<N>(M, P, sub3(posf, mk3(0, r, 0)), hx, hy, hz, hslot, ym)) return false;
-    if (!get_sdf<N>(M, P, sub3(posf, mk3(0, 0, r)), hx, hy, hz, hslot, zm)) return false;
-    grad = normalized3(mk3((float)(xp - xm), (float)(yp - ym), (float)(zp - zm)));  // grad->normalize()
+    f3v q[7];
+    q[0] = posf;
+    q[1] = add3(posf, mk3(r, 0, 0));
+    q[2] = add3(posf, mk3(0, r, 0));
+    q[3] = add3(posf, mk3(0, 0, r));
+    q[4] = sub3(posf, mk3(r, 0, 0));
+    q[5] = sub3(posf, mk3(0, r, 0));
+    q[6] = sub3(posf, mk3(0, 0, r));
+    float w[7], d[7];
+    bool ok[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        f3v origin;
+        const int slot = chunk_at<N>(M, P, q[i], hx, hy, hz, nb, origin);
+        const f3v rel = sub3(q[i], origin);
+        const int cx = (int)floorf(rel.x * P.rf_voxel), cy = (int)floorf(rel.y * P.rf_voxel), cz = (int)floorf(rel.z * P.rf_voxel);
+        const int id = (cz * N + cy) * N + cx;
+        ok[i] = slot >= 0 && id >= 0 && id < N * N * N;  // GetSDF: chunk present, linear voxel id in range (Chunk.h:81-84)
+        const size_t off = ok[i] ? (size_t)slot * (N * N * N) + id : 0;
+        w[i] = M.wgt[off];
+        d[i] = M.sdf[off];
+    }
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+        if (!(ok[i] && (double)w[i] > 1e-12)) return false;
+    dist = (double)d[0];
+    grad = normalized3(mk3((float)((double)d[1] - (double)d[4]), (float)((double)d[2] - (double)d[5]), (float)((double)d[3] - (double)d[6])));  // grad->normalize()
     return true;
 }
 
 // ChunkManager::GetColorVoxel (ChunkManager.cpp:588-607): packed RGBW of the voxel containing `pos`
 template <int N>
-__device__ inline bool get_color_voxel(const MapView &M, const MeshParams &P, f3v pos, int hx, int hy, int hz, int hslot, uchar4 &out) {
+__device__ inline bool get_color_voxel(const MapView &M, const MeshParams &P, f3v pos, int hx, int hy, int hz, const int *nb, uchar4 &out) {
     f3v origin;
-    const int slot = chunk_at<N>(M, P, pos, hx, hy, hz, hslot, origin);
+    const int slot = chunk_at<N>(M, P, pos, hx, hy, hz, nb, origin);
     if (slot < 0) return false;
     const f3v rel = sub3(pos, origin);
     const int cx = (int)floorf(rel.x * P.rf_voxel), cy = (int)floorf(rel.y * P.rf_voxel), cz = (int)floorf(rel.z * P.rf_voxel);
@@ -160,22 +186,22 @@ __device__ inline bool get_color_voxel(const MapView &M, const MeshParams &P, f3
 // ChunkManager::InterpolateColor (ChunkManager.cpp:501-573), including its use of integer voxel indices as metric
 // positions for the 8 neighbour lookups (:506-520) and the nearest-voxel fallback Chunk::GetColorAt (Chunk.cpp:118-136)
 template <int N>
-__device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f3v cp, int hx, int hy, int hz, int hslot) {
+__device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f3v cp, int hx, int hy, int hz, const int *nb) {
     const float r = P.res;
     const int x0 = (int)floorf(cp.x / r), y0 = (int)floorf(cp.y / r), z0 = (int)floorf(cp.z / r);
     const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
     uchar4 v000, v001, v011, v111, v110, v100, v010, v101;
-    bool all = get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z0), hx, hy, hz, hslot, v000);
-    all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z1), hx, hy, hz, hslot, v001);
-    all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y1, (float)z1), hx, hy, hz, hslot, v011);
-    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y1, (float)z1), hx, hy, hz, hslot, v111);
-    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y1, (float)z0), hx, hy, hz, hslot, v110);
-    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y0, (float)z0), hx, hy, hz, hslot, v100);
-    all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y1, (float)z0), hx, hy, hz, hslot, v010);
-    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y0, (float)z1), hx, hy, hz, hslot, v101);
+    bool all = get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z0), hx, hy, hz, nb, v000);
+    all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z1), hx, hy, hz, nb, v001);
+    all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y1, (float)z1), hx, hy, hz, nb, v011);
+    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y1, (float)z1), hx, hy, hz, nb, v111);
+    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y1, (float)z0), hx, hy, hz, nb, v110);
+    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y0, (float)z0), hx, hy, hz, nb, v100);
+    all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y1, (float)z0), hx, hy, hz, nb, v010);
+    all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y0, (float)z1), hx, hy, hz, nb, v101);
     if (!all) {
         f3v origin;
-        const int slot = chunk_at<N>(M, P, cp, hx, hy, hz, hslot, origin);
+        const int slot = chunk_at<N>(M, P, cp, hx, hy, hz, nb, origin);
         if (slot < 0) return mk3(0.0f, 0.0f, 0.0f);
         // Chunk::GetColorAt: AABB::Contains, then (int)((pos - origin) / res)
         const float size = (float)N * P.res;
@@ -254,26 +280,26 @@ __global__ void mesh_collect_kernel(MapView M, unsigned *mesh_flag, int *ids, in
     }
 }
 
-// slots of each listed chunk and its 7 "+" neighbours; one thread per (job, neighbour)
+// slots of each listed chunk's 27-neighbourhood; 32 threads per job
 __global__ void mesh_jobs_kernel(MapView M, const int *ids, int n, MeshJob *jobs) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * 8) return;
-    const int j = t >> 3, b = t & 7;
-    const int x = ids[3 * j] + (b & 1), y = ids[3 * j + 1] + ((b >> 1) & 1), z = ids[3 * j + 2] + ((b >> 2) & 1);
-    jobs[j].nslot[b] = hash_find(M, x, y, z);
-    if (b == 0) {
+    const int j = t >> 5, o = t & 31;
+    if (j >= n) return;
+    if (o < 27) jobs[j].nb[o] = hash_find(M, ids[3 * j] + o % 3 - 1, ids[3 * j + 1] + (o / 3) % 3 - 1, ids[3 * j + 2] + o / 9 - 1);
+    if (o == 27) {
         jobs[j].x = ids[3 * j];
         jobs[j].y = ids[3 * j + 1];
         jobs[j].z = ids[3 * j + 2];
-        jobs[j].pad = 0;
+        jobs[j].pad[0] = jobs[j].pad[1] = 0;
     }
 }
 
+constexpr int MESH_BLOCK_THREADS = 512;  // per-chunk kernel: 8 cubes (16^3) per thread
+
 // corner voxel (cx, cy, cz), each in 0..N, of the cube grid of a job: (sdf, weight); absent chunk -> weight 0
 template <int N>
-__device__ inline float2 corner_voxel(const MapView &M, const int (&nslot)[8], int cx, int cy, int cz) {
-    const int b = (cx == N ? 1 : 0) | (cy == N ? 2 : 0) | (cz == N ? 4 : 0);
-    const int slot = nslot[b];
+__device__ inline float2 corner_voxel(const MapView &M, const int *nb, int cx, int cy, int cz) {
+    const int slot = nb[NB_SELF + (cx == N ? 1 : 0) + (cy == N ? 3 : 0) + (cz == N ? 9 : 0)];
     if (slot < 0) return make_float2(0.0f, 0.0f);
     const int lx = (cx == N) ? 0 : cx, ly = (cy == N) ? 0 : cy, lz = (cz == N) ? 0 : cz;
     const size_t off = (size_t)slot * (N * N * N) + (lz * N + ly) * N + lx;
@@ -291,19 +317,28 @@ struct CornerTile {
 };
 
 template <int N>
-__device__ inline void stage_corners(const MapView &M, const int (&nslot)[8], float2 *s_vox) {
+__device__ inline void stage_corners(const MapView &M, const int *nb, float2 *s_vox) {
     if (!CornerTile<N>::STAGED) return;
-    constexpr int E = N + 1;
-    for (int i = threadIdx.x; i < E * E * E; i += blockDim.x) {
-        const int cx = i % E, cy = (i / E) % E, cz = i / (E * E);
-        s_vox[i] = corner_voxel<N>(M, nslot, cx, cy, cz);
+    constexpr int E = N + 1, TOTAL = E * E * E, U = 5;  // five corners (ten loads) of a thread in flight together
+    for (int i0 = threadIdx.x; i0 < TOTAL; i0 += U * MESH_BLOCK_THREADS) {
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = min(i0 + u * MESH_BLOCK_THREADS, TOTAL - 1);
+            v[u] = corner_voxel<N>(M, nb, i % E, (i / E) % E, i / (E * E));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u * MESH_BLOCK_THREADS;
+            if (i < TOTAL) s_vox[i] = v[u];
+        }
     }
     __syncthreads();
 }
 
 // cube (x, y, z): corner sdf values and the case index; false when a corner is unobserved (weight <= 0.5)
 template <int N>
-__device__ inline bool cube_config(const MapView &M, const int (&nslot)[8], const float2 *s_vox, int x, int y, int z, float (&s)[8],
+__device__ inline bool cube_config(const MapView &M, const int *nb, const float2 *s_vox, int x, int y, int z, float (&s)[8],
                                    int &index) {
     // cubeIndexOffsets (ChunkManager.cpp:67-69)
     const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
@@ -313,7 +348,7 @@ __device__ inline bool cube_config(const MapView &M, const int (&nslot)[8], cons
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const float2 v = CornerTile<N>::STAGED ? s_vox[((z + oz[i]) * E + (y + oy[i])) * E + (x + ox[i])]
-                                               : corner_voxel<N>(M, nslot, x + ox[i], y + oy[i], z + oz[i]);
+                                               : corner_voxel<N>(M, nb, x + ox[i], y + oy[i], z + oz[i]);
         observed = observed && (v.y > 0.5f);  // :271 / :352 "weight <= 0.5 -> not observed"
         s[i] = v.x;
         index |= (v.x < 0.0f) ? (1 << i) : 0;  // MarchingCubes::CalculateVertexConfiguration MarchingCubes.h:108-118
@@ -355,42 +390,88 @@ __device__ inline void block_scan2(int a, int b, int &oa, int &ob, int &ta, int 
     __syncthreads();
 }
 
-constexpr int MESH_BLOCK = 256;
+constexpr int MESH_BLOCK = MESH_BLOCK_THREADS;
+constexpr int MESH_TRI_BLOCK = 256;  // per-triangle kernel
 
-// vertices / grids per job: counts[2*j], counts[2*j+1]
+// One triangle of the batch: which job, which cube (rank in the reference's traversal order), which case, which of the
+// cube's triangles; gidx = position of the cube among the job's occupied cubes (its entry in Mesh::grids).
+struct TriRec {
+    unsigned job;
+    unsigned code;   // rank << 11 | case index << 3 | triangle number
+    unsigned gidx;
+};
+
+// Per chunk (one workgroup): stage the corners, count (case table popcount) and scan the cubes in the reference's
+// traversal order, reserve the chunk's range of the batch's triangle / grid numbering with one atomic each and list its
+// triangles.  counts[2j], counts[2j+1] = vertices / grids of job j; bases[2j], bases[2j+1] = its first triangle / grid
+// in the batch (the chunks' ranges follow one another in completion order; within a chunk the order is the reference's).
+// totals[0..1] = running totals (the atomics), totals[2] = set when the triangle list is too small (the host retries).
 template <int N>
-__global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const MeshJob *jobs, int *counts) {
+__global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const MeshJob *jobs, int *counts, int *bases, int *totals,
+                                                                 TriRec *tris, int tri_capacity) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
-    __shared__ int s_nslot[8];
+    __shared__ int s_nb[27];
+    __shared__ int s_base[2];
     __shared__ float2 s_vox[CornerTile<N>::SIZE];
     constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
     const MeshJob &job = jobs[blockIdx.x];
-    if (threadIdx.x < 8) s_nslot[threadIdx.x] = job.nslot[threadIdx.x];
+    if (threadIdx.x < 27) s_nb[threadIdx.x] = job.nb[threadIdx.x];
     __syncthreads();
-    int nslot[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) nslot[i] = s_nslot[i];
-    if (nslot[0] >= 0) stage_corners<N>(M, nslot, s_vox);  // block-uniform
+    const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
+    if (present) stage_corners<N>(M, s_nb, s_vox);
     int nv = 0, ng = 0;
-    if (nslot[0] >= 0) {
+    unsigned char cases[CPT];  // case index of the thread's cubes that carry triangles (0: none -- case 0 has no triangles either)
+#pragma unroll
+    for (int k = 0; k < CPT; k++) cases[k] = 0;
+    if (present) {
+#pragma unroll
         for (int k = 0; k < CPT; k++) {
             const int r = threadIdx.x * CPT + k;
-            if (r >= V) break;
-            int x, y, z, index;
-            float s[8];
-            cube_of_rank<N>(r, x, y, z);
-            if (cube_config<N>(M, nslot, s_vox, x, y, z, s, index)) {
-                const int c = c_mc_counts[index];
-                nv += c;
-                ng += (c != 0);  // IsOccupied (MarchingCubes.h:41-45)
+            if (r < V) {
+                int x, y, z, index;
+                float sc[8];
+                cube_of_rank<N>(r, x, y, z);
+                if (cube_config<N>(M, s_nb, s_vox, x, y, z, sc, index)) {
+                    const int c = c_mc_counts[index];
+                    nv += c;
+                    ng += (c != 0);  // IsOccupied (MarchingCubes.h:41-45)
+                    cases[k] = c ? (unsigned char)index : 0;
+                }
             }
         }
     }
-    int oa, ob, ta, tb;
-    block_scan2<MESH_BLOCK>(nv, ng, oa, ob, ta, tb, s_scan);
+    int ov, og, tv, tg;
+    block_scan2<MESH_BLOCK>(nv, ng, ov, og, tv, tg, s_scan);
     if (threadIdx.x == 0) {
-        counts[2 * blockIdx.x] = ta;
-        counts[2 * blockIdx.x + 1] = tb;
+        const int tb = tv ? atomicAdd(&totals[0], tv / 3) : 0;
+        const int gb = tg ? atomicAdd(&totals[1], tg) : 0;
+        counts[2 * blockIdx.x] = tv;
+        counts[2 * blockIdx.x + 1] = tg;
+        bases[2 * blockIdx.x] = tb;
+        bases[2 * blockIdx.x + 1] = gb;
+        s_base[0] = tb;
+        if (tb + tv / 3 > tri_capacity) totals[2] = 1;
+    }
+    if (tv == 0) return;  // block-uniform
+    __syncthreads();
+    const int tb = s_base[0];
+    if (tb + tv / 3 > tri_capacity || nv == 0) return;
+    int tpos = tb + ov / 3, gidx = og;
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+        const int index = cases[k];
+        if (index == 0) continue;
+        const int r = threadIdx.x * CPT + k;
+        const int nt = c_mc_counts[index] / 3;
+        for (int t = 0; t < nt; t++) {
+            TriRec rec;
+            rec.job = blockIdx.x;
+            rec.code = ((unsigned)r << 11) | ((unsigned)index << 3) | (unsigned)t;
+            rec.gidx = (unsigned)gidx;
+            tris[tpos + t] = rec;
+        }
+        tpos += nt;
+        gidx++;
     }
 }
 
@@ -403,118 +484,76 @@ __device__ inline f3v interpolate_vertex(f3v v1, f3v v2, float sdf1, float sdf2)
     return add3(v1, scl3(sub3(v2, v1), t));
 }
 
-// offsets[2*j], offsets[2*j+1]: first vertex / grid of job j in the arena (3 floats per entry)
-template <int N>
-__global__ __launch_bounds__(MESH_BLOCK) void mesh_emit_kernel(MapView M, MeshParams P, const MeshJob *jobs, const int *offsets,
-                                                                float *vertices, float *normals, float *grids) {
-    __shared__ int s_scan[MESH_BLOCK / 64][2];
-    __shared__ int s_nslot[8];
-    __shared__ float2 s_vox[CornerTile<N>::SIZE];
-    constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
-    const MeshJob &job = jobs[blockIdx.x];
-    if (threadIdx.x < 8) s_nslot[threadIdx.x] = job.nslot[threadIdx.x];
-    __syncthreads();
-    int nslot[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) nslot[i] = s_nslot[i];
-    if (nslot[0] >= 0) stage_corners<N>(M, nslot, s_vox);  // block-uniform
-    const int jx = job.x, jy = job.y, jz = job.z;
-    // pass 1: this thread's share of the counts
-    int nv = 0, ng = 0;
-    if (nslot[0] >= 0) {
-        for (int k = 0; k < CPT; k++) {
-            const int r = threadIdx.x * CPT + k;
-            if (r >= V) break;
-            int x, y, z, index;
-            float s[8];
-            cube_of_rank<N>(r, x, y, z);
-            if (cube_config<N>(M, nslot, s_vox, x, y, z, s, index)) {
-                const int c = c_mc_counts[index];
-                nv += c;
-                ng += (c != 0);
-            }
-        }
-    }
-    int ov, og, tv, tg;
-    block_scan2<MESH_BLOCK>(nv, ng, ov, og, tv, tg, s_scan);
-    if (nslot[0] < 0 || nv == 0) return;
-    size_t vpos = (size_t)offsets[2 * blockIdx.x] + ov;
-    size_t gpos = (size_t)offsets[2 * blockIdx.x + 1] + og;
-    const f3v origin = mk3((float)(N * jx) * P.res, (float)(N * jy) * P.res, (float)(N * jz) * P.res);  // Chunk.cpp:43
-    const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-    for (int k = 0; k < CPT; k++) {
-        const int r = threadIdx.x * CPT + k;
-        if (r >= V) break;
-        int x, y, z, index;
-        float s[8];
-        cube_of_rank<N>(r, x, y, z);
-        if (!cube_config<N>(M, nslot, s_vox, x, y, z, s, index)) continue;
-        const unsigned long long row = c_mc_cases[index];
-        if ((row & 0xF) == 0xF) continue;
-        // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
-        const f3v coords = add3(mk3((float)x * P.res + P.half_res, (float)y * P.res + P.half_res, (float)z * P.res + P.half_res), origin);
-        grids[3 * gpos] = coords.x;
-        grids[3 * gpos + 1] = coords.y;
-        grids[3 * gpos + 2] = coords.z;
-        gpos++;
-        f3v cc[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++)  // cornerCoords (:278-279)
-            cc[i] = add3(coords, mk3((float)ox[i] * P.res, (float)oy[i] * P.res, (float)oz[i] * P.res));
-        for (int t = 0; t < 15; t += 3) {
-            if (((row >> (4 * t)) & 0xF) == 0xF) break;
-            f3v p[3];
-#pragma unroll
-            for (int a = 0; a < 3; a++) {  // vertices pushed in the order t+2, t+1, t (MarchingCubes.h:86-88)
-                const int e = (int)((row >> (4 * (t + 2 - a))) & 0xF);
-                const int e0 = c_mc_edges[e] & 0xF, e1 = c_mc_edges[e] >> 4;
-                p[a] = interpolate_vertex(cc[e0], cc[e1], s[e0], s[e1]);
-            }
-            const f3v fn = normalized3(cross3v(sub3(p[1], p[0]), sub3(p[2], p[0])));  // :95-101
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                vertices[3 * vpos] = p[a].x;
-                vertices[3 * vpos + 1] = p[a].y;
-                vertices[3 * vpos + 2] = p[a].z;
-                normals[3 * vpos] = fn.x;
-                normals[3 * vpos + 1] = fn.y;
-                normals[3 * vpos + 2] = fn.z;
-                vpos++;
-            }
-        }
-    }
-}
+// corner i of cube (x, y, z): cubeIndexOffsets (ChunkManager.cpp:67-69) = {0,1,1,0,0,1,1,0 / 0,0,1,1,0,0,1,1 / 0,0,0,0,1,1,1,1}
+__device__ inline int corner_ox(int i) { return ((i + 1) >> 1) & 1; }
+__device__ inline int corner_oy(int i) { return (i >> 1) & 1; }
+__device__ inline int corner_oz(int i) { return i >> 2; }
 
-// Second half of RecomputeMesh, one thread per VERTEX (the per-cube loop above leaves most lanes idle: few cubes carry
-// triangles): ComputeNormalsFromGradients (ChunkManager.cpp:609-626: the face normal stays when a lookup fails) and
-// ColorizeMesh (:628-639).  Reads the vertices mesh_emit_kernel wrote (kernel boundary = visibility).
+// One thread per triangle of the batch (the cubes that carry triangles are few and unevenly spread over the chunks, so a
+// per-chunk loop leaves most lanes idle): MeshCube (MarchingCubes.h:73-106) for that triangle -- vertices pushed in the
+// order t+2, t+1, t, face normal -- then the second half of RecomputeMesh for its three vertices:
+// ComputeNormalsFromGradients (ChunkManager.cpp:609-626: the face normal stays when a lookup fails) and ColorizeMesh
+// (:628-639), which read the map, not the mesh.  Triangle i owns vertices 3i .. 3i+2 of the arena; the first triangle of
+// a cube also writes the cube's grid entry.
 template <int N>
-__global__ __launch_bounds__(MESH_BLOCK) void mesh_shade_kernel(MapView M, MeshParams P, const MeshJob *jobs, const int *offsets,
-                                                                 const int *counts, const float *vertices, float *normals, float *colors) {
-    const MeshJob &job = jobs[blockIdx.x];
-    const int nv = counts[2 * blockIdx.x];
-    if (nv == 0) return;
-    const size_t base = (size_t)offsets[2 * blockIdx.x];
-    const int jx = job.x, jy = job.y, jz = job.z, jslot = job.nslot[0];
-    for (int v = threadIdx.x; v < nv; v += MESH_BLOCK) {
-        const size_t i = base + v;
-        const f3v p = mk3(vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]);
+__global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
+                                                                    const int *__restrict__ bases, const TriRec *__restrict__ tris, int n_tris,
+                                                                    float *vertices, float *normals, float *colors, float *grids) {
+    const int i = blockIdx.x * MESH_TRI_BLOCK + threadIdx.x;
+    if (i >= n_tris) return;
+    const TriRec rec = tris[i];
+    const MeshJob &job = jobs[rec.job];  // stays in memory (L1 / L2): its neighbour table is indexed per lane
+    const int *nb = job.nb;
+    const int jx = job.x, jy = job.y, jz = job.z;
+    const int r = (int)(rec.code >> 11), index = (int)((rec.code >> 3) & 0xffu), t = 3 * (int)(rec.code & 7u);
+    int x, y, z;
+    cube_of_rank<N>(r, x, y, z);
+    const unsigned long long row = c_mc_cases[index];
+    const f3v origin = mk3((float)(N * jx) * P.res, (float)(N * jy) * P.res, (float)(N * jz) * P.res);  // Chunk.cpp:43
+    // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
+    const f3v coords = add3(mk3((float)x * P.res + P.half_res, (float)y * P.res + P.half_res, (float)z * P.res + P.half_res), origin);
+    if (t == 0) {
+        const size_t g = (size_t)bases[2 * rec.job + 1] + rec.gidx;
+        grids[3 * g] = coords.x;
+        grids[3 * g + 1] = coords.y;
+        grids[3 * g + 2] = coords.z;
+    }
+    f3v p[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int ed = (int)((row >> (4 * (t + 2 - a))) & 0xF);
+        const int e0 = c_mc_edges[ed] & 0xF, e1 = c_mc_edges[ed] >> 4;
+        // cornerCoords (:278-279) and corner sdf of the two ends of the edge
+        const f3v c0 = add3(coords, mk3((float)corner_ox(e0) * P.res, (float)corner_oy(e0) * P.res, (float)corner_oz(e0) * P.res));
+        const f3v c1 = add3(coords, mk3((float)corner_ox(e1) * P.res, (float)corner_oy(e1) * P.res, (float)corner_oz(e1) * P.res));
+        const float s0 = corner_voxel<N>(M, nb, x + corner_ox(e0), y + corner_oy(e0), z + corner_oz(e0)).x;
+        const float s1 = corner_voxel<N>(M, nb, x + corner_ox(e1), y + corner_oy(e1), z + corner_oz(e1)).x;
+        p[a] = interpolate_vertex(c0, c1, s0, s1);
+    }
+    const f3v fn = normalized3(cross3v(sub3(p[1], p[0]), sub3(p[2], p[0])));  // :95-101
+    float *vo = vertices + 9 * (size_t)i;
+    float *no = normals + 9 * (size_t)i;
+    float *co = colors ? colors + 9 * (size_t)i : nullptr;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        vo[3 * a] = p[a].x;
+        vo[3 * a + 1] = p[a].y;
+        vo[3 * a + 2] = p[a].z;
+        f3v nrm = fn;
         double dist;
         f3v grad;
-        if (get_sdf_and_gradient<N>(M, P, p, jx, jy, jz, jslot, dist, grad)) {
+        if (get_sdf_and_gradient<N>(M, P, p[a], jx, jy, jz, nb, dist, grad)) {
             const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
-            if ((double)mag > 1e-12) {
-                const f3v nrm = scl3(grad, 1.0f / mag);
-                normals[3 * i] = nrm.x;
-                normals[3 * i + 1] = nrm.y;
-                normals[3 * i + 2] = nrm.z;
-            }
+            if ((double)mag > 1e-12) nrm = scl3(grad, 1.0f / mag);
         }
-        if (P.use_color) {
-            const f3v col = interpolate_color<N>(M, P, p, jx, jy, jz, jslot);
-            colors[3 * i] = col.x;
-            colors[3 * i + 1] = col.y;
-            colors[3 * i + 2] = col.z;
+        no[3 * a] = nrm.x;
+        no[3 * a + 1] = nrm.y;
+        no[3 * a + 2] = nrm.z;
+        if (co) {
+            const f3v col = interpolate_color<N>(M, P, p[a], jx, jy, jz, nb);
+            co[3 * a] = col.x;
+            co[3 * a + 1] = col.y;
+            co[3 * a + 2] = col.z;
         }
     }
 }
@@ -526,9 +565,9 @@ __global__ void query_sdf_kernel(MapView M, MeshParams P, float x, float y, floa
     f3v grad = mk3(0, 0, 0);
     bool ok;
     if (with_gradient)
-        ok = get_sdf_and_gradient<N>(M, P, mk3(x, y, z), 0x7fffffff, 0, 0, -1, dist, grad);
+        ok = get_sdf_and_gradient<N>(M, P, mk3(x, y, z), 0, 0, 0, nullptr, dist, grad);
     else
-        ok = get_sdf<N>(M, P, mk3(x, y, z), 0x7fffffff, 0, 0, -1, dist);
+        ok = get_sdf<N>(M, P, mk3(x, y, z), 0, 0, 0, nullptr, dist);
     out[0] = dist;
     out[1] = grad.x;
     out[2] = grad.y;
@@ -539,18 +578,18 @@ __global__ void query_sdf_kernel(MapView M, MeshParams P, float x, float y, floa
 struct MeshBuffers {
     MeshJob *jobs = nullptr;
     int *ids = nullptr;
-    int *counts = nullptr;   // [2 * capacity] counts, then [2 * capacity] offsets
+    int *counts = nullptr;   // [2 * capacity] counts, then [2 * capacity] bases, then [4] totals (triangles, grids, overflow)
+    TriRec *tris = nullptr;  // triangle list of one recompute
+    int tri_capacity = 0;
     int capacity = 0;        // jobs
     unsigned *flags = nullptr;  // [max_chunks] "mesh this slot"
-    float *arena = nullptr;  // vertices | normals | colors | grids
-    size_t arena_floats = 0;
     double *query = nullptr;
 };
 inline void free_mesh_buffers(MeshBuffers &b) {
     if (b.jobs) (void)hipFree(b.jobs);
     if (b.ids) (void)hipFree(b.ids);
     if (b.counts) (void)hipFree(b.counts);
-    if (b.arena) (void)hipFree(b.arena);
+    if (b.tris) (void)hipFree(b.tris);
     if (b.flags) (void)hipFree(b.flags);
     if (b.query) (void)hipFree(b.query);
     b = MeshBuffers();

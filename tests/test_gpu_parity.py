@@ -109,6 +109,15 @@ def test_device_color_fast_path_exhaustive(hip_lib):
     assert bad.value == 0
 
 
+def test_device_reciprocal_exhaustive(hip_lib):
+    """the short reciprocal used for the projection of chunks in front of the camera == IEEE 1.0f / z for every float of
+    its admitted range [2^-40, 2^40] (6.8e8 values, all checked on the device)"""
+    import ctypes as C
+    bad, ex = C.c_ulonglong(1), C.c_uint(0)
+    assert hip_lib.chisel_hip_kat_reciprocal(C.byref(bad), C.byref(ex)) == 0
+    assert bad.value == 0, "first mismatch at bits 0x%08x" % ex.value
+
+
 # ---- frame-level parity ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("scene", ["wall", "sphere_room", "box_room"])
 def test_depth_only_stream(oracle_mod, scene):
