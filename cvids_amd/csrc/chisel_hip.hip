@@ -52,6 +52,7 @@ struct IdHash {
 // released when no chunk points into it any more (every one of its chunks has been meshed again since).
 struct MeshArena {
     float *dev = nullptr;
+    size_t capacity = 0;       // floats allocated at dev
     size_t nv = 0, ng = 0;     // vertices / grids of the whole arena
     bool color = false;
     int live = 0;              // meshes of the map that point into this arena
@@ -139,6 +140,13 @@ struct chisel_hip_map {
     int update_meshes_calls = 0;                                       // Chisel.cpp:53 "static int cnt"
     std::unordered_map<uint64_t, MeshRef, IdHash> meshes;              // ChunkManager::allMeshes
     std::vector<MeshArena> arenas;
+    std::vector<std::pair<float *, size_t>> arena_pool;                // released arena buffers (floats), reused by later recomputes
+    struct PendingMeshes {                                             // a recompute whose per-chunk results are still on the device
+        bool active = false;
+        int n = 0;                                                     // jobs
+        int arena = -1;
+    } pending_meshes;
+    hipStream_t copy_stream = nullptr;                                 // small device->host copies that must not wait for queued batches
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
     MeshBuffers mesh_buf{};
@@ -652,6 +660,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         HIP_TRY_C(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, greatest));
     }
     m->stream = m->own_stream;
+    HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
     HIP_TRY_C(hipEventCreateWithFlags(&m->call_event, hipEventDisableTiming));
     for (auto &bs : m->sets) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));
@@ -713,7 +722,9 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->call_event) (void)hipEventDestroy(m->call_event);
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
+    if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     clear_meshes(m);
+    release_arena_pool(m);
     free_mesh_buffers(m->mesh_buf);
     for (const ProfEvent &p : m->prof_live) {
         (void)hipEventDestroy(p.start);

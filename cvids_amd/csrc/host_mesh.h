@@ -48,9 +48,14 @@ int ensure_mesh_jobs(chisel_hip_map *m, int n) {
     return CHISEL_HIP_OK;
 }
 
+// device counters of a recompute, behind the per-job arrays of mesh_buf.counts
+enum { MT_TRIS = 0, MT_GRIDS = 1, MT_OVERFLOW = 2, MT_JOBS = 3 };
+int *mesh_totals(chisel_hip_map *m) { return m->mesh_buf.counts + 4 * (size_t)m->mesh_buf.capacity; }
+
 // ids of the resident chunks to mesh, built on the device: the 27-neighbourhoods of the dirty slots, de-duplicated
-// through one flag per slot, plus `extra` host-side ids (neighbourhoods of chunks that were removed while dirty)
-int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra, int *n_out) {
+// through one flag per slot, plus `extra` host-side ids (neighbourhoods of chunks that were removed while dirty).
+// The number of ids stays on the device (mesh_totals()[MT_JOBS]); nothing here waits for the stream unless `extra` is used.
+int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
     MeshBuffers &B = m->mesh_buf;
     const int C = m->view.max_chunks;
     int rc = ensure_mesh_jobs(m, C);  // worst case: every resident chunk
@@ -59,10 +64,7 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra, int *n_ou
         HIP_TRY(hipMalloc(&B.flags, (size_t)C * sizeof(unsigned)));
         HIP_TRY(hipMemsetAsync(B.flags, 0, (size_t)C * sizeof(unsigned), m->stream));
     }
-    rc = ensure_scratch(m, 16);
-    if (rc) return rc;
-    int *d_count = m->scratch_i;
-    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), m->stream));
+    HIP_TRY(hipMemsetAsync(mesh_totals(m), 0, 4 * sizeof(int), m->stream));
     const long long threads = (long long)C * 27;
     hipLaunchKernelGGL(mesh_mark_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, m->view, B.flags);
     if (!extra.empty()) {
@@ -76,20 +78,43 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra, int *n_ou
             if (slots[i] >= 0) HIP_TRY(hipMemcpyAsync(B.flags + slots[i], one.data(), sizeof(unsigned), hipMemcpyHostToDevice, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
     }
-    hipLaunchKernelGGL(mesh_collect_kernel, dim3((C + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, B.ids, d_count);
+    hipLaunchKernelGGL(mesh_collect_kernel, dim3((C + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, B.ids, mesh_totals(m) + MT_JOBS);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(n_out, d_count, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
     return CHISEL_HIP_OK;
 }
 
+// Arena buffers are recycled: a released one goes to a small pool (no hipFree, which would wait for the device) and
+// the next recompute takes the tightest fit.  Safe without synchronisation: every kernel that touched a released
+// arena ran before the recompute that replaced its last mesh, whose results the host has already waited for.
 void free_arena(chisel_hip_map *m, MeshArena &A) {
-    // the stream may still be reading it (a copy in flight): stream-ordered release
     if (A.dev) {
-        (void)hipStreamSynchronize(m->stream);
-        (void)hipFree(A.dev);
+        m->arena_pool.emplace_back(A.dev, A.capacity);
+        if (m->arena_pool.size() > 8) {  // drop the smallest
+            size_t k = 0;
+            for (size_t i = 1; i < m->arena_pool.size(); i++)
+                if (m->arena_pool[i].second < m->arena_pool[k].second) k = i;
+            (void)hipFree(m->arena_pool[k].first);
+            m->arena_pool.erase(m->arena_pool.begin() + (long)k);
+        }
     }
     A = MeshArena();
+}
+int take_arena_buffer(chisel_hip_map *m, size_t floats, float **dev, size_t *capacity) {
+    long best = -1;
+    for (size_t i = 0; i < m->arena_pool.size(); i++)
+        if (m->arena_pool[i].second >= floats && m->arena_pool[i].second <= 4 * floats + (1u << 20) &&
+            (best < 0 || m->arena_pool[i].second < m->arena_pool[(size_t)best].second))
+            best = (long)i;
+    if (best >= 0) {
+        *dev = m->arena_pool[(size_t)best].first;
+        *capacity = m->arena_pool[(size_t)best].second;
+        m->arena_pool.erase(m->arena_pool.begin() + best);
+        return CHISEL_HIP_OK;
+    }
+    const size_t cap = floats + floats / 4 + 1024;  // headroom: consecutive recomputes are of similar size
+    HIP_TRY(hipMalloc(dev, cap * sizeof(float)));
+    *capacity = cap;
+    return CHISEL_HIP_OK;
 }
 void release_mesh_ref(chisel_hip_map *m, MeshRef &ref) {
     if (ref.arena >= 0) {
@@ -99,60 +124,72 @@ void release_mesh_ref(chisel_hip_map *m, MeshRef &ref) {
     ref = MeshRef();
 }
 void clear_meshes(chisel_hip_map *m) {
+    m->pending_meshes.active = false;
     for (MeshArena &A : m->arenas) free_arena(m, A);
     m->arenas.clear();
     m->meshes.clear();
 }
+void release_arena_pool(chisel_hip_map *m) {
+    for (auto &b : m->arena_pool) (void)hipFree(b.first);
+    m->arena_pool.clear();
+}
 
-// meshes of the n chunks whose ids sit in mesh_buf.ids (device)
-int recompute_meshes(chisel_hip_map *m, int n) {
-    if (n == 0) return CHISEL_HIP_OK;
+// Wait for the stream by polling: the wake-up of a blocking wait costs more than the kernels being waited for.
+hipError_t wait_stream_spinning(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(st);
+    }
+}
+
+// meshes of the chunks whose ids sit in mesh_buf.ids (device; their number too).  One wait for the device: the
+// totals after the count kernel, which size the arena.
+int recompute_meshes(chisel_hip_map *m) {
     MeshBuffers &B = m->mesh_buf;
-    hipLaunchKernelGGL(mesh_jobs_kernel, dim3((n * 32 + 255) / 256), dim3(256), 0, m->stream, m->view, B.ids, n, B.jobs);
-    std::vector<int> counts((size_t)n * 2), bases((size_t)n * 2);
-    std::vector<MeshJob> jobs(n);
+    int *d_totals = mesh_totals(m);
+    hipLaunchKernelGGL(mesh_jobs_kernel, dim3(256), dim3(256), 0, m->stream, m->view, B.ids, d_totals + MT_JOBS, B.jobs);
     int totals[4] = {0, 0, 0, 0};
     for (int attempt = 0;; attempt++) {
         if (!B.tris) {
             B.tri_capacity = std::max(B.tri_capacity, 1 << 20);
             HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
         }
-        int *d_totals = B.counts + 4 * (size_t)B.capacity;
-        HIP_TRY(hipMemsetAsync(d_totals, 0, 4 * sizeof(int), m->stream));
         {
             ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+            const dim3 grid(2048);
+            int *bases = B.counts + 2 * (size_t)B.capacity;
             switch (m->N) {
-                case 8: launch_mesh_count<8>(m, n); break;
-                case 16: launch_mesh_count<16>(m, n); break;
-                case 32: launch_mesh_count<32>(m, n); break;
+                case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+                case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+                case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
             }
         }
         HIP_TRY(hipGetLastError());
+        int error_flag = 0;
         HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipMemcpyAsync(counts.data(), B.counts, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipMemcpyAsync(bases.data(), B.counts + 2 * (size_t)B.capacity, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        if (attempt == 0) HIP_TRY(hipMemcpyAsync(jobs.data(), B.jobs, (size_t)n * sizeof(MeshJob), hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        if (!totals[2]) break;
+        HIP_TRY(hipMemcpyAsync(&error_flag, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(wait_stream_spinning(m->stream));
+        if (error_flag != 0)  // a chunk of an earlier batch could not be allocated: the map is incomplete
+            return fail(CHISEL_HIP_ERR_POOL_FULL, error_flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
+                                                                   : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
+        if (!totals[MT_OVERFLOW]) break;
         // the triangle list was too small: grow it to what this batch needs and list again
         if (attempt > 0) return fail(CHISEL_HIP_ERR_HIP, "mesh triangle list overflow after growing it");
         HIP_TRY(hipFree(B.tris));
         B.tris = nullptr;
-        while (B.tri_capacity < totals[0]) B.tri_capacity *= 2;
+        while (B.tri_capacity < totals[MT_TRIS]) B.tri_capacity *= 2;
+        HIP_TRY(hipMemsetAsync(d_totals, 0, 3 * sizeof(int), m->stream));  // keeps MT_JOBS
     }
-    if ((size_t)totals[0] > 0x7fffffffull / 9) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^31 / 9 mesh triangles in one recompute");
-    const size_t nv = (size_t)totals[0] * 3, ng = (size_t)totals[1];
-    std::vector<int> offsets((size_t)n * 2);
-    for (int j = 0; j < n; j++) {
-        offsets[2 * j] = 3 * bases[2 * j];      // first vertex of the job in the arena
-        offsets[2 * j + 1] = bases[2 * j + 1];  // first grid entry
+    const int n = totals[MT_JOBS];
+    if (n == 0) {
+        hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+        return CHISEL_HIP_OK;
     }
+    if ((size_t)totals[MT_TRIS] > 0x7fffffffull / 9) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^31 / 9 mesh triangles in one recompute");
+    const size_t nv = (size_t)totals[MT_TRIS] * 3, ng = (size_t)totals[MT_GRIDS];
     const bool color = m->cfg.use_color != 0;
-    if (g_host_timer.on) {
-        int with_tris = 0;
-        for (int j = 0; j < n; j++) with_tris += counts[2 * j] != 0;
-        fprintf(stderr, "chisel_hip mesh recompute: %d jobs, %d with triangles, %zu vertices, %zu grids\n", n, with_tris, nv, ng);
-    }
     int arena_id = -1;
     if (nv + ng) {
         // a free arena record, or a new one
@@ -169,18 +206,49 @@ int recompute_meshes(chisel_hip_map *m, int n) {
         A.live = 0;
         A.host.clear();
         A.host_valid = false;
-        HIP_TRY(hipMalloc(&A.dev, A.floats() * sizeof(float)));
+        int rc_a = take_arena_buffer(m, A.floats(), &A.dev, &A.capacity);
+        if (rc_a) return rc_a;
         float *d_v = A.dev, *d_n = d_v + nv * 3, *d_c = d_n + nv * 3, *d_g = d_c + (color ? nv * 3 : 0);
         const MeshParams P = mesh_params(m);
-        if (totals[0]) {
+        if (totals[MT_TRIS]) {
             ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
             switch (m->N) {
-                case 8: launch_mesh_triangles<8>(m, totals[0], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
-                case 16: launch_mesh_triangles<16>(m, totals[0], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
-                case 32: launch_mesh_triangles<32>(m, totals[0], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 8: launch_mesh_triangles<8>(m, totals[MT_TRIS], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 16: launch_mesh_triangles<16>(m, totals[MT_TRIS], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+                case 32: launch_mesh_triangles<32>(m, totals[MT_TRIS], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
             }
         }
         HIP_TRY(hipGetLastError());
+    }
+    // meshesToUpdate.clear() (Chisel.cpp:57): queued behind the triangle kernel, before the host goes on
+    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    HIP_TRY(hipGetLastError());
+    // The per-chunk results (sizes, positions in the arena, ids) stay on the device for now: the caller's next batch is
+    // queued first, the bookkeeping follows when a mesh is next asked for or recomputed (resolve_pending_meshes).
+    m->pending_meshes.active = true;
+    m->pending_meshes.n = n;
+    m->pending_meshes.arena = arena_id;
+    return CHISEL_HIP_OK;
+}
+
+// Second half of a recompute: ChunkManager::allMeshes on the host side (which chunk's mesh is where).  The device
+// buffers read here were complete when recompute_meshes returned (it waited for the count kernel), so the copies use
+// their own stream and do not wait for batches queued since.
+int resolve_pending_meshes(chisel_hip_map *m) {
+    if (!m->pending_meshes.active) return CHISEL_HIP_OK;
+    m->pending_meshes.active = false;
+    MeshBuffers &B = m->mesh_buf;
+    const int n = m->pending_meshes.n, arena_id = m->pending_meshes.arena;
+    std::vector<int> counts((size_t)n * 2), bases((size_t)n * 2);
+    std::vector<MeshJob> jobs(n);
+    HIP_TRY(hipMemcpyAsync(counts.data(), B.counts, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
+    HIP_TRY(hipMemcpyAsync(bases.data(), B.counts + 2 * (size_t)B.capacity, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
+    HIP_TRY(hipMemcpyAsync(jobs.data(), B.jobs, (size_t)n * sizeof(MeshJob), hipMemcpyDeviceToHost, m->copy_stream));
+    HIP_TRY(hipStreamSynchronize(m->copy_stream));
+    if (g_host_timer.on) {
+        int with_tris = 0;
+        for (int j = 0; j < n; j++) with_tris += counts[2 * j] != 0;
+        fprintf(stderr, "chisel_hip mesh recompute: %d jobs, %d with triangles\n", n, with_tris);
     }
     for (int j = 0; j < n; j++) {
         if (jobs[j].nb[NB_SELF] < 0) continue;  // RecomputeMesh: "if (!HasChunk(chunkID)) return" (ChunkManager.cpp:93-96)
@@ -197,9 +265,9 @@ int recompute_meshes(chisel_hip_map *m, int n) {
         release_mesh_ref(m, ref);
         if (cv + cg) {
             ref.arena = arena_id;
-            ref.v_off = (size_t)offsets[2 * j];
+            ref.v_off = 3 * (size_t)bases[2 * j];  // first vertex of the job in the arena
             ref.n_v = cv;
-            ref.g_off = (size_t)offsets[2 * j + 1];
+            ref.g_off = (size_t)bases[2 * j + 1];  // first grid entry
             ref.n_g = cg;
             m->arenas[arena_id].live++;
         }
@@ -290,8 +358,7 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
     HIP_TRY(hipSetDevice(m->device));
     // Chisel.cpp:53-58: "static int cnt = 0; if (cnt++ % 10 == 0)" -- the recompute runs on every 10th call
     if (!force && (m->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;
-    int rc = check_device_error(m);
-    if (rc) return rc;
+    int rc = CHISEL_HIP_OK;
     std::vector<int> extra;
     extra.reserve(m->pending_mesh_ids.size() * 3);
     for (uint64_t key : m->pending_mesh_ids) {
@@ -299,26 +366,30 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
         unpack_id(key, x, y, z);
         extra.push_back(x); extra.push_back(y); extra.push_back(z);
     }
-    int n = 0;
-    rc = collect_mesh_ids(m, extra, &n);
+    rc = resolve_pending_meshes(m);  // the device buffers of the previous recompute are about to be reused
     if (rc) return rc;
-    rc = recompute_meshes(m, n);
+    rc = collect_mesh_ids(m, extra);
     if (rc) return rc;
-    // meshesToUpdate.clear() (Chisel.cpp:57)
-    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
-    HIP_TRY(hipGetLastError());
+    rc = recompute_meshes(m);  // ends with meshesToUpdate.clear() (Chisel.cpp:57)
+    if (rc) return rc;
     m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;
 }
 
 int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) {
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc_p = resolve_pending_meshes(m);
+    if (rc_p) return rc_p;
     *out = (int64_t)m->meshes.size();
     return CHISEL_HIP_OK;
 }
 
 int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
     if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc_p = resolve_pending_meshes(m);
+    if (rc_p) return rc_p;
     const std::vector<uint64_t> keys = sorted_mesh_keys(m);
     *count = (int64_t)keys.size();
     if (ids)
@@ -328,6 +399,9 @@ int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t
 
 int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_t *ng) {
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc_p = resolve_pending_meshes(m);
+    if (rc_p) return rc_p;
     auto it = m->meshes.find(pack_id(id[0], id[1], id[2]));
     if (it == m->meshes.end()) return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh for this chunk (ChunkManager::GetMesh would throw std::out_of_range)");
     if (nv) *nv = (int64_t)it->second.n_v;
@@ -337,6 +411,9 @@ int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_
 
 int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float *n, float *c, float *g) {
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc_p = resolve_pending_meshes(m);
+    if (rc_p) return rc_p;
     auto it = m->meshes.find(pack_id(id[0], id[1], id[2]));
     if (it == m->meshes.end()) return fail(CHISEL_HIP_ERR_NOT_FOUND, "no mesh for this chunk (ChunkManager::GetMesh would throw std::out_of_range)");
     HIP_TRY(hipSetDevice(m->device));
@@ -368,6 +445,8 @@ int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
     std::ofstream stream(path);
     if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
     HIP_TRY(hipSetDevice(m->device));
+    int rc_p = resolve_pending_meshes(m);
+    if (rc_p) return rc_p;
     const std::vector<uint64_t> keys = sorted_mesh_keys(m);
     size_t numPoints = 0;
     bool any_color = false;

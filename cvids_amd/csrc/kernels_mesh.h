@@ -281,16 +281,17 @@ __global__ void mesh_collect_kernel(MapView M, unsigned *mesh_flag, int *ids, in
 }
 
 // slots of each listed chunk's 27-neighbourhood; 32 threads per job
-__global__ void mesh_jobs_kernel(MapView M, const int *ids, int n, MeshJob *jobs) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t >> 5, o = t & 31;
-    if (j >= n) return;
-    if (o < 27) jobs[j].nb[o] = hash_find(M, ids[3 * j] + o % 3 - 1, ids[3 * j + 1] + (o / 3) % 3 - 1, ids[3 * j + 2] + o / 9 - 1);
-    if (o == 27) {
-        jobs[j].x = ids[3 * j];
-        jobs[j].y = ids[3 * j + 1];
-        jobs[j].z = ids[3 * j + 2];
-        jobs[j].pad[0] = jobs[j].pad[1] = 0;
+__global__ void mesh_jobs_kernel(MapView M, const int *ids, const int *__restrict__ n_jobs, MeshJob *jobs) {
+    const int n = *n_jobs;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; (t >> 5) < n; t += gridDim.x * blockDim.x) {
+        const int j = t >> 5, o = t & 31;
+        if (o < 27) jobs[j].nb[o] = hash_find(M, ids[3 * j] + o % 3 - 1, ids[3 * j + 1] + (o / 3) % 3 - 1, ids[3 * j + 2] + o / 9 - 1);
+        if (o == 27) {
+            jobs[j].x = ids[3 * j];
+            jobs[j].y = ids[3 * j + 1];
+            jobs[j].z = ids[3 * j + 2];
+            jobs[j].pad[0] = jobs[j].pad[1] = 0;
+        }
     }
 }
 
@@ -407,14 +408,17 @@ struct TriRec {
 // in the batch (the chunks' ranges follow one another in completion order; within a chunk the order is the reference's).
 // totals[0..1] = running totals (the atomics), totals[2] = set when the triangle list is too small (the host retries).
 template <int N>
-__global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const MeshJob *jobs, int *counts, int *bases, int *totals,
-                                                                 TriRec *tris, int tri_capacity) {
+__global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const MeshJob *jobs, const int *__restrict__ n_jobs, int *counts,
+                                                                 int *bases, int *totals, TriRec *tris, int tri_capacity) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nb[27];
     __shared__ int s_base[2];
     __shared__ float2 s_vox[CornerTile<N>::SIZE];
     constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
-    const MeshJob &job = jobs[blockIdx.x];
+    const int n = *n_jobs;  // the job count stays on the device: the grid is persistent
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    __syncthreads();  // the previous job's LDS contents are no longer read
+    const MeshJob &job = jobs[j];
     if (threadIdx.x < 27) s_nb[threadIdx.x] = job.nb[threadIdx.x];
     __syncthreads();
     const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
@@ -445,17 +449,17 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     if (threadIdx.x == 0) {
         const int tb = tv ? atomicAdd(&totals[0], tv / 3) : 0;
         const int gb = tg ? atomicAdd(&totals[1], tg) : 0;
-        counts[2 * blockIdx.x] = tv;
-        counts[2 * blockIdx.x + 1] = tg;
-        bases[2 * blockIdx.x] = tb;
-        bases[2 * blockIdx.x + 1] = gb;
+        counts[2 * j] = tv;
+        counts[2 * j + 1] = tg;
+        bases[2 * j] = tb;
+        bases[2 * j + 1] = gb;
         s_base[0] = tb;
         if (tb + tv / 3 > tri_capacity) totals[2] = 1;
     }
-    if (tv == 0) return;  // block-uniform
+    if (tv == 0) continue;  // block-uniform
     __syncthreads();
     const int tb = s_base[0];
-    if (tb + tv / 3 > tri_capacity || nv == 0) return;
+    if (tb + tv / 3 > tri_capacity || nv == 0) continue;
     int tpos = tb + ov / 3, gidx = og;
 #pragma unroll
     for (int k = 0; k < CPT; k++) {
@@ -465,13 +469,14 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
         const int nt = c_mc_counts[index] / 3;
         for (int t = 0; t < nt; t++) {
             TriRec rec;
-            rec.job = blockIdx.x;
+            rec.job = (unsigned)j;
             rec.code = ((unsigned)r << 11) | ((unsigned)index << 3) | (unsigned)t;
             rec.gidx = (unsigned)gidx;
             tris[tpos + t] = rec;
         }
         tpos += nt;
         gidx++;
+    }
     }
 }
 
