@@ -150,7 +150,7 @@ def main():
     import ctypes as C
     from cvids_amd import capi
     from cvids_amd.chisel import color_frame, depth_frame
-    from cvids_amd.sharded import FrameExchange, frames_of_rank, pack_meta
+    from cvids_amd.sharded import FrameExchange, PipelinedExchange, frames_of_rank, pack_meta
     K = max(1, args.batch)
     if world > 1 and K % world:
         K = max(world, (K // world) * world)  # every rank contributes K / world frame slots to each all-gather
@@ -187,8 +187,8 @@ def main():
     def new_map():
         m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
                    n_shards=world, shard_rank=rank)
-        m.set_stream(torch.cuda.current_stream().cuda_stream)  # RCCL -> integrate ordering comes from the stream
         m._use(integ)
+        m.px = PipelinedExchange(xch, m) if world > 1 else None  # RCCL -> integrate ordering: events, no host wait
         return m
 
     def run(m, b_lo, b_hi):
@@ -196,10 +196,12 @@ def main():
         for b in range(b_lo, b_hi):
             n, fa, ca = calls[b]
             if world > 1:
-                xch.exchange(stack[b], meta[b], buffer=b & 1)  # RCCL all-gather, ordered before the kernels on this stream
+                m.px.exchange(b, stack[b], meta[b])  # RCCL all-gather on the communication stream; the map waits for its event
             rc = L.chisel_hip_integrate_batch(h, n, fa, ca)
             if rc:
                 capi.check(rc)
+            if world > 1:
+                m.px.consumed(b)
             if args.mesh_every and (bounds[b][1] // args.mesh_every) > (bounds[b][0] // args.mesh_every):
                 m.UpdateMeshes(force=True)
 

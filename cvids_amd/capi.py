@@ -48,7 +48,7 @@ class ColorFrame(C.Structure):
 EXPORTS = [
     "chisel_hip_abi_version", "chisel_hip_last_error", "chisel_hip_device_count", "chisel_hip_create",
     "chisel_hip_destroy", "chisel_hip_reset", "chisel_hip_set_integrator", "chisel_hip_set_stream",
-    "chisel_hip_synchronize", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
+    "chisel_hip_synchronize", "chisel_hip_wait_event", "chisel_hip_record_event", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
     "chisel_hip_integrate_batch", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
     "chisel_hip_list_chunks", "chisel_hip_has_chunk", "chisel_hip_download_chunk", "chisel_hip_upload_chunk",
     "chisel_hip_meshes_to_update", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
@@ -125,8 +125,14 @@ def load_library():
     L.chisel_hip_kat_truncation.argtypes = [C.c_int, C.c_float, f32p, C.c_int, f32p, f32p]
     L.chisel_hip_kat_dist.argtypes = [f32p, C.c_int, f32p]
     L.chisel_hip_kat_color.argtypes = [u8p, C.c_int, u8p]
-    L.chisel_hip_kat_color_fresh.argtypes = [C.POINTER(C.c_uint)]
-    L.chisel_hip_kat_reciprocal.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
+    # entry points added after ABI version 1 was first built (an older library simply lacks them: A/B runs of tools/)
+    for name, types in (("chisel_hip_wait_event", [vp, vp]), ("chisel_hip_record_event", [vp, vp]),
+                        ("chisel_hip_kat_color_fresh", [C.POINTER(C.c_uint)]),
+                        ("chisel_hip_kat_reciprocal", [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)])):
+        try:
+            getattr(L, name).argtypes = types
+        except AttributeError:
+            pass
     L.chisel_hip_debug_frustum_range.argtypes = [f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                                  C.c_int, C.c_float, i32p, i32p, f32p, f32p]
     _lib = L

@@ -214,6 +214,14 @@ class Chisel:
     def set_stream(self, hip_stream):
         check(self.L.chisel_hip_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def wait_event(self, hip_event):
+        """the device frames of the next Integrate* call are complete behind this hipEvent_t (e.g. torch.cuda.Event.cuda_event)"""
+        check(self.L.chisel_hip_wait_event(self.h, C.c_void_p(hip_event)))
+
+    def record_event(self, hip_event):
+        """record the hipEvent_t behind everything queued on the map: after it the frames of earlier calls have been read"""
+        check(self.L.chisel_hip_record_event(self.h, C.c_void_p(hip_event)))
+
     def NumChunks(self):
         n = C.c_int64(0)
         check(self.L.chisel_hip_num_chunks(self.h, C.byref(n)))

@@ -126,6 +126,7 @@ struct chisel_hip_map {
     hipEvent_t call_event = nullptr;     // caller-provided stream: orders the front after the caller's producers
     hipEvent_t mutation_event = nullptr; // map changed outside the integration path (reset, upload): the next front waits
     bool mutation_pending = false;
+    hipEvent_t input_event = nullptr;    // chisel_hip_wait_event: the next batch's frames are ready behind this (caller's) event
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b & 1]
     int items_capacity = 0;
@@ -433,6 +434,11 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     if (m->mutation_pending) {
         HIP_TRY(hipStreamWaitEvent(m->aux, m->mutation_event, 0));
         m->mutation_pending = false;
+    }
+    if (m->input_event) {  // depth is read by the front half, colour by the integration kernel
+        HIP_TRY(hipStreamWaitEvent(m->aux, m->input_event, 0));
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
     }
 
     g_host_timer.lap(0);
@@ -759,6 +765,19 @@ int chisel_hip_set_stream(chisel_hip_map *m, void *s) {
     int rc = sync_all(m);
     if (rc) return rc;
     m->stream = s ? (hipStream_t)s : m->own_stream;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_wait_event(chisel_hip_map *m, void *ev) {
+    if (!m || !ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    m->input_event = (hipEvent_t)ev;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_record_event(chisel_hip_map *m, void *ev) {
+    if (!m || !ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, m->stream));
     return CHISEL_HIP_OK;
 }
 

@@ -98,6 +98,43 @@ class FrameExchange:
         return self.depth_view(b), self.meta_view(b), (self.color[b] if self.C else None)
 
 
+class PipelinedExchange:
+    """FrameExchange on its own stream, ordered against the map with events only (no host synchronisation):
+    the all-gather of batch b+1 runs while batch b is being integrated.
+
+        px = PipelinedExchange(xch, local_map)
+        for b, (local_depth, local_meta) in enumerate(batches):
+            depth, meta, _ = px.exchange(b, local_depth, local_meta)   # queued on the communication stream
+            local_map.IntegrateBatch(...)                               # waits (on the device) for that all-gather
+            px.consumed(b)                                              # buffer b & 1 may be refilled after this batch
+
+    Buffer b & 1 is reused by batch b + 2: its all-gather waits for the event recorded by consumed(b).
+    """
+
+    def __init__(self, exchange, local_map):
+        torch = exchange.torch
+        self.x, self.map, self.torch = exchange, local_map, torch
+        dev = exchange.recv[0].device
+        self.comm = torch.cuda.Stream(device=dev)
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        for e in self.ready + self.free:  # a first record creates the hipEvent_t behind the torch object
+            e.record(self.comm)
+
+    def exchange(self, b, local_depth, local_meta, local_color=None):
+        torch = self.torch
+        self.comm.wait_stream(torch.cuda.current_stream())  # the local slots were produced on the caller's stream
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.free[b & 1])
+            out = self.x.exchange(local_depth, local_meta, local_color, buffer=b & 1)
+            self.ready[b & 1].record(self.comm)
+        self.map.wait_event(self.ready[b & 1].cuda_event)
+        return out
+
+    def consumed(self, b):
+        self.map.record_event(self.free[b & 1].cuda_event)
+
+
 class ShardedChisel:
     """chisel::Chisel surface over the shards of one node (only what the sharded path changes)."""
 

@@ -132,6 +132,13 @@ int chisel_hip_set_integrator(chisel_hip_map *map, const chisel_hip_integrator *
 /* run the map's kernels on a caller-owned hipStream_t (NULL = the map's own stream) */
 int chisel_hip_set_stream(chisel_hip_map *map, void *hip_stream);
 int chisel_hip_synchronize(chisel_hip_map *map);
+/* Ordering against work the caller queued on OTHER streams, without blocking the host (no reference counterpart: the
+ * reference's images are host buffers).  wait_event: the device frames of the next integrate call are complete once
+ * `hip_event` (a hipEvent_t the caller recorded behind their producer, e.g. an RCCL all-gather) has completed.
+ * record_event: records `hip_event` behind everything queued on the map so far -- once it has completed the frames of
+ * all earlier integrate calls have been read and their buffers may be overwritten. */
+int chisel_hip_wait_event(chisel_hip_map *map, void *hip_event);
+int chisel_hip_record_event(chisel_hip_map *map, void *hip_event);
 
 /* ---- the hot path ------------------------------------------------------------------------------------ */
 /* Chisel::IntegrateDepthScan<float> Chisel.h:59-112 -> ProjectionIntegrator::Integrate ProjectionIntegrator.h:51-99

@@ -354,6 +354,41 @@ def test_back_to_back_batches_pipeline(oracle_mod, batch, force_lookup, monkeypa
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+def test_event_ordered_device_frames(oracle_mod):
+    """chisel_hip_wait_event / chisel_hip_record_event: device frames produced late on another stream (as an RCCL
+    all-gather would) and one frame buffer reused for every batch, ordered with events only -- no host wait anywhere."""
+    import torch
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+    frames = make_frames("sphere_room", 6, 64, 48, agents=2, nan_fraction=0.02)  # 12 frames
+    assert len(frames) == 12
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+    dev = torch.device("cuda:0")
+    src = [torch.from_numpy(np.stack([frames[lo + j][0] for j in range(4)])).to(dev) for lo in range(0, 12, 4)]
+    c_dev = torch.from_numpy(color).to(dev)
+    buf = torch.zeros((4, 48, 64), dtype=torch.float32, device=dev)  # ONE buffer for all batches
+    producer = torch.cuda.Stream(device=dev)
+    ready, free = torch.cuda.Event(), torch.cuda.Event()
+    ready.record(producer)
+    free.record(producer)
+    torch.cuda.synchronize()
+    for b in range(3):
+        with torch.cuda.stream(producer):
+            producer.wait_event(free)               # the previous batch has read the buffer
+            torch.cuda._sleep(20_000_000)           # the data arrives late (about 10 ms)
+            buf.copy_(src[b], non_blocking=True)
+            ready.record(producer)
+        gm.wait_event(ready.cuda_event)
+        part = frames[4 * b:4 * b + 4]
+        gm.IntegrateBatch(integ, [(buf[j], p, cam) for j, (_, p) in enumerate(part)], [(c_dev, p, cam) for _, p in part])
+        gm.record_event(free.cuda_event)
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
 @pytest.mark.parametrize("N,res,W,H", [(16, 0.04, 96, 72), (32, 0.02, 64, 48)])
 def test_batched_launch_chunk_sizes(oracle_mod, N, res, W, H):
     om, gm, integ = _mk(oracle_mod, N, res, True, max_chunks=2048)
