@@ -49,8 +49,12 @@ def parse():
     ap.add_argument("--no-color", action="store_true", help="depth-only path (IntegrateDepthScan)")
     ap.add_argument("--agents", type=int, default=1)
     ap.add_argument("--trunc-scale", type=float, default=None, help="InverseTruncator scale (default: 100*res)")
-    ap.add_argument("--mesh-every", type=int, default=0, help="UpdateMeshes(force) every M frames inside the timed region")
-    ap.add_argument("--batch", type=int, default=8, help="frames per chisel_hip_integrate_batch call (<= 8 share one launch set)")
+    ap.add_argument("--mesh-every", type=int, default=None,
+                    help="marching-cubes recompute (UpdateMeshes) every M frames inside the timed region; default: 10 at 1 GPU (the "
+                         "reference's keyframe cadence, Chisel.cpp:54 -- BASELINE config 3), 0 = off (N > 1: a sharded map is not meshed yet)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per chisel_hip_integrate_batch call (<= 8 share one launch set); default: the keyframe interval when "
+                         "meshing (10 = two launch sets of 5, the recompute falls exactly on every 10th frame), else 8")
     ap.add_argument("--max-chunks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same stream the CPU oracle is timed on (about 1 s each at 1 cm)")
@@ -133,6 +137,10 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
+    if args.mesh_every is None:
+        args.mesh_every = 10 if world == 1 else 0
+    if args.batch is None:
+        args.batch = args.mesh_every if 0 < args.mesh_every <= 16 else 8
     W, H = args.width, args.height
     intr = synth.intrinsics(W, H)
     cam = PinholeCamera(*intr, W, H, 0.05, 5.0)
@@ -266,6 +274,22 @@ def main():
                 "instrumented_ms_per_step": dt_b / args.steps * 1e3,
                 "note": "rank 0 shard; traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by tools/profile.sh into profiles/"}
 
+    # ---- pass C (1 GPU, meshing on): the same stream without the mesh recomputes, for reference ----------------
+    no_mesh = None
+    if args.mesh_every and world == 1 and not args.no_roofline:
+        every, args.mesh_every = args.mesh_every, 0
+        m = new_map()
+        run(m, 0, first_timed)
+        m.synchronize()
+        fence()
+        t2 = time.perf_counter()
+        run(m, first_timed, len(bounds))
+        fence()
+        dt_c = time.perf_counter() - t2
+        m.close()
+        args.mesh_every = every
+        no_mesh = {"value": args.steps / dt_c, "unit": "frames/s", "ms_per_step": dt_c / args.steps * 1e3}
+
     if rank == 0:
         out = {
             "metric": METRIC, "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -285,6 +309,8 @@ def main():
         }
         if roof:
             out["roofline"] = roof
+        if no_mesh:
+            out["integration_only"] = no_mesh
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, frames[args.warmup:], color_img, intr, scale)
         print(json.dumps(out), flush=True)

@@ -89,7 +89,7 @@ struct CameraParams {
 
 // One launch set (pyramid -> cull -> integrate) handles up to KMAX frames, applied to every voxel in
 // frame order.  All per-frame constants travel in the kernel-argument segment (scalar loads).
-constexpr int KMAX = 8;
+constexpr int KMAX = 16;
 
 // ProjectionIntegrator state + map constants, identical for every frame of a batch
 struct IntegratorParams {
@@ -159,7 +159,7 @@ struct WorkItem {
     int slot;                // pool slot, -1 = not resident (allocated if any voxel is integrated); candidates: -1;
                              // SLOT_LOOKUP = the previous batch may be creating this chunk: the integration kernel looks it up
     unsigned frame_mask;     // work item: frames of the batch that may touch this chunk
-                             // candidate: bits 0-7 frames that may integrate, bits 8-15 frames that may carve
+                             // candidate: bits 0-15 frames that may integrate, bits 16-31 frames that may carve
     int box;                 // row of the FrameBox array that holds this chunk's boxes (its candidate index)
     unsigned inband_mask;    // work item: frames that may integrate (used when slot == SLOT_LOOKUP)
     int pad;

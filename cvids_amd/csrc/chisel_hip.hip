@@ -26,6 +26,11 @@
 
 using namespace chisel_hip;
 
+// kernel arguments travel in a 4 KiB segment
+static_assert(sizeof(IntegrateParams) + sizeof(MapView) + 6 * sizeof(void *) <= 4096, "integrate_kernel arguments");
+static_assert(sizeof(CullParams) + sizeof(PyramidView) + 6 * sizeof(void *) <= 4096, "cull_kernel arguments");
+static_assert(sizeof(PyramidParams) + sizeof(PyramidView) + 2 * sizeof(void *) <= 4096, "depth_pyramid_kernel arguments");
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -304,8 +309,11 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         else if (IP.n_frames <= 4)
             hipLaunchKernelGGL((cull_kernel<N, 4>), cgrid, dim3(256), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
                                m->items_capacity, m->view.stamps);
-        else
+        else if (IP.n_frames <= 8)
             hipLaunchKernelGGL((cull_kernel<N, 8>), cgrid, dim3(512), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
+                               m->items_capacity, m->view.stamps);
+        else
+            hipLaunchKernelGGL((cull_kernel<N, 16>), cgrid, dim3(1024), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
                                m->items_capacity, m->view.stamps);
     }
     {
@@ -527,11 +535,18 @@ int integrate_frames(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fra
     const int kmax = std::max(1, std::min(max_group, KMAX));
     int i = 0;
     while (i < n) {
-        int g = 1;
-        while (i + g < n && g < kmax && frames[i + g].width == frames[i].width && frames[i + g].height == frames[i].height) g++;
-        int rc = integrate_group(m, g, frames + i, colors ? colors + i : nullptr);
-        if (rc) return rc;
-        i += g;
+        // the run of frames of one image size, cut into launch sets of equal length (10 frames: 5 + 5, not 8 + 2)
+        int run = 1;
+        while (i + run < n && frames[i + run].width == frames[i].width && frames[i + run].height == frames[i].height) run++;
+        int sets = (run + kmax - 1) / kmax;
+        while (run > 0) {
+            const int g = (run + sets - 1) / sets;
+            int rc = integrate_group(m, g, frames + i, colors ? colors + i : nullptr);
+            if (rc) return rc;
+            i += g;
+            run -= g;
+            sets--;
+        }
     }
     return CHISEL_HIP_OK;
 }

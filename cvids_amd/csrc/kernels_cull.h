@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
                     WorkItem wi;
                     wi.x = cx; wi.y = cy; wi.z = cz;
                     wi.slot = -1;
-                    wi.frame_mask = inband | (carve << 8);
+                    wi.frame_mask = inband | (carve << 16);
                     wi.box = pos;
                     wi.inband_mask = inband;
                     wi.pad = 0;
@@ -446,8 +446,8 @@ __device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
 // block 256).
 //   resolve_kernel : hash lookup, frame mask; the verdict is written back into the candidate (frame_mask == 0: dropped)
 //                    and counted per cost class in counts[COUNT_CLASS0 + class].
-//   order_kernel   : places the surviving candidates into the work-list class by class, most expensive first (class =
-//                    8 - number of frames that touch the chunk): the integration kernel's last workgroups then run the
+//   order_kernel   : places the surviving candidates into the work-list class by class, most expensive first (class by
+//                    the number of frames that touch the chunk, cost_class()): the integration kernel's last workgroups then run the
 //                    short items, which shortens the stretch where the chip drains.
 //   prev_pending / prev_overflow : the chunks the previous batch may create (nullptr: there is none in flight).  The
 //                                  chunk hash is read while that batch may still be inserting exactly those chunks, so
@@ -457,6 +457,9 @@ __device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
 
 // `counts_in` is `counts` again, read-only: the values read through it were written by earlier kernels, and a read-only
 // pointer lets them travel through the scalar cache instead of every wave asking the same L2 line.
+// cost class of a work item: 0 = touched by (nearly) all of the batch's frames ... 7 = by one or two
+__device__ inline int cost_class(unsigned frame_mask) { return (KMAX - __popc(frame_mask)) >> 1; }
+
 __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
                                                        int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
                                                        const int *__restrict__ prev_overflow, uint64_t *my_pending) {
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
             }
             if (kk == KEY_EMPTY) break;
         }
-        const unsigned inband = wi.frame_mask & 0xffu, carve = (wi.frame_mask >> 8) & 0xffu;
+        const unsigned inband = wi.frame_mask & 0xffffu, carve = wi.frame_mask >> 16;
         const bool uncertain = prev_pending && (all_uncertain ? (slot < 0) : pending_contains(prev_pending, key, h0));
         unsigned mask = 0;
         if (uncertain) {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
         }
         cands[c].slot = slot;
         cands[c].frame_mask = mask;
-        if (mask) cls = 8 - __popc(mask);
+        if (mask) cls = cost_class(mask);
         if (mask && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(&counts[COUNT_OVERFLOW], 1);
     }
 #pragma unroll
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(256) void order_kernel(const WorkItem *__restrict__
     int cls = -1;
     if (c < n) {
         wi = cands[c];
-        if (wi.frame_mask) cls = 8 - __popc(wi.frame_mask);
+        if (wi.frame_mask) cls = cost_class(wi.frame_mask);
     }
     // one returning atomic per (wave, class), all of a wave's classes in the same instruction: the first lane of each class
     // reserves the range for its class

@@ -304,7 +304,7 @@ def _run_batched(om, gm, integ, frames, cam, color_img, batch):
         assert sorted(map(tuple, om.meshes_to_update().tolist())) == sorted(map(tuple, gm.GetMeshesToUpdate().tolist()))
 
 
-@pytest.mark.parametrize("batch", [2, 3, 8, 11])
+@pytest.mark.parametrize("batch", [2, 3, 8, 10, 11, 16, 17])
 @pytest.mark.parametrize("color", [False, True])
 def test_batched_launch_equals_frame_by_frame(oracle_mod, batch, color):
     """K frames in one launch set (voxel state kept in registers across frames) == the reference's frame-by-frame result,
