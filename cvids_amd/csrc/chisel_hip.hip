@@ -147,11 +147,15 @@ struct chisel_hip_map {
     std::unordered_map<uint64_t, MeshRef, IdHash> meshes;              // ChunkManager::allMeshes
     std::vector<MeshArena> arenas;
     std::vector<std::pair<float *, size_t>> arena_pool;                // released arena buffers (floats), reused by later recomputes
+    size_t mesh_need_hint = 0;                                         // floats the previous recompute needed (sizes the next arena)
+    hipEvent_t mesh_counted = nullptr;                                 // recorded behind the count kernel of a recompute
     struct PendingMeshes {                                             // a recompute whose per-chunk results are still on the device
-        bool active = false;
+        bool unchecked = false;                                        // its totals have not been looked at yet (check_mesh_totals)
+        bool active = false;                                           // its per-chunk bookkeeping is outstanding (resolve_pending_meshes)
         int n = 0;                                                     // jobs
         int arena = -1;
     } pending_meshes;
+    int *mesh_totals_host = nullptr;                                   // pinned: totals + error flag of the recompute in flight
     hipStream_t copy_stream = nullptr;                                 // small device->host copies that must not wait for queued batches
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
@@ -282,6 +286,8 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
     return CHISEL_HIP_OK;
 }
 
+int check_mesh_totals(chisel_hip_map *m);  // host_mesh.h
+
 // The launch set of one batch.  Front half on the auxiliary stream, back half on the map's stream (see BatchSet).
 template <int N>
 int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidParams &PP, const CullParams &CP, const IntegrateParams &IP,
@@ -327,7 +333,12 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     }
     HIP_TRY(hipEventRecord(bs.front_done, m->aux));
     g_host_timer.lap(4);
-    // ---- back half: the map's stream
+    // ---- back half: the map's stream.  A mesh recompute still in flight must have been sized first (it may have to be
+    // emitted again from the voxels as they are now); its front-half work above did not depend on that.
+    {
+        int rc_m = check_mesh_totals(m);
+        if (rc_m) return rc_m;
+    }
     HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
     int *wc = bs.cand_count + COUNT_ITEMS;
     {
@@ -682,6 +693,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     }
     m->stream = m->own_stream;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreateWithFlags(&m->mesh_counted, hipEventDisableTiming));
+    HIP_TRY_C(hipHostMalloc((void **)&m->mesh_totals_host, 8 * sizeof(int), hipHostMallocDefault));
     HIP_TRY_C(hipEventCreateWithFlags(&m->call_event, hipEventDisableTiming));
     for (auto &bs : m->sets) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));
@@ -744,6 +757,8 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
+    if (m->mesh_counted) (void)hipEventDestroy(m->mesh_counted);
+    if (m->mesh_totals_host) (void)hipHostFree(m->mesh_totals_host);
     clear_meshes(m);
     release_arena_pool(m);
     free_mesh_buffers(m->mesh_buf);
@@ -799,6 +814,10 @@ int chisel_hip_record_event(chisel_hip_map *m, void *ev) {
 int chisel_hip_synchronize(chisel_hip_map *m) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
+    {
+        int rc_m = check_mesh_totals(m);
+        if (rc_m) return rc_m;
+    }
     return check_device_error(m);
 }
 
@@ -822,6 +841,10 @@ int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
     if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
+    {
+        int rc_m = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
+        if (rc_m) return rc_m;
+    }
     // keep the reference's meshesToUpdate entries of chunks that disappear (Chisel.h:228 lives on the host)
     std::vector<int> dirty;
     int rc = fetch_listed(m, true, dirty, nullptr);
@@ -905,7 +928,9 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
     if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)
         return fail(CHISEL_HIP_ERR_INVALID, "chunk belongs to another shard");
     HIP_TRY(hipSetDevice(m->device));
-    int rc = ensure_scratch(m, 16);
+    int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
+    if (rc) return rc;
+    rc = ensure_scratch(m, 16);
     if (rc) return rc;
     hipLaunchKernelGGL(ensure_chunk_kernel, dim3(1), dim3(1), 0, m->stream, m->view, id[0], id[1], id[2], m->scratch_i);
     int slot = -1;

@@ -16,19 +16,16 @@ MeshParams mesh_params(const chisel_hip_map *m) {
     return P;
 }
 
-template <int N>
-void launch_mesh_count(chisel_hip_map *m, int n) {
-    MeshBuffers &B = m->mesh_buf;
-    int *bases = B.counts + 2 * (size_t)B.capacity, *totals = B.counts + 4 * (size_t)B.capacity;
-    hipLaunchKernelGGL(mesh_count_kernel<N>, dim3(n), dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, B.counts, bases, totals, B.tris,
-                       B.tri_capacity);
-}
-template <int N>
-void launch_mesh_triangles(chisel_hip_map *m, int n_tris, const MeshParams &P, float *v, float *nr, float *c, float *g) {
+void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena, size_t arena_floats) {
     MeshBuffers &B = m->mesh_buf;
     const int *bases = B.counts + 2 * (size_t)B.capacity;
-    hipLaunchKernelGGL(mesh_triangle_kernel<N>, dim3((n_tris + MESH_TRI_BLOCK - 1) / MESH_TRI_BLOCK), dim3(MESH_TRI_BLOCK), 0, m->stream, m->view, P, B.jobs,
-                       bases, B.tris, n_tris, v, nr, P.use_color ? c : nullptr, g);
+    const int *totals = B.counts + 4 * (size_t)B.capacity;
+    const dim3 grid(4096), block(MESH_TRI_BLOCK);  // persistent: the number of triangles is read on the device
+    switch (m->N) {
+        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats); break;
+        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats); break;
+        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats); break;
+    }
 }
 
 int ensure_mesh_jobs(chisel_hip_map *m, int n) {
@@ -125,6 +122,7 @@ void release_mesh_ref(chisel_hip_map *m, MeshRef &ref) {
 }
 void clear_meshes(chisel_hip_map *m) {
     m->pending_meshes.active = false;
+    m->pending_meshes.unchecked = false;
     for (MeshArena &A : m->arenas) free_arena(m, A);
     m->arenas.clear();
     m->meshes.clear();
@@ -132,6 +130,19 @@ void clear_meshes(chisel_hip_map *m) {
 void release_arena_pool(chisel_hip_map *m) {
     for (auto &b : m->arena_pool) (void)hipFree(b.first);
     m->arena_pool.clear();
+}
+
+void launch_mesh_count(chisel_hip_map *m) {
+    MeshBuffers &B = m->mesh_buf;
+    int *d_totals = mesh_totals(m);
+    ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+    const dim3 grid(2048);
+    int *bases = B.counts + 2 * (size_t)B.capacity;
+    switch (m->N) {
+        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+    }
 }
 
 // Wait for the stream by polling: the wake-up of a blocking wait costs more than the kernels being waited for.
@@ -144,87 +155,118 @@ hipError_t wait_stream_spinning(hipStream_t st) {
     }
 }
 
-// meshes of the chunks whose ids sit in mesh_buf.ids (device; their number too).  One wait for the device: the
-// totals after the count kernel, which size the arena.
+// meshes of the chunks whose ids sit in mesh_buf.ids (device; their number too).  Everything is queued at once -- job
+// table, count kernel, triangle kernel into an arena sized from the previous recompute, dirty-flag reset -- and the host
+// then reads the totals behind the count kernel on its own stream: the device never waits for the host.  Only a batch
+// that outgrew the triangle list or the arena is emitted again after a full wait (the map has not changed meanwhile:
+// nothing else was queued).
 int recompute_meshes(chisel_hip_map *m) {
     MeshBuffers &B = m->mesh_buf;
     int *d_totals = mesh_totals(m);
+    const MeshParams P = mesh_params(m);
+    if (!B.tris) {
+        B.tri_capacity = std::max(B.tri_capacity, 1 << 20);
+        HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
+    }
+    // an arena record and a buffer that should do: twice what the previous recompute needed
+    int arena_id = -1;
+    for (size_t i = 0; i < m->arenas.size() && arena_id < 0; i++)
+        if (!m->arenas[i].dev) arena_id = (int)i;
+    if (arena_id < 0) {
+        m->arenas.emplace_back();
+        arena_id = (int)m->arenas.size() - 1;
+    }
+    {
+        MeshArena &A = m->arenas[arena_id];
+        A = MeshArena();
+        int rc_a = take_arena_buffer(m, std::max<size_t>(2 * m->mesh_need_hint, (size_t)1 << 22), &A.dev, &A.capacity);
+        if (rc_a) return rc_a;
+    }
     hipLaunchKernelGGL(mesh_jobs_kernel, dim3(256), dim3(256), 0, m->stream, m->view, B.ids, d_totals + MT_JOBS, B.jobs);
-    int totals[4] = {0, 0, 0, 0};
-    for (int attempt = 0;; attempt++) {
-        if (!B.tris) {
-            B.tri_capacity = std::max(B.tri_capacity, 1 << 20);
-            HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
-        }
-        {
-            ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
-            const dim3 grid(2048);
-            int *bases = B.counts + 2 * (size_t)B.capacity;
-            switch (m->N) {
-                case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
-                case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
-                case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
-            }
-        }
-        HIP_TRY(hipGetLastError());
-        int error_flag = 0;
-        HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipMemcpyAsync(&error_flag, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(wait_stream_spinning(m->stream));
-        if (error_flag != 0)  // a chunk of an earlier batch could not be allocated: the map is incomplete
-            return fail(CHISEL_HIP_ERR_POOL_FULL, error_flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
-                                                                   : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
-        if (!totals[MT_OVERFLOW]) break;
-        // the triangle list was too small: grow it to what this batch needs and list again
-        if (attempt > 0) return fail(CHISEL_HIP_ERR_HIP, "mesh triangle list overflow after growing it");
+    launch_mesh_count(m);
+    HIP_TRY(hipEventRecord(m->mesh_counted, m->stream));
+    {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+        launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity);
+    }
+    // meshesToUpdate.clear() (Chisel.cpp:57)
+    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    HIP_TRY(hipGetLastError());
+    // the totals follow on their own stream as soon as the count kernel is through; they are looked at when the caller
+    // next touches the map (check_mesh_totals): until then the host is free to queue the next batch's front half
+    HIP_TRY(hipStreamWaitEvent(m->copy_stream, m->mesh_counted, 0));
+    HIP_TRY(hipMemcpyAsync(m->mesh_totals_host, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
+    HIP_TRY(hipMemcpyAsync(m->mesh_totals_host + 4, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
+    m->pending_meshes.unchecked = true;
+    m->pending_meshes.active = false;
+    m->pending_meshes.arena = arena_id;
+    return CHISEL_HIP_OK;
+}
+
+// The totals of the recompute in flight: sizes the arena's contents, emits again when the batch outgrew the triangle
+// list or the arena.  Must run before anything else changes the map (a second emission reads the voxels): every entry
+// point that queues map-changing work calls it first; it waits for the count kernel only, not for the stream.
+int check_mesh_totals(chisel_hip_map *m) {
+    if (!m->pending_meshes.unchecked) return CHISEL_HIP_OK;
+    m->pending_meshes.unchecked = false;
+    MeshBuffers &B = m->mesh_buf;
+    int *d_totals = mesh_totals(m);
+    const bool color = m->cfg.use_color != 0;
+    const MeshParams P = mesh_params(m);
+    int arena_id = m->pending_meshes.arena;
+    HIP_TRY(wait_stream_spinning(m->copy_stream));
+    int totals[4] = {m->mesh_totals_host[0], m->mesh_totals_host[1], m->mesh_totals_host[2], m->mesh_totals_host[3]};
+    const int error_flag = m->mesh_totals_host[4];
+    if (error_flag != 0) {  // a chunk of an earlier batch could not be allocated: the map is incomplete
+        free_arena(m, m->arenas[arena_id]);
+        return fail(CHISEL_HIP_ERR_POOL_FULL, error_flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
+                                                               : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
+    }
+    bool redo = false;
+    if (totals[MT_OVERFLOW]) {
+        // the triangle list was too small: grow it to what this batch needs and list again (dirty flags are not read by the count)
+        HIP_TRY(hipStreamSynchronize(m->stream));
         HIP_TRY(hipFree(B.tris));
         B.tris = nullptr;
         while (B.tri_capacity < totals[MT_TRIS]) B.tri_capacity *= 2;
+        HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
         HIP_TRY(hipMemsetAsync(d_totals, 0, 3 * sizeof(int), m->stream));  // keeps MT_JOBS
+        launch_mesh_count(m);
+        HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (totals[MT_OVERFLOW]) return fail(CHISEL_HIP_ERR_HIP, "mesh triangle list overflow after growing it");
+        redo = true;
     }
     const int n = totals[MT_JOBS];
-    if (n == 0) {
-        hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
-        return CHISEL_HIP_OK;
-    }
     if ((size_t)totals[MT_TRIS] > 0x7fffffffull / 9) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^31 / 9 mesh triangles in one recompute");
     const size_t nv = (size_t)totals[MT_TRIS] * 3, ng = (size_t)totals[MT_GRIDS];
-    const bool color = m->cfg.use_color != 0;
-    int arena_id = -1;
-    if (nv + ng) {
-        // a free arena record, or a new one
-        for (size_t i = 0; i < m->arenas.size() && arena_id < 0; i++)
-            if (!m->arenas[i].dev) arena_id = (int)i;
-        if (arena_id < 0) {
-            m->arenas.emplace_back();
-            arena_id = (int)m->arenas.size() - 1;
-        }
+    {
         MeshArena &A = m->arenas[arena_id];
         A.nv = nv;
         A.ng = ng;
         A.color = color;
-        A.live = 0;
-        A.host.clear();
-        A.host_valid = false;
-        int rc_a = take_arena_buffer(m, A.floats(), &A.dev, &A.capacity);
-        if (rc_a) return rc_a;
-        float *d_v = A.dev, *d_n = d_v + nv * 3, *d_c = d_n + nv * 3, *d_g = d_c + (color ? nv * 3 : 0);
-        const MeshParams P = mesh_params(m);
-        if (totals[MT_TRIS]) {
-            ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
-            switch (m->N) {
-                case 8: launch_mesh_triangles<8>(m, totals[MT_TRIS], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
-                case 16: launch_mesh_triangles<16>(m, totals[MT_TRIS], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
-                case 32: launch_mesh_triangles<32>(m, totals[MT_TRIS], P, d_v, d_n, color ? d_c : nullptr, d_g); break;
+        if (redo || A.floats() > A.capacity) {
+            // did not fit (or was listed again): emit once more into a buffer of the right size
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (A.floats() > A.capacity) {
+                m->arena_pool.emplace_back(A.dev, A.capacity);
+                A.dev = nullptr;
+                int rc_a = take_arena_buffer(m, A.floats(), &A.dev, &A.capacity);
+                if (rc_a) return rc_a;
             }
+            ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+            launch_mesh_triangles(m, P, A.dev, A.capacity);
+            HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipGetLastError());
+        m->mesh_need_hint = A.floats();
+        if (nv + ng == 0) {
+            free_arena(m, A);
+            arena_id = -1;
+        }
     }
-    // meshesToUpdate.clear() (Chisel.cpp:57): queued behind the triangle kernel, before the host goes on
-    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
-    HIP_TRY(hipGetLastError());
-    // The per-chunk results (sizes, positions in the arena, ids) stay on the device for now: the caller's next batch is
-    // queued first, the bookkeeping follows when a mesh is next asked for or recomputed (resolve_pending_meshes).
+    if (n == 0) return CHISEL_HIP_OK;
+    // The per-chunk results (sizes, positions in the arena, ids) stay on the device for now: the bookkeeping follows when
+    // a mesh is next asked for or recomputed (resolve_pending_meshes).
     m->pending_meshes.active = true;
     m->pending_meshes.n = n;
     m->pending_meshes.arena = arena_id;
@@ -235,6 +277,8 @@ int recompute_meshes(chisel_hip_map *m) {
 // buffers read here were complete when recompute_meshes returned (it waited for the count kernel), so the copies use
 // their own stream and do not wait for batches queued since.
 int resolve_pending_meshes(chisel_hip_map *m) {
+    int rc_c = check_mesh_totals(m);
+    if (rc_c) return rc_c;
     if (!m->pending_meshes.active) return CHISEL_HIP_OK;
     m->pending_meshes.active = false;
     MeshBuffers &B = m->mesh_buf;

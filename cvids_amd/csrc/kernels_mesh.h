@@ -501,11 +501,18 @@ __device__ inline int corner_oz(int i) { return i >> 2; }
 // (:628-639), which read the map, not the mesh.  Triangle i owns vertices 3i .. 3i+2 of the arena; the first triangle of
 // a cube also writes the cube's grid entry.
 template <int N>
+// The totals of the count kernel are read from the device (totals[0] triangles, totals[1] grids): the arena --
+// vertices | normals | colours | grids -- was picked before they were known.  A batch that does not fit its arena
+// writes nothing (the host, which reads the same totals, then runs the kernel again on a larger one).
 __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
-                                                                    const int *__restrict__ bases, const TriRec *__restrict__ tris, int n_tris,
-                                                                    float *vertices, float *normals, float *colors, float *grids) {
-    const int i = blockIdx.x * MESH_TRI_BLOCK + threadIdx.x;
-    if (i >= n_tris) return;
+                                                                    const int *__restrict__ bases, const TriRec *__restrict__ tris,
+                                                                    const int *__restrict__ totals, float *arena, size_t arena_floats) {
+    const int n_tris = totals[0];
+    const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[1] * 3;
+    if (nv3 * (P.use_color ? 3 : 2) + ng3 > arena_floats) return;
+    float *vertices = arena, *normals = arena + nv3, *colors = P.use_color ? arena + 2 * nv3 : nullptr;
+    float *grids = arena + nv3 * (P.use_color ? 3 : 2);
+    for (int i = blockIdx.x * MESH_TRI_BLOCK + threadIdx.x; i < n_tris; i += gridDim.x * MESH_TRI_BLOCK) {
     const TriRec rec = tris[i];
     const MeshJob &job = jobs[rec.job];  // stays in memory (L1 / L2): its neighbour table is indexed per lane
     const int *nb = job.nb;
@@ -560,6 +567,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
             co[3 * a + 1] = col.y;
             co[3 * a + 2] = col.z;
         }
+    }
     }
 }
 
