@@ -124,6 +124,7 @@ struct chisel_hip_map {
         int *cand_count = nullptr;       // [COUNT_INTS] device counters of the batch (COUNT_* in kernels_cull.h)
         WorkItem *items = nullptr;       // [items_capacity]: the work-list
         uint64_t *pending = nullptr;     // [PENDING_CAPACITY]: chunks this batch may create
+        hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
         hipEvent_t front_done = nullptr;  // recorded on aux after the set's resolve
         hipEvent_t back_done = nullptr;   // recorded on the map's stream after the set's integration
     } sets[2];
@@ -132,6 +133,7 @@ struct chisel_hip_map {
     hipEvent_t mutation_event = nullptr; // map changed outside the integration path (reset, upload): the next front waits
     bool mutation_pending = false;
     hipEvent_t input_event = nullptr;    // chisel_hip_wait_event: the next batch's frames are ready behind this (caller's) event
+    bool force_pipeline = false;         // test hook (CHISEL_HIP_FORCE_PIPELINE at creation): the front half always runs on the auxiliary stream
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b & 1]
     int items_capacity = 0;
@@ -297,41 +299,47 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     g_host_timer.lap(2);
     PyramidView pyr = m->pyr;
     pyr.data = bs.pyr_data;
+    // Nothing in flight (the previous batch has been integrated, e.g. a caller that waits after every frame): no second
+    // stream to run beside, so the short form -- pyramid, cull with the lookup inline, integrate -- on the map's stream.
+    // `front` was decided in integrate_group (it also routes the staging copies).
+    hipStream_t front = bs.front_stream;
+    const bool inline_resolve = front == m->stream;
     {
-        ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID, m->aux);
+        ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID, front);
         dim3 grid((PP.W + 63) / 64, (PP.H + 63) / 64, IP.n_frames);
-        hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, m->aux, PP, pyr, bs.cand_count, bs.pending);
+        hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, front, PP, pyr, bs.cand_count, bs.pending);
     }
     g_host_timer.lap(3);
     {
-        ProfScope ps(m, CHISEL_HIP_KERNEL_CULL, m->aux);
+        ProfScope ps(m, CHISEL_HIP_KERNEL_CULL, front);
         const dim3 cgrid((total + 63) / 64);
-        if (IP.n_frames <= 1)
-            hipLaunchKernelGGL((cull_kernel<N, 1>), cgrid, dim3(64), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
-                               m->items_capacity, m->view.stamps);
-        else if (IP.n_frames <= 2)
-            hipLaunchKernelGGL((cull_kernel<N, 2>), cgrid, dim3(128), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
-                               m->items_capacity, m->view.stamps);
-        else if (IP.n_frames <= 4)
-            hipLaunchKernelGGL((cull_kernel<N, 4>), cgrid, dim3(256), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
-                               m->items_capacity, m->view.stamps);
-        else if (IP.n_frames <= 8)
-            hipLaunchKernelGGL((cull_kernel<N, 8>), cgrid, dim3(512), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
-                               m->items_capacity, m->view.stamps);
-        else
-            hipLaunchKernelGGL((cull_kernel<N, 16>), cgrid, dim3(1024), 0, m->aux, CP, pyr, bs.cands, bs.boxes, bs.cand_count,
-                               m->items_capacity, m->view.stamps);
+#define CHISEL_LAUNCH_CULL(KLV, INL, OUT)                                                                                        \
+    hipLaunchKernelGGL((cull_kernel<N, KLV, INL>), cgrid, dim3(64 * KLV), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count,      \
+                       m->items_capacity, m->view.stamps, m->view, bs.pending)
+        if (inline_resolve) {
+            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL(1, true, bs.items);
+            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL(2, true, bs.items);
+            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL(4, true, bs.items);
+            else if (IP.n_frames <= 8) CHISEL_LAUNCH_CULL(8, true, bs.items);
+            else CHISEL_LAUNCH_CULL(16, true, bs.items);
+        } else {
+            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL(1, false, bs.cands);
+            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL(2, false, bs.cands);
+            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL(4, false, bs.cands);
+            else if (IP.n_frames <= 8) CHISEL_LAUNCH_CULL(8, false, bs.cands);
+            else CHISEL_LAUNCH_CULL(16, false, bs.cands);
+        }
+#undef CHISEL_LAUNCH_CULL
     }
-    {
-        ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, m->aux);
+    if (!inline_resolve) {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
         chisel_hip_map::BatchSet *prev = (m->batch_seq || m->force_uncertain) ? &m->sets[(m->batch_seq + 1u) & 1u] : nullptr;
         const int *prev_overflow = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : (prev ? prev->cand_count + COUNT_OVERFLOW : nullptr);
         const dim3 rgrid((total + 255) / 256);
-        hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, m->aux, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
+        hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
                            prev ? prev->pending : nullptr, prev_overflow, bs.pending);
-        hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, m->aux, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items);
+        hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items);
     }
-    HIP_TRY(hipEventRecord(bs.front_done, m->aux));
     g_host_timer.lap(4);
     // ---- back half: the map's stream.  A mesh recompute still in flight must have been sized first (it may have to be
     // emitted again from the voxels as they are now); its front-half work above did not depend on that.
@@ -339,7 +347,10 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         int rc_m = check_mesh_totals(m);
         if (rc_m) return rc_m;
     }
-    HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
+    if (!inline_resolve) {
+        HIP_TRY(hipEventRecord(bs.front_done, front));
+        HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
+    }
     int *wc = bs.cand_count + COUNT_ITEMS;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
@@ -443,19 +454,25 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         }
         m->color_stage_bytes = color_bytes;
     }
-    // the front half may start as soon as the batch that last used this buffer set has been integrated; a stream given
-    // by the caller additionally orders it after whatever the caller queued there (the producers of device frames)
-    HIP_TRY(hipStreamWaitEvent(m->aux, bs.back_done, 0));
-    if (m->stream != m->own_stream) {
-        HIP_TRY(hipEventRecord(m->call_event, m->stream));
-        HIP_TRY(hipStreamWaitEvent(m->aux, m->call_event, 0));
+    // Where does the front half run?  On the auxiliary stream, beside the batch that is being integrated -- unless nothing
+    // is in flight (a caller that waits after every frame; the first batch): then there is nothing to run beside and the
+    // short form on the map's stream has the lower latency (launch_group).  A stream given by the caller orders the front
+    // half after whatever the caller queued there (the producers of device frames), which is the same stream order.
+    {
+        const chisel_hip_map::BatchSet &prev = m->sets[(m->batch_seq + 1u) & 1u];
+        const bool idle = (m->batch_seq == 0 || hipEventQuery(prev.back_done) == hipSuccess) && !m->pending_meshes.unchecked &&
+                          !m->force_pipeline;
+        bs.front_stream = (idle || m->stream != m->own_stream || m->aux == m->own_stream) ? m->stream : m->aux;
     }
-    if (m->mutation_pending) {
-        HIP_TRY(hipStreamWaitEvent(m->aux, m->mutation_event, 0));
-        m->mutation_pending = false;
+    hipStream_t front = bs.front_stream;
+    if (front != m->stream) {
+        // the front half may start as soon as the batch that last used this buffer set has been integrated
+        HIP_TRY(hipStreamWaitEvent(front, bs.back_done, 0));
+        if (m->mutation_pending) HIP_TRY(hipStreamWaitEvent(front, m->mutation_event, 0));
     }
+    m->mutation_pending = false;
     if (m->input_event) {  // depth is read by the front half, colour by the integration kernel
-        HIP_TRY(hipStreamWaitEvent(m->aux, m->input_event, 0));
+        if (front != m->stream) HIP_TRY(hipStreamWaitEvent(front, m->input_event, 0));
         HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
         m->input_event = nullptr;
     }
@@ -471,7 +488,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
             PP.depth[k] = f->depth;
         } else {
             float *dst = bs.depth_stage + (size_t)k * m->depth_stage_elems;
-            HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, m->aux));
+            HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, front));
             PP.depth[k] = dst;
         }
         F.rec = bs.rec_data + (size_t)k * npx;
@@ -484,7 +501,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
                 F.color = c->color;
             } else {
                 uint8_t *dst = bs.color_stage + (size_t)k * m->color_stage_bytes;
-                HIP_TRY(hipMemcpyAsync(dst, c->color, (size_t)c->width * c->height * c->channels, hipMemcpyHostToDevice, m->aux));
+                HIP_TRY(hipMemcpyAsync(dst, c->color, (size_t)c->width * c->height * c->channels, hipMemcpyHostToDevice, front));
                 F.color = dst;
             }
         }
@@ -706,6 +723,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     }
     HIP_TRY_C(hipEventCreateWithFlags(&m->mutation_event, hipEventDisableTiming));
     m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
+    m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
         const int one = 1;
         HIP_TRY_C(hipMemcpyAsync(m->sets[0].cand_count + COUNT_ONE, &one, sizeof(int), hipMemcpyHostToDevice, m->own_stream));

@@ -337,11 +337,32 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
     return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0);
 }
 
+__device__ inline bool pending_contains(const uint64_t *__restrict__ set, uint64_t key, uint64_t h) {
+    for (unsigned i = 0; i < PENDING_CAPACITY; i++) {
+        const uint64_t k = set[(h + i) & (PENDING_CAPACITY - 1)];
+        if (k == key) return true;
+        if (k == KEY_EMPTY) return false;
+    }
+    return false;
+}
+__device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
+    for (unsigned i = 0; i < PENDING_CAPACITY / 2; i++) {  // give up on a crowded table: the caller raises the overflow flag
+        unsigned long long *p = (unsigned long long *)&set[(h + i) & (PENDING_CAPACITY - 1)];
+        const unsigned long long cur = atomicCAS(p, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+        if (cur == KEY_EMPTY || cur == key) return true;
+    }
+    return false;
+}
+
 // One wave per frame of the batch over the same 64 chunk ids (block = 64 * KL threads, KL = frames rounded up to a
 // power of two): every per-frame constant is wave-uniform (scalar loads), the per-frame verdicts meet in LDS.
-template <int N, int KL>
-__global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *cand_count,
-                                                        int max_cands, unsigned long long *stamps) {
+// INLINE (the map is idle: nothing to run beside, the caller is waiting): the k == 0 wave also does resolve_kernel's job
+// for its survivors -- hash lookup, frame mask, compaction straight into the work-list -- and one launch set is three
+// kernels on one stream instead of five on two.
+template <int N, int KL, bool INLINE>
+__global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *counts,
+                                                        int max_cands, unsigned long long *stamps, MapView M, uint64_t *my_pending) {
+    int *cand_count = counts + (INLINE ? COUNT_ITEMS : COUNT_CANDS);
     __shared__ int s_flags[KL][64];
     __shared__ int s_pos[64];
     const int lane = threadIdx.x & 63;
@@ -382,7 +403,33 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
             inband |= (f & WI_INBAND) ? (1u << j) : 0u;
             carve |= (f & WI_CARVE) ? (1u << j) : 0u;
         }
-        const bool keep = (inband | carve) != 0u;
+        bool keep = (inband | carve) != 0u;
+        int slot = -1;
+        unsigned mask = inband | (carve << 16);
+        if (INLINE && keep) {
+            // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82); the map is at rest
+            const uint64_t key = pack_id(cx, cy, cz);
+            const uint64_t h0 = chunk_hash(cx, cy, cz), h = h0 & M.hash_mask;
+            for (uint64_t i = 0; i <= M.hash_mask; i++) {
+                const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
+                if (kk == key) {
+                    slot = M.hash_vals[(h + i) & M.hash_mask];
+                    break;
+                }
+                if (kk == KEY_EMPTY) break;
+            }
+            // a frame can only matter if it may integrate, or may carve a chunk that is resident by then
+            bool resident = slot >= 0;
+            mask = 0;
+#pragma unroll
+            for (int j = 0; j < KL; j++) {
+                const bool in = (inband >> j) & 1u;
+                if (in || (((carve >> j) & 1u) && resident)) mask |= 1u << j;
+                resident |= in;
+            }
+            keep = mask != 0;
+            if (keep && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(&counts[COUNT_OVERFLOW], 1);
+        }
         // wave64 compaction: ballot + prefix popcount, one atomic per wave
         const unsigned long long bal = __ballot(keep);
         int pos = -1;
@@ -395,8 +442,8 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
                 if (pos < max_cands) {
                     WorkItem wi;
                     wi.x = cx; wi.y = cy; wi.z = cz;
-                    wi.slot = -1;
-                    wi.frame_mask = inband | (carve << 16);
+                    wi.slot = slot;
+                    wi.frame_mask = mask;
                     wi.box = pos;
                     wi.inband_mask = inband;
                     wi.pad = 0;
@@ -423,23 +470,6 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
     }
     CSTAMP(5);
 #undef CSTAMP
-}
-
-__device__ inline bool pending_contains(const uint64_t *__restrict__ set, uint64_t key, uint64_t h) {
-    for (unsigned i = 0; i < PENDING_CAPACITY; i++) {
-        const uint64_t k = set[(h + i) & (PENDING_CAPACITY - 1)];
-        if (k == key) return true;
-        if (k == KEY_EMPTY) return false;
-    }
-    return false;
-}
-__device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
-    for (unsigned i = 0; i < PENDING_CAPACITY / 2; i++) {  // give up on a crowded table: the caller raises the overflow flag
-        unsigned long long *p = (unsigned long long *)&set[(h + i) & (PENDING_CAPACITY - 1)];
-        const unsigned long long cur = atomicCAS(p, (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-        if (cur == KEY_EMPTY || cur == key) return true;
-    }
-    return false;
 }
 
 // Candidates -> work-list, in two passes over the candidates (both on the auxiliary stream, one thread per candidate,

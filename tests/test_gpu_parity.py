@@ -319,16 +319,19 @@ def test_batched_launch_equals_frame_by_frame(oracle_mod, batch, color):
 
 
 @pytest.mark.parametrize("batch", [1, 2, 8])
-@pytest.mark.parametrize("force_lookup", [False, True])
+@pytest.mark.parametrize("force_lookup", [None, False, True])
 def test_back_to_back_batches_pipeline(oracle_mod, batch, force_lookup, monkeypatch):
     """Batches issued without any synchronisation in between: the work-list of batch b+1 is built on the auxiliary stream
     while batch b is still being integrated, so chunks batch b creates reach batch b+1 as SLOT_LOOKUP items (looked up by
     the integration kernel).  Walls that appear, move away (carving what the previous batch created) and come back.
-    force_lookup: the conservative mode used when a pending set overflows -- every candidate without a slot is looked up."""
-    if force_lookup:
-        monkeypatch.setenv("CHISEL_HIP_FORCE_UNCERTAIN", "1")
+    force_lookup None: the library picks per batch (two streams while a batch is in flight, the short single-stream form
+    when the map is idle); False: always two streams; True: also the conservative mode used when a pending set overflows
+    -- every candidate without a slot is looked up by the integration kernel."""
+    if force_lookup is not None:
+        monkeypatch.setenv("CHISEL_HIP_FORCE_UNCERTAIN" if force_lookup else "CHISEL_HIP_FORCE_PIPELINE", "1")
     om, gm, integ = _mk(oracle_mod, 8, 0.05, True, carving=True, carving_dist=0.0, max_chunks=8192)
     monkeypatch.delenv("CHISEL_HIP_FORCE_UNCERTAIN", raising=False)
+    monkeypatch.delenv("CHISEL_HIP_FORCE_PIPELINE", raising=False)
     cam = small_camera(64, 48)
     intr = (cam.fx, cam.fy, cam.cx, cam.cy)
     color = synth.render_color(64, 48, 3)

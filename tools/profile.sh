@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 100 --warmup 20 --no-cpu-baseline $@"
+ARGS="--no-cpu-baseline $@"   # bench defaults: 200 steps after 20, BASELINE config 3
 python3 bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py $ARGS --no-roofline > $OUT/bench_fetch.json 2> $OUT/fetch.err
