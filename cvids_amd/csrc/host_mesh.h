@@ -139,9 +139,9 @@ void launch_mesh_count(chisel_hip_map *m) {
     const dim3 grid(2048);
     int *bases = B.counts + 2 * (size_t)B.capacity;
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
     }
 }
 
@@ -182,15 +182,12 @@ int recompute_meshes(chisel_hip_map *m) {
         int rc_a = take_arena_buffer(m, std::max<size_t>(2 * m->mesh_need_hint, (size_t)1 << 22), &A.dev, &A.capacity);
         if (rc_a) return rc_a;
     }
-    hipLaunchKernelGGL(mesh_jobs_kernel, dim3(256), dim3(256), 0, m->stream, m->view, B.ids, d_totals + MT_JOBS, B.jobs);
     launch_mesh_count(m);
     HIP_TRY(hipEventRecord(m->mesh_counted, m->stream));
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
         launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity);
     }
-    // meshesToUpdate.clear() (Chisel.cpp:57)
-    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
     HIP_TRY(hipGetLastError());
     // the totals follow on their own stream as soon as the count kernel is through; they are looked at when the caller
     // next touches the map (check_mesh_totals): until then the host is free to queue the next batch's front half

@@ -164,11 +164,6 @@ __global__ void list_slots_kernel(MapView M, int *ids, int *slots, int max_out, 
     }
 }
 
-__global__ void clear_dirty_kernel(MapView M) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M.max_chunks) M.slot_dirty[i] = 0;
-}
-
 // ---- known-answer kernels: the device arithmetic against the reference-built golden vectors ----------
 __global__ void kat_truncation_kernel(int kind, float param, const float *depths, int n, float *trunc, float *weight1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

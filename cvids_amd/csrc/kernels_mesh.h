@@ -9,7 +9,6 @@
 // workgroup and the output position of every cube comes from a prefix sum over the cubes *in the reference's
 // traversal order* (interior cubes, then the max-x, max-y and max-z planes: ChunkManager.cpp:395-441), so the
 // vertex / normal / colour / grid arrays of a chunk are element-for-element the reference's:
-//   mesh_jobs_kernel   : slots of the chunk and of its 7 "+" neighbours (the corners a border cube needs)
 //   mesh_count_kernel    : per chunk: vertices and grids (case table popcount + block scan), the chunk's range in the
 //                          batch and the list of its triangles
 //   mesh_triangle_kernel : one thread per triangle: vertices, gradient normals and colours into one arena
@@ -256,6 +255,7 @@ __global__ void mesh_collect_kernel(MapView M, unsigned *mesh_flag, int *ids, in
     bool keep = false;
     uint64_t key = KEY_EMPTY;
     if (i < M.max_chunks) {
+        M.slot_dirty[i] = 0;  // meshesToUpdate.clear() (Chisel.cpp:57): mesh_mark_kernel, the flag's reader, has finished
         keep = mesh_flag[i] != 0u;
         if (keep) {
             mesh_flag[i] = 0u;
@@ -277,21 +277,6 @@ __global__ void mesh_collect_kernel(MapView M, unsigned *mesh_flag, int *ids, in
         ids[3 * pos] = x;
         ids[3 * pos + 1] = y;
         ids[3 * pos + 2] = z;
-    }
-}
-
-// slots of each listed chunk's 27-neighbourhood; 32 threads per job
-__global__ void mesh_jobs_kernel(MapView M, const int *ids, const int *__restrict__ n_jobs, MeshJob *jobs) {
-    const int n = *n_jobs;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; (t >> 5) < n; t += gridDim.x * blockDim.x) {
-        const int j = t >> 5, o = t & 31;
-        if (o < 27) jobs[j].nb[o] = hash_find(M, ids[3 * j] + o % 3 - 1, ids[3 * j + 1] + (o / 3) % 3 - 1, ids[3 * j + 2] + o / 9 - 1);
-        if (o == 27) {
-            jobs[j].x = ids[3 * j];
-            jobs[j].y = ids[3 * j + 1];
-            jobs[j].z = ids[3 * j + 2];
-            jobs[j].pad[0] = jobs[j].pad[1] = 0;
-        }
     }
 }
 
@@ -408,8 +393,8 @@ struct TriRec {
 // in the batch (the chunks' ranges follow one another in completion order; within a chunk the order is the reference's).
 // totals[0..1] = running totals (the atomics), totals[2] = set when the triangle list is too small (the host retries).
 template <int N>
-__global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const MeshJob *jobs, const int *__restrict__ n_jobs, int *counts,
-                                                                 int *bases, int *totals, TriRec *tris, int tri_capacity) {
+__global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
+                                                                 int *counts, int *bases, int *totals, TriRec *tris, int tri_capacity) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nb[27];
     __shared__ int s_base[2];
@@ -418,8 +403,20 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     const int n = *n_jobs;  // the job count stays on the device: the grid is persistent
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
     __syncthreads();  // the previous job's LDS contents are no longer read
-    const MeshJob &job = jobs[j];
-    if (threadIdx.x < 27) s_nb[threadIdx.x] = job.nb[threadIdx.x];
+    // the job record: the chunk id and the pool slots of its 27-neighbourhood (27 hash lookups, one per thread); kept for
+    // the triangle kernel and the host
+    const int jx = ids[3 * j], jy = ids[3 * j + 1], jz = ids[3 * j + 2];
+    if (threadIdx.x < 27) {
+        const int o = threadIdx.x;
+        const int slot = hash_find(M, jx + o % 3 - 1, jy + (o / 3) % 3 - 1, jz + o / 9 - 1);
+        s_nb[o] = slot;
+        jobs[j].nb[o] = slot;
+    } else if (threadIdx.x == 27) {
+        jobs[j].x = jx;
+        jobs[j].y = jy;
+        jobs[j].z = jz;
+        jobs[j].pad[0] = jobs[j].pad[1] = 0;
+    }
     __syncthreads();
     const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
     if (present) stage_corners<N>(M, s_nb, s_vox);
