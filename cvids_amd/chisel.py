@@ -192,6 +192,14 @@ class Chisel:
     def Reset(self):
         check(self.L.chisel_hip_reset(self.h))
 
+    def SaveMap(self, filename):
+        """binary dump of every resident chunk (chisel_hip_save_map): checkpoint"""
+        check(self.L.chisel_hip_save_map(self.h, str(filename).encode()))
+
+    def LoadMap(self, filename):
+        """replace the map's contents by a dump written by SaveMap: resume"""
+        check(self.L.chisel_hip_load_map(self.h, str(filename).encode()))
+
     def SaveAllMeshesToPLY(self, filename):
         rc = self.L.chisel_hip_save_ply(self.h, str(filename).encode())
         if rc == 6:

@@ -941,6 +941,90 @@ int chisel_hip_download_chunk(chisel_hip_map *m, const int id[3], float *sdf, fl
     return CHISEL_HIP_OK;
 }
 
+namespace {
+struct MapFileHeader {
+    char magic[8];
+    int32_t chunk_edge;
+    float resolution;
+    int32_t has_color;
+    int32_t spare;
+    int64_t n_chunks;
+};
+static_assert(sizeof(MapFileHeader) == 32, "map file header");
+}  // namespace
+
+int chisel_hip_save_map(chisel_hip_map *m, const char *path) {
+    if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_device_error(m);  // waits for the queued batches
+    if (rc) return rc;
+    std::vector<int> ids, slots;
+    rc = fetch_listed(m, false, ids, &slots);
+    if (rc) return rc;
+    const size_t n = slots.size();
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        for (int k = 0; k < 3; k++)
+            if (ids[3 * a + k] != ids[3 * b + k]) return ids[3 * a + k] < ids[3 * b + k];
+        return false;
+    });
+    std::ofstream out(path, std::ios::binary);
+    if (!out) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    MapFileHeader h;
+    memcpy(h.magic, "CHSLHIP1", 8);
+    h.chunk_edge = m->N;
+    h.resolution = m->cfg.voxel_resolution;
+    h.has_color = m->view.rgbw ? 1 : 0;
+    h.spare = 0;
+    h.n_chunks = (int64_t)n;
+    out.write(reinterpret_cast<const char *>(&h), sizeof(h));
+    const size_t V = (size_t)m->V;
+    std::vector<float> sdf(V), wgt(V);
+    std::vector<uint8_t> col(h.has_color ? 4 * V : 0);
+    for (size_t i : order) {
+        const size_t off = (size_t)slots[i] * V;
+        HIP_TRY(hipMemcpy(sdf.data(), m->view.sdf + off, V * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(wgt.data(), m->view.wgt + off, V * sizeof(float), hipMemcpyDeviceToHost));
+        if (h.has_color) HIP_TRY(hipMemcpy(col.data(), m->view.rgbw + off, 4 * V, hipMemcpyDeviceToHost));
+        out.write(reinterpret_cast<const char *>(&ids[3 * i]), 3 * sizeof(int));
+        out.write(reinterpret_cast<const char *>(sdf.data()), (std::streamsize)(V * sizeof(float)));
+        out.write(reinterpret_cast<const char *>(wgt.data()), (std::streamsize)(V * sizeof(float)));
+        if (h.has_color) out.write(reinterpret_cast<const char *>(col.data()), (std::streamsize)(4 * V));
+    }
+    if (!out) return fail(CHISEL_HIP_ERR_IO, std::string("write failed: ") + path);
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_load_map(chisel_hip_map *m, const char *path) {
+    if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    MapFileHeader h;
+    in.read(reinterpret_cast<char *>(&h), sizeof(h));
+    if (!in || memcmp(h.magic, "CHSLHIP1", 8) != 0) return fail(CHISEL_HIP_ERR_IO, "not a chisel-hip map file");
+    if (h.chunk_edge != m->N || h.resolution != m->cfg.voxel_resolution || (h.has_color != 0) != (m->view.rgbw != nullptr))
+        return fail(CHISEL_HIP_ERR_INVALID, "map file was written with another chunk size, resolution or colour setting");
+    if (h.n_chunks < 0 || h.n_chunks > m->view.max_chunks) return fail(CHISEL_HIP_ERR_POOL_FULL, "map file holds more chunks than max_chunks");
+    int rc = chisel_hip_reset(m);
+    if (rc) return rc;
+    const size_t V = (size_t)m->V;
+    std::vector<float> sdf(V), wgt(V);
+    std::vector<uint8_t> col(h.has_color ? 4 * V : 0);
+    for (int64_t i = 0; i < h.n_chunks; i++) {
+        int id[3];
+        in.read(reinterpret_cast<char *>(id), sizeof(id));
+        in.read(reinterpret_cast<char *>(sdf.data()), (std::streamsize)(V * sizeof(float)));
+        in.read(reinterpret_cast<char *>(wgt.data()), (std::streamsize)(V * sizeof(float)));
+        if (h.has_color) in.read(reinterpret_cast<char *>(col.data()), (std::streamsize)(4 * V));
+        if (!in) return fail(CHISEL_HIP_ERR_IO, std::string("truncated map file: ") + path);
+        if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank) continue;  // another shard's chunk
+        rc = chisel_hip_upload_chunk(m, id, sdf.data(), wgt.data(), h.has_color ? col.data() : nullptr);
+        if (rc) return rc;
+    }
+    return CHISEL_HIP_OK;
+}
+
 int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf, const float *weight, const uint8_t *rgbw) {
     if (!m || !id || !sdf || !weight) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)

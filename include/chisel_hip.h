@@ -185,6 +185,14 @@ int chisel_hip_get_sdf_and_gradient(chisel_hip_map *map, const float pos[3], dou
 /* Chisel::SaveAllMeshesToPLY Chisel.cpp:69-105 + SaveMeshPLYASCII io/PLY.cpp:29-88 */
 int chisel_hip_save_ply(chisel_hip_map *map, const char *path);
 
+/* Binary dump / restore of the whole map (the correct counterpart of chisel_ros FillChunkMessage,
+ * Serialization.h:31-84, whose bit packing loses data; also checkpoint / resume).  File: 32-byte header
+ * {"CHSLHIP1", int32 chunk edge, float resolution, int32 has_colour, int64 n_chunks, 4 spare bytes}, then per chunk, in
+ * ascending id order: int32 id[3], float sdf[V], float weight[V], (uint8 rgbw[4 V] if has_colour).  load replaces the
+ * map's contents (Reset first); chunk size, resolution and colour must match the map's. */
+int chisel_hip_save_map(chisel_hip_map *map, const char *path);
+int chisel_hip_load_map(chisel_hip_map *map, const char *path);
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* accumulated since creation / last reset_counters; out has CHISEL_HIP_NUM_COUNTERS entries */
 int chisel_hip_get_counters(chisel_hip_map *map, uint64_t *out, int reset_counters);

@@ -357,6 +357,34 @@ def test_back_to_back_batches_pipeline(oracle_mod, batch, force_lookup, monkeypa
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+def test_checkpoint_and_resume(oracle_mod, tmp_path):
+    """chisel_hip_save_map / load_map: a map dumped in the middle of a stream and restored into a fresh map continues
+    bit for bit like the uninterrupted run (and like the oracle); the dump itself reads back identically"""
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+    frames = make_frames("sphere_room", 10, 64, 48, nan_fraction=0.02)
+    for d, p in frames[:6]:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+    gm.IntegrateBatch(integ, [(d, p, cam) for d, p in frames[:6]], [(color, p, cam) for _, p in frames[:6]])
+    path = str(tmp_path / "map.chsl")
+    gm.SaveMap(path)
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+    from cvids_amd import chisel as ch
+    g2 = ch.Chisel((8, 8, 8), 0.05, True, max_chunks=8192)
+    g2.LoadMap(path)
+    compare_fields(om.fields(), g2.fields(), om.V, True, what="restored")
+    for d, p in frames[6:]:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+    g2.IntegrateBatch(integ, [(d, p, cam) for d, p in frames[6:]], [(color, p, cam) for _, p in frames[6:]])
+    assert om.num_chunks() == g2.NumChunks()
+    compare_fields(om.fields(), g2.fields(), om.V, True, what="resumed")
+    from cvids_amd import capi
+    with pytest.raises(capi.ChiselHipError):
+        ch.Chisel((16, 16, 16), 0.05, True).LoadMap(path)  # another chunk size
+
+
 def test_event_ordered_device_frames(oracle_mod):
     """chisel_hip_wait_event / chisel_hip_record_event: device frames produced late on another stream (as an RCCL
     all-gather would) and one frame buffer reused for every batch, ordered with events only -- no host wait anywhere."""

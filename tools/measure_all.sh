@@ -1,3 +1,4 @@
+# The measurement table of DESIGN.md section 7 (inside gpurun): bash tools/measure_all.sh
 cd $GRAFT_REPO_ROOT
 show() { python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('%-16s fps %8.0f ms/step %.4f | integrate %.2f us/launch (%.1f fr) frac %.3f | other %s | int-only %s | cpu %s' % (sys.argv[1], d['value'], d['ms_per_step'], r.get('avg_kernel_us',0), r.get('frames_per_launch',0), r.get('frac',0), {k: round(v,1) for k,v in r.get('other_kernels_us',{}).items()}, d.get('integration_only',{}).get('value'), d.get('cpu_baseline',{}).get('value')))" "$1"; }
 python3 bench.py 2>&1 | tail -1 > gpurun_out/final_default.json; cat gpurun_out/final_default.json | show default

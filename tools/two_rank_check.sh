@@ -1,3 +1,5 @@
+# N > 1 logic on ONE GPU: GPU tests, then bench.py with 1 rank and with 2 ranks over gloo (host bounce instead of RCCL);
+# the per-frame counters of both runs must be equal.  bash tools/two_rank_check.sh
 cd $GRAFT_REPO_ROOT
 timeout 600 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -3
 export HSA_ENABLE_IPC_MODE_LEGACY=0
