@@ -192,6 +192,40 @@ class Chisel:
     def Reset(self):
         check(self.L.chisel_hip_reset(self.h))
 
+    # ---- meshing a sharded map: halo chunks (chisel_hip.h "meshing a sharded map") ------------------------------
+    def ExportChunks(self, ids):
+        """-> (sdf [n, V] float32, weight [n, V] float32, rgbw [n, V, 4] uint8 or None, found [n] int32) of the listed chunks"""
+        ids = np.ascontiguousarray(np.asarray(ids, np.int32).reshape(-1, 3))
+        n = len(ids)
+        sdf = np.empty((n, self.V), np.float32)
+        wgt = np.empty((n, self.V), np.float32)
+        col = np.empty((n, self.V, 4), np.uint8) if self.use_color else None
+        found = np.zeros(n, np.int32)
+        if n:
+            check(self.L.chisel_hip_export_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n, sdf.ctypes.data, wgt.ctypes.data,
+                                                  col.ctypes.data if col is not None else None, found.ctypes.data_as(C.POINTER(C.c_int)), 0))
+        return sdf, wgt, col, found
+
+    def ImportGhostChunks(self, ids, sdf, wgt, col=None, found=None):
+        ids = np.ascontiguousarray(np.asarray(ids, np.int32).reshape(-1, 3))
+        n = len(ids)
+        if not n:
+            return
+        sdf = np.ascontiguousarray(sdf, np.float32)
+        wgt = np.ascontiguousarray(wgt, np.float32)
+        col = np.ascontiguousarray(col, np.uint8) if col is not None else None
+        found = np.ascontiguousarray(found, np.int32) if found is not None else None
+        check(self.L.chisel_hip_import_ghost_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n, sdf.ctypes.data, wgt.ctypes.data,
+                                                    col.ctypes.data if col is not None else None,
+                                                    found.ctypes.data_as(C.POINTER(C.c_int)) if found is not None else None, 0))
+
+    def DropGhostChunks(self):
+        check(self.L.chisel_hip_drop_ghost_chunks(self.h))
+
+    def UpdateMeshesOf(self, ids):
+        ids = np.ascontiguousarray(np.asarray(ids, np.int32).reshape(-1, 3))
+        check(self.L.chisel_hip_update_meshes_of(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), len(ids)))
+
     def SaveMap(self, filename):
         """binary dump of every resident chunk (chisel_hip_save_map): checkpoint"""
         check(self.L.chisel_hip_save_map(self.h, str(filename).encode()))

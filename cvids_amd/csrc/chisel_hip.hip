@@ -159,6 +159,7 @@ struct chisel_hip_map {
     } pending_meshes;
     int *mesh_totals_host = nullptr;                                   // pinned: totals + error flag of the recompute in flight
     hipStream_t copy_stream = nullptr;                                 // small device->host copies that must not wait for queued batches
+    std::vector<int> ghost_ids;                                        // chunks of other shards imported for meshing (x, y, z triples)
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
     MeshBuffers mesh_buf{};
@@ -938,6 +939,107 @@ int chisel_hip_download_chunk(chisel_hip_map *m, const int id[3], float *sdf, fl
         if (!m->view.rgbw) return fail(CHISEL_HIP_ERR_INVALID, "map has no colour voxels");
         HIP_TRY(hipMemcpy(rgbw, m->view.rgbw + off, (size_t)m->V * 4, hipMemcpyDeviceToHost));
     }
+    return CHISEL_HIP_OK;
+}
+
+namespace {
+// device staging for the batched chunk transfers: ids, flags and (host callers) the voxel rows
+struct ChunkStage {
+    int *ids = nullptr, *flags = nullptr;
+    float *sdf = nullptr, *wgt = nullptr;
+    uchar4 *col = nullptr;
+    ~ChunkStage() {
+        for (void *p : {(void *)ids, (void *)flags, (void *)sdf, (void *)wgt, (void *)col})
+            if (p) (void)hipFree(p);
+    }
+};
+}  // namespace
+
+int chisel_hip_export_chunks(chisel_hip_map *m, const int *ids, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device) {
+    if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    if (n == 0) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t V = (size_t)m->V, rows = (size_t)n * V;
+    const bool color = m->view.rgbw && rgbw;
+    ChunkStage st;
+    HIP_TRY(hipMalloc(&st.ids, (size_t)n * 3 * sizeof(int)));
+    HIP_TRY(hipMalloc(&st.flags, (size_t)n * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(st.ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    float *d_s = sdf, *d_w = weight;
+    uchar4 *d_c = reinterpret_cast<uchar4 *>(rgbw);
+    if (!on_device) {
+        HIP_TRY(hipMalloc(&st.sdf, rows * sizeof(float)));
+        HIP_TRY(hipMalloc(&st.wgt, rows * sizeof(float)));
+        if (color) HIP_TRY(hipMalloc(&st.col, rows * sizeof(uchar4)));
+        d_s = st.sdf; d_w = st.wgt; d_c = st.col;
+    }
+    hipLaunchKernelGGL(export_chunks_kernel, dim3(n), dim3(256), 0, m->stream, m->view, st.ids, m->V, d_s, d_w, color ? d_c : nullptr, st.flags);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(found, st.flags, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(sdf, st.sdf, rows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(weight, st.wgt, rows * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        if (color) HIP_TRY(hipMemcpyAsync(rgbw, st.col, rows * sizeof(uchar4), hipMemcpyDeviceToHost, m->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, const float *sdf, const float *weight, const uint8_t *rgbw,
+                                   const int *found, int on_device) {
+    if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    if (n == 0) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_mesh_totals(m);
+    if (rc) return rc;
+    for (int j = 0; j < n; j++)
+        if ((!found || found[j]) && chunk_owner(ids[3 * j], ids[3 * j + 1], ids[3 * j + 2], m->cfg.n_shards, m->cfg.shard_block) == m->cfg.shard_rank)
+            return fail(CHISEL_HIP_ERR_INVALID, "a ghost chunk must belong to another shard");
+    const size_t V = (size_t)m->V, rows = (size_t)n * V;
+    ChunkStage st;
+    HIP_TRY(hipMalloc(&st.ids, (size_t)n * 3 * sizeof(int)));
+    HIP_TRY(hipMemcpyAsync(st.ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    if (found) {
+        HIP_TRY(hipMalloc(&st.flags, (size_t)n * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(st.flags, found, (size_t)n * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    }
+    const float *d_s = sdf, *d_w = weight;
+    const uchar4 *d_c = reinterpret_cast<const uchar4 *>(rgbw);
+    if (!on_device) {
+        HIP_TRY(hipMalloc(&st.sdf, rows * sizeof(float)));
+        HIP_TRY(hipMalloc(&st.wgt, rows * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(st.sdf, sdf, rows * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(st.wgt, weight, rows * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        if (rgbw) {
+            HIP_TRY(hipMalloc(&st.col, rows * sizeof(uchar4)));
+            HIP_TRY(hipMemcpyAsync(st.col, rgbw, rows * sizeof(uchar4), hipMemcpyHostToDevice, m->stream));
+        }
+        d_s = st.sdf; d_w = st.wgt; d_c = st.col;
+    }
+    hipLaunchKernelGGL(import_chunks_kernel, dim3(n), dim3(256), 0, m->stream, m->view, st.ids, found ? st.flags : nullptr, m->V, d_s, d_w, d_c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (int j = 0; j < n; j++)
+        if (!found || found[j]) m->ghost_ids.insert(m->ghost_ids.end(), ids + 3 * j, ids + 3 * j + 3);
+    return check_device_error(m);
+}
+
+int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    if (m->ghost_ids.empty()) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_mesh_totals(m);  // a recompute in flight may still read them
+    if (rc) return rc;
+    const int n = (int)(m->ghost_ids.size() / 3);
+    rc = ensure_scratch(m, (size_t)n * 3 + 16);
+    if (rc) return rc;
+    int *d_cnt = m->scratch_i, *d_ids = m->scratch_i + 16;
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int), m->stream));
+    HIP_TRY(hipMemcpyAsync(d_ids, m->ghost_ids.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(remove_chunks_kernel, dim3(n), dim3(256), 0, m->stream, m->view, d_ids, n, d_cnt, m->V);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->ghost_ids.clear();
     return CHISEL_HIP_OK;
 }
 

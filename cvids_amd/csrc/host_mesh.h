@@ -395,7 +395,9 @@ extern "C" {
 int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     if (m->cfg.n_shards > 1)
-        return fail(CHISEL_HIP_ERR_UNSUPPORTED, "meshing a sharded map needs the neighbour shards' border voxels: not built yet");
+        return fail(CHISEL_HIP_ERR_UNSUPPORTED,
+                    "a shard cannot mesh on its own (its chunks' neighbours live on other shards): exchange them with chisel_hip_export_chunks / "
+                    "import_ghost_chunks and call chisel_hip_update_meshes_of (cvids_amd/sharded.py: ShardedChisel.UpdateMeshes)");
     HIP_TRY(hipSetDevice(m->device));
     // Chisel.cpp:53-58: "static int cnt = 0; if (cnt++ % 10 == 0)" -- the recompute runs on every 10th call
     if (!force && (m->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;
@@ -412,6 +414,28 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
     rc = collect_mesh_ids(m, extra);
     if (rc) return rc;
     rc = recompute_meshes(m);  // ends with meshesToUpdate.clear() (Chisel.cpp:57)
+    if (rc) return rc;
+    m->pending_mesh_ids.clear();
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
+    if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = resolve_pending_meshes(m);  // the device buffers of the previous recompute are about to be reused
+    if (rc) return rc;
+    for (int j = 0; j < n; j++)
+        if (chunk_owner(ids[3 * j], ids[3 * j + 1], ids[3 * j + 2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)
+            return fail(CHISEL_HIP_ERR_INVALID, "a shard meshes its own chunks only");
+    MeshBuffers &B = m->mesh_buf;
+    rc = ensure_mesh_jobs(m, std::max(n, m->view.max_chunks));
+    if (rc) return rc;
+    const int totals[4] = {0, 0, 0, n};
+    HIP_TRY(hipMemcpyAsync(mesh_totals(m), totals, sizeof(totals), hipMemcpyHostToDevice, m->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(B.ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    HIP_TRY(hipGetLastError());
+    rc = recompute_meshes(m);
     if (rc) return rc;
     m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;

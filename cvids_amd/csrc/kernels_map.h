@@ -164,6 +164,80 @@ __global__ void list_slots_kernel(MapView M, int *ids, int *slots, int max_out, 
     }
 }
 
+// ---- whole-chunk export / import (halo exchange for meshing a sharded map; batched download / upload) ---------
+// one workgroup per listed chunk: its voxel arrays -> row j of the output arrays (defaults when the chunk is absent)
+__global__ __launch_bounds__(256) void export_chunks_kernel(MapView M, const int *ids, int V, float *sdf, float *wgt, uchar4 *rgbw, int *found) {
+    __shared__ int s_slot;
+    const int j = blockIdx.x;
+    if (threadIdx.x == 0) {
+        s_slot = hash_find(M, ids[3 * j], ids[3 * j + 1], ids[3 * j + 2]);
+        found[j] = s_slot >= 0 ? 1 : 0;
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    const size_t src = (size_t)(slot >= 0 ? slot : 0) * V, dst = (size_t)j * V;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        sdf[dst + v] = slot >= 0 ? M.sdf[src + v] : 99999.0f;
+        wgt[dst + v] = slot >= 0 ? M.wgt[src + v] : 0.0f;
+        if (rgbw) rgbw[dst + v] = (slot >= 0 && M.rgbw) ? M.rgbw[src + v] : make_uchar4(0, 0, 0, 0);
+    }
+}
+// one workgroup per listed chunk with take[j] != 0: create-or-find (thread 0; serialised over the list by the caller's
+// choice of one launch per call -- the hash insert below is the single-writer form of ensure_chunk_kernel, so the
+// kernel runs with ONE workgroup at a time per id; distinct ids never collide on a slot because free_top is atomic and
+// the key is claimed with a CAS), then the row's voxels are written into the chunk
+__global__ __launch_bounds__(256) void import_chunks_kernel(MapView M, const int *ids, const int *take, int V, const float *sdf, const float *wgt,
+                                                             const uchar4 *rgbw) {
+    __shared__ int s_slot;
+    const int j = blockIdx.x;
+    if (take && !take[j]) return;
+    if (threadIdx.x == 0) {
+        const int x = ids[3 * j], y = ids[3 * j + 1], z = ids[3 * j + 2];
+        int slot = hash_find(M, x, y, z);
+        if (slot < 0) {
+            const int top = atomicSub(M.free_top, 1) - 1;
+            if (top < 0) {
+                atomicAdd(M.free_top, 1);
+                atomicExch(M.error_flag, 1);
+            } else {
+                slot = M.free_list[top];
+                const uint64_t key = pack_id(x, y, z);
+                const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+                bool placed = false;
+                for (uint64_t i = 0; i <= M.hash_mask && !placed; i++) {
+                    const uint64_t idx = (h + i) & M.hash_mask;
+                    const uint64_t cur = M.hash_keys[idx];
+                    if ((cur == KEY_EMPTY || cur == KEY_TOMB) &&
+                        atomicCAS((unsigned long long *)&M.hash_keys[idx], (unsigned long long)cur, (unsigned long long)key) == cur) {
+                        M.hash_vals[idx] = slot;
+                        placed = true;
+                    }
+                }
+                if (placed) {
+                    M.slot_key[slot] = key;
+                } else {
+                    atomicExch(M.error_flag, 2);
+                    slot = -1;
+                }
+            }
+        }
+        s_slot = slot;
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot < 0) return;
+    const size_t dst = (size_t)slot * V, src = (size_t)j * V;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        M.sdf[dst + v] = sdf[src + v];
+        M.wgt[dst + v] = wgt[src + v];
+        if (M.rgbw) M.rgbw[dst + v] = rgbw ? rgbw[src + v] : make_uchar4(0, 0, 0, 0);
+    }
+}
+__global__ void clear_dirty_kernel(MapView M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M.max_chunks) M.slot_dirty[i] = 0;
+}
+
 // ---- known-answer kernels: the device arithmetic against the reference-built golden vectors ----------
 __global__ void kat_truncation_kernel(int kind, float param, const float *depths, int n, float *trunc, float *weight1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -135,6 +135,58 @@ class PipelinedExchange:
         self.map.record_event(self.free[b & 1].cuda_event)
 
 
+# ---- meshing a sharded map -----------------------------------------------------------------------------------------
+# A chunk's mesh reads its 26 neighbours (cube corners, gradient normals, vertex colours), most of which live on other
+# shards.  Per recompute: (1) the union of all shards' meshesToUpdate is formed, (2) every shard takes the ids it owns as
+# its jobs, (3) asks the owners for the neighbours of its jobs it does not own, (4) imports what they hold as ghost
+# chunks, (5) recomputes its jobs, (6) drops the ghosts.  mesh_plan() is the pure part of that.
+def mesh_plan(union_ids, rank, world, owner_of):
+    """union_ids: iterable of (x, y, z); owner_of(id) -> rank.
+    -> (jobs: sorted list of ids this rank meshes, requests: {owner: sorted list of ids to ask that owner for})"""
+    jobs = sorted({tuple(int(v) for v in i) for i in union_ids if owner_of(i) == rank})
+    want = set()
+    for x, y, z in jobs:
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    if dx or dy or dz:
+                        want.add((x + dx, y + dy, z + dz))
+    requests = {}
+    for i in want:
+        o = owner_of(i)
+        if o != rank:
+            requests.setdefault(o, []).append(i)
+    return jobs, {o: sorted(v) for o, v in requests.items()}
+
+
+class LocalShardGroup:
+    """All shards of a map in ONE process (tests; a single GPU holding several shards): the same protocol as
+    ShardedChisel.UpdateMeshes with the exchange done by direct calls."""
+
+    def __init__(self, shards):
+        self.shards = shards
+        self.world = len(shards)
+        self.calls = 0
+
+    def UpdateMeshes(self, force=False):
+        from .chisel import chunk_owner
+        self.calls += 1
+        if not force and (self.calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
+            return
+        union = set()
+        for s_ in self.shards:
+            union.update(map(tuple, s_.GetMeshesToUpdate().tolist()))
+        owner = lambda i: chunk_owner(i, self.world, 2)
+        plans = [mesh_plan(union, r, self.world, owner) for r in range(self.world)]
+        for r, (jobs, requests) in enumerate(plans):
+            for o, ids in requests.items():
+                sdf, wgt, col, found = self.shards[o].ExportChunks(ids)
+                self.shards[r].ImportGhostChunks(ids, sdf, wgt, col, found)
+        for r, (jobs, _) in enumerate(plans):
+            self.shards[r].UpdateMeshesOf(jobs)
+            self.shards[r].DropGhostChunks()
+
+
 class ShardedChisel:
     """chisel::Chisel surface over the shards of one node (only what the sharded path changes)."""
 
@@ -157,6 +209,41 @@ class ShardedChisel:
                 colors.append((color[j], pose, cam))
         self.map.IntegrateBatch(self.integrator, frames, colors)
         return frames
+
+    def UpdateMeshes(self, force=False):
+        """Chisel::UpdateMeshes of the sharded map: every rank ends up with the meshes of the chunks it owns (mesh_plan above).
+        The id lists and the halo chunks travel as objects (all_gather_object / all_to_all via gather of lists): this is
+        the functional path; the voxel payload of a recompute is a few MB per rank."""
+        from .chisel import chunk_owner
+        self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
+        if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
+            return
+        dist, world, rank = self.x.dist, self.x.world, self.x.rank
+        mine = [tuple(i) for i in self.map.GetMeshesToUpdate().tolist()]
+        if world == 1:
+            self.map.UpdateMeshes(force=True)
+            return
+        lists = [None] * world
+        dist.all_gather_object(lists, mine)
+        union = set()
+        for l in lists:
+            union.update(l)
+        jobs, requests = mesh_plan(union, rank, world, lambda i: chunk_owner(i, world, 2))
+        asked = [None] * world                      # asked[o] = what rank o wants from each rank
+        dist.all_gather_object(asked, requests)
+        replies = {}                                # what this rank serves: requester -> (ids, sdf, wgt, col, found)
+        for requester, req in enumerate(asked):
+            ids = req.get(rank, []) if requester != rank else []
+            if ids:
+                replies[requester] = (ids,) + tuple(self.map.ExportChunks(ids))
+        served = [None] * world
+        dist.all_gather_object(served, replies)     # functional form of an all-to-all
+        for o, rep in enumerate(served):
+            if o != rank and rank in rep:
+                ids, sdf, wgt, col, found = rep[rank]
+                self.map.ImportGhostChunks(ids, sdf, wgt, col, found)
+        self.map.UpdateMeshesOf(jobs)
+        self.map.DropGhostChunks()
 
     def NumChunks(self):
         torch, dist = self.x.torch, self.x.dist

@@ -185,6 +185,25 @@ int chisel_hip_get_sdf_and_gradient(chisel_hip_map *map, const float pos[3], dou
 /* Chisel::SaveAllMeshesToPLY Chisel.cpp:69-105 + SaveMeshPLYASCII io/PLY.cpp:29-88 */
 int chisel_hip_save_ply(chisel_hip_map *map, const char *path);
 
+/* ---- meshing a sharded map (SURVEY.md 8e "meshing across shards") -------------------------------------------------
+ * A chunk's mesh reads its 26 neighbours (cube corners: ChunkManager.cpp:316-357; gradient normals and colours of border
+ * vertices: :449-499, :588-607), most of which belong to other shards.  The owners export those chunks, the mesher
+ * imports them as "ghost" chunks -- resident, never integrated (cull_kernel only takes chunks this shard owns) --
+ * recomputes the meshes of its own chunks and drops the ghosts again.  cvids_amd/sharded.py orchestrates the exchange
+ * (ShardedChisel.UpdateMeshes).  ids must not repeat within a call.  Buffers: [n][V] floats / [n][V][4] bytes, on the
+ * host or (on_device != 0) in HBM on the map's device.
+ *   export_chunks        voxels of n chunks (found[j] = 0 and default voxels for a chunk that is not resident)
+ *   import_ghost_chunks  install the chunks with found[j] != 0 (found may be NULL = all) as ghosts
+ *   drop_ghost_chunks    remove every ghost imported since the last drop
+ *   update_meshes_of     RecomputeMeshes (ChunkManager.cpp:130-169) for exactly these chunk ids -- the shard's share of
+ *                        the union of all shards' meshesToUpdate -- then meshesToUpdate.clear() (Chisel.cpp:57) */
+int chisel_hip_export_chunks(chisel_hip_map *map, const int *ids_xyz, int n, float *sdf, float *weight, uint8_t *rgbw,
+                             int *found, int on_device);
+int chisel_hip_import_ghost_chunks(chisel_hip_map *map, const int *ids_xyz, int n, const float *sdf, const float *weight,
+                                   const uint8_t *rgbw, const int *found, int on_device);
+int chisel_hip_drop_ghost_chunks(chisel_hip_map *map);
+int chisel_hip_update_meshes_of(chisel_hip_map *map, const int *ids_xyz, int n);
+
 /* Binary dump / restore of the whole map (the correct counterpart of chisel_ros FillChunkMessage,
  * Serialization.h:31-84, whose bit packing loses data; also checkpoint / resume).  File: 32-byte header
  * {"CHSLHIP1", int32 chunk edge, float resolution, int32 has_colour, int64 n_chunks, 4 spare bytes}, then per chunk, in

@@ -71,6 +71,47 @@ def test_mesh_chunk_sizes(oracle_mod, N, res, W, H):
     assert n > 0 and nv > 0
 
 
+@pytest.mark.parametrize("n_shards", [2, 4, 8])
+def test_sharded_map_meshes_equal_the_unsharded_map(oracle_mod, n_shards):
+    """SURVEY.md 8e "meshing across shards": every shard meshes the chunks it owns with its neighbours' chunks imported as
+    ghosts (export_chunks / import_ghost_chunks / update_meshes_of / drop_ghost_chunks, cvids_amd/sharded.py).  The union
+    of the shards' meshes equals the oracle's meshes of the whole map element for element, two recomputes in a row, and
+    the ghosts leave no trace in the shards' chunk lists."""
+    from cvids_amd import chisel as ch
+    from cvids_amd.sharded import LocalShardGroup
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    shards = [ch.Chisel((8, 8, 8), 0.05, True, max_chunks=8192, n_shards=n_shards, shard_rank=r) for r in range(n_shards)]
+    group = LocalShardGroup(shards)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+
+    class Union:  # the shards seen as one map by _compare_meshes
+        def GetMeshIDs(self):
+            ids = [s_.GetMeshIDs() for s_ in shards]
+            return np.concatenate([i for i in ids if len(i)], axis=0) if any(len(i) for i in ids) else np.zeros((0, 3), np.int32)
+
+        def GetMesh(self, cid):
+            return shards[ch.chunk_owner(cid, n_shards, 2)].GetMesh(cid)
+
+    for start, count in ((0, 4), (4, 3)):
+        part = make_frames("sphere_room", count, 64, 48, start=start)
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        for s_ in shards:
+            s_.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        before = [s_.NumChunks() for s_ in shards]
+        om.update_meshes(force=True)
+        group.UpdateMeshes(force=True)
+        n, nv = _compare_meshes(om, Union(), True)
+        assert n > 20 and nv > 3000
+        assert [s_.NumChunks() for s_ in shards] == before  # ghosts dropped
+        assert sum(before) == om.num_chunks()
+        for r, s_ in enumerate(shards):
+            assert all(ch.chunk_owner(cid, n_shards, 2) == r for cid in map(tuple, s_.GetMeshIDs().tolist()))
+            assert len(s_.GetMeshesToUpdate()) == 0
+
+
 def test_mesh_color_lookup_near_origin(oracle_mod):
     """10 cm voxels: InterpolateColor's integer-index lookups (ChunkManager.cpp:506-520) land inside the map"""
     om, gm, integ = _mk(oracle_mod, 8, 0.10, True, trunc=("constant", 0.3), max_chunks=8192)

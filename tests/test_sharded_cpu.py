@@ -123,3 +123,117 @@ def test_frames_of_rank():
         assert got == list(range(8))
     with pytest.raises(ValueError):
         frames_of_rank(6, 4, 0)
+
+
+# ---- meshing a sharded map: the exchange protocol (no voxels are computed here) ------------------------------------------
+def test_mesh_plan_covers_every_foreign_neighbour(hip_lib):
+    from cvids_amd.chisel import chunk_owner
+    from cvids_amd.sharded import mesh_plan
+    world = 4
+    owner = lambda i: chunk_owner(i, world, 2)
+    rng = np.random.default_rng(11)
+    union = {tuple(int(v) for v in i) for i in rng.integers(-6, 6, (200, 3))}
+    seen_jobs = set()
+    for rank in range(world):
+        jobs, requests = mesh_plan(union, rank, world, owner)
+        assert all(owner(j) == rank for j in jobs) and jobs == sorted(jobs)
+        seen_jobs.update(jobs)
+        asked = {i for ids in requests.values() for i in ids}
+        for o, ids in requests.items():
+            assert o != rank and all(owner(i) == o for i in ids) and len(set(ids)) == len(ids)
+        for x, y, z in jobs:  # every neighbour of a job is owned or asked for
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dz in (-1, 0, 1):
+                        n = (x + dx, y + dy, z + dz)
+                        assert owner(n) == rank or n in asked
+    assert seen_jobs == union  # the shards' jobs partition the union
+
+
+class MeshRecordingMap(RecordingMap):
+    """adds the mesh-side calls: resident chunks = owned ids of a fixed box; a chunk's "voxels" encode its id and owner"""
+
+    def __init__(self, rank, world):
+        super().__init__(rank, world)
+        self.ghosts, self.meshed, self.dropped = {}, None, 0
+
+    def _resident(self):
+        return set(map(tuple, self.GetChunkIDs().tolist()))
+
+    def GetMeshesToUpdate(self):
+        dirty = [i for i in sorted(self._resident()) if (i[0] + i[1] + i[2]) % 3 == 0]
+        out = {(x + dx, y + dy, z + dz) for x, y, z in dirty for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)}
+        return np.array(sorted(out), np.int32).reshape(-1, 3)
+
+    def ExportChunks(self, ids):
+        res = self._resident()
+        found = np.array([1 if tuple(i) in res else 0 for i in ids], np.int32)
+        sdf = np.array([[i[0], i[1], i[2], self.rank] for i in ids], np.float32)
+        return sdf, sdf + 0.5, None, found
+
+    def ImportGhostChunks(self, ids, sdf, wgt, col=None, found=None):
+        for j, i in enumerate(ids):
+            if found is None or found[j]:
+                self.ghosts[tuple(i)] = (np.asarray(sdf[j]).copy(), np.asarray(wgt[j]).copy())
+
+    def UpdateMeshesOf(self, ids):
+        self.meshed = ([tuple(i) for i in ids], dict(self.ghosts))
+
+    def DropGhostChunks(self):
+        self.dropped += 1
+        self.ghosts = {}
+
+
+def _mesh_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from cvids_amd.chisel import chunk_owner
+    from cvids_amd.sharded import FrameExchange, ShardedChisel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = FrameExchange(W, H, K, torch.device("cpu"), dist, channels=0)
+        local = MeshRecordingMap(rank, world)
+        sm = ShardedChisel(local, x, integrator=None)
+        sm.UpdateMeshes(force=True)
+        jobs, ghosts = local.meshed
+        out.put((rank, jobs, {k: (v[0].tolist(), v[1].tolist()) for k, v in ghosts.items()}, local.dropped, len(local.ghosts)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_update_meshes_protocol_world2(hip_lib):
+    import torch.multiprocessing as mp
+    from cvids_amd.chisel import chunk_owner
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    box = [(x, y, z) for x in range(-3, 3) for y in range(-2, 2) for z in range(0, 4)]
+    resident = {r: {i for i in box if chunk_owner(i, world, 2) == r} for r in range(world)}
+    union = set()
+    for r in range(world):
+        union.update(map(tuple, MeshRecordingMap(r, world).GetMeshesToUpdate().tolist()))
+    all_jobs = set()
+    for rank, jobs, ghosts, dropped, left in res:
+        assert dropped == 1 and left == 0
+        assert set(jobs) == {i for i in union if chunk_owner(i, world, 2) == rank}
+        all_jobs.update(jobs)
+        for x, y, z in jobs:
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dz in (-1, 0, 1):
+                        n = (x + dx, y + dy, z + dz)
+                        o = chunk_owner(n, world, 2)
+                        if o != rank and n in resident[o]:  # a neighbour another shard holds: imported, with that shard's data
+                            assert n in ghosts and ghosts[n][0] == [float(n[0]), float(n[1]), float(n[2]), float(o)]
+        assert all(chunk_owner(g, world, 2) != rank for g in ghosts)
+    assert all_jobs == union
