@@ -82,7 +82,10 @@ struct Geom {
     // record tile in LDS per workgroup (16 / 32 KiB).  Larger boxes belong to near-camera chunks whose voxels map to
     // distinct pixels: staging the whole box would move more bytes than gathering the records from L2 directly.
     static constexpr int TILE_PIXELS = (N == 8) ? 2048 : INTEGRATE_TILE;
-    static constexpr int GRID = (N == 8) ? 4096 : ((BLOCK > 512) ? 512 : 1024);  // >= what is resident at once  // persistent grid: about what fits the chip at once
+#ifndef INTEGRATE_GRID
+#define INTEGRATE_GRID 1024
+#endif
+    static constexpr int GRID = (N == 8) ? 4096 : ((BLOCK > 512) ? 512 : INTEGRATE_GRID);  // persistent grid: >= what is resident at once
     static constexpr int MIN_WAVES = (N == 8) ? 1 : INTEGRATE_MIN_WAVES;
     static_assert(BLOCK % LAYER_QUADS == 0, "a thread's quads must share x and y");
     static_assert(GRID <= INTEGRATE_MAX_GRID, "per-workgroup counter rows");

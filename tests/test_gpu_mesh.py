@@ -112,6 +112,32 @@ def test_sharded_map_meshes_equal_the_unsharded_map(oracle_mod, n_shards):
             assert len(s_.GetMeshesToUpdate()) == 0
 
 
+def test_stream_with_keyframe_meshing_no_waits(oracle_mod):
+    """The bench's call pattern on a small map: batches of 7 frames queued back to back, UpdateMeshes() after every frame
+    count that crosses a multiple of 10 (the recompute is queued whole, its totals are looked at by the next batch), no
+    wait anywhere until the end.  Voxels and every chunk's mesh arrays must equal the oracle's."""
+    om, gm, integ = _mk(oracle_mod, 16, 0.04, True, max_chunks=4096)
+    W, H = 160, 120
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(W, H, 3)
+    frames = make_frames("sphere_room", 21, W, H, agents=2, nan_fraction=0.01)  # 42 frames
+    done = 0
+    for lo in range(0, len(frames), 7):
+        part = frames[lo:lo + 7]
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        if (done + len(part)) // 10 > done // 10:
+            om.update_meshes(force=True)
+            gm.UpdateMeshes(force=True)
+        done += len(part)
+    from tests.common import compare_fields
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+    n, nv = _compare_meshes(om, gm, True)
+    assert n > 10 and nv > 1000
+
+
 def test_mesh_color_lookup_near_origin(oracle_mod):
     """10 cm voxels: InterpolateColor's integer-index lookups (ChunkManager.cpp:506-520) land inside the map"""
     om, gm, integ = _mk(oracle_mod, 8, 0.10, True, trunc=("constant", 0.3), max_chunks=8192)
