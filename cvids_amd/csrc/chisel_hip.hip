@@ -707,7 +707,9 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         // the front half is short and feeds the long integration kernel of the next batch: let its workgroups go first
         int least = 0, greatest = 0;
         HIP_TRY_C(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY_C(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, greatest));
+        const char *pr = getenv("CHISEL_HIP_AUX_PRIORITY");  // diagnostic: "low" / "normal" instead of the default high
+        const int prio = pr && !strcmp(pr, "low") ? least : (pr && !strcmp(pr, "normal") ? (least + greatest) / 2 : greatest);
+        HIP_TRY_C(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, prio));
     }
     m->stream = m->own_stream;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
