@@ -280,7 +280,7 @@ __global__ void mesh_collect_kernel(MapView M, unsigned *mesh_flag, int *ids, in
     }
 }
 
-constexpr int MESH_BLOCK_THREADS = 512;  // per-chunk kernel: 8 cubes (16^3) per thread
+constexpr int MESH_BLOCK_THREADS = 512;  // per-chunk kernel: 8 cubes (16^3) per thread (256: 33 us, 512: 24 us, 1024: 35 us per recompute)
 
 // corner voxel (cx, cy, cz), each in 0..N, of the cube grid of a job: (sdf, weight); absent chunk -> weight 0
 template <int N>
