@@ -4,15 +4,17 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one depth(+colour) frame pushed through the hot path (pyramid -> cull -> integrate kernels;
-with --mesh-every M also a marching-cubes recompute every M-th frame, the reference cadence is 10).
-Frames are synthetic (cvids_amd.synth: sphere room, 0.5 deg + 1 cm per frame) and already resident in
-HBM when the timed region starts.  Frames are handed to the library --batch at a time
-(chisel_hip_integrate_batch: one launch set applies them to every voxel in frame order; --batch 1 is the
-reference's frame-by-frame call pattern).  N > 1: one process per GPU, the chunk hash is sharded spatially
-(chisel_hip_config.n_shards); the frames of a batch are ingested round-robin (frame j on rank j * N / batch) and one
-RCCL all-gather per batch hands every rank the whole batch (cvids_amd.sharded.FrameExchange), then each rank
-integrates the chunks it owns -> total work is fixed: "scaling": "strong".
+A step = one depth(+colour) frame pushed through the hot path (pyramid -> cull -> resolve -> integrate kernels).
+The default at 1 GPU is BASELINE.json's configuration 3: 640x480 depth + BGR colour, 1 cm voxels, a marching-cubes
+recompute on every 10th frame (the reference's keyframe cadence, Chisel.cpp:54), 10 frames per call; `integration_only`
+in the JSON line is the same stream without the recomputes.  Frames are synthetic (cvids_amd.synth: sphere room,
+0.5 deg + 1 cm per frame) and already resident in HBM when the timed region starts.  Frames are handed to the library
+--batch at a time (chisel_hip_integrate_batch: one launch set applies up to 16 frames to every voxel in frame order;
+--batch 1 is the reference's frame-by-frame call pattern).  N > 1: one process per GPU, the chunk hash is sharded
+spatially (chisel_hip_config.n_shards); the frames of a batch are ingested round-robin (frame j on rank j * N / batch)
+and one RCCL all-gather per batch hands every rank the whole batch (cvids_amd.sharded.FrameExchange, on its own
+stream, ordered against the map with events), then each rank integrates the chunks it owns -> total work is fixed:
+"scaling": "strong".  N > 1 runs integrate only (16 frames per all-gather).
 
 One JSON line on rank 0.  `roofline` prices the integration kernel: algorithmic bytes per frame
 (DESIGN.md "Measurement": 16 B per integrated voxel + 8 B per carve probe + 8 B per carve + colour
@@ -140,7 +142,8 @@ def main():
     if args.mesh_every is None:
         args.mesh_every = 10 if world == 1 else 0
     if args.batch is None:
-        args.batch = args.mesh_every if 0 < args.mesh_every <= 16 else 8
+        # 1 GPU: the keyframe interval; N GPUs: 16 frames per all-gather (every rank contributes 16 / N frame slots)
+        args.batch = args.mesh_every if 0 < args.mesh_every <= 16 else (16 if world > 1 else 8)
     W, H = args.width, args.height
     intr = synth.intrinsics(W, H)
     cam = PinholeCamera(*intr, W, H, 0.05, 5.0)
@@ -307,6 +310,9 @@ def main():
                           "n_probe": vals[4] / args.steps, "n_carved": vals[5] / args.steps,
                           "work_chunks": vals[6] / args.steps, "resident_chunks_end": vals[7]},
         }
+        if world > 1:
+            out["note"] = ("N > 1: integration only (a sharded map is meshed through a functional, host-mediated exchange that is not "
+                           "part of this timing); the comparable 1-GPU figure is `integration_only` of the --gpus 1 line")
         if roof:
             out["roofline"] = roof
         if no_mesh:

@@ -341,6 +341,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
                            prev ? prev->pending : nullptr, prev_overflow, bs.pending);
         hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items);
     }
+    HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     g_host_timer.lap(4);
     // ---- back half: the map's stream.  A mesh recompute still in flight must have been sized first (it may have to be
     // emitted again from the voxels as they are now); its front-half work above did not depend on that.
@@ -348,10 +349,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         int rc_m = check_mesh_totals(m);
         if (rc_m) return rc_m;
     }
-    if (!inline_resolve) {
-        HIP_TRY(hipEventRecord(bs.front_done, front));
-        HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
-    }
+    if (!inline_resolve) HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
     int *wc = bs.cand_count + COUNT_ITEMS;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
@@ -467,8 +465,10 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     }
     hipStream_t front = bs.front_stream;
     if (front != m->stream) {
-        // the front half may start as soon as the batch that last used this buffer set has been integrated
+        // the front half may start as soon as the batch that last used this buffer set has been integrated -- and the
+        // previous batch's front half is through: its pending set is read here, and it may have run on the map's stream
         HIP_TRY(hipStreamWaitEvent(front, bs.back_done, 0));
+        if (m->batch_seq) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + 1u) & 1u].front_done, 0));
         if (m->mutation_pending) HIP_TRY(hipStreamWaitEvent(front, m->mutation_event, 0));
     }
     m->mutation_pending = false;

@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
 //                                  chunk hash is read while that batch may still be inserting exactly those chunks, so
 //                                  for them the lookup result is ignored and the item is marked SLOT_LOOKUP; every
 //                                  other key of the hash is stable (inserted before, removal never overlaps a batch).
+//                                  *prev_overflow != 0: that set is incomplete -- every candidate is marked SLOT_LOOKUP.
 //   my_pending / counts[COUNT_OVERFLOW] : receives the chunks this batch may create.
 
 // `counts_in` is `counts` again, read-only: the values read through it were written by earlier kernels, and a read-only
@@ -516,7 +517,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
             if (kk == KEY_EMPTY) break;
         }
         const unsigned inband = wi.frame_mask & 0xffffu, carve = wi.frame_mask >> 16;
-        const bool uncertain = prev_pending && (all_uncertain ? (slot < 0) : pending_contains(prev_pending, key, h0));
+        // While the previous batch is being integrated a key can already be visible whose slot value is not: the lookup
+        // result only counts for chunks that batch cannot be creating.  If its pending set is incomplete, that is nobody.
+        const bool uncertain = prev_pending && (all_uncertain || pending_contains(prev_pending, key, h0));
         unsigned mask = 0;
         if (uncertain) {
             slot = SLOT_LOOKUP;

@@ -478,7 +478,9 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
     __shared__ __attribute__((aligned(16))) PixelRec s_tiles[2][G::TILE_PIXELS];  // double buffer: the next frame's tile lands while this one is used
     __shared__ int s_flags[4];  // [2 * parity + 0]: a voxel was integrated this frame, [+1]: something changed this frame
     __shared__ int s_slot;
-    __shared__ unsigned s_changed;  // resident chunks: bit k = frame k changed some voxel (gathered once per item)
+    __shared__ unsigned s_changed[2];  // resident chunks: bit k = frame k changed some voxel (gathered once per item); the two
+                                       // words alternate per item: the next item's word is cleared one item ahead, because
+                                       // free-running waves need not meet a barrier between an item's start and this gather
     const int tid = threadIdx.x;
 #ifdef CHISEL_STAMPS
 #define STAMP(i) do { if (tid == 0 && M.stamps) M.stamps[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -496,6 +498,9 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
     Tally tally = {};
     unsigned n_new = 0, n_updated = 0;
     const IntegratorParams &ip = P.ip;
+    if (tid < 2) s_changed[tid] = 0u;
+    int changed_word = 0;  // which of s_changed the current free-running item uses (block-uniform)
+    __syncthreads();
 
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
         const WorkItem wi = items[it];
@@ -531,7 +536,6 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
 #endif
         __syncthreads();  // previous item's tile / flags / s_slot fully consumed
         if (tid < 4) s_flags[tid] = 0;
-        if (tid == 0) s_changed = 0u;
         // A chunk that already exists is "resident" for every frame, so its waves need no per-frame agreement: they
         // run through the batch independently (a barrier only where a staged tile must become visible) and report the
         // frames that changed something once, at the end.  New chunks keep the per-frame hand-shake below.
@@ -594,10 +598,13 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
                 need = prefetch_frame<N, COLOR>(F, T, S, M.sdf + base0, M.wgt + base0, COLOR ? (M.rgbw + base0) : nullptr, tid);
             if (it == (int)blockIdx.x) STAMP(16);
             LOOPT(0);
-            if (T.tw || !free_running) {
+            // [B] needed when this frame's tile must become visible to every wave, and when the next frame's tile is about to
+            // be moved into the other buffer: a wave that runs ahead must not overwrite the records a slower wave is still
+            // reading for the previous frame (free-running waves meet nowhere else).
+            if (T.tw || (more && T_next.tw) || !free_running) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the tile has landed (and its voxel reads)
 #ifndef CHISEL_ABLATE_BARRIER
-                __syncthreads();  // [B] tile visible to every wave; the other buffer and the other parity's flags are free
+                __syncthreads();  // tile visible to every wave; the other buffer and the other parity's flags are free
 #endif
             }
             LOOPT(1);
@@ -678,9 +685,11 @@ __global__ __launch_bounds__(Geom<N>::BLOCK, Geom<N>::MIN_WAVES) void integrate_
             unsigned wmask = 0u;
             for (int bit = 0; bit < P.n_frames; bit++)
                 if (__any((int)((lane_changed >> bit) & 1u))) wmask |= 1u << bit;
-            if ((tid & 63) == 0 && wmask) atomicOr(&s_changed, wmask);
+            if ((tid & 63) == 0 && wmask) atomicOr(&s_changed[changed_word], wmask);
             __syncthreads();
-            const unsigned word = s_changed;
+            const unsigned word = s_changed[changed_word];
+            changed_word ^= 1;
+            if (tid == 0) s_changed[changed_word] = 0u;  // for the next free-running item; its readers finished before this item began
             updated_any = word != 0u;
             n_updated += (tid == 0) ? (unsigned)__popc(word) : 0u;  // "needsUpdate" per frame (Chisel.h:85 / :167)
         }
