@@ -361,6 +361,18 @@ class Chisel:
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(capi.KERNEL_NAMES)}
 
 
+def condition_depth(depth64, width=640, height=480, intrinsics=None):
+    """CollaborativeServer::PublishDenseInfo's depth conditioning (chisel_hip_condition_depth): float64 depth map of any size
+    -> (float32 depth of the publish size with NaN outside [0.1, 20] m, rescaled (fx, fy, cx, cy) or None)"""
+    L = capi.load_library()
+    src = np.ascontiguousarray(depth64, np.float64)
+    h0, w0 = src.shape
+    dst = np.empty((height, width), np.float32)
+    K = (C.c_double * 4)(*(intrinsics if intrinsics is not None else (0.0, 0.0, 0.0, 0.0)))
+    check(L.chisel_hip_condition_depth(src.ctypes.data, w0, h0, 0, dst.ctypes.data, width, height, 0, K, None))
+    return dst, (tuple(K) if intrinsics is not None else None)
+
+
 def chunk_owner(cid, n_shards, shard_block=2):
     c = (C.c_int * 3)(*[int(v) for v in cid])
     return capi.load_library().chisel_hip_chunk_owner(c, int(n_shards), int(shard_block))

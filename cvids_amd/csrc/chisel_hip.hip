@@ -957,6 +957,41 @@ struct ChunkStage {
 };
 }  // namespace
 
+int chisel_hip_condition_depth(const double *src, int w0, int h0, int src_on_device, float *dst, int w, int h, int dst_on_device, double K[4],
+                               void *hip_stream) {
+    if (!src || !dst || w0 <= 0 || h0 <= 0 || w <= 0 || h <= 0) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t n0 = (size_t)w0 * h0, n1 = (size_t)w * h;
+    double *d_src = nullptr;
+    float *d_dst = nullptr;
+    const double *in = src;
+    float *out = dst;
+    if (!src_on_device) {
+        HIP_TRY(hipMalloc(&d_src, n0 * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(d_src, src, n0 * sizeof(double), hipMemcpyHostToDevice, st));
+        in = d_src;
+    }
+    if (!dst_on_device) {
+        HIP_TRY(hipMalloc(&d_dst, n1 * sizeof(float)));
+        out = d_dst;
+    }
+    hipLaunchKernelGGL(condition_depth_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, in, w0, h0, out, w, h);
+    HIP_TRY(hipGetLastError());
+    if (!dst_on_device) HIP_TRY(hipMemcpyAsync(dst, d_dst, n1 * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (!src_on_device || !dst_on_device) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (d_src) (void)hipFree(d_src);
+        if (d_dst) (void)hipFree(d_dst);
+    }
+    if (K) {  // collaborative_server_system.cpp:216-219
+        K[0] = K[0] / (double)w0 * (double)w;
+        K[2] = K[2] / (double)w0 * (double)w;
+        K[1] = K[1] / (double)h0 * (double)h;
+        K[3] = K[3] / (double)h0 * (double)h;
+    }
+    return CHISEL_HIP_OK;
+}
+
 int chisel_hip_export_chunks(chisel_hip_map *m, const int *ids, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device) {
     if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;

@@ -238,6 +238,49 @@ __global__ void clear_dirty_kernel(MapView M) {
     if (i < M.max_chunks) M.slot_dirty[i] = 0;
 }
 
+// ---- PublishDenseInfo's depth conditioning (collaborative_server_system.cpp:213, :255-269) -----------------------------
+// cv::resize(CV_64F, INTER_LINEAR) restated: position and weight of the two source samples per axis as OpenCV computes them
+__device__ inline void resize_tap(int d, double scale, int ssize, int &s0, int &s1, float &w0, float &w1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (si < 0) {
+        f = 0.0f;
+        si = 0;
+    }
+    if (si >= ssize - 1) {
+        f = 0.0f;
+        si = ssize - 1;
+    }
+    s0 = si;
+    s1 = min(si + 1, ssize - 1);
+    w0 = 1.0f - f;
+    w1 = f;
+}
+__global__ void condition_depth_kernel(const double *__restrict__ src, int w0, int h0, float *__restrict__ dst, int w, int h) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    double v;
+    if (w == w0 && h == h0) {
+        v = src[(size_t)y * w0 + x];  // same size: cv::resize copies
+    } else {
+        int x0, x1, y0, y1;
+        float a0, a1, b0, b1;
+        resize_tap(x, (double)w0 / (double)w, w0, x0, x1, a0, a1);
+        resize_tap(y, (double)h0 / (double)h, h0, y0, y1, b0, b1);
+        // horizontal pass of both rows (double work type, float weights), then the vertical one; where the second tap falls
+        // off the image the horizontal pass is S[sx] * 1
+        const double r0 = (a1 == 0.0f && x0 == w0 - 1) ? src[(size_t)y0 * w0 + x0] * 1.0
+                                                       : src[(size_t)y0 * w0 + x0] * (double)a0 + src[(size_t)y0 * w0 + x1] * (double)a1;
+        const double r1 = (a1 == 0.0f && x0 == w0 - 1) ? src[(size_t)y1 * w0 + x0] * 1.0
+                                                       : src[(size_t)y1 * w0 + x0] * (double)a0 + src[(size_t)y1 * w0 + x1] * (double)a1;
+        v = r0 * (double)b0 + r1 * (double)b1;
+    }
+    float f = (float)v;                                            // convertTo(CV_32FC1)
+    if (f < 0.1f || f > 20.0f) f = __builtin_nanf("");             // :262-265
+    dst[(size_t)y * w + x] = f;
+}
+
 // ---- known-answer kernels: the device arithmetic against the reference-built golden vectors ----------
 __global__ void kat_truncation_kernel(int kind, float param, const float *depths, int n, float *trunc, float *weight1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

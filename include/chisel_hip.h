@@ -204,6 +204,16 @@ int chisel_hip_import_ghost_chunks(chisel_hip_map *map, const int *ids_xyz, int 
 int chisel_hip_drop_ghost_chunks(chisel_hip_map *map);
 int chisel_hip_update_meshes_of(chisel_hip_map *map, const int *ids_xyz, int n);
 
+/* ---- the step before the path ------------------------------------------------------------------------
+ * CollaborativeServer::PublishDenseInfo's depth conditioning (server_pose_graph/src/collaborative_server_system.cpp:
+ * 199-276): cv::resize of the CV_64F depth map to the publish size (640 x 480 there; bilinear, OpenCV's INTER_LINEAR
+ * restated -- sample position (dx + 0.5) * scale - 0.5 narrowed to float, float weights, double accumulation; a map that
+ * already has the publish size is copied), narrowing to float, NaN for readings < 0.1 or > 20, and the rescaled
+ * intrinsics fx, fy, cx, cy (:216-219).  src: w0 x h0 doubles, dst: w x h floats, each on the host or (flag) in HBM; the
+ * result feeds chisel_hip_integrate_* directly.  Parity unpinned: OpenCV is not available to generate vectors. */
+int chisel_hip_condition_depth(const double *src, int w0, int h0, int src_on_device, float *dst, int w, int h, int dst_on_device,
+                               double intrinsics_fx_fy_cx_cy[4], void *hip_stream);
+
 /* Binary dump / restore of the whole map (the correct counterpart of chisel_ros FillChunkMessage,
  * Serialization.h:31-84, whose bit packing loses data; also checkpoint / resume).  File: 32-byte header
  * {"CHSLHIP1", int32 chunk edge, float resolution, int32 has_colour, int64 n_chunks, 4 spare bytes}, then per chunk, in

@@ -546,3 +546,25 @@ def test_full_size_stream_is_reproducible_across_modes(oracle_mod, monkeypatch):
         om.integrate_depth_color(d, p, intr, color, near=0.05, far=5.0)
     f5, _ = run(None, n_frames=5, batch=5)
     compare_fields(om.fields(), f5, om.V, True)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (376, 1241), (720, 1280), (97, 131)])
+def test_depth_conditioning(shape):
+    """chisel_hip_condition_depth == the restated PublishDenseInfo conditioning (oracle/publish_dense.py), bit for bit: same
+    size (copy), up- and down-scaling, odd sizes, readings out of range, NaN and infinity in the input"""
+    from cvids_amd.chisel import condition_depth
+    from oracle import publish_dense as pd
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    src = rng.uniform(0.0, 25.0, shape)
+    src[rng.random(shape) < 0.02] = np.nan
+    src[rng.random(shape) < 0.01] = np.inf
+    src[rng.random(shape) < 0.01] = -1.0
+    src[0, 0] = 0.1  # float(0.1) is kept: the test is "< 0.1f"
+    want = pd.condition_depth(src, 640, 480)
+    K0 = (718.856, 718.856, 607.1928, 185.2157)
+    got, K = condition_depth(src, 640, 480, K0)
+    assert got.shape == (480, 640) and got.dtype == np.float32
+    assert np.array_equal(np.isnan(want), np.isnan(got))
+    assert np.array_equal(want[~np.isnan(want)].view(np.uint32), got[~np.isnan(got)].view(np.uint32))
+    assert K == pd.rescale_intrinsics(*K0, shape[1], shape[0], 640, 480)
+    assert np.isnan(got).mean() > 0.05  # the range mask does something on this input
