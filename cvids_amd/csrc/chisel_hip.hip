@@ -65,6 +65,7 @@ struct MeshArena {
     bool host_valid = false;
     size_t floats() const { return nv * 3 * (color ? 3 : 2) + ng * 3; }
 };
+constexpr int MESH_INFO_PREFETCH = 8192;  // per-job records copied to the host with every recompute (the rest on demand)
 struct MeshRef {
     int arena = -1;            // -1: empty mesh
     size_t v_off = 0, n_v = 0, g_off = 0, n_g = 0;
@@ -158,6 +159,7 @@ struct chisel_hip_map {
         int arena = -1;
     } pending_meshes;
     int *mesh_totals_host = nullptr;                                   // pinned: totals + error flag of the recompute in flight
+    JobInfo *mesh_info_host = nullptr;                                 // pinned: its first MESH_INFO_PREFETCH per-job records
     hipStream_t copy_stream = nullptr;                                 // small device->host copies that must not wait for queued batches
     std::vector<int> ghost_ids;                                        // chunks of other shards imported for meshing (x, y, z triples)
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
@@ -715,6 +717,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
     HIP_TRY_C(hipEventCreateWithFlags(&m->mesh_counted, hipEventDisableTiming));
     HIP_TRY_C(hipHostMalloc((void **)&m->mesh_totals_host, 8 * sizeof(int), hipHostMallocDefault));
+    HIP_TRY_C(hipHostMalloc((void **)&m->mesh_info_host, (size_t)MESH_INFO_PREFETCH * sizeof(JobInfo), hipHostMallocDefault));
     HIP_TRY_C(hipEventCreateWithFlags(&m->call_event, hipEventDisableTiming));
     for (auto &bs : m->sets) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));
@@ -780,6 +783,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     if (m->mesh_counted) (void)hipEventDestroy(m->mesh_counted);
     if (m->mesh_totals_host) (void)hipHostFree(m->mesh_totals_host);
+    if (m->mesh_info_host) (void)hipHostFree(m->mesh_info_host);
     clear_meshes(m);
     release_arena_pool(m);
     free_mesh_buffers(m->mesh_buf);

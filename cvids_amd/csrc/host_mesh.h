@@ -18,8 +18,8 @@ MeshParams mesh_params(const chisel_hip_map *m) {
 
 void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena, size_t arena_floats) {
     MeshBuffers &B = m->mesh_buf;
-    const int *bases = B.counts + 2 * (size_t)B.capacity;
-    const int *totals = B.counts + 4 * (size_t)B.capacity;
+    const JobInfo *bases = B.info;
+    const int *totals = B.totals;
     const dim3 grid(4096), block(MESH_TRI_BLOCK);  // persistent: the number of triangles is read on the device
     switch (m->N) {
         case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats); break;
@@ -34,20 +34,21 @@ int ensure_mesh_jobs(chisel_hip_map *m, int n) {
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (B.jobs) HIP_TRY(hipFree(B.jobs));
     if (B.ids) HIP_TRY(hipFree(B.ids));
-    if (B.counts) HIP_TRY(hipFree(B.counts));
-    B.jobs = nullptr; B.ids = nullptr; B.counts = nullptr;
+    if (B.info) HIP_TRY(hipFree(B.info));
+    B.jobs = nullptr; B.ids = nullptr; B.info = nullptr;
     int cap = std::max(4096, B.capacity);
     while (cap < n) cap *= 2;
     HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
     HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
-    HIP_TRY(hipMalloc(&B.counts, ((size_t)cap * 4 + 8) * sizeof(int)));
+    HIP_TRY(hipMalloc(&B.info, (size_t)cap * sizeof(JobInfo)));
+    if (!B.totals) HIP_TRY(hipMalloc(&B.totals, 8 * sizeof(int)));
     B.capacity = cap;
     return CHISEL_HIP_OK;
 }
 
-// device counters of a recompute, behind the per-job arrays of mesh_buf.counts
+// device counters of a recompute (mesh_buf.totals)
 enum { MT_TRIS = 0, MT_GRIDS = 1, MT_OVERFLOW = 2, MT_JOBS = 3 };
-int *mesh_totals(chisel_hip_map *m) { return m->mesh_buf.counts + 4 * (size_t)m->mesh_buf.capacity; }
+int *mesh_totals(chisel_hip_map *m) { return m->mesh_buf.totals; }
 
 // ids of the resident chunks to mesh, built on the device: the 27-neighbourhoods of the dirty slots, de-duplicated
 // through one flag per slot, plus `extra` host-side ids (neighbourhoods of chunks that were removed while dirty).
@@ -137,11 +138,10 @@ void launch_mesh_count(chisel_hip_map *m) {
     int *d_totals = mesh_totals(m);
     ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
     const dim3 grid(2048);
-    int *bases = B.counts + 2 * (size_t)B.capacity;
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.counts, bases, d_totals, B.tris, B.tri_capacity); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.info, d_totals, B.tris, B.tri_capacity); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.info, d_totals, B.tris, B.tri_capacity); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.info, d_totals, B.tris, B.tri_capacity); break;
     }
 }
 
@@ -194,9 +194,24 @@ int recompute_meshes(chisel_hip_map *m) {
     HIP_TRY(hipStreamWaitEvent(m->copy_stream, m->mesh_counted, 0));
     HIP_TRY(hipMemcpyAsync(m->mesh_totals_host, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
     HIP_TRY(hipMemcpyAsync(m->mesh_totals_host + 4, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
+    // the per-job records of (typically all of) the jobs ride along: the bookkeeping at the next recompute is then host work only
+    HIP_TRY(hipMemcpyAsync(m->mesh_info_host, B.info, (size_t)std::min(MESH_INFO_PREFETCH, B.capacity) * sizeof(JobInfo), hipMemcpyDeviceToHost,
+                           m->copy_stream));
     m->pending_meshes.unchecked = true;
     m->pending_meshes.active = false;
     m->pending_meshes.arena = arena_id;
+    // a buffer for the NEXT recompute, allocated now that the device is busy (arenas stay referenced for long, the pool is
+    // usually empty, and an allocation in front of the next recompute would sit on its critical path)
+    {
+        const size_t want = std::max<size_t>(2 * m->mesh_need_hint, (size_t)1 << 22);
+        bool have = false;
+        for (const auto &b : m->arena_pool) have = have || (b.second >= want && b.second <= 4 * want + (1u << 20));
+        if (!have) {
+            float *spare = nullptr;
+            const size_t cap = want + want / 4 + 1024;
+            if (hipMalloc(&spare, cap * sizeof(float)) == hipSuccess) m->arena_pool.emplace_back(spare, cap);
+        }
+    }
     return CHISEL_HIP_OK;
 }
 
@@ -233,6 +248,7 @@ int check_mesh_totals(chisel_hip_map *m) {
         HIP_TRY(hipStreamSynchronize(m->stream));
         if (totals[MT_OVERFLOW]) return fail(CHISEL_HIP_ERR_HIP, "mesh triangle list overflow after growing it");
         redo = true;
+        HIP_TRY(hipMemcpy(m->mesh_info_host, B.info, (size_t)std::min(MESH_INFO_PREFETCH, B.capacity) * sizeof(JobInfo), hipMemcpyDeviceToHost));
     }
     const int n = totals[MT_JOBS];
     if ((size_t)totals[MT_TRIS] > 0x7fffffffull / 9) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^31 / 9 mesh triangles in one recompute");
@@ -280,21 +296,20 @@ int resolve_pending_meshes(chisel_hip_map *m) {
     m->pending_meshes.active = false;
     MeshBuffers &B = m->mesh_buf;
     const int n = m->pending_meshes.n, arena_id = m->pending_meshes.arena;
-    std::vector<int> counts((size_t)n * 2), bases((size_t)n * 2);
-    std::vector<MeshJob> jobs(n);
-    HIP_TRY(hipMemcpyAsync(counts.data(), B.counts, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
-    HIP_TRY(hipMemcpyAsync(bases.data(), B.counts + 2 * (size_t)B.capacity, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
-    HIP_TRY(hipMemcpyAsync(jobs.data(), B.jobs, (size_t)n * sizeof(MeshJob), hipMemcpyDeviceToHost, m->copy_stream));
-    HIP_TRY(hipStreamSynchronize(m->copy_stream));
-    if (g_host_timer.on) {
-        int with_tris = 0;
-        for (int j = 0; j < n; j++) with_tris += counts[2 * j] != 0;
-        fprintf(stderr, "chisel_hip mesh recompute: %d jobs, %d with triangles\n", n, with_tris);
+    // the records of the first MESH_INFO_PREFETCH jobs are on the host already (pinned copy queued with the recompute)
+    std::vector<JobInfo> tail;
+    if (n > MESH_INFO_PREFETCH) {
+        tail.resize((size_t)n - MESH_INFO_PREFETCH);
+        HIP_TRY(hipMemcpyAsync(tail.data(), B.info + MESH_INFO_PREFETCH, tail.size() * sizeof(JobInfo), hipMemcpyDeviceToHost, m->copy_stream));
+        HIP_TRY(hipStreamSynchronize(m->copy_stream));
     }
+    int with_tris = 0;
     for (int j = 0; j < n; j++) {
-        if (jobs[j].nb[NB_SELF] < 0) continue;  // RecomputeMesh: "if (!HasChunk(chunkID)) return" (ChunkManager.cpp:93-96)
-        const uint64_t key = pack_id(jobs[j].x, jobs[j].y, jobs[j].z);
-        const size_t cv = (size_t)counts[2 * j], cg = (size_t)counts[2 * j + 1];
+        const JobInfo &ji = j < MESH_INFO_PREFETCH ? m->mesh_info_host[j] : tail[(size_t)j - MESH_INFO_PREFETCH];
+        if (!ji.present) continue;  // RecomputeMesh: "if (!HasChunk(chunkID)) return" (ChunkManager.cpp:93-96)
+        const uint64_t key = pack_id(ji.x, ji.y, ji.z);
+        const size_t cv = (size_t)ji.n_vertices, cg = (size_t)ji.n_grids;
+        with_tris += cv != 0;
         auto it = m->meshes.find(key);
         // the reference regenerates an existing Mesh object in place (it may become empty) and inserts a new one
         // only when it has grids (ChunkManager.cpp:101-127)
@@ -306,13 +321,14 @@ int resolve_pending_meshes(chisel_hip_map *m) {
         release_mesh_ref(m, ref);
         if (cv + cg) {
             ref.arena = arena_id;
-            ref.v_off = 3 * (size_t)bases[2 * j];  // first vertex of the job in the arena
+            ref.v_off = 3 * (size_t)ji.tri_base;  // first vertex of the job in the arena
             ref.n_v = cv;
-            ref.g_off = (size_t)bases[2 * j + 1];  // first grid entry
+            ref.g_off = (size_t)ji.grid_base;     // first grid entry
             ref.n_g = cg;
             m->arenas[arena_id].live++;
         }
     }
+    if (g_host_timer.on) fprintf(stderr, "chisel_hip mesh recompute: %d jobs, %d with triangles\n", n, with_tris);
     if (arena_id >= 0 && m->arenas[arena_id].live == 0) free_arena(m, m->arenas[arena_id]);
     return CHISEL_HIP_OK;
 }

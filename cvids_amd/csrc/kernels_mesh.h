@@ -379,6 +379,15 @@ __device__ inline void block_scan2(int a, int b, int &oa, int &ob, int &ta, int 
 constexpr int MESH_BLOCK = MESH_BLOCK_THREADS;
 constexpr int MESH_TRI_BLOCK = 256;  // per-triangle kernel
 
+// What the host needs to know about a job after a recompute (one 32-byte record, fetched in one copy)
+struct JobInfo {
+    int x, y, z;       // chunk id
+    int present;       // the chunk is resident (RecomputeMesh returns at once otherwise, ChunkManager.cpp:93-96)
+    int n_vertices, n_grids;
+    int tri_base;      // first triangle of the job in the batch's numbering (its vertices start at 3 * tri_base)
+    int grid_base;     // first grid entry
+};
+
 // One triangle of the batch: which job, which cube (rank in the reference's traversal order), which case, which of the
 // cube's triangles; gidx = position of the cube among the job's occupied cubes (its entry in Mesh::grids).
 struct TriRec {
@@ -389,12 +398,12 @@ struct TriRec {
 
 // Per chunk (one workgroup): stage the corners, count (case table popcount) and scan the cubes in the reference's
 // traversal order, reserve the chunk's range of the batch's triangle / grid numbering with one atomic each and list its
-// triangles.  counts[2j], counts[2j+1] = vertices / grids of job j; bases[2j], bases[2j+1] = its first triangle / grid
-// in the batch (the chunks' ranges follow one another in completion order; within a chunk the order is the reference's).
+// triangles.  info[j] = what the host keeps of job j: sizes and its first triangle / grid in the batch (the chunks' ranges
+// follow one another in completion order; within a chunk the order is the reference's).
 // totals[0..1] = running totals (the atomics), totals[2] = set when the triangle list is too small (the host retries).
 template <int N>
 __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
-                                                                 int *counts, int *bases, int *totals, TriRec *tris, int tri_capacity) {
+                                                                 JobInfo *info, int *totals, TriRec *tris, int tri_capacity) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nb[27];
     __shared__ int s_base[2];
@@ -446,10 +455,14 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     if (threadIdx.x == 0) {
         const int tb = tv ? atomicAdd(&totals[0], tv / 3) : 0;
         const int gb = tg ? atomicAdd(&totals[1], tg) : 0;
-        counts[2 * j] = tv;
-        counts[2 * j + 1] = tg;
-        bases[2 * j] = tb;
-        bases[2 * j + 1] = gb;
+        JobInfo ji;
+        ji.x = jx; ji.y = jy; ji.z = jz;
+        ji.present = present ? 1 : 0;
+        ji.n_vertices = tv;
+        ji.n_grids = tg;
+        ji.tri_base = tb;
+        ji.grid_base = gb;
+        info[j] = ji;
         s_base[0] = tb;
         if (tb + tv / 3 > tri_capacity) totals[2] = 1;
     }
@@ -502,7 +515,7 @@ template <int N>
 // vertices | normals | colours | grids -- was picked before they were known.  A batch that does not fit its arena
 // writes nothing (the host, which reads the same totals, then runs the kernel again on a larger one).
 __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
-                                                                    const int *__restrict__ bases, const TriRec *__restrict__ tris,
+                                                                    const JobInfo *__restrict__ info, const TriRec *__restrict__ tris,
                                                                     const int *__restrict__ totals, float *arena, size_t arena_floats) {
     const int n_tris = totals[0];
     const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[1] * 3;
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
     const f3v coords = add3(mk3((float)x * P.res + P.half_res, (float)y * P.res + P.half_res, (float)z * P.res + P.half_res), origin);
     if (t == 0) {
-        const size_t g = (size_t)bases[2 * rec.job + 1] + rec.gidx;
+        const size_t g = (size_t)info[rec.job].grid_base + rec.gidx;
         grids[3 * g] = coords.x;
         grids[3 * g + 1] = coords.y;
         grids[3 * g + 2] = coords.z;
@@ -588,7 +601,8 @@ __global__ void query_sdf_kernel(MapView M, MeshParams P, float x, float y, floa
 struct MeshBuffers {
     MeshJob *jobs = nullptr;
     int *ids = nullptr;
-    int *counts = nullptr;   // [2 * capacity] counts, then [2 * capacity] bases, then [4] totals (triangles, grids, overflow)
+    JobInfo *info = nullptr; // [capacity] per-job results of a recompute
+    int *totals = nullptr;   // [8]: triangles, grids, triangle-list overflow flag, jobs
     TriRec *tris = nullptr;  // triangle list of one recompute
     int tri_capacity = 0;
     int capacity = 0;        // jobs
@@ -598,7 +612,8 @@ struct MeshBuffers {
 inline void free_mesh_buffers(MeshBuffers &b) {
     if (b.jobs) (void)hipFree(b.jobs);
     if (b.ids) (void)hipFree(b.ids);
-    if (b.counts) (void)hipFree(b.counts);
+    if (b.info) (void)hipFree(b.info);
+    if (b.totals) (void)hipFree(b.totals);
     if (b.tris) (void)hipFree(b.tris);
     if (b.flags) (void)hipFree(b.flags);
     if (b.query) (void)hipFree(b.query);
