@@ -246,10 +246,22 @@ int drain_profile(chisel_hip_map *m) {
     return CHISEL_HIP_OK;
 }
 
+// Wait for the stream by polling: the wake-up of a blocking wait costs more than the kernels being waited for.
+hipError_t wait_stream_spinning(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(st);
+    }
+}
+
+// Waits for everything queued on the map's stream (a caller that waits after every frame pays this per frame: the flag
+// lands in pinned memory and the wait polls) and reports a chunk that could not be allocated.
 int check_device_error(chisel_hip_map *m) {
-    int flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpyAsync(m->mesh_totals_host + 7, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(wait_stream_spinning(m->stream));
+    const int flag = m->mesh_totals_host[7];
     if (flag != 0)
         return fail(CHISEL_HIP_ERR_POOL_FULL, flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
                                                         : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");

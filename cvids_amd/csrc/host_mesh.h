@@ -145,16 +145,6 @@ void launch_mesh_count(chisel_hip_map *m) {
     }
 }
 
-// Wait for the stream by polling: the wake-up of a blocking wait costs more than the kernels being waited for.
-hipError_t wait_stream_spinning(hipStream_t st) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        const hipError_t e = hipStreamQuery(st);
-        if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(st);
-    }
-}
-
 // meshes of the chunks whose ids sit in mesh_buf.ids (device; their number too).  Everything is queued at once -- job
 // table, count kernel, triangle kernel into an arena sized from the previous recompute, dirty-flag reset -- and the host
 // then reads the totals behind the count kernel on its own stream: the device never waits for the host.  Only a batch
