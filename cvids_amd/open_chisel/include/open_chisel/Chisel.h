@@ -23,6 +23,7 @@
 #include "camera/PinholeCamera.h"
 #include "geometry/Geometry.h"
 #include "mesh/Mesh.h"
+#include "pointcloud/PointCloud.h"
 #include "truncation/Truncator.h"
 #include "weighting/Weighter.h"
 
@@ -297,6 +298,11 @@ class Chisel {  // Chisel.h:38-230
         c.cy = colorCamera.GetIntrinsics().GetCy();
         hip_check(chisel_hip_integrate_depth_color(map, &f, &c));
         hip_check(chisel_hip_synchronize(map));
+    }
+    // Chisel.cpp:107-157 (fusion_mode = PointCloud; CVIDS launches DepthImage mode, sample.launch:21).  Declared so that
+    // chisel_ros compiles unchanged (ChiselServer.cpp:523); the ray-cast fusion itself is not built on the MI355X path.
+    void IntegratePointCloud(const ProjectionIntegrator &, const PointCloud &, const Transform &, float /*truncation*/, float /*maxDist*/) {
+        throw std::runtime_error("chisel-hip: point-cloud fusion mode is not built (run chisel_ros with fusion_mode=DepthImage)");
     }
     void UpdateMeshes() { hip_check(chisel_hip_update_meshes(map, 0)); }  // Chisel.cpp:50-59 (every 10th call recomputes)
     void GarbageCollect(const ChunkIDList &chunks) {  // Chisel.cpp:61-67

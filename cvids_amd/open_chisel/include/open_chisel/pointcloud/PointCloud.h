@@ -1,0 +1,34 @@
+// open_chisel/pointcloud/PointCloud.h -- facade counterpart of the reference's point container
+// (open_chisel/include/open_chisel/pointcloud/PointCloud.h:32-75): chisel_ros fills one from sensor_msgs::PointCloud2
+// (ChiselServer.cpp:441-451) whichever fusion mode runs, so the type must exist for the caller to compile.
+// Point-cloud FUSION (Chisel::IntegratePointCloud) is not part of the MI355X path: see Chisel.h.
+#pragma once
+#include "../geometry/Geometry.h"
+
+namespace chisel {
+
+class PointCloud {
+   public:
+    bool HasColor() const { return !colors.empty() && colors.size() == points.size(); }
+    const Vec3List &GetPoints() const { return points; }
+    Vec3List &GetMutablePoints() { return points; }
+    const Vec3List &GetColors() const { return colors; }
+    Vec3List &GetMutableColors() { return colors; }
+    void AddPoint(const Vec3 &p) { points.push_back(p); }
+    void AddColor(const Vec3 &c) { colors.push_back(c); }
+    void AddPointAndColor(const Vec3 &p, const Vec3 &c) {
+        points.push_back(p);
+        colors.push_back(c);
+    }
+    void Clear() {
+        points.clear();
+        colors.clear();
+    }
+
+   private:
+    Vec3List points, colors;
+};
+typedef std::shared_ptr<PointCloud> PointCloudPtr;
+typedef std::shared_ptr<const PointCloud> PointCloudConstPtr;
+
+}  // namespace chisel
