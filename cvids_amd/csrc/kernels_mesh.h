@@ -504,9 +504,9 @@ __device__ inline int corner_ox(int i) { return ((i + 1) >> 1) & 1; }
 __device__ inline int corner_oy(int i) { return (i >> 1) & 1; }
 __device__ inline int corner_oz(int i) { return i >> 2; }
 
-// One thread per triangle of the batch (the cubes that carry triangles are few and unevenly spread over the chunks, so a
-// per-chunk loop leaves most lanes idle): MeshCube (MarchingCubes.h:73-106) for that triangle -- vertices pushed in the
-// order t+2, t+1, t, face normal -- then the second half of RecomputeMesh for its three vertices:
+// One thread per vertex of the batch's triangles (the cubes that carry triangles are few and unevenly spread over the
+// chunks, so a per-chunk loop leaves most lanes idle): MeshCube (MarchingCubes.h:73-106) for its triangle -- vertices
+// pushed in the order t+2, t+1, t, face normal -- then the second half of RecomputeMesh for the thread's own vertex:
 // ComputeNormalsFromGradients (ChunkManager.cpp:609-626: the face normal stays when a lookup fails) and ColorizeMesh
 // (:628-639), which read the map, not the mesh.  Triangle i owns vertices 3i .. 3i+2 of the arena; the first triangle of
 // a cube also writes the cube's grid entry.
@@ -522,7 +522,10 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     if (nv3 * (P.use_color ? 3 : 2) + ng3 > arena_floats) return;
     float *vertices = arena, *normals = arena + nv3, *colors = P.use_color ? arena + 2 * nv3 : nullptr;
     float *grids = arena + nv3 * (P.use_color ? 3 : 2);
-    for (int i = blockIdx.x * MESH_TRI_BLOCK + threadIdx.x; i < n_tris; i += gridDim.x * MESH_TRI_BLOCK) {
+    // one thread per VERTEX: all three vertices of its triangle (the face normal needs them: three cheap interpolations),
+    // then the costly part -- seven voxel lookups for the gradient, the colour lookups -- for its own vertex only
+    for (int vi = blockIdx.x * MESH_TRI_BLOCK + threadIdx.x; vi < 3 * n_tris; vi += gridDim.x * MESH_TRI_BLOCK) {
+    const int i = vi / 3, mine = vi - 3 * i;
     const TriRec rec = tris[i];
     const MeshJob &job = jobs[rec.job];  // stays in memory (L1 / L2): its neighbour table is indexed per lane
     const int *nb = job.nb;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     const f3v origin = mk3((float)(N * jx) * P.res, (float)(N * jy) * P.res, (float)(N * jz) * P.res);  // Chunk.cpp:43
     // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
     const f3v coords = add3(mk3((float)x * P.res + P.half_res, (float)y * P.res + P.half_res, (float)z * P.res + P.half_res), origin);
-    if (t == 0) {
+    if (t == 0 && mine == 0) {
         const size_t g = (size_t)info[rec.job].grid_base + rec.gidx;
         grids[3 * g] = coords.x;
         grids[3 * g + 1] = coords.y;
@@ -553,30 +556,28 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         p[a] = interpolate_vertex(c0, c1, s0, s1);
     }
     const f3v fn = normalized3(cross3v(sub3(p[1], p[0]), sub3(p[2], p[0])));  // :95-101
-    float *vo = vertices + 9 * (size_t)i;
-    float *no = normals + 9 * (size_t)i;
-    float *co = colors ? colors + 9 * (size_t)i : nullptr;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        vo[3 * a] = p[a].x;
-        vo[3 * a + 1] = p[a].y;
-        vo[3 * a + 2] = p[a].z;
-        f3v nrm = fn;
-        double dist;
-        f3v grad;
-        if (get_sdf_and_gradient<N>(M, P, p[a], jx, jy, jz, nb, dist, grad)) {
-            const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
-            if ((double)mag > 1e-12) nrm = scl3(grad, 1.0f / mag);
-        }
-        no[3 * a] = nrm.x;
-        no[3 * a + 1] = nrm.y;
-        no[3 * a + 2] = nrm.z;
-        if (co) {
-            const f3v col = interpolate_color<N>(M, P, p[a], jx, jy, jz, nb);
-            co[3 * a] = col.x;
-            co[3 * a + 1] = col.y;
-            co[3 * a + 2] = col.z;
-        }
+    const f3v pv = mine == 0 ? p[0] : (mine == 1 ? p[1] : p[2]);
+    float *vo = vertices + 3 * (size_t)vi;
+    float *no = normals + 3 * (size_t)vi;
+    vo[0] = pv.x;
+    vo[1] = pv.y;
+    vo[2] = pv.z;
+    f3v nrm = fn;
+    double dist;
+    f3v grad;
+    if (get_sdf_and_gradient<N>(M, P, pv, jx, jy, jz, nb, dist, grad)) {
+        const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
+        if ((double)mag > 1e-12) nrm = scl3(grad, 1.0f / mag);
+    }
+    no[0] = nrm.x;
+    no[1] = nrm.y;
+    no[2] = nrm.z;
+    if (colors) {
+        const f3v col = interpolate_color<N>(M, P, pv, jx, jy, jz, nb);
+        float *co = colors + 3 * (size_t)vi;
+        co[0] = col.x;
+        co[1] = col.y;
+        co[2] = col.z;
     }
     }
 }
