@@ -385,6 +385,37 @@ def test_checkpoint_and_resume(oracle_mod, tmp_path):
         ch.Chisel((16, 16, 16), 0.05, True).LoadMap(path)  # another chunk size
 
 
+def test_caller_owned_stream(oracle_mod):
+    """chisel_hip_set_stream: the map's kernels run on the caller's stream, behind the kernels that produce the frames there
+    (no event, no host wait between producer and integration); switching back to the map's own stream afterwards"""
+    import torch
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+    frames = make_frames("sphere_room", 6, 64, 48, agents=2, nan_fraction=0.02)  # 12 frames
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+    dev = torch.device("cuda:0")
+    src = [torch.from_numpy(np.stack([frames[lo + j][0] for j in range(4)])).to(dev) for lo in range(0, 12, 4)]
+    c_dev = torch.from_numpy(color).to(dev)
+    buf = torch.zeros((4, 48, 64), dtype=torch.float32, device=dev)
+    user = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    gm.set_stream(user.cuda_stream)
+    for b in range(2):
+        with torch.cuda.stream(user):
+            torch.cuda._sleep(10_000_000)          # the producer is slow; stream order alone must protect the buffer
+            buf.copy_(src[b], non_blocking=True)
+        part = frames[4 * b:4 * b + 4]
+        gm.IntegrateBatch(integ, [(buf[j], p, cam) for j, (_, p) in enumerate(part)], [(c_dev, p, cam) for _, p in part])
+    gm.set_stream(0)                               # back to the map's own stream (waits for the queued work)
+    part = frames[8:12]
+    gm.IntegrateBatch(integ, [(src[2][j], p, cam) for j, (_, p) in enumerate(part)], [(c_dev, p, cam) for _, p in part])
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
 def test_event_ordered_device_frames(oracle_mod):
     """chisel_hip_wait_event / chisel_hip_record_event: device frames produced late on another stream (as an RCCL
     all-gather would) and one frame buffer reused for every batch, ordered with events only -- no host wait anywhere."""
