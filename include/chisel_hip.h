@@ -15,10 +15,12 @@
  *     Eigen::Affine3f the reference passes; optical frame: z forward, x right, y down).
  *   - chunk ids are int[3] (chisel::ChunkID = Eigen::Vector3i); voxel i of a chunk is
  *     (z*N + y)*N + x (Chunk.h:81-84).
- *   - integrate calls are asynchronous on the map's HIP stream; every query / download
+ *   - integrate calls are asynchronous on the map's HIP stream(s); every query / download
  *     synchronises first, so the observable behaviour is the reference's synchronous one.
- *   - image pointers may be host or device memory (`on_device`); device images must stay valid
- *     until the map's stream has consumed them (chisel_hip_synchronize).
+ *   - image pointers may be host or device memory (`on_device`); device images must be complete
+ *     when the call is made (or ordered with chisel_hip_set_stream / chisel_hip_wait_event) and stay
+ *     valid until the map has consumed them (chisel_hip_synchronize / chisel_hip_record_event).
+ *   - a map is driven from one thread at a time, as the reference is (chisel_ros: one ros::spin thread).
  */
 #ifndef CHISEL_HIP_H_
 #define CHISEL_HIP_H_
@@ -147,7 +149,8 @@ int chisel_hip_integrate_depth(chisel_hip_map *map, const chisel_hip_depth_frame
 /* Chisel::IntegrateDepthScanColor<float,uint8_t> Chisel.h:114-213 -> IntegrateColor ProjectionIntegrator.h:101-183 */
 int chisel_hip_integrate_depth_color(chisel_hip_map *map, const chisel_hip_depth_frame *frame,
                                      const chisel_hip_color_frame *color);
-/* n frames in order (frame k+1 sees frame k's result, as n successive calls would); colors may be NULL */
+/* n frames in order (frame k+1 sees frame k's result, as n successive calls would); colors may be NULL.  Consecutive
+ * frames of one image size share launch sets of up to 16 frames: the voxels of a chunk stay in registers across them. */
 int chisel_hip_integrate_batch(chisel_hip_map *map, int n, const chisel_hip_depth_frame *frames,
                                const chisel_hip_color_frame *colors);
 /* Chisel::GarbageCollect(const ChunkIDList&) Chisel.cpp:61-67 / ChunkManager::RemoveChunk(ChunkID) ChunkManager.h:99-108 */
