@@ -599,3 +599,15 @@ def test_depth_conditioning(shape):
     assert np.array_equal(want[~np.isnan(want)].view(np.uint32), got[~np.isnan(got)].view(np.uint32))
     assert K == pd.rescale_intrinsics(*K0, shape[1], shape[0], 640, 480)
     assert np.isnan(got).mean() > 0.05  # the range mask does something on this input
+
+
+def test_rccl_exchange_world_size_one():
+    """the N > 1 bench's frame exchange over backend "nccl" (= RCCL) on its own stream with event ordering, run with one
+    rank on this GPU in a child process (tools/nccl_world1_check.py): same map as direct integration"""
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_world1_check.py")], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "nccl world-1 check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
