@@ -351,9 +351,11 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         chisel_hip_map::BatchSet *prev = (m->batch_seq || m->force_uncertain) ? &m->sets[(m->batch_seq + 1u) & 1u] : nullptr;
         const int *prev_overflow = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : (prev ? prev->cand_count + COUNT_OVERFLOW : nullptr);
         const dim3 rgrid((total + 255) / 256);
+        const bool direct = IP.n_frames == 1;  // one frame: nothing to order
         hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
-                           prev ? prev->pending : nullptr, prev_overflow, bs.pending);
-        hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items);
+                           prev ? prev->pending : nullptr, prev_overflow, bs.pending, direct ? bs.items : nullptr);
+        if (!direct)
+            hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items);
     }
     HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     g_host_timer.lap(4);

@@ -491,9 +491,11 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
 // cost class of a work item: 0 = touched by (nearly) all of the batch's frames ... 7 = by one or two
 __device__ inline int cost_class(unsigned frame_mask) { return (KMAX - __popc(frame_mask)) >> 1; }
 
+// items != nullptr: single-frame launch sets -- every work item is touched by exactly one frame, there is nothing to order,
+// so the survivors go straight into the work-list (one returning atomic per wave) and order_kernel is not launched.
 __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
                                                        int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
-                                                       const int *__restrict__ prev_overflow, uint64_t *my_pending) {
+                                                       const int *__restrict__ prev_overflow, uint64_t *my_pending, WorkItem *items) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + threadIdx.x;
     int n = counts_in[COUNT_CANDS];
@@ -534,11 +536,26 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
                 resident |= in;
             }
         }
-        cands[c].slot = slot;
-        cands[c].frame_mask = mask;
+        wi.slot = slot;
+        wi.frame_mask = mask;
+        if (!items) {
+            cands[c].slot = slot;
+            cands[c].frame_mask = mask;
+        }
         if (mask) cls = cost_class(mask);
         if (mask && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(&counts[COUNT_OVERFLOW], 1);
+        if (items) {  // (a wave takes this branch as a whole only in its active lanes; the ballot below counts them)
+            const unsigned long long bal = __ballot(mask != 0u);
+            if (mask) {
+                int base = 0;
+                const int leader = (int)__builtin_ctzll(bal);
+                if (lane == leader) base = atomicAdd(&counts[COUNT_ITEMS], __popcll(bal));
+                base = __shfl(base, leader);
+                items[base + __popcll(bal & ((1ull << lane) - 1ull))] = wi;
+            }
+        }
     }
+    if (items) return;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const unsigned long long bal = __ballot(cls == k);
