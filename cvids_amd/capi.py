@@ -9,8 +9,8 @@ _LIB = os.path.join(_HERE, os.environ.get("CHISEL_HIP_LIB", "libchisel_hip.so"))
 
 NUM_COUNTERS = 9
 COUNTER_NAMES = ["sdf", "col", "col_sat", "probe", "carved", "work_chunks", "new_chunks", "updated_chunks", "frames"]
-NUM_KERNELS = 5
-KERNEL_NAMES = ["pyramid", "cull", "integrate", "mesh", "resolve"]
+NUM_KERNELS = 6
+KERNEL_NAMES = ["pyramid", "cull", "integrate", "mesh", "resolve", "cloud"]
 TRUNC_CONSTANT, TRUNC_INVERSE, TRUNC_QUADRATIC = 0, 1, 2
 STATUS = {0: "OK", 1: "ERR_INVALID", 2: "ERR_HIP", 3: "ERR_POOL_FULL", 4: "ERR_NOT_FOUND", 5: "ERR_UNSUPPORTED", 6: "ERR_IO"}
 
@@ -44,12 +44,17 @@ class ColorFrame(C.Structure):
                 ("cx", C.c_float), ("cy", C.c_float)]
 
 
+class PointCloud(C.Structure):
+    _fields_ = [("points", C.c_void_p), ("colors", C.c_void_p), ("n_points", C.c_int64), ("on_device", C.c_int),
+                ("pose", C.c_float * 12), ("truncation", C.c_float), ("max_dist", C.c_float)]
+
+
 # every symbol include/chisel_hip.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
     "chisel_hip_abi_version", "chisel_hip_last_error", "chisel_hip_device_count", "chisel_hip_create",
     "chisel_hip_destroy", "chisel_hip_reset", "chisel_hip_set_integrator", "chisel_hip_set_stream",
     "chisel_hip_synchronize", "chisel_hip_wait_event", "chisel_hip_record_event", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
-    "chisel_hip_integrate_batch", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
+    "chisel_hip_integrate_batch", "chisel_hip_integrate_pointcloud", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
     "chisel_hip_list_chunks", "chisel_hip_has_chunk", "chisel_hip_download_chunk", "chisel_hip_upload_chunk",
     "chisel_hip_meshes_to_update", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
     "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
@@ -105,6 +110,7 @@ def load_library():
     L.chisel_hip_integrate_depth.argtypes = [vp, C.POINTER(DepthFrame)]
     L.chisel_hip_integrate_depth_color.argtypes = [vp, C.POINTER(DepthFrame), C.POINTER(ColorFrame)]
     L.chisel_hip_integrate_batch.argtypes = [vp, C.c_int, C.POINTER(DepthFrame), C.POINTER(ColorFrame)]
+    L.chisel_hip_integrate_pointcloud.argtypes = [vp, C.POINTER(PointCloud)]
     L.chisel_hip_garbage_collect.argtypes = [vp, i32p, C.c_int]
     L.chisel_hip_update_meshes.argtypes = [vp, C.c_int]
     L.chisel_hip_num_chunks.argtypes = [vp, i64p]
@@ -137,6 +143,7 @@ def load_library():
     # entry points added after ABI version 1 was first built (an older library simply lacks them: A/B runs of tools/)
     for name, types in (("chisel_hip_wait_event", [vp, vp]), ("chisel_hip_record_event", [vp, vp]),
                         ("chisel_hip_kat_color_fresh", [C.POINTER(C.c_uint)]),
+                        ("chisel_hip_kat_raycast", [f32p, C.c_int, i32p, i32p, i32p, C.c_int, i32p]),
                         ("chisel_hip_kat_reciprocal", [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)])):
         try:
             getattr(L, name).argtypes = types

@@ -116,6 +116,27 @@ def color_frame(color, pose, camera):
     return f, keep
 
 
+class PointCloud:
+    """chisel::PointCloud (pointcloud/PointCloud.h:33-82): points in the sensor frame and, optionally, one colour per point."""
+
+    def __init__(self, points=None, colors=None):
+        self.points = np.zeros((0, 3), np.float32) if points is None else points
+        self.colors = colors
+
+    def HasColor(self):
+        return self.colors is not None and len(self.colors) > 0
+
+    def GetPoints(self):
+        return self.points
+
+    def GetColors(self):
+        return self.colors
+
+    def Clear(self):
+        self.points = np.zeros((0, 3), np.float32)
+        self.colors = None
+
+
 class Chisel:
     """chisel::Chisel (Chisel.h:38-230) + the ChunkManager queries its callers use."""
 
@@ -181,6 +202,22 @@ class Chisel:
                 keep.append(k)
         check(self.L.chisel_hip_integrate_batch(self.h, n, fa, ca))
         self._keep = keep
+
+    def IntegratePointCloud(self, integrator, cloud, extrinsic, truncation, max_dist):
+        """Chisel::IntegratePointCloud (Chisel.h:57, Chisel.cpp:107-157).  `cloud`: a PointCloud, or a tuple (points, colors or None);
+        points (n, 3) in the sensor frame, colours (n, 3) in [0, 1]; numpy arrays or torch CUDA tensors."""
+        self._use(integrator)
+        points, colors = (cloud.points, cloud.colors) if isinstance(cloud, PointCloud) else cloud
+        pa, pdev, k1 = _image_pointer(points, np.float32)
+        n = int(np.prod(tuple(points.shape))) // 3
+        ca, cdev, k2 = (None, pdev, None)
+        if colors is not None and int(np.prod(tuple(colors.shape))) > 0:  # PointCloud::HasColor
+            ca, cdev, k2 = _image_pointer(colors, np.float32)
+            assert int(np.prod(tuple(colors.shape))) // 3 == n, "one colour per point"
+        assert cdev == pdev, "points and colours must live in the same memory space"
+        pc = capi.PointCloud(pa, ca, n, pdev, _pose12(extrinsic), float(truncation), float(max_dist))
+        check(self.L.chisel_hip_integrate_pointcloud(self.h, C.byref(pc)))
+        self._keep = [k1, k2]
 
     def GarbageCollect(self, chunk_ids):
         ids = np.ascontiguousarray(np.asarray(chunk_ids, dtype=np.int32).reshape(-1, 3))

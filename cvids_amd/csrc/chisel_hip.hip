@@ -23,6 +23,7 @@
 #include "kernels_integrate.h"
 #include "kernels_map.h"
 #include "kernels_mesh.h"
+#include "kernels_cloud.h"
 
 using namespace chisel_hip;
 
@@ -165,12 +166,17 @@ struct chisel_hip_map {
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
     MeshBuffers mesh_buf{};
+    struct CloudBuffers {                                              // point-cloud fusion mode (host_cloud.h), allocated on first use
+        float *points = nullptr, *colors = nullptr;                    // staging of host clouds
+        int64_t capacity = 0;                                          // points
+        CloudView view{};
+    } cloud;
     // profiling
     bool profiling = false;
     std::vector<ProfEvent> prof_live;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0, 0};
-    int64_t prof_launches[CHISEL_HIP_NUM_KERNELS] = {0, 0, 0, 0, 0};
+    double prof_ms[CHISEL_HIP_NUM_KERNELS] = {};
+    int64_t prof_launches[CHISEL_HIP_NUM_KERNELS] = {};
 };
 
 namespace {
@@ -262,6 +268,12 @@ int check_device_error(chisel_hip_map *m) {
     HIP_TRY(hipMemcpyAsync(m->mesh_totals_host + 7, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(wait_stream_spinning(m->stream));
     const int flag = m->mesh_totals_host[7];
+    if (flag == CLOUD_ERR_CAPACITY || flag == CLOUD_ERR_RANGE) {  // a property of one cloud, not of the map: reported once
+        HIP_TRY(hipMemsetAsync(m->view.error_flag, 0, sizeof(int), m->stream));
+        return fail(CHISEL_HIP_ERR_UNSUPPORTED, flag == CLOUD_ERR_CAPACITY
+                                                    ? "point cloud: too many chunks or (chunk, point) pairs for one call"
+                                                    : "point cloud: a ray leaves the supported chunk-id range or is too long");
+    }
     if (flag != 0)
         return fail(CHISEL_HIP_ERR_POOL_FULL, flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
                                                         : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
@@ -646,6 +658,7 @@ void expand27(const std::vector<int> &ids, std::unordered_set<uint64_t, IdHash> 
 }  // namespace
 
 #include "host_mesh.h"
+#include "host_cloud.h"
 
 extern "C" {
 
@@ -801,6 +814,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     clear_meshes(m);
     release_arena_pool(m);
     free_mesh_buffers(m->mesh_buf);
+    free_cloud_buffers(m->cloud);
     for (const ProfEvent &p : m->prof_live) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
@@ -1280,6 +1294,20 @@ int chisel_hip_kat_dist(const float *ops, int n, float *out) {
     hipLaunchKernelGGL(kat_dist_kernel, dim3(1), dim3(64), 0, 0, d_in, n, d_out);
     HIP_TRY(hipMemcpy(out, d_out, n * 2 * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(d_in); (void)hipFree(d_out);
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_kat_raycast(const float *rays, int n, const int lo[3], const int hi[3], int *cells, int cap, int *count) {
+    float *d_in = nullptr;
+    int *d_cells = nullptr, *d_count = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)n * 6 * sizeof(float)));
+    HIP_TRY(hipMalloc(&d_cells, (size_t)n * cap * 3 * sizeof(int)));
+    HIP_TRY(hipMalloc(&d_count, (size_t)n * sizeof(int)));
+    HIP_TRY(hipMemcpy(d_in, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kat_raycast_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, d_in, n, make_int3(lo[0], lo[1], lo[2]),
+                       make_int3(hi[0], hi[1], hi[2]), d_cells, cap, d_count);
+    HIP_TRY(hipMemcpy(cells, d_cells, (size_t)n * cap * 3 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(count, d_count, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_cells); (void)hipFree(d_count);
     return CHISEL_HIP_OK;
 }
 int chisel_hip_kat_color(const uint8_t *ops, int n, uint8_t *out) {

@@ -91,3 +91,23 @@ def stream(scene, n_frames, W=640, H=480, agents=1, noise=False, nan_fraction=0.
         for a in range(agents):
             pose = trajectory_pose(k, a)
             yield render_depth(scene, pose, intr, W, H, noise, nan_fraction, frame_index=k * agents + a), pose
+
+
+def depth_to_cloud(depth, intr, scale=1.0, colors=False):
+    """Back-project the valid pixels of a depth image to sensor-frame points (n, 3) float32, in row-major pixel order
+    (the shape of cloud the reference's ROSPointCloudToChisel hands to Chisel::IntegratePointCloud);
+    `scale` shrinks the scene (the reference skips points deeper than 2 m, or 5 m with colours).  With `colors`,
+    also returns (n, 3) float32 colours in [0, 1] taken from render_color()'s pattern."""
+    fx, fy, cx, cy = intr
+    H, W = depth.shape
+    z = (depth.astype(np.float64) * scale)
+    u = (np.arange(W, dtype=np.float64) + 0.5 - cx) / fx
+    v = (np.arange(H, dtype=np.float64) + 0.5 - cy) / fy
+    pts = np.stack([u[None, :] * z, v[:, None] * z, z], axis=-1).reshape(-1, 3)
+    ok = np.isfinite(pts).all(-1)
+    pts32 = np.ascontiguousarray(pts[ok].astype(np.float32))
+    if not colors:
+        return pts32
+    bgr = render_color(W, H, 3).reshape(-1, 3)[ok]
+    rgb = np.ascontiguousarray((bgr[:, ::-1].astype(np.float32) / np.float32(255.0)).astype(np.float32))
+    return pts32, rgb

@@ -95,6 +95,17 @@ typedef struct {
     float fx, fy, cx, cy;
 } chisel_hip_color_frame;
 
+/* PointCloud (pointcloud/PointCloud.h:33-82) + the arguments of Chisel::IntegratePointCloud (Chisel.h:57) */
+typedef struct {
+    const float *points;     /* n_points x (x, y, z) in the sensor frame (PointCloud::GetPoints)              */
+    const float *colors;     /* n_points x (r, g, b) in [0, 1] (PointCloud::GetColors), or NULL = no colours  */
+    int64_t n_points;
+    int on_device;           /* both arrays in device memory (complete, or ordered by stream / event)         */
+    float pose[12];          /* extrinsic: sensor -> world, row-major 3x4                                      */
+    float truncation;        /* segment half-length of the chunk enumeration (ChiselServer.cpp:523: 0.1)      */
+    float max_dist;          /* points farther from the sensor list no chunk (ChiselServer.cpp:523: far plane) */
+} chisel_hip_pointcloud;
+
 /* per-map accumulated voxel counters; index into the array of chisel_hip_get_counters */
 enum {
     CHISEL_HIP_CNT_SDF = 0,       /* DistVoxel::Integrate executions                                    */
@@ -116,7 +127,8 @@ enum {
     CHISEL_HIP_KERNEL_INTEGRATE = 2, /* projective SDF/weight/colour integration (+ allocation)          */
     CHISEL_HIP_KERNEL_MESH = 3,      /* marching cubes (count + emit)                                   */
     CHISEL_HIP_KERNEL_RESOLVE = 4,   /* hash lookup of the candidates -> work-list                       */
-    CHISEL_HIP_NUM_KERNELS = 5
+    CHISEL_HIP_KERNEL_CLOUD = 5,     /* point-cloud fusion mode (all of its kernels)                     */
+    CHISEL_HIP_NUM_KERNELS = 6
 };
 
 /* ---- life cycle ------------------------------------------------------------------------------------- */
@@ -149,6 +161,14 @@ int chisel_hip_integrate_depth(chisel_hip_map *map, const chisel_hip_depth_frame
 /* Chisel::IntegrateDepthScanColor<float,uint8_t> Chisel.h:114-213 -> IntegrateColor ProjectionIntegrator.h:101-183 */
 int chisel_hip_integrate_depth_color(chisel_hip_map *map, const chisel_hip_depth_frame *frame,
                                      const chisel_hip_color_frame *color);
+/* Chisel::IntegratePointCloud Chisel.cpp:107-157 -> ChunkManager::GetChunkIDsIntersecting(cloud) ChunkManager.cpp:214-257,
+ * ProjectionIntegrator::Integrate(cloud) ProjectionIntegrator.cpp:38-173, Raycast geometry/Raycast.cpp:35-128.  Every voxel
+ * receives the updates of the rays that meet it in cloud order, as the reference's loop applies them.  Counters afterwards:
+ * SDF, COL, PROBE (= ray cells inside listed chunks), CARVED, WORK_CHUNKS (= listed chunks), NEW_CHUNKS, UPDATED_CHUNKS.
+ * Rays whose cell walk the reference would never finish (an axis steps past its end cell) stop at that point; rays with a
+ * coordinate that is not finite meet no voxel.  CHISEL_HIP_ERR_UNSUPPORTED (at the next call that waits): more than 65536
+ * chunks or 16 (chunk, point) pairs per point in one cloud, chunk ids beyond +-2^20. */
+int chisel_hip_integrate_pointcloud(chisel_hip_map *map, const chisel_hip_pointcloud *cloud);
 /* n frames in order (frame k+1 sees frame k's result, as n successive calls would); colors may be NULL.  Consecutive
  * frames of one image size share launch sets of up to 16 frames: the voxels of a chunk stay in registers across them. */
 int chisel_hip_integrate_batch(chisel_hip_map *map, int n, const chisel_hip_depth_frame *frames,

@@ -48,6 +48,10 @@ def lib():
     L.oc_integrate_depth_color.argtypes = ([vp, f32p, C.c_int, C.c_int, f32p] + [C.c_float] * 6 +
                                            [u8p, C.c_int, C.c_int, C.c_int, f32p] + [C.c_float] * 4)
     L.oc_get_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.oc_integrate_pointcloud.argtypes = [vp, f32p, C.c_int, f32p, f32p, C.c_float, C.c_float]
+    L.oc_raycast.restype = C.c_int
+    L.oc_raycast.argtypes = [f32p, f32p, i32p, i32p, i32p, C.c_int]
+    L.oc_invert_pose.argtypes = [f32p, f32p]
     L.oc_get_phase_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.oc_num_chunks.argtypes = [vp]
     L.oc_list_chunks.argtypes = [vp, i32p]
@@ -138,6 +142,17 @@ class OracleMap:
         cfx, cfy, ccx, ccy = intr if color_intr is None else color_intr
         self.L.oc_integrate_depth_color(self.h, dp, W, H, pp, fx, fy, cx, cy, near, far, cp, CW, CH, ch, qp,
                                         cfx, cfy, ccx, ccy)
+
+    def integrate_pointcloud(self, points, pose, colors=None, truncation=0.1, max_dist=5.0):
+        """Chisel::IntegratePointCloud (Chisel.cpp:107-157): points (n, 3) in the sensor frame, colours (n, 3) in [0, 1]."""
+        pts, ptp = _f32(np.asarray(points).reshape(-1, 3))
+        p, pp = _f32(np.asarray(pose)[:3, :4])
+        if colors is not None:
+            col, colp = _f32(np.asarray(colors).reshape(-1, 3))
+            assert col.shape == pts.shape
+        else:
+            colp = None
+        self.L.oc_integrate_pointcloud(self.h, ptp, pts.shape[0], colp, pp, float(truncation), float(max_dist))
 
     def counters(self):
         out = (C.c_uint64 * len(COUNTER_NAMES))()
@@ -288,3 +303,25 @@ def triangle_table():
     for i in range(256):
         lib().oc_triangle_table_row(i, t[i].ctypes.data_as(C.POINTER(C.c_int)))
     return t
+
+
+def raycast(start, end, lo, hi, capacity=4096):
+    """geometry/Raycast.cpp:35-128: the cells of [lo, hi) a ray from `start` to `end` (cell units) passes through, in order."""
+    L = lib()
+    a, ap = _f32(start)
+    b, bp = _f32(end)
+    lo = np.ascontiguousarray(lo, np.int32)
+    hi = np.ascontiguousarray(hi, np.int32)
+    out = np.zeros((capacity, 3), np.int32)
+    i32p = C.POINTER(C.c_int)
+    n = L.oc_raycast(ap, bp, lo.ctypes.data_as(i32p), hi.ctypes.data_as(i32p), out.ctypes.data_as(i32p), capacity)
+    assert n <= capacity
+    return out[:n]
+
+
+def invert_pose(pose):
+    """Eigen::Affine3f::inverse() of a 3x4 / 4x4 pose, as a 3x4 float32 array."""
+    p, pp = _f32(np.asarray(pose)[:3, :4])
+    out = np.zeros((3, 4), np.float32)
+    lib().oc_invert_pose(pp, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out

@@ -467,6 +467,10 @@ const int kCubeOff[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1
 // ---------------------------------------------------------------------------------------------
 // the map: ChunkManager + ProjectionIntegrator + Chisel in one object
 // ---------------------------------------------------------------------------------------------
+struct CloudTally {
+    uint64_t hits = 0, sdf = 0, carved = 0;
+};
+
 struct oc_map {
     // ChunkManager state (ChunkManager.h:205-211)
     ChunkMap chunks;
@@ -640,6 +644,221 @@ struct oc_map {
         }
         return updated;
     }
+
+    // -----------------------------------------------------------------------------------------
+    // point-cloud fusion mode.  ref: Chisel.cpp:107-157, ProjectionIntegrator.cpp:52-173,
+    // ChunkManager.cpp:214-257, geometry/Raycast.cpp:4-128.  fp32 operation order of Eigen 3.3:
+    //   Transform * Vec3 (Transform.h, rhs vector of size Dim): the point is extended to (x, y, z, 1) and multiplied
+    //   by the 4x4 matrix column by column: ((m_i0 x + m_i1 y) + m_i2 z) + m_i3   (etor_product_packet_impl)
+    //   Transform::inverse() (Affine): linear().inverse() by cofactors (InverseImpl.h compute_inverse<3>),
+    //   translation = -(inverse_linear * t) with rows summed a0 + (a1 + a2).
+    // -----------------------------------------------------------------------------------------
+    struct Affine {  // row-major 3x4
+        float m[3][4];
+        V3 mul(const V3 &p) const {
+            return V3(((m[0][0] * p.x + m[0][1] * p.y) + m[0][2] * p.z) + m[0][3],
+                      ((m[1][0] * p.x + m[1][1] * p.y) + m[1][2] * p.z) + m[1][3],
+                      ((m[2][0] * p.x + m[2][1] * p.y) + m[2][2] * p.z) + m[2][3]);
+        }
+        V3 translation() const { return V3(m[0][3], m[1][3], m[2][3]); }
+        static Affine fromPose(const Pose &q) {
+            Affine a;
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) a.m[r][c] = q.R[r][c];
+                a.m[r][3] = q.t(r);
+            }
+            return a;
+        }
+        float cof(int i, int j) const {  // cofactor_3x3<i, j>
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+        }
+        Affine inverse() const {
+            Affine r;
+            const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+            const float det = sum3(c0 * m[0][0], c1 * m[1][0], c2 * m[2][0]);
+            const float invdet = 1.0f / det;
+            r.m[0][0] = c0 * invdet;
+            r.m[0][1] = c1 * invdet;
+            r.m[0][2] = c2 * invdet;
+            r.m[1][0] = cof(0, 1) * invdet;
+            r.m[1][1] = cof(1, 1) * invdet;
+            r.m[1][2] = cof(2, 1) * invdet;
+            r.m[2][0] = cof(0, 2) * invdet;
+            r.m[2][1] = cof(1, 2) * invdet;
+            r.m[2][2] = cof(2, 2) * invdet;
+            for (int i = 0; i < 3; i++) r.m[i][3] = -sum3(r.m[i][0] * m[0][3], r.m[i][1] * m[1][3], r.m[i][2] * m[2][3]);
+            return r;
+        }
+    };
+
+    // Raycast.cpp:4-33.  The unqualified fmod() binds to ::fmod(double, double) (only <cmath> is in scope), so the
+    // inner sum is taken in double and the result narrowed on return.
+    static float rc_signum(int x) { return x == 0 ? 0 : x < 0 ? -1 : 1; }
+    static float rc_mod(float value, float modulus) { return ::fmod(::fmod(value, modulus) + modulus, modulus); }
+    static float rc_intbound(float s, int ds) {
+        if (ds == 0) return std::numeric_limits<float>::infinity();  // (float)DBL_MAX on x86-64
+        if (ds < 0) return rc_intbound(-s, -ds);
+        s = rc_mod(s, 1.0f);
+        return (1 - s) / ds;
+    }
+    // floor() of a coordinate to int as x86-64 does it (cvttss2si: INT_MIN for NaN and out-of-range values)
+    static int rc_floor_to_int(float v) {
+        const float f = std::floor(v);
+        if (!(f >= -2147483648.0f && f < 2147483648.0f)) return std::numeric_limits<int>::min();
+        return (int)f;
+    }
+    // Raycast.cpp:35-128.  Deviation: the reference loops until the end cell is reached, and when rounding lets an axis step
+    // past its end coordinate it never returns.  Here the walk stops at the moment an axis would step past its end cell
+    // (a walk that terminates in the reference never does that, so terminating walks are unchanged).
+    // Rays with a coordinate that is not finite or beyond the int range are dropped (on x86-64 such coordinates all become
+    // INT_MIN; with every coordinate affected -- the only way they arise from a point and a truncation -- the reference returns
+    // at "stepX == 0 && ..." too).
+    static void Raycast(const V3 &start, const V3 &end, const I3 &mn, const I3 &mx, std::vector<I3> *output) {
+        const float c6[6] = {start.x, start.y, start.z, end.x, end.y, end.z};
+        for (float c : c6)
+            if (!(std::floor(c) >= -2147483648.0f && std::floor(c) < 2147483648.0f)) return;
+        int x = rc_floor_to_int(start.x), y = rc_floor_to_int(start.y), z = rc_floor_to_int(start.z);
+        const int endX = rc_floor_to_int(end.x), endY = rc_floor_to_int(end.y), endZ = rc_floor_to_int(end.z);
+        const int dx = (int)((unsigned)endX - (unsigned)x), dy = (int)((unsigned)endY - (unsigned)y), dz = (int)((unsigned)endZ - (unsigned)z);
+        const int stepX = (int)rc_signum(dx), stepY = (int)rc_signum(dy), stepZ = (int)rc_signum(dz);
+        float tMaxX = rc_intbound(start.x, dx), tMaxY = rc_intbound(start.y, dy), tMaxZ = rc_intbound(start.z, dz);
+        const float tDeltaX = ((float)stepX) / dx, tDeltaY = ((float)stepY) / dy, tDeltaZ = ((float)stepZ) / dz;
+        if (stepX == 0 && stepY == 0 && stepZ == 0) return;
+        while (true) {
+            if (x >= mn.x && x < mx.x && y >= mn.y && y < mx.y && z >= mn.z && z < mx.z) output->push_back(I3(x, y, z));
+            if (x == endX && y == endY && z == endZ) break;
+            if (tMaxX < tMaxY) {
+                if (tMaxX < tMaxZ) { if (x == endX) break; x += stepX; tMaxX += tDeltaX; }
+                else { if (z == endZ) break; z += stepZ; tMaxZ += tDeltaZ; }
+            } else {
+                if (tMaxY < tMaxZ) { if (y == endY) break; y += stepY; tMaxY += tDeltaY; }
+                else { if (z == endZ) break; z += stepZ; tMaxZ += tDeltaZ; }
+            }
+        }
+    }
+
+    // ChunkManager::GetChunkIDsIntersecting(cloud, ...).  ref: ChunkManager.cpp:214-257
+    void GetChunkIDsIntersectingCloud(const V3 *points, size_t n, const Affine &cameraTransform, float truncation, float maxDist,
+                                      std::vector<I3> *chunkList) const {
+        chunkList->clear();
+        const float roundX = 1.0f / (chunkSize.x * voxelResolutionMeters);
+        const float roundY = 1.0f / (chunkSize.y * voxelResolutionMeters);
+        const float roundZ = 1.0f / (chunkSize.z * voxelResolutionMeters);
+        ChunkSet map;
+        const int imax = std::numeric_limits<int>::max();
+        const I3 minVal(-imax, -imax, -imax), maxVal(imax, imax, imax);
+        std::vector<I3> intersectingChunks;
+        for (size_t p = 0; p < n; p++) {
+            V3 end = cameraTransform.mul(points[p]);
+            V3 start = cameraTransform.translation();
+            float len = norm(end - start);
+            if (len > maxDist) continue;
+            V3 dir = normalized(end - start);
+            V3 truncStart = end - dir * truncation;
+            V3 truncEnd = end + dir * truncation;
+            V3 startInt(truncStart.x * roundX, truncStart.y * roundY, truncStart.z * roundZ);
+            V3 endInt(truncEnd.x * roundX, truncEnd.y * roundY, truncEnd.z * roundZ);
+            intersectingChunks.clear();
+            Raycast(startInt, endInt, minVal, maxVal, &intersectingChunks);
+            for (const I3 &id : intersectingChunks) map[id] = true;
+        }
+        for (const auto &it : map) chunkList->push_back(it.first);
+    }
+
+    // ProjectionIntegrator::IntegratePointCloud / IntegrateColorPointCloud.  ref: ProjectionIntegrator.cpp:52-112 / :114-173
+    // (depth limit 2 m without colours, 5 m with; the colour index only advances on points that pass the limit, :68-70)
+    bool IntegrateCloudChunk(const V3 *points, size_t n, const V3 *colors, const Affine &cameraPose, const Affine &inversePose,
+                             Chunk *chunk, CloudTally *tally) const {
+        const bool withColor = colors != nullptr && !chunk->colors.empty();  // ProjectionIntegrator.cpp:42
+        const float depthLimit = withColor ? 5.0f : 2.f;
+        const float roundX = 1.0f / chunk->voxelResolutionMeters;
+        const float roundY = 1.0f / chunk->voxelResolutionMeters;
+        const float roundZ = 1.0f / chunk->voxelResolutionMeters;
+        std::vector<I3> raycastVoxels;
+        const I3 chunkMin(0, 0, 0);
+        const I3 chunkMax = chunk->numVoxels;
+        bool updated = false;
+        size_t i = 0;
+        const V3 startCamera = cameraPose.translation();
+        for (size_t p = 0; p < n; p++) {
+            const V3 &point = points[p];
+            V3 worldPoint = cameraPose.mul(point);
+            float depth = point.z;
+            if (depth > depthLimit) continue;
+            V3 dir = normalized(worldPoint - startCamera);
+            float truncation = truncator.GetTruncationDistance(depth);
+            V3 start = worldPoint - dir * truncation - chunk->origin;
+            V3 end = worldPoint + dir * truncation - chunk->origin;
+            start.x *= roundX; start.y *= roundY; start.z *= roundZ;
+            end.x *= roundX; end.y *= roundY; end.z *= roundZ;
+            raycastVoxels.clear();
+            Raycast(start, end, chunkMin, chunkMax, &raycastVoxels);
+            for (const I3 &voxelCoords : raycastVoxels) {
+                int id = chunk->GetVoxelID(voxelCoords.x, voxelCoords.y, voxelCoords.z);
+                DistVoxel &distVoxel = chunk->voxels.at(id);
+                V3 centroid = centroids[id] + chunk->origin;
+                float u = depth - (inversePose.mul(centroid) - startCamera).z;
+                float weight = ConstantWeight(weighterWeight, u, truncation);
+                tally->hits++;
+                if (fabs(u) < truncation) {
+                    distVoxel.Integrate(u, weight);
+                    if (withColor) {
+                        const V3 &color = colors[i];
+                        chunk->colors.at(id).Integrate((uint8_t)(int)(color.x * 255.0f), (uint8_t)(int)(color.y * 255.0f),
+                                                       (uint8_t)(int)(color.z * 255.0f), 1);
+                    }
+                    updated = true;
+                    tally->sdf++;
+                } else if (enableVoxelCarving && u > truncation + carvingDist) {
+                    if (distVoxel.weight > 0) {
+                        distVoxel.Integrate(1.0e-5, 5.0f);
+                        updated = true;
+                        tally->carved++;
+                    }
+                }
+            }
+            i++;
+        }
+        return updated;
+    }
+
+    // Chisel::IntegratePointCloud.  ref: Chisel.cpp:107-157 (serial here; chunks are independent)
+    void IntegratePointCloudScan(const V3 *points, size_t n, const V3 *colors, const Pose &extrinsic, float truncation, float maxDist) {
+        memset(counters, 0, sizeof(counters));
+        const Affine pose = Affine::fromPose(extrinsic);
+        const Affine inversePose = pose.inverse();
+        std::vector<I3> chunksIntersecting;
+        GetChunkIDsIntersectingCloud(points, n, pose, truncation, maxDist, &chunksIntersecting);
+        counters[OC_CNT_CANDIDATES] = chunksIntersecting.size();
+        if (chunksIntersecting.size() == 0) return;
+        std::vector<I3> garbageChunks;
+        CloudTally tally;
+        for (const I3 &chunkID : chunksIntersecting) {
+            bool chunkNew = false;
+            if (!HasChunk(chunkID)) {
+                chunkNew = true;
+                CreateChunk(chunkID);
+                counters[OC_CNT_CREATED]++;
+            }
+            ChunkPtr chunk = GetChunk(chunkID);
+            bool needsUpdate = IntegrateCloudChunk(points, n, colors, pose, inversePose, chunk.get(), &tally);
+            if (needsUpdate) {
+                MarkNeighbours(chunkID);
+                counters[OC_CNT_UPDATED_CHUNKS]++;
+            } else if (chunkNew) {
+                garbageChunks.push_back(chunkID);
+            }
+        }
+        for (const I3 &id : garbageChunks) {
+            chunks.erase(id);
+            counters[OC_CNT_COLLECTED]++;
+        }
+        counters[OC_CNT_SDF] = tally.sdf;
+        counters[OC_CNT_CARVED] = tally.carved;
+        counters[OC_CNT_VISITED] = tally.hits;
+    }
+
 
     void MarkNeighbours(const I3 &chunkID) {  // Chisel.h:87-98 / :175-189
         for (int dx = -1; dx <= 1; dx++)
@@ -1120,6 +1339,30 @@ void oc_integrate_depth_color(oc_map *m, const float *depth, int W, int H, const
     m->IntegrateDepthScanColor(d, Pose::fromRowMajor3x4(pose), makeCamera(fx, fy, cx, cy, W, H, near_plane, far_plane), c,
                                Pose::fromRowMajor3x4(color_pose),
                                makeCamera(cfx, cfy, ccx, ccy, CW, CH, near_plane, far_plane));
+}
+void oc_integrate_pointcloud(oc_map *m, const float *points_xyz, int n_points, const float *colors_rgb, const float *pose,
+                             float truncation, float max_dist) {
+    std::vector<V3> pts((size_t)n_points), cols;
+    for (int i = 0; i < n_points; i++) pts[i] = V3(points_xyz[3 * i], points_xyz[3 * i + 1], points_xyz[3 * i + 2]);
+    if (colors_rgb) {
+        cols.resize((size_t)n_points);
+        for (int i = 0; i < n_points; i++) cols[i] = V3(colors_rgb[3 * i], colors_rgb[3 * i + 1], colors_rgb[3 * i + 2]);
+    }
+    m->IntegratePointCloudScan(pts.data(), pts.size(), colors_rgb ? cols.data() : nullptr, Pose::fromRowMajor3x4(pose), truncation,
+                               max_dist);
+}
+int oc_raycast(const float *start3, const float *end3, const int *min3, const int *max3, int *cells_xyz, int capacity) {
+    std::vector<I3> out;
+    oc_map::Raycast(V3(start3[0], start3[1], start3[2]), V3(end3[0], end3[1], end3[2]), I3(min3[0], min3[1], min3[2]),
+                    I3(max3[0], max3[1], max3[2]), &out);
+    for (size_t i = 0; i < out.size() && (int)i < capacity; i++) {
+        cells_xyz[3 * i] = out[i].x; cells_xyz[3 * i + 1] = out[i].y; cells_xyz[3 * i + 2] = out[i].z;
+    }
+    return (int)out.size();
+}
+void oc_invert_pose(const float *pose, float *inverse) {
+    oc_map::Affine inv = oc_map::Affine::fromPose(Pose::fromRowMajor3x4(pose)).inverse();
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) inverse[4 * r + c] = inv.m[r][c];
 }
 void oc_get_counters(const oc_map *m, uint64_t *out) { memcpy(out, m->counters, sizeof(m->counters)); }
 void oc_get_phase_ms(const oc_map *m, double *out4) { memcpy(out4, m->phaseMs, sizeof(m->phaseMs)); }

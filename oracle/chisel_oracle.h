@@ -64,6 +64,15 @@ void oc_integrate_depth_color(oc_map *m, const float *depth, int W, int H, const
                               const uint8_t *color, int CW, int CH, int channels, const float *color_pose,
                               float cfx, float cfy, float ccx, float ccy);
 
+/* point-cloud fusion mode (Chisel.cpp:107-157): points in the sensor frame (xyz per point), optional colours in [0, 1]
+ * (rgb per point).  Counters afterwards: SDF, CARVED, VISITED (= ray cells inside listed chunks), CANDIDATES (= listed chunks),
+ * CREATED, COLLECTED, UPDATED_CHUNKS. */
+void oc_integrate_pointcloud(oc_map *m, const float *points_xyz, int n_points, const float *colors_rgb /* or NULL */,
+                             const float *pose /* row-major 3x4 */, float truncation, float max_dist);
+/* geometry/Raycast.cpp:35-128; returns the number of cells, writes at most `capacity` of them */
+int oc_raycast(const float *start3, const float *end3, const int *min3, const int *max3, int *cells_xyz, int capacity);
+/* Eigen::Affine3f::inverse() of a row-major 3x4 pose */
+void oc_invert_pose(const float *pose, float *inverse);
 void oc_get_counters(const oc_map *m, uint64_t *out /* OC_NUM_COUNTERS, last frame */);
 void oc_get_phase_ms(const oc_map *m, double *out4 /* intersect, allocation, integration, garbage */);
 

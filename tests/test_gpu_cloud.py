@@ -1,0 +1,223 @@
+"""GPU parity of the point-cloud fusion mode (Chisel::IntegratePointCloud, Chisel.cpp:107-157) against the CPU oracle.
+
+Every voxel must receive the updates of the rays that meet it in cloud order (running averages in fp32), so the fields are
+compared bit for bit, like the depth-image path.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cvids_amd import synth
+from tests.common import compare_fields
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(oracle_mod, N, res, color, trunc=("inverse", 2.0), weight=1.0, carving=True, carving_dist=0.05, max_chunks=4096):
+    from cvids_amd import chisel as ch
+    kinds = {"constant": (0, ch.ConstantTruncator), "inverse": (1, ch.InverseTruncator), "quadratic": (2, ch.QuadraticTruncator)}
+    k, cls = kinds[trunc[0]]
+    om = oracle_mod.OracleMap(N, res, color)
+    om.set_integrator(k, trunc[1], weight, carving, carving_dist)
+    gm = ch.Chisel((N, N, N), res, color, max_chunks=max_chunks)
+    integ = ch.ProjectionIntegrator(cls(trunc[1]), ch.ConstantWeighter(weight), carving_dist, carving)
+    return om, gm, integ
+
+
+def _cloud(scene, k, W, H, scale, colors, t=(0.0, 0.0, 0.0), nan_fraction=0.0):
+    intr = synth.intrinsics(W, H)
+    pose = synth.pose_yaw(3.0 * k, (0.02 * k + t[0], t[1], t[2]))
+    depth = synth.render_depth(scene, synth.pose_yaw(3.0 * k, (0.02 * k, 0, 0)), intr, W, H, nan_fraction=nan_fraction, frame_index=k)
+    out = synth.depth_to_cloud(depth, intr, scale, colors=colors)
+    pts, col = out if colors else (out, None)
+    return pts, col, pose
+
+
+def _step(om, gm, integ, pts, col, pose, truncation=0.1, max_dist=5.0, what=""):
+    om.integrate_pointcloud(pts, pose, col, truncation, max_dist)
+    gm.IntegratePointCloud(integ, (pts, col), pose, truncation, max_dist)
+    oc, gc = om.counters(), gm.counters(reset=True)
+    pairs = [("sdf", "sdf"), ("carved", "carved"), ("visited", "probe"), ("candidates", "work_chunks"), ("updated_chunks", "updated_chunks")]
+    for a, b in pairs:
+        assert oc[a] == gc[b], "%s counter %s: oracle %d gpu %d" % (what, a, oc[a], gc[b])
+    assert oc["created"] - oc["collected"] == gc["new_chunks"], what
+    assert om.num_chunks() == gm.NumChunks(), what
+    compare_fields(om.fields(), gm.fields(), om.V, om.use_color, atol=0.0, what=what)
+    assert sorted(map(tuple, om.meshes_to_update().tolist())) == sorted(map(tuple, gm.GetMeshesToUpdate().tolist())), what
+    return oc
+
+
+def test_device_raycast_matches_the_oracle(hip_lib, oracle_mod):
+    """RayWalk (kernels_cloud.h) against oracle.raycast (Raycast.cpp:35-128): random, axis-aligned, integer-valued, negative rays."""
+    rng = np.random.default_rng(7)
+    n = 4000
+    a = rng.uniform(-6, 22, (n, 3)).astype(np.float32)
+    b = (a + rng.uniform(-24, 24, (n, 3))).astype(np.float32)
+    b[:400, 0] = a[:400, 0]                       # idle axis
+    b[400:600, :2] = a[400:600, :2]               # two idle axes
+    a[600:900] = np.round(a[600:900])             # starts on cell corners
+    b[900:1200] = np.round(b[900:1200])
+    a[1200:1300] = np.round(a[1200:1300]) - np.float32(1e-7)
+    b[1300:1400] = a[1300:1400]                   # start == end
+    a[1400:1500] *= np.float32(1e-3)              # inside one cell
+    b[1400:1500] = a[1400:1500] + np.float32(1e-4)
+    a[1500, 0] = np.nan
+    b[1501, 2] = np.inf
+    rays = np.ascontiguousarray(np.concatenate([a, b], axis=1))
+    lo = np.array([0, 0, 0], np.int32)
+    hi = np.array([16, 16, 16], np.int32)
+    cap = 64
+    cells = np.zeros((n, cap, 3), np.int32)
+    count = np.zeros(n, np.int32)
+    i32p = C.POINTER(C.c_int)
+    rc = hip_lib.chisel_hip_kat_raycast(rays.ctypes.data_as(C.POINTER(C.c_float)), n, lo.ctypes.data_as(i32p), hi.ctypes.data_as(i32p),
+                                        cells.ctypes.data_as(i32p), cap, count.ctypes.data_as(i32p))
+    assert rc == 0
+    nonempty = 0
+    for i in range(n):
+        ref = oracle_mod.raycast(a[i], b[i], lo, hi)
+        assert count[i] == len(ref), "ray %d: %d cells, oracle %d" % (i, count[i], len(ref))
+        assert np.array_equal(cells[i, :count[i]], ref), "ray %d" % i
+        nonempty += len(ref) > 0
+    assert nonempty > 500
+    # chunk-level walk: unbounded box
+    lo2 = np.array([-(2 ** 31 - 1)] * 3, np.int32)
+    hi2 = np.array([2 ** 31 - 1] * 3, np.int32)
+    cap2 = 256
+    cells2 = np.zeros((n, cap2, 3), np.int32)
+    rc = hip_lib.chisel_hip_kat_raycast(rays.ctypes.data_as(C.POINTER(C.c_float)), n, lo2.ctypes.data_as(i32p), hi2.ctypes.data_as(i32p),
+                                        cells2.ctypes.data_as(i32p), cap2, count.ctypes.data_as(i32p))
+    assert rc == 0
+    for i in range(0, n, 7):
+        ref = oracle_mod.raycast(a[i], b[i], lo2, hi2)
+        assert count[i] == len(ref) and np.array_equal(cells2[i, :count[i]], ref), "ray %d (unbounded)" % i
+
+
+@pytest.mark.parametrize("N,res,color,trunc", [
+    (16, 0.02, False, ("inverse", 2.0)),
+    (16, 0.02, True, ("inverse", 2.0)),
+    (8, 0.03, True, ("constant", 0.08)),
+    (32, 0.01, True, ("quadratic", 4.0)),
+    (16, 0.01, True, ("inverse", 1.0)),
+])
+def test_cloud_sequence_matches_the_oracle(hip_lib, oracle_mod, N, res, color, trunc):
+    om, gm, integ = _mk(oracle_mod, N, res, color, trunc)
+    W, H = 80, 60
+    total = 0
+    for k in range(4):
+        pts, col, pose = _cloud("sphere_room", k, W, H, 0.6, color)
+        oc = _step(om, gm, integ, pts, col, pose, what="cloud %d" % k)
+        total += oc["sdf"]
+    assert total > 10000 and om.num_chunks() > 5
+
+
+def test_cloud_carving_and_offset_sensor(hip_lib, oracle_mod):
+    """u = depth - ((inversePose * centroid).z - cameraPose.translation().z) (ProjectionIntegrator.cpp:89): a sensor translated
+    along world z shifts every u, which sends voxels into the carve branch (weight decay by Integrate(1e-5, 5), :100)."""
+    om, gm, integ = _mk(oracle_mod, 16, 0.02, True, ("constant", 0.06), carving_dist=0.01)
+    W, H = 80, 60
+    carved = 0
+    for k, tz in enumerate([0.0, 0.1, 0.1, -0.05, 0.12]):
+        pts, col, pose = _cloud("wall", k, W, H, 0.7, True, t=(0.0, 0.0, tz))
+        oc = _step(om, gm, integ, pts, col, pose, what="cloud %d" % k)
+        carved += oc["carved"]
+    assert carved > 100
+
+
+def test_cloud_depth_limit_shifts_the_colour_index(hip_lib, oracle_mod):
+    """Points deeper than the limit are skipped without advancing the colour index (ProjectionIntegrator.cpp:130-132)."""
+    om, gm, integ = _mk(oracle_mod, 16, 0.03, True, ("inverse", 2.0))
+    W, H = 64, 48
+    intr = synth.intrinsics(W, H)
+    pose = synth.pose_yaw(10.0, (0.1, 0.0, 0.05))
+    depth = synth.render_depth("box_room", pose, intr, W, H)   # depths 4.5 m to 5.5 m after scaling
+    pts, col = synth.depth_to_cloud(depth * 2.0, intr, 1.0, colors=True)
+    assert (pts[:, 2] > 5.0).sum() > 100 and (pts[:, 2] <= 5.0).sum() > 100
+    _step(om, gm, integ, pts, col, pose, max_dist=20.0, what="coloured")
+    # without colours the limit is 2 m (:68-70)
+    om2, gm2, integ2 = _mk(oracle_mod, 16, 0.03, True, ("inverse", 2.0))
+    pts2 = (pts * np.float32(0.4)).astype(np.float32)
+    assert (pts2[:, 2] > 2.0).sum() > 100 and (pts2[:, 2] <= 2.0).sum() > 100
+    _step(om2, gm2, integ2, pts2, None, pose, max_dist=20.0, what="plain")
+    # colours given but a map without colour voxels: plain path (ProjectionIntegrator.cpp:42)
+    om3, gm3, integ3 = _mk(oracle_mod, 16, 0.03, False, ("inverse", 2.0))
+    _step(om3, gm3, integ3, pts2, col, pose, max_dist=20.0, what="no colour voxels")
+
+
+def test_cloud_edge_cases(hip_lib, oracle_mod):
+    om, gm, integ = _mk(oracle_mod, 16, 0.02, True)
+    pose = synth.pose_yaw(5.0, (0.0, 0.1, 0.0))
+    # empty cloud: nothing happens (Chisel.cpp:112-113)
+    _step(om, gm, integ, np.zeros((0, 3), np.float32), None, pose, what="empty")
+    assert gm.NumChunks() == 0
+    # NaN / inf points, points behind the sensor, a point at the sensor, max_dist cutting the list
+    pts, col, _ = _cloud("sphere_room", 0, 64, 48, 0.6, True)
+    pts = pts.copy()
+    pts[5] = np.nan
+    pts[17, 0] = np.inf
+    pts[40, 2] = np.nan
+    pts[100] = 0.0
+    pts[200:220, 2] *= -1.0
+    _step(om, gm, integ, pts, col, pose, max_dist=1.45, what="odd points")
+    # a second cloud over resident chunks, truncation larger than the chunk size
+    pts2, col2, pose2 = _cloud("sphere_room", 2, 64, 48, 0.6, True)
+    _step(om, gm, integ, pts2, col2, pose2, truncation=0.5, what="wide list")
+    # zero truncation parameter: no chunk is listed (start and end of every chunk walk share a cell)
+    n_before = gm.NumChunks()
+    _step(om, gm, integ, pts2, col2, pose2, truncation=0.0, what="nothing listed")
+    assert gm.NumChunks() == n_before
+
+
+def test_cloud_between_depth_frames(hip_lib, oracle_mod):
+    """Clouds and depth frames interleaved on one map: the cloud kernels are ordered against the two-stream depth pipeline."""
+    from tests.common import make_frames, small_camera
+    om, gm, integ = _mk(oracle_mod, 16, 0.03, True, ("inverse", 2.0))
+    W, H = 64, 48
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color_img = synth.render_color(W, H, 3)
+    frames = make_frames("sphere_room", 6, W, H)
+    for i, (depth, pose) in enumerate(frames):
+        d = (depth * np.float32(0.6)).astype(np.float32)
+        om.integrate_depth_color(d, pose, intr, color_img, near=cam.near_plane, far=cam.far_plane)
+        gm.IntegrateDepthScanColor(integ, d, pose, cam, color_img, pose, cam)
+        if i % 2 == 1:
+            pts, col, cpose = _cloud("sphere_room", i, W, H, 0.6, True)
+            om.integrate_pointcloud(pts, cpose, col, 0.1, 5.0)
+            gm.IntegratePointCloud(integ, (pts, col), cpose, 0.1, 5.0)
+    gm.counters(reset=True)
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True, atol=0.0, what="interleaved")
+    assert sorted(map(tuple, om.meshes_to_update().tolist())) == sorted(map(tuple, gm.GetMeshesToUpdate().tolist()))
+    # and the meshes built from the result agree
+    om.update_meshes(True)
+    gm.UpdateMeshes(True)
+    assert sorted(map(tuple, om.mesh_ids().tolist())) == sorted(map(tuple, gm.GetMeshIDs().tolist()))
+
+
+def test_cloud_device_resident_and_full_size(hip_lib, oracle_mod):
+    """640x480 cloud (the shape ChiselServer hands over), device-resident: two maps fed the same clouds agree bit for bit, a host-fed map
+    agrees with them, and a 160x120 sub-sampling of the same scene agrees with the oracle."""
+    import torch
+    from cvids_amd import chisel as ch
+    W, H = 640, 480
+    maps = [ch.Chisel((16, 16, 16), 0.01, True, max_chunks=20000) for _ in range(3)]
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(1.0), ch.ConstantWeighter(1.0), 0.05, True)
+    for k in range(2):
+        pts, col, pose = _cloud("sphere_room", k, W, H, 0.6, True, t=(0.0, 0.0, 0.03 * k))
+        tp, tc = torch.from_numpy(pts).cuda(), torch.from_numpy(col).cuda()
+        maps[0].IntegratePointCloud(integ, ch.PointCloud(tp, tc), pose, 0.1, 5.0)
+        maps[1].IntegratePointCloud(integ, (tp, tc), pose, 0.1, 5.0)
+        maps[2].IntegratePointCloud(integ, (pts, col), pose, 0.1, 5.0)
+    c = [m.counters(reset=True) for m in maps]
+    assert c[0] == c[1] == c[2]
+    assert c[0]["sdf"] > 5_000_000 and c[0]["work_chunks"] > 500
+    f0 = maps[0].fields()
+    compare_fields(f0, maps[1].fields(), 4096, True, atol=0.0, what="device twice")
+    compare_fields(f0, maps[2].fields(), 4096, True, atol=0.0, what="device vs host")
+    # oracle at a size it finishes in seconds
+    om, gm, integ2 = _mk(oracle_mod, 16, 0.01, True, ("inverse", 1.0), max_chunks=8192)
+    for k in range(2):
+        pts, col, pose = _cloud("sphere_room", k, 160, 120, 0.6, True, t=(0.0, 0.0, 0.03 * k))
+        _step(om, gm, integ2, pts, col, pose, what="160x120 cloud %d" % k)
