@@ -299,10 +299,26 @@ class Chisel {  // Chisel.h:38-230
         hip_check(chisel_hip_integrate_depth_color(map, &f, &c));
         hip_check(chisel_hip_synchronize(map));
     }
-    // Chisel.cpp:107-157 (fusion_mode = PointCloud; CVIDS launches DepthImage mode, sample.launch:21).  Declared so that
-    // chisel_ros compiles unchanged (ChiselServer.cpp:523); the ray-cast fusion itself is not built on the MI355X path.
-    void IntegratePointCloud(const ProjectionIntegrator &, const PointCloud &, const Transform &, float /*truncation*/, float /*maxDist*/) {
-        throw std::runtime_error("chisel-hip: point-cloud fusion mode is not built (run chisel_ros with fusion_mode=DepthImage)");
+    // Chisel.cpp:107-157 (fusion_mode = PointCloud, ChiselServer.cpp:523; CVIDS itself launches DepthImage mode, sample.launch:21)
+    void IntegratePointCloud(const ProjectionIntegrator &integrator, const PointCloud &cloud, const Transform &extrinsic, float truncation,
+                             float maxDist) {
+        static_assert(sizeof(Vec3) == 3 * sizeof(float), "Vec3 is three packed floats");
+        const chisel_hip_integrator in = integrator.HipStruct();
+        hip_check(chisel_hip_set_integrator(map, &in));
+        chisel_hip_pointcloud pc;
+        std::memset(&pc, 0, sizeof(pc));
+        pc.n_points = (int64_t)cloud.GetPoints().size();
+        pc.points = pc.n_points ? reinterpret_cast<const float *>(cloud.GetPoints().data()) : nullptr;
+        if (cloud.HasColor()) {
+            // the reference reads colors[i] for the i-th point that passes the depth limit (ProjectionIntegrator.cpp:124): one colour per point
+            if (cloud.GetColors().size() < cloud.GetPoints().size()) throw std::invalid_argument("chisel-hip: PointCloud with fewer colours than points");
+            pc.colors = reinterpret_cast<const float *>(cloud.GetColors().data());
+        }
+        Pose12(extrinsic, pc.pose);
+        pc.truncation = truncation;
+        pc.max_dist = maxDist;
+        hip_check(chisel_hip_integrate_pointcloud(map, &pc));
+        hip_check(chisel_hip_synchronize(map));  // the reference returns with every voxel update visible
     }
     void UpdateMeshes() { hip_check(chisel_hip_update_meshes(map, 0)); }  // Chisel.cpp:50-59 (every 10th call recomputes)
     void GarbageCollect(const ChunkIDList &chunks) {  // Chisel.cpp:61-67

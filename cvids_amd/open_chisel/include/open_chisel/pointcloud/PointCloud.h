@@ -1,7 +1,6 @@
 // open_chisel/pointcloud/PointCloud.h -- facade counterpart of the reference's point container
 // (open_chisel/include/open_chisel/pointcloud/PointCloud.h:32-75): chisel_ros fills one from sensor_msgs::PointCloud2
-// (ChiselServer.cpp:441-451) whichever fusion mode runs, so the type must exist for the caller to compile.
-// Point-cloud FUSION (Chisel::IntegratePointCloud) is not part of the MI355X path: see Chisel.h.
+// (ChiselServer.cpp:441-451) and hands it to Chisel::IntegratePointCloud in PointCloud fusion mode (ChiselServer.cpp:523).
 #pragma once
 #include "../geometry/Geometry.h"
 
@@ -9,7 +8,7 @@ namespace chisel {
 
 class PointCloud {
    public:
-    bool HasColor() const { return !colors.empty() && colors.size() == points.size(); }
+    bool HasColor() const { return !colors.empty(); }
     const Vec3List &GetPoints() const { return points; }
     Vec3List &GetMutablePoints() { return points; }
     const Vec3List &GetColors() const { return colors; }

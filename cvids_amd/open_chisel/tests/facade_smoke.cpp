@@ -1,5 +1,5 @@
 // facade_smoke.cpp -- drives the chisel::* facade the way chisel_ros::ChiselServer does (ChiselServer.cpp:480-516):
-// setup integrator -> IntegrateDepthScanColor per frame -> UpdateMeshes -> queries, and dumps the voxel fields so that
+// setup integrator -> IntegrateDepthScanColor per frame -> IntegratePointCloud -> UpdateMeshes -> queries, and dumps the voxel fields so that
 // tests/test_gpu_facade.py can compare them with the Python host path on the same frames.
 #include <open_chisel/Chisel.h>
 
@@ -37,6 +37,19 @@ int main(int argc, char **argv) {
                 for (int u = 0; u < W; u++) depth->SetDataAt(v, u, 1.5f + 0.1f * k);
             Transform T;  // identity
             map.IntegrateDepthScanColor<float, uint8_t>(integ, depth, T, cam, color, T, cam);
+        }
+        {
+            // PointCloud fusion mode (ChiselServer.cpp:517-524): a coloured wall at 1.2 m seen from a sensor at (0.05, 0, 0.02)
+            PointCloud cloud;
+            for (int v = 0; v < H; v++)
+                for (int u = 0; u < W; u++) {
+                    const float z = 1.2f;
+                    cloud.AddPointAndColor(Vec3((((float)u - 31.5f) / 52.5f) * z, (((float)v - 23.5f) / 52.5f) * z, z),
+                                           Vec3((float)(u % 256) / 255.0f, (float)(v % 256) / 255.0f, (float)((u + v) % 256) / 255.0f));
+                }
+            Transform T;
+            T.translation() = Vec3(0.05f, 0.0f, 0.02f);
+            map.IntegratePointCloud(integ, cloud, T, 0.1f, 5.0f);
         }
         for (int k = 0; k < 10; k++) map.UpdateMeshes();  // the first call recomputes (Chisel.cpp:53)
         const ChunkMap &chunks = map.GetChunkManager().GetChunks();

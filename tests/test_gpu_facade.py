@@ -29,6 +29,18 @@ def test_cpp_facade_matches_oracle(oracle_mod, tmp_path):
     pose = np.eye(4, dtype=np.float32)
     for k in range(3):
         om.integrate_depth_color(np.full((H, W), np.float32(1.5) + np.float32(0.1) * np.float32(k), np.float32), pose, intr, color)
+    # and the coloured cloud the program integrates afterwards (same fp32 expressions)
+    u = np.arange(W, dtype=np.float32)[None, :].repeat(H, 0)
+    v = np.arange(H, dtype=np.float32)[:, None].repeat(W, 1)
+    z = np.float32(1.2)
+    pts = np.stack([((u - np.float32(31.5)) / np.float32(52.5)) * z, ((v - np.float32(23.5)) / np.float32(52.5)) * z,
+                    np.full((H, W), z, np.float32)], axis=-1).reshape(-1, 3).astype(np.float32)
+    ui, vi = u.astype(np.int64), v.astype(np.int64)
+    cols = np.stack([(ui % 256).astype(np.float32) / np.float32(255.0), (vi % 256).astype(np.float32) / np.float32(255.0),
+                     ((ui + vi) % 256).astype(np.float32) / np.float32(255.0)], axis=-1).reshape(-1, 3).astype(np.float32)
+    cpose = np.eye(4, dtype=np.float32)
+    cpose[:3, 3] = [0.05, 0.0, 0.02]
+    om.integrate_pointcloud(pts, cpose, cols, 0.1, 5.0)
     V = N ** 3
     raw = np.fromfile(dump, np.uint8)
     rec = 12 + V * 8 + V * 4
