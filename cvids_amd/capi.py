@@ -143,6 +143,8 @@ def load_library():
     # entry points added after ABI version 1 was first built (an older library simply lacks them: A/B runs of tools/)
     for name, types in (("chisel_hip_wait_event", [vp, vp]), ("chisel_hip_record_event", [vp, vp]),
                         ("chisel_hip_kat_color_fresh", [C.POINTER(C.c_uint)]),
+                        ("chisel_hip_kat_color_any", [C.POINTER(C.c_uint)]),
+                        ("chisel_hip_debug_cloud_stats", [vp, i64p]),
                         ("chisel_hip_kat_raycast", [f32p, C.c_int, i32p, i32p, i32p, C.c_int, i32p]),
                         ("chisel_hip_kat_reciprocal", [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)])):
         try:

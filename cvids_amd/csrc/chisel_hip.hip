@@ -1329,6 +1329,33 @@ int chisel_hip_kat_color_fresh(unsigned *mismatches) {
     (void)hipFree(d);
     return CHISEL_HIP_OK;
 }
+// diagnostics of the last cloud: listed chunks, (unit, point) pairs, rays of the largest unit, units with rays
+int chisel_hip_debug_cloud_stats(chisel_hip_map *m, int64_t out[4]) {
+    if (!m || !m->cloud.view.ctl) return fail(CHISEL_HIP_ERR_INVALID, "no cloud yet");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    int ctl[2] = {0, 0};
+    HIP_TRY(hipMemcpy(ctl, m->cloud.view.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+    const int units = std::min(ctl[0], CLOUD_MAX_LISTED) * CloudUnits(m->N).count;
+    std::vector<int> off((size_t)units + 1);
+    HIP_TRY(hipMemcpy(off.data(), m->cloud.view.offsets, off.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int64_t mx = 0, used = 0;
+    for (int i = 0; i < units; i++) {
+        mx = std::max<int64_t>(mx, off[i + 1] - off[i]);
+        used += off[i + 1] > off[i];
+    }
+    out[0] = ctl[0]; out[1] = ctl[1]; out[2] = mx; out[3] = used;
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_kat_color_any(unsigned *mismatches) {
+    unsigned *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(kat_color_any_kernel, dim3(256 * 256 * 256 / 256), dim3(256), 0, 0, d);
+    HIP_TRY(hipMemcpy(mismatches, d, sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return CHISEL_HIP_OK;
+}
 int chisel_hip_kat_reciprocal(unsigned long long *mismatches, unsigned *example_bits) {
     unsigned long long *d = nullptr;
     unsigned *e = nullptr;

@@ -34,8 +34,9 @@ int ensure_cloud_buffers(chisel_hip_map *m, int64_t n) {
         HIP_TRY(hipMalloc(&C.table_keys, (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&C.table_vals, (size_t)CLOUD_TABLE_SLOTS * sizeof(int)));
         HIP_TRY(hipMalloc(&C.listed, (size_t)CLOUD_MAX_LISTED * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc(&C.offsets, (size_t)(CLOUD_MAX_LISTED + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc(&C.cursors, (size_t)CLOUD_MAX_LISTED * sizeof(int)));
+        const size_t units = (size_t)CLOUD_MAX_LISTED * CloudUnits(m->N).count;
+        HIP_TRY(hipMalloc(&C.offsets, (units + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc(&C.cursors, units * sizeof(int)));
         HIP_TRY(hipMalloc(&C.ctl, 16 * sizeof(int)));
     }
     if (n <= B.capacity) return CHISEL_HIP_OK;
@@ -63,9 +64,9 @@ int ensure_cloud_buffers(chisel_hip_map *m, int64_t n) {
 template <int N>
 void launch_cloud_integrate(chisel_hip_map *m, const CloudParams &P, const CloudView &C) {
     if (m->cfg.use_color)
-        hipLaunchKernelGGL((cloud_integrate_kernel<N, true>), dim3(CLOUD_GRID), dim3(256), 0, m->stream, P, m->view, m->view_dev, C);
+        hipLaunchKernelGGL((cloud_integrate_kernel<N, true>), dim3(CLOUD_GRID), dim3(64 * CloudGeom<N>::WAVES), 0, m->stream, P, m->view, m->view_dev, C);
     else
-        hipLaunchKernelGGL((cloud_integrate_kernel<N, false>), dim3(CLOUD_GRID), dim3(256), 0, m->stream, P, m->view, m->view_dev, C);
+        hipLaunchKernelGGL((cloud_integrate_kernel<N, false>), dim3(CLOUD_GRID), dim3(64 * CloudGeom<N>::WAVES), 0, m->stream, P, m->view, m->view_dev, C);
 }
 
 }  // namespace
@@ -113,23 +114,31 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
     P.depth_limit = P.with_color ? 5.0f : 2.0f;                         // :131 / :69
     P.n_points = n;
     P.N = m->N;
+    // Register axis of cloud_integrate_kernel: the world axis closest to the sensor's y axis (second column of the rotation).
+    // Any choice gives the same voxels; this one spreads a batch of consecutive points of an organised cloud over the lanes.
+    {
+        const float ay[3] = {fabsf(cloud->pose[1]), fabsf(cloud->pose[5]), fabsf(cloud->pose[9])};
+        P.jaxis = ay[0] >= ay[1] ? (ay[0] >= ay[2] ? 0 : 2) : (ay[1] >= ay[2] ? 1 : 2);
+    }
+    if (const char *e = getenv("CHISEL_HIP_CLOUD_AXIS")) P.jaxis = std::max(0, std::min(2, atoi(e)));  // test / tuning hook
 
     ProfScope ps(m, CHISEL_HIP_KERNEL_CLOUD);
     const int tiles = (n + CLOUD_TILE - 1) / CLOUD_TILE;
     HIP_TRY(hipMemsetAsync(C.table_keys, 0xff, (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t), m->stream));
     HIP_TRY(hipMemsetAsync(C.ctl, 0, 16 * sizeof(int), m->stream));
-    HIP_TRY(hipMemsetAsync(C.offsets, 0, (size_t)(CLOUD_MAX_LISTED + 1) * sizeof(int), m->stream));
-    HIP_TRY(hipMemsetAsync(C.cursors, 0, (size_t)CLOUD_MAX_LISTED * sizeof(int), m->stream));
+    const int units_per_chunk = CloudUnits(m->N).count;
+    const size_t units = (size_t)CLOUD_MAX_LISTED * units_per_chunk;
+    HIP_TRY(hipMemsetAsync(C.offsets, 0, (units + 1) * sizeof(int), m->stream));
+    HIP_TRY(hipMemsetAsync(C.cursors, 0, units * sizeof(int), m->stream));
     hipLaunchKernelGGL(cloud_tile_count_kernel, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C);
-    hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, m->stream, C.tile_prefix, (const int *)nullptr, tiles, (int *)nullptr, 0,
+    hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, m->stream, C.tile_prefix, (const int *)nullptr, tiles, 1, (int *)nullptr, 0,
                        m->view.error_flag);
     hipLaunchKernelGGL(cloud_prepare_kernel, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C, m->view);
     hipLaunchKernelGGL(cloud_bin_kernel<false>, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C, m->view);
-    hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, m->stream, C.offsets, (const int *)C.ctl, CLOUD_MAX_LISTED, C.ctl + 1,
-                       C.pairs_capacity, m->view.error_flag);
+    hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, m->stream, C.offsets, (const int *)C.ctl, CLOUD_MAX_LISTED, units_per_chunk,
+                       C.ctl + 1, C.pairs_capacity, m->view.error_flag);
     hipLaunchKernelGGL(cloud_bin_kernel<true>, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C, m->view);
-    const int words = std::min((n + 31) / 32, CLOUD_SORT_WORDS);
-    hipLaunchKernelGGL(cloud_sort_kernel, dim3(CLOUD_GRID), dim3(256), (size_t)words * sizeof(unsigned), m->stream, P, C);
+    hipLaunchKernelGGL(cloud_sort_kernel, dim3(CLOUD_GRID), dim3(256), 0, m->stream, P, C);
     switch (m->N) {
         case 8: launch_cloud_integrate<8>(m, P, C); break;
         case 16: launch_cloud_integrate<16>(m, P, C); break;

@@ -14,13 +14,14 @@
 //                                                      reference's colour index only advances on those, :68-70 / :130-132)
 //   cloud_prepare_kernel    per point: world point, ray direction, the two segment ends (CloudRay), colour bytes; walks the
 //                           chunk grid and enters the chunks met into a per-cloud table (step 1)
-//   cloud_bin_kernel<FILL>  per point: the listed chunks whose box the voxel walk can enter (exact per-axis cell ranges); first
-//                           pass counts per chunk, second pass (after cloud_offsets_kernel) writes the (chunk, point) pairs
-//   cloud_sort_kernel       per chunk: its points into cloud order (LDS bitmap over the point indices)
-//   cloud_integrate_kernel  per chunk: voxel box in LDS; 128 rays walked at a time (one per lane), their cells kept in LDS; then
-//                           the rays are applied one after the other in cloud order, the cells of a ray in parallel, the four
-//                           waves owning disjoint voxel blocks so that they need no barrier between rays (step 2); the chunk
-//                           is created when the first update happens (same outcome as create-then-erase, step 3)
+//   cloud_bin_kernel<FILL>  per point: the units (boxes of 8 x 8 x 16 voxels of listed chunks) the voxel walk can enter (exact
+//                           per-axis cell ranges); first pass counts per unit, second pass (after the prefix sum) writes the
+//                           (unit, point) pairs; counts are aggregated per workgroup in LDS first
+//   cloud_sort_kernel       per unit: its points into cloud order (LDS bitmap over the range of point indices it holds)
+//   cloud_integrate_kernel  per chunk, one wave per unit: the unit's voxels in registers, 64 rays walked at a time (one per lane)
+//                           setting their bit in a per-voxel mask in LDS, then every lane applies the rays of its voxels in bit
+//                           order = cloud order (step 2); the chunk is created when the first update happens (same outcome as
+//                           create-then-erase, step 3)
 #pragma once
 #include "chisel_device.h"
 
@@ -31,8 +32,8 @@ constexpr unsigned CLOUD_TABLE_SLOTS = 1u << 17; // open-addressing table of the
 constexpr int CLOUD_MAX_LISTED = 1 << 16;
 constexpr int CLOUD_PAIRS_PER_POINT = 16;        // capacity of the (chunk, point) list, per point of the cloud
 constexpr int CLOUD_MAX_RANGE = 4096;            // chunk boxes around one ray that are looked at
-constexpr int CLOUD_SORT_WORDS = 15360;          // LDS bitmap of cloud_sort_kernel (60 KB): 491 520 point indices per pass
-constexpr int CLOUD_RAYS = 128;                  // rays walked at a time by one workgroup of cloud_integrate_kernel
+constexpr int CLOUD_SORT_WORDS = 8192;           // LDS bitmap of cloud_sort_kernel (32 KB): 262 144 point indices per pass
+constexpr int CLOUD_MAX_UNITS = 64;              // cubes of 8 x 8 x 8 voxels per chunk (32-voxel chunks)
 constexpr int CLOUD_GRID = 2048;                 // persistent grids of the per-chunk kernels (<= INTEGRATE_MAX_GRID)
 // error_flag values of this path (1, 2: chunk pool / hash, kernels_integrate.h)
 constexpr int CLOUD_ERR_CAPACITY = 3;            // too many listed chunks or (chunk, point) pairs
@@ -55,6 +56,7 @@ struct CloudParams {
     int with_color;          // cloud.HasColor() && chunk->HasColors() (:42)
     int n_points;
     int N;
+    int jaxis;               // world axis each lane of cloud_integrate_kernel keeps in registers (a speed choice, host_cloud.h)
 };
 
 struct CloudView {
@@ -66,9 +68,9 @@ struct CloudView {
     uint64_t *table_keys;    // CLOUD_TABLE_SLOTS
     int *table_vals;
     uint64_t *listed;        // CLOUD_MAX_LISTED packed ids, in order of discovery
-    int *offsets;            // CLOUD_MAX_LISTED + 1: pairs per listed chunk, then their exclusive prefix
-    int *cursors;            // CLOUD_MAX_LISTED
-    int *pairs;              // pairs_capacity point indices, grouped by chunk, unordered
+    int *offsets;            // listed chunks x units per chunk + 1: pairs per unit, then their exclusive prefix
+    int *cursors;            // listed chunks x units per chunk
+    int *pairs;              // pairs_capacity point indices, grouped by unit, unordered
     int *sorted;             // the same in cloud order
     int pairs_capacity;
     int *ctl;                // [0] listed chunks, [1] pairs
@@ -197,11 +199,12 @@ __global__ __launch_bounds__(CLOUD_TILE) void cloud_tile_count_kernel(CloudParam
     __syncthreads();
     if (threadIdx.x == 0) C.tile_prefix[blockIdx.x] = s_n;
 }
-// exclusive prefix of `n` ints in place, total into *total (one workgroup of 1024 threads)
-__global__ __launch_bounds__(1024) void cloud_scan_kernel(int *data, const int *n_ptr, int n_fixed, int *total, int capacity, int *error_flag) {
+// exclusive prefix of n = min(*n_ptr, n_fixed) * mult ints in place, total into data[n] and *total (one workgroup of 1024 threads)
+__global__ __launch_bounds__(1024) void cloud_scan_kernel(int *data, const int *n_ptr, int n_fixed, int mult, int *total, int capacity,
+                                                           int *error_flag) {
     __shared__ int s_part[1024];
     __shared__ int s_carry;
-    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
+    const int n = (n_ptr ? min(*n_ptr, n_fixed) : n_fixed) * mult;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
@@ -293,80 +296,163 @@ __global__ __launch_bounds__(CLOUD_TILE) void cloud_prepare_kernel(CloudParams P
     } while (w.next());
 }
 
-// ---- (chunk, point) pairs ------------------------------------------------------------------------------------------------------
-// cells of one axis the voxel walk of ray (a, b) can take inside chunk coordinate c: between floor((a - o) * round) and
-// floor((b - o) * round), the arithmetic of ProjectionIntegrator.cpp:73-80 with o = Chunk::GetOrigin() (Chunk.cpp:43)
-__device__ inline bool axis_enters(float a, float b, int c, int N, float res, float round) {
+// ---- units: a chunk is split into cubes of 8 x 8 x 8 voxels, one wave each ------------------------------------------------------
+struct CloudUnits {
+    int per_edge;    // cubes per chunk edge
+    int count;       // 1 (N = 8), 8 (N = 16), 64 (N = 32)
+    __host__ __device__ explicit CloudUnits(int N) : per_edge(N / 8), count((N / 8) * (N / 8) * (N / 8)) {}
+};
+
+// ---- (unit, point) pairs -------------------------------------------------------------------------------------------------------
+// Cells of one axis the voxel walk of ray (a, b) takes relative to chunk coordinate c: the walk moves monotonically from
+// floor((a - o) * round) to floor((b - o) * round) -- the arithmetic of ProjectionIntegrator.cpp:73-80 with o = Chunk::GetOrigin()
+// (Chunk.cpp:43) -- so it enters [0, N) on this axis iff that closed range meets it.  false: it does not.
+__device__ inline bool axis_range(float a, float b, int c, int N, float res, float round, int &lo, int &hi) {
     const float o = (float)(N * c) * res;
     const float s = (a - o) * round, e = (b - o) * round;
     if (!(cell_coordinate_ok(s) && cell_coordinate_ok(e))) return false;
     const int si = floor_int(s), ei = floor_int(e);
-    return max(si, ei) >= 0 && min(si, ei) < N;
+    lo = max(min(si, ei), 0);
+    hi = min(max(si, ei), N - 1);
+    return lo <= hi;
 }
-template <bool FILL>
-__global__ __launch_bounds__(CLOUD_TILE) void cloud_bin_kernel(CloudParams P, CloudView C, MapView M) {
-    const int p = blockIdx.x * CLOUD_TILE + threadIdx.x;
-    if (p >= P.n_points) return;
+// calls f(unit) for every unit (listed chunk index * units per chunk + box) the voxel walk of point p can enter
+template <class F>
+__device__ inline void cloud_enumerate(const CloudParams &P, const CloudView &C, const MapView &M, int p, bool report, F f) {
     const CloudRay r = C.rays[p];
     // skipped points (NaN in ax) and rays with a coordinate that is not finite meet no cell (RayWalk::begin)
     if (!(isfinite(r.ax) && isfinite(r.ay) && isfinite(r.az) && isfinite(r.bx) && isfinite(r.by) && isfinite(r.bz))) return;
-    const float lo[3] = {fminf(r.ax, r.bx), fminf(r.ay, r.by), fminf(r.az, r.bz)};
-    const float hi[3] = {fmaxf(r.ax, r.bx), fmaxf(r.ay, r.by), fmaxf(r.az, r.bz)};
+    const float a[3] = {r.ax, r.ay, r.az}, b[3] = {r.bx, r.by, r.bz};
     const float cs = (float)P.N * P.ip.res;
     int c0[3], c1[3];
-    for (int a = 0; a < 3; a++) {
-        const float f0 = floorf(lo[a] / cs), f1 = floorf(hi[a] / cs);
+    for (int k = 0; k < 3; k++) {
+        const float f0 = floorf(fminf(a[k], b[k]) / cs), f1 = floorf(fmaxf(a[k], b[k]) / cs);
         const float lim = (float)(ID_BIAS - 4);
         if (!(f0 >= -lim && f1 <= lim)) {
-            if (FILL) atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+            if (report) atomicExch(M.error_flag, CLOUD_ERR_RANGE);
             return;
         }
-        c0[a] = (int)f0 - 1;  // one chunk of slack: the decisive test below uses the reference's own arithmetic
-        c1[a] = (int)f1 + 1;
+        c0[k] = (int)f0 - 1;  // one chunk of slack: the decisive test below uses the reference's own arithmetic
+        c1[k] = (int)f1 + 1;
     }
     if ((long long)(c1[0] - c0[0] + 1) * (c1[1] - c0[1] + 1) * (c1[2] - c0[2] + 1) > CLOUD_MAX_RANGE) {
-        if (FILL) atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+        if (report) atomicExch(M.error_flag, CLOUD_ERR_RANGE);
         return;
     }
+    const CloudUnits U(P.N);
     const float round = 1.0f / P.ip.res;
     for (int cz = c0[2]; cz <= c1[2]; cz++) {
-        if (!axis_enters(r.az, r.bz, cz, P.N, P.ip.res, round)) continue;
+        int zl, zh;
+        if (!axis_range(r.az, r.bz, cz, P.N, P.ip.res, round, zl, zh)) continue;
         for (int cy = c0[1]; cy <= c1[1]; cy++) {
-            if (!axis_enters(r.ay, r.by, cy, P.N, P.ip.res, round)) continue;
+            int yl, yh;
+            if (!axis_range(r.ay, r.by, cy, P.N, P.ip.res, round, yl, yh)) continue;
             for (int cx = c0[0]; cx <= c1[0]; cx++) {
-                if (!axis_enters(r.ax, r.bx, cx, P.N, P.ip.res, round)) continue;
+                int xl, xh;
+                if (!axis_range(r.ax, r.bx, cx, P.N, P.ip.res, round, xl, xh)) continue;
                 const int idx = cloud_table_find(C, pack_id(cx, cy, cz));
                 if (idx < 0) continue;
-                if (!FILL) {
-                    atomicAdd(&C.offsets[idx], 1);
-                } else {
-                    const int at = C.offsets[idx] + atomicAdd(&C.cursors[idx], 1);
-                    if (at < C.pairs_capacity) C.pairs[at] = p;
-                }
+                for (int uz = zl >> 3; uz <= (zh >> 3); uz++)
+                    for (int uy = yl >> 3; uy <= (yh >> 3); uy++)
+                        for (int ux = xl >> 3; ux <= (xh >> 3); ux++) f(idx * U.count + (uz * U.per_edge + uy) * U.per_edge + ux);
             }
         }
     }
 }
 
-// ---- per chunk: point indices into cloud order --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cloud_sort_kernel(CloudParams P, CloudView C) {
-    extern __shared__ unsigned s_bits[];  // words_per_pass
-    __shared__ int s_scan[256];
+// Workgroup-local table unit -> count: the 256 consecutive points of a workgroup meet a few dozen units, so the global counters
+// take one atomic per (workgroup, unit) instead of one per (point, unit) (same-address atomics serialise in L2).
+constexpr int CLOUD_LOCAL_SLOTS = 256;
+__device__ inline int cloud_local_slot(int *s_key, int key) {
+    unsigned h = ((unsigned)key * 2654435761u) >> 24;
+    for (int probe = 0; probe < CLOUD_LOCAL_SLOTS; probe++, h = (h + 1u) & (CLOUD_LOCAL_SLOTS - 1u)) {
+        const int k = s_key[h];
+        if (k == key) return (int)h;
+        if (k == -1) {
+            const int old = atomicCAS(&s_key[h], -1, key);
+            if (old == -1 || old == key) return (int)h;
+        }
+    }
+    return -1;
+}
+template <bool FILL>
+__global__ __launch_bounds__(CLOUD_TILE) void cloud_bin_kernel(CloudParams P, CloudView C, MapView M) {
+    __shared__ int s_key[CLOUD_LOCAL_SLOTS], s_cnt[CLOUD_LOCAL_SLOTS], s_base[CLOUD_LOCAL_SLOTS];
     const int tid = threadIdx.x;
-    const int n_listed = min(C.ctl[0], CLOUD_MAX_LISTED);
-    const int total_words = (P.n_points + 31) >> 5;
-    const int pass_words = min(total_words, CLOUD_SORT_WORDS);
-    for (int idx = blockIdx.x; idx < n_listed; idx += gridDim.x) {
-        const int off = C.offsets[idx];
-        const int cnt = min(C.offsets[idx + 1], C.pairs_capacity) - off;
+    const int p = blockIdx.x * CLOUD_TILE + tid;
+    const bool live = p < P.n_points;
+    for (int i = tid; i < CLOUD_LOCAL_SLOTS; i += CLOUD_TILE) {
+        s_key[i] = -1;
+        s_cnt[i] = 0;
+    }
+    __syncthreads();
+    if (live)
+        cloud_enumerate(P, C, M, p, FILL, [&](int unit) {
+            const int e = cloud_local_slot(s_key, unit);
+            if (e >= 0) atomicAdd(&s_cnt[e], 1);
+            else if (!FILL) atomicAdd(&C.offsets[unit], 1);
+        });
+    __syncthreads();
+    for (int i = tid; i < CLOUD_LOCAL_SLOTS; i += CLOUD_TILE) {
+        if (s_key[i] < 0) continue;
+        if (!FILL) {
+            atomicAdd(&C.offsets[s_key[i]], s_cnt[i]);
+        } else {
+            s_base[i] = C.offsets[s_key[i]] + atomicAdd(&C.cursors[s_key[i]], s_cnt[i]);
+            s_cnt[i] = 0;
+        }
+    }
+    if (!FILL) return;
+    __syncthreads();
+    if (live)
+        cloud_enumerate(P, C, M, p, false, [&](int unit) {
+            const int e = cloud_local_slot(s_key, unit);
+            const int at = e >= 0 ? s_base[e] + atomicAdd(&s_cnt[e], 1) : C.offsets[unit] + atomicAdd(&C.cursors[unit], 1);
+            if (at < C.pairs_capacity) C.pairs[at] = p;
+        });
+}
+
+// ---- per unit: point indices into cloud order ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cloud_sort_kernel(CloudParams P, CloudView C) {
+    __shared__ unsigned s_bits[CLOUD_SORT_WORDS];
+    __shared__ int s_scan[256];
+    __shared__ int s_lo, s_hi;
+    const int tid = threadIdx.x;
+    const int n_units = min(C.ctl[0], CLOUD_MAX_LISTED) * CloudUnits(P.N).count;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int off = C.offsets[unit];
+        const int cnt = min(C.offsets[unit + 1], C.pairs_capacity) - off;
         if (cnt <= 0) continue;
+        // the unit's points lie in a narrow index range (a few image rows): bitmap over that range only
+        if (tid == 0) {
+            s_lo = 0x7fffffff;
+            s_hi = -1;
+        }
+        __syncthreads();
+        int lo = 0x7fffffff, hi = -1;
+        for (int i = tid; i < cnt; i += 256) {
+            const int q = C.pairs[off + i];
+            lo = min(lo, q);
+            hi = max(hi, q);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_down(lo, o));
+            hi = max(hi, __shfl_down(hi, o));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&s_lo, lo);
+            atomicMax(&s_hi, hi);
+        }
+        __syncthreads();
+        const int w_first = s_lo >> 5, total_words = (s_hi >> 5) - w_first + 1;
         int written = 0;
-        for (int w0 = 0; w0 < total_words; w0 += pass_words) {
-            const int words = min(pass_words, total_words - w0);
+        for (int w0 = 0; w0 < total_words; w0 += CLOUD_SORT_WORDS) {
+            const int words = min(CLOUD_SORT_WORDS, total_words - w0);
+            const int bit0 = (w_first + w0) << 5;
             for (int i = tid; i < words; i += 256) s_bits[i] = 0u;
             __syncthreads();
             for (int i = tid; i < cnt; i += 256) {
-                const int q = C.pairs[off + i] - (w0 << 5);
+                const int q = C.pairs[off + i] - bit0;
                 if (q >= 0 && q < (words << 5)) atomicOr(&s_bits[q >> 5], 1u << (q & 31));
             }
             __syncthreads();
@@ -388,7 +474,7 @@ __global__ __launch_bounds__(256) void cloud_sort_kernel(CloudParams P, CloudVie
                 while (bits) {
                     const int bpos = __ffs(bits) - 1;
                     bits &= bits - 1u;
-                    C.sorted[at++] = ((w0 + i) << 5) + bpos;
+                    C.sorted[at++] = bit0 + (i << 5) + bpos;
                 }
             }
             written += s_scan[255];
@@ -398,171 +484,213 @@ __global__ __launch_bounds__(256) void cloud_sort_kernel(CloudParams P, CloudVie
 }
 
 // ---- per chunk: the update ----------------------------------------------------------------------------------------------------
+// One wave per unit (cube of 8 x 8 x 8 voxels); the waves of a workgroup take units of the same chunk and meet only to look the
+// chunk up, to create it and to move on.  A lane holds the 8 voxels of one line of its cube along world axis `jaxis` in REGISTERS
+// for the whole list of rays (lanes = the 8 x 8 positions on the other two axes).  Rays are taken 64 at a time, in cloud order:
+//   walk   lane r walks ray r (Raycast.cpp:35-128) and sets bit r in the mask of every voxel of the cube it meets (LDS, 64 bits
+//          per voxel);
+//   apply  every lane goes through the masks of its voxels and applies the rays whose bits are set, lowest bit first = cloud
+//          order, to the voxel in its registers (ProjectionIntegrator.cpp:85-105 / :147-167).
+// So the per-voxel order of updates is the reference's, while different voxels advance in parallel.  64 consecutive points of an
+// organised cloud are a piece of an image row: their cells spread along the row and along the viewing direction and are thin
+// across the rows, so the host picks the world axis closest to the sensor's y axis as `jaxis` and the cells of a batch land on
+// many lanes.
 template <int N>
 struct CloudGeom {
-    static constexpr int BOX = N < 16 ? N : 16;      // voxel box held in LDS
-    static constexpr int SUB = N / BOX;              // boxes per chunk edge (N = 32: 2)
-    static constexpr int BV = BOX * BOX * BOX;
-    static constexpr int HITS = 3 * BOX - 2;         // cells a monotone walk can take inside the box
-    static constexpr int HP = (HITS + 1) & ~1;       // row pitch of the cell list
-    static constexpr int BITS = BOX == 16 ? 4 : 3;   // bits per local coordinate
+    static constexpr int UV = 512;                             // voxels per unit
+    static constexpr int E = N / 8;                            // units per chunk edge
+    static constexpr int U = E * E * E;                        // units per chunk
+    static constexpr int WAVES = U < 8 ? U : 8;                // units in flight per workgroup
 };
 
+// ColorVoxel::Integrate(r, g, b, 1) (ColorVoxel.h:65-85) on packed words, any weight: color_integrate_fresh's arithmetic is exact
+// up to weight 253 (x + 0.5 < 2^16, quotient <= 255, (x + 0.5) / d at least 1 / 508 away from an integer against an error below
+// 1e-4); checked against color_integrate for EVERY (weight, old, new) by chisel_hip_kat_color_any (tests/test_gpu_cloud.py).
+__device__ inline unsigned color_integrate_any(unsigned c, unsigned rgb) {
+    if ((c >> 24) >= 254u) return c;  // weight >= 255 - weightUpdate
+    return color_integrate_fresh(c, rgb);
+}
+__global__ void kat_color_any_kernel(unsigned *mismatches) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;  // 256 * 256 * 256 cases
+    const unsigned w = i >> 16, o = (i >> 8) & 0xffu, n = i & 0xffu;
+    const uchar4 c = make_uchar4((uint8_t)o, (uint8_t)(255u - o), (uint8_t)(o ^ 0x5au), (uint8_t)w);
+    const uint8_t r = (uint8_t)n, g = (uint8_t)(255u - n), b = (uint8_t)(n ^ 0x5au);
+    const uchar4 want = color_integrate(c, r, g, b, 1);
+    const unsigned got = color_integrate_any((unsigned)c.x | ((unsigned)c.y << 8) | ((unsigned)c.z << 16) | ((unsigned)c.w << 24),
+                                             (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16));
+    const unsigned want_bits = (unsigned)want.x | ((unsigned)want.y << 8) | ((unsigned)want.z << 16) | ((unsigned)want.w << 24);
+    if (got != want_bits) atomicAdd(mismatches, 1u);
+}
+
 template <int N, bool COLOR>
-__global__ __launch_bounds__(256) void cloud_integrate_kernel(CloudParams P, MapView M, const MapView *__restrict__ Mc, CloudView C) {
+__global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kernel(CloudParams P, MapView M, const MapView *__restrict__ Mc,
+                                                                                    CloudView C) {
     using G = CloudGeom<N>;
     constexpr int V = N * N * N;
-    __shared__ float s_sdf[G::BV];
-    __shared__ float s_wgt[G::BV];
-    __shared__ unsigned s_col[COLOR ? G::BV : 1];
-    constexpr int RB = CLOUD_RAYS;
-    __shared__ unsigned short s_cells[RB * G::HP];
-    __shared__ float s_depth[RB], s_trunc[RB], s_weight[RB];
-    __shared__ unsigned s_rgb[RB];
-    __shared__ unsigned char s_ncells[RB], s_owners[RB];
+    __shared__ unsigned s_mask[G::WAVES][G::UV][2];
+    __shared__ float4 s_ray[G::WAVES][64];  // depth, truncation, weight update, colour bits
     __shared__ int s_slot;
-    __shared__ unsigned s_updated;
+    __shared__ unsigned s_upd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_listed = min(C.ctl[0], CLOUD_MAX_LISTED);
     const float res = P.ip.res, round = 1.0f / res;
+    // axis roles: ja in registers, (aa, ab) across the lanes
+    const int ja = P.jaxis, aa = ja == 0 ? 1 : 0, ab = ja == 2 ? 1 : 2;
+    const int la = lane & 7, lb = lane >> 3;
+    int lane_xyz[3], mask_mult[3];
+    lane_xyz[ja] = 0; lane_xyz[aa] = la; lane_xyz[ab] = lb;
+    mask_mult[ja] = 64; mask_mult[aa] = 1; mask_mult[ab] = 8;
+    const int j_stride = ja == 0 ? 1 : (ja == 1 ? N : N * N);
     unsigned n_hits = 0, n_sdf = 0, n_carved = 0, n_col = 0, n_new = 0, n_updated = 0, n_items = 0;
 
     for (int idx = blockIdx.x; idx < n_listed; idx += gridDim.x) {
-        const int off = C.offsets[idx];
-        const int cnt = min(C.offsets[idx + 1], C.pairs_capacity) - off;
         if (tid == 0) n_items++;
-        if (cnt <= 0) continue;  // a listed chunk no ray enters: new and untouched, or resident and unchanged
+        const int total = min(C.offsets[(idx + 1) * G::U], C.pairs_capacity) - C.offsets[idx * G::U];
+        if (total <= 0) continue;  // a listed chunk no ray enters: new and untouched, or resident and unchanged
         int cx, cy, cz;
         unpack_id(C.listed[idx], cx, cy, cz);
-        __syncthreads();  // the previous chunk's readers of s_slot are done
-        if (tid == 0) s_slot = find_chunk(Mc, cx, cy, cz);
+        __syncthreads();  // the previous chunk's readers of s_slot / s_upd are done
+        if (tid == 0) {
+            s_slot = find_chunk(Mc, cx, cy, cz);
+            s_upd = 0u;
+        }
         __syncthreads();
         int slot = s_slot;
         const float ox = (float)(N * cx) * res, oy = (float)(N * cy) * res, oz = (float)(N * cz) * res;  // Chunk.cpp:43
-        bool chunk_updated = false;
 
-        for (int sb = 0; sb < G::SUB * G::SUB * G::SUB; sb++) {
-            const int bx = (sb % G::SUB) * G::BOX, by = ((sb / G::SUB) % G::SUB) * G::BOX, bz = (sb / (G::SUB * G::SUB)) * G::BOX;
-            // voxel box into LDS (a chunk that does not exist yet holds default voxels: DistVoxel.cpp:27-31, ColorVoxel.cpp:27-31)
-            for (int i = tid; i < G::BV; i += 256) {
-                const int lx = i % G::BOX, ly = (i / G::BOX) % G::BOX, lz = i / (G::BOX * G::BOX);
-                const size_t g = (size_t)((bz + lz) * N + (by + ly)) * N + (bx + lx);
-                s_sdf[i] = slot >= 0 ? M.sdf[(size_t)slot * V + g] : 99999.0f;
-                s_wgt[i] = slot >= 0 ? M.wgt[(size_t)slot * V + g] : 0.0f;
-                if (COLOR) s_col[i] = slot >= 0 ? *reinterpret_cast<const unsigned *>(&M.rgbw[(size_t)slot * V + g]) : 0u;
-            }
-            if (tid == 0) s_updated = 0u;
-            __syncthreads();
+        for (int round_i = 0; round_i < G::U / G::WAVES; round_i++) {
+            const int u = round_i * G::WAVES + wave;
+            const int bx = (u % G::E) * 8, by = ((u / G::E) % G::E) * 8, bz = (u / (G::E * G::E)) * 8;
+            const int off = C.offsets[idx * G::U + u];
+            const int cnt = min(C.offsets[idx * G::U + u + 1], C.pairs_capacity) - off;
+            float sdf[8], wgt[8];
+            unsigned col[COLOR ? 8 : 1];
+            bool upd = false;
+            // first voxel of the lane's line, in chunk coordinates
+            const int x0 = bx + lane_xyz[0], y0 = by + lane_xyz[1], z0 = bz + lane_xyz[2];
+            const size_t g0 = (size_t)(z0 * N + y0) * N + x0;
+            if (cnt > 0) {
+                // the lane's voxels into registers (a chunk that does not exist yet holds default voxels: DistVoxel.cpp:27-31,
+                // ColorVoxel.cpp:27-31)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const size_t g = (size_t)slot * V + g0 + (size_t)j * j_stride;
+                    sdf[j] = slot >= 0 ? M.sdf[g] : 99999.0f;
+                    wgt[j] = slot >= 0 ? M.wgt[g] : 0.0f;
+                    if (COLOR) col[j] = slot >= 0 ? *reinterpret_cast<const unsigned *>(&M.rgbw[g]) : 0u;
+                }
+                for (int i = lane; i < G::UV; i += 64) {
+                    s_mask[wave][i][0] = 0u;
+                    s_mask[wave][i][1] = 0u;
+                }
 
-            for (int b0 = 0; b0 < cnt; b0 += RB) {
-                // ---- walk: one ray per lane, its cells inside the box go to LDS (ProjectionIntegrator.cpp:73-84)
-                int nc = 0;
-                unsigned owners = 0u;
-                if (tid < RB && b0 + tid < cnt) {
-                    const int p = C.sorted[off + b0 + tid];
-                    const CloudRay r = C.rays[p];
-                    s_depth[tid] = r.depth;
-                    s_trunc[tid] = r.trunc;
-                    s_weight[tid] = constant_weight(P.ip.weight, r.trunc);
-                    s_rgb[tid] = (COLOR && P.with_color) ? C.rgb[p] : 0u;
-                    RayWalk w;
-                    if (r.ax == r.ax && w.begin(((r.ax - ox)) * round, ((r.ay - oy)) * round, ((r.az - oz)) * round, ((r.bx - ox)) * round,
-                                                ((r.by - oy)) * round, ((r.bz - oz)) * round)) {
-                        if (w.length() > (1ull << 20)) {
-                            atomicExch(M.error_flag, CLOUD_ERR_RANGE);
-                        } else {
-                            do {
-                                const unsigned lx = (unsigned)(w.x - bx), ly = (unsigned)(w.y - by), lz = (unsigned)(w.z - bz);
-                                if (lx < (unsigned)G::BOX && ly < (unsigned)G::BOX && lz < (unsigned)G::BOX) {
-                                    s_cells[tid * G::HP + nc] = (unsigned short)(lx | (ly << G::BITS) | (lz << (2 * G::BITS)));
-                                    nc++;
-                                    owners |= 1u << (((lz >> (G::BITS - 1)) << 1) | (ly >> (G::BITS - 1)));
-                                }
-                            } while (w.next());
+                // the next batch's rays are fetched while the current batch is applied (two dependent global reads per batch)
+                CloudRay r_next;
+                unsigned rgb_next = 0u;
+                r_next.ax = __builtin_nanf("");
+                if (lane < cnt) {
+                    const int p = C.sorted[off + lane];
+                    r_next = C.rays[p];
+                    if (COLOR && P.with_color) rgb_next = C.rgb[p];
+                }
+                for (int b0 = 0; b0 < cnt; b0 += 64) {
+                    // ---- walk: one ray per lane (ProjectionIntegrator.cpp:73-84)
+#ifndef CLOUD_ABLATE_WALK
+                    const CloudRay r = r_next;
+                    const unsigned rgb = rgb_next;
+                    const bool have = b0 + lane < cnt;
+                    if (b0 + 64 + lane < cnt) {
+                        const int p = C.sorted[off + b0 + 64 + lane];
+                        r_next = C.rays[p];
+                        if (COLOR && P.with_color) rgb_next = C.rgb[p];
+                    }
+                    if (have) {
+                        s_ray[wave][lane] = make_float4(r.depth, r.trunc, constant_weight(P.ip.weight, r.trunc), __uint_as_float(rgb));
+                        RayWalk w;
+                        if (r.ax == r.ax && w.begin((r.ax - ox) * round, (r.ay - oy) * round, (r.az - oz) * round, (r.bx - ox) * round,
+                                                    (r.by - oy) * round, (r.bz - oz) * round)) {
+                            if (w.length() > (1ull << 20)) {
+                                atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+                            } else {
+                                do {
+                                    const unsigned cxl = (unsigned)(w.x - bx), cyl = (unsigned)(w.y - by), czl = (unsigned)(w.z - bz);
+                                    if (cxl < 8u && cyl < 8u && czl < 8u)
+                                        atomicOr(&s_mask[wave][cxl * mask_mult[0] + cyl * mask_mult[1] + czl * mask_mult[2]][lane >> 5],
+                                                 1u << (lane & 31));
+                                } while (w.next());
+                            }
                         }
                     }
-                }
-                if (tid < RB) {
-                    s_ncells[tid] = (unsigned char)nc;
-                    s_owners[tid] = (unsigned char)owners;
-                }
-                __syncthreads();
-
-                // ---- apply: rays in cloud order; wave `wave` owns the voxels with (z half, y half) == wave
-                const int nb = min(RB, cnt - b0);
-                unsigned upd = 0u;
-                for (int g0 = 0; g0 < nb; g0 += 64) {
-                    const unsigned mine = (g0 + lane < nb) ? ((s_owners[g0 + lane] >> wave) & 1u) : 0u;
-                    unsigned long long todo = __ballot(mine);
-                    while (todo) {
-                        const int q = g0 + (__ffsll((long long)todo) - 1);
-                        todo &= todo - 1ull;
-                        const int n = s_ncells[q];
-                        if (lane < n) {
-                            const unsigned cell = s_cells[q * G::HP + lane];
-                            const unsigned lx = cell & (G::BOX - 1), ly = (cell >> G::BITS) & (G::BOX - 1), lz = cell >> (2 * G::BITS);
-                            if ((((lz >> (G::BITS - 1)) << 1) | (ly >> (G::BITS - 1))) == (unsigned)wave) {
-                                const int li = (int)((lz * G::BOX + ly) * G::BOX + lx);
-                                // centroids[id] + origin (ChunkManager.cpp:50-66): (coordinate * res + res / 2) + origin
-                                const float vx = ((float)(int)(bx + lx) * res + P.ip.half_res) + ox;
-                                const float vy = ((float)(int)(by + ly) * res + P.ip.half_res) + oy;
-                                const float vz = ((float)(int)(bz + lz) * res + P.ip.half_res) + oz;
-                                const float depth = s_depth[q], trunc = s_trunc[q];
-                                const float u = depth - (affine_row(P.inv + 8, vx, vy, vz) - P.pose[11]);  // :89 / :151
-                                n_hits++;
-                                if (fabsf(u) < trunc) {
-                                    float sdf = s_sdf[li], wg = s_wgt[li];
-                                    dist_integrate(sdf, wg, u, s_weight[q]);
-                                    s_sdf[li] = sdf;
-                                    s_wgt[li] = wg;
-                                    if (COLOR && P.with_color) {
-                                        const unsigned c = s_col[li], rgb = s_rgb[q];
-                                        const uchar4 o = color_integrate(make_uchar4(c & 0xffu, (c >> 8) & 0xffu, (c >> 16) & 0xffu, c >> 24),
-                                                                         rgb & 0xffu, (rgb >> 8) & 0xffu, (rgb >> 16) & 0xffu, 1);
-                                        s_col[li] = (unsigned)o.x | ((unsigned)o.y << 8) | ((unsigned)o.z << 16) | ((unsigned)o.w << 24);
-                                        n_col++;
-                                    }
-                                    upd = 1u;
-                                    n_sdf++;
-                                } else if (P.ip.carving && u > trunc + P.ip.carving_dist) {
-                                    float sdf = s_sdf[li], wg = s_wgt[li];
-                                    if (wg > 0.0f) {
-                                        dist_integrate(sdf, wg, 1.0e-5f, 5.0f);  // :100 / :165
-                                        s_sdf[li] = sdf;
-                                        s_wgt[li] = wg;
-                                        upd = 1u;
-                                        n_carved++;
-                                    }
+#endif
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // same wave: LDS operations complete in order
+                    __builtin_amdgcn_wave_barrier();
+#ifndef CLOUD_ABLATE_APPLY
+                    // ---- apply: per voxel, the rays of this batch that met it, in cloud order
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        unsigned m0 = s_mask[wave][j * 64 + lane][0], m1 = s_mask[wave][j * 64 + lane][1];
+                        if ((m0 | m1) == 0u) continue;
+                        s_mask[wave][j * 64 + lane][0] = 0u;
+                        s_mask[wave][j * 64 + lane][1] = 0u;
+                        // centroids[id] + origin (ChunkManager.cpp:50-66): (coordinate * res + res / 2) + origin, then the z row of
+                        // inversePose * centroid (Transform * Vec3: ((m0 x + m1 y) + m2 z) + m3) minus cameraPose.translation().z
+                        // (ProjectionIntegrator.cpp:89 / :151)
+                        const float vx = ((float)(x0 + (ja == 0 ? j : 0)) * res + P.ip.half_res) + ox;
+                        const float vy = ((float)(y0 + (ja == 1 ? j : 0)) * res + P.ip.half_res) + oy;
+                        const float vz = ((float)(z0 + (ja == 2 ? j : 0)) * res + P.ip.half_res) + oz;
+                        const float cam_z = affine_row(P.inv + 8, vx, vy, vz) - P.pose[11];
+                        unsigned long long m = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+                        while (m) {
+                            const int q = __ffsll((long long)m) - 1;
+                            m &= m - 1ull;
+                            const float4 rp = s_ray[wave][q];
+                            const float u_sd = rp.x - cam_z;
+                            n_hits++;
+                            if (fabsf(u_sd) < rp.y) {
+                                dist_integrate(sdf[j], wgt[j], u_sd, rp.z);
+                                if (COLOR && P.with_color) {
+                                    col[j] = color_integrate_any(col[j], __float_as_uint(rp.w));
+                                    n_col++;
+                                }
+                                upd = true;
+                                n_sdf++;
+                            } else if (P.ip.carving && u_sd > rp.y + P.ip.carving_dist) {
+                                if (wgt[j] > 0.0f) {
+                                    dist_integrate(sdf[j], wgt[j], 1.0e-5f, 5.0f);  // :100 / :165
+                                    upd = true;
+                                    n_carved++;
                                 }
                             }
                         }
                     }
-                }
-                if (__any((int)upd) && lane == 0) atomicOr(&s_updated, 1u);
-                __syncthreads();  // cells and per-ray values are rewritten by the next rays
-            }
-
-            if (s_updated) {  // block-uniform (read after the barrier above)
-                if (slot < 0) {
-                    if (tid == 0) s_slot = create_chunk(Mc, cx, cy, cz);
-                    __syncthreads();
-                    slot = s_slot;
-                    if (slot >= 0 && tid == 0) n_new++;
-                }
-                if (slot >= 0) {
-                    for (int i = tid; i < G::BV; i += 256) {
-                        const int lx = i % G::BOX, ly = (i / G::BOX) % G::BOX, lz = i / (G::BOX * G::BOX);
-                        const size_t g = (size_t)((bz + lz) * N + (by + ly)) * N + (bx + lx);
-                        M.sdf[(size_t)slot * V + g] = s_sdf[i];
-                        M.wgt[(size_t)slot * V + g] = s_wgt[i];
-                        if (COLOR) *reinterpret_cast<unsigned *>(&M.rgbw[(size_t)slot * V + g]) = s_col[i];
-                    }
-                    chunk_updated = true;
+#endif
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
-            __syncthreads();  // the box is reloaded for the next sub-box
+            const bool unit_updated = __any((int)upd) != 0;
+            if (unit_updated && lane == 0) atomicOr(&s_upd, 1u);
+            __syncthreads();
+            if (s_upd != 0u && slot < 0) {  // block-uniform
+                if (tid == 0) {
+                    s_slot = create_chunk(Mc, cx, cy, cz);
+                    if (s_slot >= 0) n_new++;
+                }
+                __syncthreads();
+                slot = s_slot;
+            }
+            if (unit_updated && slot >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const size_t g = (size_t)slot * V + g0 + (size_t)j * j_stride;
+                    M.sdf[g] = sdf[j];
+                    M.wgt[g] = wgt[j];
+                    if (COLOR) *reinterpret_cast<unsigned *>(&M.rgbw[g]) = col[j];
+                }
+            }
         }
-        if (chunk_updated && tid == 0) {
+        __syncthreads();
+        if (tid == 0 && s_upd != 0u && slot >= 0) {
             M.slot_dirty[slot] = 1;  // Chisel.cpp:135-147 (27 neighbours: expanded by the mesher)
             n_updated++;
         }

@@ -94,6 +94,14 @@ def test_device_raycast_matches_the_oracle(hip_lib, oracle_mod):
         assert count[i] == len(ref) and np.array_equal(cells2[i, :count[i]], ref), "ray %d (unbounded)" % i
 
 
+def test_device_colour_update_any_weight(hip_lib):
+    """color_integrate_any (division-free, used by cloud_integrate_kernel) == ColorVoxel::Integrate(r, g, b, 1) for every
+    (weight, old, new); the general path itself is pinned to the reference-built vectors in test_gpu_parity.py."""
+    bad = C.c_uint(12345)
+    assert hip_lib.chisel_hip_kat_color_any(C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 @pytest.mark.parametrize("N,res,color,trunc", [
     (16, 0.02, False, ("inverse", 2.0)),
     (16, 0.02, True, ("inverse", 2.0)),

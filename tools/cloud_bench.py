@@ -71,6 +71,10 @@ def main():
         "config": {"workload": "sphere room x %.1f, %dx%d points per cloud, %.3g m voxels, 16^3 chunks, %s" %
                    (scale, W, H, args.res, "colour" if color else "no colour")},
     }
+    import ctypes as C
+    st = (C.c_int64 * 4)()
+    if gm.L.chisel_hip_debug_cloud_stats(gm.h, st) == 0:
+        out["last_cloud"] = {"listed_chunks": st[0], "unit_point_pairs": st[1], "rays_of_largest_unit": st[2], "units_with_rays": st[3]}
     if args.cpu:
         import oracle
         w2, h2 = 160, 120
