@@ -51,6 +51,7 @@ class FrameExchange:
         import torch
         self.torch = torch
         self.dist = dist_module
+        self.device = torch.device(device)
         self.world = dist_module.get_world_size() if dist_module is not None else 1
         self.rank = dist_module.get_rank() if dist_module is not None else 0
         if batch % self.world:
@@ -168,6 +169,11 @@ class LocalShardGroup:
         self.world = len(shards)
         self.calls = 0
 
+    def IntegratePointCloud(self, integrator, cloud, extrinsic, truncation, max_dist):
+        """Chisel::IntegratePointCloud on every shard: each lists and updates only the chunks it owns (cloud_prepare_kernel)."""
+        for s_ in self.shards:
+            s_.IntegratePointCloud(integrator, cloud, extrinsic, truncation, max_dist)
+
     def UpdateMeshes(self, force=False):
         from .chisel import chunk_owner
         self.calls += 1
@@ -209,6 +215,31 @@ class ShardedChisel:
                 colors.append((color[j], pose, cam))
         self.map.IntegrateBatch(self.integrator, frames, colors)
         return frames
+
+    def IntegratePointCloud(self, points, colors, extrinsic, truncation, max_dist, src=0):
+        """Chisel::IntegratePointCloud of the sharded map: rank `src` ingested the cloud (device tensors (n, 3); the other ranks
+        pass None), it is broadcast over RCCL and every rank updates the chunks it owns -- no other exchange is needed, the
+        update of a chunk depends on the cloud and that chunk only."""
+        torch, dist = self.x.torch, self.x.dist
+        rank = dist.get_rank()
+        head = [None]
+        if rank == src:
+            head[0] = (int(points.shape[0]), colors is not None, np.asarray(extrinsic, np.float32)[:3, :4].tolist())
+        dist.broadcast_object_list(head, src=src)
+        n, has_color, pose = head[0]
+        pose = np.asarray(pose, np.float32)
+        dev = self.x.device
+        pts = points.contiguous() if rank == src else torch.empty((n, 3), dtype=torch.float32, device=dev)
+        dist.broadcast(pts, src=src)
+        cols = None
+        if has_color:
+            cols = colors.contiguous() if rank == src else torch.empty((n, 3), dtype=torch.float32, device=dev)
+            dist.broadcast(cols, src=src)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()  # the map runs on its own stream
+        self.map.IntegratePointCloud(self.integrator, (pts if dev.type == "cuda" else pts.numpy(),
+                                                       None if cols is None else (cols if dev.type == "cuda" else cols.numpy())),
+                                     pose, truncation, max_dist)
 
     def UpdateMeshes(self, force=False):
         """Chisel::UpdateMeshes of the sharded map: every rank ends up with the meshes of the chunks it owns (mesh_plan above).

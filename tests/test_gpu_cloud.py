@@ -229,3 +229,31 @@ def test_cloud_device_resident_and_full_size(hip_lib, oracle_mod):
     for k in range(2):
         pts, col, pose = _cloud("sphere_room", k, 160, 120, 0.6, True, t=(0.0, 0.0, 0.03 * k))
         _step(om, gm, integ2, pts, col, pose, what="160x120 cloud %d" % k)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_clouds_equal_the_unsharded_map(hip_lib, world):
+    """Each shard lists and updates only the chunks it owns: the union of the shards is the unsharded map, chunk for chunk."""
+    from cvids_amd import chisel as ch
+    from cvids_amd.sharded import LocalShardGroup
+    one = ch.Chisel((16, 16, 16), 0.02, True, max_chunks=4096)
+    shards = [ch.Chisel((16, 16, 16), 0.02, True, max_chunks=4096, n_shards=world, shard_rank=r, shard_block=2) for r in range(world)]
+    group = LocalShardGroup(shards)
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(2.0), ch.ConstantWeighter(1.0), 0.05, True)
+    for k in range(3):
+        pts, col, pose = _cloud("sphere_room", k, 96, 72, 0.6, True, t=(0.0, 0.0, 0.02 * k))
+        one.IntegratePointCloud(integ, (pts, col), pose, 0.1, 5.0)
+        group.IntegratePointCloud(integ, (pts, col), pose, 0.1, 5.0)
+    want = one.fields()
+    got = {}
+    for r, s_ in enumerate(shards):
+        f = s_.fields()
+        assert all(ch.chunk_owner(cid, world, 2) == r for cid in f)
+        assert not (set(f) & set(got))
+        got.update(f)
+    assert len(want) > 20 and sum(1 for s_ in shards if s_.NumChunks() > 0) == world
+    compare_fields(want, got, 4096, True, atol=0.0, what="sharded clouds")
+    c1 = one.counters()
+    cs = [s_.counters() for s_ in shards]
+    for k in ("sdf", "col", "probe", "carved", "new_chunks", "updated_chunks", "work_chunks"):
+        assert c1[k] == sum(c[k] for c in cs), k

@@ -237,3 +237,67 @@ def test_sharded_update_meshes_protocol_world2(hip_lib):
                             assert n in ghosts and ghosts[n][0] == [float(n[0]), float(n[1]), float(n[2]), float(o)]
         assert all(chunk_owner(g, world, 2) != rank for g in ghosts)
     assert all_jobs == union
+
+
+class CloudRecordingMap:
+    def __init__(self):
+        self.clouds = []
+
+    def IntegratePointCloud(self, integrator, cloud, extrinsic, truncation, max_dist):
+        pts, cols = cloud
+        self.clouds.append((np.asarray(pts).copy(), None if cols is None else np.asarray(cols).copy(), np.asarray(extrinsic).copy(),
+                            truncation, max_dist))
+
+
+def _cloud_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from cvids_amd.sharded import FrameExchange, ShardedChisel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = FrameExchange(W, H, K, torch.device("cpu"), dist, channels=0)
+        local = CloudRecordingMap()
+        sm = ShardedChisel(local, x, integrator=None)
+        intr = synth.intrinsics(W, H)
+        for k, src in enumerate([0, 1, 1]):
+            pose = synth.trajectory_pose(k)
+            if rank == src:
+                depth = synth.render_depth("sphere_room", pose, intr, W, H)
+                pts, cols = synth.depth_to_cloud(depth, intr, 0.6, colors=True)
+                if k == 2:
+                    cols = None
+                sm.IntegratePointCloud(torch.from_numpy(pts), None if cols is None else torch.from_numpy(cols), pose, 0.1, 5.0, src=src)
+            else:
+                sm.IntegratePointCloud(None, None, None, 0.1, 5.0, src=src)
+        import hashlib
+        digest = lambda a: None if a is None else hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()  # small: the parent reads the queue after join()
+        out.put((rank, [(digest(c[0]), digest(c[1]), digest(c[2]), c[3], c[4]) for c in local.clouds]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pointcloud_broadcast_world2(hip_lib):
+    """ShardedChisel.IntegratePointCloud: the cloud ingested by one rank reaches every rank bit for bit (points, colours, pose)."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cloud_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert res[0][1] == res[1][1] and len(res[0][1]) == 3
+    intr = synth.intrinsics(W, H)
+    for k, rec in enumerate(res[0][1]):
+        pose = synth.trajectory_pose(k)
+        pts, cols = synth.depth_to_cloud(synth.render_depth("sphere_room", pose, intr, W, H), intr, 0.6, colors=True)
+        import hashlib
+        digest = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+        assert rec[0] == digest(pts) and rec[2] == digest(np.asarray(pose, np.float32)[:3, :4])
+        assert rec[1] == (None if k == 2 else digest(cols))
