@@ -156,7 +156,8 @@ __device__ inline unsigned cloud_table_home(uint64_t key) {
 __device__ inline void cloud_table_insert(const CloudView &C, const MapView &M, uint64_t key) {
     unsigned i = cloud_table_home(key);
     for (unsigned probe = 0; probe < CLOUD_TABLE_SLOTS; probe++, i = (i + 1u) & (CLOUD_TABLE_SLOTS - 1u)) {
-        const uint64_t k = C.table_keys[i];
+        // read at L2: a line cached before another CU's insertion would send every later wave into the compare-and-swap
+        const uint64_t k = __hip_atomic_load(&C.table_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == key) return;
         if (k == KEY_EMPTY) {
             const uint64_t old = atomicCAS((unsigned long long *)&C.table_keys[i], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
@@ -252,48 +253,56 @@ __global__ __launch_bounds__(CLOUD_TILE) void cloud_prepare_kernel(CloudParams P
     int before = C.tile_prefix[blockIdx.x];
     for (int w = 0; w < wave; w++) before += s_wave[w];
     const int cidx = before + __popcll(b & ((1ull << lane) - 1ull));
-    if (!live) return;
-
-    const float wx = affine_row(P.pose + 0, px, py, pz), wy = affine_row(P.pose + 4, px, py, pz), wz = affine_row(P.pose + 8, px, py, pz);
-    const float ddx = wx - P.pose[3], ddy = wy - P.pose[7], ddz = wz - P.pose[11];
-    const float z2 = ddx * ddx + (ddy * ddy + ddz * ddz);  // squaredNorm(): a0 + (a1 + a2)
-    float dirx = ddx, diry = ddy, dirz = ddz;               // normalized(): n / sqrt(z) when z > 0
-    const float len = sqrtf(z2);
-    if (z2 > 0.0f) {
-        dirx = ddx / len;
-        diry = ddy / len;
-        dirz = ddz / len;
-    }
-    CloudRay r;
-    r.depth = depth;
-    r.trunc = truncation_distance(P.ip.trunc_kind, P.ip.trunc_param, depth);
-    r.ax = wx - dirx * r.trunc; r.ay = wy - diry * r.trunc; r.az = wz - dirz * r.trunc;
-    r.bx = wx + dirx * r.trunc; r.by = wy + diry * r.trunc; r.bz = wz + dirz * r.trunc;
-    if (!accept) r.ax = __builtin_nanf("");
-    C.rays[p] = r;
-    if (P.with_color && accept) {
-        const float cr = C.colors[3 * (size_t)cidx], cg = C.colors[3 * (size_t)cidx + 1], cb = C.colors[3 * (size_t)cidx + 2];
-        // (uint8_t)(c * 255.0f): cvttss2si, low byte
-        C.rgb[p] = ((unsigned)(int)(cr * 255.0f) & 0xffu) | (((unsigned)(int)(cg * 255.0f) & 0xffu) << 8) |
-                   (((unsigned)(int)(cb * 255.0f) & 0xffu) << 16);
-    }
-
-    // chunks the segment world -+ dir * truncation passes through
-    if (len > P.max_dist) return;
-    const float cs = (float)P.N * P.ip.res;  // chunkSize.x() * voxelResolutionMeters
-    const float round = 1.0f / cs;
+    bool walking = false;
     RayWalk w;
-    if (!w.begin((wx - dirx * P.truncation) * round, (wy - diry * P.truncation) * round, (wz - dirz * P.truncation) * round,
-                 (wx + dirx * P.truncation) * round, (wy + diry * P.truncation) * round, (wz + dirz * P.truncation) * round))
-        return;
-    const int lim = ID_BIAS - 2;
-    if (w.length() > 4096ull || abs(w.x) > lim || abs(w.y) > lim || abs(w.z) > lim || abs(w.ex) > lim || abs(w.ey) > lim || abs(w.ez) > lim) {
-        atomicExch(M.error_flag, CLOUD_ERR_RANGE);
-        return;
+    if (live) {
+        const float wx = affine_row(P.pose + 0, px, py, pz), wy = affine_row(P.pose + 4, px, py, pz), wz = affine_row(P.pose + 8, px, py, pz);
+        const float ddx = wx - P.pose[3], ddy = wy - P.pose[7], ddz = wz - P.pose[11];
+        const float z2 = ddx * ddx + (ddy * ddy + ddz * ddz);  // squaredNorm(): a0 + (a1 + a2)
+        float dirx = ddx, diry = ddy, dirz = ddz;               // normalized(): n / sqrt(z) when z > 0
+        const float len = sqrtf(z2);
+        if (z2 > 0.0f) {
+            dirx = ddx / len;
+            diry = ddy / len;
+            dirz = ddz / len;
+        }
+        CloudRay r;
+        r.depth = depth;
+        r.trunc = truncation_distance(P.ip.trunc_kind, P.ip.trunc_param, depth);
+        r.ax = wx - dirx * r.trunc; r.ay = wy - diry * r.trunc; r.az = wz - dirz * r.trunc;
+        r.bx = wx + dirx * r.trunc; r.by = wy + diry * r.trunc; r.bz = wz + dirz * r.trunc;
+        if (!accept) r.ax = __builtin_nanf("");
+        C.rays[p] = r;
+        if (P.with_color && accept) {
+            const float cr = C.colors[3 * (size_t)cidx], cg = C.colors[3 * (size_t)cidx + 1], cb = C.colors[3 * (size_t)cidx + 2];
+            // (uint8_t)(c * 255.0f): cvttss2si, low byte
+            C.rgb[p] = ((unsigned)(int)(cr * 255.0f) & 0xffu) | (((unsigned)(int)(cg * 255.0f) & 0xffu) << 8) |
+                       (((unsigned)(int)(cb * 255.0f) & 0xffu) << 16);
+        }
+
+        // chunks the segment world -+ dir * truncation passes through
+        if (!(len > P.max_dist)) {
+            const float cs = (float)P.N * P.ip.res;  // chunkSize.x() * voxelResolutionMeters
+            const float round = 1.0f / cs;
+            if (w.begin((wx - dirx * P.truncation) * round, (wy - diry * P.truncation) * round, (wz - dirz * P.truncation) * round,
+                        (wx + dirx * P.truncation) * round, (wy + diry * P.truncation) * round, (wz + dirz * P.truncation) * round)) {
+                const int lim = ID_BIAS - 2;
+                if (w.length() > 4096ull || abs(w.x) > lim || abs(w.y) > lim || abs(w.z) > lim || abs(w.ex) > lim || abs(w.ey) > lim || abs(w.ez) > lim)
+                    atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+                else
+                    walking = true;
+            }
+        }
     }
-    do {
-        if (chunk_owner(w.x, w.y, w.z, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank) cloud_table_insert(C, M, pack_id(w.x, w.y, w.z));
-    } while (w.next());
+    // the lanes of a wave step together: neighbouring points meet the same chunks in the same order, so a lane whose left
+    // neighbour holds the same id leaves the insertion to it
+    while (__any((int)walking)) {
+        unsigned long long key = KEY_EMPTY;
+        if (walking && chunk_owner(w.x, w.y, w.z, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank) key = pack_id(w.x, w.y, w.z);
+        const unsigned long long left = __shfl_up(key, 1);
+        if (key != KEY_EMPTY && !(lane > 0 && left == key)) cloud_table_insert(C, M, key);
+        if (walking) walking = w.next();
+    }
 }
 
 // ---- units: a chunk is split into cubes of 8 x 8 x 8 voxels, one wave each ------------------------------------------------------

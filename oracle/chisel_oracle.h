@@ -14,9 +14,11 @@
  * (DistVoxel, ColorVoxel, the three truncators, ConstantWeighter, ColorImage::At) ARE pinned:
  * oracle/ref_kat builds a generator from the reference's own unmodified headers and its outputs
  * are committed as tests/golden/ref_kat.json, which this oracle must reproduce bit for bit.
- * Everything that touches Eigen types (projection, frustum, chunk enumeration, marching cubes)
- * is "parity unpinned": a restatement of the cited lines with the fp32 operation order of
- * Eigen >= 3.3 fixed-size expressions (3-term sums reduce as a0 + (a1 + a2)).
+ * Everything that touches Eigen types (projection, frustum, chunk enumeration, marching cubes,
+ * the point-cloud fusion mode with its ray walk) is "parity unpinned": a restatement of the cited
+ * lines with the fp32 operation order of Eigen >= 3.3 fixed-size expressions (3-term sums reduce
+ * as a0 + (a1 + a2); Transform * Vec3 as the homogeneous 4-vector product; Transform::inverse()
+ * by cofactors).
  */
 #ifndef CHISEL_ORACLE_H_
 #define CHISEL_ORACLE_H_
