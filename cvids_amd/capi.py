@@ -60,6 +60,7 @@ EXPORTS = [
     "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth",
+    "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
     "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner",
 ]
 
@@ -131,6 +132,10 @@ def load_library():
     L.chisel_hip_drop_ghost_chunks.argtypes = [vp]
     L.chisel_hip_condition_depth.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), vp]
     L.chisel_hip_update_meshes_of.argtypes = [vp, i32p, C.c_int]
+    L.chisel_hip_depth_filter_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.chisel_hip_depth_filter_destroy.argtypes = [vp]
+    L.chisel_hip_depth_filter_update.argtypes = [vp, vp, vp, C.c_double, C.c_int, C.c_int]
+    L.chisel_hip_depth_filter_read.argtypes = [vp, C.c_int, vp, C.c_int]
     L.chisel_hip_save_map.argtypes = [vp, C.c_char_p]
     L.chisel_hip_load_map.argtypes = [vp, C.c_char_p]
     L.chisel_hip_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]

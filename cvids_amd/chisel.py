@@ -398,6 +398,66 @@ class Chisel:
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(capi.KERNEL_NAMES)}
 
 
+class DepthFilter:
+    """DepthFilter of the dense-mapping thread (server_pose_graph/src/dense_mapping/depth_filter.cpp) with its state in HBM."""
+    A, B, INV_DEPTH, COV, RATIO, INV_DEPTH_MASKED, DEPTH = range(7)
+
+    def __init__(self, height, width, device_id=-1):
+        self.L = capi.load_library()
+        self.shape = (int(height), int(width))
+        self.h = C.c_void_p()
+        check(self.L.chisel_hip_depth_filter_create(int(height), int(width), int(device_id), C.byref(self.h)))
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.chisel_hip_depth_filter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Update(self, update_mu, update_cov, reciprocal=False):
+        """DepthFilter::Update(mUpdateMu, mUpdateCov): float64 maps (numpy or torch CUDA tensors); update_cov may be a scalar."""
+        mu_addr, dev, k1 = _image_pointer(update_mu, np.float64)
+        assert tuple(update_mu.shape) == self.shape
+        if np.isscalar(update_cov):
+            check(self.L.chisel_hip_depth_filter_update(self.h, mu_addr, None, float(update_cov), int(reciprocal), dev))
+            self._keep = [k1]
+        else:
+            cov_addr, dev2, k2 = _image_pointer(update_cov, np.float64)
+            assert dev2 == dev and tuple(update_cov.shape) == self.shape
+            check(self.L.chisel_hip_depth_filter_update(self.h, mu_addr, cov_addr, 0.0, int(reciprocal), dev))
+            self._keep = [k1, k2]
+
+    def read(self, which, out=None):
+        """-> float64 map; `out`: a torch CUDA tensor to fill in place (stays in HBM), default a new numpy array"""
+        if out is not None:
+            check(self.L.chisel_hip_depth_filter_read(self.h, int(which), out.data_ptr(), 1))
+            return out
+        a = np.empty(self.shape, np.float64)
+        check(self.L.chisel_hip_depth_filter_read(self.h, int(which), a.ctypes.data, 0))
+        return a
+
+    def GetA(self):
+        return self.read(self.A)
+
+    def GetB(self):
+        return self.read(self.B)
+
+    def GetInvDepth(self):
+        return self.read(self.INV_DEPTH)
+
+    def GetCov(self):
+        return self.read(self.COV)
+
+    def GetRatio(self):
+        return self.read(self.RATIO)
+
+
 def condition_depth(depth64, width=640, height=480, intrinsics=None):
     """CollaborativeServer::PublishDenseInfo's depth conditioning (chisel_hip_condition_depth): float64 depth map of any size
     -> (float32 depth of the publish size with NaN outside [0.1, 20] m, rescaled (fx, fy, cx, cy) or None)"""

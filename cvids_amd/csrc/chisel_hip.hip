@@ -24,6 +24,7 @@
 #include "kernels_map.h"
 #include "kernels_mesh.h"
 #include "kernels_cloud.h"
+#include "kernels_filter.h"
 
 using namespace chisel_hip;
 
@@ -1021,6 +1022,77 @@ int chisel_hip_condition_depth(const double *src, int w0, int h0, int src_on_dev
         K[1] = K[1] / (double)h0 * (double)h;
         K[3] = K[3] / (double)h0 * (double)h;
     }
+    return CHISEL_HIP_OK;
+}
+
+// ---- DepthFilter (depth_filter.cpp) ----------------------------------------------------------------------------------------
+struct chisel_hip_depth_filter {
+    int device = 0;
+    int height = 0, width = 0;
+    FilterView view{};
+    double *stage_mu = nullptr, *stage_cov = nullptr, *stage_out = nullptr;  // host arrays pass through these
+};
+int chisel_hip_depth_filter_create(int height, int width, int device_id, chisel_hip_depth_filter **out) {
+    if (!out || height <= 0 || width <= 0 || (int64_t)height * width > (1 << 28)) return fail(CHISEL_HIP_ERR_INVALID, "bad filter size");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(CHISEL_HIP_ERR_HIP, "no HIP device (there is no CPU path)");
+    if (device_id < 0) (void)hipGetDevice(&device_id);
+    if (device_id >= n_dev) return fail(CHISEL_HIP_ERR_INVALID, "bad device id");
+    HIP_TRY(hipSetDevice(device_id));
+    chisel_hip_depth_filter *f = new chisel_hip_depth_filter();
+    f->device = device_id; f->height = height; f->width = width;
+    const size_t n = (size_t)height * width;
+    f->view.n = (int)n;
+    f->view.inv_depth_range = 100 - 0.01;  // m_nMaxInvDepth - m_nMinInvDepth, depth_filter.cpp:138-141
+    double **arrays[] = {&f->view.a, &f->view.b, &f->view.mu, &f->view.cov, &f->stage_mu, &f->stage_cov, &f->stage_out};
+    for (double **p : arrays)
+        if (hipMalloc(p, n * sizeof(double)) != hipSuccess) {
+            chisel_hip_depth_filter_destroy(f);
+            return fail(CHISEL_HIP_ERR_HIP, "hipMalloc failed");
+        }
+    hipLaunchKernelGGL(filter_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, f->view);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    *out = f;
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_depth_filter_destroy(chisel_hip_depth_filter *f) {
+    if (!f) return CHISEL_HIP_OK;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = {f->view.a, f->view.b, f->view.mu, f->view.cov, f->stage_mu, f->stage_cov, f->stage_out};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete f;
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_depth_filter_update(chisel_hip_depth_filter *f, const double *mu, const double *cov, double cov_all, int reciprocal,
+                                   int on_device) {
+    if (!f || !mu) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(f->device));
+    const size_t n = (size_t)f->view.n;
+    const double *d_mu = mu, *d_cov = cov;
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(f->stage_mu, mu, n * sizeof(double), hipMemcpyHostToDevice, 0));
+        d_mu = f->stage_mu;
+        if (cov) {
+            HIP_TRY(hipMemcpyAsync(f->stage_cov, cov, n * sizeof(double), hipMemcpyHostToDevice, 0));
+            d_cov = f->stage_cov;
+        }
+    }
+    hipLaunchKernelGGL(filter_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, f->view, d_mu, d_cov, cov_all, reciprocal);
+    HIP_TRY(hipGetLastError());
+    return CHISEL_HIP_OK;  // stream 0: ordered against the next call; reads wait
+}
+int chisel_hip_depth_filter_read(chisel_hip_depth_filter *f, int which, double *dst, int dst_on_device) {
+    if (!f || !dst || which < 0 || which > 6) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(f->device));
+    const size_t n = (size_t)f->view.n;
+    double *d_out = dst_on_device ? dst : f->stage_out;
+    hipLaunchKernelGGL(filter_read_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, f->view, which, d_out);
+    HIP_TRY(hipGetLastError());
+    if (!dst_on_device) HIP_TRY(hipMemcpyAsync(dst, d_out, n * sizeof(double), hipMemcpyDeviceToHost, 0));
+    HIP_TRY(hipStreamSynchronize(0));
     return CHISEL_HIP_OK;
 }
 

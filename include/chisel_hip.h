@@ -237,6 +237,26 @@ int chisel_hip_update_meshes_of(chisel_hip_map *map, const int *ids_xyz, int n);
 int chisel_hip_condition_depth(const double *src, int w0, int h0, int src_on_device, float *dst, int w, int h, int dst_on_device,
                                double intrinsics_fx_fy_cx_cy[4], void *hip_stream);
 
+/* ---- the step before that: the inverse-depth filter ----------------------------------------------
+ * DepthFilter (server_pose_graph/src/dense_mapping/depth_filter.cpp): per-pixel Gaussian x uniform mixture filter of the
+ * inverse depth a stereo matcher delivers; its state (a, b, mu, cov: four CV_64F maps) lives in HBM here.
+ *   create   DepthFilter::DepthFilter(height, width)            depth_filter.cpp:130-142
+ *   update   DepthFilter::Update(mUpdateMu, mUpdateCov)         depth_filter.cpp:177-259 (NormPdf :10-16)
+ *            cov == NULL: cov_all for every pixel (depth_estimator.cpp:293); reciprocal != 0: the update is 1.0 / mu[i]
+ *            (depth_estimator.cpp:286 fused in).  Arrays of width * height doubles, on the host or (flag) in HBM.
+ *   read     which = 0 GetA, 1 GetB, 2 GetInvDepth, 3 GetCov, 4 GetRatio (depth_filter.h:66-86), 5 the inverse-depth map
+ *            DepthEstimator keeps (1e-5 where the ratio is below 0.5, depth_estimator.cpp:387-398), 6 the depth map 1.0 / that
+ *            (server_keyframe.cpp:1117) -- the input of chisel_hip_condition_depth, so depth can stay in HBM from the
+ *            matcher to the TSDF.
+ * All arithmetic in double in the reference's order; exp() is the device library's (parity unpinned, tolerance in
+ * tests/test_gpu_filter.py).  PropogateDepth is not built: its only call site is commented out (server_pose_graph.cpp:891). */
+typedef struct chisel_hip_depth_filter chisel_hip_depth_filter;
+int chisel_hip_depth_filter_create(int height, int width, int device_id, chisel_hip_depth_filter **out);
+int chisel_hip_depth_filter_destroy(chisel_hip_depth_filter *filter);
+int chisel_hip_depth_filter_update(chisel_hip_depth_filter *filter, const double *mu, const double *cov, double cov_all, int reciprocal,
+                                   int on_device);
+int chisel_hip_depth_filter_read(chisel_hip_depth_filter *filter, int which, double *dst, int dst_on_device);
+
 /* Binary dump / restore of the whole map (the correct counterpart of chisel_ros FillChunkMessage,
  * Serialization.h:31-84, whose bit packing loses data; also checkpoint / resume).  File: 32-byte header
  * {"CHSLHIP1", int32 chunk edge, float resolution, int32 has_colour, int64 n_chunks, 4 spare bytes}, then per chunk, in
