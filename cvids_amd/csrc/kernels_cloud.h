@@ -680,7 +680,9 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
             const bool unit_updated = __any((int)upd) != 0;
             if (unit_updated && lane == 0) atomicOr(&s_upd, 1u);
             __syncthreads();
-            if (s_upd != 0u && slot < 0) {  // block-uniform
+            const unsigned any_updated = s_upd;  // some unit of this chunk so far
+            __syncthreads();                     // (a fast wave must not raise the flag of the next round before everybody has read it)
+            if (any_updated != 0u && slot < 0) {  // block-uniform
                 if (tid == 0) {
                     s_slot = create_chunk(Mc, cx, cy, cz);
                     if (s_slot >= 0) n_new++;
