@@ -257,3 +257,38 @@ def test_sharded_clouds_equal_the_unsharded_map(hip_lib, world):
     cs = [s_.counters() for s_ in shards]
     for k in ("sdf", "col", "probe", "carved", "new_chunks", "updated_chunks", "work_chunks"):
         assert c1[k] == sum(c[k] for c in cs), k
+
+
+def _random_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    # the reference subtracts the sensor's world z from a sensor-frame z (ProjectionIntegrator.cpp:89): only small z offsets fuse anything
+    T[:3, 3] = [rng.uniform(-1.0, 1.0), rng.uniform(-1.0, 1.0), rng.uniform(-0.03, 0.03)]
+    return T.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_unorganised_clouds_and_arbitrary_poses(hip_lib, oracle_mod, seed):
+    """Points in no particular order (nothing like image rows), sensors rotated about every axis, negative chunk ids: the
+    result depends on the cloud order only through the per-voxel sequence of updates, which must still be the reference's."""
+    rng = np.random.default_rng(seed)
+    N = [16, 8, 16, 32][seed - 1]
+    om, gm, integ = _mk(oracle_mod, N, 0.02, True, [("inverse", 2.0), ("constant", 0.07), ("quadratic", 3.0), ("inverse", 1.5)][seed - 1],
+                        carving_dist=0.02)
+    for k in range(3):
+        n = 6000
+        # a bumpy sheet in front of the sensor, visited in random order, with repeated points
+        uv = rng.uniform(-0.5, 0.5, (n, 2))
+        z = 1.1 + 0.15 * np.sin(5 * uv[:, 0]) * np.cos(4 * uv[:, 1]) + rng.normal(0, 0.004, n)
+        pts = np.stack([uv[:, 0] * z, uv[:, 1] * z, z], axis=1).astype(np.float32)
+        pts[100:200] = pts[0:100]
+        col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        pose = _random_pose(rng)
+        _step(om, gm, integ, pts, col if k != 1 else None, pose, truncation=0.1 + 0.1 * k, max_dist=3.0, what="seed %d cloud %d" % (seed, k))
+    assert om.num_chunks() > 3
