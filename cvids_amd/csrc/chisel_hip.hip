@@ -1408,7 +1408,7 @@ int chisel_hip_debug_cloud_stats(chisel_hip_map *m, int64_t out[4]) {
     HIP_TRY(hipStreamSynchronize(m->stream));
     int ctl[2] = {0, 0};
     HIP_TRY(hipMemcpy(ctl, m->cloud.view.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
-    const int units = std::min(ctl[0], CLOUD_MAX_LISTED) * CloudUnits(m->N).count;
+    const int units = std::min(ctl[0], CLOUD_MAX_LISTED) * CloudUnits(m->N, 0, cloud_unit_depth(m->N)).count;
     std::vector<int> off((size_t)units + 1);
     HIP_TRY(hipMemcpy(off.data(), m->cloud.view.offsets, off.size() * sizeof(int), hipMemcpyDeviceToHost));
     int64_t mx = 0, used = 0;

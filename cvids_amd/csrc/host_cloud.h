@@ -34,7 +34,7 @@ int ensure_cloud_buffers(chisel_hip_map *m, int64_t n) {
         HIP_TRY(hipMalloc(&C.table_keys, (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t)));
         HIP_TRY(hipMalloc(&C.table_vals, (size_t)CLOUD_TABLE_SLOTS * sizeof(int)));
         HIP_TRY(hipMalloc(&C.listed, (size_t)CLOUD_MAX_LISTED * sizeof(uint64_t)));
-        const size_t units = (size_t)CLOUD_MAX_LISTED * CloudUnits(m->N).count;
+        const size_t units = (size_t)CLOUD_MAX_LISTED * CloudUnits(m->N, 0, cloud_unit_depth(m->N)).count;
         HIP_TRY(hipMalloc(&C.offsets, (units + 1) * sizeof(int)));
         HIP_TRY(hipMalloc(&C.cursors, units * sizeof(int)));
         HIP_TRY(hipMalloc(&C.ctl, 16 * sizeof(int)));
@@ -114,6 +114,7 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
     P.depth_limit = P.with_color ? 5.0f : 2.0f;                         // :131 / :69
     P.n_points = n;
     P.N = m->N;
+    P.depth = cloud_unit_depth(m->N);
     // Register axis of cloud_integrate_kernel: the world axis closest to the sensor's y axis (second column of the rotation).
     // Any choice gives the same voxels; this one spreads a batch of consecutive points of an organised cloud over the lanes.
     {
@@ -126,7 +127,7 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
     const int tiles = (n + CLOUD_TILE - 1) / CLOUD_TILE;
     HIP_TRY(hipMemsetAsync(C.table_keys, 0xff, (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t), m->stream));
     HIP_TRY(hipMemsetAsync(C.ctl, 0, 16 * sizeof(int), m->stream));
-    const int units_per_chunk = CloudUnits(m->N).count;
+    const int units_per_chunk = CloudUnits(m->N, P.jaxis, P.depth).count;
     const size_t units = (size_t)CLOUD_MAX_LISTED * units_per_chunk;
     HIP_TRY(hipMemsetAsync(C.offsets, 0, (units + 1) * sizeof(int), m->stream));
     HIP_TRY(hipMemsetAsync(C.cursors, 0, units * sizeof(int), m->stream));

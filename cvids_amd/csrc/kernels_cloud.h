@@ -28,12 +28,14 @@
 namespace chisel_hip {
 
 constexpr int CLOUD_TILE = 256;                  // points per workgroup in the per-point kernels
-constexpr unsigned CLOUD_TABLE_SLOTS = 1u << 17; // open-addressing table of the listed chunks of one cloud
-constexpr int CLOUD_MAX_LISTED = 1 << 16;
+constexpr unsigned CLOUD_TABLE_SLOTS = 1u << 16; // open-addressing table of the listed chunks of one cloud
+constexpr int CLOUD_MAX_LISTED = 1 << 14;
 constexpr int CLOUD_PAIRS_PER_POINT = 16;        // capacity of the (chunk, point) list, per point of the cloud
 constexpr int CLOUD_MAX_RANGE = 4096;            // chunk boxes around one ray that are looked at
 constexpr int CLOUD_SORT_WORDS = 8192;           // LDS bitmap of cloud_sort_kernel (32 KB): 262 144 point indices per pass
-constexpr int CLOUD_MAX_UNITS = 64;              // cubes of 8 x 8 x 8 voxels per chunk (32-voxel chunks)
+#ifndef CLOUD_DEPTH_16
+#define CLOUD_DEPTH_16 4                         // unit depth for 16-voxel chunks (8, 4 or 2; measured in DESIGN.md 3.3)
+#endif
 constexpr int CLOUD_GRID = 2048;                 // persistent grids of the per-chunk kernels (<= INTEGRATE_MAX_GRID)
 // error_flag values of this path (1, 2: chunk pool / hash, kernels_integrate.h)
 constexpr int CLOUD_ERR_CAPACITY = 3;            // too many listed chunks or (chunk, point) pairs
@@ -57,6 +59,7 @@ struct CloudParams {
     int n_points;
     int N;
     int jaxis;               // world axis each lane of cloud_integrate_kernel keeps in registers (a speed choice, host_cloud.h)
+    int depth;               // voxels per lane along that axis = unit size on it (cloud_unit_depth)
 };
 
 struct CloudView {
@@ -305,11 +308,21 @@ __global__ __launch_bounds__(CLOUD_TILE) void cloud_prepare_kernel(CloudParams P
     }
 }
 
-// ---- units: a chunk is split into cubes of 8 x 8 x 8 voxels, one wave each ------------------------------------------------------
+// ---- units: a chunk is split into boxes of 8 x 8 voxels across the lanes and `depth` voxels along the register axis, one wave each
+// (smaller units = fewer rays per wave: the longest ray list of a unit bounds the kernel)
+__host__ __device__ constexpr int cloud_unit_depth(int N) { return N == 16 ? CLOUD_DEPTH_16 : (N == 8 ? 4 : 8); }
 struct CloudUnits {
-    int per_edge;    // cubes per chunk edge
-    int count;       // 1 (N = 8), 8 (N = 16), 64 (N = 32)
-    __host__ __device__ explicit CloudUnits(int N) : per_edge(N / 8), count((N / 8) * (N / 8) * (N / 8)) {}
+    int edge[3];     // unit size per world axis
+    int per[3];      // units per chunk edge
+    int count;       // units per chunk
+    __host__ __device__ CloudUnits(int N, int jaxis, int depth) {
+        for (int k = 0; k < 3; k++) {
+            edge[k] = k == jaxis ? depth : 8;
+            per[k] = N / edge[k];
+        }
+        count = per[0] * per[1] * per[2];
+    }
+    __host__ __device__ int index(int ux, int uy, int uz) const { return (uz * per[1] + uy) * per[0] + ux; }
 };
 
 // ---- (unit, point) pairs -------------------------------------------------------------------------------------------------------
@@ -348,7 +361,7 @@ __device__ inline void cloud_enumerate(const CloudParams &P, const CloudView &C,
         if (report) atomicExch(M.error_flag, CLOUD_ERR_RANGE);
         return;
     }
-    const CloudUnits U(P.N);
+    const CloudUnits U(P.N, P.jaxis, P.depth);
     const float round = 1.0f / P.ip.res;
     for (int cz = c0[2]; cz <= c1[2]; cz++) {
         int zl, zh;
@@ -361,9 +374,9 @@ __device__ inline void cloud_enumerate(const CloudParams &P, const CloudView &C,
                 if (!axis_range(r.ax, r.bx, cx, P.N, P.ip.res, round, xl, xh)) continue;
                 const int idx = cloud_table_find(C, pack_id(cx, cy, cz));
                 if (idx < 0) continue;
-                for (int uz = zl >> 3; uz <= (zh >> 3); uz++)
-                    for (int uy = yl >> 3; uy <= (yh >> 3); uy++)
-                        for (int ux = xl >> 3; ux <= (xh >> 3); ux++) f(idx * U.count + (uz * U.per_edge + uy) * U.per_edge + ux);
+                for (int uz = zl / U.edge[2]; uz <= zh / U.edge[2]; uz++)
+                    for (int uy = yl / U.edge[1]; uy <= yh / U.edge[1]; uy++)
+                        for (int ux = xl / U.edge[0]; ux <= xh / U.edge[0]; ux++) f(idx * U.count + U.index(ux, uy, uz));
             }
         }
     }
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256) void cloud_sort_kernel(CloudParams P, CloudVie
     __shared__ int s_scan[256];
     __shared__ int s_lo, s_hi;
     const int tid = threadIdx.x;
-    const int n_units = min(C.ctl[0], CLOUD_MAX_LISTED) * CloudUnits(P.N).count;
+    const int n_units = min(C.ctl[0], CLOUD_MAX_LISTED) * CloudUnits(P.N, P.jaxis, P.depth).count;
     for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         const int off = C.offsets[unit];
         const int cnt = min(C.offsets[unit + 1], C.pairs_capacity) - off;
@@ -493,9 +506,9 @@ __global__ __launch_bounds__(256) void cloud_sort_kernel(CloudParams P, CloudVie
 }
 
 // ---- per chunk: the update ----------------------------------------------------------------------------------------------------
-// One wave per unit (cube of 8 x 8 x 8 voxels); the waves of a workgroup take units of the same chunk and meet only to look the
-// chunk up, to create it and to move on.  A lane holds the 8 voxels of one line of its cube along world axis `jaxis` in REGISTERS
-// for the whole list of rays (lanes = the 8 x 8 positions on the other two axes).  Rays are taken 64 at a time, in cloud order:
+// One wave per unit (box of 8 x 8 x D voxels, D along world axis `jaxis`); the waves of a workgroup take units of the same chunk
+// and meet only to look the chunk up, to create it and to move on.  A lane holds the D voxels of one line of its box along `jaxis`
+// in REGISTERS for the whole list of rays (lanes = the 8 x 8 positions on the other two axes).  Rays are taken 64 at a time, in cloud order:
 //   walk   lane r walks ray r (Raycast.cpp:35-128) and sets bit r in the mask of every voxel of the cube it meets (LDS, 64 bits
 //          per voxel);
 //   apply  every lane goes through the masks of its voxels and applies the rays whose bits are set, lowest bit first = cloud
@@ -506,10 +519,10 @@ __global__ __launch_bounds__(256) void cloud_sort_kernel(CloudParams P, CloudVie
 // many lanes.
 template <int N>
 struct CloudGeom {
-    static constexpr int UV = 512;                             // voxels per unit
-    static constexpr int E = N / 8;                            // units per chunk edge
-    static constexpr int U = E * E * E;                        // units per chunk
-    static constexpr int WAVES = U < 8 ? U : 8;                // units in flight per workgroup
+    static constexpr int D = cloud_unit_depth(N);              // voxels per lane
+    static constexpr int UV = 64 * D;                          // voxels per unit
+    static constexpr int U = (N / 8) * (N / 8) * (N / D);      // units per chunk
+    static constexpr int WAVES = U < 16 ? U : 16;              // units in flight per workgroup
 };
 
 // ColorVoxel::Integrate(r, g, b, 1) (ColorVoxel.h:65-85) on packed words, any weight: color_integrate_fresh's arithmetic is exact
@@ -550,6 +563,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
     lane_xyz[ja] = 0; lane_xyz[aa] = la; lane_xyz[ab] = lb;
     mask_mult[ja] = 64; mask_mult[aa] = 1; mask_mult[ab] = 8;
     const int j_stride = ja == 0 ? 1 : (ja == 1 ? N : N * N);
+    const CloudUnits units(N, ja, G::D);
     unsigned n_hits = 0, n_sdf = 0, n_carved = 0, n_col = 0, n_new = 0, n_updated = 0, n_items = 0;
 
     for (int idx = blockIdx.x; idx < n_listed; idx += gridDim.x) {
@@ -569,11 +583,12 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
 
         for (int round_i = 0; round_i < G::U / G::WAVES; round_i++) {
             const int u = round_i * G::WAVES + wave;
-            const int bx = (u % G::E) * 8, by = ((u / G::E) % G::E) * 8, bz = (u / (G::E * G::E)) * 8;
+            const int bx = (u % units.per[0]) * units.edge[0], by = ((u / units.per[0]) % units.per[1]) * units.edge[1],
+                      bz = (u / (units.per[0] * units.per[1])) * units.edge[2];
             const int off = C.offsets[idx * G::U + u];
             const int cnt = min(C.offsets[idx * G::U + u + 1], C.pairs_capacity) - off;
-            float sdf[8], wgt[8];
-            unsigned col[COLOR ? 8 : 1];
+            float sdf[G::D], wgt[G::D];
+            unsigned col[COLOR ? G::D : 1];
             bool upd = false;
             // first voxel of the lane's line, in chunk coordinates
             const int x0 = bx + lane_xyz[0], y0 = by + lane_xyz[1], z0 = bz + lane_xyz[2];
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
                 // the lane's voxels into registers (a chunk that does not exist yet holds default voxels: DistVoxel.cpp:27-31,
                 // ColorVoxel.cpp:27-31)
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < G::D; j++) {
                     const size_t g = (size_t)slot * V + g0 + (size_t)j * j_stride;
                     sdf[j] = slot >= 0 ? M.sdf[g] : 99999.0f;
                     wgt[j] = slot >= 0 ? M.wgt[g] : 0.0f;
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
                             } else {
                                 do {
                                     const unsigned cxl = (unsigned)(w.x - bx), cyl = (unsigned)(w.y - by), czl = (unsigned)(w.z - bz);
-                                    if (cxl < 8u && cyl < 8u && czl < 8u)
+                                    if (cxl < (unsigned)units.edge[0] && cyl < (unsigned)units.edge[1] && czl < (unsigned)units.edge[2])
                                         atomicOr(&s_mask[wave][cxl * mask_mult[0] + cyl * mask_mult[1] + czl * mask_mult[2]][lane >> 5],
                                                  1u << (lane & 31));
                                 } while (w.next());
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
 #ifndef CLOUD_ABLATE_APPLY
                     // ---- apply: per voxel, the rays of this batch that met it, in cloud order
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
+                    for (int j = 0; j < G::D; j++) {
                         unsigned m0 = s_mask[wave][j * 64 + lane][0], m1 = s_mask[wave][j * 64 + lane][1];
                         if ((m0 | m1) == 0u) continue;
                         s_mask[wave][j * 64 + lane][0] = 0u;
@@ -692,7 +707,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
             }
             if (unit_updated && slot >= 0) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < G::D; j++) {
                     const size_t g = (size_t)slot * V + g0 + (size_t)j * j_stride;
                     M.sdf[g] = sdf[j];
                     M.wgt[g] = wgt[j];
