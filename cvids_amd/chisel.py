@@ -230,31 +230,49 @@ class Chisel:
         check(self.L.chisel_hip_reset(self.h))
 
     # ---- meshing a sharded map: halo chunks (chisel_hip.h "meshing a sharded map") ------------------------------
-    def ExportChunks(self, ids):
-        """-> (sdf [n, V] float32, weight [n, V] float32, rgbw [n, V, 4] uint8 or None, found [n] int32) of the listed chunks"""
+    def ExportChunks(self, ids, device=False):
+        """-> (sdf [n, V] float32, weight [n, V] float32, rgbw [n, V, 4] uint8 or None, found [n] int32) of the listed chunks;
+        device=True: the three payload arrays are torch CUDA tensors (they never visit the host), `found` stays a numpy array"""
         ids = np.ascontiguousarray(np.asarray(ids, np.int32).reshape(-1, 3))
         n = len(ids)
-        sdf = np.empty((n, self.V), np.float32)
-        wgt = np.empty((n, self.V), np.float32)
-        col = np.empty((n, self.V, 4), np.uint8) if self.use_color else None
         found = np.zeros(n, np.int32)
+        if device:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            sdf = torch.empty((n, self.V), dtype=torch.float32, device=dev)
+            wgt = torch.empty((n, self.V), dtype=torch.float32, device=dev)
+            col = torch.empty((n, self.V, 4), dtype=torch.uint8, device=dev) if self.use_color else None
+            ptr = lambda t: t.data_ptr() if t is not None else None
+        else:
+            sdf = np.empty((n, self.V), np.float32)
+            wgt = np.empty((n, self.V), np.float32)
+            col = np.empty((n, self.V, 4), np.uint8) if self.use_color else None
+            ptr = lambda a: a.ctypes.data if a is not None else None
         if n:
-            check(self.L.chisel_hip_export_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n, sdf.ctypes.data, wgt.ctypes.data,
-                                                  col.ctypes.data if col is not None else None, found.ctypes.data_as(C.POINTER(C.c_int)), 0))
+            check(self.L.chisel_hip_export_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n, ptr(sdf), ptr(wgt), ptr(col),
+                                                  found.ctypes.data_as(C.POINTER(C.c_int)), int(bool(device))))
         return sdf, wgt, col, found
 
     def ImportGhostChunks(self, ids, sdf, wgt, col=None, found=None):
+        """payload: numpy arrays, or torch CUDA tensors (used in place)"""
         ids = np.ascontiguousarray(np.asarray(ids, np.int32).reshape(-1, 3))
         n = len(ids)
         if not n:
             return
-        sdf = np.ascontiguousarray(sdf, np.float32)
-        wgt = np.ascontiguousarray(wgt, np.float32)
-        col = np.ascontiguousarray(col, np.uint8) if col is not None else None
+        on_device = not isinstance(sdf, np.ndarray) and getattr(sdf, "is_cuda", False)
+        if on_device:
+            sdf, wgt = sdf.contiguous(), wgt.contiguous()
+            col = col.contiguous() if col is not None else None
+            ptr = lambda t: t.data_ptr() if t is not None else None
+        else:
+            sdf = np.ascontiguousarray(sdf, np.float32)
+            wgt = np.ascontiguousarray(wgt, np.float32)
+            col = np.ascontiguousarray(col, np.uint8) if col is not None else None
+            ptr = lambda a: a.ctypes.data if a is not None else None
         found = np.ascontiguousarray(found, np.int32) if found is not None else None
-        check(self.L.chisel_hip_import_ghost_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n, sdf.ctypes.data, wgt.ctypes.data,
-                                                    col.ctypes.data if col is not None else None,
-                                                    found.ctypes.data_as(C.POINTER(C.c_int)) if found is not None else None, 0))
+        check(self.L.chisel_hip_import_ghost_chunks(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n, ptr(sdf), ptr(wgt), ptr(col),
+                                                    found.ctypes.data_as(C.POINTER(C.c_int)) if found is not None else None, int(on_device)))
+        self._keep = [sdf, wgt, col]
 
     def DropGhostChunks(self):
         check(self.L.chisel_hip_drop_ghost_chunks(self.h))

@@ -164,10 +164,11 @@ class LocalShardGroup:
     """All shards of a map in ONE process (tests; a single GPU holding several shards): the same protocol as
     ShardedChisel.UpdateMeshes with the exchange done by direct calls."""
 
-    def __init__(self, shards):
+    def __init__(self, shards, device_payload=True):
         self.shards = shards
         self.world = len(shards)
         self.calls = 0
+        self.device_payload = device_payload
 
     def IntegratePointCloud(self, integrator, cloud, extrinsic, truncation, max_dist):
         """Chisel::IntegratePointCloud on every shard: each lists and updates only the chunks it owns (cloud_prepare_kernel)."""
@@ -186,7 +187,7 @@ class LocalShardGroup:
         plans = [mesh_plan(union, r, self.world, owner) for r in range(self.world)]
         for r, (jobs, requests) in enumerate(plans):
             for o, ids in requests.items():
-                sdf, wgt, col, found = self.shards[o].ExportChunks(ids)
+                sdf, wgt, col, found = self.shards[o].ExportChunks(ids, device=self.device_payload)  # payload stays in HBM
                 self.shards[r].ImportGhostChunks(ids, sdf, wgt, col, found)
         for r, (jobs, _) in enumerate(plans):
             self.shards[r].UpdateMeshesOf(jobs)
@@ -243,8 +244,7 @@ class ShardedChisel:
 
     def UpdateMeshes(self, force=False):
         """Chisel::UpdateMeshes of the sharded map: every rank ends up with the meshes of the chunks it owns (mesh_plan above).
-        The id lists and the halo chunks travel as objects (all_gather_object / all_to_all via gather of lists): this is
-        the functional path; the voxel payload of a recompute is a few MB per rank."""
+        The id lists travel as objects (small); the halo chunks as one all-to-all per voxel array on device tensors."""
         from .chisel import chunk_owner
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
@@ -262,17 +262,43 @@ class ShardedChisel:
         jobs, requests = mesh_plan(union, rank, world, lambda i: chunk_owner(i, world, 2))
         asked = [None] * world                      # asked[o] = what rank o wants from each rank
         dist.all_gather_object(asked, requests)
-        replies = {}                                # what this rank serves: requester -> (ids, sdf, wgt, col, found)
-        for requester, req in enumerate(asked):
-            ids = req.get(rank, []) if requester != rank else []
-            if ids:
-                replies[requester] = (ids,) + tuple(self.map.ExportChunks(ids))
-        served = [None] * world
-        dist.all_gather_object(served, replies)     # functional form of an all-to-all
-        for o, rep in enumerate(served):
-            if o != rank and rank in rep:
-                ids, sdf, wgt, col, found = rep[rank]
-                self.map.ImportGhostChunks(ids, sdf, wgt, col, found)
+        # the voxel payload travels as one all-to-all per array (RCCL on device tensors: the chunks never visit the host);
+        # rows for rank r = the chunks r asked of this rank, in r's order
+        torch = self.x.torch
+        dev = self.x.device
+        send_ids = [list(asked[r].get(rank, [])) if r != rank else [] for r in range(world)]
+        recv_ids = [list(requests.get(o, [])) for o in range(world)]
+        n_send, n_recv = [len(v) for v in send_ids], [len(v) for v in recv_ids]
+        flat_send = [i for v in send_ids for i in v]
+        flat_recv = [i for v in recv_ids for i in v]
+        on_gpu = dev.type == "cuda"
+        if on_gpu:
+            sdf_s, wgt_s, col_s, found_s = self.map.ExportChunks(flat_send, device=True)
+        else:
+            a, b, c, found_s = self.map.ExportChunks(flat_send)
+            sdf_s, wgt_s = torch.from_numpy(np.ascontiguousarray(a, np.float32)), torch.from_numpy(np.ascontiguousarray(b, np.float32))
+            col_s = torch.from_numpy(np.ascontiguousarray(c, np.uint8)) if c is not None else None
+        found_s = torch.from_numpy(np.ascontiguousarray(found_s, np.int32)).to(dev)
+        rows = sdf_s.shape[1] if sdf_s.dim() == 2 else 0
+        total = sum(n_recv)
+        sdf_r = torch.empty((total,) + tuple(sdf_s.shape[1:]), dtype=torch.float32, device=dev)
+        wgt_r = torch.empty((total,) + tuple(wgt_s.shape[1:]), dtype=torch.float32, device=dev)
+        found_r = torch.empty((total,), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(sdf_r, sdf_s, n_recv, n_send)
+        dist.all_to_all_single(wgt_r, wgt_s, n_recv, n_send)
+        dist.all_to_all_single(found_r, found_s, n_recv, n_send)
+        col_r = None
+        if col_s is not None:
+            col_r = torch.empty((total,) + tuple(col_s.shape[1:]), dtype=torch.uint8, device=dev)
+            dist.all_to_all_single(col_r, col_s, n_recv, n_send)
+        if on_gpu:
+            torch.cuda.current_stream(dev).synchronize()  # the map imports on its own stream
+        if total:
+            found_h = found_r.cpu().numpy()
+            if on_gpu:
+                self.map.ImportGhostChunks(flat_recv, sdf_r, wgt_r, col_r, found_h)
+            else:
+                self.map.ImportGhostChunks(flat_recv, sdf_r.numpy(), wgt_r.numpy(), None if col_r is None else col_r.numpy(), found_h)
         self.map.UpdateMeshesOf(jobs)
         self.map.DropGhostChunks()
 
