@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same stream the CPU oracle is timed on (about 1 s each at 1 cm)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-frames", action="store_true", help="hand host (pageable) depth buffers to the library: the PCIe-inclusive rate (never `value`)")
+    ap.add_argument("--sim-shards", type=int, default=0, help="diagnostic, 1 GPU: integrate only the chunks of one shard of an N-way sharded map "
+                                                               "(what one rank of an N-GPU run computes; every rank sees every frame)")
+    ap.add_argument("--sim-rank", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (functional check of the N > 1 logic on one GPU)")
     return ap.parse_args()
 
@@ -197,7 +200,8 @@ def main():
 
     def new_map():
         m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
-                   n_shards=world, shard_rank=rank)
+                   n_shards=args.sim_shards if (args.sim_shards and world == 1) else world,
+                   shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank)
         m._use(integ)
         m.px = PipelinedExchange(xch, m) if world > 1 else None  # RCCL -> integrate ordering: events, no host wait
         return m
