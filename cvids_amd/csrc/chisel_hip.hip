@@ -323,7 +323,7 @@ template <int N>
 int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidParams &PP, const CullParams &CP, const IntegrateParams &IP,
                  bool color) {
     using G = Geom<N>;
-    const int total = CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2];
+    const int total = CullSpace(CP).total;  // candidate slots: every id of the union range, or the owned ones of a sharded map
     g_host_timer.lap(2);
     PyramidView pyr = m->pyr;
     pyr.data = bs.pyr_data;

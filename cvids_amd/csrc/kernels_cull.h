@@ -354,6 +354,59 @@ __device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
     return false;
 }
 
+// The candidate ids one shard has to judge.  Unsharded: every id of the union range, in the reference's order (x outer, z
+// inner, ChunkManager.cpp:195-199).  Sharded: only the ids this shard owns -- chunk_owner() is (bx + 3 by + 5 bz) mod n on
+// super-blocks of b^3 chunks, so for each (by, bz) the owned bx are one residue class: slot j of (by, bz) is the j-th owned bx
+// at or after the range's first super-block.  (Before, every shard walked the whole range with n - 1 of n lanes idle.)
+struct CullSpace {
+    int sharded;
+    int b;                 // super-block edge in chunks
+    int n;                 // shards
+    int rank;
+    int sb0[3], nsb[3];    // first super-block of the range and super-blocks per axis
+    int per_row;           // owned super-blocks per (by, bz): ceil(nsb[0] / n)
+    int total;             // candidate slots (some fall outside the range and are skipped)
+    __host__ __device__ explicit CullSpace(const CullParams &P) {
+        sharded = P.ip.n_shards > 1;
+        b = P.ip.shard_block > 0 ? P.ip.shard_block : 1;
+        n = P.ip.n_shards;
+        rank = P.ip.shard_rank;
+        if (!sharded) {
+            total = P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
+            per_row = 0;
+            for (int a = 0; a < 3; a++) sb0[a] = nsb[a] = 0;
+            return;
+        }
+        for (int a = 0; a < 3; a++) {
+            sb0[a] = floor_div(P.range_min[a], b);
+            nsb[a] = floor_div(P.range_min[a] + P.range_dim[a] - 1, b) - sb0[a] + 1;
+        }
+        per_row = (nsb[0] + n - 1) / n;
+        total = per_row * nsb[1] * nsb[2] * b * b * b;
+    }
+    // slot c -> chunk id; false: nothing to judge in this slot
+    __device__ bool id(const CullParams &P, int c, int &cx, int &cy, int &cz) const {
+        if (c >= total) return false;
+        if (!sharded) {
+            const int iz = c % P.range_dim[2];
+            const int iy = (c / P.range_dim[2]) % P.range_dim[1];
+            const int ix = c / (P.range_dim[2] * P.range_dim[1]);
+            cx = P.range_min[0] + ix; cy = P.range_min[1] + iy; cz = P.range_min[2] + iz;
+            return true;
+        }
+        const int cell = c % (b * b * b), s = c / (b * b * b);
+        const int ibz = s % nsb[2], iby = (s / nsb[2]) % nsb[1], j = s / (nsb[2] * nsb[1]);
+        const int by = sb0[1] + iby, bz = sb0[2] + ibz;
+        int r = (rank - 3 * by - 5 * bz - sb0[0]) % n;  // first owned bx at or after sb0[0]: bx = sb0[0] + r (mod n)
+        if (r < 0) r += n;
+        const int bx = sb0[0] + r + j * n;
+        if (bx >= sb0[0] + nsb[0]) return false;
+        cx = bx * b + cell % b; cy = by * b + (cell / b) % b; cz = bz * b + cell / (b * b);
+        return cx >= P.range_min[0] && cx < P.range_min[0] + P.range_dim[0] && cy >= P.range_min[1] && cy < P.range_min[1] + P.range_dim[1] &&
+               cz >= P.range_min[2] && cz < P.range_min[2] + P.range_dim[2];
+    }
+};
+
 // One wave per frame of the batch over the same 64 chunk ids (block = 64 * KL threads, KL = frames rounded up to a
 // power of two): every per-frame constant is wave-uniform (scalar loads), the per-frame verdicts meet in LDS.
 // INLINE (the map is idle: nothing to run beside, the caller is waiting): the k == 0 wave also does resolve_kernel's job
@@ -373,19 +426,14 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
 #define CSTAMP(i) do { } while (0)
 #endif
     CSTAMP(0);
-    const int total = P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
+    const CullSpace space(P);
     const int c = blockIdx.x * 64 + lane;
     int cx = 0, cy = 0, cz = 0;
     FrameBox fb;
     fb.flags = 0;
     int fl = 0;
     const float2 whole = (k < P.n_frames) ? whole_image_minmax(pyr, pyr.data + (size_t)k * P.pyr_stride) : make_float2(INFINITY, -INFINITY);
-    if (c < total) {
-        // reference order: x outer, y, z inner (ChunkManager.cpp:195-199)
-        const int iz = c % P.range_dim[2];
-        const int iy = (c / P.range_dim[2]) % P.range_dim[1];
-        const int ix = c / (P.range_dim[2] * P.range_dim[1]);
-        cx = P.range_min[0] + ix; cy = P.range_min[1] + iy; cz = P.range_min[2] + iz;
+    if (space.id(P, c, cx, cy, cz)) {
         if (k < P.n_frames && chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank)
             fl = cull_chunk_frame<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, whole, cx, cy, cz, fb);
     }
