@@ -292,3 +292,21 @@ def test_unorganised_clouds_and_arbitrary_poses(hip_lib, oracle_mod, seed):
         pose = _random_pose(rng)
         _step(om, gm, integ, pts, col if k != 1 else None, pose, truncation=0.1 + 0.1 * k, max_dist=3.0, what="seed %d cloud %d" % (seed, k))
     assert om.num_chunks() > 3
+
+
+def test_cloud_outside_the_supported_envelope_is_reported(hip_lib, oracle_mod):
+    """Chunk ids beyond +-2^20 cannot be packed: the call that waits reports CHISEL_HIP_ERR_UNSUPPORTED once, the map stays usable
+    and a following cloud still matches the oracle."""
+    from cvids_amd.capi import ChiselHipError
+    om, gm, integ = _mk(oracle_mod, 16, 0.02, True)
+    pose = synth.pose_yaw(0.0, (0.0, 0.0, 0.0))
+    far = np.array([[4.0e5, 0.0, 1.0], [0.0, 0.0, 1.0]], np.float32)   # the first point lies 400 km to the side
+    gm.IntegratePointCloud(integ, (far, None), pose, 0.1, 1e9)
+    with pytest.raises(ChiselHipError) as e:
+        gm.synchronize()
+    assert e.value.code == 5 and "point cloud" in str(e.value)
+    gm.synchronize()                       # reported once
+    gm.Reset()
+    gm.counters(reset=True)
+    pts, col, pose = _cloud("sphere_room", 1, 64, 48, 0.6, True)
+    _step(om, gm, integ, pts, col, pose, what="after the error")
