@@ -1464,6 +1464,32 @@ int chisel_hip_debug_stamps(chisel_hip_map *m, unsigned long long *out, int n_gr
     return CHISEL_HIP_OK;
 }
 // host-side frustum arithmetic of the product (host_frustum.h), for CPU-only tests against the oracle
+// the candidate ids cull_kernel hands to shard `rank` of `n_shards` for an id range (host evaluation of CullSpace; no GPU needed):
+// returns the number of slots, writes the ids of the slots that hold one (at most `capacity`), *count = how many do
+int chisel_hip_debug_cull_space(const int range_min[3], const int range_dim[3], int n_shards, int shard_rank, int shard_block, int *ids,
+                                int capacity, int *count) {
+    CullParams P;
+    memset(&P, 0, sizeof(P));
+    for (int a = 0; a < 3; a++) {
+        P.range_min[a] = range_min[a];
+        P.range_dim[a] = range_dim[a];
+    }
+    P.ip.n_shards = n_shards;
+    P.ip.shard_rank = shard_rank;
+    P.ip.shard_block = shard_block;
+    const CullSpace space(P);
+    int n = 0;
+    for (int c = 0; c < space.total; c++) {
+        int x, y, z;
+        if (!space.id(P, c, x, y, z)) continue;
+        if (n < capacity) {
+            ids[3 * n] = x; ids[3 * n + 1] = y; ids[3 * n + 2] = z;
+        }
+        n++;
+    }
+    *count = n;
+    return space.total;
+}
 int chisel_hip_debug_frustum_range(const float *pose, float near_plane, float far_plane, float fy, float cy, int W, int H,
                                    int chunk_n, float res, int *range_min3, int *range_dim3, float *planes24, float *corners24) {
     hostmath::FrustumRange fr = hostmath::frustum_range(pose, near_plane, far_plane, fy, cy, W, H, chunk_n, res);

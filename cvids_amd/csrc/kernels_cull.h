@@ -385,7 +385,7 @@ struct CullSpace {
         total = per_row * nsb[1] * nsb[2] * b * b * b;
     }
     // slot c -> chunk id; false: nothing to judge in this slot
-    __device__ bool id(const CullParams &P, int c, int &cx, int &cy, int &cz) const {
+    __host__ __device__ bool id(const CullParams &P, int c, int &cx, int &cy, int &cz) const {
         if (c >= total) return false;
         if (!sharded) {
             const int iz = c % P.range_dim[2];

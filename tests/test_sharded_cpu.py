@@ -301,3 +301,36 @@ def test_sharded_pointcloud_broadcast_world2(hip_lib):
         digest = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
         assert rec[0] == digest(pts) and rec[2] == digest(np.asarray(pose, np.float32)[:3, :4])
         assert rec[1] == (None if k == 2 else digest(cols))
+
+
+def test_cull_space_enumerates_exactly_the_owned_ids(hip_lib):
+    """CullSpace (kernels_cull.h): the candidate slots cull_kernel gives a shard hold every id of the range that the shard owns,
+    each once, and nothing else; the slot count is about 1 / n of the range (evaluated on the host, no GPU)."""
+    import ctypes as C
+    from cvids_amd.chisel import chunk_owner
+    L = hip_lib
+    i32p = C.POINTER(C.c_int)
+    L.chisel_hip_debug_cull_space.argtypes = [i32p, i32p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, i32p]
+    rng = np.random.default_rng(4)
+    for trial in range(12):
+        lo = rng.integers(-40, 20, 3).astype(np.int32)
+        dim = rng.integers(1, 23, 3).astype(np.int32)
+        n = int(rng.choice([1, 2, 3, 4, 8]))
+        box = [(x, y, z) for x in range(lo[0], lo[0] + dim[0]) for y in range(lo[1], lo[1] + dim[1]) for z in range(lo[2], lo[2] + dim[2])]
+        seen = set()
+        slots = 0
+        for rank in range(n):
+            cap = len(box) + 8
+            ids = np.zeros((cap, 3), np.int32)
+            cnt = C.c_int(0)
+            total = L.chisel_hip_debug_cull_space(lo.ctypes.data_as(i32p), dim.ctypes.data_as(i32p), n, rank, 2, ids.ctypes.data_as(i32p), cap,
+                                                  C.byref(cnt))
+            got = [tuple(int(v) for v in r) for r in ids[:cnt.value]]
+            assert len(set(got)) == len(got), "an id twice"
+            assert set(got) == {i for i in box if chunk_owner(i, n, 2) == rank}, (trial, n, rank)
+            assert not (seen & set(got))
+            seen.update(got)
+            slots += total
+        assert seen == set(box)
+        if n > 1:
+            assert slots <= len(box) + 8 * n * (dim[1] // 2 + 2) * (dim[2] // 2 + 2) * 2   # partial super-blocks and the rounded-up rows only
