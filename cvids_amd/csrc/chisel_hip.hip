@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -153,14 +154,16 @@ struct chisel_hip_map {
     std::vector<MeshArena> arenas;
     std::vector<std::pair<float *, size_t>> arena_pool;                // released arena buffers (floats), reused by later recomputes
     size_t mesh_need_hint = 0;                                         // floats the previous recompute needed (sizes the next arena)
-    hipEvent_t mesh_counted = nullptr;                                 // recorded behind the count kernel of a recompute
     struct PendingMeshes {                                             // a recompute whose per-chunk results are still on the device
         bool unchecked = false;                                        // its totals have not been looked at yet (check_mesh_totals)
         bool active = false;                                           // its per-chunk bookkeeping is outstanding (resolve_pending_meshes)
         int n = 0;                                                     // jobs
         int arena = -1;
     } pending_meshes;
-    int *mesh_totals_host = nullptr;                                   // pinned: totals + error flag of the recompute in flight
+    int *mesh_totals_host = nullptr;                                   // pinned: [0-3] totals, [4] error flag, [5] sequence number of the recompute in flight (written by the device), [7] check_device_error
+    int *mesh_totals_dev = nullptr;                                    // the same memory as the device addresses it
+    int *mesh_info_dev = nullptr;                                      // mesh_info_host as the device addresses it
+    int mesh_seq = 0;                                                  // recomputes queued so far
     JobInfo *mesh_info_host = nullptr;                                 // pinned: its first MESH_INFO_PREFETCH per-job records
     hipStream_t copy_stream = nullptr;                                 // small device->host copies that must not wait for queued batches
     std::vector<int> ghost_ids;                                        // chunks of other shards imported for meshing (x, y, z triples)
@@ -743,9 +746,12 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     }
     m->stream = m->own_stream;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
-    HIP_TRY_C(hipEventCreateWithFlags(&m->mesh_counted, hipEventDisableTiming));
     HIP_TRY_C(hipHostMalloc((void **)&m->mesh_totals_host, 8 * sizeof(int), hipHostMallocDefault));
+    memset(m->mesh_totals_host, 0, 8 * sizeof(int));
+    HIP_TRY_C(hipHostGetDevicePointer((void **)&m->mesh_totals_dev, m->mesh_totals_host, 0));
     HIP_TRY_C(hipHostMalloc((void **)&m->mesh_info_host, (size_t)MESH_INFO_PREFETCH * sizeof(JobInfo), hipHostMallocDefault));
+    HIP_TRY_C(hipHostGetDevicePointer((void **)&m->mesh_info_dev, m->mesh_info_host, 0));
+    static_assert(sizeof(JobInfo) == 8 * sizeof(int), "publish_totals_kernel moves the records as ints");
     HIP_TRY_C(hipEventCreateWithFlags(&m->call_event, hipEventDisableTiming));
     for (auto &bs : m->sets) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));
@@ -809,7 +815,6 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
-    if (m->mesh_counted) (void)hipEventDestroy(m->mesh_counted);
     if (m->mesh_totals_host) (void)hipHostFree(m->mesh_totals_host);
     if (m->mesh_info_host) (void)hipHostFree(m->mesh_info_host);
     clear_meshes(m);

@@ -20,11 +20,14 @@ void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena,
     MeshBuffers &B = m->mesh_buf;
     const JobInfo *bases = B.info;
     const int *totals = B.totals;
+    int *host_info = m->mesh_info_dev;
+    volatile int *host_flags = (volatile int *)m->mesh_totals_dev;
+    const int max_jobs = std::min(MESH_INFO_PREFETCH, B.capacity), seq = m->mesh_seq;
     const dim3 grid(4096), block(MESH_TRI_BLOCK);  // persistent: the number of triangles is read on the device
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats); break;
-        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats); break;
-        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats); break;
+        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq); break;
+        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq); break;
+        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq); break;
     }
 }
 
@@ -41,7 +44,10 @@ int ensure_mesh_jobs(chisel_hip_map *m, int n) {
     HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
     HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
     HIP_TRY(hipMalloc(&B.info, (size_t)cap * sizeof(JobInfo)));
-    if (!B.totals) HIP_TRY(hipMalloc(&B.totals, 8 * sizeof(int)));
+    if (!B.totals) {
+        HIP_TRY(hipMalloc(&B.totals, 8 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(B.totals, 0, 8 * sizeof(int), m->stream));
+    }
     B.capacity = cap;
     return CHISEL_HIP_OK;
 }
@@ -62,9 +68,8 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
         HIP_TRY(hipMalloc(&B.flags, (size_t)C * sizeof(unsigned)));
         HIP_TRY(hipMemsetAsync(B.flags, 0, (size_t)C * sizeof(unsigned), m->stream));
     }
-    HIP_TRY(hipMemsetAsync(mesh_totals(m), 0, 4 * sizeof(int), m->stream));
-    const long long threads = (long long)C * 27;
-    hipLaunchKernelGGL(mesh_mark_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, m->view, B.flags);
+    const long long threads = (long long)C * 27;  // (the mark kernel also zeroes the totals)
+    hipLaunchKernelGGL(mesh_mark_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, m->view, B.flags, mesh_totals(m));
     if (!extra.empty()) {
         // (rare) ids kept on the host: flag the ones that are resident
         const int ne = (int)(extra.size() / 3);
@@ -173,20 +178,17 @@ int recompute_meshes(chisel_hip_map *m) {
         if (rc_a) return rc_a;
     }
     launch_mesh_count(m);
-    HIP_TRY(hipEventRecord(m->mesh_counted, m->stream));
+    // the totals go straight into pinned memory behind the count kernel; they are looked at when the caller next touches the
+    // map (check_mesh_totals polls the sequence number): until then the host is free to queue the next batch's front half, and
+    // by then the triangle kernel is usually still running, so the next integration queues up behind it without a gap
+    m->mesh_seq++;
+    hipLaunchKernelGGL(publish_totals_kernel, dim3(1), dim3(64), 0, m->stream, (const int *)d_totals, (const int *)m->view.error_flag,
+                       (volatile int *)m->mesh_totals_dev, m->mesh_seq);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
         launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity);
     }
     HIP_TRY(hipGetLastError());
-    // the totals follow on their own stream as soon as the count kernel is through; they are looked at when the caller
-    // next touches the map (check_mesh_totals): until then the host is free to queue the next batch's front half
-    HIP_TRY(hipStreamWaitEvent(m->copy_stream, m->mesh_counted, 0));
-    HIP_TRY(hipMemcpyAsync(m->mesh_totals_host, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
-    HIP_TRY(hipMemcpyAsync(m->mesh_totals_host + 4, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->copy_stream));
-    // the per-job records of (typically all of) the jobs ride along: the bookkeeping at the next recompute is then host work only
-    HIP_TRY(hipMemcpyAsync(m->mesh_info_host, B.info, (size_t)std::min(MESH_INFO_PREFETCH, B.capacity) * sizeof(JobInfo), hipMemcpyDeviceToHost,
-                           m->copy_stream));
     m->pending_meshes.unchecked = true;
     m->pending_meshes.active = false;
     m->pending_meshes.arena = arena_id;
@@ -216,7 +218,18 @@ int check_mesh_totals(chisel_hip_map *m) {
     const bool color = m->cfg.use_color != 0;
     const MeshParams P = mesh_params(m);
     int arena_id = m->pending_meshes.arena;
-    HIP_TRY(wait_stream_spinning(m->copy_stream));
+    {
+        // the device writes the sequence number last (publish_totals_kernel)
+        volatile int *host = m->mesh_totals_host;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (host[5] != m->mesh_seq) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HIP_TRY(hipStreamSynchronize(m->stream));  // long queue in front of the recompute, or a failed launch: no more polling
+                if (host[5] != m->mesh_seq) return fail(CHISEL_HIP_ERR_HIP, "mesh totals were not published");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     int totals[4] = {m->mesh_totals_host[0], m->mesh_totals_host[1], m->mesh_totals_host[2], m->mesh_totals_host[3]};
     const int error_flag = m->mesh_totals_host[4];
     if (error_flag != 0) {  // a chunk of an earlier batch could not be allocated: the map is incomplete
@@ -286,7 +299,18 @@ int resolve_pending_meshes(chisel_hip_map *m) {
     m->pending_meshes.active = false;
     MeshBuffers &B = m->mesh_buf;
     const int n = m->pending_meshes.n, arena_id = m->pending_meshes.arena;
-    // the records of the first MESH_INFO_PREFETCH jobs are on the host already (pinned copy queued with the recompute)
+    // the records of the first MESH_INFO_PREFETCH jobs are on the host (mesh_triangle_kernel wrote them and then the sequence number)
+    {
+        volatile int *host = m->mesh_totals_host;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (host[6] != m->mesh_seq) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HIP_TRY(hipStreamSynchronize(m->stream));
+                if (host[6] != m->mesh_seq) return fail(CHISEL_HIP_ERR_HIP, "mesh job records were not published");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     std::vector<JobInfo> tail;
     if (n > MESH_INFO_PREFETCH) {
         tail.resize((size_t)n - MESH_INFO_PREFETCH);

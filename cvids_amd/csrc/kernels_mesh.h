@@ -237,8 +237,9 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
 // meshesToUpdate on the device (Chisel.h:175-189 marks the 27-neighbourhood of every updated chunk): one thread per
 // (slot, neighbour offset); a resident neighbour of a dirty chunk gets its mesh flag set.  Ids of the neighbourhood
 // that are not resident have no chunk to mesh (RecomputeMesh returns at once: ChunkManager.cpp:93-96).
-__global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag) {
+__global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag, int *totals) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 4) totals[t] = 0;  // the recompute's counters, filled from mesh_collect_kernel on (the next launch): no memset of their own
     const int slot = t / 27, o = t % 27;
     if (slot >= M.max_chunks || !M.slot_dirty[slot]) return;
     const uint64_t key = M.slot_key[slot];
@@ -514,12 +515,27 @@ template <int N>
 // The totals of the count kernel are read from the device (totals[0] triangles, totals[1] grids): the arena --
 // vertices | normals | colours | grids -- was picked before they were known.  A batch that does not fit its arena
 // writes nothing (the host, which reads the same totals, then runs the kernel again on a larger one).
+// Housekeeping that rides along (an extra kernel, copy or event on the map's stream would sit on the critical path in front of the
+// next integration): workgroup 0 writes the per-job records into pinned host memory (`host_info`, at most max_jobs of them; the
+// host needs them at the next recompute) and then `seq` into host_flags[6].
 __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
                                                                     const JobInfo *__restrict__ info, const TriRec *__restrict__ tris,
-                                                                    const int *__restrict__ totals, float *arena, size_t arena_floats) {
+                                                                    const int *__restrict__ totals, float *arena, size_t arena_floats, int *host_info,
+                                                                    volatile int *host_flags, int max_jobs, int seq) {
     const int n_tris = totals[0];
+    const int n_jobs = totals[3];
     const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[1] * 3;
-    if (nv3 * (P.use_color ? 3 : 2) + ng3 > arena_floats) return;
+    // a triangle list that overflowed (totals[2]) is incomplete: nothing is emitted, the host lists and emits again
+    const bool fits = totals[2] == 0 && nv3 * (P.use_color ? 3 : 2) + ng3 <= arena_floats;
+    if (blockIdx.x == 0) {
+        const int *src = reinterpret_cast<const int *>(info);
+        const int n = min(n_jobs, max_jobs) * 8;
+        for (int i = threadIdx.x; i < n; i += MESH_TRI_BLOCK) host_info[i] = src[i];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) host_flags[6] = seq;
+    }
+    if (fits) {
     float *vertices = arena, *normals = arena + nv3, *colors = P.use_color ? arena + 2 * nv3 : nullptr;
     float *grids = arena + nv3 * (P.use_color ? 3 : 2);
     // one thread per VERTEX: all three vertices of its triangle (the face normal needs them: three cheap interpolations),
@@ -578,6 +594,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         co[0] = col.x;
         co[1] = col.y;
         co[2] = col.z;
+    }
     }
     }
 }
