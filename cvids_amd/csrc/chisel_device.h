@@ -52,6 +52,11 @@ __host__ __device__ inline int chunk_owner(int x, int y, int z, int n_shards, in
     return h < 0 ? h + n_shards : h;
 }
 
+// The map's error flag lives in pinned host memory (the device addresses it through MapView::error_flag): a kernel that runs out
+// of chunk slots, hash entries or cloud capacity stores its code there, and the host reads it after a wait without a copy.
+// Plain store: every writer stores a nonzero code, the last one wins.
+__device__ inline void raise_error(int *flag, int code) { *reinterpret_cast<volatile int *>(flag) = code; }
+
 struct MapView {
     float *sdf;
     float *wgt;
@@ -65,7 +70,7 @@ struct MapView {
     int *free_top;
     unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS (filled by reduce_counters_kernel)
     unsigned long long *block_counters;  // [INTEGRATE_MAX_GRID][16] per-workgroup partial sums
-    int *error_flag;         // != 0: pool / hash exhausted
+    int *error_flag;         // != 0: pool / hash exhausted (pinned host memory, see raise_error)
     int max_chunks;
     unsigned long long *stamps;  // diagnostic builds (-DCHISEL_STAMPS) only: [workgroup][8] s_memrealtime stamps
 };

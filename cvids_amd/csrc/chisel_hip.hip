@@ -162,6 +162,7 @@ struct chisel_hip_map {
     } pending_meshes;
     int *mesh_totals_host = nullptr;                                   // pinned: [0-3] totals, [4] error flag, [5] sequence number of the recompute in flight (written by the device), [7] check_device_error
     int *mesh_totals_dev = nullptr;                                    // the same memory as the device addresses it
+    int *error_flag_host = nullptr;                                    // pinned: the map's error flag (view.error_flag is its device address)
     int *mesh_info_dev = nullptr;                                      // mesh_info_host as the device addresses it
     int mesh_seq = 0;                                                  // recomputes queued so far
     JobInfo *mesh_info_host = nullptr;                                 // pinned: its first MESH_INFO_PREFETCH per-job records
@@ -269,11 +270,11 @@ hipError_t wait_stream_spinning(hipStream_t st) {
 // Waits for everything queued on the map's stream (a caller that waits after every frame pays this per frame: the flag
 // lands in pinned memory and the wait polls) and reports a chunk that could not be allocated.
 int check_device_error(chisel_hip_map *m) {
-    HIP_TRY(hipMemcpyAsync(m->mesh_totals_host + 7, m->view.error_flag, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(wait_stream_spinning(m->stream));
-    const int flag = m->mesh_totals_host[7];
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const int flag = *(volatile int *)m->error_flag_host;  // written by the device (raise_error): no copy
     if (flag == CLOUD_ERR_CAPACITY || flag == CLOUD_ERR_RANGE) {  // a property of one cloud, not of the map: reported once
-        HIP_TRY(hipMemsetAsync(m->view.error_flag, 0, sizeof(int), m->stream));
+        *(volatile int *)m->error_flag_host = 0;
         return fail(CHISEL_HIP_ERR_UNSUPPORTED, flag == CLOUD_ERR_CAPACITY
                                                     ? "point cloud: too many chunks or (chunk, point) pairs for one call"
                                                     : "point cloud: a ray leaves the supported chunk-id range or is too long");
@@ -783,7 +784,9 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
-    HIP_TRY_C(hipMalloc(&v.error_flag, sizeof(int)));
+    HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, sizeof(int), hipHostMallocDefault));
+    *m->error_flag_host = 0;
+    HIP_TRY_C(hipHostGetDevicePointer((void **)&v.error_flag, m->error_flag_host, 0));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));
     HIP_TRY_C(hipMemcpyAsync(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice, m->stream));
@@ -801,7 +804,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->stream) (void)sync_all(m);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.block_counters, v.error_flag, v.stamps, m->view_dev, m->scratch_i};
+                    v.counters, v.block_counters, v.stamps, m->view_dev, m->scratch_i};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
@@ -816,6 +819,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     if (m->mesh_totals_host) (void)hipHostFree(m->mesh_totals_host);
+    if (m->error_flag_host) (void)hipHostFree(m->error_flag_host);
     if (m->mesh_info_host) (void)hipHostFree(m->mesh_info_host);
     clear_meshes(m);
     release_arena_pool(m);

@@ -171,14 +171,14 @@ __device__ inline void cloud_table_insert(const CloudView &C, const MapView &M, 
                     C.table_vals[i] = idx;  // read by later kernels only
                 } else {
                     C.table_vals[i] = -1;
-                    atomicExch(M.error_flag, CLOUD_ERR_CAPACITY);
+                    raise_error(M.error_flag, CLOUD_ERR_CAPACITY);
                 }
                 return;
             }
             if (old == key) return;
         }
     }
-    atomicExch(M.error_flag, CLOUD_ERR_CAPACITY);
+    raise_error(M.error_flag, CLOUD_ERR_CAPACITY);
 }
 __device__ inline int cloud_table_find(const CloudView &C, uint64_t key) {
     unsigned i = cloud_table_home(key);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(1024) void cloud_scan_kernel(int *data, const int *
     if (threadIdx.x == 0) {
         data[n] = s_carry;
         if (total) *total = s_carry;
-        if (capacity > 0 && s_carry > capacity) atomicExch(error_flag, CLOUD_ERR_CAPACITY);
+        if (capacity > 0 && s_carry > capacity) raise_error(error_flag, CLOUD_ERR_CAPACITY);
     }
 }
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(CLOUD_TILE) void cloud_prepare_kernel(CloudParams P
                         (wx + dirx * P.truncation) * round, (wy + diry * P.truncation) * round, (wz + dirz * P.truncation) * round)) {
                 const int lim = ID_BIAS - 2;
                 if (w.length() > 4096ull || abs(w.x) > lim || abs(w.y) > lim || abs(w.z) > lim || abs(w.ex) > lim || abs(w.ey) > lim || abs(w.ez) > lim)
-                    atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+                    raise_error(M.error_flag, CLOUD_ERR_RANGE);
                 else
                     walking = true;
             }
@@ -351,14 +351,14 @@ __device__ inline void cloud_enumerate(const CloudParams &P, const CloudView &C,
         const float f0 = floorf(fminf(a[k], b[k]) / cs), f1 = floorf(fmaxf(a[k], b[k]) / cs);
         const float lim = (float)(ID_BIAS - 4);
         if (!(f0 >= -lim && f1 <= lim)) {
-            if (report) atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+            if (report) raise_error(M.error_flag, CLOUD_ERR_RANGE);
             return;
         }
         c0[k] = (int)f0 - 1;  // one chunk of slack: the decisive test below uses the reference's own arithmetic
         c1[k] = (int)f1 + 1;
     }
     if ((long long)(c1[0] - c0[0] + 1) * (c1[1] - c0[1] + 1) * (c1[2] - c0[2] + 1) > CLOUD_MAX_RANGE) {
-        if (report) atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+        if (report) raise_error(M.error_flag, CLOUD_ERR_RANGE);
         return;
     }
     const CloudUnits U(P.N, P.jaxis, P.depth);
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
                         if (r.ax == r.ax && w.begin((r.ax - ox) * round, (r.ay - oy) * round, (r.az - oz) * round, (r.bx - ox) * round,
                                                     (r.by - oy) * round, (r.bz - oz) * round)) {
                             if (w.length() > (1ull << 20)) {
-                                atomicExch(M.error_flag, CLOUD_ERR_RANGE);
+                                raise_error(M.error_flag, CLOUD_ERR_RANGE);
                             } else {
                                 do {
                                     const unsigned cxl = (unsigned)(w.x - bx), cyl = (unsigned)(w.y - by), czl = (unsigned)(w.z - bz);

@@ -407,7 +407,7 @@ __device__ __attribute__((noinline)) int create_chunk(const MapView *__restrict_
     const int top = atomicSub(M.free_top, 1) - 1;
     if (top < 0) {
         atomicAdd(M.free_top, 1);
-        atomicExch(M.error_flag, 1);
+        raise_error(M.error_flag, 1);
         return -1;
     }
     s = M.free_list[top];
@@ -424,7 +424,7 @@ __device__ __attribute__((noinline)) int create_chunk(const MapView *__restrict_
             }
         }
     }
-    atomicExch(M.error_flag, 2);
+    raise_error(M.error_flag, 2);
     return -1;
 }
 

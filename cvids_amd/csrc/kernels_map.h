@@ -108,7 +108,7 @@ __global__ void ensure_chunk_kernel(MapView M, int x, int y, int z, int *out_slo
         int top = atomicSub(M.free_top, 1) - 1;
         if (top < 0) {
             atomicAdd(M.free_top, 1);
-            atomicExch(M.error_flag, 1);
+            raise_error(M.error_flag, 1);
         } else {
             slot = M.free_list[top];
             const uint64_t key = pack_id(x, y, z);
@@ -126,7 +126,7 @@ __global__ void ensure_chunk_kernel(MapView M, int x, int y, int z, int *out_slo
             if (placed) {
                 M.slot_key[slot] = key;
             } else {
-                atomicExch(M.error_flag, 2);
+                raise_error(M.error_flag, 2);
                 slot = -1;
             }
         }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void import_chunks_kernel(MapView M, const int
             const int top = atomicSub(M.free_top, 1) - 1;
             if (top < 0) {
                 atomicAdd(M.free_top, 1);
-                atomicExch(M.error_flag, 1);
+                raise_error(M.error_flag, 1);
             } else {
                 slot = M.free_list[top];
                 const uint64_t key = pack_id(x, y, z);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void import_chunks_kernel(MapView M, const int
                 if (placed) {
                     M.slot_key[slot] = key;
                 } else {
-                    atomicExch(M.error_flag, 2);
+                    raise_error(M.error_flag, 2);
                     slot = -1;
                 }
             }
