@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """What one rank of an N-way sharded map does, measured on ONE GPU: the frames of the whole stream, the chunks of one shard.
 Every rank of the real run sees every frame, so the job's frame rate is the slowest rank's; the all-gather is not in here.
-    python3 tools/shard_sim.py [--agents 4] [--batch 16]"""
+The frame structs are rebuilt in Python for every call, so the RATE printed here is host-bound at high shard counts: use
+`bench.py --sim-shards N --sim-rank r` for rates (structs prebuilt) and this script under rocprofv3 for per-kernel times
+(tools/shard_kstats.sh).
+    python3 tools/shard_sim.py [--agents 4] [--batch 16] [--worlds 1,2,4,8]"""
 import argparse
 import json
 import os
