@@ -138,6 +138,7 @@ struct chisel_hip_map {
     bool mutation_pending = false;
     hipEvent_t input_event = nullptr;    // chisel_hip_wait_event: the next batch's frames are ready behind this (caller's) event
     bool force_pipeline = false;         // test hook (CHISEL_HIP_FORCE_PIPELINE at creation): the front half always runs on the auxiliary stream
+    bool mesh_tiny = false;              // test hook (CHISEL_HIP_MESH_TINY at creation): triangle list and arena start far too small, so every recompute takes the grow-and-emit-again paths
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b & 1]
     int items_capacity = 0;
@@ -763,6 +764,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         HIP_TRY_C(hipMemsetAsync(bs.pending, 0xff, (size_t)PENDING_CAPACITY * sizeof(uint64_t), m->own_stream));
     }
     HIP_TRY_C(hipEventCreateWithFlags(&m->mutation_event, hipEventDisableTiming));
+    m->mesh_tiny = getenv("CHISEL_HIP_MESH_TINY") != nullptr;
     m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {

@@ -160,7 +160,7 @@ int recompute_meshes(chisel_hip_map *m) {
     int *d_totals = mesh_totals(m);
     const MeshParams P = mesh_params(m);
     if (!B.tris) {
-        B.tri_capacity = std::max(B.tri_capacity, 1 << 20);
+        B.tri_capacity = std::max(B.tri_capacity, m->mesh_tiny ? 256 : 1 << 20);
         HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
     }
     // an arena record and a buffer that should do: twice what the previous recompute needed
@@ -174,7 +174,7 @@ int recompute_meshes(chisel_hip_map *m) {
     {
         MeshArena &A = m->arenas[arena_id];
         A = MeshArena();
-        int rc_a = take_arena_buffer(m, std::max<size_t>(2 * m->mesh_need_hint, (size_t)1 << 22), &A.dev, &A.capacity);
+        int rc_a = take_arena_buffer(m, m->mesh_tiny ? (size_t)4096 : std::max<size_t>(2 * m->mesh_need_hint, (size_t)1 << 22), &A.dev, &A.capacity);
         if (rc_a) return rc_a;
     }
     launch_mesh_count(m);

@@ -138,6 +138,30 @@ def test_stream_with_keyframe_meshing_no_waits(oracle_mod):
     assert n > 10 and nv > 1000
 
 
+def test_recompute_that_outgrows_its_buffers(oracle_mod, monkeypatch):
+    """CHISEL_HIP_MESH_TINY: the triangle list (256 entries) and the arena (4096 floats) are far too small, so every recompute first
+    runs into the overflow flag (the speculative triangle kernel must emit nothing), grows the list, counts again and emits again
+    into an arena of the right size -- with batches queued in between.  Voxels and meshes must still equal the oracle's."""
+    monkeypatch.setenv("CHISEL_HIP_MESH_TINY", "1")
+    om, gm, integ = _mk(oracle_mod, 16, 0.04, True, max_chunks=4096)
+    W, H = 160, 120
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(W, H, 3)
+    frames = make_frames("sphere_room", 24, W, H)
+    for lo in range(0, len(frames), 6):
+        part = frames[lo:lo + 6]
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        om.update_meshes(force=True)
+        gm.UpdateMeshes(force=True)
+    from tests.common import compare_fields
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+    n, nv = _compare_meshes(om, gm, True)
+    assert n > 10 and nv > 1000
+
+
 def test_mesh_color_lookup_near_origin(oracle_mod):
     """10 cm voxels: InterpolateColor's integer-index lookups (ChunkManager.cpp:506-520) land inside the map"""
     om, gm, integ = _mk(oracle_mod, 8, 0.10, True, trunc=("constant", 0.3), max_chunks=8192)
