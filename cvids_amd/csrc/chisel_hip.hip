@@ -175,6 +175,7 @@ struct chisel_hip_map {
     struct CloudBuffers {                                              // point-cloud fusion mode (host_cloud.h), allocated on first use
         float *points = nullptr, *colors = nullptr;                    // staging of host clouds
         int64_t capacity = 0;                                          // points
+        size_t zeroed_bytes = 0;                                       // table keys | control | counts | cursors: one allocation, one memset per cloud
         CloudView view{};
     } cloud;
     // profiling

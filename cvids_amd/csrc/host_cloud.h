@@ -20,8 +20,8 @@ void invert_affine(const float *m, float *r) {
 }
 
 void free_cloud_buffers(chisel_hip_map::CloudBuffers &B) {
-    void *ptrs[] = {B.points, B.colors, B.view.rays, B.view.rgb, B.view.tile_prefix, B.view.table_keys, B.view.table_vals,
-                    B.view.listed, B.view.offsets, B.view.cursors, B.view.pairs, B.view.sorted, B.view.ctl};
+    void *ptrs[] = {B.points, B.colors, B.view.rays, B.view.rgb, B.view.tile_prefix, B.view.table_keys /* + ctl, offsets, cursors */, B.view.table_vals,
+                    B.view.listed, B.view.pairs, B.view.sorted};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     B = chisel_hip_map::CloudBuffers();
@@ -31,13 +31,17 @@ int ensure_cloud_buffers(chisel_hip_map *m, int64_t n) {
     chisel_hip_map::CloudBuffers &B = m->cloud;
     CloudView &C = B.view;
     if (!C.table_keys) {
-        HIP_TRY(hipMalloc(&C.table_keys, (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t)));
+        // one allocation for everything a cloud starts from zero: table keys | control words | per-unit counts (+1) | per-unit cursors
+        const size_t units = (size_t)CLOUD_MAX_LISTED * CloudUnits(m->N, 0, cloud_unit_depth(m->N)).count;
+        B.zeroed_bytes = (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t) + 16 * sizeof(int) + (units + 1) * sizeof(int) + units * sizeof(int);
+        char *base = nullptr;
+        HIP_TRY(hipMalloc(&base, B.zeroed_bytes));
+        C.table_keys = reinterpret_cast<uint64_t *>(base);
+        C.ctl = reinterpret_cast<int *>(base + (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t));
+        C.offsets = C.ctl + 16;
+        C.cursors = C.offsets + units + 1;
         HIP_TRY(hipMalloc(&C.table_vals, (size_t)CLOUD_TABLE_SLOTS * sizeof(int)));
         HIP_TRY(hipMalloc(&C.listed, (size_t)CLOUD_MAX_LISTED * sizeof(uint64_t)));
-        const size_t units = (size_t)CLOUD_MAX_LISTED * CloudUnits(m->N, 0, cloud_unit_depth(m->N)).count;
-        HIP_TRY(hipMalloc(&C.offsets, (units + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc(&C.cursors, units * sizeof(int)));
-        HIP_TRY(hipMalloc(&C.ctl, 16 * sizeof(int)));
     }
     if (n <= B.capacity) return CHISEL_HIP_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -125,15 +129,13 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
 
     ProfScope ps(m, CHISEL_HIP_KERNEL_CLOUD);
     const int tiles = (n + CLOUD_TILE - 1) / CLOUD_TILE;
-    HIP_TRY(hipMemsetAsync(C.table_keys, 0xff, (size_t)CLOUD_TABLE_SLOTS * sizeof(uint64_t), m->stream));
-    HIP_TRY(hipMemsetAsync(C.ctl, 0, 16 * sizeof(int), m->stream));
     const int units_per_chunk = CloudUnits(m->N, P.jaxis, P.depth).count;
-    const size_t units = (size_t)CLOUD_MAX_LISTED * units_per_chunk;
-    HIP_TRY(hipMemsetAsync(C.offsets, 0, (units + 1) * sizeof(int), m->stream));
-    HIP_TRY(hipMemsetAsync(C.cursors, 0, units * sizeof(int), m->stream));
-    hipLaunchKernelGGL(cloud_tile_count_kernel, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C);
-    hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, m->stream, C.tile_prefix, (const int *)nullptr, tiles, 1, (int *)nullptr, 0,
-                       m->view.error_flag);
+    HIP_TRY(hipMemsetAsync(C.table_keys, 0, m->cloud.zeroed_bytes, m->stream));  // table, control words, counts, cursors: one fill
+    if (P.with_color) {  // the rank of a point among the accepted ones only selects its colour
+        hipLaunchKernelGGL(cloud_tile_count_kernel, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C);
+        hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, m->stream, C.tile_prefix, (const int *)nullptr, tiles, 1, (int *)nullptr, 0,
+                           m->view.error_flag);
+    }
     hipLaunchKernelGGL(cloud_prepare_kernel, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C, m->view);
     hipLaunchKernelGGL(cloud_bin_kernel<false>, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C, m->view);
     hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, m->stream, C.offsets, (const int *)C.ctl, CLOUD_MAX_LISTED, units_per_chunk,

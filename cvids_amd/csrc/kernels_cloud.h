@@ -156,15 +156,18 @@ __device__ inline unsigned cloud_table_home(uint64_t key) {
     unpack_id(key, x, y, z);
     return (unsigned)chunk_hash(x, y, z) & (CLOUD_TABLE_SLOTS - 1u);
 }
+// the table holds packed id + 1: an empty entry is 0, so the table, the counters and the control words are cleared by ONE memset
+constexpr uint64_t CLOUD_EMPTY = 0;
 __device__ inline void cloud_table_insert(const CloudView &C, const MapView &M, uint64_t key) {
+    const uint64_t stored = key + 1;
     unsigned i = cloud_table_home(key);
     for (unsigned probe = 0; probe < CLOUD_TABLE_SLOTS; probe++, i = (i + 1u) & (CLOUD_TABLE_SLOTS - 1u)) {
         // read at L2: a line cached before another CU's insertion would send every later wave into the compare-and-swap
         const uint64_t k = __hip_atomic_load(&C.table_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == key) return;
-        if (k == KEY_EMPTY) {
-            const uint64_t old = atomicCAS((unsigned long long *)&C.table_keys[i], (unsigned long long)KEY_EMPTY, (unsigned long long)key);
-            if (old == KEY_EMPTY) {
+        if (k == stored) return;
+        if (k == CLOUD_EMPTY) {
+            const uint64_t old = atomicCAS((unsigned long long *)&C.table_keys[i], (unsigned long long)CLOUD_EMPTY, (unsigned long long)stored);
+            if (old == CLOUD_EMPTY) {
                 const int idx = atomicAdd(&C.ctl[0], 1);
                 if (idx < CLOUD_MAX_LISTED) {
                     C.listed[idx] = key;
@@ -175,17 +178,18 @@ __device__ inline void cloud_table_insert(const CloudView &C, const MapView &M, 
                 }
                 return;
             }
-            if (old == key) return;
+            if (old == stored) return;
         }
     }
     raise_error(M.error_flag, CLOUD_ERR_CAPACITY);
 }
 __device__ inline int cloud_table_find(const CloudView &C, uint64_t key) {
+    const uint64_t stored = key + 1;
     unsigned i = cloud_table_home(key);
     for (unsigned probe = 0; probe < CLOUD_TABLE_SLOTS; probe++, i = (i + 1u) & (CLOUD_TABLE_SLOTS - 1u)) {
         const uint64_t k = C.table_keys[i];
-        if (k == key) return C.table_vals[i];
-        if (k == KEY_EMPTY) return -1;
+        if (k == stored) return C.table_vals[i];
+        if (k == CLOUD_EMPTY) return -1;
     }
     return -1;
 }
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(CLOUD_TILE) void cloud_prepare_kernel(CloudParams P
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) s_wave[wave] = __popcll(b);
     __syncthreads();
-    int before = C.tile_prefix[blockIdx.x];
+    int before = P.with_color ? C.tile_prefix[blockIdx.x] : 0;  // (the index only selects a colour)
     for (int w = 0; w < wave; w++) before += s_wave[w];
     const int cidx = before + __popcll(b & ((1ull << lane) - 1ull));
     bool walking = false;
