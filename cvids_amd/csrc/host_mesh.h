@@ -1,8 +1,8 @@
 // host_mesh.h -- mesh-side entry points of the C ABI (included by chisel_hip.hip).
 //
 // Chisel::UpdateMeshes (Chisel.cpp:50-59) -> ChunkManager::RecomputeMeshes (ChunkManager.cpp:130-169): the ids flagged
-// since the last recompute are meshed on the GPU (kernels_mesh.h: jobs -> count -> host prefix sum -> emit into one
-// arena).  The arena stays in HBM (MeshArena in chisel_hip.hip); only the per-chunk sizes travel to the host, the vertex
+// since the last recompute are meshed on the GPU (kernels_mesh.h: mark -> collect -> count, which also allots each job its range
+// of the triangle list -> emit into one arena).  The arena stays in HBM (MeshArena in chisel_hip.hip); only the per-chunk sizes travel to the host, the vertex
 // data follows when a caller asks for a mesh.
 namespace {
 
@@ -152,7 +152,8 @@ void launch_mesh_count(chisel_hip_map *m) {
 
 // meshes of the chunks whose ids sit in mesh_buf.ids (device; their number too).  Everything is queued at once -- job
 // table, count kernel, triangle kernel into an arena sized from the previous recompute, dirty-flag reset -- and the host
-// then reads the totals behind the count kernel on its own stream: the device never waits for the host.  Only a batch
+// then finds the totals in pinned memory, written by publish_totals_kernel behind the count kernel: the device never waits for
+// the host and nothing but kernels sits on the map's stream.  Only a batch
 // that outgrew the triangle list or the arena is emitted again after a full wait (the map has not changed meanwhile:
 // nothing else was queued).
 int recompute_meshes(chisel_hip_map *m) {
