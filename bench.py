@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same stream the CPU oracle is timed on (about 1 s each at 1 cm)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-frames", action="store_true", help="hand host (pageable) depth buffers to the library: the PCIe-inclusive rate (never `value`)")
+    ap.add_argument("--pinned", action="store_true", help="with --host-frames: the host buffers are page-locked (what a capture pipeline would hand over)")
     ap.add_argument("--sim-shards", type=int, default=0, help="diagnostic, 1 GPU: integrate only the chunks of one shard of an N-way sharded map "
                                                                "(what one rank of an N-GPU run computes; every rank sees every frame)")
     ap.add_argument("--sim-rank", type=int, default=0)
@@ -181,6 +182,14 @@ def main():
         stack = [torch.from_numpy(np.stack([frames[lo + j][0] if lo + j < hi else blank for j in mine])).to(dev) for lo, hi in bounds]
         meta = [torch.from_numpy(np.stack([pack_meta(frames[min(lo + j, hi - 1)][1], cam) for j in mine])).to(dev) for lo, hi in bounds]
 
+    host_src = None
+    if args.host_frames and world == 1:
+        if args.pinned:
+            pins = [torch.from_numpy(f[0]).pin_memory() for f in frames]
+            keep_pins = pins
+            host_src = [p.numpy() for p in pins]  # same page-locked memory, handed over as a host pointer
+        else:
+            host_src = [f[0] for f in frames]
     # the C structs of every batch are built once, outside the timed region (device addresses are fixed)
     keep = []
     calls = []
@@ -190,7 +199,7 @@ def main():
         fa = (capi.DepthFrame * n)()
         ca = (capi.ColorFrame * n)() if use_color else None
         for j in range(n):
-            fa[j], k1 = depth_frame(frames[lo + j][0] if (args.host_frames and world == 1) else src[j], frames[lo + j][1], cam)
+            fa[j], k1 = depth_frame(host_src[lo + j] if (args.host_frames and world == 1) else src[j], frames[lo + j][1], cam)
             keep.append(k1)
             if use_color:
                 ca[j], k2 = color_frame(c_dev, frames[lo + j][1], cam)
@@ -310,7 +319,7 @@ def main():
         out = {
             "metric": METRIC, "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host depth buffers: PCIe-inclusive)" if args.host_frames else ""),
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + ((" (host depth buffers, %s: PCIe-inclusive)" % ("page-locked" if args.pinned else "pageable")) if args.host_frames else ""),
             "mvoxel_updates_per_s": vals[0] / dt / 1e6, "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "config": {"workload": "%dx%d %s stream (%s, %d agent%s), %g cm voxels, chunk %d^3, InverseTruncator(%g), carving 0.05 m, "
                                    "projective TSDF integration%s" % (W, H, "depth+BGR colour" if use_color else "depth-only",

@@ -523,9 +523,22 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         if (f->on_device) {
             PP.depth[k] = f->depth;
         } else {
-            float *dst = bs.depth_stage + (size_t)k * m->depth_stage_elems;
-            HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, front));
-            PP.depth[k] = dst;
+            // Page-locked host memory is addressable by the device: the pyramid kernel reads the frame straight over the bus, once
+            // and coalesced (a copy-engine transfer per frame costs more in launch latency than it moves).  Pageable memory is
+            // copied by the runtime during the call.
+            hipPointerAttribute_t attr;
+            const float *mapped = nullptr;
+            if (hipPointerGetAttributes(&attr, f->depth) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer)
+                mapped = static_cast<const float *>(attr.devicePointer);
+            else
+                (void)hipGetLastError();  // not a registered pointer: plain pageable memory
+            if (mapped && !getenv("CHISEL_HIP_NO_ZERO_COPY")) {
+                PP.depth[k] = mapped;
+            } else {
+                float *dst = bs.depth_stage + (size_t)k * m->depth_stage_elems;
+                HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, front));
+                PP.depth[k] = dst;
+            }
         }
         F.rec = bs.rec_data + (size_t)k * npx;
         if (color) {

@@ -20,6 +20,10 @@
  *   - image pointers may be host or device memory (`on_device`); device images must be complete
  *     when the call is made (or ordered with chisel_hip_set_stream / chisel_hip_wait_event) and stay
  *     valid until the map has consumed them (chisel_hip_synchronize / chisel_hip_record_event).
+ *     Host images in pageable memory are copied during the call.  Host images in page-locked memory
+ *     (hipHostMalloc / hipHostRegister) are read by the device when the batch runs -- depth straight
+ *     over the bus by the first kernel, colour through an asynchronous copy -- so they too must stay
+ *     untouched until the map has consumed them.
  *   - a map is driven from one thread at a time, as the reference is (chisel_ros: one ros::spin thread).
  */
 #ifndef CHISEL_HIP_H_

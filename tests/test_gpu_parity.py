@@ -281,6 +281,27 @@ def test_device_resident_frames_and_batch(oracle_mod):
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+def test_page_locked_host_frames(oracle_mod):
+    """Depth frames in page-locked host memory are read by the pyramid kernel straight over the bus (no staging copy): same result
+    as pageable host frames, batches queued back to back."""
+    import torch
+    om, gm, integ = _mk(oracle_mod, 16, 0.04, True)
+    W, H = 160, 120
+    cam = small_camera(W, H)
+    frames = make_frames("sphere_room", 12, W, H, nan_fraction=0.01)
+    color = synth.render_color(W, H, 3)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+    pins = [torch.from_numpy(d).pin_memory() for d, _ in frames]
+    assert all(t.is_pinned() for t in pins)
+    views = [t.numpy() for t in pins]   # host pointers into page-locked memory
+    for lo in range(0, 12, 4):
+        gm.IntegrateBatch(integ, [(views[i], frames[i][1], cam) for i in range(lo, lo + 4)], [(color, frames[i][1], cam) for i in range(lo, lo + 4)])
+    gm.synchronize()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
 def _run_batched(om, gm, integ, frames, cam, color_img, batch):
     """oracle frame by frame, HIP path `batch` frames per chisel_hip_integrate_batch call; compare after every call"""
     intr = (cam.fx, cam.fy, cam.cx, cam.cy)
