@@ -59,7 +59,7 @@ def parse():
                          "meshing (10 = two launch sets of 5, the recompute falls exactly on every 10th frame), else 8")
     ap.add_argument("--max-chunks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same stream the CPU oracle is timed on (about 1 s each at 1 cm)")
+    ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the same stream the CPU oracle is timed on (about 1 s each at 1 cm)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--host-frames", action="store_true", help="hand host (pageable) depth buffers to the library: the PCIe-inclusive rate (never `value`)")
     ap.add_argument("--pinned", action="store_true", help="with --host-frames: the host buffers are page-locked (what a capture pipeline would hand over)")
