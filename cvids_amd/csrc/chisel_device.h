@@ -72,7 +72,6 @@ struct MapView {
     unsigned long long *block_counters;  // [INTEGRATE_MAX_GRID][16] per-workgroup partial sums
     int *error_flag;         // != 0: pool / hash exhausted (pinned host memory, see raise_error)
     int max_chunks;
-    unsigned long long *stamps;  // diagnostic builds (-DCHISEL_STAMPS) only: [workgroup][8] s_memrealtime stamps
 };
 
 // depth min/max pyramid: level l (PYR_L0 <= l <= PYR_L1) has ceil(W/2^l) x ceil(H/2^l) texels of
@@ -185,6 +184,21 @@ constexpr int WI_INBAND = 1;   // some voxel may take the in-band branch
 constexpr int WI_CARVE = 2;    // some voxel may take the carve test (only matters while the chunk is resident)
 constexpr int WI_TILE = 4;     // u0..v1 is a valid bounding box (else: gather from the whole image)
 constexpr int WI_FASTZ = 8;    // camera z of every voxel of the chunk lies in [FASTZ_MIN, FASTZ_MAX]: reciprocal_in_range() applies
+
+// Chunk-level state of one work item while its waves run (device-scope atomics only; zeroed by whoever writes the item).
+struct ItemSync {
+    unsigned band;         // items without a slot: frames in which some voxel was integrated
+    unsigned changed;      // frames in which some voxel changed (each bit is counted by the wave that sets it first)
+    int slot;              // items without a slot: 0 = nobody has allocated yet, 1 = being allocated, s + 2 = pool slot s, -1 = failed
+    unsigned arrived;      // items without a slot: waves that have deposited their band / carve figures
+    unsigned carve[KMAX];  // items without a slot: voxels that took the carve test, per frame
+};
+static_assert(sizeof(ItemSync) == 80, "ItemSync is zeroed as five 16-byte stores");
+__device__ inline void item_sync_init(ItemSync *s) {
+    uint4 *p = reinterpret_cast<uint4 *>(s);
+#pragma unroll
+    for (int i = 0; i < 5; i++) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 
 // ---- strategy arithmetic (devirtualised Truncator / Weighter) -------------------------------------
 // InverseTruncator.h:48-52

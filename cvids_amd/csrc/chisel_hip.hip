@@ -120,13 +120,14 @@ struct chisel_hip_map {
     // exists twice (sets alternate per batch); events order the halves.
     struct BatchSet {
         float2 *pyr_data = nullptr;      // [KMAX][pyr_stride]
-        PixelRec *rec_data = nullptr;    // [KMAX][W*H]
+        PixelRec *rec_data = nullptr;    // [KMAX][2 + W*H]: per frame two all-NaN records, then the image
         float *depth_stage = nullptr;    // [KMAX][depth_stage_elems]: host frames are copied here
         uint8_t *color_stage = nullptr;  // [KMAX][color_stage_bytes]
         WorkItem *cands = nullptr;       // [items_capacity]
         FrameBox *boxes = nullptr;       // [items_capacity][KMAX]
         int *cand_count = nullptr;       // [COUNT_INTS] device counters of the batch (COUNT_* in kernels_cull.h)
         WorkItem *items = nullptr;       // [items_capacity]: the work-list
+        ItemSync *sync = nullptr;        // [items_capacity]: chunk-level state of the work items while the integration kernel runs
         uint64_t *pending = nullptr;     // [PENDING_CAPACITY]: chunks this batch may create
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
         hipEvent_t front_done = nullptr;  // recorded on aux after the set's resolve
@@ -314,8 +315,13 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
         bs.pyr_data = nullptr;
         bs.rec_data = nullptr;
         HIP_TRY(hipMalloc(&bs.pyr_data, (size_t)off * KMAX * sizeof(float2)));
-        HIP_TRY(hipMalloc(&bs.rec_data, (size_t)W * H * KMAX * sizeof(PixelRec)));
+        // two records of padding in front of every frame's image, NaN once and for all (only pixels are ever written): the
+        // integration kernel points voxels that are off the image at record -1
+        const size_t rec_floats = ((size_t)W * H + 2) * KMAX * 2;
+        HIP_TRY(hipMalloc(&bs.rec_data, rec_floats * sizeof(float)));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bs.rec_data), 0x7fc00000, rec_floats, m->stream));
     }
+    HIP_TRY(hipStreamSynchronize(m->stream));  // the padding is in place before a front half (possibly on the other stream) writes pixels
     m->pyr.data = nullptr;
     m->pyr_w = W;
     m->pyr_h = H;
@@ -349,7 +355,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const dim3 cgrid((total + 63) / 64);
 #define CHISEL_LAUNCH_CULL(KLV, INL, OUT)                                                                                        \
     hipLaunchKernelGGL((cull_kernel<N, KLV, INL>), cgrid, dim3(64 * KLV), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count,      \
-                       m->items_capacity, m->view.stamps, m->view, bs.pending)
+                       m->items_capacity, m->view, bs.pending, bs.sync)
         if (inline_resolve) {
             if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL(1, true, bs.items);
             else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL(2, true, bs.items);
@@ -372,9 +378,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const dim3 rgrid((total + 255) / 256);
         const bool direct = IP.n_frames == 1;  // one frame: nothing to order
         hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
-                           prev ? prev->pending : nullptr, prev_overflow, bs.pending, direct ? bs.items : nullptr);
+                           prev ? prev->pending : nullptr, prev_overflow, bs.pending, direct ? bs.items : nullptr, bs.sync);
         if (!direct)
-            hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items);
+            hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
     }
     HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     g_host_timer.lap(4);
@@ -388,18 +394,22 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     int *wc = bs.cand_count + COUNT_ITEMS;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
-        const int grid = std::max(1, std::min(total, G::GRID));
+        // persistent grid: what the chip holds at once, or fewer blocks when the candidates cannot fill it (in steps that give
+        // every XCD whole chunks in the first round)
+        const long long units = (long long)total * G::WPC;
+        const int grid = (int)std::max<long long>(G::GRID_STEP, std::min<long long>(G::GRID, (units / 4 + G::GRID_STEP - 1) / G::GRID_STEP * G::GRID_STEP));
+        int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
         if (color && same_cam)  // CVIDS: depth and colour share one camera (sample.launch:19-20)
             hipLaunchKernelGGL((integrate_kernel<N, true, true>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               bs.items, bs.boxes, wc, m->items_capacity);
+                               bs.items, bs.boxes, bs.sync, wc, queues, m->items_capacity);
         else if (color)
             hipLaunchKernelGGL((integrate_kernel<N, true, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               bs.items, bs.boxes, wc, m->items_capacity);
+                               bs.items, bs.boxes, bs.sync, wc, queues, m->items_capacity);
         else
             hipLaunchKernelGGL((integrate_kernel<N, false, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               bs.items, bs.boxes, wc, m->items_capacity);
+                               bs.items, bs.boxes, bs.sync, wc, queues, m->items_capacity);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(bs.back_done, m->stream));
@@ -452,9 +462,9 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     PP.W = W;
     PP.H = H;
     chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq & 1u];
-    PP.rec_stride = (int)npx;
+    PP.rec_stride = (int)npx + 2;
     PP.pyr_stride = m->pyr_stride;
-    PP.rec = bs.rec_data;
+    PP.rec = bs.rec_data + 2;
     CP.n_frames = IP.n_frames = n;
     CP.pyr_stride = m->pyr_stride;
 
@@ -540,7 +550,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
                 PP.depth[k] = dst;
             }
         }
-        F.rec = bs.rec_data + (size_t)k * npx;
+        F.rec = PP.rec + (size_t)k * PP.rec_stride;
         if (color) {
             const chisel_hip_color_frame *c = &colors[k];
             fill_camera(F.ccam, c->pose, c->fx, c->fy, c->cx, c->cy, c->width, c->height);
@@ -585,11 +595,14 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
             if (b2.cands) HIP_TRY(hipFree(b2.cands));
             if (b2.boxes) HIP_TRY(hipFree(b2.boxes));
             if (b2.items) HIP_TRY(hipFree(b2.items));
+            if (b2.sync) HIP_TRY(hipFree(b2.sync));
             b2.cands = nullptr;
             b2.boxes = nullptr;
             b2.items = nullptr;
+            b2.sync = nullptr;
             HIP_TRY(hipMalloc(&b2.cands, (size_t)cap * sizeof(WorkItem)));
             HIP_TRY(hipMalloc(&b2.items, (size_t)cap * sizeof(WorkItem)));
+            HIP_TRY(hipMalloc(&b2.sync, (size_t)cap * sizeof(ItemSync)));
             HIP_TRY(hipMalloc(&b2.boxes, (size_t)cap * KMAX * sizeof(FrameBox)));
         }
         m->items_capacity = cap;
@@ -797,7 +810,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.slot_dirty, (size_t)C * sizeof(uint32_t)));
     HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
-    HIP_TRY_C(hipMalloc(&v.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc(&v.counters, 16 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, sizeof(int), hipHostMallocDefault));
@@ -820,11 +833,11 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->stream) (void)sync_all(m);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.block_counters, v.stamps, m->view_dev, m->scratch_i};
+                    v.counters, v.block_counters, m->view_dev, m->scratch_i};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
-        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.pending};
+        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.sync, bs.pending};
         for (void *p : bp)
             if (p) (void)hipFree(p);
         if (bs.front_done) (void)hipEventDestroy(bs.front_done);
@@ -1342,9 +1355,19 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
     HIP_TRY(hipSetDevice(m->device));
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, m->stream, m->view, INTEGRATE_MAX_GRID);
     HIP_TRY(hipMemcpyAsync(out, m->view.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, m->stream));
+#ifdef CHISEL_PHASES
+    uint64_t ph[16];
+    HIP_TRY(hipMemcpyAsync(ph, m->view.counters, sizeof(ph), hipMemcpyDeviceToHost, m->stream));
+#endif
     if (reset_counters)
         HIP_TRY(hipMemsetAsync(m->view.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+#ifdef CHISEL_PHASES
+    if (ph[15])  // s_memrealtime ticks of 10 ns, summed over the waves of all launches since the last reset
+        fprintf(stderr, "integrate_kernel phases, us per wave: item %.2f frames %.2f deposit %.2f store+or %.2f dequeue %.2f | alive %.2f | waves %llu units/wave %.2f\n",
+                ph[9] * 0.01 / ph[15], ph[10] * 0.01 / ph[15], ph[11] * 0.01 / ph[15], ph[12] * 0.01 / ph[15], ph[13] * 0.01 / ph[15],
+                ph[14] * 0.01 / ph[15], (unsigned long long)ph[15], (double)out[5] * 16.0 / ph[15]);
+#endif
     return CHISEL_HIP_OK;
 }
 
@@ -1469,23 +1492,6 @@ int chisel_hip_kat_reciprocal(unsigned long long *mismatches, unsigned *example_
     HIP_TRY(hipMemcpy(example_bits, e, sizeof(unsigned), hipMemcpyDeviceToHost));
     (void)hipFree(d);
     (void)hipFree(e);
-    return CHISEL_HIP_OK;
-}
-// diagnostic builds (-DCHISEL_STAMPS): allocate / read back the per-workgroup stamp buffer of integrate_kernel
-int chisel_hip_debug_stamps(chisel_hip_map *m, unsigned long long *out, int n_groups) {
-    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
-    HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    const size_t bytes = (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long);
-    if (!m->view.stamps) {
-        HIP_TRY(hipMalloc(&m->view.stamps, bytes));
-        HIP_TRY(hipMemset(m->view.stamps, 0, bytes));
-        HIP_TRY(hipMemcpy(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice));
-    }
-    if (out) {
-        HIP_TRY(hipMemcpy(out, m->view.stamps, (size_t)std::min(n_groups, INTEGRATE_MAX_GRID) * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(m->view.stamps, 0, bytes));
-    }
     return CHISEL_HIP_OK;
 }
 // host-side frustum arithmetic of the product (host_frustum.h), for CPU-only tests against the oracle

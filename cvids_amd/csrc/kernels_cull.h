@@ -32,7 +32,7 @@ namespace chisel_hip {
 
 // per-batch device counters: candidates, work items, pending-set overflow flag, a constant 1, work items per cost class,
 // placement cursors per cost class
-constexpr int COUNT_CANDS = 0, COUNT_ITEMS = 1, COUNT_OVERFLOW = 2, COUNT_ONE = 3, COUNT_CLASS0 = 4, COUNT_CURSOR0 = 12, COUNT_INTS = 20;
+constexpr int COUNT_CANDS = 0, COUNT_ITEMS = 1, COUNT_OVERFLOW = 2, COUNT_ONE = 3, COUNT_CLASS0 = 4, COUNT_CURSOR0 = 12, COUNT_QUEUE0 = 32, COUNT_INTS = COUNT_QUEUE0 + 128 * 32;  // the queue heads of the integration kernel (QUEUE_HEADS x QUEUE_STRIDE)
 
 __device__ inline bool depth_valid(float d, float max_depth) {
     // NaN never updates (Integrate: every comparison false; IntegrateColor: isnan skip :134); d > max_depth is
@@ -63,8 +63,10 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
     const int px0 = blockIdx.x * 64 + bx * 4, py0 = blockIdx.y * 64 + by * 4;
     {  // consumed by cull_kernel / resolve_kernel (next launches)
         const unsigned gid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256u + tid;
-        if (gid < (unsigned)COUNT_INTS && gid != (unsigned)COUNT_ONE) counts[gid] = 0;
-        for (unsigned i = gid; i < PENDING_CAPACITY; i += gridDim.x * gridDim.y * gridDim.z * 256u) pending[i] = KEY_EMPTY;
+        const unsigned n_threads = gridDim.x * gridDim.y * gridDim.z * 256u;
+        for (unsigned i = gid; i < (unsigned)COUNT_INTS; i += n_threads)
+            if (i != (unsigned)COUNT_ONE) counts[i] = 0;
+        for (unsigned i = gid; i < PENDING_CAPACITY; i += n_threads) pending[i] = KEY_EMPTY;
     }
     float mn = INFINITY, mx = -INFINITY;
     if (px0 < W && py0 < H) {
@@ -414,18 +416,12 @@ struct CullSpace {
 // kernels on one stream instead of five on two.
 template <int N, int KL, bool INLINE>
 __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *counts,
-                                                        int max_cands, unsigned long long *stamps, MapView M, uint64_t *my_pending) {
+                                                        int max_cands, MapView M, uint64_t *my_pending, ItemSync *sync) {
     int *cand_count = counts + (INLINE ? COUNT_ITEMS : COUNT_CANDS);
     __shared__ int s_flags[KL][64];
     __shared__ int s_pos[64];
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's frame
-#ifdef CHISEL_STAMPS
-#define CSTAMP(i) do { if (threadIdx.x == 0 && stamps && blockIdx.x < INTEGRATE_MAX_GRID) stamps[(size_t)blockIdx.x * 32 + 26 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define CSTAMP(i) do { } while (0)
-#endif
-    CSTAMP(0);
     const CullSpace space(P);
     const int c = blockIdx.x * 64 + lane;
     int cx = 0, cy = 0, cz = 0;
@@ -439,9 +435,7 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
     }
     fb.flags = fl;
     s_flags[k][lane] = fl;
-    CSTAMP(1);
     __syncthreads();
-    CSTAMP(2);
     if (k == 0) {
         // ---- merge the frames of each chunk, compact the candidates ----------------------------------------------
         unsigned inband = 0, carve = 0;
@@ -496,6 +490,7 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
                     wi.inband_mask = inband;
                     wi.pad = 0;
                     cands[pos] = wi;
+                    if (INLINE) item_sync_init(sync + pos);  // the candidate list is the work-list
                 } else {
                     pos = -1;
                 }
@@ -503,9 +498,7 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
         }
         s_pos[lane] = pos;
     }
-    CSTAMP(3);
     __syncthreads();
-    CSTAMP(4);
     const int pos = s_pos[lane];
     if (pos >= 0 && k < P.n_frames) {
         if (fl == 0) {  // frames that cannot touch the chunk: a well-defined empty box
@@ -516,8 +509,6 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
         }
         boxes[(size_t)pos * P.n_frames + k] = fb;
     }
-    CSTAMP(5);
-#undef CSTAMP
 }
 
 // Candidates -> work-list, in two passes over the candidates (both on the auxiliary stream, one thread per candidate,
@@ -543,7 +534,8 @@ __device__ inline int cost_class(unsigned frame_mask) { return (KMAX - __popc(fr
 // so the survivors go straight into the work-list (one returning atomic per wave) and order_kernel is not launched.
 __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
                                                        int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
-                                                       const int *__restrict__ prev_overflow, uint64_t *my_pending, WorkItem *items) {
+                                                       const int *__restrict__ prev_overflow, uint64_t *my_pending, WorkItem *items,
+                                                       ItemSync *sync) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + threadIdx.x;
     int n = counts_in[COUNT_CANDS];
@@ -599,7 +591,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
                 const int leader = (int)__builtin_ctzll(bal);
                 if (lane == leader) base = atomicAdd(&counts[COUNT_ITEMS], __popcll(bal));
                 base = __shfl(base, leader);
-                items[base + __popcll(bal & ((1ull << lane) - 1ull))] = wi;
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                items[pos] = wi;
+                item_sync_init(sync + pos);
             }
         }
     }
@@ -612,7 +606,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
 }
 
 __global__ __launch_bounds__(256) void order_kernel(const WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
-                                                     int max_cands, WorkItem *__restrict__ items) {
+                                                     int max_cands, WorkItem *__restrict__ items, ItemSync *sync) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + threadIdx.x;
     int n = counts_in[COUNT_CANDS];
@@ -648,7 +642,9 @@ __global__ __launch_bounds__(256) void order_kernel(const WorkItem *__restrict__
         int first = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) first = (cls == k) ? start[k] : first;
-        items[first + base + __popcll(mine & ((1ull << lane) - 1ull))] = wi;  // items holds max_cands entries
+        const int pos = first + base + __popcll(mine & ((1ull << lane) - 1ull));
+        items[pos] = wi;  // items holds max_cands entries
+        item_sync_init(sync + pos);
     }
 }
 
