@@ -151,7 +151,8 @@ def load_library():
                         ("chisel_hip_kat_color_any", [C.POINTER(C.c_uint)]),
                         ("chisel_hip_debug_cloud_stats", [vp, i64p]),
                         ("chisel_hip_kat_raycast", [f32p, C.c_int, i32p, i32p, i32p, C.c_int, i32p]),
-                        ("chisel_hip_kat_reciprocal", [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)])):
+                        ("chisel_hip_kat_reciprocal", [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]),
+                        ("chisel_hip_kat_floor", [C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)])):
         try:
             getattr(L, name).argtypes = types
         except AttributeError:

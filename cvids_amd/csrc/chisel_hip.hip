@@ -317,7 +317,7 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
         HIP_TRY(hipMalloc(&bs.pyr_data, (size_t)off * KMAX * sizeof(float2)));
         // two records of padding in front of every frame's image, NaN once and for all (only pixels are ever written): the
         // integration kernel points voxels that are off the image at record -1
-        const size_t rec_floats = ((size_t)W * H + 2) * KMAX * 2;
+        const size_t rec_floats = ((size_t)W * H + 2) * KMAX * (sizeof(PixelRec) / sizeof(float));
         HIP_TRY(hipMalloc(&bs.rec_data, rec_floats * sizeof(float)));
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(bs.rec_data), 0x7fc00000, rec_floats, m->stream));
     }
@@ -422,6 +422,8 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
 int check_frame(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
     if (!f || !f->depth || f->width <= 0 || f->height <= 0) return fail(CHISEL_HIP_ERR_INVALID, "bad depth frame");
     if (f->width > 32767 || f->height > 32767) return fail(CHISEL_HIP_ERR_INVALID, "image larger than 32767 pixels per side");
+    if ((long long)f->width * f->height > (1ll << 27))  // record offsets are 32 bits
+        return fail(CHISEL_HIP_ERR_INVALID, "image larger than 2^27 pixels");
     if (c && (!c->color || c->channels < 1 || c->channels > 4 || c->width <= 0 || c->height <= 0))
         return fail(CHISEL_HIP_ERR_INVALID, "bad colour frame");
     if (c && !m->cfg.use_color)
@@ -810,7 +812,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.slot_dirty, (size_t)C * sizeof(uint32_t)));
     HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
-    HIP_TRY_C(hipMalloc(&v.counters, 16 * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc(&v.counters, 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, sizeof(int), hipHostMallocDefault));
@@ -1356,8 +1358,10 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, m->stream, m->view, INTEGRATE_MAX_GRID);
     HIP_TRY(hipMemcpyAsync(out, m->view.counters, CHISEL_HIP_NUM_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, m->stream));
 #ifdef CHISEL_PHASES
-    uint64_t ph[16];
+    uint64_t ph[25];
     HIP_TRY(hipMemcpyAsync(ph, m->view.counters, sizeof(ph), hipMemcpyDeviceToHost, m->stream));
+    std::vector<uint64_t> rows((size_t)INTEGRATE_MAX_GRID * 16);
+    HIP_TRY(hipMemcpyAsync(rows.data(), m->view.block_counters + (size_t)INTEGRATE_MAX_GRID * 16, rows.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, m->stream));
 #endif
     if (reset_counters)
         HIP_TRY(hipMemsetAsync(m->view.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
@@ -1367,6 +1371,31 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
         fprintf(stderr, "integrate_kernel phases, us per wave: item %.2f frames %.2f deposit %.2f store+or %.2f dequeue %.2f | alive %.2f | waves %llu units/wave %.2f\n",
                 ph[9] * 0.01 / ph[15], ph[10] * 0.01 / ph[15], ph[11] * 0.01 / ph[15], ph[12] * 0.01 / ph[15], ph[13] * 0.01 / ph[15],
                 ph[14] * 0.01 / ph[15], (unsigned long long)ph[15], (double)out[5] * 16.0 / ph[15]);
+    if (ph[15])
+        fprintf(stderr, "   units %llu (%.2f per wave)  frames visited %.2f per unit, executed %.2f per unit (%.2f us each), with a band update %.2f per unit\n",
+                (unsigned long long)ph[19], (double)ph[19] / ph[15], (double)ph[16] / ph[19], (double)ph[17] / ph[19], ph[17] ? ph[18] * 0.01 / ph[17] : 0.0, (double)ph[20] / ph[19]);
+    ph[21] = ~ph[21];
+    if (ph[15] && getenv("CHISEL_HIP_PHASE_TABLE")) {  // wave 0 of every block, grouped by dispatch generation (256 blocks each)
+        uint64_t t0 = ~0ull;
+        for (int b = 0; b < INTEGRATE_MAX_GRID; b++)
+            if (rows[(size_t)b * 16 + 9] && rows[(size_t)b * 16 + 9] < t0) t0 = rows[(size_t)b * 16 + 9];
+        for (int g = 0; g < INTEGRATE_MAX_GRID / 256; g++) {
+            double s_start = 0, s_end = 0, s_units = 0, s_frames = 0, mx_end = 0, mn_end = 1e30;
+            int n = 0;
+            for (int b = g * 256; b < (g + 1) * 256; b++) {
+                const uint64_t *r = &rows[(size_t)b * 16];
+                if (!r[9]) continue;
+                n++;
+                s_start += (r[9] - t0) * 0.01; s_end += (r[10] - t0) * 0.01; s_units += (double)r[11]; s_frames += (double)r[12];
+                mx_end = std::max(mx_end, (r[10] - t0) * 0.01); mn_end = std::min(mn_end, (r[10] - t0) * 0.01);
+            }
+            if (n) fprintf(stderr, "   blocks %4d-%4d: start %.1f us, end %.1f us (min %.1f max %.1f), units %.2f, frames executed %.1f\n", g * 256, g * 256 + 255,
+                           s_start / n, s_end / n, mn_end, mx_end, s_units / n, s_frames / n);
+        }
+    }
+    if (ph[15])
+        fprintf(stderr, "   (meaningful for ONE launch) first wave start -> last wave end %.1f us; last unit started at %.1f us; longest unit %.1f us (%d frames executed, wid %d = item %d unit %d)\n",
+                (ph[22] - ph[21]) * 0.01, (ph[23] - ph[21]) * 0.01, (ph[24] >> 32) * 0.01, (int)(ph[24] & 255), (int)((ph[24] >> 8) & 0xffffff), (int)((ph[24] >> 8) & 0xffffff) / 16, (int)((ph[24] >> 8) & 0xffffff) % 16);
 #endif
     return CHISEL_HIP_OK;
 }
@@ -1488,6 +1517,20 @@ int chisel_hip_kat_reciprocal(unsigned long long *mismatches, unsigned *example_
     memcpy(&lo, &fmin, 4);
     memcpy(&hi, &fmax, 4);
     hipLaunchKernelGGL(kat_reciprocal_kernel, dim3(4096), dim3(256), 0, 0, lo, (unsigned long long)(hi - lo) + 1ull, d, e);
+    HIP_TRY(hipMemcpy(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(example_bits, e, sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    (void)hipFree(e);
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_kat_floor(unsigned long long *mismatches, unsigned *example_bits) {
+    unsigned long long *d = nullptr;
+    unsigned *e = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&e, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(e, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(kat_floor_kernel, dim3(4096), dim3(256), 0, 0, d, e);
     HIP_TRY(hipMemcpy(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(example_bits, e, sizeof(unsigned), hipMemcpyDeviceToHost));
     (void)hipFree(d);

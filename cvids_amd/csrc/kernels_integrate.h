@@ -33,10 +33,10 @@
 namespace chisel_hip {
 
 #ifndef INTEGRATE_WAVES
-#define INTEGRATE_WAVES 8      // waves per SIMD the register allocator must leave room for (<= 64 VGPRs)
+#define INTEGRATE_WAVES 6      // waves per SIMD the register allocator must leave room for (<= 80 VGPRs)
 #endif
 #ifndef INTEGRATE_BLOCKS_PER_CU
-#define INTEGRATE_BLOCKS_PER_CU 8
+#define INTEGRATE_BLOCKS_PER_CU 6
 #endif
 
 constexpr int QUEUE_STRIDE = 32;  // ints between two queue heads (one 128-byte line each)
@@ -71,6 +71,14 @@ __device__ inline int color_pixel(const CameraParams &K, float vx, float vy, flo
 
 __device__ inline float &f4(float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 __device__ inline unsigned &u4(uint4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+// (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32).  Checked against that pair
+// for every float that is not a NaN on the device, and that no NaN comes out as a possible pixel coordinate
+// (chisel_hip_kat_floor, tests/test_gpu_parity.py).
+__device__ inline int floor_to_int(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ inline unsigned wave_count(bool p) { return (unsigned)__popcll(__ballot(p)); }  // active lanes with p, wave-uniform
 
 // ChunkManager::CreateChunk (ChunkManager.cpp:171-174) on the device; one thread.  Returns the slot or -1.
@@ -157,9 +165,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
     const int grid_waves = nb * 4;
     const int rem_chunks = n_items - grid_waves / G::WPC;  // chunks behind the statically dealt ones
     const IntegratorParams &ip = P.ip;
-    unsigned t_sdf = 0, t_col = 0, t_colsat = 0, t_probe = 0, t_carved = 0, n_new = 0, n_updated = 0;  // wave-uniform
+    unsigned t_sdf = 0, t_col = 0, t_colsat = 0, t_probe = 0, t_carved = 0;  // per lane; summed over the wave when it retires
+    unsigned n_new = 0, n_updated = 0;                                       // wave-uniform
     int shard_try = 0;
 #ifdef CHISEL_PHASES
+    unsigned long long ph_last_start = 0, ph_max_unit = 0, ph_exec0 = 0;
+    int ph_wid = 0;
+    unsigned long long ph_visit = 0, ph_exec = 0, ph_exec_t = 0, ph_units = 0, ph_band = 0;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memrealtime(), ph_t0 = ph_t;
 #define PHASE(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph[i] += n_ - ph_t; ph_t = n_; } while (0)
 #else
@@ -210,6 +222,12 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 for (int j = 0; j < 4; j++) wx[j] = ((float)(xq * 4 + j) * ip.res + ip.half_res) + ox;
             }
             PHASE(0);
+#ifdef CHISEL_PHASES
+            ph_units++;
+            ph_last_start = ph_t;
+            ph_exec0 = ph_exec;
+            ph_wid = wid;
+#endif
             // default voxels: DistVoxel() DistVoxel.cpp:27-31, ColorVoxel() ColorVoxel.cpp:27-31
             float4 s4 = make_float4(99999.0f, 99999.0f, 99999.0f, 99999.0f), w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
@@ -221,6 +239,9 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
             const size_t vbase = (size_t)(existed ? slot : 0) * G::V + 4 * (size_t)q;
             unsigned bm = 0u, cm = 0u;  // frames in which this wave integrated / changed a voxel (wave-uniform)
             int carve_v = 0;            // lane k: this wave's carve tests of frame k (items without a slot)
+#ifdef INTEGRATE_FAIR_PRIO
+            int n_exec = 0;             // frames applied so far
+#endif
 
             // camera-z bounds from the cull kernel (conservative): a voxel can be in band only if z_near < z < z_far and can
             // take the carve test only if z < z_carve.  The next frame's bounds are requested while this frame is applied.
@@ -229,6 +250,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
             mask &= mask - 1u;
             FrameBox fb = fbp[k];
             while (true) {
+#ifdef CHISEL_PHASES
+                const unsigned long long fr_t = __builtin_amdgcn_s_memrealtime();
+                ph_visit++;
+#endif
                 const int flags = __builtin_amdgcn_readfirstlane(fb.flags);
                 const float z_near = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_near)));
                 const float z_far = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_far)));
@@ -252,7 +277,20 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 const bool may_band = (zhi > z_near) & (zlo < z_far);
                 const bool need = may_band | (zlo < z_carve);
                 // Branches below are wave-uniform (__any) and the lanes are predicated, so that the counters stay scalar.
+                // From here on a lane's verdicts live in vector registers -- bit masks over its four voxels, per-lane counters that
+                // are summed over the wave once, when the wave retires -- and branches are wave-uniform (__any): the scalar unit
+                // serves all four SIMDs of a CU at about half the vector rate per SIMD, and lane-mask logic (one scalar AND / OR /
+                // popcount per predicate) made it as busy as the vector units.
                 if (__any(need)) {  // else: the whole layer lies outside this frame's band and carve region
+#ifdef INTEGRATE_FAIR_PRIO
+                    switch (n_exec >> 1) {
+                        case 0: __builtin_amdgcn_s_setprio(3); break;
+                        case 1: __builtin_amdgcn_s_setprio(2); break;
+                        case 2: __builtin_amdgcn_s_setprio(1); break;
+                        default: __builtin_amdgcn_s_setprio(0); break;
+                    }
+                    n_exec++;
+#endif
                     // the quad's state, at the first frame that can touch it (straight into the tuples: no use, no wait)
                     if (need && !(st & HAVE)) {
                         s4 = *reinterpret_cast<const float4 *>(M.sdf + vbase);
@@ -265,95 +303,127 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     }
                     const float s0 = C.R[3] * dy + C.R[6] * dz;
                     const float s1 = C.R[4] * dy + C.R[7] * dz;
-                    const bool fastz = (flags & WI_FASTZ) != 0;
-                    bool band[4], carve[4];
-                    int pix[4];
+                    // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45): invZ = 1.0f / z
+                    float inv_z[4];
+                    if (flags & WI_FASTZ) {  // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < 4; j++) inv_z[j] = reciprocal_in_range(pcz[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) inv_z[j] = 1.0f / pcz[j];
+                    }
+                    // ---- geometry + projection -> record of every voxel of the quad, the four gathers in flight together --------
+                    // Record offsets are 32 bits against a scalar base; the base is the all-NaN record in front of the frame's image,
+                    // which a voxel that is off the image (or not wanted) reads: it fails the band and the carve test like a skipped
+                    // pixel.  IsPointOnImage (PinholeCamera.cpp:61-64) is 0 <= u < W && 0 <= v < H, and the integrator skips z < 0
+                    // (ProjectionIntegrator.h:68 / :126).  With iu = floor(u) (as int, saturating; INT_MIN for NaN) the image test is
+                    // (unsigned)iu < W && (unsigned)iv < H -- there floor(u) == (int)u (:72 / :131) -- and z == +-0 or NaN gives
+                    // u, v = +-inf / NaN, which fail it, so "z > 0" is the remaining predicate.  The three tests are chained through
+                    // selects (no lane-mask arithmetic).
+                    const char *rec_base = reinterpret_cast<const char *>(F.rec - 1);
+                    const unsigned row_bytes = (unsigned)C.W * (unsigned)sizeof(PixelRec);
+                    unsigned off[4];
                     PixelRec r[4];
-                    // ---- geometry + projection -> pixel of every voxel of the quad -----------------------------------
+                    float zn[4];  // camera z, or -1 for a quad this frame cannot touch
+#pragma unroll
+                    for (int j = 0; j < 4; j++) zn[j] = need ? pcz[j] : -1.0f;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const float pcx = C.R[0] * dx[j] + s0, pcy = C.R[1] * dx[j] + s1;
-                        // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45)
-                        const float invZ = fastz ? reciprocal_in_range(pcz[j]) : 1.0f / pcz[j];
-                        const float u = C.fx * pcx * invZ + C.cx;
-                        const float v = C.fy * pcy * invZ + C.cy;
-                        // IsPointOnImage (PinholeCamera.cpp:61-64): 0 <= u < W && 0 <= v < H, and not z < 0 (ProjectionIntegrator.h:68 /
-                        // :126).  z == +-0 or NaN gives u, v = +-inf / NaN, which fail the image test, so "z > 0" is the same
-                        // predicate; for u not NaN, floor(u) in [0, W) <=> 0 <= u < W, and there floor(u) == (int)u (:72 / :131).
-                        const int iu = (int)floorf(u), iv = (int)floorf(v);
-                        const bool on = need & (pcz[j] > 0.0f) & ((unsigned)iu < (unsigned)C.W) & ((unsigned)iv < (unsigned)C.H) & (u == u) & (v == v);
-                        // DepthAt(row, col) DepthImage.h:72-76; a voxel that is off the image (or not wanted) reads the all-NaN
-                        // record in front of the frame's image, which fails the band and the carve test like a skipped pixel
-                        pix[j] = on ? iv * C.W + iu : -1;
+                        const float u = C.fx * pcx * inv_z[j] + C.cx;
+                        const float v = C.fy * pcy * inv_z[j] + C.cy;
+                        const int iu = floor_to_int(u), iv = floor_to_int(v);
+                        const int iv_ok = ((unsigned)iu < (unsigned)C.W) ? iv : -1;
+                        const float z_ok = ((unsigned)iv_ok < (unsigned)C.H) ? zn[j] : -1.0f;
+                        // DepthAt(row, col) DepthImage.h:72-76
+                        off[j] = (z_ok > 0.0f) ? __umul24((unsigned)iv, row_bytes) + ((unsigned)iu + 1u) * (unsigned)sizeof(PixelRec) : 0u;
+#ifdef CHISEL_ABLATE_GATHER  // diagnostic (wrong results): what would the kernel cost if the record gathers were coalesced?
+                        r[j] = *reinterpret_cast<const PixelRec *>(rec_base + (off[j] ? (unsigned)((lane * 4 + j + 1) * sizeof(PixelRec)) : 0u));
+#else
+                        r[j] = *reinterpret_cast<const PixelRec *>(rec_base + off[j]);
+#endif
                     }
-                    // ---- the records of the four voxels, in flight together (unconditional loads) ---------------------
-#pragma unroll
-                    for (int j = 0; j < 4; j++) r[j] = F.rec[pix[j]];
-                    // ---- band tests ----------------------------------------------------------------------------------
+                    // ---- band tests: bit j of bandm / carvem = voxel j takes the in-band / the carve branch -------------------------
+                    // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail.
                     float sd[4];
-                    bool any_band = false, any_carve = false;
-                    unsigned frame_carve = 0u;  // wave-uniform
+                    unsigned bandm = 0u, carvem = 0u;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail
-                        sd[j] = r[j].x - pcz[j];                                                          // surfaceDist :79 / :139
-                        band[j] = fabsf(sd[j]) < r[j].y + ip.diag;                                        // :81 / :144
-                        carve[j] = !band[j] & (ip.carving != 0) & (sd[j] > r[j].y + ip.carving_dist);     // :86 / :164
-                        any_band |= band[j];
-                        any_carve |= carve[j];
-                        t_sdf += wave_count(band[j]);
-                        frame_carve += wave_count(carve[j]);
+                        sd[j] = r[j].x - pcz[j];                                                        // surfaceDist :79 / :139
+                        bandm |= (fabsf(sd[j]) < r[j].y + ip.diag) ? (1u << j) : 0u;                    // :81 / :144
+                        carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;                  // :86 / :164 (else branch)
                     }
+                    carvem = ip.carving ? (carvem & ~bandm) : 0u;
+                    t_sdf += (unsigned)__popc(bandm);
                     // `probe`: carve tests on a chunk the reference's map holds before this frame
-                    if (existed) t_probe += frame_carve;
-                    else carve_v = (lane == k) ? (int)frame_carve : carve_v;
-                    if (__any(any_band)) {
+                    if (existed) {
+                        t_probe += (unsigned)__popc(carvem);
+                    } else {
+                        unsigned frame_carve = 0u;  // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < 4; j++) frame_carve += wave_count((carvem >> j) & 1u);
+                        carve_v = (lane == k) ? (int)frame_carve : carve_v;
+                    }
+                    if (__any(bandm != 0u)) {
+#ifdef CHISEL_PHASES
+                        ph_band++;
+#endif
                         bm |= 1u << k;
                         cm |= 1u << k;
                         // colour first: the pixels of the in-band voxels whose colour weight is below 8 are requested now (one 4-byte
                         // gather per voxel, all in flight) and consumed after the sdf arithmetic
-                        bool fresh[4];
                         unsigned cw[4], csh[4];
                         int cpix[4];
-                        bool any_fresh = false;
+                        unsigned freshm = 0u;  // bit j: voxel j takes a colour sample
                         const bool word_gather = COLOR && F.color_channels >= 3;  // wave-uniform
                         if (COLOR) {
                             const unsigned image_bytes = (unsigned)(F.ccam.W * F.ccam.H * F.color_channels);
+                            unsigned hasm = 0u;
 #pragma unroll
                             for (int j = 0; j < 4; j++) {
-                                cpix[j] = SAMECAM ? pix[j] : (band[j] ? color_pixel(F.ccam, wx[j], wy, wz) : -1);
-                                const bool has = band[j] & (cpix[j] >= 0);
-                                fresh[j] = has & ((u4(c4, j) >> 24) < 8u);  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
-                                if (!SAMECAM) t_colsat += wave_count(has & !fresh[j]);  // one camera: colsat = sdf - col
-                                t_col += wave_count(fresh[j]);
-                                any_fresh |= fresh[j];
+                                // one camera: the colour pixel is the depth pixel (its index back from the record offset; in band => on the image)
+                                cpix[j] = SAMECAM ? (int)(off[j] / (unsigned)sizeof(PixelRec)) - 1
+                                                  : (((bandm >> j) & 1u) ? color_pixel(F.ccam, wx[j], wy, wz) : -1);
+                                if (!SAMECAM) hasm |= (cpix[j] >= 0) ? (1u << j) : 0u;
+                                freshm |= ((u4(c4, j) >> 24) < 8u) ? (1u << j) : 0u;  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
                             }
-                            if (word_gather && __any(any_fresh)) {
+                            if (SAMECAM) hasm = bandm;
+                            else hasm &= bandm;
+                            freshm &= hasm;
+                            t_col += (unsigned)__popc(freshm);
+                            if (!SAMECAM) t_colsat += (unsigned)__popc(hasm & ~freshm);  // one camera: colsat = sdf - col
+                            if (word_gather && __any(freshm != 0u)) {
 #pragma unroll
-                                for (int j = 0; j < 4; j++) cw[j] = color_gather(F.color, fresh[j] ? cpix[j] : 0, F.color_channels, image_bytes, csh[j]);
+                                for (int j = 0; j < 4; j++)
+#ifdef CHISEL_ABLATE_GATHER
+                                    cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? lane * 4 + j : 0, F.color_channels, image_bytes, csh[j]);
+#else
+                                    cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? cpix[j] : 0, F.color_channels, image_bytes, csh[j]);
+#endif
                             }
                         }
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            float wu = 1.0f;                                      // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84
-                            if (COLOR) wu = constant_weight(ip.weight, r[j].y);   // IntegrateColor: weighter->GetWeight(.., truncation) :161-162
+                            // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84; IntegrateColor: weighter->GetWeight(.., truncation) :161-162
+                            const float wu = COLOR ? constant_weight(ip.weight, r[j].y) : 1.0f;
                             float ns = f4(s4, j), nw = f4(w4, j);
                             dist_integrate(ns, nw, sd[j], wu);
-                            f4(s4, j) = band[j] ? ns : f4(s4, j);
-                            f4(w4, j) = band[j] ? nw : f4(w4, j);
+                            const bool in_band = ((bandm >> j) & 1u) != 0u;
+                            f4(s4, j) = in_band ? ns : f4(s4, j);
+                            f4(w4, j) = in_band ? nw : f4(w4, j);
                         }
-                        st |= any_band ? DCHG : 0u;
-                        if (COLOR && __any(any_fresh)) {
+                        st |= bandm ? DCHG : 0u;
+                        if (COLOR && __any(freshm != 0u)) {
                             if (word_gather) {
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
                                     const unsigned nc = color_integrate_fresh(u4(c4, j), color_word(cw[j], csh[j]));
-                                    u4(c4, j) = fresh[j] ? nc : u4(c4, j);
+                                    u4(c4, j) = ((freshm >> j) & 1u) ? nc : u4(c4, j);
                                 }
                             } else {  // 1 / 2 channel images
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
-                                    if (fresh[j]) {
+                                    if ((freshm >> j) & 1u) {
                                         unsigned cbits = u4(c4, j);
                                         uchar4 cv = *reinterpret_cast<uchar4 *>(&cbits);
                                         uint8_t cr, cg, cb;
@@ -363,29 +433,29 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                                     }
                                 }
                             }
-                            st |= any_fresh ? CCHG : 0u;
+                            st |= freshm ? CCHG : 0u;
                         }
                     }
-                    if (__any(any_carve)) {
-                        bool any_hit = false;
+                    if (__any(carvem != 0u)) {
+                        unsigned hitm = 0u;
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const bool hit = carve[j] && (f4(w4, j) > 0.0f) && sdf_below_carve_threshold(f4(s4, j));
-                            t_carved += wave_count(hit);
-                            any_hit |= hit;
-                            if (hit) {
-                                if (COLOR && !(f4(w4, j) < 5.0f)) {  // :166-177: decay
-                                    f4(w4, j) = f4(w4, j) - 1.0f;
-                                } else {                            // :88-95 / :170 Carve() == Reset()
-                                    f4(s4, j) = 99999.0f;
-                                    f4(w4, j) = 0.0f;
-                                }
-                            }
+                            const bool hit = ((carvem >> j) & 1u) && (f4(w4, j) > 0.0f) && sdf_below_carve_threshold(f4(s4, j));
+                            hitm |= hit ? (1u << j) : 0u;
+                            const bool decay = COLOR && !(f4(w4, j) < 5.0f);      // :166-177: decay
+                            const float cw_ = decay ? f4(w4, j) - 1.0f : 0.0f;    // else :88-95 / :170 Carve() == Reset()
+                            const float cs_ = decay ? f4(s4, j) : 99999.0f;
+                            f4(w4, j) = hit ? cw_ : f4(w4, j);
+                            f4(s4, j) = hit ? cs_ : f4(s4, j);
                         }
-                        st |= any_hit ? DCHG : 0u;
-                        if (__any(any_hit)) cm |= 1u << k;
+                        t_carved += (unsigned)__popc(hitm);
+                        st |= hitm ? DCHG : 0u;
+                        if (__any(hitm != 0u)) cm |= 1u << k;
                     }
                 }
+#ifdef CHISEL_PHASES
+                if (__any(need)) { ph_exec++; ph_exec_t += __builtin_amdgcn_s_memrealtime() - fr_t; }
+#endif
                 if (k_next < 0) break;
                 k = k_next;
             }
@@ -421,7 +491,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     unsigned v = counts ? cnt : 0u;
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) v += __shfl_down(v, o);
-                    t_probe += (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+                    if (lane == 0) t_probe += v;  // (the counters are per lane)
                 }
                 PHASE(2);
                 if (slot < 0) break;  // never integrated here, or no slot left (error raised)
@@ -448,6 +518,9 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
             }
         } while (false);
         PHASE(3);
+#ifdef CHISEL_PHASES
+        if (ph_last_start && ((ph_t - ph_last_start) << 32) > ph_max_unit) ph_max_unit = ((ph_t - ph_last_start) << 32) | ((unsigned long long)(ph_wid & 0xffffff) << 8) | (ph_exec - ph_exec0);
+#endif
 
         // ---- next unit: this block's home queue head, then its neighbour's.  A head serves the waves of 1 / QUEUE_HEADS of the
         // blocks (same XCD); one returning atomic per unit, <= 64 waves per head: a single word saturates near 90 atomics / us,
@@ -474,13 +547,22 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
         for (int i = 0; i < 5; i++) atomicAdd(&row[9 + i], ph[i]);
         atomicAdd(&row[14], ph_t - ph_t0);
         atomicAdd(&row[15], 1ull);
+        unsigned long long *row2 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)blockIdx.x * 16;
+        atomicMax(&row2[5], ~ph_t0); atomicMax(&row2[6], ph_t); atomicMax(&row2[7], ph_last_start); atomicMax(&row2[8], ph_max_unit);
+        if (wave == 0) { row2[9] = ph_t0; row2[10] = ph_t; row2[11] = ph_units; row2[12] = ph_exec; }
+        atomicAdd(&row2[0], ph_visit); atomicAdd(&row2[1], ph_exec); atomicAdd(&row2[2], ph_exec_t); atomicAdd(&row2[3], ph_units); atomicAdd(&row2[4], ph_band);
     }
 #endif
     // ---- counters: one no-return atomic per wave and counter into this block's private row (rows are summed lazily by
     // reduce_counters_kernel).  Nothing waits for the atomics.
+    unsigned sums[5] = {t_sdf, t_col, (COLOR && SAMECAM) ? (t_sdf - t_col) : t_colsat, t_probe, t_carved};
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sums[c] += __shfl_down(sums[c], o);
     if (lane == 0) {
         unsigned long long *row = M.block_counters + (size_t)blockIdx.x * 16;
-        const unsigned vals[8] = {t_sdf, t_col, (COLOR && SAMECAM) ? (t_sdf - t_col) : t_colsat, t_probe, t_carved, 0u, n_new, n_updated};
+        const unsigned vals[8] = {sums[0], sums[1], sums[2], sums[3], sums[4], 0u, n_new, n_updated};
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (vals[k]) atomicAdd(&row[k], (unsigned long long)vals[k]);
@@ -511,6 +593,17 @@ __global__ void reduce_counters_kernel(MapView M, int n_rows) {
         if (threadIdx.x == 0) M.counters[k] = s[0];
         __syncthreads();
     }
+#ifdef CHISEL_PHASES
+    if (threadIdx.x < 9) {
+        unsigned long long v = 0ull;
+        for (int r = 0; r < n_rows; r++) {
+            const unsigned long long x = M.block_counters[(size_t)INTEGRATE_MAX_GRID * 16 + (size_t)r * 16 + threadIdx.x];
+            if (threadIdx.x >= 5) v = x > v ? x : v;
+            else v += x;
+        }
+        M.counters[16 + threadIdx.x] = v;
+    }
+#endif
 }
 
 }  // namespace chisel_hip

@@ -362,4 +362,22 @@ __global__ void kat_reciprocal_kernel(unsigned first_bits, unsigned long long n,
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// exhaustive over the 2^32 float bit patterns: floor_to_int(x) (v_cvt_flr_i32_f32) against (int)floorf(x) as the compiler emits
+// it (v_floor_f32 + v_cvt_i32_f32) for every x that is not a NaN; for a NaN (the pair gives 0) the result must not be a possible
+// pixel coordinate: the integration kernel's image test is (unsigned)floor_to_int(u) < W and has no separate NaN test
+__global__ void kat_floor_kernel(unsigned long long *mismatches, unsigned *example) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((unsigned)i);
+        const int got = floor_to_int(x);
+        const bool ok = (x == x) ? (got == (int)floorf(x)) : ((unsigned)got >= (1u << 27));
+        if (!ok) {
+            bad++;
+            *example = (unsigned)i;
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace chisel_hip

@@ -118,6 +118,16 @@ def test_device_reciprocal_exhaustive(hip_lib):
     assert bad.value == 0, "first mismatch at bits 0x%08x" % ex.value
 
 
+def test_device_floor_exhaustive(hip_lib):
+    """the one-instruction floor-to-int of the projection ((int)u, (int)v of ProjectionIntegrator.h:72 / :131 after the image
+    test) == v_floor_f32 + v_cvt_i32_f32 for every float that is not a NaN, and a NaN never comes out as a possible pixel
+    coordinate (all 2^32 bit patterns checked on the device)"""
+    import ctypes as C
+    bad, ex = C.c_ulonglong(1), C.c_uint(0)
+    assert hip_lib.chisel_hip_kat_floor(C.byref(bad), C.byref(ex)) == 0
+    assert bad.value == 0, "first mismatch at bits 0x%08x" % ex.value
+
+
 # ---- frame-level parity ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("scene", ["wall", "sphere_room", "box_room"])
 def test_depth_only_stream(oracle_mod, scene):
