@@ -239,9 +239,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
             const size_t vbase = (size_t)(existed ? slot : 0) * G::V + 4 * (size_t)q;
             unsigned bm = 0u, cm = 0u;  // frames in which this wave integrated / changed a voxel (wave-uniform)
             int carve_v = 0;            // lane k: this wave's carve tests of frame k (items without a slot)
-#ifdef INTEGRATE_FAIR_PRIO
-            int n_exec = 0;             // frames applied so far
-#endif
 
             // camera-z bounds from the cull kernel (conservative): a voxel can be in band only if z_near < z < z_far and can
             // take the carve test only if z < z_carve.  The next frame's bounds are requested while this frame is applied.
@@ -282,15 +279,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 // serves all four SIMDs of a CU at about half the vector rate per SIMD, and lane-mask logic (one scalar AND / OR /
                 // popcount per predicate) made it as busy as the vector units.
                 if (__any(need)) {  // else: the whole layer lies outside this frame's band and carve region
-#ifdef INTEGRATE_FAIR_PRIO
-                    switch (n_exec >> 1) {
-                        case 0: __builtin_amdgcn_s_setprio(3); break;
-                        case 1: __builtin_amdgcn_s_setprio(2); break;
-                        case 2: __builtin_amdgcn_s_setprio(1); break;
-                        default: __builtin_amdgcn_s_setprio(0); break;
-                    }
-                    n_exec++;
-#endif
                     // the quad's state, at the first frame that can touch it (straight into the tuples: no use, no wait)
                     if (need && !(st & HAVE)) {
                         s4 = *reinterpret_cast<const float4 *>(M.sdf + vbase);
