@@ -16,10 +16,16 @@ and one RCCL all-gather per batch hands every rank the whole batch (cvids_amd.sh
 stream, ordered against the map with events), then each rank integrates the chunks it owns -> total work is fixed:
 "scaling": "strong".  N > 1 runs integrate only (16 frames per all-gather).
 
+The timed region (W warm-up steps, then exactly K steps between barrier + synchronize) is repeated --repeats times, each
+time from an empty map, and `value` is K / the MEDIAN of those times (p10 / p90 beside it): the driver's default region is
+20 frames = two launch sets = well under a millisecond, a single sample of that is at the mercy of one scheduling hiccup.
+
 One JSON line on rank 0.  `roofline` prices the integration kernel: algorithmic bytes per frame
 (DESIGN.md "Measurement": 16 B per integrated voxel + 8 B per carve probe + 8 B per carve + colour
 bytes + the images once) divided by the kernel's mean duration from hipEvents recorded on the map's
-stream during a second, instrumented pass over the same frames from the same initial map state.
+stream during instrumented passes over the same frames from the same initial map state (median over the passes).
+`roofline.traffic` / `hbm_frac_measured` come from the committed rocprofv3 PMC passes of exactly this command
+(tools/profile.sh -> profiles/*_digest.json, matched on steps / warmup / frames per launch / meshing), null otherwise.
 `cpu_baseline` = the oracle (oracle/liboracle.so: the reference algorithm restated, "faithful mode",
 16 threads as the reference hard-codes) on a bounded sample of the same frames.
 """
@@ -55,12 +61,14 @@ def parse():
                     help="marching-cubes recompute (UpdateMeshes) every M frames inside the timed region; default: 10 at 1 GPU (the "
                          "reference's keyframe cadence, Chisel.cpp:54 -- BASELINE config 3), 0 = off (N > 1: a sharded map is not meshed yet)")
     ap.add_argument("--batch", type=int, default=None,
-                    help="frames per chisel_hip_integrate_batch call (<= 8 share one launch set); default: the keyframe interval when "
-                         "meshing (10 = two launch sets of 5, the recompute falls exactly on every 10th frame), else 8")
+                    help="frames per chisel_hip_integrate_batch call (<= 16 share one launch set); default: the keyframe interval when "
+                         "meshing (10 frames = one launch set, the recompute falls exactly on every 10th frame), else 8")
+    ap.add_argument("--repeats", type=int, default=9, help="timed passes (each from an empty map, with its own warm-up); `value` is the median")
     ap.add_argument("--max-chunks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the same stream the CPU oracle is timed on (about 1 s each at 1 cm)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pcie-leg", action="store_true", help="skip the extra pass over page-locked HOST depth frames (`pcie_inclusive`, 1 GPU only)")
     ap.add_argument("--host-frames", action="store_true", help="hand host (pageable) depth buffers to the library: the PCIe-inclusive rate (never `value`)")
     ap.add_argument("--pinned", action="store_true", help="with --host-frames: the host buffers are page-locked (what a capture pipeline would hand over)")
     ap.add_argument("--sim-shards", type=int, default=0, help="diagnostic, 1 GPU: integrate only the chunks of one shard of an N-way sharded map "
@@ -77,11 +85,14 @@ def algorithmic_bytes(cnt, n_frames, W, H, channels):
     return b
 
 
-def pmc_traffic(kernel_key, frames_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+def pmc_traffic(kernel_key, args, frames_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command
     (tools/profile.sh -> profiles/*_digest.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs).  FETCH_SIZE is doubled
-    as MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte requests at 64 bytes); None when no digest fits."""
+    as MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte requests at 64 bytes).  A digest counts only if it
+    was taken with the same steps, warm-up, frames per launch, meshing cadence, image and voxel size; (None, None) otherwise."""
     import glob
+    want = {"steps": args.steps, "warmup": args.warmup, "frames_per_launch": frames_per_launch, "mesh_every": args.mesh_every,
+            "image": "%dx%d" % (args.width, args.height), "voxel_m": args.res, "chunk": args.chunk, "color": not args.no_color}
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_digest.json"))):
         try:
@@ -89,7 +100,7 @@ def pmc_traffic(kernel_key, frames_per_launch):
         except Exception:
             continue
         k = d.get("kernels", {}).get(kernel_key)
-        if k and "fetch_kib" in k and "write_kib" in k and d.get("frames_per_launch", frames_per_launch) == frames_per_launch:
+        if k and "fetch_kib" in k and "write_kib" in k and all(d.get("bench", {}).get(key) == val for key, val in want.items()):
             best = (f, k)
     if not best:
         return None, None
@@ -206,6 +217,7 @@ def main():
                 keep.append(k2)
         calls.append((n, fa, ca))
     first_timed = next(b for b, (lo, hi) in enumerate(bounds) if lo >= args.warmup) if args.steps else len(bounds)
+    calls_ref = [calls]
 
     def new_map():
         m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
@@ -218,7 +230,7 @@ def main():
     def run(m, b_lo, b_hi):
         L, h = m.L, m.h
         for b in range(b_lo, b_hi):
-            n, fa, ca = calls[b]
+            n, fa, ca = calls_ref[0][b]
             if world > 1:
                 m.px.exchange(b, stack[b], meta[b])  # RCCL all-gather on the communication stream; the map waits for its event
             rc = L.chisel_hip_integrate_batch(h, n, fa, ca)
@@ -234,86 +246,125 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # A process that has just started sees the GPU at idle clocks, and the first pass of a cold process is up to 15 % slower
-    # than the steady state the metric is about: a throw-away pass over the whole stream comes first, then the
-    # integration-only pass (C), the timed pass (A) and the instrumented pass (B).  Every pass starts from a fresh map and does its own W
-    # warm-up frames.
-    m = new_map()
-    run(m, 0, len(bounds))
-    m.synchronize()
-    m.close()
-    fence()
-    # ---- pass C (1 GPU, meshing on): the same stream without the mesh recomputes, for reference ----------------
-    no_mesh = None
-    if args.mesh_every and world == 1 and not args.no_roofline:
-        every, args.mesh_every = args.mesh_every, 0
-        m = new_map()
-        run(m, 0, first_timed)
-        m.synchronize()
-        fence()
-        t2 = time.perf_counter()
-        run(m, first_timed, len(bounds))
-        fence()
-        dt_c = time.perf_counter() - t2
-        m.close()
-        args.mesh_every = every
-        no_mesh = {"value": args.steps / dt_c, "unit": "frames/s", "ms_per_step": dt_c / args.steps * 1e3}
-
-    # ---- pass A: the timed region ---------------------------------------------------------------------
-    m = new_map()
-    run(m, 0, first_timed)
-    m.synchronize()
-    m.counters(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    run(m, first_timed, len(bounds))
-    t_issue = time.perf_counter() - t0  # host time to enqueue everything (no synchronisation yet)
-    fence()
-    dt = time.perf_counter() - t0
-    m.synchronize()  # surfaces pool exhaustion
-    cnt = m.counters()
-    n_chunks = m.NumChunks()
-    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
-    vals = torch.tensor([cnt["sdf"] + cnt["carved"], cnt["sdf"], cnt["col"], cnt["col_sat"], cnt["probe"], cnt["carved"],
-                         cnt["work_chunks"], n_chunks], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
-    dt = float(t_all.item())
-    vals = [float(v) for v in vals.tolist()]
-    m.close()
-
-    # ---- pass B: same frames from the same initial state, hipEvents around every kernel ---------------------
-    roof = None
-    if not args.no_roofline:
-        m = new_map()
+    def timed(m, instrumented=False):
+        """W warm-up steps, then exactly K steps between fences; returns (seconds, host issue seconds, counters, chunks, profile)"""
         run(m, 0, first_timed)
         m.synchronize()
         m.counters(reset=True)
-        m.set_profiling(True)
+        if instrumented:
+            m.set_profiling(True)
         fence()
-        t1 = time.perf_counter()
+        t0 = time.perf_counter()
         run(m, first_timed, len(bounds))
+        t_issue = time.perf_counter() - t0  # host time to enqueue everything (no synchronisation yet)
         fence()
-        dt_b = time.perf_counter() - t1
-        prof = m.profile()
-        cb = m.counters()
-        m.set_profiling(False)
-        m.close()
-        k = prof["integrate"]
-        avg_ms = k["ms"] / max(k["launches"], 1)
-        bytes_per_launch = algorithmic_bytes(cb, args.steps, W, H, channels) / max(k["launches"], 1)
+        dt = time.perf_counter() - t0
+        m.synchronize()  # surfaces pool exhaustion
+        prof = m.profile(reset=True) if instrumented else None
+        cnt = m.counters()
+        if instrumented:
+            m.set_profiling(False)
+        n_chunks = m.NumChunks()
+        t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        return float(t_all.item()), t_issue, cnt, n_chunks, prof
+
+    def median(v):
+        v = sorted(v)
+        return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+    def pct(v, q):
+        v = sorted(v)
+        return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
+
+    # A process that has just started sees the GPU at idle clocks, and the first pass of a cold process is up to 15 % slower
+    # than the steady state the metric is about: a throw-away pass over the whole stream comes first.  Then, every pass from
+    # an EMPTY map with its own W warm-up frames: the integration-only passes (C), the timed passes (A: `value`), the
+    # instrumented passes (B: hipEvents around every kernel), the PCIe-inclusive pass (D).  One map serves all of them
+    # (chisel_hip_reset between passes: the pool is not re-allocated).
+    repeats = max(1, args.repeats)
+    m = new_map()
+    run(m, 0, len(bounds))
+    m.synchronize()
+    fence()
+    # ---- passes C (1 GPU, meshing on): the same stream without the mesh recomputes, for reference ----------------
+    no_mesh = None
+    if args.mesh_every and world == 1 and not args.no_roofline:
+        every, args.mesh_every = args.mesh_every, 0
+        ts = []
+        for _ in range(min(repeats, 5)):
+            m.Reset()
+            ts.append(timed(m)[0])
+        args.mesh_every = every
+        no_mesh = {"value": args.steps / median(ts), "unit": "frames/s", "ms_per_step": median(ts) / args.steps * 1e3, "repeats": len(ts)}
+
+    # ---- passes A: the timed region ---------------------------------------------------------------------
+    ts, issues = [], []
+    for _ in range(repeats):
+        m.Reset()
+        dt_r, t_issue_r, cnt, n_chunks, _ = timed(m)
+        ts.append(dt_r)
+        issues.append(t_issue_r)
+    dt, t_issue = median(ts), median(issues)
+    vals = torch.tensor([cnt["sdf"] + cnt["carved"], cnt["sdf"], cnt["col"], cnt["col_sat"], cnt["probe"], cnt["carved"],
+                         cnt["work_chunks"], n_chunks], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+    vals = [float(v) for v in vals.tolist()]
+
+    # ---- passes B: same frames from the same initial state, hipEvents around every kernel ---------------------
+    roof = None
+    if not args.no_roofline:
+        avgs, others, dts_b = [], [], []
+        for _ in range(min(repeats, 5)):
+            m.Reset()
+            dt_b, _, cb, _, prof = timed(m, instrumented=True)
+            k = prof["integrate"]
+            avgs.append(k["ms"] / max(k["launches"], 1))
+            others.append({n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "resolve", "mesh") if prof[n]["launches"]})
+            dts_b.append(dt_b)
+        avg_ms = median(avgs)
+        launches = k["launches"]
+        bytes_per_launch = algorithmic_bytes(cb, args.steps, W, H, channels) / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernel_key = "integrate_kernel<%d, %s, %s>" % (args.chunk, "true" if use_color else "false", "true" if use_color else "false")
-        traffic, traffic_src = pmc_traffic(kernel_key, args.steps / max(k["launches"], 1)) if world == 1 else (None, None)
+        traffic, traffic_src = pmc_traffic(kernel_key, args, args.steps / max(launches, 1)) if world == 1 else (None, None)
         roof = {"bound": "hbm", "kernel": kernel_key,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "avg_kernel_us": avg_ms * 1e3, "launches": k["launches"], "frames_per_launch": args.steps / max(k["launches"], 1),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,
+                "avg_kernel_us": avg_ms * 1e3, "avg_kernel_us_min_max": [min(avgs) * 1e3, max(avgs) * 1e3], "instrumented_passes": len(avgs),
+                "launches": launches, "frames_per_launch": args.steps / max(launches, 1),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "other_kernels_us": {n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "resolve", "mesh")
-                                     if prof[n]["launches"]},
-                "instrumented_ms_per_step": dt_b / args.steps * 1e3,
-                "note": "rank 0 shard; traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by tools/profile.sh into profiles/"}
+                "other_kernels_us": {n: median([o[n] for o in others if n in o]) for n in others[0]},
+                "instrumented_ms_per_step": median(dts_b) / args.steps * 1e3,
+                "note": "rank 0 shard; algorithmic bytes count every frame's voxel updates (16 B each) although a launch moves a voxel once: "
+                        "`frac` can exceed `hbm_frac_measured`; traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by tools/profile.sh into profiles/"}
+
+    # ---- pass D (1 GPU): the same stream handed over as page-locked HOST depth frames (what a capture pipeline holds): the
+    # PCIe-inclusive rate.  Never `value`.
+    pcie = None
+    if world == 1 and not args.no_pcie_leg and not args.host_frames and not args.no_roofline:
+        pins = [torch.from_numpy(f[0]).pin_memory() for f in frames]
+        saved = calls
+        calls_d = []
+        for b, (lo, hi) in enumerate(bounds):
+            n = hi - lo
+            fa = (capi.DepthFrame * n)()
+            for j in range(n):
+                fa[j], k1 = depth_frame(pins[lo + j].numpy(), frames[lo + j][1], cam)
+                keep.append(k1)
+            calls_d.append((n, fa, saved[b][2]))
+        calls_ref[0] = calls_d
+        ts_d = []
+        for _ in range(min(repeats, 3)):
+            m.Reset()
+            ts_d.append(timed(m)[0])
+        calls_ref[0] = saved
+        pcie = {"value": args.steps / median(ts_d), "unit": "frames/s", "ms_per_step": median(ts_d) / args.steps * 1e3,
+                "source": "page-locked host depth frames read over PCIe during the call (colour image resident)", "repeats": len(ts_d)}
+    m.close()
 
     if rank == 0:
         out = {
@@ -321,12 +372,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + ((" (host depth buffers, %s: PCIe-inclusive)" % ("page-locked" if args.pinned else "pageable")) if args.host_frames else ""),
             "mvoxel_updates_per_s": vals[0] / dt / 1e6, "host_issue_ms_per_step": t_issue / args.steps * 1e3,
+            "repeats": repeats, "value_p10_p90": [args.steps / pct(ts, 0.9), args.steps / pct(ts, 0.1)],
+            "ms_per_step_min_max": [min(ts) / args.steps * 1e3, max(ts) / args.steps * 1e3],
             "config": {"workload": "%dx%d %s stream (%s, %d agent%s), %g cm voxels, chunk %d^3, InverseTruncator(%g), carving 0.05 m, "
                                    "projective TSDF integration%s" % (W, H, "depth+BGR colour" if use_color else "depth-only",
                                                                         args.scene, args.agents, "" if args.agents == 1 else "s",
                                                                         args.res * 100, args.chunk, scale,
                                                                         (" + marching cubes every %d frames" % args.mesh_every) if args.mesh_every else ""),
-                       "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color, "frames_per_call": K,
+                       "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color, "frames_per_call": K, "mesh_every": args.mesh_every,
                        "parallelism": "spatial chunk-hash shards x%d, RCCL all-gather of each %d-frame batch" % (world, K) if world > 1 else "1 GPU"},
             "per_frame": {"voxel_updates": vals[0] / args.steps, "n_sdf": vals[1] / args.steps, "n_col": vals[2] / args.steps,
                           "n_probe": vals[4] / args.steps, "n_carved": vals[5] / args.steps,
@@ -339,6 +392,8 @@ def main():
             out["roofline"] = roof
         if no_mesh:
             out["integration_only"] = no_mesh
+        if pcie:
+            out["pcie_inclusive"] = pcie
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, frames[args.warmup:], color_img, intr, scale)
         print(json.dumps(out), flush=True)

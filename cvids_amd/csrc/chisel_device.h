@@ -52,10 +52,12 @@ __host__ __device__ inline int chunk_owner(int x, int y, int z, int n_shards, in
     return h < 0 ? h + n_shards : h;
 }
 
-// The map's error flag lives in pinned host memory (the device addresses it through MapView::error_flag): a kernel that runs out
-// of chunk slots, hash entries or cloud capacity stores its code there, and the host reads it after a wait without a copy.
-// Plain store: every writer stores a nonzero code, the last one wins.
-__device__ inline void raise_error(int *flag, int code) { *reinterpret_cast<volatile int *>(flag) = code; }
+// The map's error flags live in pinned host memory (the device addresses them through MapView::error_flag): two words, so
+// that neither kind of report can overwrite the other.
+//   [0] chunk pool (1) or chunk hash (2) exhausted: the map is incomplete from here on; stays set until chisel_hip_reset
+//   [1] a property of ONE point cloud (kernels_cloud.h: 3 = too many chunks / pairs, 4 = ray out of range): reported once, cleared
+// Plain stores: every writer of a word stores a nonzero code; the host reads them after a wait, without a copy.
+__device__ inline void raise_error(int *flag, int code) { reinterpret_cast<volatile int *>(flag)[code >= 3 ? 1 : 0] = code; }
 
 struct MapView {
     float *sdf;
@@ -70,7 +72,7 @@ struct MapView {
     int *free_top;
     unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS (filled by reduce_counters_kernel)
     unsigned long long *block_counters;  // [INTEGRATE_MAX_GRID][16] per-workgroup partial sums
-    int *error_flag;         // != 0: pool / hash exhausted (pinned host memory, see raise_error)
+    int *error_flag;         // two words in pinned host memory, see raise_error
     int max_chunks;
 };
 

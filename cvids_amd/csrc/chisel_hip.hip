@@ -275,16 +275,17 @@ hipError_t wait_stream_spinning(hipStream_t st) {
 int check_device_error(chisel_hip_map *m) {
     HIP_TRY(wait_stream_spinning(m->stream));
     std::atomic_thread_fence(std::memory_order_acquire);
-    const int flag = *(volatile int *)m->error_flag_host;  // written by the device (raise_error): no copy
-    if (flag == CLOUD_ERR_CAPACITY || flag == CLOUD_ERR_RANGE) {  // a property of one cloud, not of the map: reported once
-        *(volatile int *)m->error_flag_host = 0;
-        return fail(CHISEL_HIP_ERR_UNSUPPORTED, flag == CLOUD_ERR_CAPACITY
-                                                    ? "point cloud: too many chunks or (chunk, point) pairs for one call"
-                                                    : "point cloud: a ray leaves the supported chunk-id range or is too long");
+    volatile int *flags = m->error_flag_host;  // written by the device (raise_error): no copy
+    const int cloud = flags[1];
+    if (cloud != 0) {  // a property of one cloud, not of the map: reported once
+        flags[1] = 0;
+        if (flags[0] == 0)
+            return fail(CHISEL_HIP_ERR_UNSUPPORTED, cloud == CLOUD_ERR_CAPACITY ? "point cloud: too many chunks or (chunk, point) pairs for one call"
+                                                                                : "point cloud: a ray leaves the supported chunk-id range or is too long");
     }
-    if (flag != 0)
-        return fail(CHISEL_HIP_ERR_POOL_FULL, flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
-                                                        : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
+    if (flags[0] != 0)  // the map is incomplete: every wait reports it until chisel_hip_reset
+        return fail(CHISEL_HIP_ERR_POOL_FULL, flags[0] == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
+                                                            : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
     return CHISEL_HIP_OK;
 }
 
@@ -815,8 +816,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.counters, 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
-    HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, sizeof(int), hipHostMallocDefault));
-    *m->error_flag_host = 0;
+    HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, 2 * sizeof(int), hipHostMallocDefault));
+    m->error_flag_host[0] = m->error_flag_host[1] = 0;
     HIP_TRY_C(hipHostGetDevicePointer((void **)&v.error_flag, m->error_flag_host, 0));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));

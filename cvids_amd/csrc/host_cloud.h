@@ -86,6 +86,10 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
     if (rc) return rc;
     rc = ensure_cloud_buffers(m, cloud->n_points);
     if (rc) return rc;
+    if (m->input_event) {  // chisel_hip_wait_event: a device cloud produced on another stream is ready behind this event
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
     const int n = (int)cloud->n_points;
     CloudView C = m->cloud.view;
     if (cloud->on_device) {

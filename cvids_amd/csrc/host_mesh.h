@@ -232,12 +232,11 @@ int check_mesh_totals(chisel_hip_map *m) {
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     int totals[4] = {m->mesh_totals_host[0], m->mesh_totals_host[1], m->mesh_totals_host[2], m->mesh_totals_host[3]};
-    const int error_flag = m->mesh_totals_host[4];
-    if (error_flag != 0) {  // a chunk of an earlier batch could not be allocated: the map is incomplete
-        free_arena(m, m->arenas[arena_id]);
-        return fail(CHISEL_HIP_ERR_POOL_FULL, error_flag == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
-                                                               : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
-    }
+    // A chunk of an earlier batch could not be allocated (word [0] of the map's error flags: pool / hash; cloud reports live in
+    // word [1] and are none of this function's business): the map is incomplete.  The recompute is finished all the same -- its
+    // mark / collect kernels have already consumed the dirty flags, abandoning it would leave those chunks without a mesh for
+    // good -- and the failure is reported afterwards.
+    const int pool_error = m->mesh_totals_host[4];
     bool redo = false;
     if (totals[MT_OVERFLOW]) {
         // the triangle list was too small: grow it to what this batch needs and list again (dirty flags are not read by the count)
@@ -281,12 +280,16 @@ int check_mesh_totals(chisel_hip_map *m) {
             arena_id = -1;
         }
     }
-    if (n == 0) return CHISEL_HIP_OK;
-    // The per-chunk results (sizes, positions in the arena, ids) stay on the device for now: the bookkeeping follows when
-    // a mesh is next asked for or recomputed (resolve_pending_meshes).
-    m->pending_meshes.active = true;
-    m->pending_meshes.n = n;
-    m->pending_meshes.arena = arena_id;
+    if (n != 0) {
+        // The per-chunk results (sizes, positions in the arena, ids) stay on the device for now: the bookkeeping follows when
+        // a mesh is next asked for or recomputed (resolve_pending_meshes).
+        m->pending_meshes.active = true;
+        m->pending_meshes.n = n;
+        m->pending_meshes.arena = arena_id;
+    }
+    if (pool_error != 0)
+        return fail(CHISEL_HIP_ERR_POOL_FULL, pool_error == 1 ? "chunk pool exhausted: raise chisel_hip_config.max_chunks"
+                                                              : "chunk hash table exhausted: raise chisel_hip_config.max_chunks");
     return CHISEL_HIP_OK;
 }
 

@@ -43,7 +43,8 @@ __global__ void reset_map_kernel(MapView M, int V) {
     }
     if (gid == 0) {
         *M.free_top = M.max_chunks;
-        *M.error_flag = 0;
+        M.error_flag[0] = 0;
+        M.error_flag[1] = 0;
     }
 }
 

@@ -205,6 +205,10 @@ class ShardedChisel:
     def IntegrateBatch(self, local_depth, local_poses, local_cameras, local_color=None):
         """Every rank passes the frames it ingested (x.per of them); all ranks integrate the whole batch in frame order."""
         torch = self.x.torch
+        # This is the simple, synchronous form (PipelinedExchange is the overlapped one): the map's streams may still be reading
+        # the receive / colour buffer and the temporaries of the call before last, which the exchange below refills on the
+        # communication library's stream -- wait for the map first.
+        self.map.synchronize()
         meta = torch.from_numpy(np.stack([pack_meta(p, c) for p, c in zip(local_poses, local_cameras)])).to(local_depth.device)
         depth, meta_all, color = self.x.exchange(local_depth, meta, local_color)
         meta_host = meta_all.cpu().numpy()

@@ -263,7 +263,7 @@ int chisel_hip_depth_filter_read(chisel_hip_depth_filter *filter, int which, dou
 
 /* Binary dump / restore of the whole map (the correct counterpart of chisel_ros FillChunkMessage,
  * Serialization.h:31-84, whose bit packing loses data; also checkpoint / resume).  File: 32-byte header
- * {"CHSLHIP1", int32 chunk edge, float resolution, int32 has_colour, int64 n_chunks, 4 spare bytes}, then per chunk, in
+ * {"CHSLHIP1", int32 chunk edge, float resolution, int32 has_colour, 4 spare bytes, int64 n_chunks}, then per chunk, in
  * ascending id order: int32 id[3], float sdf[V], float weight[V], (uint8 rgbw[4 V] if has_colour).  load replaces the
  * map's contents (Reset first); chunk size, resolution and colour must match the map's. */
 int chisel_hip_save_map(chisel_hip_map *map, const char *path);

@@ -17,7 +17,10 @@ class RecordingMap:
     """Stands in for cvids_amd.chisel.Chisel: records what IntegrateBatch received, owns ids by the product's ownership function."""
 
     def __init__(self, rank, world):
-        self.rank, self.world, self.calls = rank, world, []
+        self.rank, self.world, self.calls, self.syncs = rank, world, [], 0
+
+    def synchronize(self):  # the synchronous batch path waits for the map before refilling a receive buffer
+        self.syncs += 1
 
     def IntegrateBatch(self, integrator, frames, colors=None):
         self.calls.append(([(np.asarray(d.cpu()).copy(), np.asarray(p).copy(), (c.fx, c.fy, c.cx, c.cy, c.near_plane, c.far_plane, c.width, c.height))

@@ -50,6 +50,34 @@ def main(out):
             for k, v in agg.items():
                 digest["kernels"].setdefault(k, {})[key] = sum(v) / len(v)
     import json
+    # which bench command this is a profile of (bench.py: pmc_traffic() takes a digest only for exactly that command)
+    try:
+        b = json.loads(open(os.path.join(out, "bench_plain.json")).read().strip().splitlines()[-1])
+        digest["bench"] = {"steps": b["steps"], "warmup": b["warmup"], "frames_per_launch": b["roofline"]["frames_per_launch"],
+                           "mesh_every": b["config"]["mesh_every"], "image": b["config"]["image"], "voxel_m": b["config"]["voxel_m"],
+                           "chunk": b["config"]["chunk"], "color": b["config"]["color"]}
+        digest["bench_line"] = {"value": b["value"], "roofline": {k: b["roofline"][k] for k in ("frac", "avg_kernel_us", "algorithmic_bytes_per_launch", "launches")}}
+    except Exception as e:  # noqa
+        print("no bench_plain.json line:", e)
+    # the integration kernel's launches inside the timed windows only (every pass of bench.py runs W warm-up frames first; the
+    # all-launch average above mixes those in): passes are equal-length runs of launches, the timed launches are each pass's tail
+    try:
+        per_pass = -(-(b["steps"] + b["warmup"]) // b["config"]["frames_per_call"]) if b["warmup"] % b["config"]["frames_per_call"] == 0 else None
+        if per_pass is None:
+            per_pass = -(-b["warmup"] // b["config"]["frames_per_call"]) + -(-b["steps"] // b["config"]["frames_per_call"])
+        timed = -(-b["steps"] // b["config"]["frames_per_call"])
+        for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+            rows = [r for r in csv.DictReader(open(f)) if short(r["Kernel_Name"]).startswith("integrate_kernel")]
+            rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+            if per_pass and len(d) % per_pass == 0:
+                sel = [x for i, x in enumerate(d) if i % per_pass >= per_pass - timed]
+                digest["integrate_timed_window"] = {"launches": len(sel), "avg_us": sum(sel) / len(sel) / 1e3, "passes": len(d) // per_pass,
+                                                    "launches_per_pass": per_pass, "timed_launches_per_pass": timed}
+                print("== integrate_kernel inside the timed windows only: %d launches (%d passes x last %d of %d), avg %.2f us"
+                      % (len(sel), len(d) // per_pass, timed, per_pass, sum(sel) / len(sel) / 1e3))
+    except Exception as e:  # noqa
+        print("timed-window average not derived:", e)
     json.dump(digest, open(os.path.join(out, "digest.json"), "w"), indent=1, sort_keys=True)
     for name in ("bench_plain.json", "bench_trace.json"):
         p = os.path.join(out, name)
