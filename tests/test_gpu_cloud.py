@@ -310,3 +310,77 @@ def test_cloud_outside_the_supported_envelope_is_reported(hip_lib, oracle_mod):
     gm.counters(reset=True)
     pts, col, pose = _cloud("sphere_room", 1, 64, 48, 0.6, True)
     _step(om, gm, integ, pts, col, pose, what="after the error")
+
+
+def test_cloud_produced_on_another_stream_is_ordered_by_event(hip_lib):
+    """chisel_hip.h: device clouds may be ordered by an event.  The cloud is written on a second stream behind a long kernel; the
+    map is told to wait for the event recorded there (chisel_hip_wait_event) and must read the finished cloud -- the same map as
+    from a host cloud.  Afterwards the map's depth path still works (the event was consumed by the cloud call, not left armed)."""
+    import torch
+    from cvids_amd import chisel as ch
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(1.0), ch.ConstantWeighter(1.0), 0.05, True)
+    pts, col, pose = _cloud("sphere_room", 0, 320, 240, 0.6, True)
+    ref = ch.Chisel((16, 16, 16), 0.01, True, max_chunks=20000)
+    ref.IntegratePointCloud(integ, (pts, col), pose, 0.1, 5.0)
+    want = ref.fields()
+    gm = ch.Chisel((16, 16, 16), 0.01, True, max_chunks=20000)
+    side = torch.cuda.Stream()
+    tp = torch.full((len(pts), 3), float("nan"), device="cuda")  # garbage until the producer has run
+    tc = torch.zeros((len(pts), 3), device="cuda")
+    hp, hc = torch.from_numpy(pts).pin_memory(), torch.from_numpy(col).pin_memory()
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        busy = torch.randn(4096, 4096, device="cuda")
+        for _ in range(20):  # ~ tens of milliseconds in front of the copies
+            busy = busy @ busy * 1e-3
+        tp.copy_(hp, non_blocking=True)
+        tc.copy_(hc, non_blocking=True)
+        ev.record(side)
+    gm.wait_event(ev.cuda_event)
+    gm.IntegratePointCloud(integ, (tp, tc), pose, 0.1, 5.0)
+    compare_fields(want, gm.fields(), 4096, True, atol=0.0, what="cloud behind an event")
+    # the event is gone: a depth frame right after must not wait on (or trip over) it
+    del ev
+    cam = ch.PinholeCamera(*synth.intrinsics(64, 48), 64, 48, 0.05, 5.0)
+    depth, p2 = list(synth.stream("sphere_room", 1, 64, 48))[0]
+    gm.IntegrateDepthScanColor(integ, depth, p2, cam, synth.render_color(64, 48, 3), p2, cam)
+    gm.synchronize()
+    ref.close()
+    gm.close()
+
+
+def test_cloud_report_does_not_hide_pool_exhaustion(hip_lib):
+    """The map keeps two error words: a point cloud's one-off report must not overwrite "chunk pool exhausted", and a mesh
+    recompute after a cloud report must not be taken for pool exhaustion."""
+    from cvids_amd import chisel as ch
+    from cvids_amd.capi import ChiselHipError
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(2.0), ch.ConstantWeighter(1.0), 0.05, True)
+    cam = ch.PinholeCamera(*synth.intrinsics(64, 48), 64, 48, 0.05, 5.0)
+    depth, pose = list(synth.stream("sphere_room", 1, 64, 48))[0]
+    far = np.array([[2.0e6, 0.0, 1.0], [0.0, 0.0, 1.0]], np.float32)  # chunk id 5e6: beyond +-2^20
+    # (1) cloud report, then a recompute: the recompute succeeds, the report comes once as UNSUPPORTED
+    gm = ch.Chisel((8, 8, 8), 0.05, False, max_chunks=4096)
+    gm.IntegrateDepthScan(integ, depth, pose, cam)
+    gm.IntegratePointCloud(integ, (far, None), synth.pose_yaw(0.0), 0.1, 1e9)
+    gm.UpdateMeshes(force=True)
+    with pytest.raises(ChiselHipError) as e:
+        gm.synchronize()
+    assert e.value.code == 5
+    assert len(gm.GetMeshIDs()) > 10      # the recompute was not abandoned
+    gm.synchronize()
+    gm.close()
+    # (2) pool exhaustion, then a cloud report on top: the wait still says POOL_FULL, and keeps saying so until Reset
+    gm = ch.Chisel((8, 8, 8), 0.05, False, max_chunks=16)
+    gm.IntegrateDepthScan(integ, depth, pose, cam)
+    try:
+        gm.IntegratePointCloud(integ, (far, None), synth.pose_yaw(0.0), 0.1, 1e9)
+    except ChiselHipError as e0:  # a call that happens to wait may already see the exhausted pool
+        assert e0.code == 3
+    for _ in range(2):
+        with pytest.raises(ChiselHipError) as e:
+            gm.synchronize()
+        assert e.value.code == 3
+    gm.Reset()
+    gm.synchronize()
+    gm.close()

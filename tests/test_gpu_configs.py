@@ -1,0 +1,267 @@
+"""GPU parity at the BASELINE.json workloads, and of the code paths the small-scene tests do not reach:
+
+  * a colour camera whose pose, intrinsics and image size differ from the depth camera's (integrate_kernel<N, true, false>:
+    second projection, colour pixels off the colour image, saturated colour weights);
+  * config 3 at full size: 640x480 depth + BGR colour, 1 cm voxels, ten-frame launch sets, a mesh recompute on every keyframe --
+    voxels AND meshes against the oracle;
+  * config 4's workload on one GPU: four interleaved agents at 640x480 / 1 cm through eight spatial shards, whose union must be
+    the unsharded map bit for bit, whatever the schedule;
+  * config 5's workload on one GPU: 1280x720 at 0.5 cm against the oracle (far plane reduced so that the oracle's
+    allocate-everything candidate set fits this host's memory -- stated in the test), then garbage collection and a full mesh
+    extraction at the full far plane, checked through properties that do not need the oracle.
+"""
+import numpy as np
+import pytest
+
+from cvids_amd import synth
+from tests.common import compare_fields, make_frames, small_camera
+from tests.test_gpu_mesh import _compare_meshes
+from tests.test_gpu_parity import _mk
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- colour camera != depth camera ------------------------------------------------------------------------------
+def _color_rig(W, H, CW, CH):
+    """a colour camera mounted 4 cm to the right of the depth camera, turned by 3 degrees, with its own focal length and size"""
+    from cvids_amd.chisel import PinholeCamera
+    s = CW / 640.0
+    ccam = PinholeCamera(500.0 * s, 510.0 * s, (CW - 1) / 2.0 + 1.25, (CH - 1) / 2.0 - 0.75, CW, CH, 0.05, 5.0)
+    offset = synth.pose_yaw(3.0, (0.04, 0.005, -0.01)).astype(np.float64)
+    return ccam, offset
+
+
+@pytest.mark.parametrize("N,res,W,H,CW,CH", [(8, 0.05, 64, 48, 80, 60), (16, 0.04, 96, 72, 64, 48), (32, 0.02, 64, 48, 100, 56)])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("batch", [1, 5])
+def test_color_camera_differs_from_depth_camera(oracle_mod, N, res, W, H, CW, CH, channels, batch):
+    om, gm, integ = _mk(oracle_mod, N, res, True, max_chunks=4096)
+    cam = small_camera(W, H)
+    ccam, offset = _color_rig(W, H, CW, CH)
+    if channels == 2:
+        u = np.arange(CW, dtype=np.int32)[None, :].repeat(CH, 0)
+        v = np.arange(CH, dtype=np.int32)[:, None].repeat(CW, 1)
+        color = np.ascontiguousarray(np.stack([(3 * u) % 256, (5 * v + u) % 256], axis=-1).astype(np.uint8))
+    else:
+        color = synth.render_color(CW, CH, channels)
+    intr, cintr = (cam.fx, cam.fy, cam.cx, cam.cy), (ccam.fx, ccam.fy, ccam.cx, ccam.cy)
+    frames = make_frames("box_room", 10, W, H)  # ten frames: colour weights pass 8 (saturated voxels) on the way
+    n_off = 0
+    for lo in range(0, len(frames), batch):
+        part = frames[lo:lo + batch]
+        cposes = [(np.asarray(p, np.float64) @ offset).astype(np.float32) for _, p in part]
+        oc = dict.fromkeys(("sdf", "col", "col_sat", "probe", "carved", "updated_chunks"), 0)
+        for (d, p), cp in zip(part, cposes):
+            om.integrate_depth_color(d, p, intr, color, color_pose=cp, color_intr=cintr, near=cam.near_plane, far=cam.far_plane)
+            c1 = om.counters()
+            for k in oc:
+                oc[k] += c1[k]
+        if batch == 1:
+            gm.IntegrateDepthScanColor(integ, part[0][0], part[0][1], cam, color, cposes[0], ccam)
+        else:
+            gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, cp, ccam) for cp in cposes])
+        gc = gm.counters(reset=True)
+        for k in oc:
+            assert oc[k] == gc[k], "frames %d..: counter %s: oracle %d gpu %d" % (lo, k, oc[k], gc[k])
+        n_off += oc["sdf"] - oc["col"] - oc["col_sat"]  # in-band voxels whose colour pixel is off the colour image
+    compare_fields(om.fields(), gm.fields(), om.V, True, what="distinct colour camera")
+    assert n_off > 0, "the colour camera should miss some in-band voxels in this rig"
+
+
+# ---- config 3 at full size ------------------------------------------------------------------------------------------
+def test_config3_full_size_voxels_and_meshes(oracle_mod):
+    """640x480 depth + BGR colour, 1 cm voxels, 16^3 chunks, InverseTruncator(1), carving 0.05 m: twenty frames in two ten-frame
+    launch sets, UpdateMeshes(force) on each keyframe -- voxels, counters and meshes against the oracle (about 1 s of CPU per
+    frame plus the marching cubes of ~1000 chunks)."""
+    import torch
+    from cvids_amd import chisel as ch
+    W, H, N, res = 640, 480, 16, 0.01
+    intr = synth.intrinsics(W, H)
+    cam = ch.PinholeCamera(*intr, W, H, 0.05, 5.0)
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(1.0), ch.ConstantWeighter(1.0), 0.05, True)
+    frames = list(synth.stream("sphere_room", 20, W, H))
+    color = synth.render_color(W, H, 3)
+    dev = torch.device("cuda:0")
+    d_dev = [torch.from_numpy(d).to(dev) for d, _ in frames]
+    c_dev = torch.from_numpy(color).to(dev)
+    om = oracle_mod.OracleMap(N, res, True, threads=16)
+    om.set_integrator(oracle_mod.TRUNC_INVERSE, 1.0, 1.0, True, 0.05)
+    gm = ch.Chisel((N,) * 3, res, True)
+    tot_o = dict.fromkeys(("sdf", "col", "col_sat", "probe", "carved", "updated_chunks"), 0)
+    for lo in (0, 10):
+        for d, p in frames[lo:lo + 10]:
+            om.integrate_depth_color(d, p, intr, color, near=0.05, far=5.0)
+            oc = om.counters()
+            for k in tot_o:
+                tot_o[k] += oc[k]
+        gm.IntegrateBatch(integ, [(d_dev[i], frames[i][1], cam) for i in range(lo, lo + 10)],
+                          [(c_dev, frames[i][1], cam) for i in range(lo, lo + 10)])
+        om.update_meshes(force=True)
+        gm.UpdateMeshes(force=True)
+        n_meshes, n_vertices = _compare_meshes(om, gm, True)
+        assert n_meshes > 200 and n_vertices > 100000, (n_meshes, n_vertices)
+    gc = gm.counters()
+    for k in tot_o:
+        assert tot_o[k] == gc[k], (k, tot_o[k], gc[k])
+    compare_fields(om.fields(), gm.fields(), om.V, True, what="config 3")
+    assert gm.NumChunks() == om.num_chunks() and gm.NumChunks() > 800
+    gm.close()
+
+
+# ---- config 4: four agents, eight shards ---------------------------------------------------------------------------------
+def test_config4_four_agents_eight_shards_on_one_gpu(monkeypatch):
+    """4-agent 640x480 depth + colour streams (global order a0f0, a1f0, a2f0, a3f0, a0f1, ...), 1 cm voxels, through EIGHT
+    n_shards maps on one GPU: the union of the shards is the unsharded map bit for bit, the shards are disjoint and own what
+    chunk_owner() says, and neither the launch-set size nor the schedule (two-stream pipeline / conservative look-up mode)
+    changes a bit."""
+    import torch
+    from cvids_amd import chisel as ch
+    W, H, N, res, n_shards = 640, 480, 16, 0.01, 8
+    intr = synth.intrinsics(W, H)
+    cam = ch.PinholeCamera(*intr, W, H, 0.05, 5.0)
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(1.0), ch.ConstantWeighter(1.0), 0.05, True)
+    frames = list(synth.stream("sphere_room", 4, W, H, agents=4))  # 16 frames
+    color = synth.render_color(W, H, 3)
+    dev = torch.device("cuda:0")
+    d_dev = [torch.from_numpy(d).to(dev) for d, _ in frames]
+    c_dev = torch.from_numpy(color).to(dev)
+
+    def run(shards, batch, env=None):
+        for k in ("CHISEL_HIP_FORCE_UNCERTAIN", "CHISEL_HIP_FORCE_PIPELINE"):
+            monkeypatch.delenv(k, raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        maps = [ch.Chisel((N,) * 3, res, True, max_chunks=8192, n_shards=shards, shard_rank=r) for r in range(shards)]
+        if env:
+            monkeypatch.delenv(env, raising=False)
+        for lo in range(0, len(frames), batch):
+            idx = range(lo, min(lo + batch, len(frames)))
+            for m in maps:
+                m.IntegrateBatch(integ, [(d_dev[i], frames[i][1], cam) for i in idx], [(c_dev, frames[i][1], cam) for i in idx])
+        out = [m.fields() for m in maps]
+        cnt = [m.counters() for m in maps]
+        for m in maps:
+            m.close()
+        return out, cnt
+
+    (whole,), (cw,) = run(1, 16)
+    assert len(whole) > 1000
+    for batch, env in ((16, None), (4, "CHISEL_HIP_FORCE_PIPELINE"), (8, "CHISEL_HIP_FORCE_UNCERTAIN")):
+        parts, cnts = run(n_shards, batch, env)
+        union = {}
+        for r, f in enumerate(parts):
+            for cid, v in f.items():
+                assert ch.chunk_owner(cid, n_shards, 2) == r, (cid, r)
+                assert cid not in union
+                union[cid] = v
+        assert set(union) == set(whole), (batch, env, len(union), len(whole))
+        for cid in whole:
+            for a, b in zip(union[cid], whole[cid]):
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (batch, env, cid)
+        for k in ("sdf", "col", "col_sat", "probe", "carved", "new_chunks"):
+            assert sum(c[k] for c in cnts) == cw[k], (batch, env, k)
+        # the shards carry comparable loads (the ownership function spreads 2x2x2 super-blocks)
+        loads = [c["sdf"] for c in cnts]
+        assert max(loads) < 2.0 * (sum(loads) / n_shards), loads
+
+
+# ---- config 5: 1280x720 at 0.5 cm ----------------------------------------------------------------------------------
+def test_config5_hd_half_centimetre_against_the_oracle(oracle_mod):
+    """1280x720 depth + colour, 0.5 cm voxels.  The oracle allocates every chunk of the frustum's bounding box before it
+    integrates (Chisel.h:133-143): at the full 5 m far plane that is ~250 k chunks = 33 GB.  Here the far plane is 1.2 m and the
+    scene a wall 1 m in front of the camera (all surface inside the far plane), which keeps the candidate set below 1 GB; the
+    kernels see the same 1280x720 images, 0.5 cm voxels and per-voxel arithmetic as at 5 m."""
+    from cvids_amd import chisel as ch
+    W, H, N, res = 1280, 720, 16, 0.005
+    intr = synth.intrinsics(W, H)
+    cam = ch.PinholeCamera(*intr, W, H, 0.05, 1.2)
+    om = oracle_mod.OracleMap(N, res, True, threads=16)
+    om.set_integrator(oracle_mod.TRUNC_INVERSE, 0.5, 1.0, True, 0.05)
+    gm = ch.Chisel((N,) * 3, res, True, max_chunks=32768)
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(0.5), ch.ConstantWeighter(1.0), 0.05, True)
+    color = synth.render_color(W, H, 3)
+    frames = []
+    for k in range(3):
+        pose = synth.pose_yaw(0.5 * k, (0.01 * k, 0.0, 1.0))  # the "wall" scene is the plane z = 2: the camera stands 1 m from it
+        frames.append((synth.render_depth("wall", pose, intr, W, H, nan_fraction=0.01, frame_index=k), pose))
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color, near=0.05, far=1.2)
+    gm.IntegrateBatch(integ, [(d, p, cam) for d, p in frames], [(color, p, cam) for _, p in frames])
+    compare_fields(om.fields(), gm.fields(), om.V, True, what="config 5")
+    assert gm.NumChunks() == om.num_chunks() and gm.NumChunks() > 150
+    om.update_meshes(force=True)
+    gm.UpdateMeshes(force=True)
+    n_meshes, n_vertices = _compare_meshes(om, gm, True)
+    assert n_meshes > 100 and n_vertices > 100000, (n_meshes, n_vertices)
+    gm.close()
+
+
+def test_config5_hd_full_far_plane_gc_and_full_mesh_extraction():
+    """1280x720, 0.5 cm, 5 m far plane, sphere room (the workload of config 5 on one GPU; no oracle at this size): integration
+    is deterministic across launch-set sizes, garbage collection removes exactly the chunks asked for and restores the pool, a
+    full mesh extraction covers every chunk that has a surface crossing, and a map rebuilt after Reset equals the first."""
+    import torch
+    from cvids_amd import chisel as ch
+    W, H, N, res = 1280, 720, 16, 0.005
+    intr = synth.intrinsics(W, H)
+    cam = ch.PinholeCamera(*intr, W, H, 0.05, 5.0)
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(0.5), ch.ConstantWeighter(1.0), 0.05, True)
+    frames = list(synth.stream("sphere_room", 6, W, H))
+    color = synth.render_color(W, H, 3)
+    dev = torch.device("cuda:0")
+    d_dev = [torch.from_numpy(d).to(dev) for d, _ in frames]
+    c_dev = torch.from_numpy(color).to(dev)
+    gm = ch.Chisel((N,) * 3, res, True, max_chunks=131072)
+
+    def integrate(batch):
+        for lo in range(0, len(frames), batch):
+            idx = range(lo, min(lo + batch, len(frames)))
+            gm.IntegrateBatch(integ, [(d_dev[i], frames[i][1], cam) for i in idx], [(c_dev, frames[i][1], cam) for i in idx])
+
+    integrate(6)
+    ids = np.asarray(gm.GetChunkIDs()).reshape(-1, 3)
+    n0 = gm.NumChunks()
+    assert n0 == len(ids) and n0 > 1500, n0
+    c0 = gm.counters(reset=True)
+    assert c0["sdf"] > 15e6  # several million voxel updates per frame at this resolution
+    sample = [tuple(i) for i in ids[:: max(1, len(ids) // 64)]]
+    ref = {cid: gm.GetChunk(cid) for cid in sample}
+    # full mesh extraction: every chunk of the map is flagged after integration
+    gm.UpdateMeshes(force=True)
+    mesh_ids = np.asarray(gm.GetMeshIDs()).reshape(-1, 3)
+    assert 0.1 * n0 < len(mesh_ids) <= n0
+    have = set(map(tuple, ids.tolist()))
+    assert all(tuple(i) in have for i in mesh_ids.tolist())
+    nv = 0
+    for cid in [tuple(i) for i in mesh_ids[:: max(1, len(mesh_ids) // 32)]]:
+        mesh = gm.GetMesh(cid)
+        v = np.asarray(mesh["vertices"])
+        assert len(v) % 3 == 0 and len(v) > 0
+        lo = np.asarray(cid, np.float32) * N * res
+        assert (v >= lo - 1e-4).all() and (v <= lo + (N + 1) * res + 1e-4).all(), cid  # inside the chunk (+ one voxel of border cubes)
+        nrm = np.asarray(mesh["normals"])
+        assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-3)
+        nv += len(v)
+    assert nv > 1000
+    # garbage collection: remove every other chunk, the rest stays untouched, the pool takes the slots back
+    victims = ids[::2]
+    gm.GarbageCollect(victims)
+    assert gm.NumChunks() == n0 - len(victims)
+    left = set(map(tuple, np.asarray(gm.GetChunkIDs()).reshape(-1, 3).tolist()))
+    assert left == have - set(map(tuple, victims.tolist()))
+    for cid, (s, w, c) in ref.items():
+        if cid in left:
+            s2, w2, c2 = gm.GetChunk(cid)
+            assert np.array_equal(s.view(np.uint32), s2.view(np.uint32)) and np.array_equal(w, w2) and np.array_equal(c, c2)
+    # a rebuilt map (other launch-set size) equals the first one bit for bit
+    gm.Reset()
+    assert gm.NumChunks() == 0
+    integrate(2)
+    assert gm.NumChunks() == n0
+    c1 = gm.counters()
+    for k in ("sdf", "col", "col_sat", "probe", "carved", "new_chunks"):
+        assert c0[k] == c1[k], (k, c0[k], c1[k])
+    for cid, (s, w, c) in ref.items():
+        s2, w2, c2 = gm.GetChunk(cid)
+        assert np.array_equal(s.view(np.uint32), s2.view(np.uint32)) and np.array_equal(w, w2) and np.array_equal(c, c2), cid
+    gm.close()
