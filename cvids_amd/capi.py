@@ -61,7 +61,13 @@ EXPORTS = [
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
-    "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner",
+    "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum",
+]
+# the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
+SELFTEST_EXPORTS = [
+    "chisel_hip_kat_truncation", "chisel_hip_kat_dist", "chisel_hip_kat_color", "chisel_hip_kat_color_fresh", "chisel_hip_kat_color_any",
+    "chisel_hip_kat_reciprocal", "chisel_hip_kat_floor", "chisel_hip_kat_raycast", "chisel_hip_debug_cloud_stats",
+    "chisel_hip_debug_cull_space", "chisel_hip_debug_frustum_range",
 ]
 
 
@@ -157,6 +163,7 @@ def load_library():
             getattr(L, name).argtypes = types
         except AttributeError:
             pass
+    L.chisel_hip_frustum.argtypes = [f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p, f32p]
     L.chisel_hip_debug_frustum_range.argtypes = [f32p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                                                  C.c_int, C.c_float, i32p, i32p, f32p, f32p]
     _lib = L

@@ -2,6 +2,7 @@
 // gfx950 kernels in kernels_*.h.  No CPU fallback: every entry point either runs on the GPU or fails
 // with CHISEL_HIP_ERR_HIP.
 #include "../../include/chisel_hip.h"
+#include "../../include/chisel_hip_selftest.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1564,6 +1565,19 @@ int chisel_hip_debug_cull_space(const int range_min[3], const int range_dim[3], 
     }
     *count = n;
     return space.total;
+}
+int chisel_hip_frustum(const float pose[12], float fy, float cy, int width, int height, float near_plane, float far_plane, float *corners,
+                       float *lines, float *planes) {
+    if (!pose || width <= 0 || height <= 0) return fail(CHISEL_HIP_ERR_INVALID, "bad frustum arguments");
+    const hostmath::FrustumRange fr = hostmath::frustum_range(pose, near_plane, far_plane, fy, cy, width, height, 16, 1.0f);
+    if (corners) memcpy(corners, fr.corners, sizeof(fr.corners));
+    if (planes) memcpy(planes, fr.planes, sizeof(fr.planes));
+    if (lines) {
+        // far face, near face, connecting edges (Frustum.cpp:190-217)
+        static const int idx[24] = {0, 1, 3, 2, 1, 3, 2, 0, 4, 7, 6, 5, 5, 7, 6, 4, 0, 5, 1, 6, 2, 7, 3, 4};
+        for (int i = 0; i < 24; i++) memcpy(lines + 3 * i, fr.corners + 3 * idx[i], 3 * sizeof(float));
+    }
+    return CHISEL_HIP_OK;
 }
 int chisel_hip_debug_frustum_range(const float *pose, float near_plane, float far_plane, float fy, float cy, int W, int H,
                                    int chunk_n, float res, int *range_min3, int *range_dim3, float *planes24, float *corners24) {

@@ -3,8 +3,11 @@
 //
 // Same names, signatures, argument meaning and error behaviour as OpenChisel/open_chisel/include/open_chisel/*.h so
 // that chisel_ros::ChiselServer (chisel_ros/src/ChiselServer.cpp) compiles against these headers unchanged:
-//   - voxels and meshes live in HBM; ChunkManager::GetChunks() / GetChunk() / GetAllMeshes() materialise host
-//     mirrors lazily and the mirrors are invalidated by every integrate / update call;
+//   - voxels and meshes live in HBM; ChunkManager::GetChunks() / GetChunk() / GetAllMeshes() hand out host mirrors: a Chunk
+//     knows its id and geometry at once (ComputeBoundingBox, GetID, GetNumVoxels need no transfer -- chisel_ros walks all chunks
+//     for their box centres every frame, ChiselServer.cpp:594-603) and fetches its voxels on the first GetVoxels() /
+//     GetDistVoxel(); a mirror shows the map as it was when its voxels were fetched, callers hold ChunkPtrs only inside one
+//     callback;
 //   - GetChunk / GetMesh of an absent id throw std::out_of_range like the reference's unordered_map::at
 //     (ChunkManager.h:84-87, 171-178); bool results stay bool; C-ABI failures other than NOT_FOUND become
 //     std::runtime_error carrying chisel_hip_last_error().
@@ -13,6 +16,8 @@
 #define CHISEL_HIP_FACADE_CHISEL_H_
 #include <chisel_hip.h>
 
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -21,6 +26,8 @@
 #include <vector>
 
 #include "camera/PinholeCamera.h"
+#include "geometry/AABB.h"
+#include "geometry/Frustum.h"
 #include "geometry/Geometry.h"
 #include "mesh/Mesh.h"
 #include "pointcloud/PointCloud.h"
@@ -40,12 +47,23 @@ struct ChunkHasher {  // ChunkManager.h:40-52
     std::size_t operator()(const ChunkID &key) const { return (key(0) * p1 ^ key(1) * p2 ^ key(2) * p3); }
 };
 
-class DistVoxel {  // DistVoxel.h:33-77 (payload only: the update rules run in integrate_kernel)
+class DistVoxel {  // DistVoxel.h:33-77.  The map's voxels are updated by integrate_kernel; these methods act on a host mirror.
   public:
     float GetSDF() const { return sdf; }
     float GetWeight() const { return weight; }
     void SetSDF(float v) { sdf = v; }
     void SetWeight(float v) { weight = v; }
+    void Integrate(const float &distUpdate, const float &weightUpdate) {  // DistVoxel.h:52-60
+        const float oldSDF = GetSDF(), oldWeight = GetWeight();
+        const float newDist = (oldWeight * oldSDF + weightUpdate * distUpdate) / (weightUpdate + oldWeight);
+        SetSDF(newDist);
+        SetWeight(oldWeight + weightUpdate);
+    }
+    void Carve() { Reset(); }  // DistVoxel.h:62-66
+    void Reset() {             // DistVoxel.h:68-72
+        sdf = 99999.0f;
+        weight = 0.0f;
+    }
     float sdf = 99999.0f, weight = 0.0f;
 };
 class ColorVoxel {  // ColorVoxel.h:33-100
@@ -54,35 +72,94 @@ class ColorVoxel {  // ColorVoxel.h:33-100
     uint8_t GetGreen() const { return green; }
     uint8_t GetBlue() const { return blue; }
     uint8_t GetWeight() const { return weight; }
+    void SetRed(uint8_t v) { red = v; }
+    void SetGreen(uint8_t v) { green = v; }
+    void SetBlue(uint8_t v) { blue = v; }
+    void SetWeight(uint8_t v) { weight = v; }
+    void Reset() { red = green = blue = weight = 0; }
     uint8_t red = 0, green = 0, blue = 0, weight = 0;
 };
 
-class Chunk {  // Chunk.h:47-140: a host mirror of one device-resident chunk
+inline void hip_check(int rc) {
+    if (rc != CHISEL_HIP_OK) throw std::runtime_error(std::string("chisel_hip: ") + chisel_hip_last_error());
+}
+
+class Chunk {  // Chunk.h:47-140: a host object; either free-standing (to be added to a map) or the mirror of a device-resident chunk
   public:
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+    // free-standing chunk with default voxels (Chunk.cpp:33-44); ChunkManager::AddChunk uploads it
     Chunk(const ChunkID &id, const Eigen::Vector3i &nv, float res, bool color)
-        : ID(id), numVoxels(nv), voxelResolutionMeters(res), voxels((size_t)nv(0) * nv(1) * nv(2)) {
+        : ID(id), numVoxels(nv), voxelResolutionMeters(res), hasColor(color), map(nullptr), loaded(true), voxels((size_t)nv(0) * nv(1) * nv(2)) {
         if (color) colors.resize(voxels.size());
         origin = Vec3(nv(0) * id(0) * res, nv(1) * id(1) * res, nv(2) * id(2) * res);  // Chunk.cpp:43
     }
+    // mirror of the chunk `id` of `m`: the voxels are fetched when they are first asked for
+    Chunk(chisel_hip_map *m, const ChunkID &id, const Eigen::Vector3i &nv, float res, bool color)
+        : ID(id), numVoxels(nv), voxelResolutionMeters(res), hasColor(color), map(m), loaded(false) {
+        origin = Vec3(nv(0) * id(0) * res, nv(1) * id(1) * res, nv(2) * id(2) * res);
+    }
     const ChunkID &GetID() const { return ID; }
+    ChunkID &GetIDMutable() { return ID; }
+    void SetID(const ChunkID &id) { ID = id; }
     const Eigen::Vector3i &GetNumVoxels() const { return numVoxels; }
     float GetVoxelResolutionMeters() const { return voxelResolutionMeters; }
-    size_t GetTotalNumVoxels() const { return voxels.size(); }
-    bool HasColors() const { return !colors.empty(); }
-    bool HasVoxels() const { return !voxels.empty(); }
-    const std::vector<DistVoxel> &GetVoxels() const { return voxels; }
-    const std::vector<ColorVoxel> &GetColorVoxels() const { return colors; }
+    size_t GetTotalNumVoxels() const { return (size_t)numVoxels(0) * numVoxels(1) * numVoxels(2); }
+    bool HasColors() const { return hasColor; }
+    bool HasVoxels() const { return GetTotalNumVoxels() != 0; }
+    const std::vector<DistVoxel> &GetVoxels() const { return Load().voxels; }
+    const std::vector<ColorVoxel> &GetColorVoxels() const { return Load().colors; }
     size_t GetVoxelID(int x, int y, int z) const { return (z * numVoxels(2) + y) * numVoxels(0) + x; }  // Chunk.h:81-84 (sic)
-    const DistVoxel &GetDistVoxel(size_t i) const { return voxels.at(i); }
-    const ColorVoxel &GetColorVoxel(size_t i) const { return colors.at(i); }
+    const DistVoxel &GetDistVoxel(size_t i) const { return Load().voxels.at(i); }
+    DistVoxel &GetDistVoxelMutable(size_t i) { return const_cast<std::vector<DistVoxel> &>(Load().voxels).at(i); }
+    const ColorVoxel &GetColorVoxel(size_t i) const { return Load().colors.at(i); }
+    ColorVoxel &GetColorVoxelMutable(size_t i) { return const_cast<std::vector<ColorVoxel> &>(Load().colors).at(i); }
+    const DistVoxel &GetDistVoxel(int x, int y, int z) const { return GetDistVoxel(GetVoxelID(x, y, z)); }
+    const ColorVoxel &GetColorVoxel(int x, int y, int z) const { return GetColorVoxel(GetVoxelID(x, y, z)); }
     const Vec3 &GetOrigin() const { return origin; }
+    AABB ComputeBoundingBox() const {  // Chunk.cpp:65-70
+        const Vec3 pos = origin;
+        const Vec3 size = numVoxels.cast<float>() * voxelResolutionMeters;
+        return AABB(pos, pos + size);
+    }
+    Point3 GetVoxelCoords(const Vec3 &worldCoords) const {  // Chunk.cpp:72-81
+        const float roundingFactor = 1.0f / voxelResolutionMeters;
+        const Vec3 rel = worldCoords - origin;
+        return Point3((int)std::floor(rel(0) * roundingFactor), (int)std::floor(rel(1) * roundingFactor), (int)std::floor(rel(2) * roundingFactor));
+    }
   protected:
     friend class ChunkManager;
+    const Chunk &Load() const {
+        if (loaded) return *this;
+        loaded = true;
+        const size_t V = GetTotalNumVoxels();
+        voxels.assign(V, DistVoxel());
+        if (hasColor) colors.assign(V, ColorVoxel());
+        std::vector<float> sdf(V), w(V);
+        std::vector<uint8_t> rgbw(hasColor ? V * 4 : 0);
+        const int v[3] = {ID(0), ID(1), ID(2)};
+        const int rc = chisel_hip_download_chunk(map, v, sdf.data(), w.data(), hasColor ? rgbw.data() : nullptr);
+        if (rc == CHISEL_HIP_ERR_NOT_FOUND) return *this;  // removed since the mirror was made: default voxels
+        hip_check(rc);
+        for (size_t i = 0; i < V; i++) {
+            voxels[i].sdf = sdf[i];
+            voxels[i].weight = w[i];
+            if (hasColor) {
+                colors[i].red = rgbw[4 * i];
+                colors[i].green = rgbw[4 * i + 1];
+                colors[i].blue = rgbw[4 * i + 2];
+                colors[i].weight = rgbw[4 * i + 3];
+            }
+        }
+        return *this;
+    }
     ChunkID ID;
     Eigen::Vector3i numVoxels;
     float voxelResolutionMeters;
-    std::vector<DistVoxel> voxels;
-    std::vector<ColorVoxel> colors;
+    bool hasColor;
+    chisel_hip_map *map;
+    mutable bool loaded;
+    mutable std::vector<DistVoxel> voxels;
+    mutable std::vector<ColorVoxel> colors;
     Vec3 origin;
 };
 typedef std::shared_ptr<Chunk> ChunkPtr;
@@ -90,10 +167,6 @@ typedef std::shared_ptr<const Chunk> ChunkConstPtr;
 typedef std::unordered_map<ChunkID, ChunkPtr, ChunkHasher> ChunkMap;
 typedef std::unordered_map<ChunkID, bool, ChunkHasher> ChunkSet;
 typedef std::unordered_map<ChunkID, MeshPtr, ChunkHasher> MeshMap;
-
-inline void hip_check(int rc) {
-    if (rc != CHISEL_HIP_OK) throw std::runtime_error(std::string("chisel_hip: ") + chisel_hip_last_error());
-}
 
 class ProjectionIntegrator {  // ProjectionIntegrator.h:36-232 (Integrate / IntegrateColor per chunk run on the GPU)
   public:
@@ -147,35 +220,61 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
     }
     bool HasChunk(int x, int y, int z) const { return HasChunk(ChunkID(x, y, z)); }
     ChunkPtr GetChunk(const ChunkID &id) const {  // throws std::out_of_range like chunks.at(id) (ChunkManager.h:84-87)
-        const int v[3] = {id(0), id(1), id(2)};
-        const size_t V = (size_t)chunkSize(0) * chunkSize(1) * chunkSize(2);
-        std::vector<float> sdf(V), w(V);
-        std::vector<uint8_t> rgbw(useColor ? V * 4 : 0);
-        const int rc = chisel_hip_download_chunk(map, v, sdf.data(), w.data(), useColor ? rgbw.data() : nullptr);
-        if (rc == CHISEL_HIP_ERR_NOT_FOUND) throw std::out_of_range("ChunkManager::GetChunk");
-        hip_check(rc);
-        ChunkPtr c = std::make_shared<Chunk>(id, chunkSize, voxelResolutionMeters, useColor);
-        for (size_t i = 0; i < V; i++) {
-            c->voxels[i].sdf = sdf[i];
-            c->voxels[i].weight = w[i];
-            if (useColor) {
-                c->colors[i].red = rgbw[4 * i];
-                c->colors[i].green = rgbw[4 * i + 1];
-                c->colors[i].blue = rgbw[4 * i + 2];
-                c->colors[i].weight = rgbw[4 * i + 3];
-            }
-        }
-        return c;
+        if (!HasChunk(id)) throw std::out_of_range("ChunkManager::GetChunk");
+        return std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor);
     }
-    // ids of all chunks; voxels are downloaded on demand by GetChunk (ChiselServer only walks the keys: ChiselServer.cpp:594-603)
+    ChunkPtr GetChunk(int x, int y, int z) const { return GetChunk(ChunkID(x, y, z)); }
+    // every chunk of the map, as mirrors that know their id and box and fetch voxels on demand (ChunkManager.h:65-73)
     const ChunkMap &GetChunks() const {
         int64_t n = 0;
         hip_check(chisel_hip_list_chunks(map, nullptr, 0, &n));
         std::vector<int> ids((size_t)n * 3);
         if (n) hip_check(chisel_hip_list_chunks(map, ids.data(), n, &n));
         chunks.clear();
-        for (int64_t i = 0; i < n; i++) chunks[ChunkID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2])] = ChunkPtr();
+        for (int64_t i = 0; i < n; i++) {
+            const ChunkID id(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+            chunks[id] = std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor);
+        }
         return chunks;
+    }
+    ChunkMap &GetMutableChunks() {
+        GetChunks();
+        return chunks;
+    }
+    int GetBucketSize() const { return (int)chunks.bucket_count(); }
+    // ChunkManager.h:89-92: the chunk's voxels (a free-standing chunk's, or a mirror's as last fetched) become the map's
+    ChunkMap::iterator AddChunk(const ChunkPtr &chunk) {
+        const size_t V = chunk->GetTotalNumVoxels();
+        std::vector<float> sdf(V), w(V);
+        std::vector<uint8_t> rgbw(useColor ? V * 4 : 0);
+        const std::vector<DistVoxel> &dv = chunk->GetVoxels();
+        for (size_t i = 0; i < V; i++) {
+            sdf[i] = dv[i].sdf;
+            w[i] = dv[i].weight;
+        }
+        if (useColor && chunk->HasColors()) {
+            const std::vector<ColorVoxel> &cv = chunk->GetColorVoxels();
+            for (size_t i = 0; i < V; i++) {
+                rgbw[4 * i] = cv[i].red; rgbw[4 * i + 1] = cv[i].green; rgbw[4 * i + 2] = cv[i].blue; rgbw[4 * i + 3] = cv[i].weight;
+            }
+        }
+        const ChunkID id = chunk->GetID();
+        const int v[3] = {id(0), id(1), id(2)};
+        hip_check(chisel_hip_upload_chunk(map, v, sdf.data(), w.data(), useColor ? rgbw.data() : nullptr));
+        return chunks.insert(std::make_pair(id, std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor))).first;
+    }
+    ChunkMap::iterator CreateChunk(const ChunkID &id) {  // ChunkManager.cpp:171-174
+        return AddChunk(std::make_shared<Chunk>(id, chunkSize, voxelResolutionMeters, useColor));
+    }
+    ChunkID GetIDAt(const Vec3 &pos) const {  // ChunkManager.h:136-145
+        const float rx = 1.0f / (chunkSize(0) * voxelResolutionMeters), ry = 1.0f / (chunkSize(1) * voxelResolutionMeters),
+                    rz = 1.0f / (chunkSize(2) * voxelResolutionMeters);
+        return ChunkID((int)std::floor(pos(0) * rx), (int)std::floor(pos(1) * ry), (int)std::floor(pos(2) * rz));
+    }
+    ChunkPtr GetChunkAt(const Vec3 &pos) const {  // ChunkManager.h:124-134
+        const ChunkID id = GetIDAt(pos);
+        if (HasChunk(id)) return GetChunk(id);
+        return ChunkPtr();
     }
     const MeshMap &GetAllMeshes() const {
         int64_t n = 0;
@@ -216,7 +315,32 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         if (!HasChunk(id)) return false;
         const int v[3] = {id(0), id(1), id(2)};
         hip_check(chisel_hip_garbage_collect(map, v, 1));
+        chunks.erase(id);
         return true;
+    }
+    bool RemoveChunk(const ChunkPtr &chunk) { return RemoveChunk(chunk->GetID()); }  // ChunkManager.h:110-113
+    void RemoveChunk(const ChunkMap::iterator &it) {                                // ChunkManager.h:94-97
+        const ChunkID id = it->first;
+        RemoveChunk(id);
+    }
+    bool GetUseColor() const { return useColor; }
+    MeshMap &GetAllMutableMeshes() {
+        GetAllMeshes();
+        return allMeshes;
+    }
+    // ChunkManager.cpp:130-169: marching cubes of the given chunks now (Chisel::UpdateMeshes passes meshesToUpdate)
+    void RecomputeMeshes(const ChunkSet &which) {
+        std::vector<int> ids;
+        for (const std::pair<const ChunkID, bool> &c : which) {
+            ids.push_back(c.first(0)); ids.push_back(c.first(1)); ids.push_back(c.first(2));
+        }
+        hip_check(chisel_hip_update_meshes_of(map, ids.data(), (int)which.size()));
+    }
+    void PrintMemoryStatistics() const {  // ChunkManager.cpp:72-89 (the pool is fixed: what is in use)
+        int64_t n = 0;
+        hip_check(chisel_hip_num_chunks(map, &n));
+        const double mb = (double)n * chunkSize(0) * chunkSize(1) * chunkSize(2) * (useColor ? 12.0 : 8.0) / (1024.0 * 1024.0);
+        std::printf("chisel-hip: %lld chunks resident, %.1f MB of voxel payload in HBM\n", (long long)n, mb);
     }
     bool GetSDF(const Vec3 &pos, double *dist) const {  // ChunkManager.cpp:476-499
         const float p[3] = {pos(0), pos(1), pos(2)};
@@ -232,7 +356,12 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         if (found && grad) *grad = Vec3(g[0], g[1], g[2]);
         return found != 0;
     }
-    void Reset() { hip_check(chisel_hip_reset(map)); }  // ChunkManager.cpp:176-180
+    void Reset() {  // ChunkManager.cpp:176-180
+        hip_check(chisel_hip_reset(map));
+        chunks.clear();
+        allMeshes.clear();
+    }
+    chisel_hip_map *HipMap() const { return map; }
   protected:
     chisel_hip_map *map = nullptr;
     Eigen::Vector3i chunkSize;
@@ -265,6 +394,12 @@ class Chisel {  // Chisel.h:38-230
 
     const ChunkManager &GetChunkManager() const { return chunkManager; }
     ChunkManager &GetMutableChunkManager() { return chunkManager; }
+    // Chisel.h:52-55.  A ChunkManager is a view of one device map: a manager taken from another Chisel would make this object
+    // integrate into one map and answer from the other, so only views of this map are accepted.
+    void SetChunkManager(const ChunkManager &manager) {
+        if (manager.HipMap() != map) throw std::invalid_argument("chisel-hip: SetChunkManager needs a ChunkManager of this Chisel's map");
+        chunkManager = manager;
+    }
 
     template <class DataType>
     void IntegrateDepthScan(const ProjectionIntegrator &integrator, const std::shared_ptr<const DepthImage<DataType>> &depthImage,

@@ -1,11 +1,12 @@
-// camera/{Intrinsics,PinholeCamera,DepthImage,ColorImage}.h of the reference, facade edition (containers and setters
-// only: projection and frustum construction happen inside libchisel_hip.so).
+// camera/{Intrinsics,PinholeCamera,DepthImage,ColorImage}.h of the reference, facade edition (containers and setters;
+// projection and frustum construction happen inside libchisel_hip.so, SetupFrustum asks it for the result).
 #ifndef CHISEL_HIP_FACADE_CAMERA_H_
 #define CHISEL_HIP_FACADE_CAMERA_H_
 #include <cstddef>
 #include <cstdint>
 #include <memory>
 #include <vector>
+#include "../geometry/Frustum.h"
 #include "../geometry/Geometry.h"
 namespace chisel {
 class Intrinsics {  // Intrinsics.h:31-53
@@ -34,6 +35,11 @@ class PinholeCamera {  // PinholeCamera.h:35-69
     float GetFarPlane() const { return farPlane; }
     void SetNearPlane(float v) { nearPlane = v; }
     void SetFarPlane(float v) { farPlane = v; }
+    // PinholeCamera.cpp:55-59: SetFromParams(view, near, far, fy, fy, cx, cy, width, height) -- fy twice, as the reference
+    void SetupFrustum(const Transform &view, Frustum *frustum) const {
+        frustum->SetFromParams(view, nearPlane, farPlane, intrinsics.GetFy(), intrinsics.GetFy(), intrinsics.GetCx(), intrinsics.GetCy(),
+                               (float)width, (float)height);
+    }
   private:
     Intrinsics intrinsics;
     int width = 640, height = 480;

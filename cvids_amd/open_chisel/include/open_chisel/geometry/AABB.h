@@ -1,0 +1,30 @@
+// geometry/AABB.h:33-72 of the reference (facade edition: the members chisel_ros and Chunk::ComputeBoundingBox use)
+#ifndef CHISEL_HIP_FACADE_AABB_H_
+#define CHISEL_HIP_FACADE_AABB_H_
+#include "Geometry.h"
+namespace chisel {
+class AABB {
+  public:
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+    AABB() {}
+    AABB(const Vec3 &min_, const Vec3 &max_) : min(min_), max(max_) {}
+    virtual ~AABB() {}
+    bool Contains(const Vec3 &pos) const {  // AABB.h:43-47
+        return pos(0) >= min(0) && pos(1) >= min(1) && pos(2) >= min(2) && pos(0) <= max(0) && pos(1) <= max(1) && pos(2) <= max(2);
+    }
+    bool Intersects(const AABB &other) const {  // AABB.h:49-58
+        if (min.x() > other.max.x()) return false;
+        if (min.y() > other.max.y()) return false;
+        if (min.z() > other.max.z()) return false;
+        if (max.x() < other.min.x()) return false;
+        if (max.y() < other.min.y()) return false;
+        if (max.z() < other.min.z()) return false;
+        return true;
+    }
+    Vec3 GetCenter() const { return (max + min) * 0.5f; }  // AABB.h:60-63
+    Vec3 GetExtents() const { return (max - min) * 0.5f; }
+    Vec3 min;
+    Vec3 max;
+};
+}  // namespace chisel
+#endif

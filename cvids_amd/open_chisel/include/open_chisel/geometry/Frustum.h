@@ -1,0 +1,57 @@
+// geometry/Frustum.h:32-70 of the reference, facade edition: the view frustum as the library builds it for the candidate
+// enumeration (chisel_hip_frustum: Frustum::SetFromParams / SetFromVectors with the reference's quirks and fp32 order),
+// read-only for the caller (chisel_ros draws GetLines(), ChiselServer.cpp:97-134).
+#ifndef CHISEL_HIP_FACADE_FRUSTUM_H_
+#define CHISEL_HIP_FACADE_FRUSTUM_H_
+#include <chisel_hip.h>
+
+#include <stdexcept>
+
+#include "AABB.h"
+#include "Geometry.h"
+#include "Plane.h"
+namespace chisel {
+class Frustum {
+  public:
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+    Frustum() {}
+    virtual ~Frustum() {}
+    // Frustum.cpp:143-153: fx and cx are accepted and ignored, as in the reference (SetupFrustum passes fy twice anyway)
+    void SetFromParams(const Transform &view, float nearDist, float farDist, float /*fx*/, float fy, float /*cx*/, float cy, float imgWidth,
+                       float imgHeight) {
+        float pose[12], c[24], l[72], p[24];
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) pose[4 * r + k] = view.linear()(r, k);
+            pose[4 * r + 3] = view.translation()(r);
+        }
+        if (chisel_hip_frustum(pose, fy, cy, (int)imgWidth, (int)imgHeight, nearDist, farDist, c, l, p) != CHISEL_HIP_OK)
+            throw std::runtime_error(std::string("chisel_hip: ") + chisel_hip_last_error());
+        for (int i = 0; i < 8; i++) corners[i] = Vec3(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+        for (int i = 0; i < 24; i++) lines[i] = Vec3(l[3 * i], l[3 * i + 1], l[3 * i + 2]);
+        Plane *dst[6] = {&far, &near, &top, &bottom, &left, &right};
+        for (int i = 0; i < 6; i++) *dst[i] = Plane(Vec3(p[4 * i], p[4 * i + 1], p[4 * i + 2]), p[4 * i + 3]);
+    }
+    void ComputeBoundingBox(AABB *box) const {  // Frustum.cpp:101-122
+        Vec3 mn(corners[0]), mx(corners[0]);
+        for (int i = 1; i < 8; i++)
+            for (int k = 0; k < 3; k++) {
+                mn(k) = corners[i](k) < mn(k) ? corners[i](k) : mn(k);
+                mx(k) = corners[i](k) > mx(k) ? corners[i](k) : mx(k);
+            }
+        *box = AABB(mn, mx);
+    }
+    const Plane &GetBottomPlane() const { return bottom; }
+    const Plane &GetTopPlane() const { return top; }
+    const Plane &GetLeftPlane() const { return left; }
+    const Plane &GetRightPlane() const { return right; }
+    const Plane &GetNearPlane() const { return near; }
+    const Plane &GetFarPlane() const { return far; }
+    const Vec3 *GetLines() const { return lines; }
+    const Vec3 *GetCorners() const { return corners; }
+  protected:
+    Vec3 corners[8];
+    Vec3 lines[24];
+    Plane top, left, right, bottom, near, far;
+};
+}  // namespace chisel
+#endif

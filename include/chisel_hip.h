@@ -269,6 +269,20 @@ int chisel_hip_depth_filter_read(chisel_hip_depth_filter *filter, int which, dou
 int chisel_hip_save_map(chisel_hip_map *map, const char *path);
 int chisel_hip_load_map(chisel_hip_map *map, const char *path);
 
+/* ---- view frustum (host arithmetic, no GPU needed) -------------------------------------------------------------- */
+/* PinholeCamera::SetupFrustum (src/camera/PinholeCamera.cpp:55-59) -> Frustum::SetFromParams / SetFromVectors
+ * (src/geometry/Frustum.cpp:143-219), with the reference's quirks (fy is used for both focal lengths, cx is ignored) and fp32
+ * operation order: the frustum the integration enumerates its candidate chunks from, for the caller's use
+ * (chisel_ros draws it: ChiselServer.cpp:97-134).
+ *   corners[8][3]   farTopLeft, farTopRight, farBotLeft, farBotRight, nearBotRight, nearTopLeft, nearTopRight, nearBotLeft
+ *                   (Frustum::GetCorners, Frustum.cpp:181-188)
+ *   lines[24][3]    the 12 edges as point pairs in the order of Frustum::GetLines (Frustum.cpp:190-217)
+ *   planes[6][4]    far, near, top, bottom, left, right: normalised normal xyz + offset as Plane(p1, p2, p3) leaves them
+ *                   (src/geometry/Plane.cpp:44-52: the offset is NOT divided by the normal's length)
+ * Any of the three outputs may be NULL. */
+int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, int height, float near_plane, float far_plane,
+                       float *corners, float *lines, float *planes);
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* accumulated since creation / last reset_counters; out has CHISEL_HIP_NUM_COUNTERS entries */
 int chisel_hip_get_counters(chisel_hip_map *map, uint64_t *out, int reset_counters);

@@ -8,8 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "chisel_hip.h")).read()
+def declared_symbols(header="chisel_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(chisel_hip_[a-z0-9_]+)\s*\(", txt)))
 
@@ -22,6 +22,18 @@ def test_header_symbols_exported(hip_lib):
         assert hasattr(hip_lib, s), "libchisel_hip.so does not export %s" % s
     assert sorted(capi.EXPORTS) == syms, "cvids_amd/capi.py EXPORTS out of sync with include/chisel_hip.h"
     assert hip_lib.chisel_hip_abi_version() == 1
+
+
+def test_every_exported_symbol_is_declared(hip_lib):
+    """the library exports exactly what include/chisel_hip.h (the boundary) and include/chisel_hip_selftest.h
+    (device self-tests, debug read-outs) declare -- checked against the dynamic symbol table."""
+    import subprocess
+    from cvids_amd import capi
+    selftest = declared_symbols("chisel_hip_selftest.h")
+    assert sorted(capi.SELFTEST_EXPORTS) == selftest
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("chisel_hip_")})
+    assert exported == sorted(declared_symbols() + selftest), set(exported) ^ set(declared_symbols() + selftest)
 
 
 def test_struct_layouts_match_header():

@@ -59,3 +59,84 @@ def test_cpp_facade_matches_oracle(oracle_mod, tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("sdf at")][0]
     vals = [float(x) for x in line.split("dist")[1].replace("grad", "").split()]
     assert np.float32(vals[0]) == np.float32(dist) and np.allclose(vals[1:], grad, rtol=0, atol=1e-7)
+
+
+def _write_recording(path, frames, intr, color, encoding):
+    """CVIDSRC1 recording (cvids_amd/open_chisel/tests/replay.cpp): what the topics of chisel_ros would carry"""
+    import struct
+    H, W = frames[0][0].shape
+    ch = 0 if color is None else (1 if color.ndim == 2 else color.shape[2])
+    with open(path, "wb") as f:
+        f.write(b"CVIDSRC1" + struct.pack("<8i", len(frames), W, H, 1 if encoding == "16UC1" else 0, ch, 0, 0, 0))
+        for depth, pose in frames:
+            T = np.asarray(pose, np.float64)
+            R, t = T[:3, :3], T[:3, 3]
+            Ri, ti = R.T, -R.T @ t                       # the camera <- base transform tf would return
+            # quaternion of Ri (x, y, z, w)
+            w = np.sqrt(max(0.0, 1.0 + Ri[0, 0] + Ri[1, 1] + Ri[2, 2])) / 2.0
+            q = np.array([(Ri[2, 1] - Ri[1, 2]) / (4 * w), (Ri[0, 2] - Ri[2, 0]) / (4 * w), (Ri[1, 0] - Ri[0, 1]) / (4 * w), w])
+            f.write(np.asarray(intr, np.float64).tobytes() + ti.tobytes() + q.tobytes())
+            if encoding == "16UC1":
+                mm = np.where(np.isfinite(depth), np.round(depth.astype(np.float64) * 1000.0), 0).astype(np.uint16)
+                f.write(mm.tobytes())
+            else:
+                f.write(np.ascontiguousarray(depth, np.float32).tobytes())
+            if color is not None:
+                f.write(np.ascontiguousarray(color).tobytes())
+
+
+@pytest.mark.parametrize("encoding,use_color", [("32FC1", True), ("16UC1", True), ("32FC1", False)])
+def test_replay_of_a_recorded_stream_matches_the_oracle(oracle_mod, tmp_path, encoding, use_color):
+    """replay.cpp walks a 20-frame recording through ChiselServer's callback order on the C++ facade (camera info -> colour ->
+    depth -> IntegrateDepthScan[Color] -> chunk boxes -> frustum -> UpdateMeshes -> meshes / pose, then the GetAllChunks /
+    SaveMesh / Reset services).  The map it ends with -- read through the ChunkPtr mirrors GetChunks() hands out -- equals the
+    oracle's on the same images (16UC1 millimetres converted as Conversions.h:140-150 does) and the poses the program derived."""
+    tdir = os.path.join(ROOT, "cvids_amd", "open_chisel", "tests")
+    subprocess.check_call(["make", "-C", tdir, "build"])
+    W, H, N, res = 160, 120, 16, 0.04
+    intr = synth.intrinsics(W, H)
+    frames = list(synth.stream("sphere_room", 20, W, H, nan_fraction=0.01))
+    color = synth.render_color(W, H, 3)
+    rec = str(tmp_path / "stream.rec")
+    _write_recording(rec, frames, intr, color, encoding)
+    prefix = str(tmp_path / "out")
+    out = subprocess.run([os.path.join(tdir, "replay"), rec, prefix, str(N), repr(res), "1" if use_color else "0", "0.05", "5.0", "2.0", "0.05"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    per_frame = [l for l in lines if l.startswith("frame ")]
+    assert len(per_frame) == 20 and all("frustum points 24" in l for l in per_frame)
+    # meshes are recomputed on the 1st, 11th call (Chisel.cpp:53-58) and published while nothing is pending
+    assert "published 0 times" not in per_frame[-1]
+    poses = np.fromfile(prefix + ".poses", np.float32).reshape(20, 3, 4)
+    om = oracle_mod.OracleMap(N, res, use_color)
+    om.set_integrator(oracle_mod.TRUNC_INVERSE, 2.0, 1.0, True, 0.05)
+    for (depth, pose), p in zip(frames, poses):
+        assert np.abs(p - np.asarray(pose)[:3, :4]).max() < 1e-5  # the program's inverse of the recorded tf is the pose, to rounding
+        if encoding == "16UC1":
+            mm = np.where(np.isfinite(depth), np.round(depth.astype(np.float64) * 1000.0), 0).astype(np.uint16)
+            d = (np.float32(1.0) / np.float32(1000.0)) * mm.astype(np.float32)
+        else:
+            d = depth
+        P = np.eye(4, dtype=np.float32)
+        P[:3, :4] = p
+        if use_color:
+            om.integrate_depth_color(d, P, intr, color, near=0.05, far=5.0)
+        else:
+            om.integrate_depth(d, P, intr, 0.05, 5.0)
+    V = N ** 3
+    raw = np.fromfile(prefix + ".map", np.uint8)
+    recsz = 12 + V * 8 + (V * 4 if use_color else 0)
+    assert len(raw) % recsz == 0 and len(raw) > 0
+    got = {}
+    for i in range(len(raw) // recsz):
+        b = raw[i * recsz:(i + 1) * recsz]
+        cid = tuple(int(v) for v in b[:12].view(np.int32))
+        sw = b[12:12 + V * 8].view(np.float32).reshape(V, 2)
+        got[cid] = (sw[:, 0].copy(), sw[:, 1].copy(), b[12 + V * 8:].reshape(V, 4).copy() if use_color else np.zeros((V, 4), np.uint8))
+    compare_fields(om.fields(), got, V, use_color, what="replay")
+    n = om.num_chunks()
+    assert ("map: %d chunks written" % n) in out.stdout and "after Reset: 0 chunks" in out.stdout
+    assert ("GetAllChunks %d messages" % n) in out.stdout and "SaveMesh ok" in out.stdout
+    assert ("chunk boxes %d," % n) in per_frame[-1]
+    assert os.path.getsize(prefix + ".ply") > 1000

@@ -40,3 +40,22 @@ def test_range_and_planes_match_oracle(hip_lib, oracle_mod, W, H, N, res, near, 
         assert (cand.min(0) >= np.array(rmin)).all() and (cand.max(0) < np.array(rmin) + np.array(rdim)).all()
         if len(cand) == rdim[0] * rdim[1] * rdim[2]:
             assert list(cand.min(0)) == rmin and list(cand.max(0) - cand.min(0) + 1) == rdim
+
+
+def test_frustum_export_matches_oracle(hip_lib, oracle_mod):
+    """chisel_hip_frustum (the boundary's PinholeCamera::SetupFrustum: what chisel_ros draws, ChiselServer.cpp:97-134): corners and
+    planes equal the oracle's restatement of Frustum::SetFromVectors bit for bit, the 24 line end points are the corners in the
+    order of Frustum.cpp:190-217, NULL outputs are accepted."""
+    W, H = 640, 480
+    intr = synth.intrinsics(W, H)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    order = [0, 1, 3, 2, 1, 3, 2, 0, 4, 7, 6, 5, 5, 7, 6, 4, 0, 5, 1, 6, 2, 7, 3, 4]
+    for pose in [synth.trajectory_pose(k, a) for k in (0, 50, 199) for a in (0, 2)] + [synth.pose_yaw(-120.0, (-30.0, 0.5, -0.25))]:
+        p = np.ascontiguousarray(np.asarray(pose, np.float32)[:3, :4])
+        corners, lines, planes = np.zeros((8, 3), np.float32), np.zeros((24, 3), np.float32), np.zeros((6, 4), np.float32)
+        assert hip_lib.chisel_hip_frustum(fp(p), intr[1], intr[3], W, H, 0.05, 5.0, fp(corners), fp(lines), fp(planes)) == 0
+        oc, op, _ = oracle_mod.frustum(pose, 0.05, 5.0, intr[1], intr[3], W, H)
+        assert np.array_equal(corners, oc) and np.array_equal(planes, op)
+        assert np.array_equal(lines, corners[order])
+        assert hip_lib.chisel_hip_frustum(fp(p), intr[1], intr[3], W, H, 0.05, 5.0, None, fp(lines), None) == 0
+    assert hip_lib.chisel_hip_frustum(None, 1.0, 1.0, W, H, 0.05, 5.0, None, None, None) == 1
