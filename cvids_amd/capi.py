@@ -61,7 +61,7 @@ EXPORTS = [
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
-    "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum",
+    "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
 ]
 # the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
 SELFTEST_EXPORTS = [
@@ -109,6 +109,7 @@ def load_library():
     vp, i32p, f32p, u8p, i64p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
     L.chisel_hip_last_error.restype = C.c_char_p
     L.chisel_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.chisel_hip_create_group.argtypes = [C.POINTER(Config), i32p, C.c_int, C.POINTER(vp)]
     L.chisel_hip_destroy.argtypes = [vp]
     L.chisel_hip_reset.argtypes = [vp]
     L.chisel_hip_set_integrator.argtypes = [vp, C.POINTER(Integrator)]

@@ -141,7 +141,9 @@ class Chisel:
     """chisel::Chisel (Chisel.h:38-230) + the ChunkManager queries its callers use."""
 
     def __init__(self, chunk_size=(16, 16, 16), voxel_resolution=0.03, use_color=False, device_id=-1, max_chunks=0,
-                 n_shards=1, shard_rank=0, shard_block=0):
+                 n_shards=1, shard_rank=0, shard_block=0, devices=None):
+        """devices: a list of HIP device ordinals -> one map spread over these GPUs inside this process
+        (chisel_hip_create_group: one shard per entry; an ordinal may repeat)."""
         self.L = capi.load_library()
         cs = (chunk_size,) * 3 if isinstance(chunk_size, int) else tuple(int(v) for v in chunk_size)
         self.chunk_size = cs
@@ -151,7 +153,11 @@ class Chisel:
         cfg = Config((C.c_int * 3)(*cs), float(voxel_resolution), int(use_color), int(device_id), int(max_chunks),
                      int(n_shards), int(shard_rank), int(shard_block))
         self.h = C.c_void_p()
-        check(self.L.chisel_hip_create(C.byref(cfg), C.byref(self.h)))
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            check(self.L.chisel_hip_create_group(C.byref(cfg), ids, len(devices), C.byref(self.h)))
+        else:
+            check(self.L.chisel_hip_create(C.byref(cfg), C.byref(self.h)))
         self._integrator = None
         self._keep = []
 

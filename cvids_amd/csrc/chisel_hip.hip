@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -16,6 +17,7 @@
 #include <fstream>
 #include <string>
 #include <unordered_map>
+#include <set>
 #include <unordered_set>
 #include <vector>
 
@@ -104,6 +106,10 @@ struct ProfEvent {
 }  // namespace
 
 struct chisel_hip_map {
+    // a group handle (chisel_hip_create_group, host_group.h): no device state of its own, one shard map per GPU
+    bool is_group = false;
+    std::vector<chisel_hip_map *> shards;
+    void *stages = nullptr;  // std::vector<group::Stage>*: staging of device frames for shards on other devices
     chisel_hip_config cfg;
     int N = 0, V = 0;
     int device = 0;
@@ -692,10 +698,35 @@ void expand27(const std::vector<int> &ids, std::unordered_set<uint64_t, IdHash> 
                 for (int dz = -1; dz <= 1; dz++) out.insert(pack_id(ids[i] + dx, ids[i + 1] + dy, ids[i + 2] + dz));
 }
 
+// header of the binary map dump (chisel_hip_save_map / load_map; layout documented in chisel_hip.h)
+struct MapFileHeader {
+    char magic[8];
+    int32_t chunk_edge;
+    float resolution;
+    int32_t has_color;
+    int32_t spare;
+    int64_t n_chunks;
+};
+static_assert(sizeof(MapFileHeader) == 32, "map file header");
+
+// group handles (host_group.h): what the entry points defined in host_mesh.h / host_cloud.h dispatch to
+namespace group {
+int update_meshes(chisel_hip_map *g, int force);
+int get_sdf(chisel_hip_map *g, const float pos[3], double *dist, int *found);
+int get_sdf_and_gradient(chisel_hip_map *g, const float pos[3], double *dist, float grad[3], int *found);
+int integrate_cloud(chisel_hip_map *g, const chisel_hip_pointcloud *cloud);
+int list_meshes(chisel_hip_map *g, int *ids, int64_t max_ids, int64_t *count);
+int save_ply(chisel_hip_map *g, const char *path);
+inline chisel_hip_map *owner_map(chisel_hip_map *g, const int id[3]) {
+    return g->shards[chunk_owner(id[0], id[1], id[2], (int)g->shards.size(), g->cfg.shard_block)];
+}
+}  // namespace group
+
 }  // namespace
 
 #include "host_mesh.h"
 #include "host_cloud.h"
+#include "host_group.h"
 
 extern "C" {
 
@@ -831,7 +862,12 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     return CHISEL_HIP_OK;
 }
 
+int chisel_hip_create_group(const chisel_hip_config *cfg, const int *device_ids, int n_devices, chisel_hip_map **out) {
+    return group::create(cfg, device_ids, n_devices, out);
+}
+
 int chisel_hip_destroy(chisel_hip_map *m) {
+    if (m && m->is_group) return group::destroy(m);
     if (!m) return CHISEL_HIP_OK;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)sync_all(m);
@@ -869,6 +905,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
 }
 
 int chisel_hip_reset(chisel_hip_map *m) {
+    if (m && m->is_group) return group::for_all(m, [](chisel_hip_map *s) { return chisel_hip_reset(s); });
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
     hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
@@ -880,6 +917,7 @@ int chisel_hip_reset(chisel_hip_map *m) {
 }
 
 int chisel_hip_set_integrator(chisel_hip_map *m, const chisel_hip_integrator *in) {
+    if (m && m->is_group) return group::for_all(m, [&](chisel_hip_map *s) { return chisel_hip_set_integrator(s, in); });
     if (!m || !in) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (in->truncator_kind < 0 || in->truncator_kind > 2) return fail(CHISEL_HIP_ERR_INVALID, "unknown truncator kind");
     m->integ = *in;
@@ -887,6 +925,7 @@ int chisel_hip_set_integrator(chisel_hip_map *m, const chisel_hip_integrator *in
 }
 
 int chisel_hip_set_stream(chisel_hip_map *m, void *s) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a group runs on the streams of its shards (one set per GPU): order device frames with chisel_hip_wait_event / record_event");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     int rc = sync_all(m);
     if (rc) return rc;
@@ -895,12 +934,14 @@ int chisel_hip_set_stream(chisel_hip_map *m, void *s) {
 }
 
 int chisel_hip_wait_event(chisel_hip_map *m, void *ev) {
+    if (m && m->is_group) return group::for_all(m, [&](chisel_hip_map *s) { return chisel_hip_wait_event(s, ev); });
     if (!m || !ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     m->input_event = (hipEvent_t)ev;
     return CHISEL_HIP_OK;
 }
 
 int chisel_hip_record_event(chisel_hip_map *m, void *ev) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "one event cannot be recorded on the streams of several GPUs: chisel_hip_synchronize the group instead");
     if (!m || !ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipEventRecord((hipEvent_t)ev, m->stream));
@@ -908,6 +949,7 @@ int chisel_hip_record_event(chisel_hip_map *m, void *ev) {
 }
 
 int chisel_hip_synchronize(chisel_hip_map *m) {
+    if (m && m->is_group) return group::for_all(m, [](chisel_hip_map *s) { return chisel_hip_synchronize(s); });
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
     {
@@ -918,22 +960,26 @@ int chisel_hip_synchronize(chisel_hip_map *m) {
 }
 
 int chisel_hip_integrate_depth(chisel_hip_map *m, const chisel_hip_depth_frame *f) {
+    if (m && m->is_group) return group::integrate(m, 1, f, nullptr);
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     return integrate_frames(m, 1, f, nullptr, 1);
 }
 
 int chisel_hip_integrate_depth_color(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
+    if (m && m->is_group) return group::integrate(m, 1, f, c);
     if (!m || !c) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     return integrate_frames(m, 1, f, c, 1);
 }
 
 int chisel_hip_integrate_batch(chisel_hip_map *m, int n, const chisel_hip_depth_frame *frames,
                                const chisel_hip_color_frame *colors) {
+    if (m && m->is_group) return group::integrate(m, n, frames, colors);
     if (!m || n < 0 || (n > 0 && !frames)) return fail(CHISEL_HIP_ERR_INVALID, "bad batch");
     return integrate_frames(m, n, frames, colors, m->batch_frames);
 }
 
 int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
+    if (m && m->is_group) return group::garbage_collect(m, ids, n);
     if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
@@ -967,6 +1013,16 @@ int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
 }
 
 int chisel_hip_num_chunks(chisel_hip_map *m, int64_t *out) {
+    if (m && m->is_group) {
+        if (!out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+        *out = 0;
+        return group::for_all(m, [&](chisel_hip_map *s) {
+            int64_t n = 0;
+            const int rc = chisel_hip_num_chunks(s, &n);
+            *out += n;
+            return rc;
+        });
+    }
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc = check_device_error(m);
@@ -978,6 +1034,11 @@ int chisel_hip_num_chunks(chisel_hip_map *m, int64_t *out) {
 }
 
 int chisel_hip_list_chunks(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    if (m && m->is_group) {
+        std::vector<int> all;
+        const int rc = group::gather_ids(m, chisel_hip_list_chunks, false, all);
+        return rc ? rc : group::emit_ids(all, ids, max_ids, count);
+    }
     if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc = check_device_error(m);
@@ -991,6 +1052,7 @@ int chisel_hip_list_chunks(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t
 }
 
 int chisel_hip_has_chunk(chisel_hip_map *m, const int id[3], int *out) {
+    if (m && m->is_group) return id ? chisel_hip_has_chunk(group::owner_map(m, id), id, out) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     std::vector<int> slots;
@@ -1001,6 +1063,7 @@ int chisel_hip_has_chunk(chisel_hip_map *m, const int id[3], int *out) {
 }
 
 int chisel_hip_download_chunk(chisel_hip_map *m, const int id[3], float *sdf, float *weight, uint8_t *rgbw) {
+    if (m && m->is_group) return id ? chisel_hip_download_chunk(group::owner_map(m, id), id, sdf, weight, rgbw) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc = check_device_error(m);
@@ -1139,6 +1202,7 @@ int chisel_hip_depth_filter_read(chisel_hip_depth_filter *f, int which, double *
 }
 
 int chisel_hip_export_chunks(chisel_hip_map *m, const int *ids, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_export_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
@@ -1170,6 +1234,7 @@ int chisel_hip_export_chunks(chisel_hip_map *m, const int *ids, int n, float *sd
 
 int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, const float *sdf, const float *weight, const uint8_t *rgbw,
                                    const int *found, int on_device) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_import_ghost_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
@@ -1208,6 +1273,7 @@ int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, con
 }
 
 int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_drop_ghost_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     if (m->ghost_ids.empty()) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
@@ -1226,19 +1292,9 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     return CHISEL_HIP_OK;
 }
 
-namespace {
-struct MapFileHeader {
-    char magic[8];
-    int32_t chunk_edge;
-    float resolution;
-    int32_t has_color;
-    int32_t spare;
-    int64_t n_chunks;
-};
-static_assert(sizeof(MapFileHeader) == 32, "map file header");
-}  // namespace
 
 int chisel_hip_save_map(chisel_hip_map *m, const char *path) {
+    if (m && m->is_group) return group::save_map(m, path);
     if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc = check_device_error(m);  // waits for the queued batches
@@ -1282,6 +1338,7 @@ int chisel_hip_save_map(chisel_hip_map *m, const char *path) {
 }
 
 int chisel_hip_load_map(chisel_hip_map *m, const char *path) {
+    if (m && m->is_group) return group::for_all(m, [&](chisel_hip_map *s) { return chisel_hip_load_map(s, path); });  // every shard takes the chunks it owns
     if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     std::ifstream in(path, std::ios::binary);
     if (!in) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
@@ -1311,6 +1368,7 @@ int chisel_hip_load_map(chisel_hip_map *m, const char *path) {
 }
 
 int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf, const float *weight, const uint8_t *rgbw) {
+    if (m && m->is_group) return id ? chisel_hip_upload_chunk(group::owner_map(m, id), id, sdf, weight, rgbw) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id || !sdf || !weight) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)
         return fail(CHISEL_HIP_ERR_INVALID, "chunk belongs to another shard");
@@ -1335,6 +1393,11 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
 }
 
 int chisel_hip_meshes_to_update(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    if (m && m->is_group) {
+        std::vector<int> all;
+        const int rc = group::gather_ids(m, chisel_hip_meshes_to_update, true, all);
+        return rc ? rc : group::emit_ids(all, ids, max_ids, count);
+    }
     if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     std::vector<int> dirty;
@@ -1355,6 +1418,7 @@ int chisel_hip_meshes_to_update(chisel_hip_map *m, int *ids, int64_t max_ids, in
 }
 
 int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters) {
+    if (m && m->is_group) return out ? group::get_counters(m, out, reset_counters) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     hipLaunchKernelGGL(reduce_counters_kernel, dim3(1), dim3(256), 0, m->stream, m->view, INTEGRATE_MAX_GRID);
@@ -1403,6 +1467,7 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
 }
 
 int chisel_hip_set_profiling(chisel_hip_map *m, int enable) {
+    if (m && m->is_group) return group::for_all(m, [&](chisel_hip_map *s) { return chisel_hip_set_profiling(s, enable); });
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     int rc = drain_profile(m);
     m->profiling = enable != 0;
@@ -1410,6 +1475,7 @@ int chisel_hip_set_profiling(chisel_hip_map *m, int enable) {
 }
 
 int chisel_hip_get_profile(chisel_hip_map *m, double *ms_total, int64_t *launches, int reset_profile) {
+    if (m && m->is_group) return (ms_total && launches) ? group::get_profile(m, ms_total, launches, reset_profile) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     int rc = drain_profile(m);
     if (rc) return rc;
@@ -1482,6 +1548,7 @@ int chisel_hip_kat_color_fresh(unsigned *mismatches) {
 }
 // diagnostics of the last cloud: listed chunks, (unit, point) pairs, rays of the largest unit, units with rays
 int chisel_hip_debug_cloud_stats(chisel_hip_map *m, int64_t out[4]) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "per-shard read-out");
     if (!m || !m->cloud.view.ctl) return fail(CHISEL_HIP_ERR_INVALID, "no cloud yet");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));

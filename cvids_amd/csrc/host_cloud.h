@@ -76,6 +76,7 @@ void launch_cloud_integrate(chisel_hip_map *m, const CloudParams &P, const Cloud
 }  // namespace
 
 extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_hip_pointcloud *cloud) {
+    if (m && m->is_group) return group::integrate_cloud(m, cloud);
     if (!m || !cloud) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (cloud->n_points < 0 || (cloud->n_points > 0 && !cloud->points)) return fail(CHISEL_HIP_ERR_INVALID, "bad point list");
     if (cloud->n_points > (int64_t)(0x7fffffff / (CLOUD_PAIRS_PER_POINT * 2)))

@@ -1,0 +1,478 @@
+// host_group.h -- one TSDF map spread over several GPUs of the node INSIDE ONE PROCESS (chisel_hip_create_group).
+//
+// The reference has one chisel::Chisel object per map (Chisel.h:38-230) and its caller is one process with one thread
+// (chisel_ros: ros::spin); a C++ caller that links libchisel_hip.so therefore cannot start one process per GPU the way
+// bench.py / cvids_amd/sharded.py do.  A group handle is a chisel_hip_map* like any other: every entry point of chisel_hip.h
+// works on it, the library does what the ranks of the multi-process form do --
+//   * one shard map per entry of device_ids[] (n_shards = n, shard_rank = i: chunk_owner() decides who holds a chunk; the same
+//     device may be named several times, which is how the tests run on one GPU);
+//   * integrate: every shard is handed every frame, in order (host frames as they are; device frames are used in place by the
+//     shards on the frame's device and copied peer-to-peer, on a copy stream ordered with events, for the others), and all
+//     shards integrate concurrently on their own streams;
+//   * UpdateMeshes: the union of the shards' meshesToUpdate is formed, every shard meshes the ids it owns after importing the
+//     neighbour chunks it lacks from their owners as ghosts (payload exported into / imported from HBM, peer copy between
+//     devices) -- the protocol of cvids_amd/sharded.py: ShardedChisel.UpdateMeshes without the collectives;
+//   * queries are routed to the owner (chunks, meshes, SDF) or merged in ascending id order (listings, PLY, map dump).
+// No data-path collective is involved: a voxel has one owner and no reduction exists on this path.
+#pragma once
+
+namespace {
+namespace group {
+
+struct Stage {                       // device frames copied to a shard on another device (two sets alternate per batch)
+    float *depth[2] = {nullptr, nullptr};
+    uint8_t *color[2] = {nullptr, nullptr};
+    size_t depth_elems = 0, color_bytes = 0;   // per frame
+    hipStream_t copy = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    bool armed[2] = {false, false};
+    unsigned turn = 0;
+};
+
+inline int n_shards(const chisel_hip_map *g) { return (int)g->shards.size(); }
+inline int owner_of(const chisel_hip_map *g, const int id[3]) { return chunk_owner(id[0], id[1], id[2], n_shards(g), g->cfg.shard_block); }
+inline bool id_less(const int *a, const int *b) { return a[0] != b[0] ? a[0] < b[0] : (a[1] != b[1] ? a[1] < b[1] : a[2] < b[2]); }
+
+int create(const chisel_hip_config *cfg, const int *device_ids, int n, chisel_hip_map **out) {
+    if (!cfg || !out || !device_ids || n < 1 || n > 64) return fail(CHISEL_HIP_ERR_INVALID, "bad device list");
+    *out = nullptr;
+    chisel_hip_map *g = new chisel_hip_map();
+    g->cfg = *cfg;
+    g->cfg.n_shards = n;
+    g->cfg.shard_rank = 0;
+    g->cfg.shard_block = cfg->shard_block < 1 ? 2 : cfg->shard_block;
+    g->is_group = true;
+    for (int i = 0; i < n; i++) {
+        chisel_hip_config c = *cfg;
+        c.device_id = device_ids[i];
+        c.n_shards = n;
+        c.shard_rank = i;
+        chisel_hip_map *s = nullptr;
+        const int rc = chisel_hip_create(&c, &s);
+        if (rc) {
+            for (chisel_hip_map *p : g->shards) chisel_hip_destroy(p);
+            delete g;
+            return rc;
+        }
+        g->shards.push_back(s);
+    }
+    g->N = g->shards[0]->N;
+    g->V = g->shards[0]->V;
+    g->device = g->shards[0]->device;
+    g->stages = new std::vector<Stage>(n);
+    // peer access between the devices of the group (a failure here only costs the copies their direct path)
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            if (g->shards[i]->device != g->shards[j]->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, g->shards[i]->device, g->shards[j]->device) == hipSuccess && can) {
+                    (void)hipSetDevice(g->shards[i]->device);
+                    (void)hipDeviceEnablePeerAccess(g->shards[j]->device, 0);
+                    (void)hipGetLastError();
+                }
+            }
+    *out = g;
+    return CHISEL_HIP_OK;
+}
+
+int destroy(chisel_hip_map *g) {
+    std::vector<Stage> *st = static_cast<std::vector<Stage> *>(g->stages);
+    for (size_t i = 0; i < g->shards.size(); i++) {
+        if (st) {
+            Stage &S = (*st)[i];
+            (void)hipSetDevice(g->shards[i]->device);
+            if (S.copy) (void)hipStreamSynchronize(S.copy);
+            for (int b = 0; b < 2; b++) {
+                if (S.depth[b]) (void)hipFree(S.depth[b]);
+                if (S.color[b]) (void)hipFree(S.color[b]);
+                if (S.ready[b]) (void)hipEventDestroy(S.ready[b]);
+                if (S.consumed[b]) (void)hipEventDestroy(S.consumed[b]);
+            }
+            if (S.copy) (void)hipStreamDestroy(S.copy);
+        }
+        chisel_hip_destroy(g->shards[i]);
+    }
+    delete st;
+    delete g;
+    return CHISEL_HIP_OK;
+}
+
+template <class F>
+int for_all(chisel_hip_map *g, F fn) {
+    for (chisel_hip_map *s : g->shards) {
+        const int rc = fn(s);
+        if (rc) return rc;
+    }
+    return CHISEL_HIP_OK;
+}
+
+int device_of(const void *p, int fallback) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeDevice) return attr.device;
+    (void)hipGetLastError();
+    return fallback;
+}
+
+// n <= KMAX frames of one image size to every shard
+int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors) {
+    std::vector<Stage> &st = *static_cast<std::vector<Stage> *>(g->stages);
+    const size_t npx = (size_t)frames[0].width * frames[0].height;
+    size_t cbytes = 0;
+    if (colors)
+        for (int k = 0; k < n; k++) cbytes = std::max(cbytes, (size_t)colors[k].width * colors[k].height * colors[k].channels);
+    for (size_t i = 0; i < g->shards.size(); i++) {
+        chisel_hip_map *s = g->shards[i];
+        std::vector<chisel_hip_depth_frame> f(frames, frames + n);
+        std::vector<chisel_hip_color_frame> c;
+        if (colors) c.assign(colors, colors + n);
+        bool foreign = false;
+        for (int k = 0; k < n; k++) {
+            foreign |= f[k].on_device && device_of(f[k].depth, s->device) != s->device;
+            if (colors) foreign |= c[k].on_device && device_of(c[k].color, s->device) != s->device;
+        }
+        Stage &S = st[i];
+        int b = -1;
+        if (foreign) {
+            HIP_TRY(hipSetDevice(s->device));
+            if (!S.copy) {
+                HIP_TRY(hipStreamCreateWithFlags(&S.copy, hipStreamNonBlocking));
+                for (int q = 0; q < 2; q++) {
+                    HIP_TRY(hipEventCreateWithFlags(&S.ready[q], hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&S.consumed[q], hipEventDisableTiming));
+                }
+            }
+            if (npx > S.depth_elems || cbytes > S.color_bytes) {
+                HIP_TRY(hipStreamSynchronize(S.copy));
+                int rc = chisel_hip_synchronize(s);
+                if (rc) return rc;
+                for (int q = 0; q < 2; q++) {
+                    if (S.depth[q]) HIP_TRY(hipFree(S.depth[q]));
+                    if (S.color[q]) HIP_TRY(hipFree(S.color[q]));
+                    S.depth[q] = nullptr;
+                    S.color[q] = nullptr;
+                    HIP_TRY(hipMalloc(&S.depth[q], std::max(npx, S.depth_elems) * KMAX * sizeof(float)));
+                    if (std::max(cbytes, S.color_bytes)) HIP_TRY(hipMalloc(&S.color[q], std::max(cbytes, S.color_bytes) * KMAX));
+                    S.armed[q] = false;
+                }
+                S.depth_elems = std::max(npx, S.depth_elems);
+                S.color_bytes = std::max(cbytes, S.color_bytes);
+            }
+            b = (int)(S.turn++ & 1u);
+            if (S.armed[b]) HIP_TRY(hipStreamWaitEvent(S.copy, S.consumed[b], 0));  // the batch that last used this set has been integrated
+            for (int k = 0; k < n; k++) {
+                if (f[k].on_device) {
+                    const int src = device_of(f[k].depth, s->device);
+                    if (src != s->device) {
+                        float *dst = S.depth[b] + (size_t)k * S.depth_elems;
+                        HIP_TRY(hipMemcpyPeerAsync(dst, s->device, f[k].depth, src, npx * sizeof(float), S.copy));
+                        f[k].depth = dst;
+                    }
+                }
+                if (colors && c[k].on_device) {
+                    const int src = device_of(c[k].color, s->device);
+                    if (src != s->device) {
+                        uint8_t *dst = S.color[b] + (size_t)k * S.color_bytes;
+                        HIP_TRY(hipMemcpyPeerAsync(dst, s->device, c[k].color, src, (size_t)c[k].width * c[k].height * c[k].channels, S.copy));
+                        c[k].color = dst;
+                    }
+                }
+            }
+            HIP_TRY(hipEventRecord(S.ready[b], S.copy));
+            int rc = chisel_hip_wait_event(s, S.ready[b]);
+            if (rc) return rc;
+        }
+        int rc = chisel_hip_integrate_batch(s, n, f.data(), colors ? c.data() : nullptr);
+        if (rc) return rc;
+        if (foreign) {
+            rc = chisel_hip_record_event(s, S.consumed[b]);
+            if (rc) return rc;
+            S.armed[b] = true;
+        }
+    }
+    return CHISEL_HIP_OK;
+}
+
+// frames in order; consecutive frames of one image size go out KMAX at a time (as integrate_frames cuts them for one map)
+int integrate(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors) {
+    if (n < 0 || (n > 0 && !frames)) return fail(CHISEL_HIP_ERR_INVALID, "bad frame list");
+    int i = 0;
+    while (i < n) {
+        int run = 1;
+        while (i + run < n && run < KMAX && frames[i + run].width == frames[i].width && frames[i + run].height == frames[i].height) run++;
+        const int rc = integrate_set(g, run, frames + i, colors ? colors + i : nullptr);
+        if (rc) return rc;
+        i += run;
+    }
+    return CHISEL_HIP_OK;
+}
+
+int integrate_cloud(chisel_hip_map *g, const chisel_hip_pointcloud *cloud) {
+    if (!cloud) return fail(CHISEL_HIP_ERR_INVALID, "null cloud");
+    if (cloud->on_device) {
+        for (chisel_hip_map *s : g->shards)
+            if (device_of(cloud->points, s->device) != s->device)
+                return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a device-resident point cloud must live on the device of every shard of the group: pass a host cloud");
+    }
+    return for_all(g, [&](chisel_hip_map *s) { return chisel_hip_integrate_pointcloud(s, cloud); });
+}
+
+int garbage_collect(chisel_hip_map *g, const int *ids, int n) {
+    if (n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
+    std::vector<std::vector<int>> per(g->shards.size());
+    for (int j = 0; j < n; j++) {
+        std::vector<int> &v = per[owner_of(g, ids + 3 * j)];
+        v.insert(v.end(), ids + 3 * j, ids + 3 * j + 3);
+    }
+    for (size_t i = 0; i < g->shards.size(); i++)
+        if (!per[i].empty()) {
+            const int rc = chisel_hip_garbage_collect(g->shards[i], per[i].data(), (int)per[i].size() / 3);
+            if (rc) return rc;
+        }
+    return CHISEL_HIP_OK;
+}
+
+// sorted union / concatenation of per-shard id listings
+template <class F>
+int gather_ids(chisel_hip_map *g, F list_fn, bool unique, std::vector<int> &out) {
+    std::vector<std::array<int, 3>> all;
+    for (chisel_hip_map *s : g->shards) {
+        int64_t n = 0;
+        int rc = list_fn(s, nullptr, 0, &n);
+        if (rc) return rc;
+        std::vector<int> ids((size_t)n * 3);
+        if (n) {
+            rc = list_fn(s, ids.data(), n, &n);
+            if (rc) return rc;
+        }
+        for (int64_t j = 0; j < n; j++) all.push_back({ids[3 * j], ids[3 * j + 1], ids[3 * j + 2]});
+    }
+    std::sort(all.begin(), all.end());
+    if (unique) all.erase(std::unique(all.begin(), all.end()), all.end());
+    out.clear();
+    for (const auto &a : all) out.insert(out.end(), a.begin(), a.end());
+    return CHISEL_HIP_OK;
+}
+int emit_ids(const std::vector<int> &all, int *ids, int64_t max_ids, int64_t *count) {
+    if (!count) return fail(CHISEL_HIP_ERR_INVALID, "null count");
+    *count = (int64_t)all.size() / 3;
+    if (ids) memcpy(ids, all.data(), (size_t)std::min<int64_t>(max_ids, *count) * 3 * sizeof(int));
+    return CHISEL_HIP_OK;
+}
+
+// Chisel::UpdateMeshes of the group: cvids_amd/sharded.py: ShardedChisel.UpdateMeshes, with direct calls for the collectives
+int update_meshes(chisel_hip_map *g, int force) {
+    if (!force && (g->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;  // Chisel.cpp:53-58: every 10th call
+    const int W = n_shards(g);
+    if (W == 1) return chisel_hip_update_meshes(g->shards[0], 1);
+    std::vector<int> uni;
+    int rc = gather_ids(g, chisel_hip_meshes_to_update, true, uni);
+    if (rc) return rc;
+    const size_t V = (size_t)g->V;
+    const bool color = g->cfg.use_color != 0;
+    for (int r = 0; r < W; r++) {
+        // jobs of shard r, and the neighbours of its jobs it does not own, by owner
+        std::vector<int> jobs;
+        for (size_t j = 0; j + 2 < uni.size(); j += 3)
+            if (owner_of(g, &uni[j]) == r) jobs.insert(jobs.end(), uni.begin() + j, uni.begin() + j + 3);
+        std::vector<std::set<std::array<int, 3>>> want(W);
+        for (size_t j = 0; j + 2 < jobs.size(); j += 3)
+            for (int dz = -1; dz <= 1; dz++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (!dx && !dy && !dz) continue;
+                        const int id[3] = {jobs[j] + dx, jobs[j + 1] + dy, jobs[j + 2] + dz};
+                        const int o = owner_of(g, id);
+                        if (o != r) want[o].insert({id[0], id[1], id[2]});
+                    }
+        chisel_hip_map *dst = g->shards[r];
+        for (int o = 0; o < W; o++) {
+            if (want[o].empty()) continue;
+            chisel_hip_map *src = g->shards[o];
+            std::vector<int> ids;
+            for (const auto &a : want[o]) ids.insert(ids.end(), a.begin(), a.end());
+            const int n = (int)ids.size() / 3;
+            // payload: exported into HBM on the owner's device, brought to the meshing shard's device, imported from HBM
+            float *sdf = nullptr, *wgt = nullptr;
+            uint8_t *rgbw = nullptr;
+            std::vector<int> found(n);
+            HIP_TRY(hipSetDevice(src->device));
+            HIP_TRY(hipMalloc(&sdf, (size_t)n * V * sizeof(float)));
+            HIP_TRY(hipMalloc(&wgt, (size_t)n * V * sizeof(float)));
+            if (color) HIP_TRY(hipMalloc(&rgbw, (size_t)n * V * 4));
+            rc = chisel_hip_export_chunks(src, ids.data(), n, sdf, wgt, rgbw, found.data(), 1);
+            float *sdf2 = sdf, *wgt2 = wgt;
+            uint8_t *rgbw2 = rgbw;
+            if (!rc && src->device != dst->device) {
+                HIP_TRY(hipSetDevice(dst->device));
+                HIP_TRY(hipMalloc(&sdf2, (size_t)n * V * sizeof(float)));
+                HIP_TRY(hipMalloc(&wgt2, (size_t)n * V * sizeof(float)));
+                if (color) HIP_TRY(hipMalloc(&rgbw2, (size_t)n * V * 4));
+                HIP_TRY(hipMemcpyPeer(sdf2, dst->device, sdf, src->device, (size_t)n * V * sizeof(float)));
+                HIP_TRY(hipMemcpyPeer(wgt2, dst->device, wgt, src->device, (size_t)n * V * sizeof(float)));
+                if (color) HIP_TRY(hipMemcpyPeer(rgbw2, dst->device, rgbw, src->device, (size_t)n * V * 4));
+            }
+            if (!rc) rc = chisel_hip_import_ghost_chunks(dst, ids.data(), n, sdf2, wgt2, rgbw2, found.data(), 1);
+            if (!rc) rc = chisel_hip_synchronize(dst);  // the import has read the payload
+            if (sdf2 != sdf) {
+                (void)hipFree(sdf2);
+                (void)hipFree(wgt2);
+                if (rgbw2) (void)hipFree(rgbw2);
+            }
+            (void)hipSetDevice(src->device);
+            (void)hipFree(sdf);
+            (void)hipFree(wgt);
+            if (rgbw) (void)hipFree(rgbw);
+            if (rc) return rc;
+        }
+        rc = chisel_hip_update_meshes_of(dst, jobs.data(), (int)jobs.size() / 3);
+        if (rc) return rc;
+        rc = chisel_hip_drop_ghost_chunks(dst);
+        if (rc) return rc;
+    }
+    return CHISEL_HIP_OK;
+}
+
+int list_meshes(chisel_hip_map *g, int *ids, int64_t max_ids, int64_t *count) {
+    std::vector<int> all;
+    const int rc = gather_ids(g, chisel_hip_list_meshes, false, all);
+    return rc ? rc : emit_ids(all, ids, max_ids, count);
+}
+
+// Chisel::SaveAllMeshesToPLY over the shards: every mesh from its owner, ascending chunk id, one file in the single-map format
+int save_ply(chisel_hip_map *g, const char *path) {
+    std::ofstream stream(path);
+    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    std::vector<int> ids;
+    int rc = gather_ids(g, chisel_hip_list_meshes, false, ids);
+    if (rc) return rc;
+    const size_t n = ids.size() / 3;
+    const bool color = g->cfg.use_color != 0;
+    std::vector<std::vector<float>> v(n), c(n);
+    std::vector<MeshView> views(n);
+    size_t numPoints = 0;
+    bool any_color = false;
+    for (size_t i = 0; i < n; i++) {
+        chisel_hip_map *s = owner_map(g, &ids[3 * i]);
+        int64_t nv = 0, ng = 0;
+        rc = chisel_hip_mesh_size(s, &ids[3 * i], &nv, &ng);
+        if (rc) return rc;
+        v[i].resize((size_t)nv * 3);
+        std::vector<float> nrm((size_t)nv * 3), grids((size_t)ng * 3);
+        if (color) c[i].resize((size_t)nv * 3);
+        rc = chisel_hip_download_mesh(s, &ids[3 * i], v[i].data(), nrm.data(), color ? c[i].data() : nullptr, grids.data());
+        if (rc) return rc;
+        views[i].v = v[i].data();
+        views[i].c = color ? c[i].data() : nullptr;
+        views[i].n_v = (size_t)nv;
+        numPoints += (size_t)nv;
+        any_color = any_color || (nv && color);
+    }
+    write_ply(stream, views, numPoints, any_color);
+    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("write failed: ") + path);
+    return CHISEL_HIP_OK;
+}
+
+// chisel_hip_save_map of the group: the single-map file (every chunk from its owner, ascending id): a group and a single map
+// read each other's files
+int save_map(chisel_hip_map *g, const char *path) {
+    if (!path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    std::vector<int> ids;
+    int rc = gather_ids(g, chisel_hip_list_chunks, false, ids);
+    if (rc) return rc;
+    std::ofstream out(path, std::ios::binary);
+    if (!out) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    MapFileHeader h;
+    memcpy(h.magic, "CHSLHIP1", 8);
+    h.chunk_edge = g->N;
+    h.resolution = g->cfg.voxel_resolution;
+    h.has_color = g->cfg.use_color ? 1 : 0;
+    h.spare = 0;
+    h.n_chunks = (int64_t)(ids.size() / 3);
+    out.write(reinterpret_cast<const char *>(&h), sizeof(h));
+    const size_t V = (size_t)g->V;
+    std::vector<float> sdf(V), wgt(V);
+    std::vector<uint8_t> col(h.has_color ? 4 * V : 0);
+    for (size_t i = 0; i + 2 < ids.size(); i += 3) {
+        rc = chisel_hip_download_chunk(owner_map(g, &ids[i]), &ids[i], sdf.data(), wgt.data(), h.has_color ? col.data() : nullptr);
+        if (rc) return rc;
+        out.write(reinterpret_cast<const char *>(&ids[i]), 3 * sizeof(int));
+        out.write(reinterpret_cast<const char *>(sdf.data()), (std::streamsize)(V * sizeof(float)));
+        out.write(reinterpret_cast<const char *>(wgt.data()), (std::streamsize)(V * sizeof(float)));
+        if (h.has_color) out.write(reinterpret_cast<const char *>(col.data()), (std::streamsize)(4 * V));
+    }
+    if (!out) return fail(CHISEL_HIP_ERR_IO, std::string("write failed: ") + path);
+    return CHISEL_HIP_OK;
+}
+
+int chunk_id_at(const chisel_hip_map *g, const float pos[3], int id[3]) {  // ChunkManager::GetIDAt (ChunkManager.h:136-145)
+    const float rf = 1.0f / ((float)g->N * g->cfg.voxel_resolution);
+    for (int k = 0; k < 3; k++) id[k] = (int)std::floor(pos[k] * rf);
+    return owner_of(g, id);
+}
+int get_sdf(chisel_hip_map *g, const float pos[3], double *dist, int *found) {
+    int id[3];
+    return chisel_hip_get_sdf(g->shards[chunk_id_at(g, pos, id)], pos, dist, found);
+}
+// ChunkManager::GetSDFAndGradient (ChunkManager.cpp:449-474): seven GetSDF lookups, each at its own owner
+int get_sdf_and_gradient(chisel_hip_map *g, const float pos[3], double *dist, float grad[3], int *found) {
+    const float r = g->cfg.voxel_resolution;
+    const float posf[3] = {std::floor(pos[0] / r) * r + r / 2.0f, std::floor(pos[1] / r) * r + r / 2.0f, std::floor(pos[2] / r) * r + r / 2.0f};
+    double d[7];
+    for (int i = 0; i < 7; i++) {
+        float q[3] = {posf[0], posf[1], posf[2]};
+        if (i >= 1 && i <= 3) q[i - 1] = posf[i - 1] + r;
+        if (i >= 4) q[i - 4] = posf[i - 4] - r;
+        int ok = 0;
+        const int rc = get_sdf(g, q, &d[i], &ok);
+        if (rc) return rc;
+        if (!ok) {
+            if (found) *found = 0;
+            return CHISEL_HIP_OK;
+        }
+    }
+    if (dist) *dist = d[0];
+    if (grad) {
+        const float gx = (float)(d[1] - d[4]), gy = (float)(d[2] - d[5]), gz = (float)(d[3] - d[6]);
+        const float z = gx * gx + (gy * gy + gz * gz);  // grad->normalize(): z > 0 ? a / sqrt(z) : a
+        if (z > 0.0f) {
+            const float s = std::sqrt(z);
+            grad[0] = gx / s; grad[1] = gy / s; grad[2] = gz / s;
+        } else {
+            grad[0] = gx; grad[1] = gy; grad[2] = gz;
+        }
+    }
+    if (found) *found = 1;
+    return CHISEL_HIP_OK;
+}
+
+int get_counters(chisel_hip_map *g, uint64_t *out, int reset) {
+    uint64_t sum[CHISEL_HIP_NUM_COUNTERS] = {0};
+    for (size_t i = 0; i < g->shards.size(); i++) {
+        uint64_t c[CHISEL_HIP_NUM_COUNTERS];
+        const int rc = chisel_hip_get_counters(g->shards[i], c, reset);
+        if (rc) return rc;
+        for (int k = 0; k < CHISEL_HIP_NUM_COUNTERS; k++) sum[k] = (k == 8) ? std::max(sum[k], c[k]) : sum[k] + c[k];  // [8]: frames (every shard sees all)
+    }
+    memcpy(out, sum, sizeof(sum));
+    return CHISEL_HIP_OK;
+}
+int get_profile(chisel_hip_map *g, double *ms_total, int64_t *launches, int reset) {
+    for (int k = 0; k < CHISEL_HIP_NUM_KERNELS; k++) {
+        ms_total[k] = 0.0;
+        launches[k] = 0;
+    }
+    for (chisel_hip_map *s : g->shards) {
+        double ms[CHISEL_HIP_NUM_KERNELS];
+        int64_t n[CHISEL_HIP_NUM_KERNELS];
+        const int rc = chisel_hip_get_profile(s, ms, n, reset);
+        if (rc) return rc;
+        for (int k = 0; k < CHISEL_HIP_NUM_KERNELS; k++) {
+            ms_total[k] += ms[k];
+            launches[k] += n[k];
+        }
+    }
+    return CHISEL_HIP_OK;
+}
+
+}  // namespace group
+}  // namespace

@@ -427,6 +427,7 @@ std::vector<uint64_t> sorted_mesh_keys(const chisel_hip_map *m) {
 extern "C" {
 
 int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
+    if (m && m->is_group) return group::update_meshes(m, force);
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     if (m->cfg.n_shards > 1)
         return fail(CHISEL_HIP_ERR_UNSUPPORTED,
@@ -454,6 +455,7 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
 }
 
 int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_update_meshes_of is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
     HIP_TRY(hipSetDevice(m->device));
     int rc = resolve_pending_meshes(m);  // the device buffers of the previous recompute are about to be reused
@@ -476,6 +478,17 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
 }
 
 int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) {
+    if (m && m->is_group) {
+        if (!out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+        *out = 0;
+        for (chisel_hip_map *s : m->shards) {
+            int64_t n = 0;
+            const int rc = chisel_hip_num_meshes(s, &n);
+            if (rc) return rc;
+            *out += n;
+        }
+        return CHISEL_HIP_OK;
+    }
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc_p = resolve_pending_meshes(m);
@@ -485,6 +498,7 @@ int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) {
 }
 
 int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    if (m && m->is_group) return group::list_meshes(m, ids, max_ids, count);
     if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc_p = resolve_pending_meshes(m);
@@ -497,6 +511,7 @@ int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t
 }
 
 int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_t *ng) {
+    if (m && m->is_group) return id ? chisel_hip_mesh_size(group::owner_map(m, id), id, nv, ng) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc_p = resolve_pending_meshes(m);
@@ -509,6 +524,7 @@ int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_
 }
 
 int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float *n, float *c, float *g) {
+    if (m && m->is_group) return id ? chisel_hip_download_mesh(group::owner_map(m, id), id, v, n, c, g) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc_p = resolve_pending_meshes(m);
@@ -527,35 +543,21 @@ int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float
 }
 
 int chisel_hip_get_sdf(chisel_hip_map *m, const float pos[3], double *dist, int *found) {
+    if (m && m->is_group) return pos ? group::get_sdf(m, pos, dist, found) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !pos) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     return query_sdf(m, pos, 0, dist, nullptr, found);
 }
 
 int chisel_hip_get_sdf_and_gradient(chisel_hip_map *m, const float pos[3], double *dist, float grad[3], int *found) {
+    if (m && m->is_group) return pos ? group::get_sdf_and_gradient(m, pos, dist, grad, found) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !pos) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     return query_sdf(m, pos, 1, dist, grad, found);
 }
 
-// Chisel::SaveAllMeshesToPLY (Chisel.cpp:69-105) + SaveMeshPLYASCII (io/PLY.cpp:29-88): same text format, same number
-// formatting (operator<< of float / int).  The reference concatenates the meshes in the iteration order of its
-// std::unordered_map (unspecified); here chunks are written in ascending id order.
-int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
-    if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
-    std::ofstream stream(path);
-    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
-    HIP_TRY(hipSetDevice(m->device));
-    int rc_p = resolve_pending_meshes(m);
-    if (rc_p) return rc_p;
-    const std::vector<uint64_t> keys = sorted_mesh_keys(m);
-    size_t numPoints = 0;
-    bool any_color = false;
-    std::vector<MeshView> views(keys.size());
-    for (size_t i = 0; i < keys.size(); i++) {
-        int rc = view_mesh(m, m->meshes.at(keys[i]), views[i]);
-        if (rc) return rc;
-        numPoints += views[i].n_v;
-        any_color = any_color || (views[i].n_v && views[i].c);
-    }
+}  // extern "C"
+namespace {
+// SaveMeshPLYASCII (io/PLY.cpp:29-88) over the concatenated meshes: same text format, same number formatting (operator<< of float / int)
+void write_ply(std::ofstream &stream, const std::vector<MeshView> &views, size_t numPoints, bool any_color) {
     stream << "ply" << std::endl;
     stream << "format ascii 1.0" << std::endl;
     stream << "element vertex " << numPoints << std::endl;
@@ -587,6 +589,33 @@ int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
         for (int j = 0; j < 3; j++) stream << (i + j) << " ";
         stream << std::endl;
     }
+}
+
+}  // namespace
+extern "C" {
+
+// Chisel::SaveAllMeshesToPLY (Chisel.cpp:69-105) + SaveMeshPLYASCII (io/PLY.cpp:29-88): same text format, same number
+// formatting (operator<< of float / int).  The reference concatenates the meshes in the iteration order of its
+// std::unordered_map (unspecified); here chunks are written in ascending id order.
+int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
+    if (m && m->is_group) return path ? group::save_ply(m, path) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    std::ofstream stream(path);
+    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    HIP_TRY(hipSetDevice(m->device));
+    int rc_p = resolve_pending_meshes(m);
+    if (rc_p) return rc_p;
+    const std::vector<uint64_t> keys = sorted_mesh_keys(m);
+    size_t numPoints = 0;
+    bool any_color = false;
+    std::vector<MeshView> views(keys.size());
+    for (size_t i = 0; i < keys.size(); i++) {
+        int rc = view_mesh(m, m->meshes.at(keys[i]), views[i]);
+        if (rc) return rc;
+        numPoints += views[i].n_v;
+        any_color = any_color || (views[i].n_v && views[i].c);
+    }
+    write_ply(stream, views, numPoints, any_color);
     if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("write failed: ") + path);
     return CHISEL_HIP_OK;
 }

@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -383,7 +384,23 @@ class Chisel {  // Chisel.h:38-230
         cfg.use_color = useColor ? 1 : 0;
         cfg.device_id = -1;
         cfg.n_shards = 1;
-        hip_check(chisel_hip_create(&cfg, &map));
+        // CHISEL_HIP_DEVICES=0,1,2,3 (environment of the node, e.g. in the launch file): the map is spread over these GPUs inside
+        // this process (chisel_hip_create_group); every call below stays the same
+        std::vector<int> devices;
+        if (const char *env = std::getenv("CHISEL_HIP_DEVICES")) {
+            for (const char *p = env; *p;) {
+                char *end = nullptr;
+                const long d = std::strtol(p, &end, 10);
+                if (end == p) break;
+                devices.push_back((int)d);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+        if (devices.size() > 1) hip_check(chisel_hip_create_group(&cfg, devices.data(), (int)devices.size(), &map));
+        else {
+            if (devices.size() == 1) cfg.device_id = devices[0];
+            hip_check(chisel_hip_create(&cfg, &map));
+        }
         chunkManager = ChunkManager(map, chunkSize, voxelResolution, useColor);
     }
     virtual ~Chisel() {

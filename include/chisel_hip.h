@@ -269,6 +269,18 @@ int chisel_hip_depth_filter_read(chisel_hip_depth_filter *filter, int which, dou
 int chisel_hip_save_map(chisel_hip_map *map, const char *path);
 int chisel_hip_load_map(chisel_hip_map *map, const char *path);
 
+/* ---- one map over several GPUs of the node, inside one process -------------------------------------------------------- */
+/* The reference has one chisel::Chisel object per map (Chisel.h:38-230) and one calling thread; a C++ caller that links this
+ * library (chisel_ros) cannot start one process per GPU.  chisel_hip_create_group returns a handle that every entry point of
+ * this header accepts like any other map: behind it one shard map per entry of device_ids[] (n_shards = n_devices, shard i on
+ * device_ids[i]; chunk ownership = chisel_hip_chunk_owner; a device may be named several times).  The library hands every
+ * shard every frame (device frames are copied peer-to-peer to the shards on other devices), all shards integrate concurrently,
+ * chisel_hip_update_meshes exchanges the neighbour chunks between the shards, queries go to the owner, listings / PLY / map
+ * dumps are merged in ascending id order and equal a single map's.  cfg->device_id, n_shards and shard_rank are ignored.
+ * Not available on a group: chisel_hip_set_stream, chisel_hip_record_event (one stream / event cannot span GPUs: use
+ * chisel_hip_synchronize), and the shard-to-shard calls (export / import / drop ghost chunks, update_meshes_of). */
+int chisel_hip_create_group(const chisel_hip_config *cfg, const int *device_ids, int n_devices, chisel_hip_map **out);
+
 /* ---- view frustum (host arithmetic, no GPU needed) -------------------------------------------------------------- */
 /* PinholeCamera::SetupFrustum (src/camera/PinholeCamera.cpp:55-59) -> Frustum::SetFromParams / SetFromVectors
  * (src/geometry/Frustum.cpp:143-219), with the reference's quirks (fy is used for both focal lengths, cx is ignored) and fp32

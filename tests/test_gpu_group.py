@@ -1,0 +1,125 @@
+"""chisel_hip_create_group: one map spread over several shards inside one process, behind the ordinary map ABI.
+
+Only one GPU is available to these tests, so every shard lives on device 0 (a device may be named several times); that runs the
+whole group logic -- frame fan-out, routed queries, merged listings, the ghost-chunk exchange of UpdateMeshes -- except the
+peer-to-peer copies between devices."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cvids_amd import synth
+from tests.common import compare_fields, make_frames, small_camera
+from tests.test_gpu_mesh import _compare_meshes
+from tests.test_gpu_parity import _mk
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n_shards", [2, 4, 8])
+def test_group_equals_oracle_and_single_map(oracle_mod, tmp_path, n_shards):
+    from cvids_amd import chisel as ch
+    N, res, W, H = 16, 0.04, 96, 72
+    om, single, integ = _mk(oracle_mod, N, res, True, max_chunks=4096)
+    grp = ch.Chisel((N,) * 3, res, True, max_chunks=4096, devices=[0] * n_shards)
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(W, H, 3)
+    frames = make_frames("box_room", 7, W, H, nan_fraction=0.01)
+    for lo in (0, 4):
+        part = frames[lo:lo + 4]
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        for m in (single, grp):
+            m.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        # meshesToUpdate: the union over the shards is the reference's set
+        want = sorted(map(tuple, om.meshes_to_update().tolist()))
+        assert sorted(map(tuple, grp.GetMeshesToUpdate().tolist())) == want
+        om.update_meshes(force=True)
+        single.UpdateMeshes(force=True)
+        grp.UpdateMeshes(force=True)
+        _compare_meshes(om, grp, True)
+    # voxels, counters, listings
+    compare_fields(om.fields(), grp.fields(), om.V, True, what="group of %d" % n_shards)
+    assert grp.NumChunks() == om.num_chunks() == single.NumChunks()
+    assert np.array_equal(np.asarray(grp.GetChunkIDs()).reshape(-1, 3), np.asarray(sorted(map(tuple, np.asarray(single.GetChunkIDs()).reshape(-1, 3).tolist()))))
+    cg, cs = grp.counters(), single.counters()
+    for k in ("sdf", "col", "col_sat", "probe", "carved", "new_chunks", "updated_chunks", "frames"):
+        assert cg[k] == cs[k], (k, cg[k], cs[k])
+    # routed queries
+    ids = np.asarray(grp.GetChunkIDs()).reshape(-1, 3)
+    for cid in map(tuple, ids[:: max(1, len(ids) // 16)]):
+        assert grp.HasChunk(cid)
+        a, b = grp.GetChunk(cid), single.GetChunk(cid)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert not grp.HasChunk((1000, 1000, 1000))
+    with pytest.raises(KeyError):  # ChunkMap::at of an absent id (CHISEL_HIP_ERR_NOT_FOUND from the owner shard)
+        grp.GetChunk((1000, 1000, 1000))
+    hits = 0
+    for pos in [(0.01, 0.01, 2.46), (0.5, 0.3, 2.48), (-0.7, -0.4, 2.45), (1.0, 0.5, 2.5), (0.63, -0.31, 2.52), (0.0, 0.0, 0.0)]:
+        rs, rg = single.GetSDFAndGradient(pos), grp.GetSDFAndGradient(pos)
+        assert rs[0] == rg[0]
+        if rs[0]:
+            hits += 1
+            assert np.float32(rs[1]) == np.float32(rg[1]) and np.array_equal(np.asarray(rs[2], np.float32), np.asarray(rg[2], np.float32))
+        assert single.GetSDF(pos) == grp.GetSDF(pos)
+    assert hits >= 3
+    # files: PLY and map dump equal the single map's byte for byte; a group reads a single map's dump and vice versa
+    single.SaveAllMeshesToPLY(str(tmp_path / "s.ply"))
+    grp.SaveAllMeshesToPLY(str(tmp_path / "g.ply"))
+    assert open(tmp_path / "s.ply", "rb").read() == open(tmp_path / "g.ply", "rb").read()
+    single.SaveMap(str(tmp_path / "s.map"))
+    grp.SaveMap(str(tmp_path / "g.map"))
+    assert open(tmp_path / "s.map", "rb").read() == open(tmp_path / "g.map", "rb").read()
+    grp2 = ch.Chisel((N,) * 3, res, True, max_chunks=4096, devices=[0] * n_shards)
+    grp2.LoadMap(str(tmp_path / "s.map"))
+    compare_fields(om.fields(), grp2.fields(), om.V, True, what="group loaded from a single map's dump")
+    # garbage collection is routed to the owners
+    victims = ids[::3]
+    grp.GarbageCollect(victims)
+    single.GarbageCollect(victims)
+    assert grp.NumChunks() == single.NumChunks() == len(ids) - len(victims)
+    # Reset
+    grp.Reset()
+    assert grp.NumChunks() == 0
+    for m in (single, grp, grp2):
+        m.close()
+
+
+def test_group_through_the_cpp_facade(oracle_mod, tmp_path):
+    """CHISEL_HIP_DEVICES=0,0,0,0: the C++ facade's Chisel is a group of four shards; replay.cpp (ChiselServer's sequence) runs
+    unchanged and produces the oracle's map."""
+    from tests.test_gpu_facade import _write_recording
+    tdir = os.path.join(ROOT, "cvids_amd", "open_chisel", "tests")
+    subprocess.check_call(["make", "-C", tdir, "build"])
+    W, H, N, res = 160, 120, 16, 0.04
+    intr = synth.intrinsics(W, H)
+    frames = list(synth.stream("sphere_room", 12, W, H))
+    color = synth.render_color(W, H, 3)
+    rec = str(tmp_path / "stream.rec")
+    _write_recording(rec, frames, intr, color, "32FC1")
+    prefix = str(tmp_path / "out")
+    env = dict(os.environ, CHISEL_HIP_DEVICES="0,0,0,0")
+    out = subprocess.run([os.path.join(tdir, "replay"), rec, prefix, str(N), repr(res), "1", "0.05", "5.0", "2.0", "0.05"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    poses = np.fromfile(prefix + ".poses", np.float32).reshape(12, 3, 4)
+    om = oracle_mod.OracleMap(N, res, True)
+    om.set_integrator(oracle_mod.TRUNC_INVERSE, 2.0, 1.0, True, 0.05)
+    for (depth, _), p in zip(frames, poses):
+        P = np.eye(4, dtype=np.float32)
+        P[:3, :4] = p
+        om.integrate_depth_color(depth, P, intr, color, near=0.05, far=5.0)
+    V = N ** 3
+    raw = np.fromfile(prefix + ".map", np.uint8)
+    recsz = 12 + V * 12
+    got = {}
+    for i in range(len(raw) // recsz):
+        b = raw[i * recsz:(i + 1) * recsz]
+        cid = tuple(int(v) for v in b[:12].view(np.int32))
+        sw = b[12:12 + V * 8].view(np.float32).reshape(V, 2)
+        got[cid] = (sw[:, 0].copy(), sw[:, 1].copy(), b[12 + V * 8:].reshape(V, 4).copy())
+    compare_fields(om.fields(), got, V, True, what="facade over a group")
+    assert ("map: %d chunks written" % om.num_chunks()) in out.stdout and "SaveMesh ok" in out.stdout
