@@ -26,14 +26,24 @@ def build(force=False):
 
 
 _lib = None
+_variants = {}
 
 
-def lib():
+def lib(variant=None):
+    """variant: None = the oracle; "SUM32" / "SQRTF" / "TRIGF" = the oracle rebuilt with one alternative reading
+    (chisel_oracle.cpp header) -- for the risk assessment of tests/test_oracle_readings.py only."""
     global _lib
-    if _lib is not None:
+    if variant is None and _lib is not None:
         return _lib
-    build()
-    L = C.CDLL(_LIB_PATH)
+    if variant is not None and variant in _variants:
+        return _variants[variant]
+    if variant is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+    else:
+        name = "liboracle_alt_%s.so" % variant
+        subprocess.check_call(["make", "-C", _HERE, name])
+        L = C.CDLL(os.path.join(_HERE, name))
     f32p = C.POINTER(C.c_float)
     u8p = C.POINTER(C.c_uint8)
     i32p = C.POINTER(C.c_int)
@@ -53,6 +63,8 @@ def lib():
     L.oc_raycast.argtypes = [f32p, f32p, i32p, i32p, i32p, C.c_int]
     L.oc_invert_pose.argtypes = [f32p, f32p]
     L.oc_get_phase_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    L.oc_bilinear_interpolate.argtypes = [C.c_float] * 6
+    L.oc_bilinear_interpolate.restype = C.c_float
     L.oc_num_chunks.argtypes = [vp]
     L.oc_list_chunks.argtypes = [vp, i32p]
     L.oc_has_chunk.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -84,7 +96,10 @@ def lib():
     L.oc_mesh_cube.restype = C.c_int
     L.oc_mesh_cube.argtypes = [f32p, f32p, C.c_float, f32p, f32p]
     L.oc_triangle_table_row.argtypes = [C.c_int, i32p]
-    _lib = L
+    if variant is None:
+        _lib = L
+    else:
+        _variants[variant] = L
     return L
 
 
@@ -101,8 +116,8 @@ def _u8(a):
 class OracleMap:
     """chisel::Chisel + ProjectionIntegrator + ChunkManager of the reference, on the CPU."""
 
-    def __init__(self, chunk_size=16, resolution=0.02, use_color=False, threads=16):
-        self.L = lib()
+    def __init__(self, chunk_size=16, resolution=0.02, use_color=False, threads=16, variant=None):
+        self.L = lib(variant)
         cs = (chunk_size,) * 3 if isinstance(chunk_size, int) else tuple(chunk_size)
         self.chunk_size = cs
         self.V = cs[0] * cs[1] * cs[2]

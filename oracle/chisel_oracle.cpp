@@ -17,6 +17,13 @@
  * of a 3x3 * 3x1 lazy product, squaredNorm()) as a0 + (a1 + a2) (redux_novec_unroller splits
  * [0,3) into [0,1) and [1,3)); Eigen 3.2's coefficient product was ((a0 + a1) + a2).  The
  * reference does not pin an Eigen version (catkin.cmake:7); this oracle fixes the 3.3 order.
+ *
+ * ALTERNATIVE READINGS (risk assessment only, tests/test_oracle_readings.py): three build switches turn the choices the
+ * oracle had to make without being able to compile the reference's Eigen code into the other plausible reading --
+ *   -DORACLE_ALT_SUM32    3-term reductions as (a0 + a1) + a2 (Eigen 3.2)
+ *   -DORACLE_ALT_SQRTF    the band's voxel diagonal through sqrtf (float) instead of ::sqrt(double)
+ *   -DORACLE_ALT_TRIGF    the frustum's atan2 / tan in float instead of double
+ * so that the distance between the readings can be measured on the BASELINE scenes.  The product follows the default.
  */
 #include "chisel_oracle.h"
 
@@ -54,7 +61,11 @@ inline V3 operator*(const V3 &a, float s) { return V3(a.x * s, a.y * s, a.z * s)
 inline V3 operator*(float s, const V3 &a) { return V3(s * a.x, s * a.y, s * a.z); }
 inline V3 operator/(const V3 &a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
 // Eigen 3.3 redux order for 3 terms
+#ifdef ORACLE_ALT_SUM32
+inline float sum3(float a0, float a1, float a2) { return (a0 + a1) + a2; }
+#else
 inline float sum3(float a0, float a1, float a2) { return a0 + (a1 + a2); }
+#endif
 inline float dot(const V3 &a, const V3 &b) { return sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
 inline V3 cross(const V3 &a, const V3 &b) {
     // Eigen cross3: (a1*b2 - a2*b1, a2*b0 - a0*b2, a0*b1 - a1*b0)
@@ -242,7 +253,11 @@ struct Frustum {
 
     void SetFromVectors(const V3 &forward, const V3 &pos, const V3 &rightVec, const V3 &up, float nearDist,
                         float farDist, float fov, float aspect) {  // Frustum.cpp:155-219
+#ifdef ORACLE_ALT_TRIGF
+        float angleTangent = tanf(fov / 2);
+#else
         float angleTangent = ::tan((double)(fov / 2));  // ::tan(double), narrowed
+#endif
         float heightFar = angleTangent * farDist;
         float widthFar = heightFar * aspect;
         float heightNear = angleTangent * nearDist;
@@ -279,7 +294,11 @@ struct Frustum {
         V3 d = view.col(2);
         V3 p = view.t;
         float aspect = (fx * imgWidth) / (fy * imgHeight);
+#ifdef ORACLE_ALT_TRIGF
+        float fov = atan2f(cy, fy) + atan2f(imgHeight - cy, fy);
+#else
         float fov = ::atan2((double)cy, (double)fy) + ::atan2((double)(imgHeight - cy), (double)fy);  // double, narrowed
+#endif
         SetFromVectors(d, p, right_, up, nearDist, farDist, fov, aspect);
     }
     void ComputeBoundingBox(AABB *box) const {  // Frustum.cpp:101-122
@@ -558,7 +577,11 @@ struct oc_map {
                    bool chunkIsNew, Tally *tally) const {
         float resolution = chunk->voxelResolutionMeters;
         V3 origin = chunk->origin;
+#ifdef ORACLE_ALT_SQRTF
+        float diag = 2.0 * sqrtf(3.0f) * resolution;
+#else
         float diag = 2.0 * ::sqrt((double)3.0f) * resolution;  // unqualified sqrt(float) binds to ::sqrt(double) under <cmath>
+#endif
         V3 voxelCenter;
         bool updated = false;
         for (size_t i = 0; i < centroids.size(); i++) {
@@ -595,7 +618,11 @@ struct oc_map {
                         Chunk *chunk, bool chunkIsNew, Tally *tally) const {
         float resolution = chunk->voxelResolutionMeters;
         V3 origin = chunk->origin;
+#ifdef ORACLE_ALT_SQRTF
+        float resolutionDiagonal = 2.0 * sqrtf(3.0f) * resolution;
+#else
         float resolutionDiagonal = 2.0 * ::sqrt((double)3.0f) * resolution;
+#endif
         bool updated = false;
         for (size_t i = 0; i < centroids.size(); i++) {
             uint8_t color[4] = {0, 0, 0, 0};
@@ -1494,6 +1521,13 @@ int oc_mesh_cube(const float *s, const float *o, float res, float *verts, float 
         normals[3 * i] = mesh.normals[i].x; normals[3 * i + 1] = mesh.normals[i].y; normals[3 * i + 2] = mesh.normals[i].z;
     }
     return (int)mesh.vertices.size();
+}
+// geometry/Interpolate.h:28-36 (off the live path: only DepthImage::BilinearInterpolateDepth calls it and
+// its call sites, ProjectionIntegrator.h:72,131, are commented out).  Restated for the known-answer test.
+float oc_bilinear_interpolate(float c00, float c10, float c01, float c11, float tx, float ty) {
+    float a = c00 + (c10 - c00) * tx;
+    float b = c01 + (c11 - c01) * tx;
+    return a + (b - a) * ty;
 }
 void oc_triangle_table_row(int index, int *row16) { memcpy(row16, triTable().rows[index & 255], 16 * sizeof(int)); }
 

@@ -2,7 +2,7 @@
 // Eigen-free headers (compiled where they lie under /root/reference; see oracle/Makefile `ref`).
 // It is the only part of the reference path that builds in this image (everything else needs
 // Eigen).  Its stdout is committed as tests/golden/ref_kat.json by tools/gen_golden.py and pins
-// rows a8 (DistVoxel/ColorVoxel), a11 (truncators, weighter) and a16 (ColorImage::At) of
+// rows a8 (DistVoxel/ColorVoxel), a11 (truncators, weighter), a16 (ColorImage::At; Interpolate.h) of
 // the oracle restatement and the HIP kernels must reproduce it bit for bit.
 // Floats are printed as their IEEE-754 bit patterns (hex) so the fixture is exact.
 #include <cmath>
@@ -16,6 +16,7 @@
 #include <open_chisel/ColorVoxel.h>
 #include <open_chisel/DistVoxel.h>
 #include <open_chisel/camera/ColorImage.h>
+#include <open_chisel/geometry/Interpolate.h>
 #include <open_chisel/truncation/ConstantTruncator.h>
 #include <open_chisel/truncation/InverseTruncator.h>
 #include <open_chisel/truncation/QuadraticTruncator.h>
@@ -123,6 +124,23 @@ int main() {
                 printf("%s[%u,%u,%u,%u]", (r || c) ? "," : "", col.red, col.green, col.blue, col.alpha);
             }
         printf("]}%s\n", ch < 4 ? "," : "");
+    }
+    printf("],\n");
+
+    // ---- geometry/Interpolate.h -----------------------------------------------------------------
+    // Off the live path (its only caller, DepthImage::BilinearInterpolateDepth, is called from
+    // nowhere: ProjectionIntegrator.h:72,131 are commented out); pinned so that a maintainer who
+    // re-enables it has the vectors.  Own seed: the sections above keep their values.
+    lcg_state = 777u;
+    printf("\"bilinear\": [");
+    for (int k = 0; k < 64; k++) {
+        float c[4], tx = urand(0.0f, 1.0f), ty = urand(0.0f, 1.0f);
+        for (int i = 0; i < 4; i++) c[i] = urand(0.2f, 8.0f);
+        if (k == 3) c[1] = std::numeric_limits<float>::quiet_NaN();
+        if (k == 4) { tx = 0.0f; ty = 1.0f; }
+        float v = chisel::BilinearInterpolate(c[0], c[1], c[2], c[3], tx, ty);
+        printf("%s[\"%08x\",\"%08x\",\"%08x\",\"%08x\",\"%08x\",\"%08x\",\"%08x\"]", k ? "," : "",
+               bits(c[0]), bits(c[1]), bits(c[2]), bits(c[3]), bits(tx), bits(ty), bits(v));
     }
     printf("]\n}\n");
     return 0;
