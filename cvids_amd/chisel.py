@@ -494,6 +494,18 @@ def condition_depth(depth64, width=640, height=480, intrinsics=None):
     return dst, (tuple(K) if intrinsics is not None else None)
 
 
+def condition_color(image, width=640, height=480):
+    """PublishDenseInfo's cv::resize of the colour image (chisel_hip_condition_color): uint8 (H, W) or (H, W, 1 / 3 / 4) ->
+    uint8 of the publish size, same channel count"""
+    L = capi.load_library()
+    src = np.ascontiguousarray(image, np.uint8)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    h0, w0 = src.shape[:2]
+    dst = np.empty((height, width) if src.ndim == 2 else (height, width, cn), np.uint8)
+    check(L.chisel_hip_condition_color(src.ctypes.data, w0, h0, cn, 0, dst.ctypes.data, width, height, 0, None))
+    return dst
+
+
 def chunk_owner(cid, n_shards, shard_block=2):
     c = (C.c_int * 3)(*[int(v) for v in cid])
     return capi.load_library().chisel_hip_chunk_owner(c, int(n_shards), int(shard_block))

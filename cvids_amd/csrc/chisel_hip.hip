@@ -1130,6 +1130,37 @@ int chisel_hip_condition_depth(const double *src, int w0, int h0, int src_on_dev
     return CHISEL_HIP_OK;
 }
 
+int chisel_hip_condition_color(const uint8_t *src, int w0, int h0, int channels, int src_on_device, uint8_t *dst, int w, int h,
+                               int dst_on_device, void *hip_stream) {
+    if (!src || !dst || w0 <= 0 || h0 <= 0 || w <= 0 || h <= 0 || (channels != 1 && channels != 3 && channels != 4))
+        return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    if ((size_t)w0 * h0 * channels > ((size_t)1 << 31) || (size_t)w * h * channels > ((size_t)1 << 31))
+        return fail(CHISEL_HIP_ERR_INVALID, "image too large");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t n0 = (size_t)w0 * h0 * channels, n1 = (size_t)w * h * channels;
+    uint8_t *d_src = nullptr, *d_dst = nullptr;
+    const uint8_t *in = src;
+    uint8_t *out = dst;
+    if (!src_on_device) {
+        HIP_TRY(hipMalloc(&d_src, n0));
+        HIP_TRY(hipMemcpyAsync(d_src, src, n0, hipMemcpyHostToDevice, st));
+        in = d_src;
+    }
+    if (!dst_on_device) {
+        HIP_TRY(hipMalloc(&d_dst, n1));
+        out = d_dst;
+    }
+    hipLaunchKernelGGL(condition_color_kernel, dim3((w * channels + 255) / 256, h), dim3(256), 0, st, in, w0, h0, channels, out, w, h);
+    HIP_TRY(hipGetLastError());
+    if (!dst_on_device) HIP_TRY(hipMemcpyAsync(dst, d_dst, n1, hipMemcpyDeviceToHost, st));
+    if (!src_on_device || !dst_on_device) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (d_src) (void)hipFree(d_src);
+        if (d_dst) (void)hipFree(d_dst);
+    }
+    return CHISEL_HIP_OK;
+}
+
 // ---- DepthFilter (depth_filter.cpp) ----------------------------------------------------------------------------------------
 struct chisel_hip_depth_filter {
     int device = 0;

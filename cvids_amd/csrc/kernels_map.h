@@ -239,9 +239,20 @@ __global__ void clear_dirty_kernel(MapView M) {
     if (i < M.max_chunks) M.slot_dirty[i] = 0;
 }
 
-// ---- PublishDenseInfo's depth conditioning (collaborative_server_system.cpp:213, :255-269) -----------------------------
-// cv::resize(CV_64F, INTER_LINEAR) restated: position and weight of the two source samples per axis as OpenCV computes them
-__device__ inline void resize_tap(int d, double scale, int ssize, int &s0, int &s1, float &w0, float &w1) {
+// ---- PublishDenseInfo's image conditioning (collaborative_server_system.cpp:213-214, :255-269) -------------------------
+// cv::resize(..., INTER_LINEAR) restated (OpenCV imgproc/resize.cpp, 3.x / 4.x without IPP; parity unpinned -- no OpenCV in this
+// image).  scale = 1. / ((double)dst / src).  Along x: tap position (dx + 0.5) * scale - 0.5 narrowed to float, sx = floor,
+// fx -= sx; sx < 0 -> (0, fx = 0); sx >= width - 1 -> (width - 1, fx = 0) and the horizontal pass there is S[sx] * ONE.  Along y
+// the fraction is NOT reset: the two source rows are clipped to the image instead.  Exactly halving both axes makes
+// cv::resize substitute INTER_AREA (mean of the 2 x 2 block); equal sizes are copied.
+struct ResizeTap {
+    int s;      // first source sample
+    float f;    // weight of the second one
+    bool edge;  // second sample beyond the row: the horizontal pass is S[s] * ONE
+};
+__device__ inline double resize_scale(int dst, int src) { return 1.0 / ((double)dst / (double)src); }
+__device__ inline ResizeTap resize_tap_x(int d, double scale, int ssize) {
+    ResizeTap t;
     float f = (float)(((double)d + 0.5) * scale - 0.5);
     int si = (int)floorf(f);
     f -= (float)si;
@@ -249,14 +260,21 @@ __device__ inline void resize_tap(int d, double scale, int ssize, int &s0, int &
         f = 0.0f;
         si = 0;
     }
-    if (si >= ssize - 1) {
+    t.edge = si >= ssize - 1;
+    if (t.edge) {
         f = 0.0f;
         si = ssize - 1;
     }
-    s0 = si;
-    s1 = min(si + 1, ssize - 1);
-    w0 = 1.0f - f;
-    w1 = f;
+    t.s = si;
+    t.f = f;
+    return t;
+}
+__device__ inline void resize_tap_y(int d, double scale, int ssize, int &r0, int &r1, float &f) {
+    f = (float)(((double)d + 0.5) * scale - 0.5);
+    const int si = (int)floorf(f);
+    f -= (float)si;
+    r0 = min(max(si, 0), ssize - 1);
+    r1 = min(max(si + 1, 0), ssize - 1);
 }
 __global__ void condition_depth_kernel(const double *__restrict__ src, int w0, int h0, float *__restrict__ dst, int w, int h) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -264,22 +282,52 @@ __global__ void condition_depth_kernel(const double *__restrict__ src, int w0, i
     double v;
     if (w == w0 && h == h0) {
         v = src[(size_t)y * w0 + x];  // same size: cv::resize copies
+    } else if (w0 == 2 * w && h0 == 2 * h) {
+        // INTER_AREA, integer scale: sum of the block in row-major order (double), times the float 1 / area
+        const double *s = src + (size_t)(2 * y) * w0 + 2 * x;
+        v = (((s[0] + s[1]) + s[w0]) + s[w0 + 1]) * (double)0.25f;
     } else {
-        int x0, x1, y0, y1;
-        float a0, a1, b0, b1;
-        resize_tap(x, (double)w0 / (double)w, w0, x0, x1, a0, a1);
-        resize_tap(y, (double)h0 / (double)h, h0, y0, y1, b0, b1);
-        // horizontal pass of both rows (double work type, float weights), then the vertical one; where the second tap falls
-        // off the image the horizontal pass is S[sx] * 1
-        const double r0 = (a1 == 0.0f && x0 == w0 - 1) ? src[(size_t)y0 * w0 + x0] * 1.0
-                                                       : src[(size_t)y0 * w0 + x0] * (double)a0 + src[(size_t)y0 * w0 + x1] * (double)a1;
-        const double r1 = (a1 == 0.0f && x0 == w0 - 1) ? src[(size_t)y1 * w0 + x0] * 1.0
-                                                       : src[(size_t)y1 * w0 + x0] * (double)a0 + src[(size_t)y1 * w0 + x1] * (double)a1;
+        const ResizeTap tx = resize_tap_x(x, resize_scale(w, w0), w0);
+        int y0, y1;
+        float fy;
+        resize_tap_y(y, resize_scale(h, h0), h0, y0, y1, fy);
+        const float a0 = 1.0f - tx.f, a1 = tx.f, b0 = 1.0f - fy, b1 = fy;
+        // horizontal pass of both rows (double work type, float weights), then the vertical one
+        const double *s0 = src + (size_t)y0 * w0 + tx.s, *s1 = src + (size_t)y1 * w0 + tx.s;
+        const double r0 = tx.edge ? s0[0] * 1.0 : s0[0] * (double)a0 + s0[1] * (double)a1;
+        const double r1 = tx.edge ? s1[0] * 1.0 : s1[0] * (double)a0 + s1[1] * (double)a1;
         v = r0 * (double)b0 + r1 * (double)b1;
     }
     float f = (float)v;                                            // convertTo(CV_32FC1)
     if (f < 0.1f || f > 20.0f) f = __builtin_nanf("");             // :262-265
     dst[(size_t)y * w + x] = f;
+}
+// 8-bit images (MONO8 / BGR8 / BGRA8, cn interleaved channels): OpenCV's fixed-point path.  Weights are shorts,
+// round-to-nearest-even of the float weight * 2048; horizontal pass in int (S[sx] * 2048 at the edge); vertical pass
+// uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2).  Halving: (a + b + c + d + 2) >> 2.
+__device__ inline int resize_coef(float c) { return (int)rintf(c * 2048.0f); }
+__global__ void condition_color_kernel(const uint8_t *__restrict__ src, int w0, int h0, int cn, uint8_t *__restrict__ dst, int w, int h) {
+    const int xc = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;  // xc: pixel * cn + channel
+    if (xc >= w * cn || y >= h) return;
+    const int x = xc / cn, c = xc - x * cn;
+    uint8_t out;
+    if (w == w0 && h == h0) {
+        out = src[(size_t)y * w0 * cn + xc];
+    } else if (w0 == 2 * w && h0 == 2 * h) {
+        const uint8_t *s = src + ((size_t)(2 * y) * w0 + 2 * x) * cn + c;
+        out = (uint8_t)((s[0] + s[cn] + s[(size_t)w0 * cn] + s[(size_t)w0 * cn + cn] + 2) >> 2);
+    } else {
+        const ResizeTap tx = resize_tap_x(x, resize_scale(w, w0), w0);
+        int y0, y1;
+        float fy;
+        resize_tap_y(y, resize_scale(h, h0), h0, y0, y1, fy);
+        const int a0 = resize_coef(1.0f - tx.f), a1 = resize_coef(tx.f), b0 = resize_coef(1.0f - fy), b1 = resize_coef(fy);
+        const uint8_t *s0 = src + ((size_t)y0 * w0 + tx.s) * cn + c, *s1 = src + ((size_t)y1 * w0 + tx.s) * cn + c;
+        const int r0 = tx.edge ? s0[0] * 2048 : s0[0] * a0 + s0[cn] * a1;
+        const int r1 = tx.edge ? s1[0] * 2048 : s1[0] * a0 + s1[cn] * a1;
+        out = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+    dst[(size_t)y * w * cn + xc] = out;
 }
 
 // ---- known-answer kernels: the device arithmetic against the reference-built golden vectors ----------

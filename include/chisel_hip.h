@@ -232,14 +232,22 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *map);
 int chisel_hip_update_meshes_of(chisel_hip_map *map, const int *ids_xyz, int n);
 
 /* ---- the step before the path ------------------------------------------------------------------------
- * CollaborativeServer::PublishDenseInfo's depth conditioning (server_pose_graph/src/collaborative_server_system.cpp:
- * 199-276): cv::resize of the CV_64F depth map to the publish size (640 x 480 there; bilinear, OpenCV's INTER_LINEAR
- * restated -- sample position (dx + 0.5) * scale - 0.5 narrowed to float, float weights, double accumulation; a map that
- * already has the publish size is copied), narrowing to float, NaN for readings < 0.1 or > 20, and the rescaled
- * intrinsics fx, fy, cx, cy (:216-219).  src: w0 x h0 doubles, dst: w x h floats, each on the host or (flag) in HBM; the
- * result feeds chisel_hip_integrate_* directly.  Parity unpinned: OpenCV is not available to generate vectors. */
+ * CollaborativeServer::PublishDenseInfo's image conditioning (server_pose_graph/src/collaborative_server_system.cpp:
+ * 199-276): cv::resize of the depth map (CV_64F) and the colour image (CV_8UC1 / CV_8UC3) to the publish size (640 x 480
+ * there, :213-214), and for depth the narrowing to float (:255), NaN for readings < 0.1 or > 20 (:262-265) and the rescaled
+ * intrinsics fx, fy, cx, cy (:216-219).  cv::resize with its default INTER_LINEAR is restated from OpenCV's published
+ * algorithm (imgproc/resize.cpp without IPP): scale = 1. / (dst / (double)src); tap position (d + 0.5) * scale - 0.5 narrowed
+ * to float; along x out-of-image taps clamp with weight 0 and the last column's horizontal pass is S[sx] * ONE; along y the rows
+ * are clipped and the weights kept; 64-bit floats use float weights and double sums; 8-bit images use short weights
+ * (round-to-even of weight * 2048), an int horizontal pass and uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2)
+ * vertically; halving both axes exactly is INTER_AREA (mean of the 2 x 2 block: double sum * 0.25f, 8-bit (sum + 2) >> 2); an
+ * image that already has the publish size is copied.  src: w0 x h0 (x channels, interleaved), dst: w x h, each on the host or
+ * (flag) in HBM; the results feed chisel_hip_integrate_* directly.  Parity unpinned: OpenCV is not available here to generate
+ * vectors; hand-computed cases of the rules above are in tests/test_publish_dense.py. */
 int chisel_hip_condition_depth(const double *src, int w0, int h0, int src_on_device, float *dst, int w, int h, int dst_on_device,
                                double intrinsics_fx_fy_cx_cy[4], void *hip_stream);
+int chisel_hip_condition_color(const uint8_t *src, int w0, int h0, int channels, int src_on_device, uint8_t *dst, int w, int h,
+                               int dst_on_device, void *hip_stream);
 
 /* ---- the step before that: the inverse-depth filter ----------------------------------------------
  * DepthFilter (server_pose_graph/src/dense_mapping/depth_filter.cpp): per-pixel Gaussian x uniform mixture filter of the

@@ -610,7 +610,7 @@ def test_full_size_stream_is_reproducible_across_modes(oracle_mod, monkeypatch):
     compare_fields(om.fields(), f5, om.V, True)
 
 
-@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (376, 1241), (720, 1280), (97, 131)])
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (376, 1241), (720, 1280), (97, 131), (960, 1280), (1, 1)])
 def test_depth_conditioning(shape):
     """chisel_hip_condition_depth == the restated PublishDenseInfo conditioning (oracle/publish_dense.py), bit for bit: same
     size (copy), up- and down-scaling, odd sizes, readings out of range, NaN and infinity in the input"""
@@ -630,6 +630,21 @@ def test_depth_conditioning(shape):
     assert np.array_equal(want[~np.isnan(want)].view(np.uint32), got[~np.isnan(got)].view(np.uint32))
     assert K == pd.rescale_intrinsics(*K0, shape[1], shape[0], 640, 480)
     assert np.isnan(got).mean() > 0.05  # the range mask does something on this input
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (376, 1241), (720, 1280), (97, 131), (960, 1280), (1, 1)])
+@pytest.mark.parametrize("cn", [0, 1, 3, 4])
+def test_color_conditioning(shape, cn):
+    """chisel_hip_condition_color == the restated cv::resize of the 8-bit colour image (oracle/publish_dense.py), byte for byte:
+    copy, up- and down-scaling, exact halving (INTER_AREA), odd sizes; MONO8 / BGR8 / BGRA8"""
+    from cvids_amd.chisel import condition_color
+    from oracle import publish_dense as pd
+    rng = np.random.default_rng(shape[0] * 11 + shape[1] + cn)
+    src = rng.integers(0, 256, shape if cn == 0 else shape + (cn,), dtype=np.uint8)
+    want = pd.condition_color(src, 640, 480)
+    got = condition_color(src, 640, 480)
+    assert got.shape == want.shape and got.dtype == np.uint8
+    assert np.array_equal(want, got)
 
 
 def test_rccl_exchange_world_size_one():
