@@ -1471,6 +1471,14 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
     if (ph[15])
         fprintf(stderr, "   units %llu (%.2f per wave)  frames visited %.2f per unit, executed %.2f per unit (%.2f us each), with a band update %.2f per unit\n",
                 (unsigned long long)ph[19], (double)ph[19] / ph[15], (double)ph[16] / ph[19], (double)ph[17] / ph[19], ph[17] ? ph[18] * 0.01 / ph[17] : 0.0, (double)ph[20] / ph[19]);
+    if (ph[15]) {  // lane-level utilisation of the executed wave-frames
+        uint64_t u[6] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < 64; b++)
+            for (int c = 0; c < 3; c++) { u[c] += rows[(size_t)b * 16 + 13 + c]; u[3 + c] += rows[(size_t)(64 + b) * 16 + 13 + c]; }
+        const double ex = (double)ph[17];
+        fprintf(stderr, "   per executed wave-frame: lanes needed %.1f / 64, voxels with a record %.1f / 256, voxels in band or carve test %.1f / 256; band code run by %.2f of them with %.1f lanes, carve code by %.2f with %.1f lanes\n",
+                u[0] / ex, u[1] / ex, u[2] / ex, ph[20] / ex, ph[20] ? (double)u[3] / ph[20] : 0.0, u[5] / ex, u[5] ? (double)u[4] / u[5] : 0.0);
+    }
     ph[21] = ~ph[21];
     if (ph[15] && getenv("CHISEL_HIP_PHASE_TABLE")) {  // wave 0 of every block, grouped by dispatch generation (256 blocks each)
         uint64_t t0 = ~0ull;

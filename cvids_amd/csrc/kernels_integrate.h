@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
     unsigned long long ph_last_start = 0, ph_max_unit = 0, ph_exec0 = 0;
     int ph_wid = 0;
     unsigned long long ph_visit = 0, ph_exec = 0, ph_exec_t = 0, ph_units = 0, ph_band = 0;
+    unsigned long long ph_need_l = 0, ph_vox = 0, ph_band_l = 0, ph_carve_w = 0, ph_carve_l = 0, ph_bandcarve_v = 0;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memrealtime(), ph_t0 = ph_t;
 #define PHASE(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph[i] += n_ - ph_t; ph_t = n_; } while (0)
 #else
@@ -343,6 +344,14 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     }
                     carvem = ip.carving ? (carvem & ~bandm) : 0u;
                     t_sdf += (unsigned)__popc(bandm);
+#ifdef CHISEL_PHASES
+                    ph_need_l += __builtin_popcountll(__ballot(need));
+                    for (int j = 0; j < 4; j++) ph_vox += __builtin_popcountll(__ballot(off[j] != 0u));
+                    ph_band_l += __builtin_popcountll(__ballot(bandm != 0u));
+                    ph_carve_l += __builtin_popcountll(__ballot(carvem != 0u));
+                    for (int j = 0; j < 4; j++) ph_bandcarve_v += __builtin_popcountll(__ballot(((bandm | carvem) >> j) & 1u));
+                    if (__any(carvem != 0u)) ph_carve_w++;
+#endif
                     // `probe`: carve tests on a chunk the reference's map holds before this frame
                     if (existed) {
                         t_probe += (unsigned)__popc(carvem);
@@ -539,6 +548,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
         atomicMax(&row2[5], ~ph_t0); atomicMax(&row2[6], ph_t); atomicMax(&row2[7], ph_last_start); atomicMax(&row2[8], ph_max_unit);
         if (wave == 0) { row2[9] = ph_t0; row2[10] = ph_t; row2[11] = ph_units; row2[12] = ph_exec; }
         atomicAdd(&row2[0], ph_visit); atomicAdd(&row2[1], ph_exec); atomicAdd(&row2[2], ph_exec_t); atomicAdd(&row2[3], ph_units); atomicAdd(&row2[4], ph_band);
+        unsigned long long *row3 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)(blockIdx.x & 63) * 16;  // rows 0-63, columns 13-15 (three packed pairs)
+        atomicAdd(&row3[13], ph_need_l); atomicAdd(&row3[14], ph_vox); atomicAdd(&row3[15], ph_bandcarve_v);
+        unsigned long long *row4 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)(64 + (blockIdx.x & 63)) * 16;
+        atomicAdd(&row4[13], ph_band_l); atomicAdd(&row4[14], ph_carve_l); atomicAdd(&row4[15], ph_carve_w);
     }
 #endif
     // ---- counters: one no-return atomic per wave and counter into this block's private row (rows are summed lazily by
