@@ -24,7 +24,8 @@ namespace chisel_hip {
 constexpr uint64_t KEY_EMPTY = ~0ull;
 constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
 constexpr int ID_BIAS = 1 << 20;  // chunk ids in [-2^20, 2^20)
-constexpr int INTEGRATE_MAX_GRID = 4096;  // rows of per-workgroup counters (largest persistent grid)
+constexpr int INTEGRATE_MAX_GRID = 4096;  // rows of per-workgroup counters (power of two; larger grids wrap around)
+constexpr int INTEGRATE_GRID_CAP = 1 << 17;  // largest integration grid (workgroups)
 
 __host__ __device__ inline uint64_t pack_id(int x, int y, int z) {
     return (uint64_t)(uint32_t)(x + ID_BIAS) | ((uint64_t)(uint32_t)(y + ID_BIAS) << 21) |
@@ -53,7 +54,8 @@ __host__ __device__ inline int chunk_owner(int x, int y, int z, int n_shards, in
 }
 
 // The map's error flags live in pinned host memory (the device addresses them through MapView::error_flag): two words, so
-// that neither kind of report can overwrite the other.
+// that neither kind of report can overwrite the other (a third word, [2], is not an error: the number of work items of the
+// latest integration launch, from which the host sizes a later launch's grid).
 //   [0] chunk pool (1) or chunk hash (2) exhausted: the map is incomplete from here on; stays set until chisel_hip_reset
 //   [1] a property of ONE point cloud (kernels_cloud.h: 3 = too many chunks / pairs, 4 = ray out of range): reported once, cleared
 // Plain stores: every writer of a word stores a nonzero code; the host reads them after a wait, without a copy.

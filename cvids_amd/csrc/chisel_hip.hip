@@ -402,10 +402,20 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     int *wc = bs.cand_count + COUNT_ITEMS;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
-        // persistent grid: what the chip holds at once, or fewer blocks when the candidates cannot fill it (in steps that give
-        // every XCD whole chunks in the first round)
+        // Grid.  One unit per wave and the hardware's in-order workgroup dispatch over the cost-ordered work-list is the
+        // schedule that works best (the SIMDs issue from their oldest wave first: a persistent wave that pulls a second unit keeps
+        // its age and starves the younger waves' first units -- the longest unit of a launch took 62 us for ten frames that cost
+        // 27 us on average).  The number of work items is only known on the device, so the grid is sized from the count a recent
+        // launch of this map reported (pinned word [2] beside the error flags, written by the integration kernel; it lags by the
+        // launches in flight) plus 1/8; surplus workgroups find no unit and leave, a shortfall is pulled from the queue heads by
+        // the workgroups as they finish.  Without a report yet: what the chip holds at once.
         const long long units = (long long)total * G::WPC;
-        const int grid = (int)std::max<long long>(G::GRID_STEP, std::min<long long>(G::GRID, (units / 4 + G::GRID_STEP - 1) / G::GRID_STEP * G::GRID_STEP));
+        const long long hint = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[2];
+        long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * G::WPC + 3) / 4 : (long long)G::GRID;
+        if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) blocks = atoi(e) ? (long long)G::GRID : blocks;
+        blocks = std::min<long long>(blocks, (units + 3) / 4);
+        blocks = std::min<long long>(blocks, (long long)INTEGRATE_GRID_CAP);
+        const int grid = (int)std::max<long long>(G::GRID_STEP, (blocks + G::GRID_STEP - 1) / G::GRID_STEP * G::GRID_STEP);
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
@@ -848,8 +858,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.counters, 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
-    HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, 2 * sizeof(int), hipHostMallocDefault));
-    m->error_flag_host[0] = m->error_flag_host[1] = 0;
+    HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, 4 * sizeof(int), hipHostMallocDefault));
+    m->error_flag_host[0] = m->error_flag_host[1] = m->error_flag_host[2] = m->error_flag_host[3] = 0;
     HIP_TRY_C(hipHostGetDevicePointer((void **)&v.error_flag, m->error_flag_host, 0));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));
@@ -1478,6 +1488,14 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
         const double ex = (double)ph[17];
         fprintf(stderr, "   per executed wave-frame: lanes needed %.1f / 64, voxels with a record %.1f / 256, voxels in band or carve test %.1f / 256; band code run by %.2f of them with %.1f lanes, carve code by %.2f with %.1f lanes\n",
                 u[0] / ex, u[1] / ex, u[2] / ex, ph[20] / ex, ph[20] ? (double)u[3] / ph[20] : 0.0, u[5] / ex, u[5] ? (double)u[4] / u[5] : 0.0);
+    }
+    if (ph[15] && ph[17]) {  // where an executed frame's time goes (10 ns ticks summed over waves)
+        uint64_t f[6] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < 64; b++)
+            for (int c = 0; c < 3; c++) { f[c] += rows[(size_t)(128 + b) * 16 + 13 + c]; f[3 + c] += rows[(size_t)(192 + b) * 16 + 13 + c]; }
+        const double ex = (double)ph[17] * 100.0;
+        fprintf(stderr, "   an executed frame, us: constants + z test %.2f | state loads + projection, gathers issued %.2f | records arrived, band / carve verdicts %.2f | band update (colour) %.2f | carve %.2f\n",
+                f[0] / ex, f[1] / ex, f[2] / ex, f[3] / ex, f[4] / ex);
     }
     ph[21] = ~ph[21];
     if (ph[15] && getenv("CHISEL_HIP_PHASE_TABLE")) {  // wave 0 of every block, grouped by dispatch generation (256 blocks each)

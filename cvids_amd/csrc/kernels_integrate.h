@@ -38,6 +38,16 @@ namespace chisel_hip {
 #ifndef INTEGRATE_BLOCKS_PER_CU
 #define INTEGRATE_BLOCKS_PER_CU 6
 #endif
+#ifndef INTEGRATE_VPL
+#define INTEGRATE_VPL 4        // x-consecutive voxels per lane (4 or 2): fewer = more, shorter units
+#endif
+constexpr int VPL = INTEGRATE_VPL;
+static_assert(VPL == 4 || VPL == 2, "voxels per lane");
+#ifndef INTEGRATE_LPW
+#define INTEGRATE_LPW 1        // 64-quad groups ("layers") a wave carries through the batch, applied one after the other per frame
+#endif
+constexpr int LPW = INTEGRATE_LPW;
+static_assert(LPW == 1 || LPW == 2, "layers per wave");
 
 constexpr int QUEUE_STRIDE = 32;  // ints between two queue heads (one 128-byte line each)
 constexpr int QUEUE_HEADS = 128;  // power of two, multiple of 8 (a head's waves share an XCD)
@@ -45,15 +55,17 @@ constexpr int QUEUE_HEADS = 128;  // power of two, multiple of 8 (a head's waves
 template <int N>
 struct Geom {
     static constexpr int V = N * N * N;
-    static constexpr int QX = N / 4;                 // quads per x-row
-    static constexpr int QUADS = V / 4;
+    static constexpr int QX = N / VPL;               // quads (a lane's VPL voxels) per x-row
+    static constexpr int QUADS = V / VPL;
     static constexpr int LAYER_QUADS = QX * N;       // quads per z-layer
-    static constexpr int WPC = QUADS / 64;           // wave units per chunk: 2 (8^3), 16 (16^3), 128 (32^3)
+    static constexpr int WPC = QUADS / (64 * LPW);   // wave units per chunk: 2 (8^3), 16 (16^3), 128 (32^3) at one layer per wave
+    static_assert(QUADS % (64 * LPW) == 0, "whole waves");
     static constexpr int BLOCK = 256;
     static constexpr int GRID = 256 * INTEGRATE_BLOCKS_PER_CU;  // persistent grid: what is resident at once
     static constexpr int GRID_STEP = (2 * WPC > 32) ? 2 * WPC : 32;  // blocks: every XCD's share of the first round is whole chunks
     static_assert(GRID % GRID_STEP == 0, "the statically dealt units are whole chunks");
     static_assert(GRID <= INTEGRATE_MAX_GRID, "per-workgroup counter rows");
+    static_assert(INTEGRATE_GRID_CAP % GRID_STEP == 0, "largest grid");
 };
 
 // colour-camera pixel of a voxel centre given in world coordinates (ProjectionIntegrator.h:146-149); -1 = off the image
@@ -69,8 +81,11 @@ __device__ inline int color_pixel(const CameraParams &K, float vx, float vy, flo
     return -1;
 }
 
-__device__ inline float &f4(float4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
-__device__ inline unsigned &u4(uint4 &v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+// a lane's voxels: VPL floats / packed colours, moved as one 16- or 8-byte access
+struct alignas(4 * VPL) QuadF { float v[VPL]; };
+struct alignas(4 * VPL) QuadU { unsigned v[VPL]; };
+__device__ inline float &f4(QuadF &q, int j) { return q.v[j]; }
+__device__ inline unsigned &u4(QuadU &q, int j) { return q.v[j]; }
 // (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32).  Checked against that pair
 // for every float that is not a NaN on the device, and that no NaN comes out as a possible pixel coordinate
 // (chisel_hip_kat_floor, tests/test_gpu_parity.py).
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
     int n_items = *work_count;
     if (n_items > max_items) n_items = max_items;
     const int total = n_items * G::WPC;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<volatile int *>(M.error_flag)[2] = n_items;  // sizes a later launch's grid (host)
     const int grid_waves = nb * 4;
     const int rem_chunks = n_items - grid_waves / G::WPC;  // chunks behind the statically dealt ones
     const IntegratorParams &ip = P.ip;
@@ -172,11 +188,14 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
     unsigned long long ph_last_start = 0, ph_max_unit = 0, ph_exec0 = 0;
     int ph_wid = 0;
     unsigned long long ph_visit = 0, ph_exec = 0, ph_exec_t = 0, ph_units = 0, ph_band = 0;
+    unsigned long long ph_f[5] = {0, 0, 0, 0, 0}, ph_ft = 0;
+#define FSTAMP(i, dep) do { asm volatile("" ::"v"(dep)); const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph_f[i] += n_ - ph_ft; ph_ft = n_; } while (0)
     unsigned long long ph_need_l = 0, ph_vox = 0, ph_band_l = 0, ph_carve_w = 0, ph_carve_l = 0, ph_bandcarve_v = 0;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memrealtime(), ph_t0 = ph_t;
 #define PHASE(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph[i] += n_ - ph_t; ph_t = n_; } while (0)
 #else
 #define PHASE(i) do { } while (0)
+#define FSTAMP(i, dep) do { } while (0)
 #endif
 
     int wid = ((local_unit / G::WPC) * 8 + xcd) * G::WPC + local_unit % G::WPC;
@@ -212,15 +231,20 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
 
             // voxelCenter = centroids[i] + origin (ChunkManager.cpp:61: Vec3(x,y,z)*res + half; ProjectionIntegrator.h:63),
             // origin = numVoxels * ID (int) * resolution (Chunk.cpp:43)
-            const int q = wq * 64 + lane;
-            float wx[4], wy, wz;
+            const int q0 = wq * (64 * LPW) + lane;  // layer h of this wave: quads q0 + 64 h (same x; y / z as the chunk size has it)
+            float wx[VPL], wya[LPW], wza[LPW];
             {
                 const float ox = (float)(N * cxi) * ip.res, oy = (float)(N * cyi) * ip.res, oz = (float)(N * czi) * ip.res;
-                const int xq = q % G::QX, y = (q / G::QX) % N, z = q / G::LAYER_QUADS;
-                wy = ((float)y * ip.res + ip.half_res) + oy;
-                wz = ((float)z * ip.res + ip.half_res) + oz;
+                const int xq = q0 % G::QX;
+                static_assert(64 % G::QX == 0, "the layers of a wave share their x");
 #pragma unroll
-                for (int j = 0; j < 4; j++) wx[j] = ((float)(xq * 4 + j) * ip.res + ip.half_res) + ox;
+                for (int h = 0; h < LPW; h++) {
+                    const int y = ((q0 + 64 * h) / G::QX) % N, z = (q0 + 64 * h) / G::LAYER_QUADS;
+                    wya[h] = ((float)y * ip.res + ip.half_res) + oy;
+                    wza[h] = ((float)z * ip.res + ip.half_res) + oz;
+                }
+#pragma unroll
+                for (int j = 0; j < VPL; j++) wx[j] = ((float)(xq * VPL + j) * ip.res + ip.half_res) + ox;
             }
             PHASE(0);
 #ifdef CHISEL_PHASES
@@ -230,14 +254,24 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
             ph_wid = wid;
 #endif
             // default voxels: DistVoxel() DistVoxel.cpp:27-31, ColorVoxel() ColorVoxel.cpp:27-31
-            float4 s4 = make_float4(99999.0f, 99999.0f, 99999.0f, 99999.0f), w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
+            QuadF s4a[LPW], w4a[LPW];
+            QuadU c4a[LPW];
+#pragma unroll
+            for (int h = 0; h < LPW; h++)
+#pragma unroll
+                for (int j = 0; j < VPL; j++) {
+                    s4a[h].v[j] = 99999.0f;
+                    w4a[h].v[j] = 0.0f;
+                    c4a[h].v[j] = 0u;
+                }
             // per-lane flags, kept in one vector register (as lane masks they would cost eight scalar registers):
             // HAVE / HAVEC: sdf+weight / colour registers hold the chunk's values (a chunk without a slot has default voxels:
             // nothing to read); DCHG / CCHG: they differ from memory
             constexpr unsigned HAVE = 1u, HAVEC = 2u, DCHG = 4u, CCHG = 8u;
-            unsigned st = existed ? 0u : (HAVE | HAVEC);
-            const size_t vbase = (size_t)(existed ? slot : 0) * G::V + 4 * (size_t)q;
+            unsigned sta[LPW];
+#pragma unroll
+            for (int h = 0; h < LPW; h++) sta[h] = existed ? 0u : (HAVE | HAVEC);
+            const size_t vbase0 = (size_t)(existed ? slot : 0) * G::V + VPL * (size_t)q0;
             unsigned bm = 0u, cm = 0u;  // frames in which this wave integrated / changed a voxel (wave-uniform)
             int carve_v = 0;            // lane k: this wave's carve tests of frame k (items without a slot)
 
@@ -261,17 +295,24 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 if (k_next >= 0) fb = fbp[k_next];
                 const FrameCam &F = P.f[k];
                 const CameraParams &C = F.cam;
+#pragma unroll
+                for (int h = 0; h < LPW; h++) {  // (indentation kept: the body is one layer's frame)
+                QuadF &s4 = s4a[h], &w4 = w4a[h];
+                QuadU &c4 = c4a[h];
+                unsigned &st = sta[h];
+                const size_t vbase = vbase0 + (size_t)(64 * VPL) * h;
+                const float wy = wya[h], wz = wza[h];
                 // inCamera = R^T * (voxelCenter - t) (ProjectionIntegrator.h:64), row i of R^T summed as a0 + (a1 + a2)
                 const float dy = wy - C.t[1], dz = wz - C.t[2];
                 const float s2 = C.R[5] * dy + C.R[8] * dz;
-                float dx[4], pcz[4];
+                float dx[VPL], pcz[VPL];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < VPL; j++) {
                     dx[j] = wx[j] - C.t[0];
                     pcz[j] = C.R[2] * dx[j] + s2;
                 }
-                const float zlo = fminf(fminf(pcz[0], pcz[1]), fminf(pcz[2], pcz[3]));
-                const float zhi = fmaxf(fmaxf(pcz[0], pcz[1]), fmaxf(pcz[2], pcz[3]));
+                const float zlo = VPL == 4 ? fminf(fminf(pcz[0], pcz[1]), fminf(pcz[VPL - 2], pcz[VPL - 1])) : fminf(pcz[0], pcz[1]);
+                const float zhi = VPL == 4 ? fmaxf(fmaxf(pcz[0], pcz[1]), fmaxf(pcz[VPL - 2], pcz[VPL - 1])) : fmaxf(pcz[0], pcz[1]);
                 const bool may_band = (zhi > z_near) & (zlo < z_far);
                 const bool need = may_band | (zlo < z_carve);
                 // Branches below are wave-uniform (__any) and the lanes are predicated, so that the counters stay scalar.
@@ -280,26 +321,30 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 // serves all four SIMDs of a CU at about half the vector rate per SIMD, and lane-mask logic (one scalar AND / OR /
                 // popcount per predicate) made it as busy as the vector units.
                 if (__any(need)) {  // else: the whole layer lies outside this frame's band and carve region
+#ifdef CHISEL_PHASES
+                    ph_ft = fr_t;
+#endif
+                    FSTAMP(0, (int)need);
                     // the quad's state, at the first frame that can touch it (straight into the tuples: no use, no wait)
                     if (need && !(st & HAVE)) {
-                        s4 = *reinterpret_cast<const float4 *>(M.sdf + vbase);
-                        w4 = *reinterpret_cast<const float4 *>(M.wgt + vbase);
+                        s4 = *reinterpret_cast<const QuadF *>(M.sdf + vbase);
+                        w4 = *reinterpret_cast<const QuadF *>(M.wgt + vbase);
                         st |= HAVE;
                     }
                     if (COLOR && need && may_band && !(st & HAVEC)) {
-                        c4 = *reinterpret_cast<const uint4 *>(M.rgbw + vbase);
+                        c4 = *reinterpret_cast<const QuadU *>(M.rgbw + vbase);
                         st |= HAVEC;
                     }
                     const float s0 = C.R[3] * dy + C.R[6] * dz;
                     const float s1 = C.R[4] * dy + C.R[7] * dz;
                     // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45): invZ = 1.0f / z
-                    float inv_z[4];
+                    float inv_z[VPL];
                     if (flags & WI_FASTZ) {  // wave-uniform
 #pragma unroll
-                        for (int j = 0; j < 4; j++) inv_z[j] = reciprocal_in_range(pcz[j]);
+                        for (int j = 0; j < VPL; j++) inv_z[j] = reciprocal_in_range(pcz[j]);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) inv_z[j] = 1.0f / pcz[j];
+                        for (int j = 0; j < VPL; j++) inv_z[j] = 1.0f / pcz[j];
                     }
                     // ---- geometry + projection -> record of every voxel of the quad, the four gathers in flight together --------
                     // Record offsets are 32 bits against a scalar base; the base is the all-NaN record in front of the frame's image,
@@ -311,13 +356,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     // selects (no lane-mask arithmetic).
                     const char *rec_base = reinterpret_cast<const char *>(F.rec - 1);
                     const unsigned row_bytes = (unsigned)C.W * (unsigned)sizeof(PixelRec);
-                    unsigned off[4];
-                    PixelRec r[4];
-                    float zn[4];  // camera z, or -1 for a quad this frame cannot touch
+                    unsigned off[VPL];
+                    PixelRec r[VPL];
+                    float zn[VPL];  // camera z, or -1 for a quad this frame cannot touch
 #pragma unroll
-                    for (int j = 0; j < 4; j++) zn[j] = need ? pcz[j] : -1.0f;
+                    for (int j = 0; j < VPL; j++) zn[j] = need ? pcz[j] : -1.0f;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
+                    for (int j = 0; j < VPL; j++) {
                         const float pcx = C.R[0] * dx[j] + s0, pcy = C.R[1] * dx[j] + s1;
                         const float u = C.fx * pcx * inv_z[j] + C.cx;
                         const float v = C.fy * pcy * inv_z[j] + C.cy;
@@ -327,29 +372,31 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                         // DepthAt(row, col) DepthImage.h:72-76
                         off[j] = (z_ok > 0.0f) ? __umul24((unsigned)iv, row_bytes) + ((unsigned)iu + 1u) * (unsigned)sizeof(PixelRec) : 0u;
 #ifdef CHISEL_ABLATE_GATHER  // diagnostic (wrong results): what would the kernel cost if the record gathers were coalesced?
-                        r[j] = *reinterpret_cast<const PixelRec *>(rec_base + (off[j] ? (unsigned)((lane * 4 + j + 1) * sizeof(PixelRec)) : 0u));
+                        r[j] = *reinterpret_cast<const PixelRec *>(rec_base + (off[j] ? (unsigned)((lane * VPL + j + 1) * sizeof(PixelRec)) : 0u));
 #else
                         r[j] = *reinterpret_cast<const PixelRec *>(rec_base + off[j]);
 #endif
                     }
+                    FSTAMP(1, off[VPL - 1]);
                     // ---- band tests: bit j of bandm / carvem = voxel j takes the in-band / the carve branch -------------------------
                     // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail.
-                    float sd[4];
+                    float sd[VPL];
                     unsigned bandm = 0u, carvem = 0u;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
+                    for (int j = 0; j < VPL; j++) {
                         sd[j] = r[j].x - pcz[j];                                                        // surfaceDist :79 / :139
                         bandm |= (fabsf(sd[j]) < r[j].y + ip.diag) ? (1u << j) : 0u;                    // :81 / :144
                         carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;                  // :86 / :164 (else branch)
                     }
                     carvem = ip.carving ? (carvem & ~bandm) : 0u;
+                    FSTAMP(2, bandm | carvem);
                     t_sdf += (unsigned)__popc(bandm);
 #ifdef CHISEL_PHASES
                     ph_need_l += __builtin_popcountll(__ballot(need));
-                    for (int j = 0; j < 4; j++) ph_vox += __builtin_popcountll(__ballot(off[j] != 0u));
+                    for (int j = 0; j < VPL; j++) ph_vox += __builtin_popcountll(__ballot(off[j] != 0u));
                     ph_band_l += __builtin_popcountll(__ballot(bandm != 0u));
                     ph_carve_l += __builtin_popcountll(__ballot(carvem != 0u));
-                    for (int j = 0; j < 4; j++) ph_bandcarve_v += __builtin_popcountll(__ballot(((bandm | carvem) >> j) & 1u));
+                    for (int j = 0; j < VPL; j++) ph_bandcarve_v += __builtin_popcountll(__ballot(((bandm | carvem) >> j) & 1u));
                     if (__any(carvem != 0u)) ph_carve_w++;
 #endif
                     // `probe`: carve tests on a chunk the reference's map holds before this frame
@@ -358,8 +405,8 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     } else {
                         unsigned frame_carve = 0u;  // wave-uniform
 #pragma unroll
-                        for (int j = 0; j < 4; j++) frame_carve += wave_count((carvem >> j) & 1u);
-                        carve_v = (lane == k) ? (int)frame_carve : carve_v;
+                        for (int j = 0; j < VPL; j++) frame_carve += wave_count((carvem >> j) & 1u);
+                        carve_v += (lane == k) ? (int)frame_carve : 0;
                     }
                     if (__any(bandm != 0u)) {
 #ifdef CHISEL_PHASES
@@ -369,15 +416,15 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                         cm |= 1u << k;
                         // colour first: the pixels of the in-band voxels whose colour weight is below 8 are requested now (one 4-byte
                         // gather per voxel, all in flight) and consumed after the sdf arithmetic
-                        unsigned cw[4], csh[4];
-                        int cpix[4];
+                        unsigned cw[VPL], csh[VPL];
+                        int cpix[VPL];
                         unsigned freshm = 0u;  // bit j: voxel j takes a colour sample
                         const bool word_gather = COLOR && F.color_channels >= 3;  // wave-uniform
                         if (COLOR) {
                             const unsigned image_bytes = (unsigned)(F.ccam.W * F.ccam.H * F.color_channels);
                             unsigned hasm = 0u;
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
+                            for (int j = 0; j < VPL; j++) {
                                 // one camera: the colour pixel is the depth pixel (its index back from the record offset; in band => on the image)
                                 cpix[j] = SAMECAM ? (int)(off[j] / (unsigned)sizeof(PixelRec)) - 1
                                                   : (((bandm >> j) & 1u) ? color_pixel(F.ccam, wx[j], wy, wz) : -1);
@@ -391,16 +438,16 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                             if (!SAMECAM) t_colsat += (unsigned)__popc(hasm & ~freshm);  // one camera: colsat = sdf - col
                             if (word_gather && __any(freshm != 0u)) {
 #pragma unroll
-                                for (int j = 0; j < 4; j++)
+                                for (int j = 0; j < VPL; j++)
 #ifdef CHISEL_ABLATE_GATHER
-                                    cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? lane * 4 + j : 0, F.color_channels, image_bytes, csh[j]);
+                                    cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? lane * VPL + j : 0, F.color_channels, image_bytes, csh[j]);
 #else
                                     cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? cpix[j] : 0, F.color_channels, image_bytes, csh[j]);
 #endif
                             }
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
+                        for (int j = 0; j < VPL; j++) {
                             // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84; IntegrateColor: weighter->GetWeight(.., truncation) :161-162
                             const float wu = COLOR ? constant_weight(ip.weight, r[j].y) : 1.0f;
                             float ns = f4(s4, j), nw = f4(w4, j);
@@ -413,13 +460,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                         if (COLOR && __any(freshm != 0u)) {
                             if (word_gather) {
 #pragma unroll
-                                for (int j = 0; j < 4; j++) {
+                                for (int j = 0; j < VPL; j++) {
                                     const unsigned nc = color_integrate_fresh(u4(c4, j), color_word(cw[j], csh[j]));
                                     u4(c4, j) = ((freshm >> j) & 1u) ? nc : u4(c4, j);
                                 }
                             } else {  // 1 / 2 channel images
 #pragma unroll
-                                for (int j = 0; j < 4; j++) {
+                                for (int j = 0; j < VPL; j++) {
                                     if ((freshm >> j) & 1u) {
                                         unsigned cbits = u4(c4, j);
                                         uchar4 cv = *reinterpret_cast<uchar4 *>(&cbits);
@@ -433,10 +480,11 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                             st |= freshm ? CCHG : 0u;
                         }
                     }
+                    FSTAMP(3, f4(s4, 0));
                     if (__any(carvem != 0u)) {
                         unsigned hitm = 0u;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
+                        for (int j = 0; j < VPL; j++) {
                             const bool hit = ((carvem >> j) & 1u) && (f4(w4, j) > 0.0f) && sdf_below_carve_threshold(f4(s4, j));
                             hitm |= hit ? (1u << j) : 0u;
                             const bool decay = COLOR && !(f4(w4, j) < 5.0f);      // :166-177: decay
@@ -451,8 +499,9 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     }
                 }
 #ifdef CHISEL_PHASES
-                if (__any(need)) { ph_exec++; ph_exec_t += __builtin_amdgcn_s_memrealtime() - fr_t; }
+                if (__any(need)) { FSTAMP(4, f4(s4, 0)); ph_exec++; ph_exec_t += __builtin_amdgcn_s_memrealtime() - fr_t; }
 #endif
+                }  // layer h
                 if (k_next < 0) break;
                 k = k_next;
             }
@@ -493,14 +542,14 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 PHASE(2);
                 if (slot < 0) break;  // never integrated here, or no slot left (error raised)
             }
-            {
-                float *sp = M.sdf + (size_t)slot * G::V + 4 * (size_t)q;
-                float *wp = M.wgt + (size_t)slot * G::V + 4 * (size_t)q;
-                if (st & DCHG) {
-                    *reinterpret_cast<float4 *>(sp) = s4;
-                    *reinterpret_cast<float4 *>(wp) = w4;
+#pragma unroll
+            for (int h = 0; h < LPW; h++) {
+                const size_t v = (size_t)slot * G::V + VPL * (size_t)(q0 + 64 * h);
+                if (sta[h] & DCHG) {
+                    *reinterpret_cast<QuadF *>(M.sdf + v) = s4a[h];
+                    *reinterpret_cast<QuadF *>(M.wgt + v) = w4a[h];
                 }
-                if (COLOR && (st & CCHG)) *reinterpret_cast<uint4 *>(M.rgbw + (size_t)slot * G::V + 4 * (size_t)q) = c4;
+                if (COLOR && (sta[h] & CCHG)) *reinterpret_cast<QuadU *>(M.rgbw + v) = c4a[h];
             }
             if (cm) {
                 // "needsUpdate" of the chunk per frame (Chisel.h:85 / :167): each frame counts once per chunk -- by the wave
@@ -524,13 +573,14 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
         // and eight heads for 8192 waves cost every wave 10-20 us per unit.
         wid = total;
         while (rem_chunks > 0 && shard_try < 2) {
-            const int h = ((int)blockIdx.x + shard_try * 8) & (QUEUE_HEADS - 1);
-            const int units = rem_chunks > h ? ((rem_chunks - h + QUEUE_HEADS - 1) / QUEUE_HEADS) * G::WPC : 0;  // chunks h, h + H, ... of the remainder
+            const int heads = nb < QUEUE_HEADS ? nb : QUEUE_HEADS;  // every head is some workgroup's home (nb is a multiple of 8)
+            const int h = ((int)blockIdx.x + shard_try * 8) % heads;
+            const int units = rem_chunks > h ? ((rem_chunks - h + heads - 1) / heads) * G::WPC : 0;  // chunks h, h + heads, ... of the remainder
             int t = units;
             if (lane == 0 && units > 0) t = atomicAdd(&queues[h * QUEUE_STRIDE], 1);
             t = __builtin_amdgcn_readfirstlane(t);
             if (t < units) {
-                wid = grid_waves + ((t / G::WPC) * QUEUE_HEADS + h) * G::WPC + (t % G::WPC);
+                wid = grid_waves + ((t / G::WPC) * heads + h) * G::WPC + (t % G::WPC);
                 break;
             }
             shard_try++;
@@ -540,11 +590,11 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
 
 #ifdef CHISEL_PHASES
     if (lane == 0) {
-        unsigned long long *row = M.block_counters + (size_t)blockIdx.x * 16;
+        unsigned long long *row = M.block_counters + (size_t)(blockIdx.x & (INTEGRATE_MAX_GRID - 1)) * 16;
         for (int i = 0; i < 5; i++) atomicAdd(&row[9 + i], ph[i]);
         atomicAdd(&row[14], ph_t - ph_t0);
         atomicAdd(&row[15], 1ull);
-        unsigned long long *row2 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)blockIdx.x * 16;
+        unsigned long long *row2 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)(blockIdx.x & (INTEGRATE_MAX_GRID - 1)) * 16;
         atomicMax(&row2[5], ~ph_t0); atomicMax(&row2[6], ph_t); atomicMax(&row2[7], ph_last_start); atomicMax(&row2[8], ph_max_unit);
         if (wave == 0) { row2[9] = ph_t0; row2[10] = ph_t; row2[11] = ph_units; row2[12] = ph_exec; }
         atomicAdd(&row2[0], ph_visit); atomicAdd(&row2[1], ph_exec); atomicAdd(&row2[2], ph_exec_t); atomicAdd(&row2[3], ph_units); atomicAdd(&row2[4], ph_band);
@@ -552,6 +602,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
         atomicAdd(&row3[13], ph_need_l); atomicAdd(&row3[14], ph_vox); atomicAdd(&row3[15], ph_bandcarve_v);
         unsigned long long *row4 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)(64 + (blockIdx.x & 63)) * 16;
         atomicAdd(&row4[13], ph_band_l); atomicAdd(&row4[14], ph_carve_l); atomicAdd(&row4[15], ph_carve_w);
+        unsigned long long *row5 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)(128 + (blockIdx.x & 63)) * 16;
+        atomicAdd(&row5[13], ph_f[0]); atomicAdd(&row5[14], ph_f[1]); atomicAdd(&row5[15], ph_f[2]);
+        unsigned long long *row6 = M.block_counters + (size_t)INTEGRATE_MAX_GRID * 16 + (size_t)(192 + (blockIdx.x & 63)) * 16;
+        atomicAdd(&row6[13], ph_f[3]); atomicAdd(&row6[14], ph_f[4]);
     }
 #endif
     // ---- counters: one no-return atomic per wave and counter into this block's private row (rows are summed lazily by
@@ -562,7 +616,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sums[c] += __shfl_down(sums[c], o);
     if (lane == 0) {
-        unsigned long long *row = M.block_counters + (size_t)blockIdx.x * 16;
+        unsigned long long *row = M.block_counters + (size_t)(blockIdx.x & (INTEGRATE_MAX_GRID - 1)) * 16;
         const unsigned vals[8] = {sums[0], sums[1], sums[2], sums[3], sums[4], 0u, n_new, n_updated};
 #pragma unroll
         for (int k = 0; k < 8; k++)
