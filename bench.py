@@ -99,9 +99,12 @@ def pmc_traffic(kernel_key, args, frames_per_launch):
             d = json.load(open(f))
         except Exception:
             continue
-        k = d.get("kernels", {}).get(kernel_key)
-        if k and "fetch_kib" in k and "write_kib" in k and all(d.get("bench", {}).get(key) == val for key, val in want.items()):
-            best = (f, k)
+        # the kernel has one instantiation per granularity (..., 2> / ..., 4>: voxels per lane, picked per launch): all of them count
+        ks = [v for n, v in d.get("kernels", {}).items() if n.startswith(kernel_key) and "fetch_kib" in v and "write_kib" in v]
+        if ks and all(d.get("bench", {}).get(key) == val for key, val in want.items()):
+            calls = sum(v.get("calls", 1) for v in ks) or 1
+            best = (f, {"fetch_kib": sum(v["fetch_kib"] * v.get("calls", 1) for v in ks) / calls,
+                        "write_kib": sum(v["write_kib"] * v.get("calls", 1) for v in ks) / calls})
     if not best:
         return None, None
     f, k = best
@@ -328,9 +331,9 @@ def main():
         launches = k["launches"]
         bytes_per_launch = algorithmic_bytes(cb, args.steps, W, H, channels) / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        kernel_key = "integrate_kernel<%d, %s, %s>" % (args.chunk, "true" if use_color else "false", "true" if use_color else "false")
+        kernel_key = "integrate_kernel<%d, %s, %s" % (args.chunk, "true" if use_color else "false", "true" if use_color else "false")
         traffic, traffic_src = pmc_traffic(kernel_key, args, args.steps / max(launches, 1)) if world == 1 else (None, None)
-        roof = {"bound": "hbm", "kernel": kernel_key,
+        roof = {"bound": "hbm", "kernel": kernel_key + ", 2|4>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and avg_ms > 0) else None,

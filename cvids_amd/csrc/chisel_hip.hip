@@ -342,7 +342,6 @@ int check_mesh_totals(chisel_hip_map *m);  // host_mesh.h
 template <int N>
 int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidParams &PP, const CullParams &CP, const IntegrateParams &IP,
                  bool color) {
-    using G = Geom<N>;
     const int total = CullSpace(CP).total;  // candidate slots: every id of the union range, or the owned ones of a sharded map
     g_host_timer.lap(2);
     PyramidView pyr = m->pyr;
@@ -404,30 +403,40 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
         // Grid.  One unit per wave and the hardware's in-order workgroup dispatch over the cost-ordered work-list is the
         // schedule that works best (the SIMDs issue from their oldest wave first: a persistent wave that pulls a second unit keeps
-        // its age and starves the younger waves' first units -- the longest unit of a launch took 62 us for ten frames that cost
-        // 27 us on average).  The number of work items is only known on the device, so the grid is sized from the count a recent
-        // launch of this map reported (pinned word [2] beside the error flags, written by the integration kernel; it lags by the
-        // launches in flight) plus 1/8; surplus workgroups find no unit and leave, a shortfall is pulled from the queue heads by
-        // the workgroups as they finish.  Without a report yet: what the chip holds at once.
-        const long long units = (long long)total * G::WPC;
+        // its age and starves the younger waves' first units).  The number of work items is only known on the device, so the grid
+        // is sized from the count a recent launch of this map reported (pinned word [2] beside the error flags, written by the
+        // integration kernel; it lags by the launches in flight) plus 1/8; surplus workgroups find no unit and leave, a shortfall
+        // is pulled from the queue heads by the workgroups as they finish.  Without a report yet: what the chip holds at once.
+        // The same figure picks the granularity: 2 voxels per lane for launches of several frames below INTEGRATE_FINE_BELOW items
+        // (about three rounds of the chip at 4 voxels per lane), 4 otherwise (kernels_integrate.h).
         const long long hint = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[2];
-        long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * G::WPC + 3) / 4 : (long long)G::GRID;
-        if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) blocks = atoi(e) ? (long long)G::GRID : blocks;
+        int vpl = (IP.n_frames >= 4 && hint > 0 && hint * (long long)(N * N * N) < (long long)INTEGRATE_FINE_BELOW * 4096) ? 2 : 4;
+        if (const char *e = getenv("CHISEL_HIP_VPL")) vpl = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : vpl);
+        const int wpc = vpl == 2 ? Geom<N, 2>::WPC : Geom<N, 4>::WPC;
+        const int step = vpl == 2 ? Geom<N, 2>::GRID_STEP : Geom<N, 4>::GRID_STEP;
+        const long long units = (long long)total * wpc;
+        long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * wpc + 3) / 4 : (long long)Geom<N, 4>::GRID;
+        if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) blocks = atoi(e) ? (long long)Geom<N, 4>::GRID : blocks;
         blocks = std::min<long long>(blocks, (units + 3) / 4);
         blocks = std::min<long long>(blocks, (long long)INTEGRATE_GRID_CAP);
-        const int grid = (int)std::max<long long>(G::GRID_STEP, (blocks + G::GRID_STEP - 1) / G::GRID_STEP * G::GRID_STEP);
+        const int grid = (int)std::max<long long>(step, (blocks + step - 1) / step * step);
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
-        if (color && same_cam)  // CVIDS: depth and colour share one camera (sample.launch:19-20)
-            hipLaunchKernelGGL((integrate_kernel<N, true, true>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               bs.items, bs.boxes, bs.sync, wc, queues, m->items_capacity);
-        else if (color)
-            hipLaunchKernelGGL((integrate_kernel<N, true, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               bs.items, bs.boxes, bs.sync, wc, queues, m->items_capacity);
-        else
-            hipLaunchKernelGGL((integrate_kernel<N, false, false>), dim3(grid), dim3(G::BLOCK), 0, m->stream, IP, m->view, m->view_dev,
-                               bs.items, bs.boxes, bs.sync, wc, queues, m->items_capacity);
+#define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
+    hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(256), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
+                       bs.boxes, bs.sync, wc, queues, m->items_capacity)
+        if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
+            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);
+            else CHISEL_LAUNCH_INTEGRATE(true, true, 4);
+        } else if (color) {
+            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, false, 2);
+            else CHISEL_LAUNCH_INTEGRATE(true, false, 4);
+        } else {
+            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(false, false, 2);
+            else CHISEL_LAUNCH_INTEGRATE(false, false, 4);
+        }
+#undef CHISEL_LAUNCH_INTEGRATE
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(bs.back_done, m->stream));

@@ -38,11 +38,14 @@ namespace chisel_hip {
 #ifndef INTEGRATE_BLOCKS_PER_CU
 #define INTEGRATE_BLOCKS_PER_CU 6
 #endif
-#ifndef INTEGRATE_VPL
-#define INTEGRATE_VPL 4        // x-consecutive voxels per lane (4 or 2): fewer = more, shorter units
+// Voxels per lane (x-consecutive), a template parameter of the kernel: 4 for launches that fill the chip many times over (least
+// arithmetic per voxel: the quad's y / z terms are shared), 2 for small launches (twice as many units of half the length: what
+// such a launch takes is the length of its longest chains, not its arithmetic).  The host picks per launch: measured at 640x480 /
+// 1 cm, 10 frames per launch, 2 voxels per lane win by 10 % at 540 work items (61 against 68 us) and by 3 % at 1 240, lose 17 % at
+// 1 500+ items (318 against 272 us) and 20 % on one-frame launches (nothing to shorten: 21 against 17 us).
+#ifndef INTEGRATE_FINE_BELOW
+#define INTEGRATE_FINE_BELOW 1280  // work items (16^3 chunks; scaled by voxels per chunk) below which a launch of >= 4 frames runs with 2 voxels per lane
 #endif
-constexpr int VPL = INTEGRATE_VPL;
-static_assert(VPL == 4 || VPL == 2, "voxels per lane");
 #ifndef INTEGRATE_LPW
 #define INTEGRATE_LPW 1        // 64-quad groups ("layers") a wave carries through the batch, applied one after the other per frame
 #endif
@@ -52,8 +55,9 @@ static_assert(LPW == 1 || LPW == 2, "layers per wave");
 constexpr int QUEUE_STRIDE = 32;  // ints between two queue heads (one 128-byte line each)
 constexpr int QUEUE_HEADS = 128;  // power of two, multiple of 8 (a head's waves share an XCD)
 
-template <int N>
+template <int N, int VPL>
 struct Geom {
+    static_assert(VPL == 4 || VPL == 2, "voxels per lane");
     static constexpr int V = N * N * N;
     static constexpr int QX = N / VPL;               // quads (a lane's VPL voxels) per x-row
     static constexpr int QUADS = V / VPL;
@@ -82,10 +86,14 @@ __device__ inline int color_pixel(const CameraParams &K, float vx, float vy, flo
 }
 
 // a lane's voxels: VPL floats / packed colours, moved as one 16- or 8-byte access
-struct alignas(4 * VPL) QuadF { float v[VPL]; };
-struct alignas(4 * VPL) QuadU { unsigned v[VPL]; };
-__device__ inline float &f4(QuadF &q, int j) { return q.v[j]; }
-__device__ inline unsigned &u4(QuadU &q, int j) { return q.v[j]; }
+template <int VPL>
+struct alignas(4 * VPL) QuadFT { float v[VPL]; };
+template <int VPL>
+struct alignas(4 * VPL) QuadUT { unsigned v[VPL]; };
+template <int VPL>
+__device__ inline float &f4(QuadFT<VPL> &q, int j) { return q.v[j]; }
+template <int VPL>
+__device__ inline unsigned &u4(QuadUT<VPL> &q, int j) { return q.v[j]; }
 // (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32).  Checked against that pair
 // for every float that is not a NaN on the device, and that no NaN comes out as a possible pixel coordinate
 // (chisel_hip_kat_floor, tests/test_gpu_parity.py).
@@ -159,13 +167,15 @@ __device__ __attribute__((noinline)) int claim_slot(const MapView *__restrict__ 
     return s >= 2 ? s - 2 : -1;
 }
 
-template <int N, bool COLOR, bool SAMECAM>
+template <int N, bool COLOR, bool SAMECAM, int VPL>
 __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(IntegrateParams P, MapView M, const MapView *__restrict__ Mc,
                                                                           const WorkItem *__restrict__ items,
                                                                           const FrameBox *__restrict__ boxes, ItemSync *sync,
                                                                           const int *__restrict__ work_count, int *queues,
                                                                           int max_items) {
-    using G = Geom<N>;
+    using G = Geom<N, VPL>;
+    using QuadF = QuadFT<VPL>;
+    using QuadU = QuadUT<VPL>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Blocks b and b + 8 share an XCD (observed dispatch order; speed only).  The first round is dealt statically: XCD x takes
