@@ -8,18 +8,20 @@
 // (DistVoxel::Integrate is a running average, DistVoxel.h:52-60), so a unit of work is a serial chain of K frames.  With a
 // workgroup per chunk (4096 voxels, 8 voxels per thread, 128 registers, a barrier and a staged pixel tile per frame) the
 // chip held 512 chains of K x 3-5 us and a launch lasted ceil(items / 512) such chains: 0.19 of the HBM roofline with the
-// vector units 13-23 % busy.  Here the unit is a wave that owns 64 quads (256 voxels: one z-layer of a 16^3 chunk), four
-// voxels per lane, <= 64 registers -> eight waves per SIMD, 8192 chains in flight, each K x (one quad's work).  Waves never
-// meet: no barrier, no LDS; the pixel records come from L2 (the frames of a batch stay there and in the Infinity Cache), and
-// a wave whose layer lies outside the band and the carve region of a frame skips that frame after 16 instructions.
+// vector units 13-23 % busy.  Here the unit is a wave that owns 64 "quads" -- a lane's 4 (or 2) x-consecutive voxels; 256
+// voxels are one z-layer of a 16^3 chunk --, 77 (57) registers -> six to eight waves per SIMD, thousands of chains in flight,
+// each K x (one quad's work).  Waves never meet: no barrier, no LDS; the pixel records come from L2 / the Infinity Cache (a
+// batch's frames stay there), and a wave whose layer lies outside the band and the carve region of a frame skips that frame
+// after 16 instructions.
 //
-//   - work unit `wid` = (work item, 64-quad group); the first 8192 are dealt statically so that the groups of one chunk sit on
-//     one XCD (its L2 then holds the pixel footprint of "its" chunks only), the rest are pulled from eight per-XCD queue
-//     heads (one returning atomic per unit; a shard that runs dry steals from the next);
-//   - a lane owns one quad of 4 consecutive x voxels: every voxel-plane access of a wave is 1 KiB contiguous; the state is
-//     read once (at the first frame that can touch the quad), lives in registers for the batch and is written once, only
-//     where it changed;
-//   - counters are scalar: wave ballot + popcount per voxel column instead of a per-lane add;
+//   - work unit `wid` = (work item, 64-quad group), dealt statically so that the groups of one chunk sit on one XCD and every
+//     XCD gets the same mix of expensive and cheap chunks; the host sizes the grid to about one unit per wave from the item
+//     count a recent launch reported (chisel_hip.hip: launch_group), whatever exceeds the grid is pulled from up to 128 queue
+//     heads (one returning atomic per unit; a head serves workgroups of one XCD, one neighbour is tried when it runs dry);
+//   - a lane owns one quad: every voxel-plane access of a wave is 1 KiB (512 B) contiguous; the state is read once (at the
+//     first frame that can touch the quad), lives in registers for the batch and is written once, only where it changed;
+//   - a lane's verdicts are bit masks over its voxels and its counters per-lane adds, reduced when the wave retires; branches
+//     are wave-uniform (__any): the scalar unit is shared by the four SIMDs of a CU and lane-mask arithmetic saturates it;
 //   - chunk-level facts the reference derives per frame ("did any voxel integrate", "did anything change") travel through a
 //     per-item record in HBM touched by device-scope atomics only (ItemSync): the first wave that integrates a voxel of a
 //     chunk without a slot allocates it (free-list pop + hash CAS) and publishes the slot, its siblings take it from there;
@@ -27,6 +29,8 @@
 //     arrives last.  Resident chunks need one atomic OR per wave that changed something.
 //   - per-voxel arithmetic follows the reference operation by operation in fp32 (compiled with -ffp-contract=off, IEEE
 //     divide), 3-term sums in Eigen's a0 + (a1 + a2) order.
+// Build parameters for experiments: INTEGRATE_WAVES / INTEGRATE_BLOCKS_PER_CU (occupancy), INTEGRATE_LPW (two
+// 64-quad groups per wave: slower), CHISEL_PHASES (in-kernel timers and utilisation counters), CHISEL_ABLATE_GATHER.
 #pragma once
 #include "chisel_device.h"
 

@@ -388,6 +388,45 @@ def test_back_to_back_batches_pipeline(oracle_mod, batch, force_lookup, monkeypa
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+@pytest.mark.parametrize("chunk", [8, 16, 32])
+@pytest.mark.parametrize("mode", ["vpl2", "vpl4", "persistent", "growing"])
+def test_integration_schedules(oracle_mod, chunk, mode, monkeypatch):
+    """The integration kernel's two granularities (2 / 4 voxels per lane, normally picked per launch from the item count a
+    recent launch reported) and its two ways of handing out units (one unit per wave with a grid sized from that count;
+    persistent waves pulling from the queue heads) give the same map: each forced over a stream with batches of 1..8 frames,
+    colour, carving.  "growing": the reported count is far too small for the next launch (a small wall, then the whole room),
+    so most units come from the queue heads of a small grid."""
+    if mode == "vpl2":
+        monkeypatch.setenv("CHISEL_HIP_VPL", "2")
+    elif mode == "vpl4":
+        monkeypatch.setenv("CHISEL_HIP_VPL", "4")
+    elif mode == "persistent":
+        monkeypatch.setenv("CHISEL_HIP_PERSISTENT", "1")
+    res = {8: 0.05, 16: 0.03, 32: 0.02}[chunk]
+    om, gm, integ = _mk(oracle_mod, chunk, res, True, carving=True, carving_dist=0.02, max_chunks=8192)
+    cam = small_camera(96, 72)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(96, 72, 3)
+    frames = make_frames("sphere_room", 14, 96, 72, agents=2, nan_fraction=0.02)
+    if mode == "growing":
+        tiny = np.full((72, 96), np.nan, np.float32)
+        tiny[30:40, 40:56] = 1.0
+        frames = [(tiny, synth.pose_yaw(0.0))] * 3 + frames
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+    sizes = [1, 1, 1, 4, 8, 2, 5] if mode == "growing" else [1, 4, 8, 2, 5]
+    lo = 0
+    for n in sizes * 4:
+        part = frames[lo:lo + n]
+        if not part:
+            break
+        gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        lo += n
+    assert lo >= len(frames)
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
 def test_checkpoint_and_resume(oracle_mod, tmp_path):
     """chisel_hip_save_map / load_map: a map dumped in the middle of a stream and restored into a fresh map continues
     bit for bit like the uninterrupted run (and like the oracle); the dump itself reads back identically"""
