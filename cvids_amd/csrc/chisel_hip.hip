@@ -1498,6 +1498,15 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
         fprintf(stderr, "   per executed wave-frame: lanes needed %.1f / 64, voxels with a record %.1f / 256, voxels in band or carve test %.1f / 256; band code run by %.2f of them with %.1f lanes, carve code by %.2f with %.1f lanes\n",
                 u[0] / ex, u[1] / ex, u[2] / ex, ph[20] / ex, ph[20] ? (double)u[3] / ph[20] : 0.0, u[5] / ex, u[5] ? (double)u[4] / u[5] : 0.0);
     }
+    {
+        unsigned long long mp[8];
+        if (hipMemcpyFromSymbol(mp, HIP_SYMBOL(g_mesh_phase), sizeof(mp)) == hipSuccess && mp[7]) {
+            fprintf(stderr, "mesh_count_kernel, us per job (thread 0): lookups %.2f | corners staged %.2f | cubes classified %.2f | scan %.2f | reserve %.2f | records %.2f | jobs %llu\n",
+                    mp[0] * 0.01 / mp[7], mp[1] * 0.01 / mp[7], mp[2] * 0.01 / mp[7], mp[3] * 0.01 / mp[7], mp[4] * 0.01 / mp[7], mp[5] * 0.01 / mp[7], mp[7]);
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_phase), z, sizeof(z));
+        }
+    }
     if (ph[15] && ph[17]) {  // where an executed frame's time goes (10 ns ticks summed over waves)
         uint64_t f[6] = {0, 0, 0, 0, 0, 0};
         for (int b = 0; b < 64; b++)

@@ -63,6 +63,24 @@ __device__ inline int hash_find(const MapView &M, int x, int y, int z, uint64_t 
     return -1;
 }
 
+// The same for kernels that run while nothing inserts into the hash (the mesh kernels: the map's stream is theirs): key and
+// slot of the home bucket are requested together -- one round trip instead of two for the chunks that sit in their home bucket.
+__device__ inline int hash_find_quiescent(const MapView &M, int x, int y, int z) {
+    const uint64_t key = pack_id(x, y, z);
+    const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+    const uint64_t k0 = M.hash_keys[h];
+    const int v0 = M.hash_vals[h];
+    if (k0 == key) return v0;
+    if (k0 == KEY_EMPTY) return -1;
+    for (uint64_t i = 1; i <= M.hash_mask; i++) {
+        const uint64_t idx = (h + i) & M.hash_mask;
+        const uint64_t k = M.hash_keys[idx];
+        if (k == key) return M.hash_vals[idx];
+        if (k == KEY_EMPTY) break;
+    }
+    return -1;
+}
+
 // HasChunk / GetChunk (ChunkManager.h:79-87): slot per id, -1 when absent
 __global__ void lookup_kernel(MapView M, const int *ids, int n, int *slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

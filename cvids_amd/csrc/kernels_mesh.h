@@ -22,7 +22,7 @@
 namespace chisel_hip {
 
 __constant__ unsigned long long c_mc_cases[256] = CHISEL_MC_PACKED_CASES;
-__constant__ unsigned char c_mc_counts[256] = CHISEL_MC_VERTEX_COUNTS;
+__constant__ __attribute__((aligned(4))) unsigned char c_mc_counts[256] = CHISEL_MC_VERTEX_COUNTS;
 __constant__ unsigned char c_mc_edges[12] = CHISEL_MC_EDGE_CORNERS;
 
 struct MeshJob {
@@ -306,7 +306,7 @@ struct CornerTile {
 template <int N>
 __device__ inline void stage_corners(const MapView &M, const int *nb, float2 *s_vox) {
     if (!CornerTile<N>::STAGED) return;
-    constexpr int E = N + 1, TOTAL = E * E * E, U = 5;  // five corners (ten loads) of a thread in flight together
+    constexpr int E = N + 1, TOTAL = E * E * E, U = (TOTAL + MESH_BLOCK_THREADS - 1) / MESH_BLOCK_THREADS;  // all of a thread's corners (2 U loads) in flight together: one round trip
     for (int i0 = threadIdx.x; i0 < TOTAL; i0 += U * MESH_BLOCK_THREADS) {
         float2 v[U];
 #pragma unroll
@@ -402,6 +402,12 @@ struct TriRec {
 // triangles.  info[j] = what the host keeps of job j: sizes and its first triangle / grid in the batch (the chunks' ranges
 // follow one another in completion order; within a chunk the order is the reference's).
 // totals[0..1] = running totals (the atomics), totals[2] = set when the triangle list is too small (the host retries).
+#ifdef CHISEL_PHASES
+__device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per stage of mesh_count_kernel (thread 0 of every workgroup), [7] = jobs
+#define MSTAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_mesh_phase[i], n_ - mt_); mt_ = n_; } } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
 template <int N>
 __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
                                                                  JobInfo *info, int *totals, TriRec *tris, int tri_capacity) {
@@ -409,16 +415,26 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     __shared__ int s_nb[27];
     __shared__ int s_base[2];
     __shared__ float2 s_vox[CornerTile<N>::SIZE];
+    __shared__ unsigned s_counts[64];  // the 256 vertex counts of the case table, four to a word (a per-lane index into constant memory is a global load)
     constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
+    // (the first job's id is requested together with the job count: the id buffer holds at least 4096 entries -- more than the
+    // grid has workgroups -- whatever the count; ensure_mesh_jobs)
+    int jx0 = ids[3 * blockIdx.x], jy0 = ids[3 * blockIdx.x + 1], jz0 = ids[3 * blockIdx.x + 2];
     const int n = *n_jobs;  // the job count stays on the device: the grid is persistent
+    if (threadIdx.x < 64) s_counts[threadIdx.x] = reinterpret_cast<const unsigned *>(c_mc_counts)[threadIdx.x];  // (first barrier below)
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
+#ifdef CHISEL_PHASES
+    unsigned long long mt_ = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) atomicAdd(&g_mesh_phase[7], 1ull);
+#endif
     __syncthreads();  // the previous job's LDS contents are no longer read
     // the job record: the chunk id and the pool slots of its 27-neighbourhood (27 hash lookups, one per thread); kept for
     // the triangle kernel and the host
-    const int jx = ids[3 * j], jy = ids[3 * j + 1], jz = ids[3 * j + 2];
+    const bool first = j == (int)blockIdx.x;
+    const int jx = first ? jx0 : ids[3 * j], jy = first ? jy0 : ids[3 * j + 1], jz = first ? jz0 : ids[3 * j + 2];
     if (threadIdx.x < 27) {
         const int o = threadIdx.x;
-        const int slot = hash_find(M, jx + o % 3 - 1, jy + (o / 3) % 3 - 1, jz + o / 9 - 1);
+        const int slot = hash_find_quiescent(M, jx + o % 3 - 1, jy + (o / 3) % 3 - 1, jz + o / 9 - 1);
         s_nb[o] = slot;
         jobs[j].nb[o] = slot;
     } else if (threadIdx.x == 27) {
@@ -429,7 +445,9 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     }
     __syncthreads();
     const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
+    MSTAMP(0);
     if (present) stage_corners<N>(M, s_nb, s_vox);
+    MSTAMP(1);
     int nv = 0, ng = 0;
     unsigned char cases[CPT];  // case index of the thread's cubes that carry triangles (0: none -- case 0 has no triangles either)
 #pragma unroll
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
                 float sc[8];
                 cube_of_rank<N>(r, x, y, z);
                 if (cube_config<N>(M, s_nb, s_vox, x, y, z, sc, index)) {
-                    const int c = c_mc_counts[index];
+                    const int c = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu);
                     nv += c;
                     ng += (c != 0);  // IsOccupied (MarchingCubes.h:41-45)
                     cases[k] = c ? (unsigned char)index : 0;
@@ -452,7 +470,10 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
         }
     }
     int ov, og, tv, tg;
+    asm volatile("" ::"v"(nv));
+    MSTAMP(2);
     block_scan2<MESH_BLOCK>(nv, ng, ov, og, tv, tg, s_scan);
+    MSTAMP(3);
     if (threadIdx.x == 0) {
         const int tb = tv ? atomicAdd(&totals[0], tv / 3) : 0;
         const int gb = tg ? atomicAdd(&totals[1], tg) : 0;
@@ -469,6 +490,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     }
     if (tv == 0) continue;  // block-uniform
     __syncthreads();
+    MSTAMP(4);
     const int tb = s_base[0];
     if (tb + tv / 3 > tri_capacity || nv == 0) continue;
     int tpos = tb + ov / 3, gidx = og;
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
         const int index = cases[k];
         if (index == 0) continue;
         const int r = threadIdx.x * CPT + k;
-        const int nt = c_mc_counts[index] / 3;
+        const int nt = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu) / 3;
         for (int t = 0; t < nt; t++) {
             TriRec rec;
             rec.job = (unsigned)j;
@@ -488,6 +510,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
         tpos += nt;
         gidx++;
     }
+    MSTAMP(5);
     }
 }
 
