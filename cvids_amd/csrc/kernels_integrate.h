@@ -29,8 +29,8 @@
 //     arrives last.  Resident chunks need one atomic OR per wave that changed something.
 //   - per-voxel arithmetic follows the reference operation by operation in fp32 (compiled with -ffp-contract=off, IEEE
 //     divide), 3-term sums in Eigen's a0 + (a1 + a2) order.
-// Build parameters for experiments: INTEGRATE_WAVES / INTEGRATE_BLOCKS_PER_CU (occupancy), INTEGRATE_LPW (two
-// 64-quad groups per wave: slower), CHISEL_PHASES (in-kernel timers and utilisation counters), CHISEL_ABLATE_GATHER.
+// Build parameters for experiments: INTEGRATE_WAVES / INTEGRATE_BLOCKS_PER_CU (occupancy),
+// CHISEL_PHASES (in-kernel timers and utilisation counters), CHISEL_ABLATE_GATHER.
 #pragma once
 #include "chisel_device.h"
 
@@ -50,11 +50,6 @@ namespace chisel_hip {
 #ifndef INTEGRATE_FINE_BELOW
 #define INTEGRATE_FINE_BELOW 1280  // work items (16^3 chunks; scaled by voxels per chunk) below which a launch of >= 4 frames runs with 2 voxels per lane
 #endif
-#ifndef INTEGRATE_LPW
-#define INTEGRATE_LPW 1        // 64-quad groups ("layers") a wave carries through the batch, applied one after the other per frame
-#endif
-constexpr int LPW = INTEGRATE_LPW;
-static_assert(LPW == 1 || LPW == 2, "layers per wave");
 
 constexpr int QUEUE_STRIDE = 32;  // ints between two queue heads (one 128-byte line each)
 constexpr int QUEUE_HEADS = 128;  // power of two, multiple of 8 (a head's waves share an XCD)
@@ -66,8 +61,8 @@ struct Geom {
     static constexpr int QX = N / VPL;               // quads (a lane's VPL voxels) per x-row
     static constexpr int QUADS = V / VPL;
     static constexpr int LAYER_QUADS = QX * N;       // quads per z-layer
-    static constexpr int WPC = QUADS / (64 * LPW);   // wave units per chunk: 2 (8^3), 16 (16^3), 128 (32^3) at one layer per wave
-    static_assert(QUADS % (64 * LPW) == 0, "whole waves");
+    static constexpr int WPC = QUADS / 64;           // wave units per chunk at 4 voxels per lane: 2 (8^3), 16 (16^3), 128 (32^3)
+    static_assert(QUADS % 64 == 0, "whole waves");
     static constexpr int BLOCK = 256;
     static constexpr int GRID = 256 * INTEGRATE_BLOCKS_PER_CU;  // persistent grid: what is resident at once
     static constexpr int GRID_STEP = (2 * WPC > 32) ? 2 * WPC : 32;  // blocks: every XCD's share of the first round is whole chunks
@@ -245,18 +240,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
 
             // voxelCenter = centroids[i] + origin (ChunkManager.cpp:61: Vec3(x,y,z)*res + half; ProjectionIntegrator.h:63),
             // origin = numVoxels * ID (int) * resolution (Chunk.cpp:43)
-            const int q0 = wq * (64 * LPW) + lane;  // layer h of this wave: quads q0 + 64 h (same x; y / z as the chunk size has it)
-            float wx[VPL], wya[LPW], wza[LPW];
+            const int q = wq * 64 + lane;
+            float wx[VPL], wy, wz;
             {
                 const float ox = (float)(N * cxi) * ip.res, oy = (float)(N * cyi) * ip.res, oz = (float)(N * czi) * ip.res;
-                const int xq = q0 % G::QX;
-                static_assert(64 % G::QX == 0, "the layers of a wave share their x");
-#pragma unroll
-                for (int h = 0; h < LPW; h++) {
-                    const int y = ((q0 + 64 * h) / G::QX) % N, z = (q0 + 64 * h) / G::LAYER_QUADS;
-                    wya[h] = ((float)y * ip.res + ip.half_res) + oy;
-                    wza[h] = ((float)z * ip.res + ip.half_res) + oz;
-                }
+                const int xq = q % G::QX, y = (q / G::QX) % N, z = q / G::LAYER_QUADS;
+                wy = ((float)y * ip.res + ip.half_res) + oy;
+                wz = ((float)z * ip.res + ip.half_res) + oz;
 #pragma unroll
                 for (int j = 0; j < VPL; j++) wx[j] = ((float)(xq * VPL + j) * ip.res + ip.half_res) + ox;
             }
@@ -268,24 +258,20 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
             ph_wid = wid;
 #endif
             // default voxels: DistVoxel() DistVoxel.cpp:27-31, ColorVoxel() ColorVoxel.cpp:27-31
-            QuadF s4a[LPW], w4a[LPW];
-            QuadU c4a[LPW];
+            QuadF s4, w4;
+            QuadU c4;
 #pragma unroll
-            for (int h = 0; h < LPW; h++)
-#pragma unroll
-                for (int j = 0; j < VPL; j++) {
-                    s4a[h].v[j] = 99999.0f;
-                    w4a[h].v[j] = 0.0f;
-                    c4a[h].v[j] = 0u;
-                }
+            for (int j = 0; j < VPL; j++) {
+                s4.v[j] = 99999.0f;
+                w4.v[j] = 0.0f;
+                c4.v[j] = 0u;
+            }
             // per-lane flags, kept in one vector register (as lane masks they would cost eight scalar registers):
             // HAVE / HAVEC: sdf+weight / colour registers hold the chunk's values (a chunk without a slot has default voxels:
             // nothing to read); DCHG / CCHG: they differ from memory
             constexpr unsigned HAVE = 1u, HAVEC = 2u, DCHG = 4u, CCHG = 8u;
-            unsigned sta[LPW];
-#pragma unroll
-            for (int h = 0; h < LPW; h++) sta[h] = existed ? 0u : (HAVE | HAVEC);
-            const size_t vbase0 = (size_t)(existed ? slot : 0) * G::V + VPL * (size_t)q0;
+            unsigned st = existed ? 0u : (HAVE | HAVEC);
+            const size_t vbase = (size_t)(existed ? slot : 0) * G::V + VPL * (size_t)q;
             unsigned bm = 0u, cm = 0u;  // frames in which this wave integrated / changed a voxel (wave-uniform)
             int carve_v = 0;            // lane k: this wave's carve tests of frame k (items without a slot)
 
@@ -309,13 +295,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 if (k_next >= 0) fb = fbp[k_next];
                 const FrameCam &F = P.f[k];
                 const CameraParams &C = F.cam;
-#pragma unroll
-                for (int h = 0; h < LPW; h++) {  // (indentation kept: the body is one layer's frame)
-                QuadF &s4 = s4a[h], &w4 = w4a[h];
-                QuadU &c4 = c4a[h];
-                unsigned &st = sta[h];
-                const size_t vbase = vbase0 + (size_t)(64 * VPL) * h;
-                const float wy = wya[h], wz = wza[h];
                 // inCamera = R^T * (voxelCenter - t) (ProjectionIntegrator.h:64), row i of R^T summed as a0 + (a1 + a2)
                 const float dy = wy - C.t[1], dz = wz - C.t[2];
                 const float s2 = C.R[5] * dy + C.R[8] * dz;
@@ -515,7 +494,6 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
 #ifdef CHISEL_PHASES
                 if (__any(need)) { FSTAMP(4, f4(s4, 0)); ph_exec++; ph_exec_t += __builtin_amdgcn_s_memrealtime() - fr_t; }
 #endif
-                }  // layer h
                 if (k_next < 0) break;
                 k = k_next;
             }
@@ -556,14 +534,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 PHASE(2);
                 if (slot < 0) break;  // never integrated here, or no slot left (error raised)
             }
-#pragma unroll
-            for (int h = 0; h < LPW; h++) {
-                const size_t v = (size_t)slot * G::V + VPL * (size_t)(q0 + 64 * h);
-                if (sta[h] & DCHG) {
-                    *reinterpret_cast<QuadF *>(M.sdf + v) = s4a[h];
-                    *reinterpret_cast<QuadF *>(M.wgt + v) = w4a[h];
+            {
+                const size_t v = (size_t)slot * G::V + VPL * (size_t)q;
+                if (st & DCHG) {
+                    *reinterpret_cast<QuadF *>(M.sdf + v) = s4;
+                    *reinterpret_cast<QuadF *>(M.wgt + v) = w4;
                 }
-                if (COLOR && (sta[h] & CCHG)) *reinterpret_cast<QuadU *>(M.rgbw + v) = c4a[h];
+                if (COLOR && (st & CCHG)) *reinterpret_cast<QuadU *>(M.rgbw + v) = c4;
             }
             if (cm) {
                 // "needsUpdate" of the chunk per frame (Chisel.h:85 / :167): each frame counts once per chunk -- by the wave
