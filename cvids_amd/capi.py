@@ -59,7 +59,7 @@ EXPORTS = [
     "chisel_hip_meshes_to_update", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
     "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
-    "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color",
+    "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
     "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
 ]
@@ -139,6 +139,7 @@ def load_library():
     L.chisel_hip_drop_ghost_chunks.argtypes = [vp]
     L.chisel_hip_condition_depth.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), vp]
     L.chisel_hip_condition_color.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.chisel_hip_publish_cloud.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
     L.chisel_hip_update_meshes_of.argtypes = [vp, i32p, C.c_int]
     L.chisel_hip_depth_filter_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.chisel_hip_depth_filter_destroy.argtypes = [vp]

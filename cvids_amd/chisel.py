@@ -506,6 +506,19 @@ def condition_color(image, width=640, height=480):
     return dst
 
 
+def publish_cloud(depth64, color):
+    """CollaborativeServer::SendPointCloud (chisel_hip_publish_cloud): float64 depth (H, W) + uint8 colour image (H, W[, C]) ->
+    the PointCloud2 data array as uint32 (H, W, 4): x, y, z float bits and the packed grey rgb"""
+    L = capi.load_library()
+    d = np.ascontiguousarray(depth64, np.float64)
+    c = np.ascontiguousarray(color, np.uint8)
+    h, w = d.shape
+    step = c.size // h
+    out = np.empty((h, w, 4), np.uint32)
+    check(L.chisel_hip_publish_cloud(d.ctypes.data, c.ctypes.data, w, h, step, 0, out.ctypes.data, 0, None))
+    return out
+
+
 def chunk_owner(cid, n_shards, shard_block=2):
     c = (C.c_int * 3)(*[int(v) for v in cid])
     return capi.load_library().chisel_hip_chunk_owner(c, int(n_shards), int(shard_block))

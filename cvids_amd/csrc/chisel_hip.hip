@@ -1180,6 +1180,41 @@ int chisel_hip_condition_color(const uint8_t *src, int w0, int h0, int channels,
     return CHISEL_HIP_OK;
 }
 
+int chisel_hip_publish_cloud(const double *depth, const uint8_t *color, int w, int h, int color_step, int src_on_device, void *points,
+                             int dst_on_device, void *hip_stream) {
+    if (!depth || !color || !points || w <= 0 || h <= 0 || color_step < w) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t npx = (size_t)w * h, cbytes = (size_t)color_step * h;
+    double *d_depth = nullptr;
+    uint8_t *d_color = nullptr;
+    uint4 *d_pts = nullptr;
+    const double *in_d = depth;
+    const uint8_t *in_c = color;
+    uint4 *out = static_cast<uint4 *>(points);
+    if (!src_on_device) {
+        HIP_TRY(hipMalloc(&d_depth, npx * sizeof(double)));
+        HIP_TRY(hipMalloc(&d_color, cbytes));
+        HIP_TRY(hipMemcpyAsync(d_depth, depth, npx * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_color, color, cbytes, hipMemcpyHostToDevice, st));
+        in_d = d_depth;
+        in_c = d_color;
+    }
+    if (!dst_on_device) {
+        HIP_TRY(hipMalloc(&d_pts, npx * sizeof(uint4)));
+        out = d_pts;
+    }
+    hipLaunchKernelGGL(publish_cloud_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, in_d, in_c, w, h, color_step, out);
+    HIP_TRY(hipGetLastError());
+    if (!dst_on_device) HIP_TRY(hipMemcpyAsync(points, d_pts, npx * sizeof(uint4), hipMemcpyDeviceToHost, st));
+    if (!src_on_device || !dst_on_device) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (d_depth) (void)hipFree(d_depth);
+        if (d_color) (void)hipFree(d_color);
+        if (d_pts) (void)hipFree(d_pts);
+    }
+    return CHISEL_HIP_OK;
+}
+
 // ---- DepthFilter (depth_filter.cpp) ----------------------------------------------------------------------------------------
 struct chisel_hip_depth_filter {
     int device = 0;

@@ -348,6 +348,28 @@ __global__ void condition_color_kernel(const uint8_t *__restrict__ src, int w0, 
     dst[(size_t)y * w * cn + xc] = out;
 }
 
+// CollaborativeServer::SendPointCloud (collaborative_server_system.cpp:318-381): the organised "point cloud" PublishDenseInfo sends
+// beside the images -- one 16-byte point per pixel: x = column, y = row (pixel coordinates, as floats), z = depth narrowed to float,
+// rgb = the grey byte at (row, column) of the colour image replicated into 0x00gggggg; all four words NaN unless 0.1 < depth < 10.
+// The colour byte is mColorImage.at<uint8_t>(u, v): byte v of row u whatever the channel count (color_step = bytes per row).
+__global__ void publish_cloud_kernel(const double *__restrict__ depth, const uint8_t *__restrict__ color, int w, int h, int color_step,
+                                     uint4 *__restrict__ points) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+    if (v >= w || u >= h) return;
+    const float dep = (float)depth[(size_t)u * w + v];
+    uint4 p;
+    if (dep < 10.0f && dep > 0.1f) {
+        const unsigned g = color[(size_t)u * color_step + v];
+        p.x = __float_as_uint((float)v);
+        p.y = __float_as_uint((float)u);
+        p.z = __float_as_uint(dep);
+        p.w = (g << 16) | (g << 8) | g;
+    } else {
+        p.x = p.y = p.z = p.w = 0x7fc00000u;  // std::numeric_limits<float>::quiet_NaN()
+    }
+    points[(size_t)u * w + v] = p;
+}
+
 // ---- known-answer kernels: the device arithmetic against the reference-built golden vectors ----------
 __global__ void kat_truncation_kernel(int kind, float param, const float *depths, int n, float *trunc, float *weight1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -248,6 +248,13 @@ int chisel_hip_condition_depth(const double *src, int w0, int h0, int src_on_dev
                                double intrinsics_fx_fy_cx_cy[4], void *hip_stream);
 int chisel_hip_condition_color(const uint8_t *src, int w0, int h0, int channels, int src_on_device, uint8_t *dst, int w, int h,
                                int dst_on_device, void *hip_stream);
+/* CollaborativeServer::SendPointCloud (collaborative_server_system.cpp:318-381), the third thing PublishDenseInfo sends (:249): the
+ * data array of its organised sensor_msgs::PointCloud2 -- w * h points of 16 bytes {float x = column, float y = row, float z =
+ * (float)depth, int32 rgb = grey byte replicated}, all four words NaN unless 0.1 < z < 10.  depth: w x h doubles (the resized
+ * map); color: the resized colour image, color_step bytes per row; the grey byte is the one at byte offset `column` of the row,
+ * as mColorImage.at<uint8_t>(u, v) reads it whatever the channel count.  Both inputs on the host or both (flag) in HBM. */
+int chisel_hip_publish_cloud(const double *depth, const uint8_t *color, int w, int h, int color_step, int src_on_device, void *points,
+                             int dst_on_device, void *hip_stream);
 
 /* ---- the step before that: the inverse-depth filter ----------------------------------------------
  * DepthFilter (server_pose_graph/src/dense_mapping/depth_filter.cpp): per-pixel Gaussian x uniform mixture filter of the

@@ -1,7 +1,8 @@
 """CPU restatement (numpy) of CollaborativeServer::PublishDenseInfo's image conditioning -- TEST INFRASTRUCTURE ONLY.
 
 Follows server_pose_graph/src/collaborative_server_system.cpp:199-276: cv::resize of the CV_64F depth map and of the 8-bit colour
-image to the publish size (:213-214), convertTo(CV_32FC1) (:255), NaN outside [0.1, 20] (:262-265), intrinsics rescale (:216-219).
+image to the publish size (:213-214), convertTo(CV_32FC1) (:255), NaN outside [0.1, 20] (:262-265), intrinsics rescale (:216-219),
+and SendPointCloud (:318-381, called at :249): the data array of the organised PointCloud2 sent beside the images.
 
 cv::resize is a third-party dependency that is absent from /root/reference (OpenCV, found by the reference's CMakeLists through
 find_package(OpenCV); any 3.x / 4.x build without IPP); its published algorithm (modules/imgproc/src/resize.cpp) restated:
@@ -100,6 +101,28 @@ def condition_depth(src, w, h):
 
 def condition_color(src, w, h):
     return resize_u8(src, w, h)
+
+
+def publish_cloud(depth, color):
+    """CollaborativeServer::SendPointCloud (collaborative_server_system.cpp:318-381): the PointCloud2 data array as uint32
+    (H, W, 4): x = column, y = row, z = (float)depth as float bits, rgb = the grey byte at byte offset `column` of the colour image's
+    row (mColorImage.at<uint8_t>(u, v) whatever the channel count) replicated; NaN bits in all four unless 0.1 < z < 10"""
+    d = np.asarray(depth, np.float64)
+    c = np.ascontiguousarray(color, np.uint8)
+    h, w = d.shape
+    rows = c.reshape(h, -1)
+    with np.errstate(invalid="ignore", over="ignore"):
+        dep = d.astype(np.float32)
+        ok = (dep < np.float32(10.0)) & (dep > np.float32(0.1))
+    g = rows[:, :w].astype(np.uint32)
+    out = np.full((h, w, 4), 0x7fc00000, np.uint32)
+    xs = np.broadcast_to(np.arange(w, dtype=np.float32)[None, :], (h, w)).copy().view(np.uint32)
+    ys = np.broadcast_to(np.arange(h, dtype=np.float32)[:, None], (h, w)).copy().view(np.uint32)
+    out[..., 0][ok] = xs[ok]
+    out[..., 1][ok] = ys[ok]
+    out[..., 2][ok] = dep.view(np.uint32)[ok]
+    out[..., 3][ok] = ((g << 16) | (g << 8) | g)[ok]
+    return out
 
 
 def rescale_intrinsics(fx, fy, cx, cy, w0, h0, w, h):

@@ -686,6 +686,24 @@ def test_color_conditioning(shape, cn):
     assert np.array_equal(want, got)
 
 
+@pytest.mark.parametrize("cn", [0, 3])
+def test_publish_cloud(cn):
+    """chisel_hip_publish_cloud == the restated SendPointCloud (oracle/publish_dense.py), word for word: range mask, pixel
+    coordinates as floats, the grey byte taken at byte offset `column` of the row for 1- and 3-channel images"""
+    from cvids_amd.chisel import publish_cloud
+    from oracle import publish_dense as pd
+    rng = np.random.default_rng(5 + cn)
+    h, w = 480, 640
+    depth = rng.uniform(0.0, 12.0, (h, w))
+    depth[rng.random((h, w)) < 0.02] = np.nan
+    depth[0, 0], depth[0, 1], depth[0, 2] = 0.1, 10.0, 0.5  # float(0.1) > 0.1f is false, 10.0 < 10.0f is false
+    color = rng.integers(0, 256, (h, w) if cn == 0 else (h, w, cn), dtype=np.uint8)
+    want = pd.publish_cloud(depth, color)
+    got = publish_cloud(depth, color)
+    assert np.array_equal(want, got)
+    assert (got[0, 0] == 0x7fc00000).all() and (got[0, 1] == 0x7fc00000).all() and got[0, 2, 2] == np.float32(0.5).view(np.uint32)
+
+
 def test_rccl_exchange_world_size_one():
     """the N > 1 bench's frame exchange over backend "nccl" (= RCCL) on its own stream with event ordering, run with one
     rank on this GPU in a child process (tools/nccl_world1_check.py): same map as direct integration"""

@@ -66,3 +66,17 @@ def test_conditioning_masks_out_of_range():
     d = np.array([[0.05, 0.1, 20.0, 20.5, np.nan, np.inf, -1.0]])
     out = pd.condition_depth(d, 7, 1)
     assert np.isnan(out[0, [0, 3, 4, 5, 6]]).all() and out[0, 1] == np.float32(0.1) and out[0, 2] == np.float32(20.0)
+
+
+def test_publish_cloud_by_hand():
+    """SendPointCloud (collaborative_server_system.cpp:318-381): 2 x 3 map, BGR image: the grey byte of pixel (u, v) is byte v of row u"""
+    depth = np.array([[0.5, 0.05, 9.99], [10.0, np.nan, 2.0]])
+    color = np.arange(18, dtype=np.uint8).reshape(2, 3, 3) + 10  # row 0 bytes 10..18, row 1 bytes 19..27
+    out = pd.publish_cloud(depth, color)
+    f = lambda x: int(np.float32(x).view(np.uint32))
+    nan = 0x7fc00000
+    assert out[0, 0].tolist() == [f(0.0), f(0.0), f(0.5), (10 << 16) | (10 << 8) | 10]
+    assert out[0, 1].tolist() == [nan] * 4
+    assert out[0, 2].tolist() == [f(2.0), f(0.0), f(9.99), (12 << 16) | (12 << 8) | 12]
+    assert out[1, 0].tolist() == [nan] * 4 and out[1, 1].tolist() == [nan] * 4
+    assert out[1, 2].tolist() == [f(2.0), f(1.0), f(2.0), (21 << 16) | (21 << 8) | 21]
