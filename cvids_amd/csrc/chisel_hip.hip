@@ -169,7 +169,7 @@ struct chisel_hip_map {
         int n = 0;                                                     // jobs
         int arena = -1;
     } pending_meshes;
-    int *mesh_totals_host = nullptr;                                   // pinned: [0-3] totals, [4] error flag, [5] sequence number of the recompute in flight (written by the device), [7] check_device_error
+    int *mesh_totals_host = nullptr;                                   // pinned: [0-3] totals of the recompute in flight and its sequence number (one 16-byte store of the device), [6] sequence number of the job records, [7] check_device_error
     int *mesh_totals_dev = nullptr;                                    // the same memory as the device addresses it
     int *error_flag_host = nullptr;                                    // pinned: the map's error flag (view.error_flag is its device address)
     int *mesh_info_dev = nullptr;                                      // mesh_info_host as the device addresses it

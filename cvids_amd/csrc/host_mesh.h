@@ -183,8 +183,8 @@ int recompute_meshes(chisel_hip_map *m) {
     // map (check_mesh_totals polls the sequence number): until then the host is free to queue the next batch's front half, and
     // by then the triangle kernel is usually still running, so the next integration queues up behind it without a gap
     m->mesh_seq++;
-    hipLaunchKernelGGL(publish_totals_kernel, dim3(1), dim3(64), 0, m->stream, (const int *)d_totals, (const int *)m->view.error_flag,
-                       (volatile int *)m->mesh_totals_dev, m->mesh_seq);
+    hipLaunchKernelGGL(publish_totals_kernel, dim3(1), dim3(64), 0, m->stream, (const int *)d_totals, reinterpret_cast<uint4 *>(m->mesh_totals_dev),
+                       m->mesh_seq);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
         launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity);
@@ -220,23 +220,25 @@ int check_mesh_totals(chisel_hip_map *m) {
     const MeshParams P = mesh_params(m);
     int arena_id = m->pending_meshes.arena;
     {
-        // the device writes the sequence number last (publish_totals_kernel)
+        // the device writes totals and sequence number as one 16-byte store (publish_totals_kernel): word 3 is the sequence number
         volatile int *host = m->mesh_totals_host;
         const auto t0 = std::chrono::steady_clock::now();
-        while (host[5] != m->mesh_seq) {
+        while (host[3] != m->mesh_seq) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
                 HIP_TRY(hipStreamSynchronize(m->stream));  // long queue in front of the recompute, or a failed launch: no more polling
-                if (host[5] != m->mesh_seq) return fail(CHISEL_HIP_ERR_HIP, "mesh totals were not published");
+                if (host[3] != m->mesh_seq) return fail(CHISEL_HIP_ERR_HIP, "mesh totals were not published");
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
-    int totals[4] = {m->mesh_totals_host[0], m->mesh_totals_host[1], m->mesh_totals_host[2], m->mesh_totals_host[3]};
+    const unsigned packed_jobs = (unsigned)m->mesh_totals_host[2];
+    int totals[4] = {m->mesh_totals_host[0], m->mesh_totals_host[1], (int)(packed_jobs >> 31), (int)(packed_jobs & 0x7fffffffu)};
     // A chunk of an earlier batch could not be allocated (word [0] of the map's error flags: pool / hash; cloud reports live in
     // word [1] and are none of this function's business): the map is incomplete.  The recompute is finished all the same -- its
     // mark / collect kernels have already consumed the dirty flags, abandoning it would leave those chunks without a mesh for
     // good -- and the failure is reported afterwards.
-    const int pool_error = m->mesh_totals_host[4];
+    // (read from the flag itself: every kernel that could have raised it finished before the count kernel started)
+    const int pool_error = reinterpret_cast<volatile int *>(m->error_flag_host)[0];
     bool redo = false;
     if (totals[MT_OVERFLOW]) {
         // the triangle list was too small: grow it to what this batch needs and list again (dirty flags are not read by the count)
