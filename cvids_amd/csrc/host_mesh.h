@@ -58,7 +58,8 @@ int *mesh_totals(chisel_hip_map *m) { return m->mesh_buf.totals; }
 
 // ids of the resident chunks to mesh, built on the device: the 27-neighbourhoods of the dirty slots, de-duplicated
 // through one flag per slot, plus `extra` host-side ids (neighbourhoods of chunks that were removed while dirty).
-// The number of ids stays on the device (mesh_totals()[MT_JOBS]); nothing here waits for the stream unless `extra` is used.
+// The number of ids stays on the device (one of two alternating counters behind the totals, copied to mesh_totals()[MT_JOBS] by
+// the count kernel); nothing here waits for the stream unless `extra` is used.
 int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
     MeshBuffers &B = m->mesh_buf;
     const int C = m->view.max_chunks;
@@ -69,19 +70,24 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
         HIP_TRY(hipMemsetAsync(B.flags, 0, (size_t)C * sizeof(unsigned), m->stream));
     }
     const long long threads = (long long)C * 27;  // (the mark kernel also zeroes the totals)
-    hipLaunchKernelGGL(mesh_mark_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, m->view, B.flags, mesh_totals(m));
+    int *n_jobs = mesh_totals(m) + 4 + (B.mark_turn & 1), *n_jobs_next = mesh_totals(m) + 4 + ((B.mark_turn + 1) & 1);
+    B.mark_turn++;
+    B.n_jobs = n_jobs;
+    hipLaunchKernelGGL(mesh_mark_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, m->view, B.flags, mesh_totals(m), B.ids,
+                       n_jobs, n_jobs_next);
     if (!extra.empty()) {
-        // (rare) ids kept on the host: flag the ones that are resident
+        // (rare) ids kept on the host: the ones that are resident join the job list
         const int ne = (int)(extra.size() / 3);
         std::vector<int> slots;
         rc = lookup_slots(m, extra.data(), ne, slots);
         if (rc) return rc;
-        std::vector<unsigned> one(1, 1u);
-        for (int i = 0; i < ne; i++)
-            if (slots[i] >= 0) HIP_TRY(hipMemcpyAsync(B.flags + slots[i], one.data(), sizeof(unsigned), hipMemcpyHostToDevice, m->stream));
+        int *d_slots = nullptr;
+        HIP_TRY(hipMalloc(&d_slots, (size_t)ne * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), (size_t)ne * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        hipLaunchKernelGGL(mesh_append_kernel, dim3((ne + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, (const int *)d_slots, ne, B.ids, n_jobs);
         HIP_TRY(hipStreamSynchronize(m->stream));
+        HIP_TRY(hipFree(d_slots));
     }
-    hipLaunchKernelGGL(mesh_collect_kernel, dim3((C + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, B.ids, mesh_totals(m) + MT_JOBS);
     HIP_TRY(hipGetLastError());
     return CHISEL_HIP_OK;
 }
@@ -141,12 +147,13 @@ void release_arena_pool(chisel_hip_map *m) {
 void launch_mesh_count(chisel_hip_map *m) {
     MeshBuffers &B = m->mesh_buf;
     int *d_totals = mesh_totals(m);
+    int *n_jobs = B.n_jobs ? B.n_jobs : d_totals + MT_JOBS;  // the mark kernel's counter, or the count a caller put into the totals
     ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
     const dim3 grid(2048);
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.info, d_totals, B.tris, B.tri_capacity); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.info, d_totals, B.tris, B.tri_capacity); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, d_totals + MT_JOBS, B.info, d_totals, B.tris, B.tri_capacity); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.tri_capacity, B.flags); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.tri_capacity, B.flags); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.tri_capacity, B.flags); break;
     }
 }
 
@@ -469,6 +476,7 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
     rc = ensure_mesh_jobs(m, std::max(n, m->view.max_chunks));
     if (rc) return rc;
     const int totals[4] = {0, 0, 0, n};
+    B.n_jobs = nullptr;  // the count is the one written here
     HIP_TRY(hipMemcpyAsync(mesh_totals(m), totals, sizeof(totals), hipMemcpyHostToDevice, m->stream));
     if (n) HIP_TRY(hipMemcpyAsync(B.ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);

@@ -235,50 +235,40 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
 }
 
 // meshesToUpdate on the device (Chisel.h:175-189 marks the 27-neighbourhood of every updated chunk): one thread per
-// (slot, neighbour offset); a resident neighbour of a dirty chunk gets its mesh flag set.  Ids of the neighbourhood
-// that are not resident have no chunk to mesh (RecomputeMesh returns at once: ChunkManager.cpp:93-96).
-__global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag, int *totals) {
+// (slot, neighbour offset); a resident neighbour of a dirty chunk becomes a job -- the thread whose exchange sets the
+// neighbour's flag first appends its id to the job list (no compaction kernel behind this one: every launch on the map's
+// stream costs >= 5 us there).  Ids of the neighbourhood that are not resident have no chunk to mesh (RecomputeMesh returns
+// at once: ChunkManager.cpp:93-96).  The job counter `n_jobs` was zeroed by the previous recompute's launch of this kernel,
+// which zeroes `n_jobs_next` for the next one (two counters alternate: zeroing the one in use here would race with the
+// appends); flags and dirty bits are reset by the count kernel, job by job (every dirty slot is a job: offset 13 is itself).
+__device__ inline void mesh_append_job(const MapView &M, unsigned *mesh_flag, int slot, int *ids, int *n_jobs) {
+    if (atomicExch(&mesh_flag[slot], 1u) != 0u) return;
+    const uint64_t key = M.slot_key[slot];
+    if (key == KEY_EMPTY) return;
+    const int pos = atomicAdd(n_jobs, 1);
+    int x, y, z;
+    unpack_id(key, x, y, z);
+    ids[3 * pos] = x;
+    ids[3 * pos + 1] = y;
+    ids[3 * pos + 2] = z;
+}
+__global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag, int *totals, int *ids, int *n_jobs, int *n_jobs_next) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 4) totals[t] = 0;  // the recompute's counters, filled from mesh_collect_kernel on (the next launch): no memset of their own
+    if (t < 3) totals[t] = 0;  // triangles, grids, overflow: the count kernel's (the next launch's) counters
+    if (t == 3) *n_jobs_next = 0;
     const int slot = t / 27, o = t % 27;
     if (slot >= M.max_chunks || !M.slot_dirty[slot]) return;
     const uint64_t key = M.slot_key[slot];
     if (key == KEY_EMPTY) return;
     int x, y, z;
     unpack_id(key, x, y, z);
-    const int ns = (o == 13) ? slot : hash_find(M, x + o % 3 - 1, y + (o / 3) % 3 - 1, z + o / 9 - 1);
-    if (ns >= 0) mesh_flag[ns] = 1u;
+    const int ns = (o == 13) ? slot : hash_find_quiescent(M, x + o % 3 - 1, y + (o / 3) % 3 - 1, z + o / 9 - 1);
+    if (ns >= 0) mesh_append_job(M, mesh_flag, ns, ids, n_jobs);
 }
-
-// compaction of the flagged slots into the id list of the jobs (ballot + prefix popcount); clears the flags
-__global__ void mesh_collect_kernel(MapView M, unsigned *mesh_flag, int *ids, int *count) {
+// (rare) resident chunks the host wants meshed as well: neighbourhoods of chunks that were removed while dirty
+__global__ void mesh_append_kernel(MapView M, unsigned *mesh_flag, const int *slots, int n, int *ids, int *n_jobs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool keep = false;
-    uint64_t key = KEY_EMPTY;
-    if (i < M.max_chunks) {
-        M.slot_dirty[i] = 0;  // meshesToUpdate.clear() (Chisel.cpp:57): mesh_mark_kernel, the flag's reader, has finished
-        keep = mesh_flag[i] != 0u;
-        if (keep) {
-            mesh_flag[i] = 0u;
-            key = M.slot_key[i];
-            keep = key != KEY_EMPTY;
-        }
-    }
-    const unsigned long long mask = __ballot(keep);
-    if (!mask) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = (int)__builtin_ctzll(mask);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(count, __popcll(mask));
-    base = __shfl(base, leader);
-    if (keep) {
-        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-        int x, y, z;
-        unpack_id(key, x, y, z);
-        ids[3 * pos] = x;
-        ids[3 * pos + 1] = y;
-        ids[3 * pos + 2] = z;
-    }
+    if (i < n && slots[i] >= 0) mesh_append_job(M, mesh_flag, slots[i], ids, n_jobs);
 }
 
 constexpr int MESH_BLOCK_THREADS = 512;  // per-chunk kernel: 8 cubes (16^3) per thread (256: 33 us, 512: 24 us, 1024: 35 us per recompute)
@@ -410,7 +400,7 @@ __device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per s
 #endif
 template <int N>
 __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
-                                                                 JobInfo *info, int *totals, TriRec *tris, int tri_capacity) {
+                                                                 JobInfo *info, int *totals, TriRec *tris, int tri_capacity, unsigned *mesh_flag) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nb[27];
     __shared__ int s_base[2];
@@ -421,6 +411,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     // grid has workgroups -- whatever the count; ensure_mesh_jobs)
     int jx0 = ids[3 * blockIdx.x], jy0 = ids[3 * blockIdx.x + 1], jz0 = ids[3 * blockIdx.x + 2];
     const int n = *n_jobs;  // the job count stays on the device: the grid is persistent
+    if (blockIdx.x == 0 && threadIdx.x == 0) totals[3] = n;  // where the kernels behind this one (and a second emission) read it
     if (threadIdx.x < 64) s_counts[threadIdx.x] = reinterpret_cast<const unsigned *>(c_mc_counts)[threadIdx.x];  // (first barrier below)
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
 #ifdef CHISEL_PHASES
@@ -445,6 +436,11 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
     }
     __syncthreads();
     const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
+    if (threadIdx.x == 28 && present) {
+        // meshesToUpdate.clear() (Chisel.cpp:57) and the job flag of mesh_mark_kernel, which has finished: this job's own
+        if (mesh_flag) mesh_flag[s_nb[NB_SELF]] = 0u;
+        M.slot_dirty[s_nb[NB_SELF]] = 0u;
+    }
     MSTAMP(0);
     if (present) stage_corners<N>(M, s_nb, s_vox);
     MSTAMP(1);
@@ -643,7 +639,9 @@ struct MeshBuffers {
     MeshJob *jobs = nullptr;
     int *ids = nullptr;
     JobInfo *info = nullptr; // [capacity] per-job results of a recompute
-    int *totals = nullptr;   // [8]: triangles, grids, triangle-list overflow flag, jobs
+    int *totals = nullptr;   // [8]: triangles, grids, triangle-list overflow flag, jobs; [4], [5]: the mark kernel's alternating job counters
+    int *n_jobs = nullptr;   // where the count kernel finds the number of jobs (one of the two counters, or null: totals[3])
+    unsigned mark_turn = 0;  // which of the two counters the next mark kernel fills
     TriRec *tris = nullptr;  // triangle list of one recompute
     int tri_capacity = 0;
     int capacity = 0;        // jobs
