@@ -834,7 +834,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipHostGetDevicePointer((void **)&m->mesh_totals_dev, m->mesh_totals_host, 0));
     HIP_TRY_C(hipHostMalloc((void **)&m->mesh_info_host, (size_t)MESH_INFO_PREFETCH * sizeof(JobInfo), hipHostMallocDefault));
     HIP_TRY_C(hipHostGetDevicePointer((void **)&m->mesh_info_dev, m->mesh_info_host, 0));
-    static_assert(sizeof(JobInfo) == 8 * sizeof(int), "publish_totals_kernel moves the records as ints");
+    static_assert(sizeof(JobInfo) == 8 * sizeof(int), "the triangle kernel moves the records to the host as ints");
     HIP_TRY_C(hipEventCreateWithFlags(&m->call_event, hipEventDisableTiming));
     for (auto &bs : m->sets) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));

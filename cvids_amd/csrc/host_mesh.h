@@ -16,7 +16,7 @@ MeshParams mesh_params(const chisel_hip_map *m) {
     return P;
 }
 
-void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena, size_t arena_floats) {
+void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena, size_t arena_floats, int publish = 0) {
     MeshBuffers &B = m->mesh_buf;
     const JobInfo *bases = B.info;
     const int *totals = B.totals;
@@ -25,9 +25,9 @@ void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena,
     const int max_jobs = std::min(MESH_INFO_PREFETCH, B.capacity), seq = m->mesh_seq;
     const dim3 grid(4096), block(MESH_TRI_BLOCK);  // persistent: the number of triangles is read on the device
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq); break;
-        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq); break;
-        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq); break;
+        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
     }
 }
 
@@ -159,7 +159,7 @@ void launch_mesh_count(chisel_hip_map *m) {
 
 // meshes of the chunks whose ids sit in mesh_buf.ids (device; their number too).  Everything is queued at once -- job
 // table, count kernel, triangle kernel into an arena sized from the previous recompute, dirty-flag reset -- and the host
-// then finds the totals in pinned memory, written by publish_totals_kernel behind the count kernel: the device never waits for
+// then finds the totals in pinned memory, written by the triangle kernel's first thread: the device never waits for
 // the host and nothing but kernels sits on the map's stream.  Only a batch
 // that outgrew the triangle list or the arena is emitted again after a full wait (the map has not changed meanwhile:
 // nothing else was queued).
@@ -186,15 +186,13 @@ int recompute_meshes(chisel_hip_map *m) {
         if (rc_a) return rc_a;
     }
     launch_mesh_count(m);
-    // the totals go straight into pinned memory behind the count kernel; they are looked at when the caller next touches the
-    // map (check_mesh_totals polls the sequence number): until then the host is free to queue the next batch's front half, and
-    // by then the triangle kernel is usually still running, so the next integration queues up behind it without a gap
+    // the totals go straight into pinned memory from the first thread of the triangle kernel; they are looked at when the caller
+    // next touches the map (check_mesh_totals polls the sequence number): until then the host is free to queue the next batch's
+    // front half, and by then the triangle kernel is usually still running, so the next integration queues up behind it without a gap
     m->mesh_seq++;
-    hipLaunchKernelGGL(publish_totals_kernel, dim3(1), dim3(64), 0, m->stream, (const int *)d_totals, reinterpret_cast<uint4 *>(m->mesh_totals_dev),
-                       m->mesh_seq);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
-        launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity);
+        launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity, 1);
     }
     HIP_TRY(hipGetLastError());
     m->pending_meshes.unchecked = true;
@@ -227,7 +225,7 @@ int check_mesh_totals(chisel_hip_map *m) {
     const MeshParams P = mesh_params(m);
     int arena_id = m->pending_meshes.arena;
     {
-        // the device writes totals and sequence number as one 16-byte store (publish_totals_kernel): word 3 is the sequence number
+        // the device writes totals and sequence number as one 16-byte store (mesh_triangle_kernel): word 3 is the sequence number
         volatile int *host = m->mesh_totals_host;
         const auto t0 = std::chrono::steady_clock::now();
         while (host[3] != m->mesh_seq) {

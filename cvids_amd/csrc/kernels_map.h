@@ -406,22 +406,6 @@ __global__ void kat_color_kernel(const uint8_t *ops, int n, uint8_t *out) {
         out[4 * i + 3] = c.w;
     }
 }
-// The totals of a mesh recompute, written straight into pinned host memory behind the count kernel by one thread as ONE 16-byte
-// store -- {triangles, grids, jobs | overflow << 31, sequence number} -- which the host polls for this recompute's sequence number
-// (word 3): no copy engine, no event and no stream wait in between (an event record on the map's stream costs a barrier packet of
-// 7-12 us in front of the next kernel).  One store instead of five words, a system-scope fence and the sequence number: the kernel
-// sits between the count and the triangle kernel and took 6 us of bus round trips (it also fetched the map's error flag from host
-// memory, which the host reads itself now).
-__global__ void publish_totals_kernel(const int *__restrict__ totals, uint4 *host, int seq) {
-    if (blockIdx.x || threadIdx.x) return;
-    uint4 v;
-    v.x = (unsigned)totals[0];
-    v.y = (unsigned)totals[1];
-    v.z = (unsigned)totals[3] | (totals[2] ? 0x80000000u : 0u);
-    v.w = (unsigned)seq;
-    *host = v;
-}
-
 // exhaustive: color_integrate_fresh (division-free, packed) against color_integrate for every weight < 8, old and new channel
 // value (the three channels carry old, 255 - old and old ^ 0x5a; new likewise); counts the words that differ
 __global__ void kat_color_fresh_kernel(unsigned *mismatches) {

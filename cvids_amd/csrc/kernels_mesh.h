@@ -540,9 +540,21 @@ template <int N>
 __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
                                                                     const JobInfo *__restrict__ info, const TriRec *__restrict__ tris,
                                                                     const int *__restrict__ totals, float *arena, size_t arena_floats, int *host_info,
-                                                                    volatile int *host_flags, int max_jobs, int seq) {
+                                                                    volatile int *host_flags, int max_jobs, int seq, int publish) {
     const int n_tris = totals[0];
     const int n_jobs = totals[3];
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+        // The recompute's totals, straight into pinned host memory as ONE 16-byte store -- {triangles, grids, jobs | overflow << 31,
+        // sequence number} -- before anything else: the host polls word 3 for this recompute's sequence number when the caller next
+        // touches the map.  No copy engine, no event, no stream wait and no kernel of its own in between (an event record on the
+        // map's stream costs a barrier packet of 7-12 us in front of the next kernel, a one-thread kernel 5 us).
+        uint4 v;
+        v.x = (unsigned)n_tris;
+        v.y = (unsigned)totals[1];
+        v.z = (unsigned)n_jobs | (totals[2] ? 0x80000000u : 0u);
+        v.w = (unsigned)seq;
+        *reinterpret_cast<uint4 *>(const_cast<int *>(host_flags)) = v;
+    }
     const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[1] * 3;
     // a triangle list that overflowed (totals[2]) is incomplete: nothing is emitted, the host lists and emits again
     const bool fits = totals[2] == 0 && nv3 * (P.use_color ? 3 : 2) + ng3 <= arena_floats;
