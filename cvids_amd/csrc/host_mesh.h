@@ -98,7 +98,7 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
 void free_arena(chisel_hip_map *m, MeshArena &A) {
     if (A.dev) {
         m->arena_pool.emplace_back(A.dev, A.capacity);
-        if (m->arena_pool.size() > 8) {  // drop the smallest
+        if (m->arena_pool.size() > 32) {  // drop the smallest (take_arena_buffer accepts any buffer that is large enough)
             size_t k = 0;
             for (size_t i = 1; i < m->arena_pool.size(); i++)
                 if (m->arena_pool[i].second < m->arena_pool[k].second) k = i;
@@ -111,8 +111,9 @@ void free_arena(chisel_hip_map *m, MeshArena &A) {
 int take_arena_buffer(chisel_hip_map *m, size_t floats, float **dev, size_t *capacity) {
     long best = -1;
     for (size_t i = 0; i < m->arena_pool.size(); i++)
-        if (m->arena_pool[i].second >= floats && m->arena_pool[i].second <= 4 * floats + (1u << 20) &&
-            (best < 0 || m->arena_pool[i].second < m->arena_pool[(size_t)best].second))
+        // the tightest fit; no upper bound -- a pool of buffers that are all "too large" made every recompute allocate a new one and
+        // free_arena drop it again (the smallest), about 0.4 ms of hipMalloc / hipFree per recompute for the rest of the process
+        if (m->arena_pool[i].second >= floats && (best < 0 || m->arena_pool[i].second < m->arena_pool[(size_t)best].second))
             best = (long)i;
     if (best >= 0) {
         *dev = m->arena_pool[(size_t)best].first;
@@ -203,7 +204,7 @@ int recompute_meshes(chisel_hip_map *m) {
     {
         const size_t want = std::max<size_t>(2 * m->mesh_need_hint, (size_t)1 << 22);
         bool have = false;
-        for (const auto &b : m->arena_pool) have = have || (b.second >= want && b.second <= 4 * want + (1u << 20));
+        for (const auto &b : m->arena_pool) have = have || b.second >= want;
         if (!have) {
             float *spare = nullptr;
             const size_t cap = want + want / 4 + 1024;
