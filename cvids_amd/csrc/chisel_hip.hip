@@ -383,7 +383,11 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         chisel_hip_map::BatchSet *prev = (m->batch_seq || m->force_uncertain) ? &m->sets[(m->batch_seq + 1u) & 1u] : nullptr;
         const int *prev_overflow = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : (prev ? prev->cand_count + COUNT_OVERFLOW : nullptr);
         const dim3 rgrid((total + 255) / 256);
-        const bool direct = IP.n_frames == 1;  // one frame: nothing to order
+        // one frame: nothing to order; and a work-list that fits the chip in one go (<= 256 items by the count a recent launch
+        // reported: every unit starts at once, whatever its place in the list) is not worth a launch of its own either -- the
+        // shards of a multi-GPU map are in this regime, where the front half is what a rank's rate hangs on
+        const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
+        const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= 256);
         hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
                            prev ? prev->pending : nullptr, prev_overflow, bs.pending, direct ? bs.items : nullptr, bs.sync);
         if (!direct)
@@ -410,7 +414,8 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // The same figure picks the granularity: 2 voxels per lane for launches of several frames below INTEGRATE_FINE_BELOW items
         // (about three rounds of the chip at 4 voxels per lane), 4 otherwise (kernels_integrate.h).
         const long long hint = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[2];
-        int vpl = (IP.n_frames >= 4 && hint > 0 && hint * (long long)(N * N * N) < (long long)INTEGRATE_FINE_BELOW * 4096) ? 2 : 4;
+        const long long pairs = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[3];  // (item, frame) pairs of that launch, 0 = unknown
+        int vpl = (IP.n_frames >= 4 && hint > 0 && hint * (long long)(N * N * N) < (long long)INTEGRATE_FINE_BELOW * 4096 && (pairs == 0 || pairs >= 6 * hint)) ? 2 : 4;
         if (const char *e = getenv("CHISEL_HIP_VPL")) vpl = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : vpl);
         const int wpc = vpl == 2 ? Geom<N, 2>::WPC : Geom<N, 4>::WPC;
         const int step = vpl == 2 ? Geom<N, 2>::GRID_STEP : Geom<N, 4>::GRID_STEP;

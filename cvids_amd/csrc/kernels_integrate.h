@@ -33,6 +33,7 @@
 // CHISEL_PHASES (in-kernel timers and utilisation counters), CHISEL_ABLATE_GATHER.
 #pragma once
 #include "chisel_device.h"
+#include "kernels_cull.h"  // COUNT_* (the batch counters the work-list builders leave behind)
 
 namespace chisel_hip {
 
@@ -46,7 +47,8 @@ namespace chisel_hip {
 // arithmetic per voxel: the quad's y / z terms are shared), 2 for small launches (twice as many units of half the length: what
 // such a launch takes is the length of its longest chains, not its arithmetic).  The host picks per launch: measured at 640x480 /
 // 1 cm, 10 frames per launch, 2 voxels per lane win by 10 % at 540 work items (61 against 68 us) and by 3 % at 1 240, lose 17 % at
-// 1 500+ items (318 against 272 us) and 20 % on one-frame launches (nothing to shorten: 21 against 17 us).
+// 1 500+ items (318 against 272 us) and 20 % on one-frame launches (nothing to shorten: 21 against 17 us); and 9 % on a 16-frame
+// launch of the 4-agent stream, where a chunk is seen by 4-5 of the frames: the choice also asks for >= 6 frames per item on average.
 #ifndef INTEGRATE_FINE_BELOW
 #define INTEGRATE_FINE_BELOW 1280  // work items (16^3 chunks; scaled by voxels per chunk) below which a launch of >= 4 frames runs with 2 voxels per lane
 #endif
@@ -186,7 +188,16 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
     int n_items = *work_count;
     if (n_items > max_items) n_items = max_items;
     const int total = n_items * G::WPC;
-    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<volatile int *>(M.error_flag)[2] = n_items;  // sizes a later launch's grid (host)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // what the host sizes a later launch from: the number of work items, and the number of (item, frame) pairs as the order
+        // kernel's cost classes give it (0 when the list was not ordered): chains of few frames are not worth 2 voxels per lane
+        volatile int *report = reinterpret_cast<volatile int *>(M.error_flag);
+        const int *cls = work_count - COUNT_ITEMS + COUNT_CLASS0;
+        int pairs = 0;
+        for (int c = 0; c < 8; c++) pairs += cls[c] * (KMAX - 2 * c);
+        report[2] = n_items;
+        report[3] = pairs;
+    }
     const int grid_waves = nb * 4;
     const int rem_chunks = n_items - grid_waves / G::WPC;  // chunks behind the statically dealt ones
     const IntegratorParams &ip = P.ip;
