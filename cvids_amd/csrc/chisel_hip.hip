@@ -123,8 +123,11 @@ struct chisel_hip_map {
     //   front (auxiliary stream): host->device staging, depth_pyramid_kernel, cull_kernel (these read the frames only),
     //         resolve_kernel (reads the chunk hash; tolerates the previous batch's insertions, see kernels_cull.h)
     //   back  (the map's stream): integrate_kernel
-    // The front of batch b+1 runs while the back of batch b is still executing, so every buffer the front writes
-    // exists twice (sets alternate per batch); events order the halves.
+    // The fronts of batches b+1 and b+2 run while the back of batch b is still executing -- on two auxiliary streams, so that
+    // consecutive fronts overlap each other too (each is a chain of four short kernels: one stream runs them at half the rate the
+    // chip could) -- so every buffer the front writes exists three times (sets rotate per batch); events order the halves.
+    // The pending sets (chunks a batch may create) rotate over four buffers of their own: batch b reads those of b-1 and b-2
+    // while b+1 is already filling its own, and b+2's pyramid kernel may be clearing the fourth.
     struct BatchSet {
         float2 *pyr_data = nullptr;      // [KMAX][pyr_stride]
         PixelRec *rec_data = nullptr;    // [KMAX][2 + W*H]: per frame two all-NaN records, then the image
@@ -135,12 +138,13 @@ struct chisel_hip_map {
         int *cand_count = nullptr;       // [COUNT_INTS] device counters of the batch (COUNT_* in kernels_cull.h)
         WorkItem *items = nullptr;       // [items_capacity]: the work-list
         ItemSync *sync = nullptr;        // [items_capacity]: chunk-level state of the work items while the integration kernel runs
-        uint64_t *pending = nullptr;     // [PENDING_CAPACITY]: chunks this batch may create
+        uint64_t *pending = nullptr;     // chunks this batch may create: one of pending_ring (assigned per batch)
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
-        hipEvent_t front_done = nullptr;  // recorded on aux after the set's resolve
+        hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's work-list (and with it its pending set) is complete
         hipEvent_t back_done = nullptr;   // recorded on the map's stream after the set's integration
-    } sets[2];
-    hipStream_t aux = nullptr;
+    } sets[3];
+    uint64_t *pending_ring[4] = {nullptr, nullptr, nullptr, nullptr};  // [PENDING_CAPACITY + 1] each: the set, then its overflow flag
+    hipStream_t aux = nullptr, aux2 = nullptr;  // the front halves of even / odd batches
     hipEvent_t call_event = nullptr;     // caller-provided stream: orders the front after the caller's producers
     hipEvent_t mutation_event = nullptr; // map changed outside the integration path (reset, upload): the next front waits
     bool mutation_pending = false;
@@ -148,7 +152,8 @@ struct chisel_hip_map {
     bool force_pipeline = false;         // test hook (CHISEL_HIP_FORCE_PIPELINE at creation): the front half always runs on the auxiliary stream
     bool mesh_tiny = false;              // test hook (CHISEL_HIP_MESH_TINY at creation): triangle list and arena start far too small, so every recompute takes the grow-and-emit-again paths
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
-    unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b & 1]
+    unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % 3] and pending_ring[b % 4]
+    unsigned recomputes = 0, recomputes_seen = 0;  // mesh recomputes issued / as of the previous batch (front-stream choice)
     int items_capacity = 0;
     int pyr_w = 0, pyr_h = 0, pyr_stride = 0;
     PyramidView pyr{};                   // level geometry; .data is set per batch
@@ -198,9 +203,11 @@ namespace {
 
 // everything queued by the map, on both of its streams (needed before a batch buffer is reallocated)
 int sync_all(chisel_hip_map *m) {
-    if (m->aux) HIP_TRY(hipStreamSynchronize(m->aux));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    if (m->aux) HIP_TRY(hipStreamSynchronize(m->aux));
+    for (int pass = 0; pass < 2; pass++) {
+        if (m->aux) HIP_TRY(hipStreamSynchronize(m->aux));
+        if (m->aux2) HIP_TRY(hipStreamSynchronize(m->aux2));
+        if (!pass) HIP_TRY(hipStreamSynchronize(m->stream));
+    }
     return CHISEL_HIP_OK;
 }
 
@@ -379,9 +386,14 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
 #undef CHISEL_LAUNCH_CULL
     }
     if (!inline_resolve) {
+        // the chunks the batches in flight may create: the pending sets of the previous two (complete once the previous batch's
+        // resolve step is through: the one wait between consecutive front halves)
+        const unsigned b = m->batch_seq;
+        const uint64_t *prev_pending = (b >= 1 || m->force_uncertain) ? m->pending_ring[(b + 3u) & 3u] : nullptr;
+        const uint64_t *prev2_pending = b >= 2 ? m->pending_ring[(b + 2u) & 3u] : nullptr;
+        if (b >= 1) HIP_TRY(hipStreamWaitEvent(front, m->sets[(b + 2u) % 3u].front_done, 0));
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
-        chisel_hip_map::BatchSet *prev = (m->batch_seq || m->force_uncertain) ? &m->sets[(m->batch_seq + 1u) & 1u] : nullptr;
-        const int *prev_overflow = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : (prev ? prev->cand_count + COUNT_OVERFLOW : nullptr);
+        const int *force_flag = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : nullptr;
         const dim3 rgrid((total + 255) / 256);
         // one frame: nothing to order; and a work-list that fits the chip in one go (<= 256 items by the count a recent launch
         // reported: every unit starts at once, whatever its place in the list) is not worth a launch of its own either -- the
@@ -389,7 +401,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
         const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= 256);
         hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
-                           prev ? prev->pending : nullptr, prev_overflow, bs.pending, direct ? bs.items : nullptr, bs.sync);
+                           prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync);
         if (!direct)
             hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
     }
@@ -495,7 +507,8 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     PP.ip = CP.ip = IP.ip = ip;
     PP.W = W;
     PP.H = H;
-    chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq & 1u];
+    chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq % 3u];
+    bs.pending = m->pending_ring[m->batch_seq & 3u];
     PP.rec_stride = (int)npx + 2;
     PP.pyr_stride = m->pyr_stride;
     PP.rec = bs.rec_data + 2;
@@ -536,18 +549,29 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     // is in flight (a caller that waits after every frame; the first batch): then there is nothing to run beside and the
     // short form on the map's stream has the lower latency (launch_group).  A stream given by the caller orders the front
     // half after whatever the caller queued there (the producers of device frames), which is the same stream order.
+    const bool meshing = m->recomputes != m->recomputes_seen;  // a mesh recompute was issued since the previous batch
+    m->recomputes_seen = m->recomputes;
     {
-        const chisel_hip_map::BatchSet &prev = m->sets[(m->batch_seq + 1u) & 1u];
+        const chisel_hip_map::BatchSet &prev = m->sets[(m->batch_seq + 2u) % 3u];  // the previous batch's (integrations complete in order)
         const bool idle = (m->batch_seq == 0 || hipEventQuery(prev.back_done) == hipSuccess) && !m->pending_meshes.unchecked &&
                           !m->force_pipeline;
-        bs.front_stream = (idle || m->stream != m->own_stream || m->aux == m->own_stream) ? m->stream : m->aux;
+        // Two auxiliary streams, taken in turn, double the rate of the front halves -- which is what a stream without meshing
+        // hangs on (98 -> 122 k frames/s) -- but a stream that recomputes meshes between its batches is paced by integration +
+        // meshing on the map's stream, and a second front half beside them only takes 3 % from it: one stream then.
+        hipStream_t side = (m->batch_seq & 1u) && m->aux2 && !meshing ? m->aux2 : m->aux;
+        bs.front_stream = (idle || m->stream != m->own_stream || m->aux == m->own_stream) ? m->stream : side;
     }
     hipStream_t front = bs.front_stream;
     if (front != m->stream) {
-        // the front half may start as soon as the batch that last used this buffer set has been integrated -- and the
-        // previous batch's front half is through: its pending set is read here, and it may have run on the map's stream
+        // the front half may start as soon as the batch that last used this buffer set (three batches ago) has been integrated;
+        // only its resolve step waits for the previous batch's (launch_group).  The previous front half may have run on the map's
+        // stream (short form): what it wrote must be complete before this one's kernels read the candidates' neighbours' state
         HIP_TRY(hipStreamWaitEvent(front, bs.back_done, 0));
-        if (m->batch_seq) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + 1u) & 1u].front_done, 0));
+        // this batch's pyramid kernel clears the pending buffer that the resolve step of batch b-2 still reads (as its b-4)
+        if (m->batch_seq >= 2) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + 1u) % 3u].front_done, 0));
+        // a stream paced by integration + meshing gains nothing from a front half that starts a batch earlier (it only runs
+        // beside more of the kernels that set the pace): the two-set rule for it
+        if (meshing && m->batch_seq >= 2) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + 1u) % 3u].back_done, 0));
         if (m->mutation_pending) HIP_TRY(hipStreamWaitEvent(front, m->mutation_event, 0));
     }
     m->mutation_pending = false;
@@ -831,6 +855,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         const char *pr = getenv("CHISEL_HIP_AUX_PRIORITY");  // diagnostic: "low" / "normal" instead of the default high
         const int prio = pr && !strcmp(pr, "low") ? least : (pr && !strcmp(pr, "normal") ? (least + greatest) / 2 : greatest);
         HIP_TRY_C(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, prio));
+        if (!getenv("CHISEL_HIP_ONE_FRONT_STREAM")) HIP_TRY_C(hipStreamCreateWithPriority(&m->aux2, hipStreamNonBlocking, prio));
     }
     m->stream = m->own_stream;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
@@ -846,8 +871,11 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.back_done, hipEventDisableTiming));
         HIP_TRY_C(hipMalloc(&bs.cand_count, COUNT_INTS * sizeof(int)));
         HIP_TRY_C(hipMemsetAsync(bs.cand_count, 0, COUNT_INTS * sizeof(int), m->own_stream));
-        HIP_TRY_C(hipMalloc(&bs.pending, (size_t)PENDING_CAPACITY * sizeof(uint64_t)));
-        HIP_TRY_C(hipMemsetAsync(bs.pending, 0xff, (size_t)PENDING_CAPACITY * sizeof(uint64_t), m->own_stream));
+    }
+    for (auto &pr : m->pending_ring) {
+        HIP_TRY_C(hipMalloc(&pr, ((size_t)PENDING_CAPACITY + 1) * sizeof(uint64_t)));
+        HIP_TRY_C(hipMemsetAsync(pr, 0xff, (size_t)PENDING_CAPACITY * sizeof(uint64_t), m->own_stream));
+        HIP_TRY_C(hipMemsetAsync(pr + PENDING_CAPACITY, 0, sizeof(uint64_t), m->own_stream));
     }
     HIP_TRY_C(hipEventCreateWithFlags(&m->mutation_event, hipEventDisableTiming));
     m->mesh_tiny = getenv("CHISEL_HIP_MESH_TINY") != nullptr;
@@ -901,15 +929,18 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
-        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.sync, bs.pending};
+        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.sync};
         for (void *p : bp)
             if (p) (void)hipFree(p);
         if (bs.front_done) (void)hipEventDestroy(bs.front_done);
         if (bs.back_done) (void)hipEventDestroy(bs.back_done);
     }
+    for (auto &pr : m->pending_ring)
+        if (pr) (void)hipFree(pr);
     if (m->call_event) (void)hipEventDestroy(m->call_event);
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
+    if (m->aux2) (void)hipStreamDestroy(m->aux2);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     if (m->mesh_totals_host) (void)hipHostFree(m->mesh_totals_host);
     if (m->error_flag_host) (void)hipHostFree(m->error_flag_host);

@@ -191,6 +191,7 @@ int recompute_meshes(chisel_hip_map *m) {
     // next touches the map (check_mesh_totals polls the sequence number): until then the host is free to queue the next batch's
     // front half, and by then the triangle kernel is usually still running, so the next integration queues up behind it without a gap
     m->mesh_seq++;
+    m->recomputes++;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
         launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity, 1);

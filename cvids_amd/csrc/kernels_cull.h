@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
         for (unsigned i = gid; i < (unsigned)COUNT_INTS; i += n_threads)
             if (i != (unsigned)COUNT_ONE) counts[i] = 0;
         for (unsigned i = gid; i < PENDING_CAPACITY; i += n_threads) pending[i] = KEY_EMPTY;
+        if (gid == 0) pending[PENDING_CAPACITY] = 0;  // the set's overflow flag travels with it (the sets rotate independently of the counters)
     }
     float mn = INFINITY, mx = -INFINITY;
     if (px0 < W && py0 < H) {
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
                 resident |= in;
             }
             keep = mask != 0;
-            if (keep && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(&counts[COUNT_OVERFLOW], 1);
+            if (keep && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) my_pending[PENDING_CAPACITY] = 1;
         }
         // wave64 compaction: ballot + prefix popcount, one atomic per wave
         const unsigned long long bal = __ballot(keep);
@@ -534,14 +535,16 @@ __device__ inline int cost_class(unsigned frame_mask) { return (KMAX - __popc(fr
 // so the survivors go straight into the work-list (one returning atomic per wave) and order_kernel is not launched.
 __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
                                                        int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
-                                                       const int *__restrict__ prev_overflow, uint64_t *my_pending, WorkItem *items,
-                                                       ItemSync *sync) {
+                                                       const uint64_t *__restrict__ prev2_pending, const int *__restrict__ force_uncertain,
+                                                       uint64_t *my_pending, WorkItem *items, ItemSync *sync) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + threadIdx.x;
     int n = counts_in[COUNT_CANDS];
     if (n > max_cands) n = max_cands;
     if ((int)(blockIdx.x * 256) >= n) return;
-    const bool all_uncertain = prev_overflow && *prev_overflow != 0;  // pending set of the previous batch incomplete
+    // a pending set of the batches in flight is incomplete (its overflow flag sits behind its last bucket), or the test hook
+    const bool all_uncertain = (force_uncertain && *force_uncertain != 0) || (prev_pending && prev_pending[PENDING_CAPACITY] != 0) ||
+                               (prev2_pending && prev2_pending[PENDING_CAPACITY] != 0);
     int cls = -1;
     if (c < n) {
         WorkItem wi = cands[c];
@@ -561,7 +564,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
         const unsigned inband = wi.frame_mask & 0xffffu, carve = wi.frame_mask >> 16;
         // While the previous batch is being integrated a key can already be visible whose slot value is not: the lookup
         // result only counts for chunks that batch cannot be creating.  If its pending set is incomplete, that is nobody.
-        const bool uncertain = prev_pending && (all_uncertain || pending_contains(prev_pending, key, h0));
+        const bool uncertain = all_uncertain || (prev_pending && pending_contains(prev_pending, key, h0)) ||
+                               (prev2_pending && pending_contains(prev2_pending, key, h0));
         unsigned mask = 0;
         if (uncertain) {
             slot = SLOT_LOOKUP;
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
             cands[c].frame_mask = mask;
         }
         if (mask) cls = cost_class(mask);
-        if (mask && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) atomicExch(&counts[COUNT_OVERFLOW], 1);
+        if (mask && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) my_pending[PENDING_CAPACITY] = 1;
         if (items) {  // (a wave takes this branch as a whole only in its active lanes; the ballot below counts them)
             const unsigned long long bal = __ballot(mask != 0u);
             if (mask) {
