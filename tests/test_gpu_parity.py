@@ -262,6 +262,39 @@ def test_reset_and_garbage_collect(oracle_mod):
     _run(om, gm, integ, frames, cam)
 
 
+def test_reset_and_garbage_collect_between_batches_in_flight(oracle_mod, monkeypatch):
+    """Reset and GarbageCollect issued while batches are queued on all three streams (no synchronisation by the caller): the front
+    halves of the batches that follow must see the map as those calls left it (pending sets of batches before the reset are
+    stale, removed chunks must not be found in the hash, freed slots are handed out again)"""
+    monkeypatch.setenv("CHISEL_HIP_FORCE_PIPELINE", "1")
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, carving=True, carving_dist=0.02, max_chunks=8192)
+    monkeypatch.delenv("CHISEL_HIP_FORCE_PIPELINE", raising=False)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+    frames = make_frames("sphere_room", 24, 64, 48, agents=2, nan_fraction=0.02)
+
+    def both(part):
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        for lo in range(0, len(part), 2):
+            chunk = part[lo:lo + 2]
+            gm.IntegrateBatch(integ, [(d, p, cam) for d, p in chunk], [(color, p, cam) for _, p in chunk])  # asynchronous
+
+    both(frames[:8])
+    gm.Reset()
+    om.reset()
+    both(frames[4:14])
+    ids = gm.GetChunkIDs()  # (waits for the batches queued so far)
+    victims = ids[::4]
+    gm.GarbageCollect(victims)
+    for v in victims:
+        om.remove_chunk(v)
+    both(frames[10:24])  # re-creates some of the removed chunks while the hash still holds their tombstones
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
 def test_pool_exhaustion_is_reported(oracle_mod):
     from cvids_amd import capi
     om, gm, integ = _mk(oracle_mod, 8, 0.05, False, max_chunks=16)
