@@ -190,6 +190,8 @@ constexpr int WI_INBAND = 1;   // some voxel may take the in-band branch
 constexpr int WI_CARVE = 2;    // some voxel may take the carve test (only matters while the chunk is resident)
 constexpr int WI_TILE = 4;     // u0..v1 is a valid bounding box (else: gather from the whole image)
 constexpr int WI_FASTZ = 8;    // camera z of every voxel of the chunk lies in [FASTZ_MIN, FASTZ_MAX]: reciprocal_in_range() applies
+constexpr int WI_FASTWU = 16;  // ConstantWeighter(1) and 5 x truncation distance of every valid pixel under the chunk lies in that range:
+                               // weight / (5 * truncation) (ConstantWeighter.h:43-46) is reciprocal_in_range(5 * truncation), exactly
 
 // Chunk-level state of one work item while its waves run (device-scope atomics only; zeroed by whoever writes the item).
 struct ItemSync {

@@ -337,7 +337,10 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
     // kernel's own z carries the rounding of three products of magnitude <= mag: keep well clear of it.
     const float mag = fabsf(C.t[0]) + fabsf(C.t[1]) + fabsf(C.t[2]) + fabsf(bminx) + fabsf(bminy) + fabsf(bminz) + 3.0f * ext;
     const bool fastz = !any_behind && (zmin >= FASTZ_MIN + 1e-5f * mag) && (zmax <= FASTZ_MAX);
-    return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0);
+    // the in-band update's weight 1 / (5 * truncation) by the same short reciprocal: every valid pixel under the chunk has its
+    // truncation distance in [tmin, tmax] (conservative, see truncation_range), a factor of two inside the checked range
+    const bool fastwu = ip.weight == 1.0f && (5.0f * tmin >= 2.0f * FASTZ_MIN) && (5.0f * tmax <= 0.5f * FASTZ_MAX);
+    return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0) | (fastwu ? WI_FASTWU : 0);
 }
 
 __device__ inline bool pending_contains(const uint64_t *__restrict__ set, uint64_t key, uint64_t h) {

@@ -450,12 +450,22 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
 #endif
                             }
                         }
+                        // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84; IntegrateColor: weighter->GetWeight(.., truncation) :161-162 --
+                        // weight / (5 * truncation), an IEEE division (11 instructions) unless the cull kernel has established that the
+                        // weight is 1 and 5 * truncation of every pixel under the chunk is in the range where the 4-instruction reciprocal
+                        // is exact (WI_FASTWU; wave-uniform)
+                        float wu[VPL];
+                        if (COLOR && (flags & WI_FASTWU)) {
+#pragma unroll
+                            for (int j = 0; j < VPL; j++) wu[j] = reciprocal_in_range(5.0f * r[j].y);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < VPL; j++) wu[j] = COLOR ? constant_weight(ip.weight, r[j].y) : 1.0f;
+                        }
 #pragma unroll
                         for (int j = 0; j < VPL; j++) {
-                            // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84; IntegrateColor: weighter->GetWeight(.., truncation) :161-162
-                            const float wu = COLOR ? constant_weight(ip.weight, r[j].y) : 1.0f;
                             float ns = f4(s4, j), nw = f4(w4, j);
-                            dist_integrate(ns, nw, sd[j], wu);
+                            dist_integrate(ns, nw, sd[j], wu[j]);
                             const bool in_band = ((bandm >> j) & 1u) != 0u;
                             f4(s4, j) = in_band ? ns : f4(s4, j);
                             f4(w4, j) = in_band ? nw : f4(w4, j);
