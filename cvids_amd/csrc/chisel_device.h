@@ -69,7 +69,8 @@ struct MapView {
     int *hash_vals;
     uint64_t hash_mask;      // capacity - 1 (power of two)
     uint64_t *slot_key;
-    uint32_t *slot_dirty;
+    uint32_t *slot_dirty;    // [max_chunks] "updated since the last mesh recompute"; behind them [max_chunks] the slots whose flag went 0 -> 1
+                             // since the flags were last cleared, in order of appearance, and [2 * max_chunks] their number (mark_slot_dirty)
     int *free_list;
     int *free_top;
     unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS (filled by reduce_counters_kernel)
@@ -77,6 +78,15 @@ struct MapView {
     int *error_flag;         // two words in pinned host memory, see raise_error
     int max_chunks;
 };
+
+// A chunk was updated (Chisel.h:85 / :167 needsUpdate -> meshesToUpdate, Chisel.h:175-189): its flag, and -- for the mesher, which must
+// not have to scan a pool of millions of slots for a few hundred dirty ones -- its slot into the list of dirty slots, once.
+__device__ inline void mark_slot_dirty(const MapView &M, int slot) {
+    if (atomicExch(&M.slot_dirty[slot], 1u) == 0u) {
+        const unsigned p = atomicAdd(&M.slot_dirty[2 * (size_t)M.max_chunks], 1u);
+        if (p < (unsigned)M.max_chunks) M.slot_dirty[(size_t)M.max_chunks + p] = (unsigned)slot;  // (else: the mesher scans the flags)
+    }
+}
 
 // depth min/max pyramid: level l (PYR_L0 <= l <= PYR_L1) has ceil(W/2^l) x ceil(H/2^l) texels of
 // (min, max) over the valid pixels of a 2^l x 2^l block; (+inf, -inf) when the block has none.

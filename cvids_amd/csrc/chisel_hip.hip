@@ -894,7 +894,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.hash_keys, hc * sizeof(uint64_t)));
     HIP_TRY_C(hipMalloc(&v.hash_vals, hc * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.slot_key, (size_t)C * sizeof(uint64_t)));
-    HIP_TRY_C(hipMalloc(&v.slot_dirty, (size_t)C * sizeof(uint32_t)));
+    HIP_TRY_C(hipMalloc(&v.slot_dirty, (2 * (size_t)C + 4) * sizeof(uint32_t)));  // flags, list of dirty slots, its length
     HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.counters, 32 * sizeof(unsigned long long)));

@@ -69,11 +69,11 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
         HIP_TRY(hipMalloc(&B.flags, (size_t)C * sizeof(unsigned)));
         HIP_TRY(hipMemsetAsync(B.flags, 0, (size_t)C * sizeof(unsigned), m->stream));
     }
-    const long long threads = (long long)C * 27;  // (the mark kernel also zeroes the totals)
+    // (the mark kernel also zeroes the totals; its grid is persistent: the number of dirty slots is read on the device)
     int *n_jobs = mesh_totals(m) + 4 + (B.mark_turn & 1), *n_jobs_next = mesh_totals(m) + 4 + ((B.mark_turn + 1) & 1);
     B.mark_turn++;
     B.n_jobs = n_jobs;
-    hipLaunchKernelGGL(mesh_mark_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, m->view, B.flags, mesh_totals(m), B.ids,
+    hipLaunchKernelGGL(mesh_mark_kernel, dim3(1024), dim3(256), 0, m->stream, m->view, B.flags, mesh_totals(m), B.ids,
                        n_jobs, n_jobs_next);
     if (!extra.empty()) {
         // (rare) ids kept on the host: the ones that are resident join the job list

@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
         }
         __syncthreads();
         if (tid == 0 && s_upd != 0u && slot >= 0) {
-            M.slot_dirty[slot] = 1;  // Chisel.cpp:135-147 (27 neighbours: expanded by the mesher)
+            mark_slot_dirty(M, slot);  // Chisel.cpp:135-147 (27 neighbours: expanded by the mesher)
             n_updated++;
         }
     }

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 unsigned old = 0u;
                 if (lane == 0) {
                     old = atomicOr(&sy->changed, cm);
-                    M.slot_dirty[slot] = 1;
+                    mark_slot_dirty(M, slot);
                 }
                 old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
                 n_updated += (unsigned)__popc(cm & ~old);

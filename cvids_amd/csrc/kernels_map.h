@@ -42,6 +42,7 @@ __global__ void reset_map_kernel(MapView M, int V) {
         if (c4) c4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (gid == 0) {
+        M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // the list of dirty slots is empty
         *M.free_top = M.max_chunks;
         M.error_flag[0] = 0;
         M.error_flag[1] = 0;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void import_chunks_kernel(MapView M, const int
 __global__ void clear_dirty_kernel(MapView M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M.max_chunks) M.slot_dirty[i] = 0;
+    if (i == 0) M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // and their list
 }
 
 // ---- PublishDenseInfo's image conditioning (collaborative_server_system.cpp:213-214, :255-269) -------------------------

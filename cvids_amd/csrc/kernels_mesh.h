@@ -253,17 +253,26 @@ __device__ inline void mesh_append_job(const MapView &M, unsigned *mesh_flag, in
     ids[3 * pos + 2] = z;
 }
 __global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag, int *totals, int *ids, int *n_jobs, int *n_jobs_next) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 3) totals[t] = 0;  // triangles, grids, overflow: the count kernel's (the next launch's) counters
-    if (t == 3) *n_jobs_next = 0;
-    const int slot = t / 27, o = t % 27;
-    if (slot >= M.max_chunks || !M.slot_dirty[slot]) return;
-    const uint64_t key = M.slot_key[slot];
-    if (key == KEY_EMPTY) return;
-    int x, y, z;
-    unpack_id(key, x, y, z);
-    const int ns = (o == 13) ? slot : hash_find_quiescent(M, x + o % 3 - 1, y + (o / 3) % 3 - 1, z + o / 9 - 1);
-    if (ns >= 0) mesh_append_job(M, mesh_flag, ns, ids, n_jobs);
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (gid < 3) totals[gid] = 0;  // triangles, grids, overflow: the count kernel's (the next launch's) counters
+    if (gid == 3) *n_jobs_next = 0;
+    // the dirty slots come from the list the integration kernels keep (mark_slot_dirty): the work here is proportional to what
+    // changed, not to the size of the pool; a list that overflowed (slots dirtied, removed and dirtied again many times over
+    // without a recompute in between) falls back to the flags of all slots
+    const unsigned listed = M.slot_dirty[2 * (size_t)M.max_chunks];
+    const bool scan = listed > (unsigned)M.max_chunks;
+    const long long n = 27ll * (scan ? (long long)M.max_chunks : (long long)listed);
+    for (long long t = gid; t < n; t += stride) {
+        const int entry = (int)(t / 27), o = (int)(t % 27);
+        const int slot = scan ? entry : (int)M.slot_dirty[(size_t)M.max_chunks + entry];
+        if (!M.slot_dirty[slot]) continue;  // (cleared since it was listed: the chunk was removed)
+        const uint64_t key = M.slot_key[slot];
+        if (key == KEY_EMPTY) continue;
+        int x, y, z;
+        unpack_id(key, x, y, z);
+        const int ns = (o == 13) ? slot : hash_find_quiescent(M, x + o % 3 - 1, y + (o / 3) % 3 - 1, z + o / 9 - 1);
+        if (ns >= 0) mesh_append_job(M, mesh_flag, ns, ids, n_jobs);
+    }
 }
 // (rare) resident chunks the host wants meshed as well: neighbourhoods of chunks that were removed while dirty
 __global__ void mesh_append_kernel(MapView M, unsigned *mesh_flag, const int *slots, int n, int *ids, int *n_jobs) {
@@ -441,6 +450,7 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
         if (mesh_flag) mesh_flag[s_nb[NB_SELF]] = 0u;
         M.slot_dirty[s_nb[NB_SELF]] = 0u;
     }
+    if (j == 0 && threadIdx.x == 29) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;  // the list of dirty slots has been consumed (mark kernel)
     MSTAMP(0);
     if (present) stage_corners<N>(M, s_nb, s_vox);
     MSTAMP(1);
