@@ -14,7 +14,11 @@ in the JSON line is the same stream without the recomputes.  Frames are syntheti
 spatially (chisel_hip_config.n_shards); the frames of a batch are ingested round-robin (frame j on rank j * N / batch)
 and one RCCL all-gather per batch hands every rank the whole batch (cvids_amd.sharded.FrameExchange, on its own
 stream, ordered against the map with events), then each rank integrates the chunks it owns -> total work is fixed:
-"scaling": "strong".  N > 1 runs integrate only (16 frames per all-gather).
+"scaling": "strong".  N > 1 runs the same workload, the mesh recompute included (cvids_amd.sharded.ShardedChisel.UpdateMeshes:
+every rank meshes the chunks it owns, neighbour chunks of other ranks arrive as ghosts).  Without WORLD_SIZE in the
+environment `--gpus N` with N > 1 starts the N ranks itself (torch.distributed.run as a child process, before anything
+touches a GPU) and relays rank 0's line.  --config picks one of BASELINE.json's configurations (3 is the default; 5 ends
+with a garbage collection and a full mesh extraction inside the timed region).
 
 The timed region (W warm-up steps, then exactly K steps between barrier + synchronize) is repeated --repeats times, each
 time from an empty map, and `value` is K / the MEDIAN of those times (p10 / p90 beside it): the driver's default region is
@@ -75,7 +79,56 @@ def parse():
                                                                "(what one rank of an N-GPU run computes; every rank sees every frame)")
     ap.add_argument("--sim-rank", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (functional check of the N > 1 logic on one GPU)")
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5),
+                    help="BASELINE.json configuration: 2 = depth only @ 2 cm; 3 = depth + colour @ 1 cm, meshes every 10th frame (the metric's); "
+                         "4 = four interleaved agents; 5 = 1280x720 @ 0.5 cm, garbage collection + full mesh extraction at the end of the timed region")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which a self-launched N > 1 run is killed")
+    ap.add_argument("--no-e2e-leg", action="store_true", help="skip the end-to-end pass (per-frame depth AND colour from page-locked host buffers, `e2e`, 1 GPU only)")
+    args = ap.parse_args()
+    given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+    preset = {2: {"res": 0.02, "no_color": True, "mesh_every": 0},
+              3: {},
+              4: {"agents": 4},
+              5: {"width": 1280, "height": 720, "res": 0.005, "mesh_every": 0, "batch": 8, "max_chunks": 1 << 18}}[args.config]
+    for k, v in preset.items():
+        if "--" + k.replace("_", "-") not in given:
+            setattr(args, k, v)
+    if args.config == 5 and "--steps" not in given:
+        args.steps, args.warmup = 40, 8
+    return args
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` from a plain shell: this process touches no GPU; it starts the N ranks as children
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1), lets their output through (rank 0 prints the JSON line) and
+    exits with their status.  Children that outlive --launch-timeout are killed (the whole process group) and the exit code is 124."""
+    import signal
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d-rank run did not finish within %.0f s: killing it" % (args.gpus, args.launch_timeout), file=sys.stderr)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        rc = 124
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGKILL)
+        raise
+    sys.exit(rc)
 
 
 def algorithmic_bytes(cnt, n_frames, W, H, channels):
@@ -128,12 +181,16 @@ def cpu_baseline(args, frames, color_img, intr, scale):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 16 if not args.no_color else 1, "kind": "port",
             "host_cpus": os.cpu_count(), "mvoxel_updates_per_s": upd / dt / 1e6,
-            "sample": "first %d frames of the same stream (oracle faithful mode: %d candidate chunks visited per frame, %s), %.1f s"
+            "sample": "the first %d of the timed frames, integrated into an EMPTY oracle map (the GPU's timed region starts from the map the "
+                      "warm-up frames left; the oracle's cost per frame is set by the %d candidate chunks it visits, not by the map's state); "
+                      "oracle faithful mode, %s; %.1f s"
                       % (n, c["candidates"], "16 std::threads as Chisel.h:150" if not args.no_color else "serial as Chisel.h:71", dt)}
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # does not return
     import torch
     import torch.distributed as dist
     from cvids_amd import synth
@@ -143,9 +200,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`" % (args.gpus, args.gpus), file=sys.stderr)
-            sys.exit(2)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if args.dist_backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)  # functional check: ranks may share a GPU
     torch.cuda.set_device(local_rank)
@@ -158,7 +214,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     if args.mesh_every is None:
-        args.mesh_every = 10 if world == 1 else 0
+        args.mesh_every = 10  # the reference's keyframe cadence (Chisel.cpp:54), at every N
     if args.batch is None:
         # 1 GPU: the keyframe interval; N GPUs: 16 frames per all-gather (every rank contributes 16 / N frame slots)
         args.batch = args.mesh_every if 0 < args.mesh_every <= 16 else (16 if world > 1 else 8)
@@ -179,7 +235,7 @@ def main():
     import ctypes as C
     from cvids_amd import capi
     from cvids_amd.chisel import color_frame, depth_frame
-    from cvids_amd.sharded import FrameExchange, PipelinedExchange, frames_of_rank, pack_meta
+    from cvids_amd.sharded import FrameExchange, PipelinedExchange, ShardedChisel, frames_of_rank, pack_meta
     K = max(1, args.batch)
     if world > 1 and K % world:
         K = max(world, (K // world) * world)  # every rank contributes K / world frame slots to each all-gather
@@ -228,7 +284,35 @@ def main():
                    shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank)
         m._use(integ)
         m.px = PipelinedExchange(xch, m) if world > 1 else None  # RCCL -> integrate ordering: events, no host wait
+        m.sharded = ShardedChisel(m, xch, integ) if world > 1 else None  # Chisel::UpdateMeshes of the sharded map
         return m
+
+    mesh_stats = {"recomputes": 0, "ghost_bytes": 0}
+
+    def update_meshes(m, ids=None):
+        mesh_stats["recomputes"] += 1
+        if world > 1:
+            mesh_stats["ghost_bytes"] += m.sharded.UpdateMeshes(force=True, ids=ids) or 0
+        elif ids is None:
+            m.UpdateMeshes(force=True)
+        else:
+            m.UpdateMeshesOf(ids)
+
+    def finish_config5(m):
+        """BASELINE config 5's "chunk GC + full mesh extraction": the chunks that lie behind the camera of the last frame (centre's
+        camera z < 0: the map forgets what it has turned away from) are garbage-collected (Chisel::GarbageCollect, Chisel.cpp:61-67),
+        then every remaining chunk is meshed.  Each rank handles the chunks it owns."""
+        pose = np.asarray(frames[total - 1][1], np.float64)
+        ids = np.asarray(m.GetChunkIDs(), np.int64).reshape(-1, 3)
+        if len(ids):
+            centre = (ids + 0.5) * (args.chunk * args.res)
+            z_cam = (centre - pose[:3, 3]) @ pose[:3, 2]
+            behind = ids[z_cam < 0.0]
+            if len(behind):
+                m.GarbageCollect(behind.astype(np.int32))
+            ids = ids[z_cam >= 0.0]
+        update_meshes(m, ids.astype(np.int32))
+        return len(ids)
 
     def run(m, b_lo, b_hi):
         L, h = m.L, m.h
@@ -242,7 +326,9 @@ def main():
             if world > 1:
                 m.px.consumed(b)
             if args.mesh_every and (bounds[b][1] // args.mesh_every) > (bounds[b][0] // args.mesh_every):
-                m.UpdateMeshes(force=True)
+                update_meshes(m)
+        if args.config == 5 and b_hi == len(bounds) and b_hi > b_lo:
+            finish_config5(m)
 
     def fence():
         if world > 1:
@@ -367,6 +453,83 @@ def main():
         calls_ref[0] = saved
         pcie = {"value": args.steps / median(ts_d), "unit": "frames/s", "ms_per_step": median(ts_d) / args.steps * 1e3,
                 "source": "page-locked host depth frames read over PCIe during the call (colour image resident)", "repeats": len(ts_d)}
+    # ---- pass E (1 GPU): end to end as SURVEY.md 8(d) defines it -- every frame's depth AND colour image start in page-locked host
+    # memory (a new colour image per frame, as the caller delivers it: ChiselServer.cpp:379-421), are copied to one of two device
+    # buffer sets on a copy stream while the previous batch is integrated (events both ways, no host wait), then integrated.
+    e2e = None
+    if world == 1 and not args.no_e2e_leg and not args.host_frames and not args.no_roofline:
+        nb = len(bounds)
+        kmax = max(hi - lo for lo, hi in bounds)
+        h_depth = [torch.from_numpy(np.stack([frames[i][0] for i in range(lo, hi)])).pin_memory() for lo, hi in bounds]
+        h_color = None
+        if use_color:
+            uu, vv = np.meshgrid(np.arange(W), np.arange(H))
+            pat = lambda k: np.stack([(uu + k) % 256, vv % 256, (uu + vv + k) % 256], axis=-1).astype(np.uint8)  # (u + k, v, u + v + k) mod 256
+            h_color = [torch.from_numpy(np.stack([pat(i) for i in range(lo, hi)])).pin_memory() for lo, hi in bounds]
+        d_depth = [torch.empty((kmax, H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        d_color = [torch.empty((kmax, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if use_color else None
+        calls_e = []
+        for b, (lo, hi) in enumerate(bounds):
+            n = hi - lo
+            fa = (capi.DepthFrame * n)()
+            ca = (capi.ColorFrame * n)() if use_color else None
+            for j in range(n):
+                fa[j], k1 = depth_frame(d_depth[b & 1][j], frames[lo + j][1], cam)
+                keep.append(k1)
+                if use_color:
+                    ca[j], k2 = color_frame(d_color[b & 1][j], frames[lo + j][1], cam)
+                    keep.append(k2)
+            calls_e.append((n, fa, ca))
+        copy_stream = torch.cuda.Stream(device=dev)
+        ready = [torch.cuda.Event() for _ in range(2)]
+        free = [torch.cuda.Event() for _ in range(2)]
+        for e in ready + free:
+            e.record(copy_stream)
+
+        def run_e2e(m, b_lo, b_hi):
+            for b in range(b_lo, b_hi):
+                n, fa, ca = calls_e[b]
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(free[b & 1])  # the batch that last used this buffer set has been integrated
+                    d_depth[b & 1][:n].copy_(h_depth[b], non_blocking=True)
+                    if use_color:
+                        d_color[b & 1][:n].copy_(h_color[b], non_blocking=True)
+                    ready[b & 1].record(copy_stream)
+                m.wait_event(ready[b & 1].cuda_event)
+                rc = m.L.chisel_hip_integrate_batch(m.h, n, fa, ca)
+                if rc:
+                    capi.check(rc)
+                m.record_event(free[b & 1].cuda_event)
+                if args.mesh_every and (bounds[b][1] // args.mesh_every) > (bounds[b][0] // args.mesh_every):
+                    update_meshes(m)
+
+        ts_e = []
+        for _ in range(min(repeats, 3)):
+            m.Reset()
+            run_e2e(m, 0, first_timed)
+            m.synchronize()
+            fence()
+            t0 = time.perf_counter()
+            run_e2e(m, first_timed, nb)
+            fence()
+            ts_e.append(time.perf_counter() - t0)
+            m.synchronize()
+        # the bus rate this box gives a plain page-locked copy (64 MiB, best of 5)
+        big_h = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        big_d = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        best = 1e9
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            big_d.copy_(big_h, non_blocking=True)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        frame_bytes = W * H * (4 + (3 if use_color else 0))
+        e2e = {"value": args.steps / median(ts_e), "unit": "frames/s", "ms_per_step": median(ts_e) / args.steps * 1e3, "repeats": len(ts_e),
+               "host_bytes_per_frame": frame_bytes, "h2d_gb_per_s": args.steps * frame_bytes / median(ts_e) / 1e9,
+               "pcie_copy_gb_per_s_measured": (64 << 20) / best / 1e9,
+               "source": "every frame's depth and colour image ((u + k, v, u + v + k) mod 256) copied from page-locked host memory into one of two "
+                         "device buffer sets on a copy stream, overlapped with the previous batch's integration (events, no host wait)"}
     m.close()
 
     if rank == 0:
@@ -382,22 +545,32 @@ def main():
                                                                         args.scene, args.agents, "" if args.agents == 1 else "s",
                                                                         args.res * 100, args.chunk, scale,
                                                                         (" + marching cubes every %d frames" % args.mesh_every) if args.mesh_every else ""),
-                       "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color, "frames_per_call": K, "mesh_every": args.mesh_every,
+                       "baseline_config": args.config, "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color, "frames_per_call": K, "mesh_every": args.mesh_every,
                        "parallelism": "spatial chunk-hash shards x%d, RCCL all-gather of each %d-frame batch" % (world, K) if world > 1 else "1 GPU"},
             "per_frame": {"voxel_updates": vals[0] / args.steps, "n_sdf": vals[1] / args.steps, "n_col": vals[2] / args.steps,
                           "n_probe": vals[4] / args.steps, "n_carved": vals[5] / args.steps,
                           "work_chunks": vals[6] / args.steps, "resident_chunks_end": vals[7]},
         }
         if world > 1:
-            out["note"] = ("N > 1: integration only (a sharded map is meshed through a functional, host-mediated exchange that is not "
-                           "part of this timing); the comparable 1-GPU figure is `integration_only` of the --gpus 1 line")
+            out["sharded_meshing"] = {"recomputes": mesh_stats["recomputes"],
+                                      "ghost_bytes_per_recompute_rank0": mesh_stats["ghost_bytes"] / max(1, mesh_stats["recomputes"])}
+            out["note"] = ("N > 1: one map sharded over the ranks (total work fixed); every batch is all-gathered, every rank integrates the chunks it "
+                           "owns and meshes them with ghost copies of the neighbours other ranks own")
         if roof:
             out["roofline"] = roof
         if no_mesh:
             out["integration_only"] = no_mesh
         if pcie:
             out["pcie_inclusive"] = pcie
-        if not args.no_cpu_baseline and world == 1:
+        if e2e:
+            out["e2e"] = e2e
+        if args.config == 5:
+            out["config"]["end_of_region"] = "garbage collection of the chunks behind the last camera + mesh extraction of every remaining chunk (inside the timed region)"
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 16, "kind": "port",
+                                       "sample": "infeasible as specified: the reference allocates every chunk of the frustum's bounding box per frame, "
+                                                 "about 250 k chunks = 33 GB at 1280x720 / 0.5 cm / 5 m (BASELINE.md section 2)"}
+        elif not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, frames[args.warmup:], color_img, intr, scale)
         print(json.dumps(out), flush=True)
     if world > 1:

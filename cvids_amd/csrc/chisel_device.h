@@ -25,7 +25,7 @@ constexpr uint64_t KEY_EMPTY = ~0ull;
 constexpr uint64_t KEY_TOMB = ~0ull - 1ull;
 constexpr int ID_BIAS = 1 << 20;  // chunk ids in [-2^20, 2^20)
 constexpr int INTEGRATE_MAX_GRID = 4096;  // rows of per-workgroup counters (power of two; larger grids wrap around)
-constexpr int INTEGRATE_GRID_CAP = 1 << 17;  // largest integration grid (workgroups)
+constexpr int INTEGRATE_GRID_CAP = 1 << 19;  // largest integration grid (workgroups)
 
 __host__ __device__ inline uint64_t pack_id(int x, int y, int z) {
     return (uint64_t)(uint32_t)(x + ID_BIAS) | ((uint64_t)(uint32_t)(y + ID_BIAS) << 21) |
@@ -202,6 +202,10 @@ constexpr int WI_TILE = 4;     // u0..v1 is a valid bounding box (else: gather f
 constexpr int WI_FASTZ = 8;    // camera z of every voxel of the chunk lies in [FASTZ_MIN, FASTZ_MAX]: reciprocal_in_range() applies
 constexpr int WI_FASTWU = 16;  // ConstantWeighter(1) and 5 x truncation distance of every valid pixel under the chunk lies in that range:
                                // weight / (5 * truncation) (ConstantWeighter.h:43-46) is reciprocal_in_range(5 * truncation), exactly
+constexpr int WI_INSIDE = 32;  // WI_FASTZ, and every voxel of the chunk projects onto the image in this frame (two pixels of margin on every
+                               // side, rounding of the per-voxel projection bounded: cull_chunk_frame): IsPointOnImage holds for all of them
+constexpr int WI_FASTDIV = 64; // WI_FASTWU with 5 x truncation in [2^-10, 2^10]: the in-band update's division may take the unscaled
+                               // sequence (dist_integrate_fast) where the voxel state is sane and the numerator is not tiny
 
 // Chunk-level state of one work item while its waves run (device-scope atomics only; zeroed by whoever writes the item).
 struct ItemSync {
@@ -323,6 +327,34 @@ __device__ inline unsigned color_gather(const uint8_t *data, int idx, int channe
 __device__ inline unsigned color_word(unsigned raw, unsigned shift) {
     const unsigned v = raw >> shift;  // B | G << 8 | R << 16 (| A << 24)
     return ((v >> 16) & 0xffu) | (v & 0xff00u) | ((v & 0xffu) << 16);
+}
+
+// The same two steps with fewer instructions (round 3).  color_gather2: offset by a 24-bit multiply, the last pixel's clamp by a
+// minimum (last_word = image_bytes - 4).  color_integrate_fresh_bgr: color_integrate for weightUpdate == 1 and weight < 8 on the
+// pixel's bytes as they lie in memory (v = raw >> shift: blue | green << 8 | red << 16; ColorImage::At's BGR decode is the
+// choice of byte per channel).  Per channel x = weight * old + new <= 2040 (exact in fp32), and the integer quotient x / d,
+// d = weight + 1 in 1..8, comes from v_cvt_pk_u8_f32, which rounds to nearest (even) and saturates: x / d - 1/2 + 1 / (2 d)
+// lies within 1/2 - 1/16 of floor(x / d), and the computed value -- one fma on a reciprocal good to 1 ulp, magnitudes below
+// 2^12 -- within 2^-10 of that.  Checked against color_integrate for every (weight, old, new) on the device
+// (chisel_hip_kat_color_fresh).
+__device__ inline unsigned color_gather2(const uint8_t *data, unsigned idx, unsigned channels, unsigned last_word, unsigned &shift) {
+    const unsigned b = __umul24(idx, channels);
+    const unsigned lo = b < last_word ? b : last_word;
+    shift = (b - lo) * 8u;
+    return *reinterpret_cast<const unaligned_u32 *>(data + lo);
+}
+__device__ inline unsigned color_integrate_fresh_bgr(unsigned c, unsigned v) {
+    const float wf = (float)(c >> 24);
+    const float r = __builtin_amdgcn_rcpf(wf + 1.0f);
+    const float hr = __builtin_fmaf(0.5f, r, -0.5f);
+    const float x0 = __builtin_fmaf(wf, (float)(c & 0xffu), (float)((v >> 16) & 0xffu));          // red
+    const float x1 = __builtin_fmaf(wf, (float)((c >> 8) & 0xffu), (float)((v >> 8) & 0xffu));    // green
+    const float x2 = __builtin_fmaf(wf, (float)((c >> 16) & 0xffu), (float)(v & 0xffu));          // blue
+    unsigned q = c + 0x01000000u;  // weight + 1 (< 9); the three colour bytes are replaced below
+    q = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x0, r, hr), 0u, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x1, r, hr), 1u, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(x2, r, hr), 2u, q);
+    return q;
 }
 
 // thresholds the reference compares in double against fp32 values, folded to fp32 (exactly equivalent):

@@ -432,16 +432,17 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const int wpc = vpl == 2 ? Geom<N, 2>::WPC : Geom<N, 4>::WPC;
         const int step = vpl == 2 ? Geom<N, 2>::GRID_STEP : Geom<N, 4>::GRID_STEP;
         const long long units = (long long)total * wpc;
-        long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * wpc + 3) / 4 : (long long)Geom<N, 4>::GRID;
+        constexpr int WPB = Geom<N, 4>::WPB;
+        long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * wpc + WPB - 1) / WPB : (long long)Geom<N, 4>::GRID;
         if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) blocks = atoi(e) ? (long long)Geom<N, 4>::GRID : blocks;
-        blocks = std::min<long long>(blocks, (units + 3) / 4);
+        blocks = std::min<long long>(blocks, (units + WPB - 1) / WPB);
         blocks = std::min<long long>(blocks, (long long)INTEGRATE_GRID_CAP);
         const int grid = (int)std::max<long long>(step, (blocks + step - 1) / step * step);
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
 #define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
-    hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(256), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
+    hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
                        bs.boxes, bs.sync, wc, queues, m->items_capacity)
         if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
             if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);

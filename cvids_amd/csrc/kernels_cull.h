@@ -292,13 +292,14 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
     zmin -= zslack;
     zmax += zslack;
     int u0 = 0, v0 = 0, u1 = C.W - 1, v1 = C.H - 1;
-    bool tile = false;
+    bool tile = false, box_inside = false;
     if (zmax < 0.0f) return 0;  // every voxel has z < 0 (ProjectionIntegrator.h:68)
     if (!any_behind) {
         // all corners in front: the projection of the box is inside the bbox of the projected corners
         float fu0 = floorf(umin) - 2.0f, fu1 = floorf(umax) + 2.0f, fv0 = floorf(vmin) - 2.0f, fv1 = floorf(vmax) + 2.0f;
         if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1))
             return 0;  // projects entirely off the image (IsPointOnImage fails for every voxel)
+        box_inside = fu0 >= 0.0f && fv0 >= 0.0f && fu1 <= (float)(C.W - 1) && fv1 <= (float)(C.H - 1);
         u0 = (int)fmaxf(fu0, 0.0f); v0 = (int)fmaxf(fv0, 0.0f);
         u1 = (int)fminf(fu1, (float)(C.W - 1)); v1 = (int)fminf(fv1, (float)(C.H - 1));
         tile = true;
@@ -340,7 +341,16 @@ __device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFra
     // the in-band update's weight 1 / (5 * truncation) by the same short reciprocal: every valid pixel under the chunk has its
     // truncation distance in [tmin, tmax] (conservative, see truncation_range), a factor of two inside the checked range
     const bool fastwu = ip.weight == 1.0f && (5.0f * tmin >= 2.0f * FASTZ_MIN) && (5.0f * tmax <= 0.5f * FASTZ_MAX);
-    return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0) | (fastwu ? WI_FASTWU : 0);
+    // Every voxel on the image: the box of the projected corners keeps two pixels from every border (above), and the integration
+    // kernel's own u, v differ from the exact projection by a small fraction of a pixel: its camera coordinates carry the rounding of
+    // three products of magnitude <= mag (<= 4 ulp: e = 5e-7 mag); u = fx x / z + cx turns an error e of x and of z into at most
+    // fx e (1 + |x| / z) / z, and on the image |x| / z <= (W + |cx|) / fx -- so z >= 1e-5 (fx + W + |cx|) mag bounds it by 0.05 pixels
+    // (the three roundings of u itself add a few ulp of a value below 2^15).
+    const float span = fmaxf(fabsf(C.fx), fabsf(C.fy)) + (float)(C.W + C.H) + fabsf(C.cx) + fabsf(C.cy);
+    const bool inside = box_inside && fastz && (zmin >= 1e-5f * span * mag);
+    const bool fastdiv = fastwu && (5.0f * tmin >= 0.0009765625f) && (5.0f * tmax <= 1024.0f) && (ip.diag <= 1024.0f);
+    return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0) | (fastwu ? WI_FASTWU : 0) |
+           (inside ? WI_INSIDE : 0) | (fastdiv ? WI_FASTDIV : 0);
 }
 
 __device__ inline bool pending_contains(const uint64_t *__restrict__ set, uint64_t key, uint64_t h) {

@@ -43,6 +43,14 @@ namespace chisel_hip {
 #ifndef INTEGRATE_BLOCKS_PER_CU
 #define INTEGRATE_BLOCKS_PER_CU 6
 #endif
+// Waves per workgroup.  The waves of a workgroup never meet (no barrier, no LDS), but the hardware takes a workgroup's place back
+// only when its LAST wave has ended: with four waves per workgroup a place idles for the difference between the longest and the
+// mean of four chains.
+// Measured on the driver's window (640x480 / 1 cm, 10 frames per launch, 1 257 items; round 3): 4 voxels per lane 113 us with four
+// waves per workgroup, 98-100 us with one; 2 voxels per lane 110 -> 100 us with eight instead of six waves per SIMD.
+#ifndef INTEGRATE_WPB
+#define INTEGRATE_WPB 1
+#endif
 // Voxels per lane (x-consecutive), a template parameter of the kernel: 4 for launches that fill the chip many times over (least
 // arithmetic per voxel: the quad's y / z terms are shared), 2 for small launches (twice as many units of half the length: what
 // such a launch takes is the length of its longest chains, not its arithmetic).  The host picks per launch: measured at 640x480 /
@@ -51,6 +59,20 @@ namespace chisel_hip {
 // launch of the 4-agent stream, where a chunk is seen by 4-5 of the frames: the choice also asks for >= 6 frames per item on average.
 #ifndef INTEGRATE_FINE_BELOW
 #define INTEGRATE_FINE_BELOW 1280  // work items (16^3 chunks; scaled by voxels per chunk) below which a launch of >= 4 frames runs with 2 voxels per lane
+#endif
+
+// Round-3 instruction-count work, each switchable for A/B builds (all on by default):
+#ifndef OPT_INSIDE
+#define OPT_INSIDE 1     // chunks whose voxels all project onto the image (WI_INSIDE): no per-voxel image tests, offset by one mad
+#endif
+#ifndef OPT_ENDZ
+#define OPT_ENDZ 1       // camera-z extrema of a quad from its two end voxels (z is monotone along x)
+#endif
+#ifndef OPT_CARVESKIP
+#define OPT_CARVESKIP 1  // no carve (band) verdicts in wave-frames where no lane's z interval reaches the carve (band) region
+#endif
+#ifndef OPT_COLOR2
+#define OPT_COLOR2 1     // colour sample: bytes converted where they lie (no swizzle), one fma less per channel, clamp by min
 #endif
 
 constexpr int QUEUE_STRIDE = 32;  // ints between two queue heads (one 128-byte line each)
@@ -65,11 +87,12 @@ struct Geom {
     static constexpr int LAYER_QUADS = QX * N;       // quads per z-layer
     static constexpr int WPC = QUADS / 64;           // wave units per chunk at 4 voxels per lane: 2 (8^3), 16 (16^3), 128 (32^3)
     static_assert(QUADS % 64 == 0, "whole waves");
-    static constexpr int BLOCK = 256;
-    static constexpr int GRID = 256 * INTEGRATE_BLOCKS_PER_CU;  // persistent grid: what is resident at once
-    static constexpr int GRID_STEP = (2 * WPC > 32) ? 2 * WPC : 32;  // blocks: every XCD's share of the first round is whole chunks
+    static constexpr int WPB = INTEGRATE_WPB;         // waves per workgroup
+    static constexpr int BLOCK = 64 * WPB;
+    static constexpr int GRID = 256 * INTEGRATE_BLOCKS_PER_CU * (4 / WPB);  // persistent grid: what is resident at once
+    static constexpr int GRID_STEP = (8 * WPC / WPB > 32) ? 8 * WPC / WPB : 32;  // blocks: every XCD's share of the first round is whole chunks
     static_assert(GRID % GRID_STEP == 0, "the statically dealt units are whole chunks");
-    static_assert(GRID <= INTEGRATE_MAX_GRID, "per-workgroup counter rows");
+    static_assert(WPB == 1 || WPB == 2 || WPB == 4, "waves per workgroup");
     static_assert(INTEGRATE_GRID_CAP % GRID_STEP == 0, "largest grid");
 };
 
@@ -169,7 +192,16 @@ __device__ __attribute__((noinline)) int claim_slot(const MapView *__restrict__ 
 }
 
 template <int N, bool COLOR, bool SAMECAM, int VPL>
-__global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(IntegrateParams P, MapView M, const MapView *__restrict__ Mc,
+#ifndef INTEGRATE_WAVES2
+#define INTEGRATE_WAVES2 8  // the instantiations with 2 voxels per lane need 56 vector registers: eight waves per SIMD once the compiler also keeps
+                            // to the 80 scalar registers that go with them (it derives that cap from this bound; 14 cold values go to lanes of a vector register)
+#endif
+#ifdef INTEGRATE_SGPRS
+#define INTEGRATE_SGPR_ATTR __attribute__((amdgpu_num_sgpr(INTEGRATE_SGPRS)))
+#else
+#define INTEGRATE_SGPR_ATTR
+#endif
+__global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : INTEGRATE_WAVES)) INTEGRATE_SGPR_ATTR void integrate_kernel(IntegrateParams P, MapView M, const MapView *__restrict__ Mc,
                                                                           const WorkItem *__restrict__ items,
                                                                           const FrameBox *__restrict__ boxes, ItemSync *sync,
                                                                           const int *__restrict__ work_count, int *queues,
@@ -184,7 +216,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
     // footprint of "its" chunks only -- and every XCD gets the same mix of expensive and cheap chunks.
     const int nb = (int)gridDim.x;  // multiple of 8 and of 2 * WPC
     const int xcd = (int)blockIdx.x & 7;
-    const int local_unit = ((int)blockIdx.x >> 3) * 4 + wave;  // this wave among its XCD's
+    const int local_unit = ((int)blockIdx.x >> 3) * G::WPB + wave;  // this wave among its XCD's
     int n_items = *work_count;
     if (n_items > max_items) n_items = max_items;
     const int total = n_items * G::WPC;
@@ -198,7 +230,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
         report[2] = n_items;
         report[3] = pairs;
     }
-    const int grid_waves = nb * 4;
+    const int grid_waves = nb * G::WPB;
     const int rem_chunks = n_items - grid_waves / G::WPC;  // chunks behind the statically dealt ones
     const IntegratorParams &ip = P.ip;
     unsigned t_sdf = 0, t_col = 0, t_colsat = 0, t_probe = 0, t_carved = 0;  // per lane; summed over the wave when it retires
@@ -282,7 +314,10 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
             // nothing to read); DCHG / CCHG: they differ from memory
             constexpr unsigned HAVE = 1u, HAVEC = 2u, DCHG = 4u, CCHG = 8u;
             unsigned st = existed ? 0u : (HAVE | HAVEC);
-            const size_t vbase = (size_t)(existed ? slot : 0) * G::V + VPL * (size_t)q;
+            // voxel addresses as a wave-uniform base (the slot: scalar registers) plus a 32-bit lane offset (one vector register
+            // instead of three 64-bit addresses)
+            const size_t slot_base = (size_t)(existed ? slot : 0) * G::V;
+            const unsigned lane_off = (unsigned)(VPL * q);
             unsigned bm = 0u, cm = 0u;  // frames in which this wave integrated / changed a voxel (wave-uniform)
             int carve_v = 0;            // lane k: this wave's carve tests of frame k (items without a slot)
 
@@ -315,10 +350,13 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     dx[j] = wx[j] - C.t[0];
                     pcz[j] = C.R[2] * dx[j] + s2;
                 }
-                const float zlo = VPL == 4 ? fminf(fminf(pcz[0], pcz[1]), fminf(pcz[VPL - 2], pcz[VPL - 1])) : fminf(pcz[0], pcz[1]);
-                const float zhi = VPL == 4 ? fmaxf(fmaxf(pcz[0], pcz[1]), fmaxf(pcz[VPL - 2], pcz[VPL - 1])) : fmaxf(pcz[0], pcz[1]);
+                // z is monotone along the quad: wx[j] grows with j, and subtracting a constant, multiplying by a constant and adding a
+                // constant are each monotone (weakly, after rounding) -- the extrema sit at the end voxels
+                const float zlo = (VPL == 4 && !OPT_ENDZ) ? fminf(fminf(pcz[0], pcz[1]), fminf(pcz[VPL - 2], pcz[VPL - 1])) : fminf(pcz[0], pcz[VPL - 1]);
+                const float zhi = (VPL == 4 && !OPT_ENDZ) ? fmaxf(fmaxf(pcz[0], pcz[1]), fmaxf(pcz[VPL - 2], pcz[VPL - 1])) : fmaxf(pcz[0], pcz[VPL - 1]);
                 const bool may_band = (zhi > z_near) & (zlo < z_far);
-                const bool need = may_band | (zlo < z_carve);
+                const bool may_carve = zlo < z_carve;
+                const bool need = may_band | may_carve;
                 // Branches below are wave-uniform (__any) and the lanes are predicated, so that the counters stay scalar.
                 // From here on a lane's verdicts live in vector registers -- bit masks over its four voxels, per-lane counters that
                 // are summed over the wave once, when the wave retires -- and branches are wave-uniform (__any): the scalar unit
@@ -331,12 +369,12 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     FSTAMP(0, (int)need);
                     // the quad's state, at the first frame that can touch it (straight into the tuples: no use, no wait)
                     if (need && !(st & HAVE)) {
-                        s4 = *reinterpret_cast<const QuadF *>(M.sdf + vbase);
-                        w4 = *reinterpret_cast<const QuadF *>(M.wgt + vbase);
+                        s4 = *reinterpret_cast<const QuadF *>((M.sdf + slot_base) + lane_off);
+                        w4 = *reinterpret_cast<const QuadF *>((M.wgt + slot_base) + lane_off);
                         st |= HAVE;
                     }
                     if (COLOR && need && may_band && !(st & HAVEC)) {
-                        c4 = *reinterpret_cast<const QuadU *>(M.rgbw + vbase);
+                        c4 = *reinterpret_cast<const QuadU *>((M.rgbw + slot_base) + lane_off);
                         st |= HAVEC;
                     }
                     const float s0 = C.R[3] * dy + C.R[6] * dz;
@@ -363,6 +401,21 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                     unsigned off[VPL];
                     PixelRec r[VPL];
                     float zn[VPL];  // camera z, or -1 for a quad this frame cannot touch
+                    if (OPT_INSIDE && (flags & WI_INSIDE)) {  // wave-uniform
+                        // Every voxel of the chunk lies in front of the camera and projects onto the image (cull_chunk_frame): the three
+                        // tests hold, the offset is row * row_bytes + (col + 1) * 8.  A lane this frame cannot touch (`need`, from the cull
+                        // kernel's conservative bounds: its verdicts would fail anyway) reads the NaN record instead of a pixel.
+                        const unsigned nm = need ? 0xffffffffu : 0u;
+#pragma unroll
+                        for (int j = 0; j < VPL; j++) {
+                            const float pcx = C.R[0] * dx[j] + s0, pcy = C.R[1] * dx[j] + s1;
+                            const float u = C.fx * pcx * inv_z[j] + C.cx;
+                            const float v = C.fy * pcy * inv_z[j] + C.cy;
+                            const unsigned iu = (unsigned)floor_to_int(u), iv = (unsigned)floor_to_int(v);
+                            off[j] = (__umul24(iv, row_bytes) + ((iu << 3) + 8u)) & nm;
+                            r[j] = *reinterpret_cast<const PixelRec *>(rec_base + off[j]);
+                        }
+                    } else {
 #pragma unroll
                     for (int j = 0; j < VPL; j++) zn[j] = need ? pcz[j] : -1.0f;
 #pragma unroll
@@ -381,11 +434,27 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                         r[j] = *reinterpret_cast<const PixelRec *>(rec_base + off[j]);
 #endif
                     }
+                    }
                     FSTAMP(1, off[VPL - 1]);
                     // ---- band tests: bit j of bandm / carvem = voxel j takes the in-band / the carve branch -------------------------
                     // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail.
                     float sd[VPL];
                     unsigned bandm = 0u, carvem = 0u;
+#if OPT_CARVESKIP
+                    // No lane's z interval reaches the carve region (the band) of this frame -- bounds from the cull kernel, conservative:
+                    // the tests would fail for every voxel -- : the verdict stays 0 without the compares.
+#pragma unroll
+                    for (int j = 0; j < VPL; j++) sd[j] = r[j].x - pcz[j];                              // surfaceDist :79 / :139
+                    if (__any(may_band)) {
+#pragma unroll
+                        for (int j = 0; j < VPL; j++) bandm |= (fabsf(sd[j]) < r[j].y + ip.diag) ? (1u << j) : 0u;  // :81 / :144
+                    }
+                    if (__any(may_carve)) {  // (z_carve is -inf when carving is off)
+#pragma unroll
+                        for (int j = 0; j < VPL; j++) carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;  // :86 / :164 (else branch)
+                        carvem &= ~bandm;
+                    }
+#else
 #pragma unroll
                     for (int j = 0; j < VPL; j++) {
                         sd[j] = r[j].x - pcz[j];                                                        // surfaceDist :79 / :139
@@ -393,6 +462,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                         carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;                  // :86 / :164 (else branch)
                     }
                     carvem = ip.carving ? (carvem & ~bandm) : 0u;
+#endif
                     FSTAMP(2, bandm | carvem);
                     t_sdf += (unsigned)__popc(bandm);
 #ifdef CHISEL_PHASES
@@ -421,6 +491,7 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                         // colour first: the pixels of the in-band voxels whose colour weight is below 8 are requested now (one 4-byte
                         // gather per voxel, all in flight) and consumed after the sdf arithmetic
                         unsigned cw[VPL], csh[VPL];
+                        unsigned lastm = 0u;  // OPT_COLOR2: bit j = the word of voxel j was read one byte low (last pixel of a 3-channel image)
                         int cpix[VPL];
                         unsigned freshm = 0u;  // bit j: voxel j takes a colour sample
                         const bool word_gather = COLOR && F.color_channels >= 3;  // wave-uniform
@@ -440,7 +511,18 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                             freshm &= hasm;
                             t_col += (unsigned)__popc(freshm);
                             if (!SAMECAM) t_colsat += (unsigned)__popc(hasm & ~freshm);  // one camera: colsat = sdf - col
-                            if (word_gather && __any(freshm != 0u)) {
+                            if (OPT_COLOR2 && word_gather && __any(freshm != 0u)) {
+                                // (the shift of the image's last pixel is kept as one bit per voxel: the words stay in registers
+                                // through the sdf arithmetic, four shift counts beside them cost the kernel a wave per SIMD)
+                                const unsigned last_word = image_bytes - 4u;
+                                lastm = 0u;
+#pragma unroll
+                                for (int j = 0; j < VPL; j++) {
+                                    unsigned sh;
+                                    cw[j] = color_gather2(F.color, ((freshm >> j) & 1u) ? (unsigned)cpix[j] : 0u, (unsigned)F.color_channels, last_word, sh);
+                                    lastm |= sh ? (1u << j) : 0u;
+                                }
+                            } else if (word_gather && __any(freshm != 0u)) {
 #pragma unroll
                                 for (int j = 0; j < VPL; j++)
 #ifdef CHISEL_ABLATE_GATHER
@@ -469,13 +551,17 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                             const bool in_band = ((bandm >> j) & 1u) != 0u;
                             f4(s4, j) = in_band ? ns : f4(s4, j);
                             f4(w4, j) = in_band ? nw : f4(w4, j);
+#ifdef OPT_SERIAL_DIV
+                            __builtin_amdgcn_sched_barrier(0);  // one voxel's division at a time: its temporaries are not kept four times over
+#endif
                         }
                         st |= bandm ? DCHG : 0u;
                         if (COLOR && __any(freshm != 0u)) {
                             if (word_gather) {
 #pragma unroll
                                 for (int j = 0; j < VPL; j++) {
-                                    const unsigned nc = color_integrate_fresh(u4(c4, j), color_word(cw[j], csh[j]));
+                                    const unsigned nc = OPT_COLOR2 ? color_integrate_fresh_bgr(u4(c4, j), cw[j] >> (((lastm >> j) & 1u) * 8u))
+                                                                   : color_integrate_fresh(u4(c4, j), color_word(cw[j], csh[j]));
                                     u4(c4, j) = ((freshm >> j) & 1u) ? nc : u4(c4, j);
                                 }
                             } else {  // 1 / 2 channel images
@@ -556,12 +642,12 @@ __global__ __launch_bounds__(256, INTEGRATE_WAVES) void integrate_kernel(Integra
                 if (slot < 0) break;  // never integrated here, or no slot left (error raised)
             }
             {
-                const size_t v = (size_t)slot * G::V + VPL * (size_t)q;
+                const size_t out_base = (size_t)slot * G::V;  // wave-uniform
                 if (st & DCHG) {
-                    *reinterpret_cast<QuadF *>(M.sdf + v) = s4;
-                    *reinterpret_cast<QuadF *>(M.wgt + v) = w4;
+                    *reinterpret_cast<QuadF *>((M.sdf + out_base) + lane_off) = s4;
+                    *reinterpret_cast<QuadF *>((M.wgt + out_base) + lane_off) = w4;
                 }
-                if (COLOR && (st & CCHG)) *reinterpret_cast<QuadU *>(M.rgbw + v) = c4;
+                if (COLOR && (st & CCHG)) *reinterpret_cast<QuadU *>((M.rgbw + out_base) + lane_off) = c4;
             }
             if (cm) {
                 // "needsUpdate" of the chunk per frame (Chisel.h:85 / :167): each frame counts once per chunk -- by the wave

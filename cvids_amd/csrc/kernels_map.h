@@ -421,6 +421,10 @@ __global__ void kat_color_fresh_kernel(unsigned *mismatches) {
                                                (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16));
     const unsigned want_bits = (unsigned)want.x | ((unsigned)want.y << 8) | ((unsigned)want.z << 16) | ((unsigned)want.w << 24);
     if (got != want_bits) atomicAdd(mismatches, 1u);
+    // and the form the integration kernel uses: the new colour as the pixel's bytes lie in memory (blue, green, red[, alpha])
+    const unsigned got2 = color_integrate_fresh_bgr((unsigned)c.x | ((unsigned)c.y << 8) | ((unsigned)c.z << 16) | ((unsigned)c.w << 24),
+                                                    (unsigned)b | ((unsigned)g << 8) | ((unsigned)r << 16) | ((i * 2654435761u) & 0xff000000u));
+    if (got2 != want_bits) atomicAdd(mismatches, 1u);
 }
 // exhaustive: reciprocal_in_range(z) against the IEEE division 1.0f / z for every float in [FASTZ_MIN, FASTZ_MAX]
 // (81 binades x 2^23 mantissas); counts the mismatches and keeps one offending input

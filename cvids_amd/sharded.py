@@ -246,18 +246,33 @@ class ShardedChisel:
                                                        None if cols is None else (cols if dev.type == "cuda" else cols.numpy())),
                                      pose, truncation, max_dist)
 
-    def UpdateMeshes(self, force=False):
+    def _all_to_all(self, out, inp, n_recv, n_send):
+        """all_to_all_single; gloo has no device all-to-all: functional check only, bounced through the host"""
+        dist = self.x.dist
+        if dist.get_backend() == "gloo" and inp.is_cuda:
+            o = self.x.torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), n_recv, n_send)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, n_recv, n_send)
+
+    def UpdateMeshes(self, force=False, ids=None):
         """Chisel::UpdateMeshes of the sharded map: every rank ends up with the meshes of the chunks it owns (mesh_plan above).
-        The id lists travel as objects (small); the halo chunks as one all-to-all per voxel array on device tensors."""
+        The id lists travel as objects (small); the halo chunks as one all-to-all per voxel array on device tensors.
+        ids: mesh these chunks (every rank passes ids of its own choice, the union is meshed) instead of meshesToUpdate.
+        -> bytes of ghost voxels this rank received"""
         from .chisel import chunk_owner
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
-            return
+            return 0
         dist, world, rank = self.x.dist, self.x.world, self.x.rank
-        mine = [tuple(i) for i in self.map.GetMeshesToUpdate().tolist()]
+        mine = [tuple(int(v) for v in i) for i in (self.map.GetMeshesToUpdate() if ids is None else np.asarray(ids).reshape(-1, 3)).tolist()]
         if world == 1:
-            self.map.UpdateMeshes(force=True)
-            return
+            if ids is None:
+                self.map.UpdateMeshes(force=True)
+            else:
+                self.map.UpdateMeshesOf(mine)
+            return 0
         lists = [None] * world
         dist.all_gather_object(lists, mine)
         union = set()
@@ -288,13 +303,13 @@ class ShardedChisel:
         sdf_r = torch.empty((total,) + tuple(sdf_s.shape[1:]), dtype=torch.float32, device=dev)
         wgt_r = torch.empty((total,) + tuple(wgt_s.shape[1:]), dtype=torch.float32, device=dev)
         found_r = torch.empty((total,), dtype=torch.int32, device=dev)
-        dist.all_to_all_single(sdf_r, sdf_s, n_recv, n_send)
-        dist.all_to_all_single(wgt_r, wgt_s, n_recv, n_send)
-        dist.all_to_all_single(found_r, found_s, n_recv, n_send)
+        self._all_to_all(sdf_r, sdf_s, n_recv, n_send)
+        self._all_to_all(wgt_r, wgt_s, n_recv, n_send)
+        self._all_to_all(found_r, found_s, n_recv, n_send)
         col_r = None
         if col_s is not None:
             col_r = torch.empty((total,) + tuple(col_s.shape[1:]), dtype=torch.uint8, device=dev)
-            dist.all_to_all_single(col_r, col_s, n_recv, n_send)
+            self._all_to_all(col_r, col_s, n_recv, n_send)
         if on_gpu:
             torch.cuda.current_stream(dev).synchronize()  # the map imports on its own stream
         if total:
@@ -305,6 +320,7 @@ class ShardedChisel:
                 self.map.ImportGhostChunks(flat_recv, sdf_r.numpy(), wgt_r.numpy(), None if col_r is None else col_r.numpy(), found_h)
         self.map.UpdateMeshesOf(jobs)
         self.map.DropGhostChunks()
+        return int(sdf_r.numel() * 4 + wgt_r.numel() * 4 + (col_r.numel() if col_r is not None else 0))
 
     def NumChunks(self):
         torch, dist = self.x.torch, self.x.dist

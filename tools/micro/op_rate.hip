@@ -49,6 +49,21 @@ KERNEL(k_fmac, "v_fmac_f32 %0, %1, %2", "+v"(x[i]) : "v"(a), "v"(b))
 KERNEL(k_sub, "v_sub_f32 %0, %0, %1", "+v"(x[i]) : "v"(a))
 KERNEL(k_divfix, "v_div_fixup_f32 %0, %0, %1, %2", "+v"(x[i]) : "v"(a), "v"(b))
 KERNEL(k_divfmas, "v_div_fmas_f32 %0, %0, %1, %2", "+v"(x[i]) : "v"(a), "v"(b) : "vcc")
+KERNEL(k_floor, "v_floor_f32 %0, %0", "+v"(x[i]) :)
+KERNEL(k_cvt_u, "v_cvt_u32_f32 %0, %1", "=v"(u[i]) : "v"(x[i]))
+KERNEL(k_cvtpk8, "v_cvt_pk_u8_f32 %0, %1, 1, %0", "+v"(u[i]) : "v"(x[i]))
+KERNEL(k_lshladd, "v_lshl_add_u32 %0, %0, 3, %1", "+v"(u[i]) : "v"(8u))
+KERNEL(k_lshlor, "v_lshl_or_b32 %0, %0, 3, %1", "+v"(u[i]) : "v"(8u))
+KERNEL(k_min3, "v_min3_f32 %0, %0, %1, %2", "+v"(x[i]) : "v"(a), "v"(b))
+KERNEL(k_med3, "v_med3_f32 %0, %0, %1, %2", "+v"(x[i]) : "v"(a), "v"(b))
+KERNEL(k_mullo, "v_mul_lo_u32 %0, %0, %1", "+v"(u[i]) : "v"(3u))
+KERNEL(k_xor, "v_xor_b32 %0, %0, %1", "+v"(u[i]) : "v"(0x7fc00000u))
+KERNEL(k_cmpabs, "v_cmp_lt_f32 vcc, |%0|, %1", : "v"(x[i]), "v"(a) : "vcc")
+KERNEL(k_bcnt, "v_bcnt_u32_b32 %0, %1, %0", "+v"(u[i]) : "v"(0xf0fu))
+KERNEL(k_andor, "v_and_or_b32 %0, %0, %1, %2", "+v"(u[i]) : "v"(0xffu), "v"(0x100u))
+KERNEL(k_bfi, "v_bfi_b32 %0, %1, %0, %2", "+v"(u[i]) : "v"(0xff00u), "v"(0x100u))
+KERNEL(k_fma_lit, "v_fma_f32 %0, %0, %1, 0.5", "+v"(x[i]) : "v"(a))
+KERNEL(k_add_s, "v_add_f32 %0, %1, %0", "+v"(x[i]) : "s"(a))
 KERNEL(k_divscale, "v_div_scale_f32 %0, vcc, %0, %1, %2", "+v"(x[i]) : "v"(a), "v"(b) : "vcc")
 template <typename K>
 void run(const char *name, K k, float *out) {
@@ -71,6 +86,7 @@ int main() {
 #define R(k) run(#k, k, out);
     R(k_mul) R(k_fma) R(k_fmac) R(k_sub) R(k_mul_s) R(k_min) R(k_max3) R(k_mov) R(k_and) R(k_or) R(k_addu) R(k_lshl) R(k_mul24) R(k_mad24) R(k_add3)
     R(k_bfe) R(k_perm) R(k_cvt_fu) R(k_cvt_flr) R(k_cvt_ub) R(k_rcp) R(k_cmp_vcc) R(k_cmp_sg) R(k_cmp_u) R(k_cnd_vcc) R(k_cnd_sg) R(k_rfl)
+    R(k_floor) R(k_cvt_u) R(k_cvtpk8) R(k_lshladd) R(k_lshlor) R(k_min3) R(k_med3) R(k_mullo) R(k_xor) R(k_cmpabs) R(k_bcnt) R(k_andor) R(k_bfi) R(k_fma_lit) R(k_add_s)
     R(k_divscale) R(k_divfmas) R(k_divfix)
     return 0;
 }
