@@ -115,18 +115,34 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     child = subprocess.Popen(cmd, env=env, start_new_session=True)
-    try:
-        rc = child.wait(timeout=args.launch_timeout)
-    except subprocess.TimeoutExpired:
-        print("bench.py: the %d-rank run did not finish within %.0f s: killing it" % (args.gpus, args.launch_timeout), file=sys.stderr)
+
+    def kill_tree():
+        # the launcher puts every rank into a process group of its own: walk the tree (exact pids, never a pattern)
+        victims = []
+        try:
+            import psutil
+            victims = psutil.Process(child.pid).children(recursive=True)
+        except Exception:
+            pass
+        for p in victims:
+            try:
+                p.send_signal(signal.SIGKILL)
+            except Exception:
+                pass
         try:
             os.killpg(child.pid, signal.SIGKILL)
         except ProcessLookupError:
             pass
+
+    try:
+        rc = child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d-rank run did not finish within %.0f s: killing it" % (args.gpus, args.launch_timeout), file=sys.stderr)
+        kill_tree()
         child.wait()
         rc = 124
     except KeyboardInterrupt:
-        os.killpg(child.pid, signal.SIGKILL)
+        kill_tree()
         raise
     sys.exit(rc)
 

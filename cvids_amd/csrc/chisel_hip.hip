@@ -682,6 +682,13 @@ int integrate_frames(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fra
         if (rc) return rc;
     }
     const int kmax = std::max(1, std::min(max_group, KMAX));
+    // chisel_hip_wait_event covers every frame of this call: each launch set waits for it (a later set's front half runs on the
+    // other auxiliary stream and is not ordered behind the first set's pyramid kernel)
+    const hipEvent_t call_input = m->input_event;
+    struct Disarm {
+        chisel_hip_map *m;
+        ~Disarm() { m->input_event = nullptr; }
+    } disarm{m};
     int i = 0;
     while (i < n) {
         // the run of frames of one image size, cut into launch sets of equal length (10 frames: 5 + 5, not 8 + 2)
@@ -690,6 +697,7 @@ int integrate_frames(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fra
         int sets = (run + kmax - 1) / kmax;
         while (run > 0) {
             const int g = (run + sets - 1) / sets;
+            m->input_event = call_input;
             int rc = integrate_group(m, g, frames + i, colors ? colors + i : nullptr);
             if (rc) return rc;
             i += g;
@@ -990,7 +998,11 @@ int chisel_hip_set_stream(chisel_hip_map *m, void *s) {
 }
 
 int chisel_hip_wait_event(chisel_hip_map *m, void *ev) {
-    if (m && m->is_group) return group::for_all(m, [&](chisel_hip_map *s) { return chisel_hip_wait_event(s, ev); });
+    if (m && m->is_group) {  // kept on the group: every launch set of the next integrate call re-arms its shards with it (group::integrate)
+        if (!ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+        m->input_event = (hipEvent_t)ev;
+        return CHISEL_HIP_OK;
+    }
     if (!m || !ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     m->input_event = (hipEvent_t)ev;
     return CHISEL_HIP_OK;

@@ -116,6 +116,9 @@ int device_of(const void *p, int fallback) {
 // n <= KMAX frames of one image size to every shard
 int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors) {
     std::vector<Stage> &st = *static_cast<std::vector<Stage> *>(g->stages);
+    // test hook: device frames take the staging path (peer copy on the copy stream, event hand-over) even when they already live on the
+    // shard's device -- the box the tests run on has one GPU
+    static const bool force_stage = getenv("CHISEL_HIP_GROUP_FORCE_STAGE") != nullptr;
     const size_t npx = (size_t)frames[0].width * frames[0].height;
     size_t cbytes = 0;
     if (colors)
@@ -127,8 +130,8 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
         if (colors) c.assign(colors, colors + n);
         bool foreign = false;
         for (int k = 0; k < n; k++) {
-            foreign |= f[k].on_device && device_of(f[k].depth, s->device) != s->device;
-            if (colors) foreign |= c[k].on_device && device_of(c[k].color, s->device) != s->device;
+            foreign |= f[k].on_device && (force_stage || device_of(f[k].depth, s->device) != s->device);
+            if (colors) foreign |= c[k].on_device && (force_stage || device_of(c[k].color, s->device) != s->device);
         }
         Stage &S = st[i];
         int b = -1;
@@ -159,10 +162,13 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
             }
             b = (int)(S.turn++ & 1u);
             if (S.armed[b]) HIP_TRY(hipStreamWaitEvent(S.copy, S.consumed[b], 0));  // the batch that last used this set has been integrated
+            // the caller's event (chisel_hip_wait_event on the group) guards the frames the peer copies read; the shard itself then
+            // waits for the copies (S.ready below), which orders it behind the caller's event as well
+            if (s->input_event) HIP_TRY(hipStreamWaitEvent(S.copy, s->input_event, 0));
             for (int k = 0; k < n; k++) {
                 if (f[k].on_device) {
                     const int src = device_of(f[k].depth, s->device);
-                    if (src != s->device) {
+                    if (src != s->device || force_stage) {
                         float *dst = S.depth[b] + (size_t)k * S.depth_elems;
                         HIP_TRY(hipMemcpyPeerAsync(dst, s->device, f[k].depth, src, npx * sizeof(float), S.copy));
                         f[k].depth = dst;
@@ -170,7 +176,7 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
                 }
                 if (colors && c[k].on_device) {
                     const int src = device_of(c[k].color, s->device);
-                    if (src != s->device) {
+                    if (src != s->device || force_stage) {
                         uint8_t *dst = S.color[b] + (size_t)k * S.color_bytes;
                         HIP_TRY(hipMemcpyPeerAsync(dst, s->device, c[k].color, src, (size_t)c[k].width * c[k].height * c[k].channels, S.copy));
                         c[k].color = dst;
@@ -195,15 +201,19 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
 // frames in order; consecutive frames of one image size go out KMAX at a time (as integrate_frames cuts them for one map)
 int integrate(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors) {
     if (n < 0 || (n > 0 && !frames)) return fail(CHISEL_HIP_ERR_INVALID, "bad frame list");
-    int i = 0;
-    while (i < n) {
+    // chisel_hip_wait_event on the group: the event covers every frame of this call, so every launch set arms its shards with it
+    const hipEvent_t call_input = g->input_event;
+    g->input_event = nullptr;
+    int i = 0, rc = CHISEL_HIP_OK;
+    while (i < n && !rc) {
         int run = 1;
         while (i + run < n && run < KMAX && frames[i + run].width == frames[i].width && frames[i + run].height == frames[i].height) run++;
-        const int rc = integrate_set(g, run, frames + i, colors ? colors + i : nullptr);
-        if (rc) return rc;
+        for (chisel_hip_map *s : g->shards) s->input_event = call_input;
+        rc = integrate_set(g, run, frames + i, colors ? colors + i : nullptr);
         i += run;
     }
-    return CHISEL_HIP_OK;
+    for (chisel_hip_map *s : g->shards) s->input_event = nullptr;
+    return rc;
 }
 
 int integrate_cloud(chisel_hip_map *g, const chisel_hip_pointcloud *cloud) {
@@ -213,7 +223,12 @@ int integrate_cloud(chisel_hip_map *g, const chisel_hip_pointcloud *cloud) {
             if (device_of(cloud->points, s->device) != s->device)
                 return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a device-resident point cloud must live on the device of every shard of the group: pass a host cloud");
     }
-    return for_all(g, [&](chisel_hip_map *s) { return chisel_hip_integrate_pointcloud(s, cloud); });
+    const hipEvent_t call_input = g->input_event;  // chisel_hip_wait_event on the group
+    g->input_event = nullptr;
+    return for_all(g, [&](chisel_hip_map *s) {
+        s->input_event = call_input;
+        return chisel_hip_integrate_pointcloud(s, cloud);
+    });
 }
 
 int garbage_collect(chisel_hip_map *g, const int *ids, int n) {

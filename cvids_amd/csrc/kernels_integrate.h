@@ -188,6 +188,7 @@ __device__ __attribute__((noinline)) int claim_slot(const MapView *__restrict__ 
         __builtin_amdgcn_s_sleep(8);
         s = atomicOr(&sy->slot, 0);
     }
+    if (s == 1) raise_error(Mc->error_flag, 1);  // the allocating wave never published (a second, pre-empted?): the map is incomplete, say so
     return s >= 2 ? s - 2 : -1;
 }
 

@@ -1,0 +1,52 @@
+"""bench.py as the driver runs it: `python3 bench.py --gpus N ...` from a plain shell (no torchrun, no WORLD_SIZE).
+
+N = 2 on the one GPU of the test box with the gloo backend (RCCL refuses two ranks on one device): the parent process starts the
+ranks itself, the sharded map is meshed inside the timed region, and what the two shards computed together equals what one map
+computed -- voxel counters, chunks, frames."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_launched_by_bench_itself_equal_one_rank():
+    common = ["--steps", "20", "--warmup", "5", "--width", "320", "--height", "240", "--res", "0.02", "--no-cpu-baseline", "--no-roofline",
+              "--repeats", "2"]
+    one = _bench("--gpus", "1", *common)
+    two = _bench("--gpus", "2", "--dist-backend", "gloo", *common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["mesh_every"] == 10 and one["config"]["mesh_every"] == 10  # meshes inside the timed region at every N
+    assert two["sharded_meshing"]["recomputes"] > 0
+    for k in ("voxel_updates", "n_sdf", "n_col", "n_probe", "n_carved", "resident_chunks_end"):
+        assert one["per_frame"][k] == two["per_frame"][k], (k, one["per_frame"][k], two["per_frame"][k])
+    assert two["value"] > 0 and two["steps"] == 20 and two["warmup"] == 5
+
+
+def test_config5_line_carries_gc_and_full_extraction():
+    line = _bench("--gpus", "1", "--config", "5", "--steps", "8", "--warmup", "4", "--width", "320", "--height", "180", "--res", "0.02",
+                  "--trunc-scale", "2.0", "--no-roofline", "--repeats", "1")
+    assert line["config"]["baseline_config"] == 5 and "garbage collection" in line["config"]["end_of_region"]
+    assert line["cpu_baseline"]["value"] is None and "infeasible" in line["cpu_baseline"]["sample"]
+    assert line["value"] > 0
+
+
+def test_a_hung_rank_is_killed_and_reported():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--launch-timeout", "1",
+                          "--steps", "20", "--warmup", "5"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=90)
+    assert out.returncode == 124 and "killing it" in out.stderr

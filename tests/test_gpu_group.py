@@ -123,3 +123,46 @@ def test_group_through_the_cpp_facade(oracle_mod, tmp_path):
         got[cid] = (sw[:, 0].copy(), sw[:, 1].copy(), b[12 + V * 8:].reshape(V, 4).copy())
     compare_fields(om.fields(), got, V, True, what="facade over a group")
     assert ("map: %d chunks written" % om.num_chunks()) in out.stdout and "SaveMesh ok" in out.stdout
+
+
+def test_group_staging_path_waits_for_the_callers_event(oracle_mod):
+    """Device frames that a shard has to stage (peer copy on its copy stream): the copies wait for the event given to
+    chisel_hip_wait_event, every launch set of the call does.  One GPU here, so the hook CHISEL_HIP_GROUP_FORCE_STAGE sends
+    same-device frames down that path (run in a child process: the hook is read once per process)."""
+    code = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import oracle
+from cvids_amd import chisel as ch, synth
+from tests.common import compare_fields, make_frames, small_camera
+N, res, W, H = 8, 0.05, 64, 48
+cam = small_camera(W, H)
+intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+color = synth.render_color(W, H, 3)
+frames = make_frames("sphere_room", 20, W, H, agents=2, nan_fraction=0.02)   # 40 frames: three launch sets
+om = oracle.OracleMap(N, res, True)
+om.set_integrator(oracle.TRUNC_INVERSE, 2.0, 1.0, True, 0.05)
+integ = ch.ProjectionIntegrator(ch.InverseTruncator(2.0), ch.ConstantWeighter(1.0), 0.05, True)
+for d, p in frames:
+    om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+dev = torch.device("cuda:0")
+grp = ch.Chisel((N,) * 3, res, True, max_chunks=8192, devices=[0, 0, 0])
+src = torch.from_numpy(np.stack([d for d, _ in frames])).to(dev)
+c_dev = torch.from_numpy(color).to(dev)
+buf = torch.full((len(frames), H, W), float("nan"), dtype=torch.float32, device=dev)
+producer = torch.cuda.Stream(device=dev)
+ready = torch.cuda.Event()
+torch.cuda.synchronize()
+with torch.cuda.stream(producer):
+    torch.cuda._sleep(20_000_000)
+    buf.copy_(src, non_blocking=True)
+    ready.record(producer)
+grp.wait_event(ready.cuda_event)
+grp.IntegrateBatch(integ, [(buf[j], p, cam) for j, (_, p) in enumerate(frames)], [(c_dev, p, cam) for _, p in frames])
+assert grp.NumChunks() == om.num_chunks(), (grp.NumChunks(), om.num_chunks())
+compare_fields(om.fields(), grp.fields(), om.V, True, what="staged group")
+print("staged ok")
+""" % ROOT
+    env = dict(os.environ, CHISEL_HIP_GROUP_FORCE_STAGE="1", CHISEL_HIP_FORCE_PIPELINE="1")
+    out = subprocess.run([os.sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "staged ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -554,6 +554,37 @@ def test_event_ordered_device_frames(oracle_mod):
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+def test_event_ordered_device_frames_of_a_call_cut_into_several_launch_sets(oracle_mod, monkeypatch):
+    """One chisel_hip_integrate_batch call of 40 device frames = three launch sets whose front halves alternate between the two
+    auxiliary streams: the event of chisel_hip_wait_event must hold back every one of them, not only the first (the frames arrive
+    about 10 ms after the call has been issued)."""
+    import torch
+    monkeypatch.setenv("CHISEL_HIP_FORCE_PIPELINE", "1")
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+    frames = make_frames("sphere_room", 20, 64, 48, agents=2, nan_fraction=0.02)
+    assert len(frames) == 40
+    for d, p in frames:
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(np.stack([d for d, _ in frames])).to(dev)
+    c_dev = torch.from_numpy(color).to(dev)
+    buf = torch.full((40, 48, 64), float("nan"), dtype=torch.float32, device=dev)  # until the producer has run: no valid pixel
+    producer = torch.cuda.Stream(device=dev)
+    ready = torch.cuda.Event()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(producer):
+        torch.cuda._sleep(20_000_000)
+        buf.copy_(src, non_blocking=True)
+        ready.record(producer)
+    gm.wait_event(ready.cuda_event)
+    gm.IntegrateBatch(integ, [(buf[j], p, cam) for j, (_, p) in enumerate(frames)], [(c_dev, p, cam) for _, p in frames])
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+
+
 @pytest.mark.parametrize("N,res,W,H", [(16, 0.04, 96, 72), (32, 0.02, 64, 48)])
 def test_batched_launch_chunk_sizes(oracle_mod, N, res, W, H):
     om, gm, integ = _mk(oracle_mod, N, res, True, max_chunks=2048)
