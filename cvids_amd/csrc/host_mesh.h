@@ -25,9 +25,9 @@ void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena,
     const int max_jobs = std::min(MESH_INFO_PREFETCH, B.capacity), seq = m->mesh_seq;
     const dim3 grid(4096), block(MESH_TRI_BLOCK);  // persistent: the number of triangles is read on the device
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
-        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
-        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
     }
 }
 
@@ -152,9 +152,9 @@ void launch_mesh_count(chisel_hip_map *m) {
     ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
     const dim3 grid(2048);
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.tri_capacity, B.flags); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.tri_capacity, B.flags); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.tri_capacity, B.flags); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags); break;
     }
 }
 
@@ -171,6 +171,7 @@ int recompute_meshes(chisel_hip_map *m) {
     if (!B.tris) {
         B.tri_capacity = std::max(B.tri_capacity, m->mesh_tiny ? 256 : 1 << 20);
         HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
+        HIP_TRY(hipMalloc(&B.corners, (size_t)B.tri_capacity * sizeof(CubeCorners)));
     }
     // an arena record and a buffer that should do: twice what the previous recompute needed
     int arena_id = -1;
@@ -251,9 +252,12 @@ int check_mesh_totals(chisel_hip_map *m) {
         // the triangle list was too small: grow it to what this batch needs and list again (dirty flags are not read by the count)
         HIP_TRY(hipStreamSynchronize(m->stream));
         HIP_TRY(hipFree(B.tris));
+        HIP_TRY(hipFree(B.corners));
         B.tris = nullptr;
+        B.corners = nullptr;
         while (B.tri_capacity < totals[MT_TRIS]) B.tri_capacity *= 2;
         HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
+        HIP_TRY(hipMalloc(&B.corners, (size_t)B.tri_capacity * sizeof(CubeCorners)));
         HIP_TRY(hipMemsetAsync(d_totals, 0, 3 * sizeof(int), m->stream));  // keeps MT_JOBS
         launch_mesh_count(m);
         HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));

@@ -292,31 +292,71 @@ __device__ inline float2 corner_voxel(const MapView &M, const int *nb, int cx, i
     return make_float2(M.sdf[off], M.wgt[off]);
 }
 
-// The (N+1)^3 corner voxels a chunk's cubes read -- the chunk plus one layer of its "+" neighbours -- staged once in
-// LDS as (sdf, weight) pairs (39 KiB for 16^3 chunks): every voxel is fetched from HBM once per kernel instead of
-// once per cube corner (8x).  32^3 chunks (287 KiB) do not fit and read their corners through L2.
+// The (N+1)^3 corner voxels a chunk's cubes read -- the chunk plus one layer of its "+" neighbours -- staged once in LDS:
+// every voxel is fetched from HBM once per kernel instead of once per cube corner (8x).  What the cubes need of a corner is its
+// distance and whether it has been observed (weight > 0.5: ChunkManager.cpp:271 / :352), so one float per corner carries both:
+// the distance, or NaN for "not observed" (19.6 KiB per 16^3 chunk instead of 39 KiB of (sdf, weight) pairs: four chunks per CU
+// are in flight instead of two).  [A stored distance that is itself NaN under a weight above 0.5 would read as unobserved here
+// and as a NaN vertex in the reference; integration cannot produce one: invalid depth pixels never update a voxel.]
+// The chunk's own N^3 voxels arrive as 16-byte loads (x rows are contiguous in the pool), the 3 N^2 + 3 N + 1 border corners of
+// the "+" neighbours one by one.  32^3 chunks (140 KiB) stay in L2 and fold on the fly.
 template <int N>
 struct CornerTile {
     static constexpr bool STAGED = (N <= 16);
     static constexpr int E = N + 1;
     static constexpr int SIZE = STAGED ? E * E * E : 1;
 };
+__device__ inline float fold_corner(float sdf, float weight) { return weight > 0.5f ? sdf : __builtin_nanf(""); }
 
 template <int N>
-__device__ inline void stage_corners(const MapView &M, const int *nb, float2 *s_vox) {
+__device__ inline void stage_corners(const MapView &M, const int *nb, float *s_vox) {
     if (!CornerTile<N>::STAGED) return;
-    constexpr int E = N + 1, TOTAL = E * E * E, U = (TOTAL + MESH_BLOCK_THREADS - 1) / MESH_BLOCK_THREADS;  // all of a thread's corners (2 U loads) in flight together: one round trip
-    for (int i0 = threadIdx.x; i0 < TOTAL; i0 += U * MESH_BLOCK_THREADS) {
-        float2 v[U];
+    constexpr int E = N + 1, V = N * N * N, Q = V / 4, QU = (Q + MESH_BLOCK_THREADS - 1) / MESH_BLOCK_THREADS;
+    constexpr int BORDER = E * E * E - V, BU = (BORDER + MESH_BLOCK_THREADS - 1) / MESH_BLOCK_THREADS;
+    const int self = nb[NB_SELF];
+    const float4 *sp = reinterpret_cast<const float4 *>(M.sdf + (size_t)self * V);
+    const float4 *wp = reinterpret_cast<const float4 *>(M.wgt + (size_t)self * V);
+    float4 vs[QU], vw[QU];
+    float2 vb[BU];
+    // every load of the thread is requested before the first is used: one round trip
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = min(i0 + u * MESH_BLOCK_THREADS, TOTAL - 1);
-            v[u] = corner_voxel<N>(M, nb, i % E, (i / E) % E, i / (E * E));
+    for (int u = 0; u < QU; u++) {
+        const int q = min((int)threadIdx.x + u * MESH_BLOCK_THREADS, Q - 1);
+        vs[u] = sp[q];
+        vw[u] = wp[q];
+    }
+#pragma unroll
+    for (int u = 0; u < BU; u++) {
+        // border corners in three groups: the plane cz = N (E x E, its edges included), the plane cy = N below it (E x N), the plane
+        // cx = N below both (N x N)
+        const int b = min((int)threadIdx.x + u * MESH_BLOCK_THREADS, BORDER - 1);
+        int cx, cy, cz;
+        if (b < E * E) { cx = b % E; cy = b / E; cz = N; }
+        else if (b < E * E + N * E) { const int t = b - E * E; cx = t % E; cy = N; cz = t / E; }
+        else { const int t = b - E * E - N * E; cx = N; cy = t % N; cz = t / N; }
+        vb[u] = corner_voxel<N>(M, nb, cx, cy, cz);
+    }
+#pragma unroll
+    for (int u = 0; u < QU; u++) {
+        const int q = (int)threadIdx.x + u * MESH_BLOCK_THREADS;
+        if (q < Q) {
+            const int i = 4 * q, x = i % N, y = (i / N) % N, z = i / (N * N);
+            float *d = s_vox + (z * E + y) * E + x;
+            d[0] = fold_corner(vs[u].x, vw[u].x);
+            d[1] = fold_corner(vs[u].y, vw[u].y);
+            d[2] = fold_corner(vs[u].z, vw[u].z);
+            d[3] = fold_corner(vs[u].w, vw[u].w);
         }
+    }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = i0 + u * MESH_BLOCK_THREADS;
-            if (i < TOTAL) s_vox[i] = v[u];
+    for (int u = 0; u < BU; u++) {
+        const int b = (int)threadIdx.x + u * MESH_BLOCK_THREADS;
+        if (b < BORDER) {
+            int cx, cy, cz;
+            if (b < E * E) { cx = b % E; cy = b / E; cz = N; }
+            else if (b < E * E + N * E) { const int t = b - E * E; cx = t % E; cy = N; cz = t / E; }
+            else { const int t = b - E * E - N * E; cx = N; cy = t % N; cz = t / N; }
+            s_vox[(cz * E + cy) * E + cx] = fold_corner(vb[u].x, vb[u].y);
         }
     }
     __syncthreads();
@@ -324,7 +364,7 @@ __device__ inline void stage_corners(const MapView &M, const int *nb, float2 *s_
 
 // cube (x, y, z): corner sdf values and the case index; false when a corner is unobserved (weight <= 0.5)
 template <int N>
-__device__ inline bool cube_config(const MapView &M, const int *nb, const float2 *s_vox, int x, int y, int z, float (&s)[8],
+__device__ inline bool cube_config(const MapView &M, const int *nb, const float *s_vox, int x, int y, int z, float (&s)[8],
                                    int &index) {
     // cubeIndexOffsets (ChunkManager.cpp:67-69)
     const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
@@ -333,11 +373,16 @@ __device__ inline bool cube_config(const MapView &M, const int *nb, const float2
     bool observed = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const float2 v = CornerTile<N>::STAGED ? s_vox[((z + oz[i]) * E + (y + oy[i])) * E + (x + ox[i])]
-                                               : corner_voxel<N>(M, nb, x + ox[i], y + oy[i], z + oz[i]);
-        observed = observed && (v.y > 0.5f);  // :271 / :352 "weight <= 0.5 -> not observed"
-        s[i] = v.x;
-        index |= (v.x < 0.0f) ? (1 << i) : 0;  // MarchingCubes::CalculateVertexConfiguration MarchingCubes.h:108-118
+        float v;
+        if (CornerTile<N>::STAGED) {
+            v = s_vox[((z + oz[i]) * E + (y + oy[i])) * E + (x + ox[i])];
+        } else {
+            const float2 c = corner_voxel<N>(M, nb, x + ox[i], y + oy[i], z + oz[i]);
+            v = fold_corner(c.x, c.y);
+        }
+        observed = observed && (v == v);  // :271 / :352 "weight <= 0.5 -> not observed"
+        s[i] = v;
+        index |= (v < 0.0f) ? (1 << i) : 0;  // MarchingCubes::CalculateVertexConfiguration MarchingCubes.h:108-118
     }
     return observed;
 }
@@ -377,6 +422,9 @@ __device__ inline void block_scan2(int a, int b, int &oa, int &ob, int &ta, int 
 }
 
 constexpr int MESH_BLOCK = MESH_BLOCK_THREADS;
+#ifndef MESH_COUNT_WAVES
+#define MESH_COUNT_WAVES 6  // waves per SIMD the count kernel leaves room for: three 512-thread workgroups per CU (<= 80 registers; 64 spill)
+#endif
 constexpr int MESH_TRI_BLOCK = 256;  // per-triangle kernel
 
 // What the host needs to know about a job after a recompute (one 32-byte record, fetched in one copy)
@@ -393,8 +441,21 @@ struct JobInfo {
 struct TriRec {
     unsigned job;
     unsigned code;   // rank << 11 | case index << 3 | triangle number
-    unsigned gidx;
+    unsigned gidx;   // the cube's entry in the batch's grid numbering (job's grid base + position among the job's occupied cubes)
 };
+// Beside the triangle list, per occupied cube (indexed like the grids): its eight corner distances (all observed: the cube carries
+// triangles).  The count kernel has them in LDS; the triangle kernel would fetch each through two dependent loads (neighbour
+// table, then voxel).
+struct alignas(16) CubeCorners {
+    float s[8];
+};
+constexpr int MESH_LIST_CAP = 1024;  // occupied cubes of a job listed in LDS at a time
+// s[e] for a per-lane e (a register array cannot be indexed per lane: seven selects)
+__device__ inline float pick8(const float (&s)[8], int e) {
+    const float a0 = (e & 1) ? s[1] : s[0], a1 = (e & 1) ? s[3] : s[2], a2 = (e & 1) ? s[5] : s[4], a3 = (e & 1) ? s[7] : s[6];
+    const float b0 = (e & 2) ? a1 : a0, b1 = (e & 2) ? a3 : a2;
+    return (e & 4) ? b1 : b0;
+}
 
 // Per chunk (one workgroup): stage the corners, count (case table popcount) and scan the cubes in the reference's
 // traversal order, reserve the chunk's range of the batch's triangle / grid numbering with one atomic each and list its
@@ -408,12 +469,14 @@ __device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per s
 #define MSTAMP(i) do { } while (0)
 #endif
 template <int N>
-__global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
-                                                                 JobInfo *info, int *totals, TriRec *tris, int tri_capacity, unsigned *mesh_flag) {
+__global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
+                                                                 JobInfo *info, int *totals, TriRec *tris, CubeCorners *corners, int tri_capacity, unsigned *mesh_flag) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nb[27];
     __shared__ int s_base[2];
-    __shared__ float2 s_vox[CornerTile<N>::SIZE];
+    __shared__ float s_vox[CornerTile<N>::SIZE];
+    __shared__ __attribute__((aligned(16))) unsigned char s_case[N * N * N];  // case index per cube, by traversal rank
+    __shared__ unsigned s_list_a[MESH_LIST_CAP], s_list_t[MESH_LIST_CAP];  // occupied cubes of the job: rank | case << 16, first triangle (relative)
     __shared__ unsigned s_counts[64];  // the 256 vertex counts of the case table, four to a word (a per-lane index into constant memory is a global load)
     constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
     // (the first job's id is requested together with the job count: the id buffer holds at least 4096 entries -- more than the
@@ -459,19 +522,34 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
 #pragma unroll
     for (int k = 0; k < CPT; k++) cases[k] = 0;
     if (present) {
-#pragma unroll
+        // Classification with neighbouring lanes on neighbouring cubes (rank k * MESH_BLOCK + thread: consecutive corners, no LDS
+        // bank conflicts -- with a thread's own CPT consecutive cubes the lanes sit 8 corners apart, an 8-way conflict on every one
+        // of the 64 corner reads); the case bytes go through LDS to the thread that owns the cube in the traversal order.
+#pragma unroll 2  // (two cubes' sixteen corner reads in flight; all of them at once would cost a workgroup per CU in registers)
         for (int k = 0; k < CPT; k++) {
-            const int r = threadIdx.x * CPT + k;
+            const int r = k * MESH_BLOCK + (int)threadIdx.x;
             if (r < V) {
                 int x, y, z, index;
                 float sc[8];
                 cube_of_rank<N>(r, x, y, z);
+                unsigned char cs = 0;
                 if (cube_config<N>(M, s_nb, s_vox, x, y, z, sc, index)) {
                     const int c = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu);
-                    nv += c;
-                    ng += (c != 0);  // IsOccupied (MarchingCubes.h:41-45)
-                    cases[k] = c ? (unsigned char)index : 0;
+                    cs = c ? (unsigned char)index : 0;
                 }
+                s_case[r] = cs;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPT; k++) {
+            const int r = threadIdx.x * CPT + k;
+            if (r < V) {
+                const int index = s_case[r];
+                const int c = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu);  // (case 0 has no vertices)
+                nv += c;
+                ng += (c != 0);  // IsOccupied (MarchingCubes.h:41-45)
+                cases[k] = (unsigned char)index;
             }
         }
     }
@@ -492,29 +570,49 @@ __global__ __launch_bounds__(MESH_BLOCK) void mesh_count_kernel(MapView M, const
         ji.grid_base = gb;
         info[j] = ji;
         s_base[0] = tb;
-        if (tb + tv / 3 > tri_capacity) totals[2] = 1;
+        s_base[1] = gb;
+        if (tb + tv / 3 > tri_capacity || gb + tg > tri_capacity) totals[2] = 1;  // (a cube has at least one triangle: the host grows both lists by the triangle total)
     }
     if (tv == 0) continue;  // block-uniform
     __syncthreads();
     MSTAMP(4);
-    const int tb = s_base[0];
-    if (tb + tv / 3 > tri_capacity || nv == 0) continue;
-    int tpos = tb + ov / 3, gidx = og;
+    const int tb = s_base[0], gb = s_base[1];
+    if (tb + tv / 3 > tri_capacity || gb + tg > tri_capacity) continue;  // block-uniform
+    // The occupied cubes (a few hundred of the 4096, unevenly spread over the threads) are listed in LDS and emitted by all threads
+    // together -- one cube each instead of up to CPT in a row on a few lanes --, MESH_LIST_CAP of them per round.
+    for (int base = 0; base < tg; base += MESH_LIST_CAP) {
+        if (base) __syncthreads();  // the previous round's list has been read
+        int trel = ov / 3, gidx = og;
 #pragma unroll
-    for (int k = 0; k < CPT; k++) {
-        const int index = cases[k];
-        if (index == 0) continue;
-        const int r = threadIdx.x * CPT + k;
-        const int nt = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu) / 3;
-        for (int t = 0; t < nt; t++) {
-            TriRec rec;
-            rec.job = (unsigned)j;
-            rec.code = ((unsigned)r << 11) | ((unsigned)index << 3) | (unsigned)t;
-            rec.gidx = (unsigned)gidx;
-            tris[tpos + t] = rec;
+        for (int k = 0; k < CPT; k++) {
+            const int index = cases[k];
+            if (index == 0) continue;
+            if ((unsigned)(gidx - base) < (unsigned)MESH_LIST_CAP) {
+                s_list_a[gidx - base] = (unsigned)(threadIdx.x * CPT + k) | ((unsigned)index << 16);
+                s_list_t[gidx - base] = (unsigned)trel;
+            }
+            trel += (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu) / 3;
+            gidx++;
         }
-        tpos += nt;
-        gidx++;
+        __syncthreads();
+        const int n_round = min(tg - base, MESH_LIST_CAP);
+        for (int e = threadIdx.x; e < n_round; e += MESH_BLOCK) {
+            const unsigned a = s_list_a[e];
+            const int r = (int)(a & 0xffffu), index = (int)(a >> 16), t0 = tb + (int)s_list_t[e];
+            const int nt = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu) / 3;
+            CubeCorners cc;
+            int x, y, z, idx2;
+            cube_of_rank<N>(r, x, y, z);
+            (void)cube_config<N>(M, s_nb, s_vox, x, y, z, cc.s, idx2);
+            corners[gb + base + e] = cc;
+            for (int t = 0; t < nt; t++) {
+                TriRec rec;
+                rec.job = (unsigned)j;
+                rec.code = ((unsigned)r << 11) | ((unsigned)index << 3) | (unsigned)t;
+                rec.gidx = (unsigned)(gb + base + e);
+                tris[t0 + t] = rec;
+            }
+        }
     }
     MSTAMP(5);
     }
@@ -549,7 +647,7 @@ template <int N>
 // host needs them at the next recompute) and then `seq` into host_flags[6].
 __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
                                                                     const JobInfo *__restrict__ info, const TriRec *__restrict__ tris,
-                                                                    const int *__restrict__ totals, float *arena, size_t arena_floats, int *host_info,
+                                                                    const CubeCorners *__restrict__ corners, const int *__restrict__ totals, float *arena, size_t arena_floats, int *host_info,
                                                                     volatile int *host_flags, int max_jobs, int seq, int publish) {
     const int n_tris = totals[0];
     const int n_jobs = totals[3];
@@ -594,8 +692,9 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     const f3v origin = mk3((float)(N * jx) * P.res, (float)(N * jy) * P.res, (float)(N * jz) * P.res);  // Chunk.cpp:43
     // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
     const f3v coords = add3(mk3((float)x * P.res + P.half_res, (float)y * P.res + P.half_res, (float)z * P.res + P.half_res), origin);
+    const CubeCorners cc = corners[rec.gidx];
     if (t == 0 && mine == 0) {
-        const size_t g = (size_t)info[rec.job].grid_base + rec.gidx;
+        const size_t g = (size_t)rec.gidx;
         grids[3 * g] = coords.x;
         grids[3 * g + 1] = coords.y;
         grids[3 * g + 2] = coords.z;
@@ -608,8 +707,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         // cornerCoords (:278-279) and corner sdf of the two ends of the edge
         const f3v c0 = add3(coords, mk3((float)corner_ox(e0) * P.res, (float)corner_oy(e0) * P.res, (float)corner_oz(e0) * P.res));
         const f3v c1 = add3(coords, mk3((float)corner_ox(e1) * P.res, (float)corner_oy(e1) * P.res, (float)corner_oz(e1) * P.res));
-        const float s0 = corner_voxel<N>(M, nb, x + corner_ox(e0), y + corner_oy(e0), z + corner_oz(e0)).x;
-        const float s1 = corner_voxel<N>(M, nb, x + corner_ox(e1), y + corner_oy(e1), z + corner_oz(e1)).x;
+        const float s0 = pick8(cc.s, e0), s1 = pick8(cc.s, e1);  // (corner i of the cube: cubeIndexOffsets column i, as cube_config reads them)
         p[a] = interpolate_vertex(c0, c1, s0, s1);
     }
     const f3v fn = normalized3(cross3v(sub3(p[1], p[0]), sub3(p[2], p[0])));  // :95-101
@@ -665,6 +763,7 @@ struct MeshBuffers {
     int *n_jobs = nullptr;   // where the count kernel finds the number of jobs (one of the two counters, or null: totals[3])
     unsigned mark_turn = 0;  // which of the two counters the next mark kernel fills
     TriRec *tris = nullptr;  // triangle list of one recompute
+    CubeCorners *corners = nullptr;  // [tri_capacity] corner distances of its occupied cubes
     int tri_capacity = 0;
     int capacity = 0;        // jobs
     unsigned *flags = nullptr;  // [max_chunks] "mesh this slot"
@@ -676,6 +775,7 @@ inline void free_mesh_buffers(MeshBuffers &b) {
     if (b.info) (void)hipFree(b.info);
     if (b.totals) (void)hipFree(b.totals);
     if (b.tris) (void)hipFree(b.tris);
+    if (b.corners) (void)hipFree(b.corners);
     if (b.flags) (void)hipFree(b.flags);
     if (b.query) (void)hipFree(b.query);
     b = MeshBuffers();

@@ -8,7 +8,7 @@ TAG=${1:-r02}; shift
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--gpus 1 --no-cpu-baseline --no-pcie-leg $@"
+ARGS="--gpus 1 --no-cpu-baseline --no-pcie-leg --no-e2e-leg $@"
 python3 bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 # the profiled processes run fewer passes (3 timed + 3 instrumented) so that the traces stay small
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS --repeats 3 > $OUT/bench_trace.json 2> $OUT/trace.err
