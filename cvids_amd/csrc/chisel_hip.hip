@@ -366,7 +366,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     g_host_timer.lap(3);
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_CULL, front);
-        const dim3 cgrid((total + 63) / 64);
+        const CullSpace cspace(CP);
+        static_assert(CULL_BLOCK * CULL_BLOCK * CULL_BLOCK == 64, "one wave per block of ids");
+        const dim3 cgrid = cspace.sharded ? dim3((total + 63) / 64) : dim3(cspace.nsb[2], cspace.nsb[1], cspace.nsb[0]);
 #define CHISEL_LAUNCH_CULL(KLV, INL, OUT)                                                                                        \
     hipLaunchKernelGGL((cull_kernel<N, KLV, INL>), cgrid, dim3(64 * KLV), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count,      \
                        m->items_capacity, m->view, bs.pending, bs.sync)

@@ -204,66 +204,89 @@ __device__ inline float2 whole_image_minmax(const PyramidView &pyr, const float2
     return make_float2(mn, mx);
 }
 
-// the per-frame test of one chunk; returns the FrameBox flags (0: this frame cannot touch the chunk)
+// The per-frame test of one chunk, in two steps so that a wave whose 64 chunks (one 4 x 4 x 4 block of ids: cull_kernel) all fail
+// the cheap part retires after it -- empty space and everything outside the view is most of the enumerated range.
+//   cull_pre : the reference's id range (ChunkManager.cpp:189-199), then the bounding sphere of the chunk's box against the
+//              view: one camera-space point, approximate reciprocals, every bound widened accordingly -> the pixel box under
+//              the sphere and its camera-z interval.  No memory access.
+//   cull_post: depth range under that pixel box (pyramid) against the z interval; then the reference's plane test
+//              (Frustum::Intersects, kept for fidelity: it never prunes) and the exact bounds from the eight corners.
+// Both are conservative: a (chunk, frame) pair is dropped only when no voxel of the chunk can be updated or carved by the frame.
+struct CullPre {
+    int su0, sv0, su1, sv1;   // pixel box under the bounding sphere (the whole image when the sphere reaches behind the camera)
+    float zs0, zs1, slack;    // camera-z interval of the sphere, rounding slack
+};
 template <int N>
-__device__ inline int cull_chunk_frame(const IntegratorParams &ip, const CullFrame &F, const PyramidView &pyr,
-                                       const float2 *__restrict__ pdata, float2 whole, int cx, int cy, int cz, FrameBox &fb) {
-    // the reference enumerates ids range_min .. range_min + range_dim - 1 (ChunkManager.cpp:189-199)
+__device__ inline bool cull_pre(const IntegratorParams &ip, const CullFrame &F, int cx, int cy, int cz, CullPre &pre) {
     if ((unsigned)(cx - F.range_min[0]) >= (unsigned)F.range_dim[0] || (unsigned)(cy - F.range_min[1]) >= (unsigned)F.range_dim[1] ||
         (unsigned)(cz - F.range_min[2]) >= (unsigned)F.range_dim[2])
-        return 0;
+        return false;
+    const CameraParams &C = F.cam;
+    const float bminx = (float)(cx * N) * ip.res, bminy = (float)(cy * N) * ip.res, bminz = (float)(cz * N) * ip.res;
+    const float ext = (float)N * ip.res;
+    const float hx = 0.5f * ext;
+    const float rad = hx * 1.7320508f * 1.001f + 1e-6f;
+    const float wx = (bminx + hx) - C.t[0], wy = (bminy + hx) - C.t[1], wz = (bminz + hx) - C.t[2];
+    const float px = C.R[0] * wx + C.R[3] * wy + C.R[6] * wz;
+    const float py = C.R[1] * wx + C.R[4] * wy + C.R[7] * wz;
+    const float pz = C.R[2] * wx + C.R[5] * wy + C.R[8] * wz;
+    const float slack = 1e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + rad);
+    const float zs1 = pz + rad + slack;
+    if (zs1 < 0.0f) return false;  // every voxel has z < 0 (ProjectionIntegrator.h:68)
+    const float zs0 = pz - rad - slack;
+    pre.su0 = 0; pre.sv0 = 0; pre.su1 = C.W - 1; pre.sv1 = C.H - 1;
+    if (zs0 > 0.25f * ip.res) {
+        // camera-space box [px +- rad] x [py +- rad] x [zs0, zs1] projects inside these bounds
+        const float i0 = __builtin_amdgcn_rcpf(zs0) * 1.00001f, i1 = __builtin_amdgcn_rcpf(zs1) * 0.99999f;
+        const float xl = px - rad - slack, xh = px + rad + slack, yl = py - rad - slack, yh = py + rad + slack;
+        const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
+        const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
+        const float fu0 = floorf(ul) - 3.0f, fu1 = floorf(uh) + 3.0f, fv0 = floorf(vl) - 3.0f, fv1 = floorf(vh) + 3.0f;
+        if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1)) return false;  // off the image
+        pre.su0 = (int)fmaxf(fu0, 0.0f); pre.sv0 = (int)fmaxf(fv0, 0.0f);
+        pre.su1 = (int)fminf(fu1, (float)(C.W - 1)); pre.sv1 = (int)fminf(fv1, (float)(C.H - 1));
+    }
+    pre.zs0 = zs0; pre.zs1 = zs1; pre.slack = slack;
+    return true;
+}
+// does pyramid_minmax fall back to the extrema of the whole image for this box?
+__device__ inline bool box_needs_whole_image(int u0, int v0, int u1, int v1) {
+    return ((u1 >> PYR_L1) - (u0 >> PYR_L1)) > 2 || ((v1 >> PYR_L1) - (v0 >> PYR_L1)) > 2;
+}
+
+template <int N>
+__device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, const PyramidView &pyr, const float2 *__restrict__ pdata,
+                                float2 whole, int cx, int cy, int cz, const CullPre &pre, FrameBox &fb) {
+    const CameraParams &C = F.cam;
+    {
+        float dmin, dmax;
+        pyramid_minmax(pyr, pdata, whole, pre.su0, pre.sv0, pre.su1, pre.sv1, dmin, dmax);
+        if (!(dmin <= dmax)) return 0;  // no valid depth under the chunk
+        float tmin, tmax;
+        truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
+        const float zlo = fmaxf(pre.zs0, 0.0f) - pre.slack;
+        const float band = tmax + ip.diag;
+        const bool inband = (dmin - band < pre.zs1) && (dmax + band > zlo);
+        const bool carve = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
+        if (!inband && !carve) return 0;
+    }
     // chunk box exactly as the reference builds it (ChunkManager.cpp:201-203)
     const float bminx = (float)(cx * N) * ip.res, bminy = (float)(cy * N) * ip.res, bminz = (float)(cz * N) * ip.res;
     const float ext = (float)N * ip.res;
     const float bmaxx = bminx + ext, bmaxy = bminy + ext, bmaxz = bminz + ext;
     // Frustum::Intersects (Frustum.cpp:41-79): true as soon as ONE plane has the p-vertex on its positive side
-    bool hit = false;
-#pragma unroll
-    for (int p = 0; p < 6; p++) {
-        float nx = F.planes[4 * p], ny = F.planes[4 * p + 1], nz = F.planes[4 * p + 2], dd = F.planes[4 * p + 3];
-        float vx = (nx < 0.0f) ? bminx : bmaxx;
-        float vy = (ny < 0.0f) ? bminy : bmaxy;
-        float vz = (nz < 0.0f) ? bminz : bmaxz;
-        float dotv = __fadd_rn(__fmul_rn(vx, nx), __fadd_rn(__fmul_rn(vy, ny), __fmul_rn(vz, nz)));  // a0 + (a1 + a2)
-        if (__fadd_rn(dotv, dd) > 0.0f) hit = true;
-    }
-    if (!hit) return 0;
-    const CameraParams &C = F.cam;
-    // ---- cheap reject with the bounding sphere of the box (most candidates are empty space): one camera-space
-    // point instead of eight corners, approximate reciprocals, every bound widened accordingly ---------------
     {
-        const float hx = 0.5f * ext;
-        const float rad = hx * 1.7320508f * 1.001f + 1e-6f;
-        const float wx = (bminx + hx) - C.t[0], wy = (bminy + hx) - C.t[1], wz = (bminz + hx) - C.t[2];
-        const float px = C.R[0] * wx + C.R[3] * wy + C.R[6] * wz;
-        const float py = C.R[1] * wx + C.R[4] * wy + C.R[7] * wz;
-        const float pz = C.R[2] * wx + C.R[5] * wy + C.R[8] * wz;
-        const float slack = 1e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + rad);
-        const float zs1 = pz + rad + slack;
-        if (zs1 < 0.0f) return 0;  // every voxel has z < 0 (ProjectionIntegrator.h:68)
-        const float zs0 = pz - rad - slack;
-        int su0 = 0, sv0 = 0, su1 = C.W - 1, sv1 = C.H - 1;
-        if (zs0 > 0.25f * ip.res) {
-            // camera-space box [px +- rad] x [py +- rad] x [zs0, zs1] projects inside these bounds
-            const float i0 = __builtin_amdgcn_rcpf(zs0) * 1.00001f, i1 = __builtin_amdgcn_rcpf(zs1) * 0.99999f;
-            const float xl = px - rad - slack, xh = px + rad + slack, yl = py - rad - slack, yh = py + rad + slack;
-            const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
-            const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
-            const float fu0 = floorf(ul) - 3.0f, fu1 = floorf(uh) + 3.0f, fv0 = floorf(vl) - 3.0f, fv1 = floorf(vh) + 3.0f;
-            if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1)) return 0;  // off the image
-            su0 = (int)fmaxf(fu0, 0.0f); sv0 = (int)fmaxf(fv0, 0.0f);
-            su1 = (int)fminf(fu1, (float)(C.W - 1)); sv1 = (int)fminf(fv1, (float)(C.H - 1));
+        bool hit = false;
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            float nx = F.planes[4 * p], ny = F.planes[4 * p + 1], nz = F.planes[4 * p + 2], dd = F.planes[4 * p + 3];
+            float vx = (nx < 0.0f) ? bminx : bmaxx;
+            float vy = (ny < 0.0f) ? bminy : bmaxy;
+            float vz = (nz < 0.0f) ? bminz : bmaxz;
+            float dotv = __fadd_rn(__fmul_rn(vx, nx), __fadd_rn(__fmul_rn(vy, ny), __fmul_rn(vz, nz)));  // a0 + (a1 + a2)
+            if (__fadd_rn(dotv, dd) > 0.0f) hit = true;
         }
-        float dmin, dmax;
-        pyramid_minmax(pyr, pdata, whole, su0, sv0, su1, sv1, dmin, dmax);
-        if (!(dmin <= dmax)) return 0;  // no valid depth under the chunk
-        float tmin, tmax;
-        truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
-        const float zlo = fmaxf(zs0, 0.0f) - slack;
-        const float band = tmax + ip.diag;
-        const bool inband = (dmin - band < zs1) && (dmax + band > zlo);
-        const bool carve = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
-        if (!inband && !carve) return 0;
+        if (!hit) return 0;
     }
     // ---- survivors: conservative camera-space bounds of the box itself (voxel centres lie strictly inside it)
     float zmin = INFINITY, zmax = -INFINITY, umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
@@ -370,10 +393,12 @@ __device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
     return false;
 }
 
-// The candidate ids one shard has to judge.  Unsharded: every id of the union range, in the reference's order (x outer, z
-// inner, ChunkManager.cpp:195-199).  Sharded: only the ids this shard owns -- chunk_owner() is (bx + 3 by + 5 bz) mod n on
+// The candidate ids one shard has to judge.  Unsharded: every id of the union range (the reference walks it x outer, z inner,
+// ChunkManager.cpp:195-199; the order of the candidates has no bearing on the voxel fields, and the work-list is cost-ordered
+// anyway), here in blocks of 4 x 4 x 4 ids per wave.  Sharded: only the ids this shard owns -- chunk_owner() is (bx + 3 by + 5 bz) mod n on
 // super-blocks of b^3 chunks, so for each (by, bz) the owned bx are one residue class: slot j of (by, bz) is the j-th owned bx
 // at or after the range's first super-block.  (Before, every shard walked the whole range with n - 1 of n lanes idle.)
+constexpr int CULL_BLOCK = 4;
 struct CullSpace {
     int sharded;
     int b;                 // super-block edge in chunks
@@ -388,9 +413,14 @@ struct CullSpace {
         n = P.ip.n_shards;
         rank = P.ip.shard_rank;
         if (!sharded) {
-            total = P.range_dim[0] * P.range_dim[1] * P.range_dim[2];
+            // blocks of CULL_BLOCK^3 ids (64 = the lanes of a wave: spatially compact, so that most waves see nothing but empty space
+            // or nothing but space outside the view and retire early); nsb = blocks per axis, cells beyond the range are skipped
+            for (int a = 0; a < 3; a++) {
+                sb0[a] = 0;
+                nsb[a] = (P.range_dim[a] + CULL_BLOCK - 1) / CULL_BLOCK;
+            }
+            total = nsb[0] * nsb[1] * nsb[2] * CULL_BLOCK * CULL_BLOCK * CULL_BLOCK;
             per_row = 0;
-            for (int a = 0; a < 3; a++) sb0[a] = nsb[a] = 0;
             return;
         }
         for (int a = 0; a < 3; a++) {
@@ -404,11 +434,13 @@ struct CullSpace {
     __host__ __device__ bool id(const CullParams &P, int c, int &cx, int &cy, int &cz) const {
         if (c >= total) return false;
         if (!sharded) {
-            const int iz = c % P.range_dim[2];
-            const int iy = (c / P.range_dim[2]) % P.range_dim[1];
-            const int ix = c / (P.range_dim[2] * P.range_dim[1]);
+            constexpr int B3 = CULL_BLOCK * CULL_BLOCK * CULL_BLOCK;
+            const int cell = c % B3, blk = c / B3;
+            const int bz = blk % nsb[2], by = (blk / nsb[2]) % nsb[1], bx = blk / (nsb[2] * nsb[1]);
+            const int ix = bx * CULL_BLOCK + cell % CULL_BLOCK, iy = by * CULL_BLOCK + (cell / CULL_BLOCK) % CULL_BLOCK,
+                      iz = bz * CULL_BLOCK + cell / (CULL_BLOCK * CULL_BLOCK);
             cx = P.range_min[0] + ix; cy = P.range_min[1] + iy; cz = P.range_min[2] + iz;
-            return true;
+            return ix < P.range_dim[0] && iy < P.range_dim[1] && iz < P.range_dim[2];
         }
         const int cell = c % (b * b * b), s = c / (b * b * b);
         const int ibz = s % nsb[2], iby = (s / nsb[2]) % nsb[1], j = s / (nsb[2] * nsb[1]);
@@ -436,16 +468,33 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
     __shared__ int s_pos[64];
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's frame
-    const CullSpace space(P);
-    const int c = blockIdx.x * 64 + lane;
     int cx = 0, cy = 0, cz = 0;
+    bool have_id;
+    if (P.ip.n_shards > 1) {
+        const CullSpace space(P);
+        have_id = space.id(P, (int)blockIdx.x * 64 + lane, cx, cy, cz);
+    } else {
+        // unsharded: a three-dimensional grid of 4 x 4 x 4 blocks, lane = cell (CullSpace::id without its integer divisions)
+        const int ix = (int)blockIdx.z * CULL_BLOCK + (lane & 3), iy = (int)blockIdx.y * CULL_BLOCK + ((lane >> 2) & 3),
+                  iz = (int)blockIdx.x * CULL_BLOCK + (lane >> 4);
+        cx = P.range_min[0] + ix; cy = P.range_min[1] + iy; cz = P.range_min[2] + iz;
+        have_id = ix < P.range_dim[0] && iy < P.range_dim[1] && iz < P.range_dim[2];
+    }
     FrameBox fb;
     fb.flags = 0;
     int fl = 0;
-    const float2 whole = (k < P.n_frames) ? whole_image_minmax(pyr, pyr.data + (size_t)k * P.pyr_stride) : make_float2(INFINITY, -INFINITY);
-    if (space.id(P, c, cx, cy, cz)) {
+    CullPre pre;
+    bool alive = false;
+    if (have_id) {
         if (k < P.n_frames && chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank)
-            fl = cull_chunk_frame<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, whole, cx, cy, cz, fb);
+            alive = cull_pre<N>(P.ip, P.f[k], cx, cy, cz, pre);
+    }
+    if (__any(alive)) {  // wave-uniform: most waves stop here
+        // the extrema of the whole image (a wave-wide reduction of the coarsest pyramid level) only where a box is wider than three
+        // of its texels: chunks next to the camera
+        float2 whole = make_float2(INFINITY, -INFINITY);
+        if (__any(alive && box_needs_whole_image(pre.su0, pre.sv0, pre.su1, pre.sv1))) whole = whole_image_minmax(pyr, pyr.data + (size_t)k * P.pyr_stride);
+        if (alive) fl = cull_post<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, whole, cx, cy, cz, pre, fb);
     }
     fb.flags = fl;
     s_flags[k][lane] = fl;
