@@ -50,6 +50,12 @@ class PointCloud(C.Structure):
 
 
 # every symbol include/chisel_hip.h declares (tests/test_abi.py checks the header against this list)
+class Statistics(C.Structure):
+    """chisel_hip_statistics (include/chisel_hip.h): ChunkManager::PrintMemoryStatistics' census"""
+    _fields_ = [("n_unknown", C.c_int64), ("n_known_inside", C.c_int64), ("n_known_outside", C.c_int64), ("total_weight", C.c_double),
+                ("n_chunks", C.c_int64), ("id_min", C.c_int32 * 3), ("id_max", C.c_int32 * 3)]
+
+
 EXPORTS = [
     "chisel_hip_abi_version", "chisel_hip_last_error", "chisel_hip_device_count", "chisel_hip_create",
     "chisel_hip_destroy", "chisel_hip_reset", "chisel_hip_set_integrator", "chisel_hip_set_stream",
@@ -61,7 +67,7 @@ EXPORTS = [
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
-    "chisel_hip_get_counters", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
+    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
 ]
 # the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
 SELFTEST_EXPORTS = [
@@ -149,6 +155,8 @@ def load_library():
     L.chisel_hip_load_map.argtypes = [vp, C.c_char_p]
     L.chisel_hip_get_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.chisel_hip_set_profiling.argtypes = [vp, C.c_int]
+    if hasattr(L, "chisel_hip_memory_statistics"):
+        L.chisel_hip_memory_statistics.argtypes = [vp, C.POINTER(Statistics)]
     L.chisel_hip_get_profile.argtypes = [vp, C.POINTER(C.c_double), i64p, C.c_int]
     L.chisel_hip_chunk_owner.argtypes = [i32p, C.c_int, C.c_int]
     L.chisel_hip_kat_truncation.argtypes = [C.c_int, C.c_float, f32p, C.c_int, f32p, f32p]

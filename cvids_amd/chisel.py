@@ -406,6 +406,25 @@ class Chisel:
         check(self.L.chisel_hip_get_sdf_and_gradient(self.h, p, C.byref(d), g, C.byref(found)))
         return bool(found.value), d.value, np.array(list(g), np.float32)
 
+    def MemoryStatistics(self):
+        """ChunkManager::PrintMemoryStatistics (ChunkManager.cpp:641-678) as numbers: the voxel census of Chunk::ComputeStatistics over
+        the resident chunks, the weight sum, the bounds of the chunk boxes and the two memory figures the reference prints (it
+        prices a voxel at sizeof(DistVoxel) = 16 bytes)."""
+        st = capi.Statistics()
+        check(self.L.chisel_hip_memory_statistics(self.h, C.byref(st)))
+        n, res = self.chunk_size, np.float32(self.voxel_resolution)
+        out = {"numUnknown": st.n_unknown, "numKnownInside": st.n_known_inside, "numKnownOutside": st.n_known_outside,
+               "totalWeight": st.total_weight, "chunks": st.n_chunks}
+        if st.n_chunks:
+            lo = np.array([np.float32(n[a] * st.id_min[a]) * res for a in range(3)], np.float32)                       # Chunk.cpp:43
+            hi = np.array([np.float32(n[a] * st.id_max[a]) * res + np.float32(n[a]) * res for a in range(3)], np.float32)  # Chunk.cpp:65-70
+            out["bounds"] = (lo, hi)
+            ext = (hi - lo) * np.float32(0.5)                                                                         # AABB::GetExtents
+            nv = ext * np.float32(2) / res
+            out["max_memory_mb"] = float(nv[0] * nv[1] * nv[2] * np.float32(16) / np.float32(1000000.0))
+        out["current_memory_mb"] = float(np.float32(st.n_chunks * n[0] * n[1] * n[2] * 16) / np.float32(1000000.0))
+        return out
+
     # ---- measurement ----------------------------------------------------------------------------------
     def counters(self, reset=False):
         out = (C.c_uint64 * capi.NUM_COUNTERS)()

@@ -5,6 +5,7 @@
 #include "../../include/chisel_hip_selftest.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -97,6 +98,27 @@ struct HostTimer {
     }
 };
 HostTimer g_host_timer;
+
+// roctx ranges (rocprofv3 --marker-trace) around the two halves of a launch set and the mesh recompute: CHISEL_HIP_ROCTX=1.  The
+// library is looked up at run time (libroctx64.so of the ROCm installation): no link-time dependency, nothing when the variable is unset.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        if (!getenv("CHISEL_HIP_ROCTX")) return;
+        void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+Roctx g_roctx;
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { if (g_roctx.push) g_roctx.push(name); }
+    ~RoctxRange() { if (g_roctx.pop) g_roctx.pop(); }
+};
 
 struct ProfEvent {
     int kernel;
@@ -359,6 +381,8 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     hipStream_t front = bs.front_stream;
     const bool inline_resolve = front == m->stream;
     {
+    RoctxRange front_range("chisel_hip front half: pyramid, cull, resolve, order");
+    {
         ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID, front);
         dim3 grid((PP.W + 63) / 64, (PP.H + 63) / 64, IP.n_frames);
         hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, front, PP, pyr, bs.cand_count, bs.pending);
@@ -408,7 +432,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
             hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
     }
     HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
+    }
     g_host_timer.lap(4);
+    RoctxRange back_range("chisel_hip back half: integrate");
     // ---- back half: the map's stream.  A mesh recompute still in flight must have been sized first (it may have to be
     // emitted again from the voxels as they are now); its front-half work above did not depend on that.
     {
@@ -1624,6 +1650,52 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
         fprintf(stderr, "   (meaningful for ONE launch) first wave start -> last wave end %.1f us; last unit started at %.1f us; longest unit %.1f us (%d frames executed, wid %d = item %d unit %d)\n",
                 (ph[22] - ph[21]) * 0.01, (ph[23] - ph[21]) * 0.01, (ph[24] >> 32) * 0.01, (int)(ph[24] & 255), (int)((ph[24] >> 8) & 0xffffff), (int)((ph[24] >> 8) & 0xffffff) / 16, (int)((ph[24] >> 8) & 0xffffff) % 16);
 #endif
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_memory_statistics(chisel_hip_map *m, chisel_hip_statistics *out) {
+    if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    for (int a = 0; a < 3; a++) {
+        out->id_min[a] = INT32_MAX;
+        out->id_max[a] = INT32_MIN;
+    }
+    if (m->is_group) {  // the shards' chunks are disjoint: sums, and extrema of extrema
+        return group::for_all(m, [&](chisel_hip_map *s) -> int {
+            chisel_hip_statistics t;
+            const int rc = chisel_hip_memory_statistics(s, &t);
+            if (rc) return rc;
+            out->n_unknown += t.n_unknown; out->n_known_inside += t.n_known_inside; out->n_known_outside += t.n_known_outside;
+            out->total_weight += t.total_weight; out->n_chunks += t.n_chunks;
+            for (int a = 0; a < 3 && t.n_chunks; a++) {
+                out->id_min[a] = std::min(out->id_min[a], t.id_min[a]);
+                out->id_max[a] = std::max(out->id_max[a], t.id_max[a]);
+            }
+            return CHISEL_HIP_OK;
+        });
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = ensure_scratch(m, sizeof(CensusOut) / sizeof(int) + 4);
+    if (rc) return rc;
+    CensusOut init;
+    memset(&init, 0, sizeof(init));
+    for (int a = 0; a < 3; a++) {
+        init.id_min[a] = INT32_MAX;
+        init.id_max[a] = INT32_MIN;
+    }
+    CensusOut *d = reinterpret_cast<CensusOut *>(m->scratch_i);
+    HIP_TRY(hipMemcpyAsync(d, &init, sizeof(init), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(census_kernel, dim3(std::min(m->view.max_chunks, 8192)), dim3(256), 0, m->stream, m->view, m->V, d);
+    HIP_TRY(hipGetLastError());
+    CensusOut h;
+    HIP_TRY(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    out->n_unknown = (int64_t)h.unknown; out->n_known_inside = (int64_t)h.inside; out->n_known_outside = (int64_t)h.outside;
+    out->total_weight = h.weight; out->n_chunks = (int64_t)h.chunks;
+    for (int a = 0; a < 3; a++) {
+        out->id_min[a] = h.id_min[a];
+        out->id_max[a] = h.id_max[a];
+    }
     return CHISEL_HIP_OK;
 }
 

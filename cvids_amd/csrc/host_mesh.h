@@ -165,6 +165,7 @@ void launch_mesh_count(chisel_hip_map *m) {
 // that outgrew the triangle list or the arena is emitted again after a full wait (the map has not changed meanwhile:
 // nothing else was queued).
 int recompute_meshes(chisel_hip_map *m) {
+    RoctxRange range("chisel_hip mesh recompute: count, triangles");
     MeshBuffers &B = m->mesh_buf;
     int *d_totals = mesh_totals(m);
     const MeshParams P = mesh_params(m);
@@ -231,10 +232,10 @@ int check_mesh_totals(chisel_hip_map *m) {
         // the device writes totals and sequence number as one 16-byte store (mesh_triangle_kernel): word 3 is the sequence number
         volatile int *host = m->mesh_totals_host;
         const auto t0 = std::chrono::steady_clock::now();
-        while (host[3] != m->mesh_seq) {
+        while (host[5] != m->mesh_seq) {  // (the copy of the sequence number written behind a system-scope fence: words 0-3 are complete)
             if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
                 HIP_TRY(hipStreamSynchronize(m->stream));  // long queue in front of the recompute, or a failed launch: no more polling
-                if (host[3] != m->mesh_seq) return fail(CHISEL_HIP_ERR_HIP, "mesh totals were not published");
+                if (host[5] != m->mesh_seq || host[3] != m->mesh_seq) return fail(CHISEL_HIP_ERR_HIP, "mesh totals were not published");
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -460,9 +461,13 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
     rc = resolve_pending_meshes(m);  // the device buffers of the previous recompute are about to be reused
     if (rc) return rc;
     rc = collect_mesh_ids(m, extra);
-    if (rc) return rc;
-    rc = recompute_meshes(m);  // ends with meshesToUpdate.clear() (Chisel.cpp:57)
-    if (rc) return rc;
+    if (!rc) rc = recompute_meshes(m);  // ends with meshesToUpdate.clear() (Chisel.cpp:57)
+    if (rc) {
+        // the mark kernel may have flagged slots that no count kernel will now reset: a slot whose flag stays set could never
+        // become a job again
+        if (m->mesh_buf.flags) (void)hipMemsetAsync(m->mesh_buf.flags, 0, (size_t)m->view.max_chunks * sizeof(unsigned), m->stream);
+        return rc;
+    }
     m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;
 }

@@ -154,6 +154,65 @@ __global__ void ensure_chunk_kernel(MapView M, int x, int y, int z, int *out_slo
     *out_slot = slot;
 }
 
+// Chunk::ComputeStatistics (Chunk.cpp:89-116) over every resident chunk, ChunkManager::PrintMemoryStatistics' sums (ChunkManager.cpp:641-678):
+// one workgroup per slot (grid-stride), 16-byte loads, wave shuffles, one atomic per workgroup, slot and quantity.
+// out: [0] unknown, [1] inside, [2] outside, [3] chunks (64-bit counts), then the weight sum (double), then id min[3] / max[3] (int).
+struct CensusOut {
+    unsigned long long unknown, inside, outside, chunks;
+    double weight;
+    int id_min[3], id_max[3];
+};
+__global__ __launch_bounds__(256) void census_kernel(MapView M, int V, CensusOut *out) {
+    __shared__ unsigned s_cnt[4][3];
+    __shared__ double s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int slot = blockIdx.x; slot < M.max_chunks; slot += gridDim.x) {
+        const uint64_t key = M.slot_key[slot];  // block-uniform
+        if (key == KEY_EMPTY) continue;
+        unsigned unknown = 0, inside = 0, outside = 0;
+        double wsum = 0.0;
+        const float4 *sp = reinterpret_cast<const float4 *>(M.sdf + (size_t)slot * V), *wp = reinterpret_cast<const float4 *>(M.wgt + (size_t)slot * V);
+        for (int q = threadIdx.x; q < V / 4; q += 256) {
+            const float4 s4 = sp[q], w4 = wp[q];
+            const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (wv[i] > 0) {
+                    if (sv[i] < 0) inside++;
+                    else outside++;
+                } else {
+                    unknown++;
+                }
+                wsum += (double)wv[i];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            unknown += __shfl_down(unknown, o);
+            inside += __shfl_down(inside, o);
+            outside += __shfl_down(outside, o);
+            wsum += __shfl_down(wsum, o);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            s_cnt[wave][0] = unknown; s_cnt[wave][1] = inside; s_cnt[wave][2] = outside;
+            s_w[wave] = wsum;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&out->unknown, (unsigned long long)(s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0]));
+            atomicAdd(&out->inside, (unsigned long long)(s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1]));
+            atomicAdd(&out->outside, (unsigned long long)(s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2]));
+            atomicAdd(&out->chunks, 1ull);
+            atomicAdd(&out->weight, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+            int x, y, z;
+            unpack_id(key, x, y, z);
+            atomicMin(&out->id_min[0], x); atomicMin(&out->id_min[1], y); atomicMin(&out->id_min[2], z);
+            atomicMax(&out->id_max[0], x); atomicMax(&out->id_max[1], y); atomicMax(&out->id_max[2], z);
+        }
+    }
+}
+
 // enumerate resident chunks (GetChunks()) or the dirty ones: ballot compaction over the slot table
 template <bool DIRTY_ONLY>
 __global__ void list_slots_kernel(MapView M, int *ids, int *slots, int max_out, int *count) {

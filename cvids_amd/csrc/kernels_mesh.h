@@ -485,6 +485,9 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
     const int n = *n_jobs;  // the job count stays on the device: the grid is persistent
     if (blockIdx.x == 0 && threadIdx.x == 0) totals[3] = n;  // where the kernels behind this one (and a second emission) read it
     if (threadIdx.x < 64) s_counts[threadIdx.x] = reinterpret_cast<const unsigned *>(c_mc_counts)[threadIdx.x];  // (first barrier below)
+    // the list of dirty slots has been consumed by the mark kernel -- also when none of them became a job (every listed chunk
+    // removed since): reset outside the job loop
+    if (blockIdx.x == 0 && threadIdx.x == 29) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
 #ifdef CHISEL_PHASES
     unsigned long long mt_ = __builtin_amdgcn_s_memrealtime();
@@ -513,7 +516,6 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
         if (mesh_flag) mesh_flag[s_nb[NB_SELF]] = 0u;
         M.slot_dirty[s_nb[NB_SELF]] = 0u;
     }
-    if (j == 0 && threadIdx.x == 29) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;  // the list of dirty slots has been consumed (mark kernel)
     MSTAMP(0);
     if (present) stage_corners<N>(M, s_nb, s_vox);
     MSTAMP(1);
@@ -662,6 +664,10 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         v.z = (unsigned)n_jobs | (totals[2] ? 0x80000000u : 0u);
         v.w = (unsigned)seq;
         *reinterpret_cast<uint4 *>(const_cast<int *>(host_flags)) = v;
+        // what the host polls is a second copy of the sequence number behind a system-scope fence: that the 16 bytes above arrive
+        // as one piece is how the bus behaves, not a guarantee (this thread alone pays the few hundred nanoseconds)
+        __threadfence_system();
+        host_flags[5] = seq;
     }
     const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[1] * 3;
     // a triangle list that overflowed (totals[2]) is incomplete: nothing is emitted, the host lists and emits again

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -337,11 +338,25 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         }
         hip_check(chisel_hip_update_meshes_of(map, ids.data(), (int)which.size()));
     }
-    void PrintMemoryStatistics() const {  // ChunkManager.cpp:72-89 (the pool is fixed: what is in use)
-        int64_t n = 0;
-        hip_check(chisel_hip_num_chunks(map, &n));
-        const double mb = (double)n * chunkSize(0) * chunkSize(1) * chunkSize(2) * (useColor ? 12.0 : 8.0) / (1024.0 * 1024.0);
-        std::printf("chisel-hip: %lld chunks resident, %.1f MB of voxel payload in HBM\n", (long long)n, mb);
+    void PrintMemoryStatistics() const {  // ChunkManager.cpp:641-678: the same three lines, the census from one reduction kernel
+        chisel_hip_statistics st;
+        hip_check(chisel_hip_memory_statistics(map, &st));
+        const float big = std::numeric_limits<float>::max();
+        float lo[3] = {big, big, big}, hi[3] = {-big, -big, -big};
+        for (int a = 0; a < 3 && st.n_chunks; a++) {
+            lo[a] = (float)(chunkSize(a) * st.id_min[a]) * voxelResolutionMeters;                                                  // Chunk.cpp:43
+            hi[a] = (float)(chunkSize(a) * st.id_max[a]) * voxelResolutionMeters + (float)chunkSize(a) * voxelResolutionMeters;   // Chunk.cpp:65-70
+        }
+        float numVoxels[3];
+        for (int a = 0; a < 3; a++) numVoxels[a] = ((hi[a] - lo[a]) * 0.5f) * 2 / voxelResolutionMeters;                         // AABB::GetExtents
+        const float totalNum = numVoxels[0] * numVoxels[1] * numVoxels[2];
+        const float maxMemory = totalNum * 16 / 1000000.0f;  // sizeof(DistVoxel) of the reference build (vptr + two floats, padded)
+        const size_t currentNum = (size_t)st.n_chunks * (size_t)(chunkSize(0) * chunkSize(1) * chunkSize(2));
+        const float currentMemory = currentNum * 16 / 1000000.0f;
+        std::printf("Num Unknown: %lu, Num KnownIn: %lu, Num KnownOut: %lu Weight: %f\n", (unsigned long)st.n_unknown, (unsigned long)st.n_known_inside,
+                    (unsigned long)st.n_known_outside, (float)st.total_weight);
+        std::printf("Bounds: %f %f %f %f %f %f\n", lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+        std::printf("Theoretical max (MB): %f, Current (MB): %f\n", maxMemory, currentMemory);
     }
     bool GetSDF(const Vec3 &pos, double *dist) const {  // ChunkManager.cpp:476-499
         const float p[3] = {pos(0), pos(1), pos(2)};

@@ -313,6 +313,19 @@ int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* accumulated since creation / last reset_counters; out has CHISEL_HIP_NUM_COUNTERS entries */
 int chisel_hip_get_counters(chisel_hip_map *map, uint64_t *out, int reset_counters);
+/* ChunkManager::PrintMemoryStatistics (src/ChunkManager.cpp:641-678; the reference calls it after every depth-only frame,
+ * Chisel.h:111): the census of Chunk::ComputeStatistics (src/Chunk.cpp:89-116) over every resident chunk -- voxels with weight > 0 and
+ * sdf < 0 / >= 0, voxels with weight <= 0 -- as one reduction kernel, the sum of the weights (a double here; the reference adds floats
+ * in hash-map order), and the smallest / largest resident chunk id per axis, from which the caller forms the bounds
+ * (min = chunk_size * id_min * resolution, max = chunk_size * (id_max + 1) * resolution, Chunk.cpp:65-70).  n_chunks == 0: the ids are
+ * undefined. */
+typedef struct chisel_hip_statistics {
+    int64_t n_unknown, n_known_inside, n_known_outside;
+    double total_weight;
+    int64_t n_chunks;
+    int32_t id_min[3], id_max[3];
+} chisel_hip_statistics;
+int chisel_hip_memory_statistics(chisel_hip_map *map, chisel_hip_statistics *out);
 /* hipEvent pairs around every kernel launch on the map's stream (off by default) */
 int chisel_hip_set_profiling(chisel_hip_map *map, int enable);
 /* total milliseconds and launch counts per CHISEL_HIP_KERNEL_* since enabled / last reset */
