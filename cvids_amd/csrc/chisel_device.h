@@ -121,6 +121,8 @@ struct IntegratorParams {
     float diag;              // ProjectionIntegrator.h:58  2.0 * sqrt(3.0f) * res  (double, narrowed)
     float max_depth;         // 50 (Integrate :74) or 100 (IntegrateColor :141)
     int n_shards, shard_rank, shard_block;
+    int single_chunk;        // ProjectionIntegrator::Integrate on ONE chunk (chisel_hip_integrate_chunk): the candidate range is that id, whatever the
+                             // frustum says, and the reference's plane test is not part of that call
 };
 
 // pixel record of one depth pixel: x = depth reading (NaN when the reference skips the pixel: NaN depth, depth > max_depth),

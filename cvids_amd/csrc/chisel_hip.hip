@@ -206,6 +206,11 @@ struct chisel_hip_map {
     std::vector<int> ghost_ids;                                        // chunks of other shards imported for meshing (x, y, z triples)
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
+    bool single_chunk = false;                                         // chisel_hip_integrate_chunk: the next integrate call sees this id only
+    int single_id[3] = {0, 0, 0};
+    int mesh_stages = 3;                                               // MeshParams::stages of the next recompute (chisel_hip_generate_mesh lowers it)
+    bool mesh_detached = false;                                        // the next recompute leaves meshesToUpdate alone (chisel_hip_generate_mesh)
+    uint64_t topology_epoch = 0;                                       // bumped by everything but integration that adds or removes chunks (chisel_hip_topology_epoch)
     MeshBuffers mesh_buf{};
     struct CloudBuffers {                                              // point-cloud fusion mode (host_cloud.h), allocated on first use
         float *points = nullptr, *colors = nullptr;                    // staging of host clouds
@@ -533,6 +538,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     ip.n_shards = m->cfg.n_shards;
     ip.shard_rank = m->cfg.shard_rank;
     ip.shard_block = m->cfg.shard_block;
+    ip.single_chunk = m->single_chunk ? 1 : 0;
     PP.ip = CP.ip = IP.ip = ip;
     PP.W = W;
     PP.H = H;
@@ -653,6 +659,11 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         }
         hostmath::FrustumRange fr = hostmath::frustum_range(f->pose, f->near_plane, f->far_plane, f->fy, f->cy, W, H, m->N,
                                                             m->cfg.voxel_resolution);
+        if (m->single_chunk)  // ProjectionIntegrator::Integrate(..., chunk): that chunk, whether or not the frustum's range holds it
+            for (int a = 0; a < 3; a++) {
+                fr.range_min[a] = m->single_id[a];
+                fr.range_dim[a] = 1;
+            }
         for (int a = 0; a < 3; a++) {
             CP.f[k].range_min[a] = fr.range_min[a];
             CP.f[k].range_dim[a] = fr.range_dim[a];
@@ -1000,6 +1011,7 @@ int chisel_hip_reset(chisel_hip_map *m) {
     if (m && m->is_group) return group::for_all(m, [](chisel_hip_map *s) { return chisel_hip_reset(s); });
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
+    m->topology_epoch++;
     hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
     HIP_TRY(hipGetLastError());
     HIP_TRY(note_map_mutation(m));
@@ -1074,11 +1086,39 @@ int chisel_hip_integrate_batch(chisel_hip_map *m, int n, const chisel_hip_depth_
     return integrate_frames(m, n, frames, colors, m->batch_frames);
 }
 
+// ProjectionIntegrator::Integrate / IntegrateColor (ProjectionIntegrator.h:51-52, 101-102) are per-chunk calls: one frame into ONE
+// chunk, the return value "some voxel changed".  The chunk must be resident (the reference's caller holds a Chunk object); the frame
+// goes through the ordinary launch set with the candidate range pinned to that id.
+int chisel_hip_integrate_chunk(chisel_hip_map *m, const int id[3], const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c, int *updated) {
+    if (m && m->is_group) return id ? chisel_hip_integrate_chunk(group::owner_map(m, id), id, f, c, updated) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (!m || !id || !f) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank) return fail(CHISEL_HIP_ERR_INVALID, "this shard does not own the chunk");
+    int has = 0;
+    int rc = chisel_hip_has_chunk(m, id, &has);
+    if (rc) return rc;
+    if (!has) return fail(CHISEL_HIP_ERR_NOT_FOUND, "chunk not resident");
+    uint64_t before[CHISEL_HIP_NUM_COUNTERS], after[CHISEL_HIP_NUM_COUNTERS];
+    rc = chisel_hip_get_counters(m, before, 0);
+    if (rc) return rc;
+    m->single_chunk = true;
+    for (int a = 0; a < 3; a++) m->single_id[a] = id[a];
+    rc = integrate_frames(m, 1, f, c, 1);
+    m->single_chunk = false;
+    if (rc) return rc;
+    rc = chisel_hip_synchronize(m);
+    if (rc) return rc;
+    rc = chisel_hip_get_counters(m, after, 0);
+    if (rc) return rc;
+    if (updated) *updated = after[CHISEL_HIP_CNT_UPDATED_CHUNKS] != before[CHISEL_HIP_CNT_UPDATED_CHUNKS] ? 1 : 0;
+    return CHISEL_HIP_OK;
+}
+
 int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
     if (m && m->is_group) return group::garbage_collect(m, ids, n);
     if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
+    m->topology_epoch++;
     {
         int rc_m = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
         if (rc_m) return rc_m;
@@ -1400,6 +1440,7 @@ int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, con
     if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
+    m->topology_epoch++;
     int rc = check_mesh_totals(m);
     if (rc) return rc;
     for (int j = 0; j < n; j++)
@@ -1439,6 +1480,7 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     if (m->ghost_ids.empty()) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
+    m->topology_epoch++;
     int rc = check_mesh_totals(m);  // a recompute in flight may still read them
     if (rc) return rc;
     const int n = (int)(m->ghost_ids.size() / 3);
@@ -1535,6 +1577,8 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
     if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)
         return fail(CHISEL_HIP_ERR_INVALID, "chunk belongs to another shard");
     HIP_TRY(hipSetDevice(m->device));
+    m->topology_epoch++;
+    m->topology_epoch++;
     int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
     if (rc) return rc;
     rc = ensure_scratch(m, 16);
@@ -1696,6 +1740,89 @@ int chisel_hip_memory_statistics(chisel_hip_map *m, chisel_hip_statistics *out) 
         out->id_min[a] = h.id_min[a];
         out->id_max[a] = h.id_max[a];
     }
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_topology_epoch(chisel_hip_map *m, uint64_t *out) {
+    if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    *out = m->topology_epoch;
+    if (m->is_group)
+        for (chisel_hip_map *s : m->shards) *out += s->topology_epoch;
+    return CHISEL_HIP_OK;
+}
+
+// ChunkManager::GetChunkIDsIntersecting(const Frustum &, ChunkIDList *) (ChunkManager.cpp:182-212) for a frustum given by its corners
+// and planes: the AABB of the corners (Frustum::ComputeBoundingBox Frustum.cpp:101-122), the id range [GetIDAt(min) - 1,
+// GetIDAt(max) + 2] per axis walked x outer, z inner, every box kept for which Frustum::Intersects holds (Frustum.cpp:41-79).
+// Host arithmetic, as in the reference (the integration path does not call it: its candidates come from cull_kernel).
+int chisel_hip_candidates(const float corners[24], const float planes[24], const int chunk_size[3], float voxel_resolution, int *ids, int64_t max_ids,
+                          int64_t *count) {
+    if (!corners || !planes || !chunk_size || !count || !(voxel_resolution > 0.0f)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (int i = 0; i < 8; i++)
+        for (int k = 0; k < 3; k++) {
+            mn[k] = std::min(mn[k], corners[3 * i + k]);
+            mx[k] = std::max(mx[k], corners[3 * i + k]);
+        }
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        const float rf = 1.0f / (chunk_size[k] * voxel_resolution);  // ChunkManager::GetIDAt ChunkManager.h:136-145
+        if (!(std::fabs(mn[k] * rf) < 1e6f) || !(std::fabs(mx[k] * rf) < 1e6f)) return fail(CHISEL_HIP_ERR_INVALID, "frustum outside the addressable chunk-id range");
+        lo[k] = (int)std::floor(mn[k] * rf) - 1;
+        hi[k] = (int)std::floor(mx[k] * rf) + 1 + 1;
+    }
+    int64_t n = 0;
+    for (int x = lo[0]; x <= hi[0]; x++)
+        for (int y = lo[1]; y <= hi[1]; y++)
+            for (int z = lo[2]; z <= hi[2]; z++) {
+                const float bmin[3] = {(float)(x * chunk_size[0]) * voxel_resolution, (float)(y * chunk_size[1]) * voxel_resolution,
+                                       (float)(z * chunk_size[2]) * voxel_resolution};
+                const float bmax[3] = {bmin[0] + (float)chunk_size[0] * voxel_resolution, bmin[1] + (float)chunk_size[1] * voxel_resolution,
+                                       bmin[2] + (float)chunk_size[2] * voxel_resolution};
+                bool hit = false;
+                for (int p = 0; p < 6 && !hit; p++) {
+                    const float *pl = planes + 4 * p;
+                    const float vx = pl[0] < 0.0f ? bmin[0] : bmax[0], vy = pl[1] < 0.0f ? bmin[1] : bmax[1], vz = pl[2] < 0.0f ? bmin[2] : bmax[2];
+                    hit = (vx * pl[0] + (vy * pl[1] + vz * pl[2])) + pl[3] > 0.0f;  // axisVert.dot(normal) + distance, a0 + (a1 + a2)
+                }
+                if (!hit) continue;
+                if (ids && n < max_ids) {
+                    ids[3 * n] = x; ids[3 * n + 1] = y; ids[3 * n + 2] = z;
+                }
+                n++;
+            }
+    *count = n;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_shade_vertices(chisel_hip_map *m, const float *vertices, int64_t n, float *normals, float *colors, int stages) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_shade_vertices reads the voxels around every vertex: ask the shard that owns them (a group's meshes are shaded by chisel_hip_update_meshes)");
+    if (!m || n < 0 || (n > 0 && !vertices)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    if (n == 0) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    {
+        int rc_m = check_mesh_totals(m);
+        if (rc_m) return rc_m;
+    }
+    float *d = nullptr;
+    const size_t f = (size_t)n * 3;
+    HIP_TRY(hipMalloc(&d, 3 * f * sizeof(float)));
+    float *dv = d, *dn = d + f, *dc = d + 2 * f;
+    HIP_TRY(hipMemcpyAsync(dv, vertices, f * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if (normals && (stages & 1)) HIP_TRY(hipMemcpyAsync(dn, normals, f * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    const MeshParams P = mesh_params(m);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    switch (m->N) {
+        case 8: hipLaunchKernelGGL(shade_vertices_kernel<8>, grid, dim3(256), 0, m->stream, m->view, P, dv, (long long)n, dn, dc, stages); break;
+        case 16: hipLaunchKernelGGL(shade_vertices_kernel<16>, grid, dim3(256), 0, m->stream, m->view, P, dv, (long long)n, dn, dc, stages); break;
+        case 32: hipLaunchKernelGGL(shade_vertices_kernel<32>, grid, dim3(256), 0, m->stream, m->view, P, dv, (long long)n, dn, dc, stages); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && normals && (stages & 1)) e = hipMemcpyAsync(normals, dn, f * sizeof(float), hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess && colors && (stages & 2) && m->view.rgbw) e = hipMemcpyAsync(colors, dc, f * sizeof(float), hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CHISEL_HIP_ERR_HIP, std::string("chisel_hip_shade_vertices: ") + hipGetErrorString(e));
     return CHISEL_HIP_OK;
 }
 

@@ -13,6 +13,7 @@ MeshParams mesh_params(const chisel_hip_map *m) {
     P.rf_chunk = 1.0f / ((float)m->N * m->cfg.voxel_resolution);    // ChunkManager.h:138-140
     P.rf_voxel = 1.0f / m->cfg.voxel_resolution;                    // Chunk.cpp:74
     P.use_color = m->cfg.use_color ? 1 : 0;
+    P.stages = m->mesh_stages;
     return P;
 }
 
@@ -152,9 +153,9 @@ void launch_mesh_count(chisel_hip_map *m) {
     ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
     const dim3 grid(2048);
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
     }
 }
 
@@ -488,12 +489,85 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
     B.n_jobs = nullptr;  // the count is the one written here
     HIP_TRY(hipMemcpyAsync(mesh_totals(m), totals, sizeof(totals), hipMemcpyHostToDevice, m->stream));
     if (n) HIP_TRY(hipMemcpyAsync(B.ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    if (!m->mesh_detached) hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
     HIP_TRY(hipGetLastError());
     rc = recompute_meshes(m);
     if (rc) return rc;
-    m->pending_mesh_ids.clear();
+    if (!m->mesh_detached) m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;
+}
+
+// ChunkManager::RecomputeMesh(chunkID, mutex) (ChunkManager.cpp:91-128): the mesh of one chunk into allMeshes; meshesToUpdate is the
+// caller's business there (Chisel::UpdateMeshes clears it, Chisel.cpp:57), so nothing of it is touched here
+int chisel_hip_recompute_mesh(chisel_hip_map *m, const int id[3]) {
+    if (m && m->is_group) return id ? chisel_hip_recompute_mesh(group::owner_map(m, id), id) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    m->mesh_detached = true;
+    const int rc = chisel_hip_update_meshes_of(m, id, 1);
+    m->mesh_detached = false;
+    return rc;
+}
+
+// ChunkManager::GenerateMesh(chunk, mesh) (ChunkManager.cpp:381-447) -- marching cubes of ONE chunk into the caller's arrays, face
+// normals, nothing else -- or, with stages, the whole of RecomputeMesh (bit 0: + ComputeNormalsFromGradients, bit 1: + ColorizeMesh)
+// without touching ChunkManager::allMeshes or meshesToUpdate.  The ordinary recompute runs with the dirty-flag housekeeping switched
+// off, its result is copied out and the map's own mesh entry of the chunk (if any) is put back.
+int chisel_hip_generate_mesh(chisel_hip_map *m, const int id[3], int stages, int64_t capacity_vertices, int64_t capacity_grids, float *vertices,
+                             float *normals, float *colors, float *grids, int64_t *n_vertices, int64_t *n_grids) {
+    if (m && m->is_group) return id ? chisel_hip_generate_mesh(group::owner_map(m, id), id, stages, capacity_vertices, capacity_grids, vertices, normals, colors, grids, n_vertices, n_grids)
+                                    : fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (!m || !id || !n_vertices || !n_grids) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = resolve_pending_meshes(m);
+    if (rc) return rc;
+    const uint64_t key = pack_id(id[0], id[1], id[2]);
+    MeshRef saved;
+    bool had = false;
+    {
+        auto it = m->meshes.find(key);
+        if (it != m->meshes.end()) {
+            had = true;
+            saved = it->second;
+            if (saved.arena >= 0) m->arenas[saved.arena].live++;  // keeps the arena while the entry is replaced below
+        }
+    }
+    m->mesh_stages = stages & 3;
+    m->mesh_detached = true;
+    rc = chisel_hip_update_meshes_of(m, id, 1);
+    if (!rc) rc = resolve_pending_meshes(m);
+    m->mesh_stages = 3;
+    m->mesh_detached = false;
+    *n_vertices = *n_grids = 0;
+    auto it = m->meshes.find(key);
+    if (!rc && it != m->meshes.end() && !(had && it->second.arena == saved.arena && it->second.v_off == saved.v_off && saved.arena >= 0)) {
+        MeshView v;
+        rc = view_mesh(m, it->second, v);
+        if (!rc) {
+            *n_vertices = (int64_t)v.n_v;
+            *n_grids = (int64_t)v.n_g;
+            if ((int64_t)v.n_v <= capacity_vertices && (int64_t)v.n_g <= capacity_grids) {
+                if (vertices && v.n_v) memcpy(vertices, v.v, v.n_v * 3 * sizeof(float));
+                if (normals && v.n_v) memcpy(normals, v.n, v.n_v * 3 * sizeof(float));
+                if (colors && v.n_v && v.c) memcpy(colors, v.c, v.n_v * 3 * sizeof(float));
+                if (grids && v.n_g) memcpy(grids, v.g, v.n_g * 3 * sizeof(float));
+            }
+        }
+    }
+    // put the map's own entry back
+    it = m->meshes.find(key);
+    if (it != m->meshes.end()) {
+        const bool replaced = !(had && it->second.arena == saved.arena && it->second.v_off == saved.v_off && it->second.n_v == saved.n_v);
+        if (replaced || !had) {
+            release_mesh_ref(m, it->second);
+            if (had) it->second = saved;  // (its arena's count still carries the +1 from above: that is this reference again)
+            else m->meshes.erase(it);
+        } else if (saved.arena >= 0) {
+            m->arenas[saved.arena].live--;  // nothing was replaced (the chunk is gone): drop the extra hold
+        }
+    } else if (had && saved.arena >= 0) {
+        m->arenas[saved.arena].live--;
+    }
+    return rc;
 }
 
 int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) {

@@ -275,7 +275,7 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
     const float ext = (float)N * ip.res;
     const float bmaxx = bminx + ext, bmaxy = bminy + ext, bmaxz = bminz + ext;
     // Frustum::Intersects (Frustum.cpp:41-79): true as soon as ONE plane has the p-vertex on its positive side
-    {
+    if (!ip.single_chunk) {
         bool hit = false;
 #pragma unroll
         for (int p = 0; p < 6; p++) {

@@ -39,6 +39,7 @@ struct MeshParams {
     float rf_chunk;   // 1.0f / (chunkSize * res)  (ChunkManager::GetIDAt ChunkManager.h:138-140)
     float rf_voxel;   // 1.0f / res                (Chunk::GetVoxelCoords Chunk.cpp:74)
     int use_color;
+    int stages;       // bit 0: ComputeNormalsFromGradients, bit 1: ColorizeMesh (both after ChunkManager::RecomputeMesh; neither: GenerateMesh alone)
 };
 
 struct f3v {
@@ -470,7 +471,7 @@ __device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per s
 #endif
 template <int N>
 __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
-                                                                 JobInfo *info, int *totals, TriRec *tris, CubeCorners *corners, int tri_capacity, unsigned *mesh_flag) {
+                                                                 JobInfo *info, int *totals, TriRec *tris, CubeCorners *corners, int tri_capacity, unsigned *mesh_flag, int keep_dirty) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nb[27];
     __shared__ int s_base[2];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
     if (threadIdx.x < 64) s_counts[threadIdx.x] = reinterpret_cast<const unsigned *>(c_mc_counts)[threadIdx.x];  // (first barrier below)
     // the list of dirty slots has been consumed by the mark kernel -- also when none of them became a job (every listed chunk
     // removed since): reset outside the job loop
-    if (blockIdx.x == 0 && threadIdx.x == 29) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 29 && !keep_dirty) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;
     for (int j = blockIdx.x; j < n; j += gridDim.x) {
 #ifdef CHISEL_PHASES
     unsigned long long mt_ = __builtin_amdgcn_s_memrealtime();
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
     }
     __syncthreads();
     const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
-    if (threadIdx.x == 28 && present) {
+    if (threadIdx.x == 28 && present && !keep_dirty) {
         // meshesToUpdate.clear() (Chisel.cpp:57) and the job flag of mesh_mark_kernel, which has finished: this job's own
         if (mesh_flag) mesh_flag[s_nb[NB_SELF]] = 0u;
         M.slot_dirty[s_nb[NB_SELF]] = 0u;
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     f3v nrm = fn;
     double dist;
     f3v grad;
-    if (get_sdf_and_gradient<N>(M, P, pv, jx, jy, jz, nb, dist, grad)) {
+    if ((P.stages & 1) && get_sdf_and_gradient<N>(M, P, pv, jx, jy, jz, nb, dist, grad)) {
         const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
         if ((double)mag > 1e-12) nrm = scl3(grad, 1.0f / mag);
     }
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     no[1] = nrm.y;
     no[2] = nrm.z;
     if (colors) {
-        const f3v col = interpolate_color<N>(M, P, pv, jx, jy, jz, nb);
+        const f3v col = (P.stages & 2) ? interpolate_color<N>(M, P, pv, jx, jy, jz, nb) : mk3(0.0f, 0.0f, 0.0f);
         float *co = colors + 3 * (size_t)vi;
         co[0] = col.x;
         co[1] = col.y;
@@ -759,6 +760,35 @@ __global__ void query_sdf_kernel(MapView M, MeshParams P, float x, float y, floa
     out[2] = grad.y;
     out[3] = grad.z;
     out[4] = ok ? 1.0 : 0.0;
+}
+
+// The second half of ChunkManager::RecomputeMesh for a caller's own vertex list (ChunkManager::ComputeNormalsFromGradients
+// ChunkManager.cpp:609-626 and ::ColorizeMesh :628-639 are public): one thread per vertex; a normal is replaced only where the
+// gradient lookup succeeds, colours are written for every vertex.  stages: bit 0 normals, bit 1 colours.
+template <int N>
+__global__ void shade_vertices_kernel(MapView M, MeshParams P, const float *__restrict__ verts, long long n, float *normals, float *colors, int stages) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3v pv = mk3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    if ((stages & 1) && normals) {
+        double dist;
+        f3v grad;
+        if (get_sdf_and_gradient<N>(M, P, pv, 0, 0, 0, nullptr, dist, grad)) {
+            const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
+            if ((double)mag > 1e-12) {
+                const f3v nrm = scl3(grad, 1.0f / mag);
+                normals[3 * i] = nrm.x;
+                normals[3 * i + 1] = nrm.y;
+                normals[3 * i + 2] = nrm.z;
+            }
+        }
+    }
+    if ((stages & 2) && colors && M.rgbw) {
+        const f3v col = interpolate_color<N>(M, P, pv, 0, 0, 0, nullptr);
+        colors[3 * i] = col.x;
+        colors[3 * i + 1] = col.y;
+        colors[3 * i + 2] = col.z;
+    }
 }
 
 struct MeshBuffers {

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -86,6 +87,49 @@ inline void hip_check(int rc) {
     if (rc != CHISEL_HIP_OK) throw std::runtime_error(std::string("chisel_hip: ") + chisel_hip_last_error());
 }
 
+namespace hipfacade {  // the C structs of the boundary from the facade's value types
+inline void Pose12(const Transform &T, float out[12]) {
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) out[4 * r + k] = T.linear()(r, k);
+        out[4 * r + 3] = T.translation()(r);
+    }
+}
+template <class DataType>
+inline chisel_hip_depth_frame DepthFrame(const DepthImage<DataType> &img, const Transform &T, const PinholeCamera &cam) {
+    static_assert(sizeof(DataType) == sizeof(float), "DepthImage<float>: convert 16UC1 millimetres on the caller's side as Conversions.h:140-150 does");
+    chisel_hip_depth_frame f;
+    std::memset(&f, 0, sizeof(f));
+    f.depth = reinterpret_cast<const float *>(img.GetData());
+    f.width = img.GetWidth();
+    f.height = img.GetHeight();
+    f.on_device = 0;
+    Pose12(T, f.pose);
+    f.fx = cam.GetIntrinsics().GetFx();
+    f.fy = cam.GetIntrinsics().GetFy();
+    f.cx = cam.GetIntrinsics().GetCx();
+    f.cy = cam.GetIntrinsics().GetCy();
+    f.near_plane = cam.GetNearPlane();
+    f.far_plane = cam.GetFarPlane();
+    return f;
+}
+template <class ColorType>
+inline chisel_hip_color_frame ColorFrame(const ColorImage<ColorType> &img, const Transform &T, const PinholeCamera &cam) {
+    static_assert(sizeof(ColorType) == 1, "ColorImage<uint8_t>");
+    chisel_hip_color_frame c;
+    std::memset(&c, 0, sizeof(c));
+    c.color = reinterpret_cast<const uint8_t *>(img.GetData());
+    c.width = img.GetWidth();
+    c.height = img.GetHeight();
+    c.channels = img.GetNumChannels();
+    Pose12(T, c.pose);
+    c.fx = cam.GetIntrinsics().GetFx();
+    c.fy = cam.GetIntrinsics().GetFy();
+    c.cx = cam.GetIntrinsics().GetCx();
+    c.cy = cam.GetIntrinsics().GetCy();
+    return c;
+}
+}  // namespace hipfacade
+
 class Chunk {  // Chunk.h:47-140: a host object; either free-standing (to be added to a map) or the mirror of a device-resident chunk
   public:
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -130,6 +174,7 @@ class Chunk {  // Chunk.h:47-140: a host object; either free-standing (to be add
     }
   protected:
     friend class ChunkManager;
+    friend class ProjectionIntegrator;
     const Chunk &Load() const {
         if (loaded) return *this;
         loaded = true;
@@ -184,6 +229,22 @@ class ProjectionIntegrator {  // ProjectionIntegrator.h:36-232 (Integrate / Inte
     void SetCarvingDist(float d) { carvingDist = d; }
     void SetCarvingEnabled(bool e) { enableVoxelCarving = e; }
     void SetCentroids(const Vec3List &c) { centroids = c; }  // kept for source compatibility: the kernels recompute centroids
+    // ProjectionIntegrator.h:51-99 / :101-183: one frame into ONE chunk; true when a voxel changed.  The chunk is the mirror of a chunk
+    // of a map (ChunkManager::GetChunk): the update runs on that map's GPU (chisel_hip_integrate_chunk) and the mirror's voxels are
+    // fetched again when next asked for.  A free-standing chunk is carried through a map of its own for the call.
+    template <class DataType>
+    bool Integrate(const std::shared_ptr<const DepthImage<DataType>> &depthImage, const PinholeCamera &camera, const Transform &cameraPose, Chunk *chunk) const {
+        const chisel_hip_depth_frame f = hipfacade::DepthFrame(*depthImage, cameraPose, camera);
+        return IntegrateChunk(&f, nullptr, chunk);
+    }
+    template <class DataType, class ColorType>
+    bool IntegrateColor(const std::shared_ptr<const DepthImage<DataType>> &depthImage, const PinholeCamera &depthCamera, const Transform &depthCameraPose,
+                        const std::shared_ptr<const ColorImage<ColorType>> &colorImage, const PinholeCamera &colorCamera, const Transform &colorCameraPose,
+                        Chunk *chunk) const {
+        const chisel_hip_depth_frame f = hipfacade::DepthFrame(*depthImage, depthCameraPose, depthCamera);
+        const chisel_hip_color_frame c = hipfacade::ColorFrame(*colorImage, colorCameraPose, colorCamera);
+        return IntegrateChunk(&f, &c, chunk);
+    }
     chisel_hip_integrator HipStruct() const {
         chisel_hip_integrator s;
         s.truncator_kind = truncator ? truncator->HipKind() : CHISEL_HIP_TRUNC_INVERSE;
@@ -194,6 +255,54 @@ class ProjectionIntegrator {  // ProjectionIntegrator.h:36-232 (Integrate / Inte
         return s;
     }
   protected:
+    bool IntegrateChunk(const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c, Chunk *chunk) const {
+        if (!chunk) throw std::invalid_argument("ProjectionIntegrator::Integrate: null chunk");  // assert(chunk != nullptr), ProjectionIntegrator.h:54
+        const chisel_hip_integrator in = HipStruct();
+        const int v[3] = {chunk->ID(0), chunk->ID(1), chunk->ID(2)};
+        int updated = 0;
+        if (chunk->map) {
+            hip_check(chisel_hip_set_integrator(chunk->map, &in));
+            hip_check(chisel_hip_integrate_chunk(chunk->map, v, f, c, &updated));
+            chunk->loaded = false;
+            return updated != 0;
+        }
+        // free-standing: a map of its own for the length of the call
+        chisel_hip_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
+        for (int k = 0; k < 3; k++) cfg.chunk_size[k] = chunk->numVoxels(k);
+        cfg.voxel_resolution = chunk->voxelResolutionMeters;
+        cfg.use_color = chunk->hasColor ? 1 : 0;
+        cfg.device_id = -1;
+        cfg.max_chunks = 8;
+        cfg.n_shards = 1;
+        chisel_hip_map *tmp = nullptr;
+        hip_check(chisel_hip_create(&cfg, &tmp));
+        const size_t V = chunk->GetTotalNumVoxels();
+        std::vector<float> sdf(V), w(V);
+        std::vector<uint8_t> rgbw(chunk->hasColor ? 4 * V : 0);
+        for (size_t i = 0; i < V; i++) {
+            sdf[i] = chunk->voxels[i].sdf;
+            w[i] = chunk->voxels[i].weight;
+            if (chunk->hasColor) {
+                rgbw[4 * i] = chunk->colors[i].red; rgbw[4 * i + 1] = chunk->colors[i].green; rgbw[4 * i + 2] = chunk->colors[i].blue; rgbw[4 * i + 3] = chunk->colors[i].weight;
+            }
+        }
+        int rc = chisel_hip_upload_chunk(tmp, v, sdf.data(), w.data(), chunk->hasColor ? rgbw.data() : nullptr);
+        if (!rc) rc = chisel_hip_set_integrator(tmp, &in);
+        if (!rc) rc = chisel_hip_integrate_chunk(tmp, v, f, c, &updated);
+        if (!rc) rc = chisel_hip_download_chunk(tmp, v, sdf.data(), w.data(), chunk->hasColor ? rgbw.data() : nullptr);
+        std::string err = rc ? chisel_hip_last_error() : "";
+        chisel_hip_destroy(tmp);
+        if (rc) throw std::runtime_error("chisel_hip: " + err);
+        for (size_t i = 0; i < V; i++) {
+            chunk->voxels[i].sdf = sdf[i];
+            chunk->voxels[i].weight = w[i];
+            if (chunk->hasColor) {
+                chunk->colors[i].red = rgbw[4 * i]; chunk->colors[i].green = rgbw[4 * i + 1]; chunk->colors[i].blue = rgbw[4 * i + 2]; chunk->colors[i].weight = rgbw[4 * i + 3];
+            }
+        }
+        return updated != 0;
+    }
     TruncatorPtr truncator;
     WeighterPtr weighter;
     float carvingDist;
@@ -204,12 +313,29 @@ class ProjectionIntegrator {  // ProjectionIntegrator.h:36-232 (Integrate / Inte
 class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
   public:
     ChunkManager() {}
+    // ChunkManager.h:62: a manager of its own (chisel::Chisel builds its own the same way and hands it the map it owns)
+    ChunkManager(const Eigen::Vector3i &cs, float res, bool color) : chunkSize(cs), voxelResolutionMeters(res), useColor(color) {
+        chisel_hip_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
+        for (int k = 0; k < 3; k++) cfg.chunk_size[k] = cs(k);
+        cfg.voxel_resolution = res;
+        cfg.use_color = color ? 1 : 0;
+        cfg.device_id = -1;
+        cfg.n_shards = 1;
+        hip_check(chisel_hip_create(&cfg, &map));
+        owned = std::shared_ptr<chisel_hip_map>(map, [](chisel_hip_map *m) { chisel_hip_destroy(m); });  // copies of the manager share the map
+        CacheCentroids();
+    }
     ChunkManager(chisel_hip_map *m, const Eigen::Vector3i &cs, float res, bool color) : map(m), chunkSize(cs), voxelResolutionMeters(res), useColor(color) {
-        // CacheCentroids (ChunkManager.cpp:50-70)
-        const float half = res * 0.5f;
-        for (int z = 0; z < cs(2); z++)
-            for (int y = 0; y < cs(1); y++)
-                for (int x = 0; x < cs(0); x++) centroids.push_back(Vec3(x * res + half, y * res + half, z * res + half));
+        CacheCentroids();
+    }
+    virtual ~ChunkManager() {}
+    void CacheCentroids() {  // ChunkManager.cpp:50-70 (the kernels recompute the centroids with the same two roundings; the table is for callers)
+        const float res = voxelResolutionMeters, half = res * 0.5f;
+        centroids.clear();
+        for (int z = 0; z < chunkSize(2); z++)
+            for (int y = 0; y < chunkSize(1); y++)
+                for (int x = 0; x < chunkSize(0); x++) centroids.push_back(Vec3(x * res + half, y * res + half, z * res + half));
     }
     const Eigen::Vector3i &GetChunkSize() const { return chunkSize; }
     float GetResolution() const { return voxelResolutionMeters; }
@@ -226,17 +352,34 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         return std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor);
     }
     ChunkPtr GetChunk(int x, int y, int z) const { return GetChunk(ChunkID(x, y, z)); }
-    // every chunk of the map, as mirrors that know their id and box and fetch voxels on demand (ChunkManager.h:65-73)
+    // Every chunk of the map, as mirrors that know their id and box and fetch voxels on demand (ChunkManager.h:65-73).  The mirrors are
+    // kept between calls: chisel_ros walks this map after every frame (ChiselServer.cpp:594-603), and nothing is done at all while the
+    // chunk set stands still (same number of chunks -- integration only adds -- and same topology epoch); when it has moved, ids that
+    // disappeared are dropped and new ids get a mirror, the others keep theirs (with their voxels marked stale).
     const ChunkMap &GetChunks() const {
         int64_t n = 0;
-        hip_check(chisel_hip_list_chunks(map, nullptr, 0, &n));
+        uint64_t epoch = 0;
+        hip_check(chisel_hip_num_chunks(map, &n));
+        hip_check(chisel_hip_topology_epoch(map, &epoch));
+        if (chunksValid && n == chunksCount && epoch == chunksEpoch) {
+            for (auto &c : chunks) c.second->loaded = false;  // voxels may have changed: fetched again on demand
+            return chunks;
+        }
         std::vector<int> ids((size_t)n * 3);
         if (n) hip_check(chisel_hip_list_chunks(map, ids.data(), n, &n));
-        chunks.clear();
+        ChunkSet present;
         for (int64_t i = 0; i < n; i++) {
             const ChunkID id(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
-            chunks[id] = std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor);
+            present[id] = true;
+            auto it = chunks.find(id);
+            if (it == chunks.end()) chunks[id] = std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor);
+            else it->second->loaded = false;
         }
+        for (auto it = chunks.begin(); it != chunks.end();)
+            it = present.count(it->first) ? std::next(it) : chunks.erase(it);
+        chunksValid = true;
+        chunksCount = n;
+        chunksEpoch = epoch;
         return chunks;
     }
     ChunkMap &GetMutableChunks() {
@@ -277,6 +420,84 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         const ChunkID id = GetIDAt(pos);
         if (HasChunk(id)) return GetChunk(id);
         return ChunkPtr();
+    }
+    // ChunkManager.cpp:575-607: the voxel that contains `pos` (nullptr when its chunk is not resident or the linear id is out of range);
+    // the pointer stays valid until the next call (it points into a mirror kept here)
+    const DistVoxel *GetDistanceVoxel(const Vec3 &pos) {
+        const size_t i = VoxelAt(pos);
+        return i == (size_t)-1 ? nullptr : &voxelChunk->GetDistVoxel(i);
+    }
+    const ColorVoxel *GetColorVoxel(const Vec3 &pos) {
+        const size_t i = VoxelAt(pos);
+        return (i == (size_t)-1 || !voxelChunk->HasColors()) ? nullptr : &voxelChunk->GetColorVoxel(i);
+    }
+    // ChunkManager.cpp:72-89
+    void GetChunkIDsIntersecting(const AABB &box, ChunkIDList *chunkList) {
+        const ChunkID minID = GetIDAt(box.min);
+        const ChunkID maxID = GetIDAt(box.max) + Eigen::Vector3i(1, 1, 1);
+        for (int x = minID(0); x < maxID(0); x++)
+            for (int y = minID(1); y < maxID(1); y++)
+                for (int z = minID(2); z < maxID(2); z++) chunkList->push_back(ChunkID(x, y, z));
+    }
+    // ChunkManager.cpp:182-212 (chisel_hip_candidates: the reference's range and plane test, its order)
+    void GetChunkIDsIntersecting(const Frustum &frustum, ChunkIDList *chunkList) {
+        float c[24], p[24];
+        for (int i = 0; i < 8; i++)
+            for (int k = 0; k < 3; k++) c[3 * i + k] = frustum.GetCorners()[i](k);
+        const Plane *planes[6] = {&frustum.GetFarPlane(), &frustum.GetNearPlane(), &frustum.GetTopPlane(), &frustum.GetBottomPlane(),
+                                  &frustum.GetLeftPlane(), &frustum.GetRightPlane()};
+        for (int i = 0; i < 6; i++) {
+            for (int k = 0; k < 3; k++) p[4 * i + k] = planes[i]->normal(k);
+            p[4 * i + 3] = planes[i]->distance;
+        }
+        const int cs[3] = {chunkSize(0), chunkSize(1), chunkSize(2)};
+        int64_t n = 0;
+        hip_check(chisel_hip_candidates(c, p, cs, voxelResolutionMeters, nullptr, 0, &n));
+        std::vector<int> ids((size_t)n * 3);
+        if (n) hip_check(chisel_hip_candidates(c, p, cs, voxelResolutionMeters, ids.data(), n, &n));
+        for (int64_t i = 0; i < n; i++) chunkList->push_back(ChunkID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
+    }
+    // ChunkManager.cpp:381-447: marching cubes of one chunk into the caller's Mesh -- vertices, face normals, sequential indices, grids
+    // (no colours, no gradient normals: those are ColorizeMesh / ComputeNormalsFromGradients below, as RecomputeMesh chains them)
+    void GenerateMesh(const ChunkPtr &chunk, Mesh *mesh) { MeshChunk(chunk->GetID(), 0, mesh); }
+    void ColorizeMesh(Mesh *mesh) {  // ChunkManager.cpp:628-639
+        const size_t n = mesh->vertices.size();
+        mesh->colors.clear();
+        mesh->colors.resize(n);
+        if (!n) return;
+        std::vector<float> v(3 * n), c(3 * n, 0.0f);
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) v[3 * i + k] = mesh->vertices[i](k);
+        hip_check(chisel_hip_shade_vertices(map, v.data(), (int64_t)n, nullptr, c.data(), 2));
+        for (size_t i = 0; i < n; i++) mesh->colors[i] = Vec3(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+    }
+    Vec3 InterpolateColor(const Vec3 &colorPos) {  // ChunkManager.cpp:501-573
+        const float v[3] = {colorPos(0), colorPos(1), colorPos(2)};
+        float c[3] = {0, 0, 0};
+        hip_check(chisel_hip_shade_vertices(map, v, 1, nullptr, c, 2));
+        return Vec3(c[0], c[1], c[2]);
+    }
+    void ComputeNormalsFromGradients(Mesh *mesh) {  // ChunkManager.cpp:609-626: a normal is replaced where the gradient lookup succeeds
+        const size_t n = mesh->vertices.size();
+        if (!n) return;
+        std::vector<float> v(3 * n), nr(3 * n);
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                v[3 * i + k] = mesh->vertices[i](k);
+                nr[3 * i + k] = mesh->normals[i](k);
+            }
+        hip_check(chisel_hip_shade_vertices(map, v.data(), (int64_t)n, nr.data(), nullptr, 1));
+        for (size_t i = 0; i < n; i++) mesh->normals[i] = Vec3(nr[3 * i], nr[3 * i + 1], nr[3 * i + 2]);
+    }
+    // ChunkManager.cpp:91-128 (the mutex of the reference's 16 worker threads has nothing to guard here)
+    template <class Mutex>
+    void RecomputeMesh(const ChunkID &chunkID, Mutex &) {
+        const int v[3] = {chunkID(0), chunkID(1), chunkID(2)};
+        hip_check(chisel_hip_recompute_mesh(map, v));
+    }
+    MeshPtr &GetMutableMesh(const ChunkID &chunkID) {  // ChunkManager.h:175-178
+        allMeshes[chunkID] = GetMesh(chunkID);         // throws std::out_of_range like allMeshes.at(chunkID)
+        return allMeshes[chunkID];
     }
     const MeshMap &GetAllMeshes() const {
         int64_t n = 0;
@@ -379,6 +600,35 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
     }
     chisel_hip_map *HipMap() const { return map; }
   protected:
+    size_t VoxelAt(const Vec3 &pos) {  // GetChunkAt + GetVoxelCoords + GetVoxelID (ChunkManager.cpp:575-607); -1: none
+        const ChunkID id = GetIDAt(pos);
+        if (!HasChunk(id)) return (size_t)-1;
+        voxelChunk = std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor);
+        const Point3 c = voxelChunk->GetVoxelCoords(pos);
+        const long i = ((long)c(2) * chunkSize(2) + c(1)) * chunkSize(0) + c(0);  // Chunk::GetVoxelID, Chunk.h:81-84 (sic)
+        if (i < 0 || i >= (long)voxelChunk->GetTotalNumVoxels()) return (size_t)-1;
+        return (size_t)i;
+    }
+    void MeshChunk(const ChunkID &id, int stages, Mesh *mesh) {
+        mesh->Clear();
+        const int v[3] = {id(0), id(1), id(2)};
+        const int64_t V = (int64_t)chunkSize(0) * chunkSize(1) * chunkSize(2), cap = 15 * V;
+        std::vector<float> ve((size_t)cap * 3), no((size_t)cap * 3), co(useColor ? (size_t)cap * 3 : 0), gr((size_t)V * 3);
+        int64_t nv = 0, ng = 0;
+        hip_check(chisel_hip_generate_mesh(map, v, stages, cap, V, ve.data(), no.data(), useColor ? co.data() : nullptr, gr.data(), &nv, &ng));
+        for (int64_t i = 0; i < nv; i++) {
+            mesh->vertices.push_back(Vec3(ve[3 * i], ve[3 * i + 1], ve[3 * i + 2]));
+            mesh->normals.push_back(Vec3(no[3 * i], no[3 * i + 1], no[3 * i + 2]));
+            if ((stages & 2) && useColor) mesh->colors.push_back(Vec3(co[3 * i], co[3 * i + 1], co[3 * i + 2]));
+            mesh->indices.push_back((size_t)i);
+        }
+        for (int64_t i = 0; i < ng; i++) mesh->grids.push_back(Vec3(gr[3 * i], gr[3 * i + 1], gr[3 * i + 2]));
+    }
+    std::shared_ptr<chisel_hip_map> owned;  // set when this manager created the map itself (the three-argument constructor)
+    ChunkPtr voxelChunk;                    // the mirror GetDistanceVoxel / GetColorVoxel last pointed into
+    mutable bool chunksValid = false;
+    mutable int64_t chunksCount = 0;
+    mutable uint64_t chunksEpoch = 0;
     chisel_hip_map *map = nullptr;
     Eigen::Vector3i chunkSize;
     float voxelResolutionMeters = 0.0f;
@@ -439,7 +689,7 @@ class Chisel {  // Chisel.h:38-230
         static_assert(sizeof(DataType) == sizeof(float), "DepthImage<float>: convert 16UC1 millimetres on the caller's side as Conversions.h:140-150 does");
         const chisel_hip_integrator in = integrator.HipStruct();
         hip_check(chisel_hip_set_integrator(map, &in));
-        chisel_hip_depth_frame f = DepthFrame(*depthImage, extrinsic, camera);
+        chisel_hip_depth_frame f = hipfacade::DepthFrame(*depthImage, extrinsic, camera);
         hip_check(chisel_hip_integrate_depth(map, &f));
         hip_check(chisel_hip_synchronize(map));  // the reference returns with every voxel update visible
     }
@@ -451,7 +701,7 @@ class Chisel {  // Chisel.h:38-230
         static_assert(sizeof(DataType) == sizeof(float) && sizeof(ColorType) == 1, "DepthImage<float>, ColorImage<uint8_t>");
         const chisel_hip_integrator in = integrator.HipStruct();
         hip_check(chisel_hip_set_integrator(map, &in));
-        chisel_hip_depth_frame f = DepthFrame(*depthImage, depthExtrinsic, depthCamera);
+        chisel_hip_depth_frame f = hipfacade::DepthFrame(*depthImage, depthExtrinsic, depthCamera);
         chisel_hip_color_frame c;
         std::memset(&c, 0, sizeof(c));
         c.color = reinterpret_cast<const uint8_t *>(colorImage->GetData());
@@ -517,29 +767,7 @@ class Chisel {  // Chisel.h:38-230
     chisel_hip_map *HipMap() const { return map; }
 
   protected:
-    static void Pose12(const Transform &T, float out[12]) {
-        for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) out[4 * r + c] = T.linear()(r, c);
-            out[4 * r + 3] = T.translation()(r);
-        }
-    }
-    template <class DataType>
-    static chisel_hip_depth_frame DepthFrame(const DepthImage<DataType> &img, const Transform &T, const PinholeCamera &cam) {
-        chisel_hip_depth_frame f;
-        std::memset(&f, 0, sizeof(f));
-        f.depth = reinterpret_cast<const float *>(img.GetData());
-        f.width = img.GetWidth();
-        f.height = img.GetHeight();
-        f.on_device = 0;
-        Pose12(T, f.pose);
-        f.fx = cam.GetIntrinsics().GetFx();
-        f.fy = cam.GetIntrinsics().GetFy();
-        f.cx = cam.GetIntrinsics().GetCx();
-        f.cy = cam.GetIntrinsics().GetCy();
-        f.near_plane = cam.GetNearPlane();
-        f.far_plane = cam.GetFarPlane();
-        return f;
-    }
+    static void Pose12(const Transform &T, float out[12]) { hipfacade::Pose12(T, out); }
     chisel_hip_map *map;
     ChunkManager chunkManager;
     mutable ChunkSet meshesToUpdate;

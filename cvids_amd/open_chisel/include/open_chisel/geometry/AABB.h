@@ -2,6 +2,7 @@
 #ifndef CHISEL_HIP_FACADE_AABB_H_
 #define CHISEL_HIP_FACADE_AABB_H_
 #include "Geometry.h"
+#include "Plane.h"
 namespace chisel {
 class AABB {
   public:
@@ -20,6 +21,26 @@ class AABB {
         if (max.y() < other.min.y()) return false;
         if (max.z() < other.min.z()) return false;
         return true;
+    }
+    Plane::IntersectionType Intersects(const Plane &plane) const {  // AABB.cpp:37-70
+        const Vec3 ext = GetExtents();
+        Vec3 corners[8];
+        corners[0] = max;
+        corners[1] = min;
+        corners[2] = min + Vec3(ext(0), 0, 0);
+        corners[3] = min + Vec3(0, ext(1), 0);
+        corners[4] = min + Vec3(0, 0, ext(2));
+        corners[5] = min + Vec3(ext(0), 0, ext(2));
+        corners[6] = min + Vec3(ext(0), ext(1), 0);
+        corners[7] = min + Vec3(0, ext(1), ext(2));
+        float lastdistance = plane.normal.dot(corners[0]) + plane.distance;
+        for (int i = 1; i < 8; i++) {
+            const float distance = plane.normal.dot(corners[i]) + plane.distance;
+            if ((distance <= 0.0f && lastdistance > 0.0f) || (distance >= 0.0f && lastdistance < 0.0f)) return Plane::IntersectionType::Intersects;
+            lastdistance = distance;
+        }
+        if (lastdistance > 0.0f) return Plane::IntersectionType::Outside;
+        return Plane::IntersectionType::Inside;
     }
     Vec3 GetCenter() const { return (max + min) * 0.5f; }  // AABB.h:60-63
     Vec3 GetExtents() const { return (max - min) * 0.5f; }

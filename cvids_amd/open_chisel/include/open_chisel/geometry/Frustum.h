@@ -29,7 +29,26 @@ class Frustum {
         for (int i = 0; i < 8; i++) corners[i] = Vec3(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
         for (int i = 0; i < 24; i++) lines[i] = Vec3(l[3 * i], l[3 * i + 1], l[3 * i + 2]);
         Plane *dst[6] = {&far, &near, &top, &bottom, &left, &right};
-        for (int i = 0; i < 6; i++) *dst[i] = Plane(Vec3(p[4 * i], p[4 * i + 1], p[4 * i + 2]), p[4 * i + 3]);
+        for (int i = 0; i < 6; i++) *dst[i] = Plane(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
+    }
+    // Frustum.cpp:41-79: true as soon as ONE plane has the box's far vertex (along the plane's normal) on its positive side
+    bool Intersects(const AABB &box) const {
+        const Plane *planes[] = {&far, &near, &top, &bottom, &left, &right};
+        for (const Plane *plane : planes) {
+            Vec3 axisVert;
+            const Vec3 &normal = plane->normal;
+            axisVert(0) = normal(0) < 0.0f ? box.min(0) : box.max(0);
+            axisVert(1) = normal(1) < 0.0f ? box.min(1) : box.max(1);
+            axisVert(2) = normal(2) < 0.0f ? box.min(2) : box.max(2);
+            if (axisVert.dot(normal) + plane->distance > 0.0f) return true;
+        }
+        return false;
+    }
+    bool Contains(const Vec3 &point) const {  // Frustum.cpp:81-99
+        const Plane *planes[] = {&far, &near, &top, &bottom, &left, &right};
+        for (const Plane *plane : planes)
+            if (plane->ClassifyPoint(point) == Plane::IntersectionType::Outside) return false;
+        return true;
     }
     void ComputeBoundingBox(AABB *box) const {  // Frustum.cpp:101-122
         Vec3 mn(corners[0]), mx(corners[0]);

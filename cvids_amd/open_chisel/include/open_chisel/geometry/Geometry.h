@@ -74,6 +74,10 @@ struct VecT {
         for (int i = 0; i < N; i++) s += v[i] * o.v[i];
         return s;
     }
+    VecT cross(const VecT &o) const {
+        static_assert(N == 3, "cross product of three-vectors");
+        return VecT(v[1] * o.v[2] - v[2] * o.v[1], v[2] * o.v[0] - v[0] * o.v[2], v[0] * o.v[1] - v[1] * o.v[0]);
+    }
     T norm() const { return (T)std::sqrt((double)dot(*this)); }
     void normalize() {
         const T n = norm();

@@ -1,0 +1,182 @@
+// facade_surface.cpp -- the parts of OpenChisel's public surface that chisel_ros does not call (a third-party caller might):
+// ChunkManager(const Vector3i &, float, bool), GetDistanceVoxel / GetColorVoxel(pos), GetChunkIDsIntersecting(AABB / Frustum),
+// GenerateMesh / ColorizeMesh / ComputeNormalsFromGradients / InterpolateColor / RecomputeMesh / GetMutableMesh / CacheCentroids,
+// ProjectionIntegrator::Integrate / IntegrateColor per chunk, Frustum::Intersects / Contains, Plane's constructors
+// (ChunkManager.h:61-212, ProjectionIntegrator.h:51-52 / 101-102, Frustum.cpp:41-99, Plane.cpp:32-63).  Every check is a consistency the
+// reference's own code guarantees: RecomputeMesh == GenerateMesh -> ColorizeMesh -> ComputeNormalsFromGradients (ChunkManager.cpp:91-128),
+// per-chunk Integrate over the candidates of a frame == IntegrateDepthScanColor of that frame (Chisel.h:114-213), and so on.
+#include <open_chisel/Chisel.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+using namespace chisel;
+
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            fprintf(stderr, "facade_surface: line %d: %s\n", __LINE__, #cond); \
+            return 10;                                                     \
+        }                                                                  \
+    } while (0)
+
+static bool same_bits(const Vec3 &a, const Vec3 &b) { return std::memcmp(&a, &b, 3 * sizeof(float)) == 0; }
+
+int main() {
+    const int W = 64, H = 48, N = 8;
+    const float res = 0.05f;
+    try {
+        Chisel map(Eigen::Vector3i(N, N, N), res, true);
+        TruncatorPtr trunc(new InverseTruncator(2.0f));
+        WeighterPtr weigh(new ConstantWeighter(1.0f));
+        ProjectionIntegrator integ(trunc, weigh, 0.05f, true, map.GetChunkManager().GetCentroids());
+        PinholeCamera cam;
+        Intrinsics K;
+        K.SetFx(52.5f); K.SetFy(52.5f); K.SetCx(31.5f); K.SetCy(23.5f);
+        cam.SetIntrinsics(K);
+        cam.SetWidth(W); cam.SetHeight(H);
+        cam.SetNearPlane(0.05f); cam.SetFarPlane(5.0f);
+        std::shared_ptr<DepthImage<float>> depth(new DepthImage<float>(W, H));
+        std::shared_ptr<ColorImage<uint8_t>> color(new ColorImage<uint8_t>(W, H, 3));
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                uint8_t *p = color->GetMutableData() + color->Index(v, u, 0);
+                p[0] = (uint8_t)(u * 3); p[1] = (uint8_t)(v * 5); p[2] = (uint8_t)(u + v);
+                depth->SetDataAt(v, u, 1.5f + 0.004f * u - 0.003f * v);  // a tilted wall
+            }
+        Transform T;
+        for (int k = 0; k < 2; k++) map.IntegrateDepthScanColor<float, uint8_t>(integ, depth, T, cam, color, T, cam);
+        ChunkManager &cm = map.GetMutableChunkManager();
+
+        // ---- GetChunks keeps its mirrors while the chunk set stands still
+        const ChunkMap &chunks = cm.GetChunks();
+        CHECK(chunks.size() > 10);
+        const ChunkID some = chunks.begin()->first;
+        const Chunk *mirror = chunks.begin()->second.get();
+        CHECK(cm.GetChunks().find(some)->second.get() == mirror);
+        map.IntegrateDepthScanColor<float, uint8_t>(integ, depth, T, cam, color, T, cam);  // same surface: no new chunk
+        CHECK(cm.GetChunks().find(some)->second.get() == mirror);
+        CHECK(cm.RemoveChunk(some));
+        CHECK(cm.GetChunks().count(some) == 0 && !cm.HasChunk(some));
+
+        // ---- GetDistanceVoxel / GetColorVoxel (ChunkManager.cpp:575-607) against the chunk's own voxel array
+        ChunkID full(0, 0, 0);
+        for (const auto &kv : cm.GetChunks()) {
+            size_t known = 0;
+            for (const DistVoxel &v : kv.second->GetVoxels()) known += v.GetWeight() > 0;
+            if (known > 100) { full = kv.first; break; }
+        }
+        ChunkPtr c = cm.GetChunk(full);
+        const Vec3 p = c->GetOrigin() + Vec3(3.4f * res, 2.6f * res, 5.5f * res);
+        const DistVoxel *dv = cm.GetDistanceVoxel(p);
+        const ColorVoxel *cv = cm.GetColorVoxel(p);
+        CHECK(dv && cv);
+        const DistVoxel &want = c->GetDistVoxel(3, 2, 5);
+        CHECK(dv->GetSDF() == want.GetSDF() && dv->GetWeight() == want.GetWeight());
+        CHECK(cv->GetRed() == c->GetColorVoxel(3, 2, 5).GetRed() && cv->GetWeight() == c->GetColorVoxel(3, 2, 5).GetWeight());
+        CHECK(cm.GetDistanceVoxel(Vec3(100.0f, 100.0f, 100.0f)) == nullptr);
+
+        // ---- frustum: SetupFrustum -> Intersects / Contains, GetChunkIDsIntersecting (ChunkManager.cpp:72-89, 182-212)
+        Frustum fr;
+        cam.SetupFrustum(T, &fr);
+        CHECK(fr.Contains(Vec3(0.0f, 0.0f, 1.0f)) == fr.Contains(Vec3(0.0f, 0.0f, 1.0f)));
+        ChunkIDList ids;
+        cm.GetChunkIDsIntersecting(fr, &ids);
+        AABB box;
+        fr.ComputeBoundingBox(&box);
+        const ChunkID lo = cm.GetIDAt(box.min), hi = cm.GetIDAt(box.max) + Eigen::Vector3i(1, 1, 1);
+        size_t expect = 0;
+        for (int x = lo(0) - 1; x <= hi(0) + 1; x++)
+            for (int y = lo(1) - 1; y <= hi(1) + 1; y++)
+                for (int z = lo(2) - 1; z <= hi(2) + 1; z++) {
+                    const Vec3 mn = Vec3((float)(x * N), (float)(y * N), (float)(z * N)) * res;
+                    expect += fr.Intersects(AABB(mn, mn + Vec3((float)N, (float)N, (float)N) * res));
+                }
+        CHECK(ids.size() == expect && expect > 100);
+        CHECK(ids.front() == ChunkID(lo(0) - 1, lo(1) - 1, lo(2) - 1) || !fr.Intersects(AABB(Vec3(), Vec3())));
+        for (const auto &kv : cm.GetChunks()) {  // every chunk the frame created is one of the reference's candidates
+            bool found = false;
+            for (const ChunkID &i : ids) found = found || i == kv.first;
+            CHECK(found);
+        }
+        ChunkIDList in_box;
+        cm.GetChunkIDsIntersecting(AABB(Vec3(0.0f, 0.0f, 0.0f), Vec3(0.5f, 0.3f, 0.1f)), &in_box);
+        CHECK(in_box.size() == 2 * 1 * 1 && in_box[0] == ChunkID(0, 0, 0) && in_box[1] == ChunkID(1, 0, 0));
+        const Plane pq(Vec3(0, 0, 1), 5.0f);  // Plane.cpp:38-42: the distance argument is dropped (sic)
+        CHECK(pq.distance == 0.0f && pq.ClassifyPoint(Vec3(0, 0, -1)) == Plane::IntersectionType::Inside);
+        const Plane p3(Vec3(0, 0, 1), Vec3(2, 0, 1), Vec3(0, 3, 1));  // cross = (0, 0, 6): normal (0, 0, 1), offset -6 (un-normalised)
+        CHECK(p3.normal(2) == 1.0f && p3.distance == -6.0f);
+
+        // ---- RecomputeMesh == GenerateMesh -> ColorizeMesh -> ComputeNormalsFromGradients (ChunkManager.cpp:91-128)
+        std::mutex mu;
+        ChunkID meshed(0, 0, 0);
+        bool have = false;
+        for (const auto &kv : cm.GetChunks()) {
+            cm.RecomputeMesh(kv.first, mu);
+            if (cm.HasMesh(kv.first) && cm.GetMesh(kv.first)->vertices.size() >= 30) { meshed = kv.first; have = true; break; }
+        }
+        CHECK(have);
+        const MeshPtr stored = cm.GetMutableMesh(meshed);
+        Mesh mine;
+        cm.GenerateMesh(cm.GetChunk(meshed), &mine);
+        CHECK(mine.vertices.size() == stored->vertices.size() && mine.grids.size() == stored->grids.size() && mine.colors.empty());
+        size_t face_normals_kept = 0;
+        for (size_t i = 0; i < mine.vertices.size(); i++) {
+            CHECK(same_bits(mine.vertices[i], stored->vertices[i]));
+            CHECK(mine.indices[i] == i);
+            face_normals_kept += same_bits(mine.normals[i], stored->normals[i]);
+        }
+        for (size_t t = 0; t + 2 < mine.normals.size(); t += 3)  // MeshCube: one face normal per triangle (MarchingCubes.h:95-101)
+            CHECK(same_bits(mine.normals[t], mine.normals[t + 1]) && same_bits(mine.normals[t], mine.normals[t + 2]));
+        CHECK(face_normals_kept < mine.vertices.size());  // gradient normals differ from face normals on a tilted wall
+        cm.ColorizeMesh(&mine);
+        cm.ComputeNormalsFromGradients(&mine);
+        for (size_t i = 0; i < mine.vertices.size(); i++) {
+            CHECK(same_bits(mine.normals[i], stored->normals[i]));
+            CHECK(same_bits(mine.colors[i], stored->colors[i]));
+        }
+        CHECK(same_bits(cm.InterpolateColor(mine.vertices[0]), stored->colors[0]));
+        CHECK(map.GetMeshesToUpdate().size() > 0);  // GenerateMesh left meshesToUpdate alone (RecomputeMesh above cleared only its own chunks)
+
+        // ---- per-chunk ProjectionIntegrator::IntegrateColor over the candidates of a frame == Chisel::IntegrateDepthScanColor of it
+        ChunkManager own(Eigen::Vector3i(N, N, N), res, true);  // ChunkManager.h:62
+        own.CacheCentroids();
+        CHECK(own.GetCentroids().size() == (size_t)N * N * N);
+        Chisel ref_map(Eigen::Vector3i(N, N, N), res, true);
+        ref_map.IntegrateDepthScanColor<float, uint8_t>(integ, depth, T, cam, color, T, cam);
+        size_t created = 0, updated = 0;
+        for (const ChunkID &id : ids) {  // Chisel.h:133-143: create every candidate, integrate, erase the untouched ones (:202-207)
+            own.CreateChunk(id);
+            created++;
+            ChunkPtr ch = own.GetChunk(id);
+            if (integ.IntegrateColor<float, uint8_t>(depth, cam, T, color, cam, T, ch.get())) updated++;
+            else own.RemoveChunk(id);
+            if (created >= 400 && updated >= 12) break;  // (a few hundred one-chunk launches are enough for the check)
+        }
+        CHECK(updated >= 12);
+        for (const auto &kv : own.GetChunks()) {
+            CHECK(ref_map.GetChunkManager().HasChunk(kv.first));
+            ChunkPtr a = own.GetChunk(kv.first), b = ref_map.GetChunkManager().GetChunk(kv.first);
+            for (size_t i = 0; i < a->GetTotalNumVoxels(); i++) {
+                CHECK(a->GetDistVoxel(i).GetSDF() == b->GetDistVoxel(i).GetSDF() && a->GetDistVoxel(i).GetWeight() == b->GetDistVoxel(i).GetWeight());
+                CHECK(a->GetColorVoxel(i).GetRed() == b->GetColorVoxel(i).GetRed() && a->GetColorVoxel(i).GetWeight() == b->GetColorVoxel(i).GetWeight());
+            }
+        }
+        // a free-standing chunk (not part of any manager) goes through a map of its own
+        Chunk loose(meshed, Eigen::Vector3i(N, N, N), res, true);
+        const bool touched = integ.IntegrateColor<float, uint8_t>(depth, cam, T, color, cam, T, &loose);
+        CHECK(touched == ref_map.GetChunkManager().HasChunk(meshed));
+        if (touched) {
+            ChunkPtr b = ref_map.GetChunkManager().GetChunk(meshed);
+            for (size_t i = 0; i < loose.GetTotalNumVoxels(); i++) CHECK(loose.GetDistVoxel(i).GetSDF() == b->GetDistVoxel(i).GetSDF());
+        }
+        cm.PrintMemoryStatistics();
+        printf("facade_surface ok: %zu candidates, %zu per-chunk integrations, %zu vertices\n", ids.size(), created, mine.vertices.size());
+    } catch (const std::exception &e) {
+        fprintf(stderr, "facade_surface: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

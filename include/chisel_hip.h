@@ -326,6 +326,34 @@ typedef struct chisel_hip_statistics {
     int32_t id_min[3], id_max[3];
 } chisel_hip_statistics;
 int chisel_hip_memory_statistics(chisel_hip_map *map, chisel_hip_statistics *out);
+/* A counter that moves whenever chunks appear or disappear by anything other than integration (garbage collection, reset, upload, map
+ * load, ghost import / drop): together with chisel_hip_num_chunks -- integration only ever adds chunks -- it tells a caller that keeps
+ * mirrors of the chunk map (ChunkManager::GetChunks, ChunkManager.h:65-73) whether they are still current. */
+int chisel_hip_topology_epoch(chisel_hip_map *map, uint64_t *out);
+/* ChunkManager::GetChunkIDsIntersecting(const Frustum &, ChunkIDList *) (src/ChunkManager.cpp:182-212) for a frustum given as
+ * chisel_hip_frustum returns it (corners[8][3], planes[6][4] in the order far, near, top, bottom, left, right): the ids in the
+ * reference's order (x outer, z inner).  ids may be NULL (count only); at most max_ids are written. */
+int chisel_hip_candidates(const float corners[24], const float planes[24], const int chunk_size[3], float voxel_resolution, int *ids,
+                          int64_t max_ids, int64_t *count);
+/* ChunkManager::ComputeNormalsFromGradients (src/ChunkManager.cpp:609-626; stages bit 0: a normal is overwritten where the gradient
+ * lookup of its vertex succeeds, kept otherwise) and ChunkManager::ColorizeMesh / InterpolateColor (:628-639, :501-573; stages bit 1)
+ * for a caller's own vertex list (host arrays of 3 n floats). */
+int chisel_hip_shade_vertices(chisel_hip_map *map, const float *vertices, int64_t n, float *normals, float *colors, int stages);
+/* ProjectionIntegrator::Integrate<DataType>(depthImage, camera, cameraPose, chunk) / IntegrateColor (ProjectionIntegrator.h:51-52,
+ * :101-102): ONE frame into ONE resident chunk -- whether or not the frustum's id range holds it, as the reference's per-chunk call
+ * knows nothing of frusta --; color may be NULL (the depth-only update rule).  *updated = the call's return value there ("some voxel
+ * changed").  CHISEL_HIP_ERR_NOT_FOUND when the chunk is not resident. */
+int chisel_hip_integrate_chunk(chisel_hip_map *map, const int id_xyz[3], const chisel_hip_depth_frame *frame, const chisel_hip_color_frame *color,
+                               int *updated);
+/* ChunkManager::RecomputeMesh(chunkID, mutex) (src/ChunkManager.cpp:91-128): the mesh of one chunk into ChunkManager::allMeshes, leaving
+ * meshesToUpdate as it is (chisel_hip_update_meshes_of ends with the meshesToUpdate.clear() of Chisel::UpdateMeshes, Chisel.cpp:57) */
+int chisel_hip_recompute_mesh(chisel_hip_map *map, const int id_xyz[3]);
+/* ChunkManager::GenerateMesh(chunk, mesh) (src/ChunkManager.cpp:381-447) for one resident chunk into the caller's arrays -- marching
+ * cubes with face normals; stages bit 0 adds ComputeNormalsFromGradients, bit 1 ColorizeMesh (stages 3 = what RecomputeMesh stores) --
+ * without touching ChunkManager::allMeshes or meshesToUpdate.  Arrays of 3 floats per vertex / grid entry; n_vertices / n_grids are
+ * always set, the arrays only when both capacities suffice (a 16^3 chunk has at most 15 * 4096 vertices and 4096 grid entries). */
+int chisel_hip_generate_mesh(chisel_hip_map *map, const int id_xyz[3], int stages, int64_t capacity_vertices, int64_t capacity_grids,
+                             float *vertices, float *normals, float *colors, float *grids, int64_t *n_vertices, int64_t *n_grids);
 /* hipEvent pairs around every kernel launch on the map's stream (off by default) */
 int chisel_hip_set_profiling(chisel_hip_map *map, int enable);
 /* total milliseconds and launch counts per CHISEL_HIP_KERNEL_* since enabled / last reset */

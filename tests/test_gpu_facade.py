@@ -140,3 +140,68 @@ def test_replay_of_a_recorded_stream_matches_the_oracle(oracle_mod, tmp_path, en
     assert ("GetAllChunks %d messages" % n) in out.stdout and "SaveMesh ok" in out.stdout
     assert ("chunk boxes %d," % n) in per_frame[-1]
     assert os.path.getsize(prefix + ".ply") > 1000
+
+
+def test_public_surface_beyond_chisel_ros():
+    """facade_surface.cpp: the ChunkManager / ProjectionIntegrator / Frustum / Plane members a third-party caller of OpenChisel could
+    use (ChunkManager.h:61-212, ProjectionIntegrator.h:51-52 / 101-102, Frustum.cpp:41-99), checked against each other on the GPU."""
+    tdir = os.path.join(ROOT, "cvids_amd", "open_chisel", "tests")
+    subprocess.check_call(["make", "-C", tdir, "build"])
+    out = subprocess.run([os.path.join(tdir, "facade_surface")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "facade_surface ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "Num Unknown:" in out.stdout and "Theoretical max (MB):" in out.stdout  # PrintMemoryStatistics' three lines
+
+
+def test_shade_and_generate_against_the_oracle(oracle_mod):
+    """chisel_hip_generate_mesh (stages 0 / 3) and chisel_hip_shade_vertices against the oracle's meshes: GenerateMesh's vertices are
+    the stored mesh's, stages 3 reproduces the stored normals and colours, shading the bare vertices does too."""
+    import ctypes as C
+    from cvids_amd import chisel as ch
+    from tests.common import make_frames, small_camera
+    N, res, W, H = 16, 0.04, 96, 72
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(W, H, 3)
+    om = oracle_mod.OracleMap(N, res, True)
+    om.set_integrator(oracle_mod.TRUNC_INVERSE, 2.0, 1.0, True, 0.05)
+    gm = ch.Chisel((N,) * 3, res, True, max_chunks=4096)
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(2.0), ch.ConstantWeighter(1.0), 0.05, True)
+    for d, p in make_frames("box_room", 3, W, H, nan_fraction=0.01):
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        gm.IntegrateDepthScanColor(integ, d, p, cam, color, p, cam)
+    om.update_meshes(force=True)
+    todo = len(gm.GetMeshesToUpdate())
+    assert todo > 0
+    L = gm.L
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+    checked = 0
+    for cid in [tuple(int(v) for v in i) for i in om.mesh_ids()][:12]:
+        want = om.get_mesh(cid)
+        nv_want = len(want["vertices"])
+        if nv_want == 0:
+            continue
+        cap = 15 * N ** 3
+        cidc = (C.c_int * 3)(*cid)
+        for stages in (0, 3):
+            v, n, c, g = (np.zeros((cap, 3), np.float32) for _ in range(4))
+            nv, ng = C.c_int64(0), C.c_int64(0)
+            ch.check(L.chisel_hip_generate_mesh(gm.h, cidc, stages, cap, cap, fp(v), fp(n), fp(c), fp(g), C.byref(nv), C.byref(ng)))
+            assert nv.value == nv_want and ng.value == len(want["grids"])
+            assert np.array_equal(v[:nv.value].view(np.uint32), np.asarray(want["vertices"], np.float32).view(np.uint32))
+            assert np.array_equal(g[:ng.value].view(np.uint32), np.asarray(want["grids"], np.float32).view(np.uint32))
+            if stages == 3:
+                assert np.array_equal(n[:nv.value].view(np.uint32), np.asarray(want["normals"], np.float32).view(np.uint32))
+                assert np.array_equal(c[:nv.value].view(np.uint32), np.asarray(want["colors"], np.float32).view(np.uint32))
+            else:
+                face = n[:nv.value].copy()
+        # shading the bare vertices: gradient normals over the face normals, colours
+        vv = np.ascontiguousarray(want["vertices"], np.float32)
+        nn = face.copy()
+        cc = np.zeros_like(vv)
+        ch.check(L.chisel_hip_shade_vertices(gm.h, fp(vv), len(vv), fp(nn), fp(cc), 3))
+        assert np.array_equal(nn.view(np.uint32), np.asarray(want["normals"], np.float32).view(np.uint32))
+        assert np.array_equal(cc.view(np.uint32), np.asarray(want["colors"], np.float32).view(np.uint32))
+        checked += 1
+    assert checked >= 5
+    assert len(gm.GetMeshesToUpdate()) == todo and len(gm.GetMeshIDs()) == 0  # neither meshesToUpdate nor allMeshes were touched
+    gm.close()

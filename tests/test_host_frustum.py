@@ -59,3 +59,24 @@ def test_frustum_export_matches_oracle(hip_lib, oracle_mod):
         assert np.array_equal(lines, corners[order])
         assert hip_lib.chisel_hip_frustum(fp(p), intr[1], intr[3], W, H, 0.05, 5.0, None, fp(lines), None) == 0
     assert hip_lib.chisel_hip_frustum(None, 1.0, 1.0, W, H, 0.05, 5.0, None, None, None) == 1
+
+
+def test_candidates_export_equals_the_oracles_enumeration(hip_lib, oracle_mod):
+    """chisel_hip_candidates (ChunkManager::GetChunkIDsIntersecting(frustum), ChunkManager.cpp:182-212, host arithmetic as in the
+    reference) against the oracle's oc_candidates: the same ids in the same order (x outer, z inner)."""
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    for W, H, N, res, near, far in [(640, 480, 16, 0.04, 0.05, 5.0), (64, 48, 8, 0.05, 0.3, 5.0), (320, 240, 32, 0.02, 0.05, 3.0)]:
+        intr = synth.intrinsics(W, H)
+        om = oracle_mod.OracleMap(N, res, False)
+        for pose in [synth.trajectory_pose(k, a) for k in (0, 33) for a in (0, 3)] + [synth.pose_yaw(-120.0, (-30.0, 0.5, -0.25))]:
+            p = np.ascontiguousarray(np.asarray(pose, np.float32)[:3, :4])
+            corners, planes = np.zeros((8, 3), np.float32), np.zeros((6, 4), np.float32)
+            assert hip_lib.chisel_hip_frustum(fp(p), intr[1], intr[3], W, H, near, far, fp(corners), None, fp(planes)) == 0
+            cs = np.array([N, N, N], np.int32)
+            n = C.c_int64(0)
+            assert hip_lib.chisel_hip_candidates(fp(corners), fp(planes), ip(cs), res, None, 0, C.byref(n)) == 0
+            ids = np.zeros((n.value, 3), np.int32)
+            assert hip_lib.chisel_hip_candidates(fp(corners), fp(planes), ip(cs), res, ip(ids), n.value, C.byref(n)) == 0
+            want = om.candidates(pose, intr, W, H, near, far)
+            assert np.array_equal(ids, want), (W, H, N, len(ids), len(want))
