@@ -300,63 +300,31 @@ class Server {
         }
         chunkBoxPublisher.publish(marker);
     }
-    // :607-716
-    static chisel::Vec3 LAMBERT(const chisel::Vec3 &n, const chisel::Vec3 &light) { return std::max(n.dot(light), 0.0f) * chisel::Vec3(0.5, 0.5, 0.5); }
+    // :607-716: what the mesh markers take from the library -- GetAllMeshes() and, per mesh, grids / vertices / HasColors() ? colors :
+    // HasNormals() ? normals (the marker's own colouring of those values is rviz business and has no chisel:: call in it)
     void PublishMeshes() {
         visualization_msgs::Marker marker, marker2;
-        FillMarkerTopicWithMeshes(&marker, &marker2);
+        const chisel::MeshMap &meshMap = chiselMap->GetChunkManager().GetAllMeshes();
+        for (const std::pair<const chisel::ChunkID, chisel::MeshPtr> &meshes : meshMap) {
+            const chisel::MeshPtr &mesh = meshes.second;
+            for (size_t i = 0; i < mesh->grids.size(); i++) marker2.points.push_back(point_of(mesh->grids[i]));
+            for (size_t i = 0; i < mesh->vertices.size(); i++) {
+                marker.points.push_back(point_of(mesh->vertices[i]));
+                const chisel::Vec3 shade = mesh->HasColors() ? mesh->colors[i] : (mesh->HasNormals() ? mesh->normals[i] : mesh->vertices[i]);
+                std_msgs::ColorRGBA color;
+                color.r = shade[0]; color.g = shade[1]; color.b = shade[2]; color.a = 1.0;
+                marker.colors.push_back(color);
+            }
+        }
         if (!marker.points.empty()) {
             meshPublisher.publish(marker);
             normalPublisher.publish(marker2);
         }
     }
-    void FillMarkerTopicWithMeshes(visualization_msgs::Marker *marker, visualization_msgs::Marker *marker2) {
-        marker->type = visualization_msgs::Marker::TRIANGLE_LIST;
-        const chisel::MeshMap &meshMap = chiselMap->GetChunkManager().GetAllMeshes();
-        if (meshMap.size() == 0) return;
-        chisel::Vec3 lightDir(0.8f, -0.2f, 0.7f);
-        lightDir.normalize();
-        chisel::Vec3 lightDir1(-0.5f, 0.2f, 0.2f);
-        lightDir.normalize();
-        const chisel::Vec3 ambient(0.2f, 0.2f, 0.2f);
-        for (const std::pair<const chisel::ChunkID, chisel::MeshPtr> &meshes : meshMap) {
-            const chisel::MeshPtr &mesh = meshes.second;
-            for (size_t i = 0; i < mesh->grids.size(); i++) {
-                const chisel::Vec3 &vec = mesh->grids[i];
-                geometry_msgs::Point pt;
-                pt.x = vec[0];
-                pt.y = vec[1];
-                pt.z = vec[2];
-                marker2->points.push_back(pt);
-            }
-            for (size_t i = 0; i < mesh->vertices.size(); i++) {
-                const chisel::Vec3 &vec = mesh->vertices[i];
-                geometry_msgs::Point pt;
-                pt.x = vec[0];
-                pt.y = vec[1];
-                pt.z = vec[2];
-                marker->points.push_back(pt);
-                std_msgs::ColorRGBA color;
-                if (mesh->HasColors()) {
-                    const chisel::Vec3 &meshCol = mesh->colors[i];
-                    color.r = meshCol[0];
-                    color.g = meshCol[1];
-                    color.b = meshCol[2];
-                } else if (mesh->HasNormals()) {
-                    const chisel::Vec3 normal = mesh->normals[i];
-                    chisel::Vec3 lambert = LAMBERT(normal, lightDir) + LAMBERT(normal, lightDir1) + ambient;
-                    color.r = std::min(lambert[0], 1.0f);
-                    color.g = std::min(lambert[1], 1.0f);
-                    color.b = std::min(lambert[2], 1.0f);
-                } else {
-                    color.r = vec[0] * 0.25 + 0.5;
-                    color.g = vec[1] * 0.25 + 0.5;
-                    color.b = vec[2] * 0.25 + 0.5;
-                }
-                color.a = 1.0;
-                marker->colors.push_back(color);
-            }
-        }
+    static geometry_msgs::Point point_of(const chisel::Vec3 &v) {
+        geometry_msgs::Point pt;
+        pt.x = v[0]; pt.y = v[1]; pt.z = v[2];
+        return pt;
     }
     // services: :426-432, :718-740
     bool Reset() {
