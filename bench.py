@@ -546,6 +546,7 @@ def main():
                "pcie_copy_gb_per_s_measured": (64 << 20) / best / 1e9,
                "source": "every frame's depth and colour image ((u + k, v, u + v + k) mod 256) copied from page-locked host memory into one of two "
                          "device buffer sets on a copy stream, overlapped with the previous batch's integration (events, no host wait)"}
+    sharded_totals = (getattr(m.sharded, "shell_bytes", 0), getattr(m.sharded, "whole_chunk_bytes", 0)) if world > 1 else (0, 0)
     m.close()
 
     if rank == 0:
@@ -569,7 +570,9 @@ def main():
         }
         if world > 1:
             out["sharded_meshing"] = {"recomputes": mesh_stats["recomputes"],
-                                      "ghost_bytes_per_recompute_rank0": mesh_stats["ghost_bytes"] / max(1, mesh_stats["recomputes"])}
+                                      "ghost_bytes_per_recompute_rank0": mesh_stats["ghost_bytes"] / max(1, mesh_stats["recomputes"]),
+                                      "whole_ghost_chunks_would_be": sharded_totals[1] / max(1, mesh_stats["recomputes"]),
+                                      "shells_over_whole_chunks": sharded_totals[0] / max(1, sharded_totals[1])}
             out["note"] = ("N > 1: one map sharded over the ranks (total work fixed); every batch is all-gathered, every rank integrates the chunks it "
                            "owns and meshes them with ghost copies of the neighbours other ranks own")
         if roof:

@@ -67,7 +67,8 @@ EXPORTS = [
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
-    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
+    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan",
+    "chisel_hip_shell_volume", "chisel_hip_export_shells", "chisel_hip_import_ghost_shells", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
 ]
 # the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
 SELFTEST_EXPORTS = [
@@ -161,6 +162,12 @@ def load_library():
         L.chisel_hip_shade_vertices.argtypes = [vp, f32p, C.c_int64, f32p, f32p, C.c_int]
         L.chisel_hip_integrate_chunk.argtypes = [vp, i32p, C.POINTER(DepthFrame), C.POINTER(ColorFrame), i32p]
         L.chisel_hip_recompute_mesh.argtypes = [vp, i32p]
+        L.chisel_hip_dirty_ids_device.argtypes = [vp, vp, C.c_int]
+        L.chisel_hip_mesh_shell_plan.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]
+        L.chisel_hip_shell_volume.argtypes = [C.c_int, C.c_int]
+        L.chisel_hip_shell_volume.restype = C.c_int64
+        L.chisel_hip_export_shells.argtypes = [vp, i32p, C.c_int, vp, vp, vp, vp, C.c_int]
+        L.chisel_hip_import_ghost_shells.argtypes = [vp, i32p, C.c_int, vp, vp, vp, vp, C.c_int]
         L.chisel_hip_generate_mesh.argtypes = [vp, i32p, C.c_int, C.c_int64, C.c_int64, f32p, f32p, f32p, f32p, i64p, i64p]
     if hasattr(L, "chisel_hip_memory_statistics"):
         L.chisel_hip_memory_statistics.argtypes = [vp, C.POINTER(Statistics)]

@@ -280,6 +280,69 @@ class Chisel:
                                                     found.ctypes.data_as(C.POINTER(C.c_int)) if found is not None else None, int(on_device)))
         self._keep = [sdf, wgt, col]
 
+    # ---- meshing a sharded map with shells (chisel_hip.h "meshing a sharded map with shells") --------------------
+    def DirtyIdsDevice(self, out):
+        """out: torch int32 CUDA tensor of 1 + 4 * capacity elements -> [n, (x, y, z, flag) * n] (filled on the map's stream: no wait)"""
+        check(self.L.chisel_hip_dirty_ids_device(self.h, out.data_ptr(), (out.numel() - 1) // 4))
+
+    def DirtyEntries(self):
+        """the same list on the host: (n, 4) int32"""
+        import torch
+        cap = 1 << 14
+        while True:
+            buf = torch.zeros((1 + 4 * cap,), dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            torch.cuda.current_stream().synchronize()  # the buffer is zero before the map's stream writes into it
+            self.DirtyIdsDevice(buf)
+            self.synchronize()
+            h = buf.cpu().numpy()
+            if h[0] <= cap:
+                return h[1:1 + 4 * int(h[0])].reshape(-1, 4).copy()
+            cap = 2 * int(h[0])
+
+    def ExportShells(self, items, device=False):
+        """items: (n, 4) int32 (x, y, z, box) -> (sdf [vox], weight [vox], rgbw [vox, 4] or None, found [n]) packed box after box;
+        device=True: torch CUDA tensors, nothing has been waited for (record_event orders the consumer)"""
+        items = np.ascontiguousarray(np.asarray(items, np.int32).reshape(-1, 4))
+        n = len(items)
+        edge = self.chunk_size[0]
+        vox = int(sum(self.L.chisel_hip_shell_volume(int(b), edge) for b in items[:, 3])) if n else 0
+        if device:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            sdf = torch.empty((vox,), dtype=torch.float32, device=dev)
+            wgt = torch.empty((vox,), dtype=torch.float32, device=dev)
+            col = torch.empty((vox, 4), dtype=torch.uint8, device=dev) if self.use_color else None
+            found = torch.empty((n,), dtype=torch.int32, device=dev)  # (every entry is written by the kernel)
+            ptr = lambda t: t.data_ptr() if t is not None else None
+        else:
+            sdf, wgt = np.empty(vox, np.float32), np.empty(vox, np.float32)
+            col = np.empty((vox, 4), np.uint8) if self.use_color else None
+            found = np.zeros(n, np.int32)
+            ptr = lambda a: a.ctypes.data if a is not None else None
+        if n:
+            check(self.L.chisel_hip_export_shells(self.h, items.ctypes.data_as(C.POINTER(C.c_int)), n, ptr(sdf), ptr(wgt), ptr(col), ptr(found),
+                                                  int(bool(device))))
+        self._keep = [items]
+        return sdf, wgt, col, found
+
+    def ImportGhostShells(self, items, sdf, wgt, col, found):
+        """payload as ExportShells returns it (numpy arrays, or torch CUDA tensors used in place behind wait_event)"""
+        items = np.ascontiguousarray(np.asarray(items, np.int32).reshape(-1, 4))
+        n = len(items)
+        if not n:
+            return
+        on_device = not isinstance(sdf, np.ndarray) and getattr(sdf, "is_cuda", False)
+        if on_device:
+            ptr = lambda t: t.data_ptr() if t is not None else None
+        else:
+            sdf, wgt = np.ascontiguousarray(sdf, np.float32), np.ascontiguousarray(wgt, np.float32)
+            col = np.ascontiguousarray(col, np.uint8) if col is not None else None
+            found = np.ascontiguousarray(found, np.int32)
+            ptr = lambda a: a.ctypes.data if a is not None else None
+        check(self.L.chisel_hip_import_ghost_shells(self.h, items.ctypes.data_as(C.POINTER(C.c_int)), n, ptr(sdf), ptr(wgt), ptr(col), ptr(found),
+                                                    int(on_device)))
+        self._keep = [items, sdf, wgt, col, found]
+
     def DropGhostChunks(self):
         check(self.L.chisel_hip_drop_ghost_chunks(self.h))
 
@@ -541,3 +604,20 @@ def publish_cloud(depth64, color):
 def chunk_owner(cid, n_shards, shard_block=2):
     c = (C.c_int * 3)(*[int(v) for v in cid])
     return capi.load_library().chisel_hip_chunk_owner(c, int(n_shards), int(shard_block))
+
+
+def mesh_shell_plan(entries, n_shards, rank, shard_block=2):
+    """chisel_hip_mesh_shell_plan: entries (n, 4) int32 (x, y, z, flag) -> (jobs (nj, 3), items (ni, 5): owner, x, y, z, box)"""
+    L = capi.load_library()
+    e = np.ascontiguousarray(np.asarray(entries, np.int32).reshape(-1, 4))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+    nj, ni = C.c_int64(0), C.c_int64(0)
+    check(L.chisel_hip_mesh_shell_plan(ip(e), len(e), int(n_shards), int(rank), int(shard_block), None, 0, C.byref(nj), None, 0, C.byref(ni)))
+    jobs, items = np.zeros((nj.value, 3), np.int32), np.zeros((ni.value, 5), np.int32)
+    check(L.chisel_hip_mesh_shell_plan(ip(e), len(e), int(n_shards), int(rank), int(shard_block), ip(jobs), nj.value, C.byref(nj), ip(items), ni.value,
+                                       C.byref(ni)))
+    return jobs, items
+
+
+def shell_volume(box, chunk_edge):
+    return int(capi.load_library().chisel_hip_shell_volume(int(box), int(chunk_edge)))

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <set>
@@ -206,6 +207,10 @@ struct chisel_hip_map {
     std::vector<int> ghost_ids;                                        // chunks of other shards imported for meshing (x, y, z triples)
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
+    uint64_t ghost_bytes = 0;                                          // group handle: ghost voxel bytes its recomputes have moved between shards
+    int *shell_items_dev = nullptr;                                    // staging of the items / offsets of chisel_hip_export_shells / import_ghost_shells
+    long long *shell_offs_dev = nullptr;
+    int shell_capacity = 0;
     bool single_chunk = false;                                         // chisel_hip_integrate_chunk: the next integrate call sees this id only
     int single_id[3] = {0, 0, 0};
     int mesh_stages = 3;                                               // MeshParams::stages of the next recompute (chisel_hip_generate_mesh lowers it)
@@ -973,7 +978,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->stream) (void)sync_all(m);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.block_counters, m->view_dev, m->scratch_i};
+                    v.counters, v.block_counters, m->view_dev, m->scratch_i, m->shell_items_dev, m->shell_offs_dev};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
@@ -1496,6 +1501,247 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     return CHISEL_HIP_OK;
 }
 
+
+// ---- meshing a sharded map: shells (kernels_map.h) -------------------------------------------------------------------------------
+namespace {
+// items (x, y, z, box) and their payload offsets onto the device (the map's stream; staging buffers kept by the map)
+int stage_shell_items(chisel_hip_map *m, const int *items, int n, long long *total) {
+    if (n > m->shell_capacity) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (m->shell_items_dev) HIP_TRY(hipFree(m->shell_items_dev));
+        if (m->shell_offs_dev) HIP_TRY(hipFree(m->shell_offs_dev));
+        m->shell_items_dev = nullptr;
+        m->shell_offs_dev = nullptr;
+        const int cap = std::max(4096, 2 * n);
+        HIP_TRY(hipMalloc(&m->shell_items_dev, (size_t)cap * 4 * sizeof(int)));
+        HIP_TRY(hipMalloc(&m->shell_offs_dev, (size_t)cap * sizeof(long long)));
+        m->shell_capacity = cap;
+    }
+    std::vector<long long> offs((size_t)n);
+    long long t = 0;
+    for (int j = 0; j < n; j++) {
+        if (items[4 * j + 3] < 0 || items[4 * j + 3] > 63) return fail(CHISEL_HIP_ERR_INVALID, "bad shell box code");
+        offs[(size_t)j] = t;
+        t += shell_volume(items[4 * j + 3], m->N);
+    }
+    *total = t;
+    HIP_TRY(hipMemcpyAsync(m->shell_items_dev, items, (size_t)n * 4 * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->shell_offs_dev, offs.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, m->stream));
+    return CHISEL_HIP_OK;
+}
+}  // namespace
+
+int chisel_hip_dirty_ids_device(chisel_hip_map *m, int *out_dev, int capacity) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || !out_dev || capacity < 0) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    // meshesToUpdate entries kept on the host (27-neighbourhoods of chunks removed while dirty) come first, as entries that are not
+    // expanded again (flag 1); the kernel appends the dirty chunks (flag 0) behind them
+    if (m->input_event) {  // chisel_hip_wait_event: the caller's buffer is ready behind this event (its allocator's stream, not the map's)
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    std::vector<int> head(1, 0);
+    for (uint64_t key : m->pending_mesh_ids) {
+        if (head[0] >= capacity) break;
+        int x, y, z;
+        unpack_id(key, x, y, z);
+        head.push_back(x); head.push_back(y); head.push_back(z); head.push_back(1);
+        head[0]++;
+    }
+    HIP_TRY(hipMemcpyAsync(out_dev, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(list_dirty_ids_kernel, dim3(256), dim3(256), 0, m->stream, m->view, out_dev, capacity);
+    HIP_TRY(hipGetLastError());
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_export_shells(chisel_hip_map *m, const int *items, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || n < 0 || (n > 0 && (!items || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    if (n == 0) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    {
+        int rc_m = check_mesh_totals(m);
+        if (rc_m) return rc_m;
+    }
+    if (m->input_event) {  // chisel_hip_wait_event: the output buffers may be used from here on
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    long long total = 0;
+    int rc = stage_shell_items(m, items, n, &total);
+    if (rc) return rc;
+    const bool color = m->view.rgbw && rgbw;
+    ChunkStage st;
+    float *d_s = sdf, *d_w = weight;
+    uchar4 *d_c = reinterpret_cast<uchar4 *>(rgbw);
+    int *d_f = found;
+    if (!on_device) {
+        HIP_TRY(hipMalloc(&st.sdf, (size_t)total * sizeof(float)));
+        HIP_TRY(hipMalloc(&st.wgt, (size_t)total * sizeof(float)));
+        if (color) HIP_TRY(hipMalloc(&st.col, (size_t)total * sizeof(uchar4)));
+        HIP_TRY(hipMalloc(&st.flags, (size_t)n * sizeof(int)));
+        d_s = st.sdf; d_w = st.wgt; d_c = st.col; d_f = st.flags;
+    }
+    hipLaunchKernelGGL(export_shells_kernel, dim3(n), dim3(256), 0, m->stream, m->view, m->shell_items_dev, m->shell_offs_dev, m->N, d_s, d_w, color ? d_c : nullptr, d_f);
+    HIP_TRY(hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(sdf, st.sdf, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(weight, st.wgt, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        if (color) HIP_TRY(hipMemcpyAsync(rgbw, st.col, (size_t)total * sizeof(uchar4), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(found, st.flags, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    return CHISEL_HIP_OK;  // on_device: nothing has been waited for (chisel_hip_record_event orders the consumer)
+}
+
+int chisel_hip_import_ghost_shells(chisel_hip_map *m, const int *items, int n, const float *sdf, const float *weight, const uint8_t *rgbw,
+                                   const int *found, int on_device) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || n < 0 || (n > 0 && (!items || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    if (n == 0) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    m->topology_epoch++;
+    int rc = check_mesh_totals(m);
+    if (rc) return rc;
+    // the distinct ghosts (several boxes may belong to one), each with the item whose `found` decides whether it is created
+    std::unordered_set<uint64_t, IdHash> seen;
+    std::vector<int> first;
+    for (int j = 0; j < n; j++) {
+        if (chunk_owner(items[4 * j], items[4 * j + 1], items[4 * j + 2], m->cfg.n_shards, m->cfg.shard_block) == m->cfg.shard_rank)
+            return fail(CHISEL_HIP_ERR_INVALID, "a ghost chunk must belong to another shard");
+        if (seen.insert(pack_id(items[4 * j], items[4 * j + 1], items[4 * j + 2])).second) first.push_back(j);
+    }
+    if (m->input_event) {  // chisel_hip_wait_event: the payload arrives on another stream (the collective's)
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    long long total = 0;
+    rc = stage_shell_items(m, items, n, &total);
+    if (rc) return rc;
+    ChunkStage st;
+    const float *d_s = sdf, *d_w = weight;
+    const uchar4 *d_c = reinterpret_cast<const uchar4 *>(rgbw);
+    const int *d_f = found;
+    if (!on_device) {
+        HIP_TRY(hipMalloc(&st.sdf, (size_t)total * sizeof(float)));
+        HIP_TRY(hipMalloc(&st.wgt, (size_t)total * sizeof(float)));
+        HIP_TRY(hipMalloc(&st.flags, (size_t)n * sizeof(int)));
+        HIP_TRY(hipMemcpyAsync(st.sdf, sdf, (size_t)total * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(st.wgt, weight, (size_t)total * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(st.flags, found, (size_t)n * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        if (rgbw) {
+            HIP_TRY(hipMalloc(&st.col, (size_t)total * sizeof(uchar4)));
+            HIP_TRY(hipMemcpyAsync(st.col, rgbw, (size_t)total * sizeof(uchar4), hipMemcpyHostToDevice, m->stream));
+        }
+        d_s = st.sdf; d_w = st.wgt; d_c = st.col; d_f = st.flags;
+    }
+    // phase 1: one thread block per distinct ghost creates the chunk (distinct ids never collide); phase 2: every box is written
+    int *d_first = nullptr;
+    HIP_TRY(hipMalloc(&d_first, first.size() * sizeof(int)));
+    hipError_t e1 = hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, m->stream);
+    if (e1 == hipSuccess) {
+        hipLaunchKernelGGL(ensure_ghosts_kernel, dim3((unsigned)first.size()), dim3(64), 0, m->stream, m->view, m->shell_items_dev, d_first, d_f);
+        hipLaunchKernelGGL(import_shells_kernel, dim3(n), dim3(256), 0, m->stream, m->view, m->shell_items_dev, m->shell_offs_dev, d_f, m->N, d_s, d_w, d_c);
+        e1 = hipGetLastError();
+    }
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(m->stream);  // (d_first is freed below; the payload has been read)
+    (void)hipFree(d_first);
+    if (e1 != hipSuccess) return fail(CHISEL_HIP_ERR_HIP, std::string("chisel_hip_import_ghost_shells: ") + hipGetErrorString(e1));
+    HIP_TRY(hipGetLastError());
+    // every item may have become a ghost (which of them were resident at their owner is known on the device only): all are dropped
+    // again by chisel_hip_drop_ghost_chunks (removing an absent id does nothing)
+    for (int j = 0; j < n; j++) m->ghost_ids.insert(m->ghost_ids.end(), items + 4 * j, items + 4 * j + 3);
+    if (!on_device) HIP_TRY(hipStreamSynchronize(m->stream));  // (the staging buffers above are freed on return)
+    HIP_TRY(note_map_mutation(m));
+    return CHISEL_HIP_OK;
+}
+
+// The plan of one rank for a recompute of a sharded map (pure host arithmetic, the same on every rank for the same entries -- so
+// every rank can also work out what the others will ask of it, and the request lists need no exchange of their own):
+//   entries: (x, y, z, flag) x n: flag 0 = a chunk updated since the last recompute (its 27-neighbourhood is to be meshed,
+//            Chisel.h:175-189), flag 1 = an id to be meshed as it is
+//   jobs:    the ids of that set `rank` owns, ascending (x, then y, then z)
+//   items:   (owner, x, y, z, box) x n_items, ascending by owner, then id, then box: the ghosts `rank` needs -- the 26 neighbours of
+//            its jobs that other shards own -- with the boxes of each (what its jobs read of it; a box another one contains is
+//            dropped, the two ends of one axis become one box)
+int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shards, int rank, int shard_block, int *jobs, int64_t max_jobs,
+                               int64_t *n_jobs, int *items, int64_t max_items, int64_t *n_items) {
+    if ((n_entries > 0 && !entries) || n_shards < 1 || rank < 0 || rank >= n_shards || !n_jobs || !n_items) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    const int sb = shard_block < 1 ? 2 : shard_block;
+    std::set<std::array<int, 3>> mine;
+    for (int64_t i = 0; i < n_entries; i++) {
+        const int *e = entries + 4 * i;
+        const int r = e[3] ? 0 : 1;
+        for (int dx = -r; dx <= r; dx++)
+            for (int dy = -r; dy <= r; dy++)
+                for (int dz = -r; dz <= r; dz++)
+                    if (chunk_owner(e[0] + dx, e[1] + dy, e[2] + dz, n_shards, sb) == rank) mine.insert({e[0] + dx, e[1] + dy, e[2] + dz});
+    }
+    // (owner, x, y, z) -> the boxes asked of that ghost: one per job and direction, minus those another one contains
+    auto axis_within = [](int a, int b) { return b == 0 || a == b || (b == 3 && a != 0); };  // coordinates of code a within those of code b
+    auto box_within = [&](int a, int b) { return axis_within(a & 3, b & 3) && axis_within((a >> 2) & 3, (b >> 2) & 3) && axis_within((a >> 4) & 3, (b >> 4) & 3); };
+    std::map<std::array<int, 4>, std::vector<int>> ghosts;
+    for (const auto &j : mine)
+        for (int dx = -1; dx <= 1; dx++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dz = -1; dz <= 1; dz++) {
+                    if (!dx && !dy && !dz) continue;
+                    const int g[3] = {j[0] + dx, j[1] + dy, j[2] + dz};
+                    const int o = chunk_owner(g[0], g[1], g[2], n_shards, sb);
+                    if (o == rank) continue;
+                    const int d[3] = {dx, dy, dz};
+                    int box = 0;
+                    for (int a = 0; a < 3; a++) box |= (d[a] > 0 ? 1 : (d[a] < 0 ? 2 : 0)) << (2 * a);
+                    std::vector<int> &v = ghosts[{o, g[0], g[1], g[2]}];
+                    bool covered = false;
+                    for (int b : v) covered = covered || box_within(box, b);
+                    if (covered) continue;
+                    v.erase(std::remove_if(v.begin(), v.end(), [&](int b) { return box_within(b, box); }), v.end());
+                    v.push_back(box);
+                }
+    // two boxes that differ on one axis only, one end each: one box with both ends
+    int64_t total_items = 0;
+    for (auto &g : ghosts) {
+        std::vector<int> &v = g.second;
+        bool merged = true;
+        while (merged) {
+            merged = false;
+            for (size_t i = 0; i < v.size() && !merged; i++)
+                for (size_t k = i + 1; k < v.size() && !merged; k++)
+                    for (int a = 0; a < 3 && !merged; a++) {
+                        const int m = 3 << (2 * a), ca = (v[i] >> (2 * a)) & 3, cb = (v[k] >> (2 * a)) & 3;
+                        if ((v[i] & ~m) == (v[k] & ~m) && ca != 0 && cb != 0 && ca != cb) {
+                            v[i] = (v[i] & ~m) | (3 << (2 * a));
+                            v.erase(v.begin() + (long)k);
+                            merged = true;
+                        }
+                    }
+        }
+        std::sort(v.begin(), v.end());
+        total_items += (int64_t)v.size();
+    }
+    *n_jobs = (int64_t)mine.size();
+    *n_items = total_items;
+    int64_t k = 0;
+    if (jobs)
+        for (const auto &j : mine) {
+            if (k >= max_jobs) break;
+            jobs[3 * k] = j[0]; jobs[3 * k + 1] = j[1]; jobs[3 * k + 2] = j[2];
+            k++;
+        }
+    k = 0;
+    if (items)
+        for (const auto &g : ghosts)
+            for (int box : g.second) {
+                if (k >= max_items) break;
+                items[5 * k] = g.first[0]; items[5 * k + 1] = g.first[1]; items[5 * k + 2] = g.first[2]; items[5 * k + 3] = g.first[3]; items[5 * k + 4] = box;
+                k++;
+            }
+    return CHISEL_HIP_OK;
+}
+// voxels in the payload of a box of a chunk of edge n
+int64_t chisel_hip_shell_volume(int box, int chunk_edge) { return (int64_t)shell_volume(box, chunk_edge); }
 
 int chisel_hip_save_map(chisel_hip_map *m, const char *path) {
     if (m && m->is_group) return group::save_map(m, path);

@@ -279,67 +279,83 @@ int update_meshes(chisel_hip_map *g, int force) {
     if (!force && (g->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;  // Chisel.cpp:53-58: every 10th call
     const int W = n_shards(g);
     if (W == 1) return chisel_hip_update_meshes(g->shards[0], 1);
+    // meshesToUpdate of the whole map, as (x, y, z, 1) entries (already the 27-neighbourhoods: chisel_hip_meshes_to_update expands)
     std::vector<int> uni;
     int rc = gather_ids(g, chisel_hip_meshes_to_update, true, uni);
     if (rc) return rc;
-    const size_t V = (size_t)g->V;
+    std::vector<int> entries;
+    entries.reserve(uni.size() / 3 * 4);
+    for (size_t j = 0; j + 2 < uni.size(); j += 3) {
+        entries.insert(entries.end(), uni.begin() + j, uni.begin() + j + 3);
+        entries.push_back(1);
+    }
     const bool color = g->cfg.use_color != 0;
     for (int r = 0; r < W; r++) {
-        // jobs of shard r, and the neighbours of its jobs it does not own, by owner
-        std::vector<int> jobs;
-        for (size_t j = 0; j + 2 < uni.size(); j += 3)
-            if (owner_of(g, &uni[j]) == r) jobs.insert(jobs.end(), uni.begin() + j, uni.begin() + j + 3);
-        std::vector<std::set<std::array<int, 3>>> want(W);
-        for (size_t j = 0; j + 2 < jobs.size(); j += 3)
-            for (int dz = -1; dz <= 1; dz++)
-                for (int dy = -1; dy <= 1; dy++)
-                    for (int dx = -1; dx <= 1; dx++) {
-                        if (!dx && !dy && !dz) continue;
-                        const int id[3] = {jobs[j] + dx, jobs[j + 1] + dy, jobs[j + 2] + dz};
-                        const int o = owner_of(g, id);
-                        if (o != r) want[o].insert({id[0], id[1], id[2]});
-                    }
+        // the plan of shard r: its jobs and, per ghost it needs, the shell that travels (chisel_hip_mesh_shell_plan: one item per ghost,
+        // ascending by owner)
+        int64_t nj = 0, ni = 0;
+        rc = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, nullptr, 0, &nj, nullptr, 0, &ni);
+        if (rc) return rc;
+        std::vector<int> jobs((size_t)nj * 3), items((size_t)ni * 5);
+        rc = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, jobs.data(), nj, &nj, items.data(), ni, &ni);
+        if (rc) return rc;
         chisel_hip_map *dst = g->shards[r];
-        for (int o = 0; o < W; o++) {
-            if (want[o].empty()) continue;
+        for (int64_t lo = 0; lo < ni;) {
+            const int o = items[5 * lo];
+            int64_t hi = lo;
+            std::vector<int> it4;
+            long long vox = 0;
+            while (hi < ni && items[5 * hi] == o) {
+                it4.insert(it4.end(), items.begin() + 5 * hi + 1, items.begin() + 5 * hi + 5);
+                vox += shell_volume(items[5 * hi + 4], g->N);
+                hi++;
+            }
+            const int n = (int)(hi - lo);
+            lo = hi;
             chisel_hip_map *src = g->shards[o];
-            std::vector<int> ids;
-            for (const auto &a : want[o]) ids.insert(ids.end(), a.begin(), a.end());
-            const int n = (int)ids.size() / 3;
-            // payload: exported into HBM on the owner's device, brought to the meshing shard's device, imported from HBM
+            // payload: packed into HBM on the owner's device, brought to the meshing shard's device, installed from HBM
             float *sdf = nullptr, *wgt = nullptr;
             uint8_t *rgbw = nullptr;
-            std::vector<int> found(n);
+            int *found = nullptr;
             HIP_TRY(hipSetDevice(src->device));
-            HIP_TRY(hipMalloc(&sdf, (size_t)n * V * sizeof(float)));
-            HIP_TRY(hipMalloc(&wgt, (size_t)n * V * sizeof(float)));
-            if (color) HIP_TRY(hipMalloc(&rgbw, (size_t)n * V * 4));
-            rc = chisel_hip_export_chunks(src, ids.data(), n, sdf, wgt, rgbw, found.data(), 1);
+            HIP_TRY(hipMalloc(&sdf, (size_t)vox * sizeof(float)));
+            HIP_TRY(hipMalloc(&wgt, (size_t)vox * sizeof(float)));
+            HIP_TRY(hipMalloc(&found, (size_t)n * sizeof(int)));
+            if (color) HIP_TRY(hipMalloc(&rgbw, (size_t)vox * 4));
+            rc = chisel_hip_export_shells(src, it4.data(), n, sdf, wgt, rgbw, found, 1);
+            if (!rc) rc = chisel_hip_synchronize(src);  // the payload is complete (the peer copies below run on no stream of the owner)
             float *sdf2 = sdf, *wgt2 = wgt;
             uint8_t *rgbw2 = rgbw;
+            int *found2 = found;
             if (!rc && src->device != dst->device) {
                 HIP_TRY(hipSetDevice(dst->device));
-                HIP_TRY(hipMalloc(&sdf2, (size_t)n * V * sizeof(float)));
-                HIP_TRY(hipMalloc(&wgt2, (size_t)n * V * sizeof(float)));
-                if (color) HIP_TRY(hipMalloc(&rgbw2, (size_t)n * V * 4));
-                HIP_TRY(hipMemcpyPeer(sdf2, dst->device, sdf, src->device, (size_t)n * V * sizeof(float)));
-                HIP_TRY(hipMemcpyPeer(wgt2, dst->device, wgt, src->device, (size_t)n * V * sizeof(float)));
-                if (color) HIP_TRY(hipMemcpyPeer(rgbw2, dst->device, rgbw, src->device, (size_t)n * V * 4));
+                HIP_TRY(hipMalloc(&sdf2, (size_t)vox * sizeof(float)));
+                HIP_TRY(hipMalloc(&wgt2, (size_t)vox * sizeof(float)));
+                HIP_TRY(hipMalloc(&found2, (size_t)n * sizeof(int)));
+                if (color) HIP_TRY(hipMalloc(&rgbw2, (size_t)vox * 4));
+                HIP_TRY(hipMemcpyPeer(sdf2, dst->device, sdf, src->device, (size_t)vox * sizeof(float)));
+                HIP_TRY(hipMemcpyPeer(wgt2, dst->device, wgt, src->device, (size_t)vox * sizeof(float)));
+                HIP_TRY(hipMemcpyPeer(found2, dst->device, found, src->device, (size_t)n * sizeof(int)));
+                if (color) HIP_TRY(hipMemcpyPeer(rgbw2, dst->device, rgbw, src->device, (size_t)vox * 4));
             }
-            if (!rc) rc = chisel_hip_import_ghost_chunks(dst, ids.data(), n, sdf2, wgt2, rgbw2, found.data(), 1);
+            if (!rc) rc = chisel_hip_import_ghost_shells(dst, it4.data(), n, sdf2, wgt2, rgbw2, found2, 1);
             if (!rc) rc = chisel_hip_synchronize(dst);  // the import has read the payload
             if (sdf2 != sdf) {
+                (void)hipSetDevice(dst->device);
                 (void)hipFree(sdf2);
                 (void)hipFree(wgt2);
+                (void)hipFree(found2);
                 if (rgbw2) (void)hipFree(rgbw2);
             }
             (void)hipSetDevice(src->device);
             (void)hipFree(sdf);
             (void)hipFree(wgt);
+            (void)hipFree(found);
             if (rgbw) (void)hipFree(rgbw);
             if (rc) return rc;
+            g->ghost_bytes += (uint64_t)vox * (color ? 12 : 8);
         }
-        rc = chisel_hip_update_meshes_of(dst, jobs.data(), (int)jobs.size() / 3);
+        rc = chisel_hip_update_meshes_of(dst, jobs.data(), (int)nj);
         if (rc) return rc;
         rc = chisel_hip_drop_ghost_chunks(dst);
         if (rc) return rc;

@@ -312,6 +312,112 @@ __global__ __launch_bounds__(256) void import_chunks_kernel(MapView M, const int
         if (M.rgbw) M.rgbw[dst + v] = rgbw ? rgbw[src + v] : make_uchar4(0, 0, 0, 0);
     }
 }
+// ---- meshing a sharded map with shells instead of whole ghost chunks -------------------------------------------------------------
+// What a job chunk J reads of a neighbour G = J + d (d in {-1, 0, 1}^3): cube corners one voxel into the "+" neighbours, gradients
+// one voxel around the voxel that holds a vertex (vertices lie between the centres of voxel 0 and of the "+" neighbour's voxel 0),
+// the nearest voxel's colour: along an axis with d = +1 the coordinates {0, 1} of G, with d = -1 the coordinate {N - 1}, with d = 0 all
+// of them.  A box code holds that choice per axis (2 bits each: 0 = all, 1 = {0, 1}, 2 = {N - 1}, 3 = {0, 1, N - 1}); the requests
+// of several jobs for one ghost merge per axis (both ends -> 3, anything with all -> all).  The payload of an item is its box in z, y, x order; the host computes the items' offsets
+// from the codes alone, on both sides of the exchange.
+__host__ __device__ inline int shell_len(int code, int N) { return code == 0 ? N : (code == 1 ? 2 : (code == 2 ? 1 : 3)); }
+__host__ __device__ inline int shell_coord(int code, int i, int N) { return code == 2 ? N - 1 : ((code == 3 && i == 2) ? N - 1 : i); }
+__host__ __device__ inline long long shell_volume(int box, int N) {
+    return (long long)shell_len(box & 3, N) * shell_len((box >> 2) & 3, N) * shell_len((box >> 4) & 3, N);
+}
+// items: (x, y, z, box) per entry; offs: first payload voxel of every item
+__global__ __launch_bounds__(256) void export_shells_kernel(MapView M, const int *items, const long long *offs, int N, float *sdf, float *wgt, uchar4 *rgbw,
+                                                             int *found) {
+    __shared__ int s_slot;
+    const int j = blockIdx.x;
+    if (threadIdx.x == 0) {
+        s_slot = hash_find(M, items[4 * j], items[4 * j + 1], items[4 * j + 2]);
+        found[j] = s_slot >= 0 ? 1 : 0;
+    }
+    __syncthreads();
+    const int slot = s_slot, box = items[4 * j + 3];
+    const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
+    const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
+    const long long base = offs[j];
+    const size_t src = (size_t)(slot >= 0 ? slot : 0) * N * N * N;
+    for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
+        const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
+        const size_t i = src + (size_t)(z * N + y) * N + x;
+        sdf[base + v] = slot >= 0 ? M.sdf[i] : 99999.0f;
+        wgt[base + v] = slot >= 0 ? M.wgt[i] : 0.0f;
+        if (rgbw) rgbw[base + v] = (slot >= 0 && M.rgbw) ? M.rgbw[i] : make_uchar4(0, 0, 0, 0);
+    }
+}
+// Installing shells, phase 1: one workgroup per DISTINCT ghost id (first[k] = an item of that ghost; its `found` decides): create the
+// chunk unless it is there -- a fresh slot holds default voxels (pool invariant).  Distinct ids never collide on a slot: free_top is
+// atomic and the hash key is claimed with a CAS.
+__global__ void ensure_ghosts_kernel(MapView M, const int *items, const int *first, const int *found) {
+    if (threadIdx.x) return;
+    const int j = first[blockIdx.x];
+    if (!found[j]) return;
+    const int x = items[4 * j], y = items[4 * j + 1], z = items[4 * j + 2];
+    if (hash_find(M, x, y, z) >= 0) return;
+    const int top = atomicSub(M.free_top, 1) - 1;
+    if (top < 0) {
+        atomicAdd(M.free_top, 1);
+        raise_error(M.error_flag, 1);
+        return;
+    }
+    const int slot = M.free_list[top];
+    const uint64_t key = pack_id(x, y, z);
+    const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+    for (uint64_t i = 0; i <= M.hash_mask; i++) {
+        const uint64_t idx = (h + i) & M.hash_mask;
+        const uint64_t cur = M.hash_keys[idx];
+        if ((cur == KEY_EMPTY || cur == KEY_TOMB) &&
+            atomicCAS((unsigned long long *)&M.hash_keys[idx], (unsigned long long)cur, (unsigned long long)key) == cur) {
+            M.hash_vals[idx] = slot;
+            M.slot_key[slot] = key;
+            return;
+        }
+    }
+    raise_error(M.error_flag, 2);
+}
+// phase 2 (the next launch): one workgroup per item whose chunk exists now writes its box
+__global__ __launch_bounds__(256) void import_shells_kernel(MapView M, const int *items, const long long *offs, const int *found, int N, const float *sdf,
+                                                             const float *wgt, const uchar4 *rgbw) {
+    __shared__ int s_slot;
+    const int j = blockIdx.x;
+    if (!found[j]) return;
+    if (threadIdx.x == 0) s_slot = hash_find(M, items[4 * j], items[4 * j + 1], items[4 * j + 2]);
+    __syncthreads();
+    const int slot = s_slot, box = items[4 * j + 3];
+    if (slot < 0) return;
+    const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
+    const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
+    const long long base = offs[j];
+    const size_t dst = (size_t)slot * N * N * N;
+    for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
+        const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
+        const size_t i = dst + (size_t)(z * N + y) * N + x;
+        M.sdf[i] = sdf[base + v];
+        M.wgt[i] = wgt[base + v];
+        if (M.rgbw) M.rgbw[i] = rgbw ? rgbw[base + v] : make_uchar4(0, 0, 0, 0);
+    }
+}
+// the chunks updated since the last recompute (Chisel.h:175-189 marks their 27-neighbourhoods; the expansion is the planner's), as
+// (x, y, z, 0) entries behind a count, for the all-gather of a sharded recompute: out[0] = n, out[1 + 4 i ...] = entry i
+__global__ void list_dirty_ids_kernel(MapView M, int *out, int capacity) {
+    const unsigned listed = M.slot_dirty[2 * (size_t)M.max_chunks];
+    const bool scan = listed > (unsigned)M.max_chunks;
+    const long long n = scan ? (long long)M.max_chunks : (long long)listed;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int slot = scan ? (int)t : (int)M.slot_dirty[(size_t)M.max_chunks + t];
+        if (!M.slot_dirty[slot]) continue;
+        const uint64_t key = M.slot_key[slot];
+        if (key == KEY_EMPTY) continue;
+        const int pos = atomicAdd(&out[0], 1);
+        if (pos < capacity) {
+            int x, y, z;
+            unpack_id(key, x, y, z);
+            out[1 + 4 * pos] = x; out[2 + 4 * pos] = y; out[3 + 4 * pos] = z; out[4 + 4 * pos] = 0;
+        }
+    }
+}
 __global__ void clear_dirty_kernel(MapView M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M.max_chunks) M.slot_dirty[i] = 0;

@@ -176,19 +176,21 @@ class LocalShardGroup:
             s_.IntegratePointCloud(integrator, cloud, extrinsic, truncation, max_dist)
 
     def UpdateMeshes(self, force=False):
-        from .chisel import chunk_owner
+        from .chisel import mesh_shell_plan
         self.calls += 1
         if not force and (self.calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return
-        union = set()
-        for s_ in self.shards:
-            union.update(map(tuple, s_.GetMeshesToUpdate().tolist()))
-        owner = lambda i: chunk_owner(i, self.world, 2)
-        plans = [mesh_plan(union, r, self.world, owner) for r in range(self.world)]
-        for r, (jobs, requests) in enumerate(plans):
-            for o, ids in requests.items():
-                sdf, wgt, col, found = self.shards[o].ExportChunks(ids, device=self.device_payload)  # payload stays in HBM
-                self.shards[r].ImportGhostChunks(ids, sdf, wgt, col, found)
+        entries = np.concatenate([s_.DirtyEntries() for s_ in self.shards], axis=0)
+        plans = [mesh_shell_plan(entries, self.world, r) for r in range(self.world)]
+        self.ghost_bytes = 0
+        for r, (jobs, items) in enumerate(plans):
+            for o in sorted(set(items[:, 0].tolist())):
+                it = items[items[:, 0] == o][:, 1:5]
+                sdf, wgt, col, found = self.shards[o].ExportShells(it, device=self.device_payload)  # payload stays in HBM
+                if self.device_payload:
+                    self.shards[o].synchronize()
+                self.shards[r].ImportGhostShells(it, sdf, wgt, col, found)
+                self.ghost_bytes += int(sdf.nbytes if isinstance(sdf, np.ndarray) else sdf.numel() * 4) * (3 if col is not None else 2)
         for r, (jobs, _) in enumerate(plans):
             self.shards[r].UpdateMeshesOf(jobs)
             self.shards[r].DropGhostChunks()
@@ -257,70 +259,125 @@ class ShardedChisel:
             dist.all_to_all_single(out, inp, n_recv, n_send)
 
     def UpdateMeshes(self, force=False, ids=None):
-        """Chisel::UpdateMeshes of the sharded map: every rank ends up with the meshes of the chunks it owns (mesh_plan above).
-        The id lists travel as objects (small); the halo chunks as one all-to-all per voxel array on device tensors.
+        """Chisel::UpdateMeshes of the sharded map: every rank ends up with the meshes of the chunks it owns.
+
+        1. every rank lists the chunks it has updated since the last recompute as a device int array (chisel_hip_dirty_ids_device) and
+           ONE all_gather hands every rank all of them (a fixed-capacity int tensor: no pickled objects, no sizes to agree on first);
+        2. the plan is host arithmetic every rank evaluates for every rank (chisel_hip_mesh_shell_plan): its own jobs, the ghosts it
+           needs, and what the others will ask of it -- the request lists are never exchanged;
+        3. the owners pack the requested SHELLS (the one or two voxel layers a neighbour's mesh reads, not whole chunks:
+           chisel_hip_export_shells), one all_to_all per voxel array moves them, the receivers install them as ghost chunks
+           (chisel_hip_import_ghost_shells); map stream and collective stream are ordered by events (record_event / wait_event),
+           the host waits once, for the gathered id list of step 1;
+        4. every rank recomputes its jobs and drops the ghosts.
         ids: mesh these chunks (every rank passes ids of its own choice, the union is meshed) instead of meshesToUpdate.
         -> bytes of ghost voxels this rank received"""
-        from .chisel import chunk_owner
+        from .chisel import mesh_shell_plan, shell_volume
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return 0
-        dist, world, rank = self.x.dist, self.x.world, self.x.rank
-        mine = [tuple(int(v) for v in i) for i in (self.map.GetMeshesToUpdate() if ids is None else np.asarray(ids).reshape(-1, 3)).tolist()]
+        torch, dist, world, rank, dev = self.x.torch, self.x.dist, self.x.world, self.x.rank, self.x.device
         if world == 1:
             if ids is None:
                 self.map.UpdateMeshes(force=True)
             else:
-                self.map.UpdateMeshesOf(mine)
+                self.map.UpdateMeshesOf(np.asarray(ids, np.int32).reshape(-1, 3))
             return 0
-        lists = [None] * world
-        dist.all_gather_object(lists, mine)
-        union = set()
-        for l in lists:
-            union.update(l)
-        jobs, requests = mesh_plan(union, rank, world, lambda i: chunk_owner(i, world, 2))
-        asked = [None] * world                      # asked[o] = what rank o wants from each rank
-        dist.all_gather_object(asked, requests)
-        # the voxel payload travels as one all-to-all per array (RCCL on device tensors: the chunks never visit the host);
-        # rows for rank r = the chunks r asked of this rank, in r's order
-        torch = self.x.torch
-        dev = self.x.device
-        send_ids = [list(asked[r].get(rank, [])) if r != rank else [] for r in range(world)]
-        recv_ids = [list(requests.get(o, [])) for o in range(world)]
-        n_send, n_recv = [len(v) for v in send_ids], [len(v) for v in recv_ids]
-        flat_send = [i for v in send_ids for i in v]
-        flat_recv = [i for v in recv_ids for i in v]
         on_gpu = dev.type == "cuda"
+        edge = int(self.map.chunk_size[0])
+        # ---- 1. the ranks' dirty chunks
+        while True:
+            cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 14)
+            buf = torch.zeros((1 + 4 * cap,), dtype=torch.int32, device=dev)
+            if ids is None and on_gpu:
+                self._order_map_after_collectives()  # (the buffer was zeroed on torch's stream)
+                self.map.DirtyIdsDevice(buf)
+                self._order_after_map()
+            else:
+                e = np.asarray(self.map.DirtyEntries(), np.int32).reshape(-1, 4) if ids is None else \
+                    np.concatenate([np.asarray(ids, np.int32).reshape(-1, 3), np.ones((len(np.asarray(ids).reshape(-1, 3)), 1), np.int32)], axis=1)
+                head = np.zeros(1 + 4 * cap, np.int32)
+                head[0] = len(e)
+                head[1:1 + 4 * min(len(e), cap)] = e[:cap].reshape(-1)
+                buf.copy_(torch.from_numpy(head))
+            gathered = torch.empty((world * (1 + 4 * cap),), dtype=torch.int32, device=dev)
+            if dist.get_backend() == "gloo" and on_gpu:  # functional check only: gloo has no device collectives
+                host = torch.empty(gathered.shape, dtype=torch.int32)
+                dist.all_gather_into_tensor(host, buf.cpu())
+            else:
+                dist.all_gather_into_tensor(gathered, buf)
+                host = gathered.cpu()  # the one host wait of a recompute
+            g = host.numpy().reshape(world, 1 + 4 * cap)
+            if int(g[:, 0].max()) <= cap:
+                break
+            self._dirty_cap = 2 * int(g[:, 0].max())  # (every rank sees the same counts and takes the same turn)
+        entries = np.concatenate([g[r, 1:1 + 4 * int(g[r, 0])].reshape(-1, 4) for r in range(world)], axis=0)
+        # ---- 2. the plans
+        jobs, items = mesh_shell_plan(entries, world, rank)
+        recv_items = items[:, 1:5]
+        n_recv = [int(np.count_nonzero(items[:, 0] == o)) for o in range(world)]
+        send_parts = []
+        for q in range(world):
+            if q == rank:
+                send_parts.append(np.zeros((0, 4), np.int32))
+            else:
+                it_q = mesh_shell_plan(entries, world, q)[1]
+                send_parts.append(it_q[it_q[:, 0] == rank][:, 1:5])
+        send_items = np.concatenate(send_parts, axis=0)
+        n_send = [len(p) for p in send_parts]
+        vol = lambda it: int(sum(shell_volume(int(b), edge) for b in it[:, 3])) if len(it) else 0
+        v_send = [vol(p) for p in send_parts]
+        v_recv = [vol(recv_items[sum(n_recv[:o]):sum(n_recv[:o + 1])]) for o in range(world)]
+        # ---- 3. shells: export -> all_to_all -> import
         if on_gpu:
-            sdf_s, wgt_s, col_s, found_s = self.map.ExportChunks(flat_send, device=True)
+            self._order_map_after_collectives()
+            sdf_s, wgt_s, col_s, found_s = self.map.ExportShells(send_items, device=True)
+            self._order_after_map()
         else:
-            a, b, c, found_s = self.map.ExportChunks(flat_send)
+            a, b, c, f = self.map.ExportShells(send_items)
             sdf_s, wgt_s = torch.from_numpy(np.ascontiguousarray(a, np.float32)), torch.from_numpy(np.ascontiguousarray(b, np.float32))
             col_s = torch.from_numpy(np.ascontiguousarray(c, np.uint8)) if c is not None else None
-        found_s = torch.from_numpy(np.ascontiguousarray(found_s, np.int32)).to(dev)
-        rows = sdf_s.shape[1] if sdf_s.dim() == 2 else 0
-        total = sum(n_recv)
-        sdf_r = torch.empty((total,) + tuple(sdf_s.shape[1:]), dtype=torch.float32, device=dev)
-        wgt_r = torch.empty((total,) + tuple(wgt_s.shape[1:]), dtype=torch.float32, device=dev)
-        found_r = torch.empty((total,), dtype=torch.int32, device=dev)
-        self._all_to_all(sdf_r, sdf_s, n_recv, n_send)
-        self._all_to_all(wgt_r, wgt_s, n_recv, n_send)
+            found_s = torch.from_numpy(np.ascontiguousarray(f, np.int32))
+        total = sum(v_recv)
+        sdf_r = torch.empty((total,), dtype=torch.float32, device=dev)
+        wgt_r = torch.empty((total,), dtype=torch.float32, device=dev)
+        found_r = torch.empty((sum(n_recv),), dtype=torch.int32, device=dev)
+        self._all_to_all(sdf_r, sdf_s, v_recv, v_send)
+        self._all_to_all(wgt_r, wgt_s, v_recv, v_send)
         self._all_to_all(found_r, found_s, n_recv, n_send)
         col_r = None
         if col_s is not None:
-            col_r = torch.empty((total,) + tuple(col_s.shape[1:]), dtype=torch.uint8, device=dev)
-            self._all_to_all(col_r, col_s, n_recv, n_send)
-        if on_gpu:
-            torch.cuda.current_stream(dev).synchronize()  # the map imports on its own stream
-        if total:
-            found_h = found_r.cpu().numpy()
+            col_r = torch.empty((total, 4), dtype=torch.uint8, device=dev)
+            self._all_to_all(col_r, col_s, v_recv, v_send)
+        if len(recv_items):
             if on_gpu:
-                self.map.ImportGhostChunks(flat_recv, sdf_r, wgt_r, col_r, found_h)
+                self._order_map_after_collectives()
+                self.map.ImportGhostShells(recv_items, sdf_r, wgt_r, col_r, found_r)
             else:
-                self.map.ImportGhostChunks(flat_recv, sdf_r.numpy(), wgt_r.numpy(), None if col_r is None else col_r.numpy(), found_h)
+                self.map.ImportGhostShells(recv_items, sdf_r.numpy(), wgt_r.numpy(), None if col_r is None else col_r.numpy(), found_r.numpy())
+        # ---- 4.
         self.map.UpdateMeshesOf(jobs)
         self.map.DropGhostChunks()
-        return int(sdf_r.numel() * 4 + wgt_r.numel() * 4 + (col_r.numel() if col_r is not None else 0))
+        per_voxel = 12 if col_r is not None else 8
+        # for the record: what whole ghost chunks (the round-2 protocol) would have moved for the same ghosts
+        self.whole_chunk_bytes = getattr(self, "whole_chunk_bytes", 0) + len({tuple(i[:3]) for i in recv_items.tolist()}) * edge ** 3 * per_voxel
+        self.shell_bytes = getattr(self, "shell_bytes", 0) + int(total * per_voxel)
+        return int(total * per_voxel)
+
+    def _order_after_map(self):
+        """the collective queued next on torch's current stream starts after what the map has queued so far (an event, no host wait)"""
+        torch = self.x.torch
+        ev = self._ev = getattr(self, "_ev", None) or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())  # (a first record creates the hipEvent_t behind the torch object)
+        self.map.record_event(ev.cuda_event)
+        torch.cuda.current_stream().wait_event(ev)
+
+    def _order_map_after_collectives(self):
+        """the map's next call starts after the collectives queued on torch's current stream"""
+        torch = self.x.torch
+        ev = self._ev2 = getattr(self, "_ev2", None) or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.map.wait_event(ev.cuda_event)
 
     def NumChunks(self):
         torch, dist = self.x.torch, self.x.dist

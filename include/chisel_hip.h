@@ -310,6 +310,30 @@ int chisel_hip_create_group(const chisel_hip_config *cfg, const int *device_ids,
 int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, int height, float near_plane, float far_plane,
                        float *corners, float *lines, float *planes);
 
+/* ---- meshing a sharded map with shells -----------------------------------------------------------------
+ * What a chunk's mesh reads of a neighbour chunk is a shell one or two voxels thick (cube corners, gradients around the vertices, the
+ * nearest voxel's colour: SURVEY.md 8e's "faces"), not the whole chunk.  A "box code" names the part of a ghost chunk that travels:
+ * two bits per axis (x: bits 0-1, y: 2-3, z: 4-5), 0 = every coordinate, 1 = {0, 1}, 2 = {N - 1}, 3 = {0, 1, N - 1}; chisel_hip_shell_volume gives its
+ * number of voxels; the payload of a list of items (x, y, z, box) is the concatenation of their boxes in z, y, x order.
+ *   chisel_hip_dirty_ids_device  the chunks updated since the last recompute as a DEVICE int array: out[0] = n, then n entries
+ *                                (x, y, z, flag) -- flag 0: the chunk was updated (its 27-neighbourhood is meshesToUpdate, Chisel.h:175-189),
+ *                                flag 1: an entry of meshesToUpdate kept on the host; nothing is waited for (record_event orders the
+ *                                collective that gathers the ranks' arrays)
+ *   chisel_hip_mesh_shell_plan   host arithmetic, identical on every rank: from the gathered entries the ids `rank` meshes (jobs) and
+ *                                the ghosts it needs as items (owner, x, y, z, box), one per ghost, ascending by owner then id --
+ *                                every rank can evaluate it for every other rank, so the request lists need no exchange
+ *   chisel_hip_export_shells     the boxes of the listed chunks of this shard, packed (device pointers with on_device: no wait);
+ *                                found[j] = 0 and default voxels for a chunk that is not resident
+ *   chisel_hip_import_ghost_shells  installs them as ghost chunks (only the box is written; honours chisel_hip_wait_event);
+ *                                chisel_hip_drop_ghost_chunks removes them again */
+int chisel_hip_dirty_ids_device(chisel_hip_map *map, int *out_dev, int capacity);
+int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shards, int rank, int shard_block, int *jobs, int64_t max_jobs,
+                               int64_t *n_jobs, int *items, int64_t max_items, int64_t *n_items);
+int64_t chisel_hip_shell_volume(int box, int chunk_edge);
+int chisel_hip_export_shells(chisel_hip_map *map, const int *items, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device);
+int chisel_hip_import_ghost_shells(chisel_hip_map *map, const int *items, int n, const float *sdf, const float *weight, const uint8_t *rgbw,
+                                   const int *found, int on_device);
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 /* accumulated since creation / last reset_counters; out has CHISEL_HIP_NUM_COUNTERS entries */
 int chisel_hip_get_counters(chisel_hip_map *map, uint64_t *out, int reset_counters);

@@ -32,6 +32,7 @@ def test_two_ranks_launched_by_bench_itself_equal_one_rank():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["mesh_every"] == 10 and one["config"]["mesh_every"] == 10  # meshes inside the timed region at every N
     assert two["sharded_meshing"]["recomputes"] > 0
+    assert 0 < two["sharded_meshing"]["shells_over_whole_chunks"] < 0.25  # shells, not whole ghost chunks (two shards are the worst case)
     for k in ("voxel_updates", "n_sdf", "n_col", "n_probe", "n_carved", "resident_chunks_end"):
         assert one["per_frame"][k] == two["per_frame"][k], (k, one["per_frame"][k], two["per_frame"][k])
     assert two["value"] > 0 and two["steps"] == 20 and two["warmup"] == 5

@@ -154,33 +154,53 @@ def test_mesh_plan_covers_every_foreign_neighbour(hip_lib):
 
 
 class MeshRecordingMap(RecordingMap):
-    """adds the mesh-side calls: resident chunks = owned ids of a fixed box; a chunk's "voxels" encode its id and owner"""
+    """adds the mesh-side calls: resident chunks = owned ids of a fixed box; a voxel of a chunk's shell encodes the chunk's id, its
+    owner and the voxel's coordinates, so that a ghost's box can be checked voxel by voxel"""
+    EDGE = 8
 
     def __init__(self, rank, world):
         super().__init__(rank, world)
+        self.chunk_size = (self.EDGE,) * 3
         self.ghosts, self.meshed, self.dropped = {}, None, 0
 
     def _resident(self):
         return set(map(tuple, self.GetChunkIDs().tolist()))
 
-    def GetMeshesToUpdate(self):
+    def DirtyEntries(self):
         dirty = [i for i in sorted(self._resident()) if (i[0] + i[1] + i[2]) % 3 == 0]
-        out = {(x + dx, y + dy, z + dz) for x, y, z in dirty for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)}
-        return np.array(sorted(out), np.int32).reshape(-1, 3)
+        return np.array([list(i) + [0] for i in dirty], np.int32).reshape(-1, 4)
 
-    def ExportChunks(self, ids):
+    @staticmethod
+    def _box(code, n):
+        rng = lambda c: range(n) if c == 0 else (range(0, 2) if c == 1 else (range(n - 1, n) if c == 2 else (0, 1, n - 1)))
+        return [(x, y, z) for z in rng((code >> 4) & 3) for y in rng((code >> 2) & 3) for x in rng(code & 3)]
+
+    @classmethod
+    def voxel_value(cls, cid, owner, v):
+        return float(((cid[0] * 31 + cid[1]) * 31 + cid[2]) * 1000 + owner * 512 + (v[2] * cls.EDGE + v[1]) * cls.EDGE + v[0])
+
+    def ExportShells(self, items):
         res = self._resident()
-        found = np.array([1 if tuple(i) in res else 0 for i in ids], np.int32)
-        sdf = np.array([[i[0], i[1], i[2], self.rank] for i in ids], np.float32)
-        return sdf, sdf + 0.5, None, found
+        sdf, found = [], []
+        for x, y, z, code in np.asarray(items).reshape(-1, 4).tolist():
+            found.append(1 if (x, y, z) in res else 0)
+            sdf.extend(self.voxel_value((x, y, z), self.rank, v) for v in self._box(code, self.EDGE))
+        sdf = np.array(sdf, np.float32)
+        return sdf, sdf + 0.5, None, np.array(found, np.int32)
 
-    def ImportGhostChunks(self, ids, sdf, wgt, col=None, found=None):
-        for j, i in enumerate(ids):
-            if found is None or found[j]:
-                self.ghosts[tuple(i)] = (np.asarray(sdf[j]).copy(), np.asarray(wgt[j]).copy())
+    def ImportGhostShells(self, items, sdf, wgt, col, found):
+        off = 0
+        for j, (x, y, z, code) in enumerate(np.asarray(items).reshape(-1, 4).tolist()):
+            box = self._box(code, self.EDGE)
+            if found[j]:
+                cells = self.ghosts.setdefault((x, y, z), {})
+                for k, v in enumerate(box):
+                    cells[v] = (float(sdf[off + k]), float(wgt[off + k]))
+            off += len(box)
+        assert off == len(sdf)
 
     def UpdateMeshesOf(self, ids):
-        self.meshed = ([tuple(i) for i in ids], dict(self.ghosts))
+        self.meshed = ([tuple(int(v) for v in i) for i in np.asarray(ids).reshape(-1, 3)], dict(self.ghosts))
 
     def DropGhostChunks(self):
         self.dropped += 1
@@ -190,7 +210,6 @@ class MeshRecordingMap(RecordingMap):
 def _mesh_worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
-    from cvids_amd.chisel import chunk_owner
     from cvids_amd.sharded import FrameExchange, ShardedChisel
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -199,16 +218,20 @@ def _mesh_worker(rank, world, port, out):
         x = FrameExchange(W, H, K, torch.device("cpu"), dist, channels=0)
         local = MeshRecordingMap(rank, world)
         sm = ShardedChisel(local, x, integrator=None)
-        sm.UpdateMeshes(force=True)
+        nbytes = sm.UpdateMeshes(force=True)
         jobs, ghosts = local.meshed
-        out.put((rank, jobs, {k: (v[0].tolist(), v[1].tolist()) for k, v in ghosts.items()}, local.dropped, len(local.ghosts)))
+        out.put((rank, jobs, ghosts, local.dropped, len(local.ghosts), nbytes))
     finally:
         dist.destroy_process_group()
 
 
 def test_sharded_update_meshes_protocol_world2(hip_lib):
+    """The shell protocol between two processes (gloo): every rank meshes the owned part of the union of the 27-neighbourhoods, every
+    neighbour another rank holds arrives as a ghost with exactly the voxel box its position asks for -- coordinates {0, 1} where the
+    ghost lies on the + side of a job, {N - 1} on the - side, all along an axis they share -- carrying the owner's values, and far
+    fewer bytes travel than whole chunks would take."""
     import torch.multiprocessing as mp
-    from cvids_amd.chisel import chunk_owner
+    from cvids_amd.chisel import chunk_owner, mesh_shell_plan
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -216,30 +239,79 @@ def test_sharded_update_meshes_protocol_world2(hip_lib):
     procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
+    res = sorted((q.get(timeout=170) for _ in range(world)), key=lambda r: r[0])  # before the joins: a child blocks in put() until its data is read
     for p in procs:
-        p.join(180)
+        p.join(60)
         assert p.exitcode == 0
-    res = sorted(q.get(timeout=10) for _ in range(world))
+    E = MeshRecordingMap.EDGE
     box = [(x, y, z) for x in range(-3, 3) for y in range(-2, 2) for z in range(0, 4)]
     resident = {r: {i for i in box if chunk_owner(i, world, 2) == r} for r in range(world)}
     union = set()
     for r in range(world):
-        union.update(map(tuple, MeshRecordingMap(r, world).GetMeshesToUpdate().tolist()))
+        for x, y, z, _ in MeshRecordingMap(r, world).DirtyEntries().tolist():
+            union.update((x + dx, y + dy, z + dz) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1))
     all_jobs = set()
-    for rank, jobs, ghosts, dropped, left in res:
+    for rank, jobs, ghosts, dropped, left, nbytes in res:
         assert dropped == 1 and left == 0
         assert set(jobs) == {i for i in union if chunk_owner(i, world, 2) == rank}
         all_jobs.update(jobs)
+        need = {}  # ghost -> set of voxel coordinates some job of this rank reads
         for x, y, z in jobs:
             for dx in (-1, 0, 1):
                 for dy in (-1, 0, 1):
                     for dz in (-1, 0, 1):
                         n = (x + dx, y + dy, z + dz)
                         o = chunk_owner(n, world, 2)
-                        if o != rank and n in resident[o]:  # a neighbour another shard holds: imported, with that shard's data
-                            assert n in ghosts and ghosts[n][0] == [float(n[0]), float(n[1]), float(n[2]), float(o)]
+                        if o == rank or n not in resident[o]:
+                            continue
+                        rng = lambda d: range(E) if d == 0 else (range(0, 2) if d > 0 else range(E - 1, E))
+                        need.setdefault(n, set()).update((vx, vy, vz) for vx in rng(dx) for vy in rng(dy) for vz in rng(dz))
+        assert set(ghosts) == set(need)  # every neighbour another shard holds has arrived, nothing else
+        total_vox = 0
+        for g, cells in ghosts.items():
+            o = chunk_owner(g, world, 2)
+            assert need[g] <= set(cells)  # the boxes cover what the jobs read
+            assert len(cells) <= 1.5 * len(need[g])  # and little more
+            for v, (sd, wg) in cells.items():  # with the owner's values
+                assert sd == np.float32(MeshRecordingMap.voxel_value(g, o, v)) and wg == np.float32(np.float32(MeshRecordingMap.voxel_value(g, o, v)) + np.float32(0.5))
+            total_vox += len(cells)
+        assert nbytes >= 8 * total_vox  # (boxes of chunks that turned out not to be resident travel too)
+        n_items = len(mesh_shell_plan(np.concatenate([MeshRecordingMap(r, world).DirtyEntries() for r in range(world)]), world, rank)[1])
+        assert nbytes < 0.5 * 8 * E ** 3 * n_items  # less than half of what whole ghost chunks would take, even with two shards and 8^3 chunks
         assert all(chunk_owner(g, world, 2) != rank for g in ghosts)
     assert all_jobs == union
+
+
+def test_mesh_shell_plan_is_consistent_across_ranks(hip_lib):
+    """chisel_hip_mesh_shell_plan: jobs partition the union, one item per ghost, sorted by owner then id, and what rank q plans to ask of
+    rank r is what r works out for q (the request lists are never exchanged)."""
+    from cvids_amd.chisel import chunk_owner, mesh_shell_plan, shell_volume
+    rng = np.random.default_rng(11)
+    for world in (2, 4, 8):
+        dirty = np.unique(rng.integers(-6, 6, (60, 3)), axis=0)
+        entries = np.concatenate([dirty, np.zeros((len(dirty), 1), np.int64)], axis=1).astype(np.int32)
+        entries = np.concatenate([entries, np.array([[20, 20, 20, 1]], np.int32)])  # an id taken as it is
+        union = {(x + dx, y + dy, z + dz) for x, y, z in dirty.tolist() for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)} | {(20, 20, 20)}
+        seen = set()
+        for rank in range(world):
+            jobs, items = mesh_shell_plan(entries, world, rank)
+            jl = [tuple(j) for j in jobs.tolist()]
+            assert jl == sorted(jl) and all(chunk_owner(j, world, 2) == rank for j in jl)
+            seen.update(jl)
+            keys = [tuple(i) for i in items.tolist()]
+            assert keys == sorted(keys) and len(set(keys)) == len(keys)
+            for o, x, y, z, box in items.tolist():
+                assert o != rank and chunk_owner((x, y, z), world, 2) == o
+                assert 0 <= box < 64 and 1 <= shell_volume(box, 16) <= 4096
+            asked = {tuple(i[1:4]) for i in items.tolist()}
+            for x, y, z in jl:
+                for dx in (-1, 0, 1):
+                    for dy in (-1, 0, 1):
+                        for dz in (-1, 0, 1):
+                            n = (x + dx, y + dy, z + dz)
+                            assert chunk_owner(n, world, 2) == rank or n in asked
+        assert seen == union
+    assert [shell_volume(b, 16) for b in (0, 1, 2, 3, 1 | (1 << 2), 2 | (2 << 2) | (2 << 4), 1 | (2 << 2) | (0 << 4))] == [4096, 512, 256, 768, 64, 1, 32]
 
 
 class CloudRecordingMap:
