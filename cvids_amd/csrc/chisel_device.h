@@ -206,8 +206,6 @@ constexpr int WI_FASTWU = 16;  // ConstantWeighter(1) and 5 x truncation distanc
                                // weight / (5 * truncation) (ConstantWeighter.h:43-46) is reciprocal_in_range(5 * truncation), exactly
 constexpr int WI_INSIDE = 32;  // WI_FASTZ, and every voxel of the chunk projects onto the image in this frame (two pixels of margin on every
                                // side, rounding of the per-voxel projection bounded: cull_chunk_frame): IsPointOnImage holds for all of them
-constexpr int WI_FASTDIV = 64; // WI_FASTWU with 5 x truncation in [2^-10, 2^10]: the in-band update's division may take the unscaled
-                               // sequence (dist_integrate_fast) where the voxel state is sane and the numerator is not tiny
 
 // Chunk-level state of one work item while its waves run (device-scope atomics only; zeroed by whoever writes the item).
 struct ItemSync {

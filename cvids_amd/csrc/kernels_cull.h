@@ -371,9 +371,8 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
     // (the three roundings of u itself add a few ulp of a value below 2^15).
     const float span = fmaxf(fabsf(C.fx), fabsf(C.fy)) + (float)(C.W + C.H) + fabsf(C.cx) + fabsf(C.cy);
     const bool inside = box_inside && fastz && (zmin >= 1e-5f * span * mag);
-    const bool fastdiv = fastwu && (5.0f * tmin >= 0.0009765625f) && (5.0f * tmax <= 1024.0f) && (ip.diag <= 1024.0f);
     return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0) | (fastwu ? WI_FASTWU : 0) |
-           (inside ? WI_INSIDE : 0) | (fastdiv ? WI_FASTDIV : 0);
+           (inside ? WI_INSIDE : 0);
 }
 
 __device__ inline bool pending_contains(const uint64_t *__restrict__ set, uint64_t key, uint64_t h) {

@@ -32,6 +32,8 @@
 // Build parameters for experiments: INTEGRATE_WAVES / INTEGRATE_BLOCKS_PER_CU (occupancy),
 // CHISEL_PHASES (in-kernel timers and utilisation counters), CHISEL_ABLATE_GATHER.
 #pragma once
+#include <type_traits>
+
 #include "chisel_device.h"
 #include "kernels_cull.h"  // COUNT_* (the batch counters the work-list builders leave behind)
 
@@ -192,7 +194,7 @@ __device__ __attribute__((noinline)) int claim_slot(const MapView *__restrict__ 
     return s >= 2 ? s - 2 : -1;
 }
 
-template <int N, bool COLOR, bool SAMECAM, int VPL>
+template <int N, bool COLOR, bool SAMECAM, int VPL0>
 #ifndef INTEGRATE_WAVES2
 #define INTEGRATE_WAVES2 8  // the instantiations with 2 voxels per lane need 56 vector registers: eight waves per SIMD once the compiler also keeps
                             // to the 80 scalar registers that go with them (it derives that cap from this bound; 14 cold values go to lanes of a vector register)
@@ -202,14 +204,13 @@ template <int N, bool COLOR, bool SAMECAM, int VPL>
 #else
 #define INTEGRATE_SGPR_ATTR
 #endif
-__global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : INTEGRATE_WAVES)) INTEGRATE_SGPR_ATTR void integrate_kernel(IntegrateParams P, MapView M, const MapView *__restrict__ Mc,
+__global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 : INTEGRATE_WAVES)) INTEGRATE_SGPR_ATTR void integrate_kernel(IntegrateParams P, MapView M, const MapView *__restrict__ Mc,
                                                                           const WorkItem *__restrict__ items,
                                                                           const FrameBox *__restrict__ boxes, ItemSync *sync,
                                                                           const int *__restrict__ work_count, int *queues,
-                                                                          int max_items) {
-    using G = Geom<N, VPL>;
-    using QuadF = QuadFT<VPL>;
-    using QuadU = QuadUT<VPL>;
+                                                                          int max_items, int split) {
+    using G = Geom<N, VPL0>;   // the launch's own granularity: what the grid and the queue heads are laid out for
+    using GF = Geom<N, 2>;     // the fine one (2 voxels per lane) of the items behind `split`
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Blocks b and b + 8 share an XCD (observed dispatch order; speed only).  The first round is dealt statically: XCD x takes
@@ -232,7 +233,22 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : 
         report[3] = pairs;
     }
     const int grid_waves = nb * G::WPB;
-    const int rem_chunks = n_items - grid_waves / G::WPC;  // chunks behind the statically dealt ones
+    // Two granularities in one launch (VPL0 == 4): the items behind `split` -- the tail of the cost-ordered list -- run with 2 voxels per
+    // lane: twice as many units of half the length, so that the stretch in which the chip drains (one unit long) is half as long.  Only
+    // when the grid covers every unit statically (sized by the host from a recent launch's item count); a launch that turns out
+    // larger than that takes the one granularity and the queue heads, as before.
+    int n_coarse_x = 0, units_x = 0;  // this XCD's chunks x, x + 8, ...: how many of them are coarse; its units in all
+    bool mixed = false;
+    if (VPL0 == 4 && split >= 0 && split < n_items) {
+        const int u0 = ((split + 7) / 8) * G::WPC + ((n_items + 7) / 8 - (split + 7) / 8) * GF::WPC;  // XCD 0 holds the most
+        mixed = u0 <= (nb / 8) * G::WPB;
+        if (mixed) {
+            n_coarse_x = split > xcd ? (split - xcd + 7) / 8 : 0;
+            const int n_x = n_items > xcd ? (n_items - xcd + 7) / 8 : 0;
+            units_x = n_coarse_x * G::WPC + (n_x - n_coarse_x) * GF::WPC;
+        }
+    }
+    const int rem_chunks = mixed ? 0 : n_items - grid_waves / G::WPC;  // chunks behind the statically dealt ones
     const IntegratorParams &ip = P.ip;
     unsigned t_sdf = 0, t_col = 0, t_colsat = 0, t_probe = 0, t_carved = 0;  // per lane; summed over the wave when it retires
     unsigned n_new = 0, n_updated = 0;                                       // wave-uniform
@@ -251,10 +267,12 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : 
 #define FSTAMP(i, dep) do { } while (0)
 #endif
 
-    int wid = ((local_unit / G::WPC) * 8 + xcd) * G::WPC + local_unit % G::WPC;
-    while (wid < total) {
-        do {  // one unit; `break` = done with it
-            const int it = wid / G::WPC, wq = wid % G::WPC;
+    // one unit = (work item, 64-quad group) at VPL voxels per lane; `return` = done with it
+    auto run_unit = [&](auto vpl_tag, const int it, const int wq, const int wid) {
+            constexpr int VPL = decltype(vpl_tag)::value;
+            using G = Geom<N, VPL>;
+            using QuadF = QuadFT<VPL>;
+            using QuadU = QuadUT<VPL>;
             const WorkItem wi = items[it];
             const int cxi = __builtin_amdgcn_readfirstlane(wi.x), cyi = __builtin_amdgcn_readfirstlane(wi.y),
                       czi = __builtin_amdgcn_readfirstlane(wi.z);
@@ -274,11 +292,11 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : 
                 if (slot < 0) {
                     // not resident: frames before the first one that may integrate could only carve, i.e. do nothing
                     const unsigned inband = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.inband_mask);
-                    if (inband == 0u) break;
+                    if (inband == 0u) return;
                     mask &= ~((1u << __builtin_ctz(inband)) - 1u);
                 }
             }
-            if (mask == 0u) break;
+            if (mask == 0u) return;
             const bool existed = slot >= 0;  // memory of `slot` holds this chunk's voxels
             ItemSync *sy = sync + it;
 
@@ -552,9 +570,6 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : 
                             const bool in_band = ((bandm >> j) & 1u) != 0u;
                             f4(s4, j) = in_band ? ns : f4(s4, j);
                             f4(w4, j) = in_band ? nw : f4(w4, j);
-#ifdef OPT_SERIAL_DIV
-                            __builtin_amdgcn_sched_barrier(0);  // one voxel's division at a time: its temporaries are not kept four times over
-#endif
                         }
                         st |= bandm ? DCHG : 0u;
                         if (COLOR && __any(freshm != 0u)) {
@@ -640,7 +655,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : 
                     if (lane == 0) t_probe += v;  // (the counters are per lane)
                 }
                 PHASE(2);
-                if (slot < 0) break;  // never integrated here, or no slot left (error raised)
+                if (slot < 0) return;  // never integrated here, or no slot left (error raised)
             }
             {
                 const size_t out_base = (size_t)slot * G::V;  // wave-uniform
@@ -661,7 +676,18 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL == 2 ? INTEGRATE_WAVES2 : 
                 old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
                 n_updated += (unsigned)__popc(cm & ~old);
             }
-        } while (false);
+    };
+    if (mixed) {  // one unit per wave, all of them dealt statically
+        if (local_unit < units_x) {
+            const int u4 = n_coarse_x * G::WPC;
+            if (local_unit < u4) run_unit(std::integral_constant<int, VPL0>{}, (local_unit / G::WPC) * 8 + xcd, local_unit % G::WPC, local_unit);
+            else run_unit(std::integral_constant<int, 2>{}, (n_coarse_x + (local_unit - u4) / GF::WPC) * 8 + xcd, (local_unit - u4) % GF::WPC, local_unit);
+        }
+        PHASE(3);
+    }
+    int wid = mixed ? total : ((local_unit / G::WPC) * 8 + xcd) * G::WPC + local_unit % G::WPC;
+    while (wid < total) {
+        run_unit(std::integral_constant<int, VPL0>{}, wid / G::WPC, wid % G::WPC, wid);
         PHASE(3);
 #ifdef CHISEL_PHASES
         if (ph_last_start && ((ph_t - ph_last_start) << 32) > ph_max_unit) ph_max_unit = ((ph_t - ph_last_start) << 32) | ((unsigned long long)(ph_wid & 0xffffff) << 8) | (ph_exec - ph_exec0);
