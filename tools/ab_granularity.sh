@@ -1,5 +1,5 @@
 #!/bin/bash
-# drv window with forced granularity: bash tools/r3_vpl.sh <variant> ...
+# drv window with forced granularity: bash tools/ab_granularity.sh <variant> ...
 cd $GRAFT_REPO_ROOT
 show() { python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-16s fps %8.0f | integrate %7.2f us/launch [%.1f-%.1f] frac %.3f' % (sys.argv[1], d['value'], r['avg_kernel_us'], r['avg_kernel_us_min_max'][0], r['avg_kernel_us_min_max'][1], r['frac']))" "$1"; }
 for v in "$@"; do
