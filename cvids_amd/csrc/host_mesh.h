@@ -168,7 +168,6 @@ void launch_mesh_count(chisel_hip_map *m) {
 int recompute_meshes(chisel_hip_map *m) {
     RoctxRange range("chisel_hip mesh recompute: count, triangles");
     MeshBuffers &B = m->mesh_buf;
-    int *d_totals = mesh_totals(m);
     const MeshParams P = mesh_params(m);
     if (!B.tris) {
         B.tri_capacity = std::max(B.tri_capacity, m->mesh_tiny ? 256 : 1 << 20);
