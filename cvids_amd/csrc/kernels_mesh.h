@@ -281,7 +281,10 @@ __global__ void mesh_append_kernel(MapView M, unsigned *mesh_flag, const int *sl
     if (i < n && slots[i] >= 0) mesh_append_job(M, mesh_flag, slots[i], ids, n_jobs);
 }
 
-constexpr int MESH_BLOCK_THREADS = 512;  // per-chunk kernel: 8 cubes (16^3) per thread (256: 33 us, 512: 24 us, 1024: 35 us per recompute)
+#ifndef MESH_THREADS
+#define MESH_THREADS 512
+#endif
+constexpr int MESH_BLOCK_THREADS = MESH_THREADS;  // per-chunk kernel: 8 cubes (16^3) per thread (256: 33 us, 512: 24 us, 1024: 35 us per recompute)
 
 // corner voxel (cx, cy, cz), each in 0..N, of the cube grid of a job: (sdf, weight); absent chunk -> weight 0
 template <int N>
