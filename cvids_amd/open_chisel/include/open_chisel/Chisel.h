@@ -422,14 +422,15 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         return ChunkPtr();
     }
     // ChunkManager.cpp:575-607: the voxel that contains `pos` (nullptr when its chunk is not resident or the linear id is out of range);
-    // the pointer stays valid until the next call (it points into a mirror kept here)
+    // the pointer stays valid until the next call of the same member (it points into a mirror kept here, one per member: asking
+    // for the colour voxel of a position does not take the distance voxel away)
     const DistVoxel *GetDistanceVoxel(const Vec3 &pos) {
-        const size_t i = VoxelAt(pos);
-        return i == (size_t)-1 ? nullptr : &voxelChunk->GetDistVoxel(i);
+        const size_t i = VoxelAt(pos, distVoxelChunk);
+        return i == (size_t)-1 ? nullptr : &distVoxelChunk->GetDistVoxel(i);
     }
     const ColorVoxel *GetColorVoxel(const Vec3 &pos) {
-        const size_t i = VoxelAt(pos);
-        return (i == (size_t)-1 || !voxelChunk->HasColors()) ? nullptr : &voxelChunk->GetColorVoxel(i);
+        const size_t i = VoxelAt(pos, colorVoxelChunk);
+        return (i == (size_t)-1 || !colorVoxelChunk->HasColors()) ? nullptr : &colorVoxelChunk->GetColorVoxel(i);
     }
     // ChunkManager.cpp:72-89
     void GetChunkIDsIntersecting(const AABB &box, ChunkIDList *chunkList) {
@@ -600,7 +601,7 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
     }
     chisel_hip_map *HipMap() const { return map; }
   protected:
-    size_t VoxelAt(const Vec3 &pos) {  // GetChunkAt + GetVoxelCoords + GetVoxelID (ChunkManager.cpp:575-607); -1: none
+    size_t VoxelAt(const Vec3 &pos, ChunkPtr &voxelChunk) {  // GetChunkAt + GetVoxelCoords + GetVoxelID (ChunkManager.cpp:575-607); -1: none
         const ChunkID id = GetIDAt(pos);
         if (!HasChunk(id)) return (size_t)-1;
         voxelChunk = std::make_shared<Chunk>(map, id, chunkSize, voxelResolutionMeters, useColor);
@@ -625,7 +626,7 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         for (int64_t i = 0; i < ng; i++) mesh->grids.push_back(Vec3(gr[3 * i], gr[3 * i + 1], gr[3 * i + 2]));
     }
     std::shared_ptr<chisel_hip_map> owned;  // set when this manager created the map itself (the three-argument constructor)
-    ChunkPtr voxelChunk;                    // the mirror GetDistanceVoxel / GetColorVoxel last pointed into
+    ChunkPtr distVoxelChunk, colorVoxelChunk;  // the mirrors GetDistanceVoxel / GetColorVoxel last pointed into
     mutable bool chunksValid = false;
     mutable int64_t chunksCount = 0;
     mutable uint64_t chunksEpoch = 0;
