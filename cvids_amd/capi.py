@@ -67,7 +67,7 @@ EXPORTS = [
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
-    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan",
+    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_cloud_candidates", "chisel_hip_mesh_cube", "chisel_hip_write_mesh_ply", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan",
     "chisel_hip_shell_volume", "chisel_hip_export_shells", "chisel_hip_import_ghost_shells", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
 ]
 # the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
@@ -159,6 +159,9 @@ def load_library():
     if hasattr(L, "chisel_hip_candidates"):
         L.chisel_hip_topology_epoch.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.chisel_hip_candidates.argtypes = [f32p, f32p, i32p, C.c_float, i32p, C.c_int64, i64p]
+        L.chisel_hip_cloud_candidates.argtypes = [vp, C.POINTER(PointCloud), i32p, C.c_int64, i64p]
+        L.chisel_hip_mesh_cube.argtypes = [vp, i32p, i32p, f32p, f32p, f32p, i32p, i32p]
+        L.chisel_hip_write_mesh_ply.argtypes = [C.c_char_p, f32p, f32p, C.c_int64, i64p, C.c_int64]
         L.chisel_hip_shade_vertices.argtypes = [vp, f32p, C.c_int64, f32p, f32p, C.c_int]
         L.chisel_hip_integrate_chunk.argtypes = [vp, i32p, C.POINTER(DepthFrame), C.POINTER(ColorFrame), i32p]
         L.chisel_hip_recompute_mesh.argtypes = [vp, i32p]

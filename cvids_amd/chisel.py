@@ -225,6 +225,19 @@ class Chisel:
         check(self.L.chisel_hip_integrate_pointcloud(self.h, C.byref(pc)))
         self._keep = [k1, k2]
 
+    def CloudCandidates(self, cloud, extrinsic, truncation, max_dist):
+        """ChunkManager::GetChunkIDsIntersecting(cloud, cameraTransform, truncation, maxDist, chunkList) (ChunkManager.cpp:214-257): ids of
+        the chunks the cloud's truncated rays pass through, ascending."""
+        points, colors = (cloud.points, cloud.colors) if isinstance(cloud, PointCloud) else cloud
+        pa, pdev, k1 = _image_pointer(points, np.float32)
+        n = int(np.prod(tuple(points.shape))) // 3
+        pc = capi.PointCloud(pa, None, n, pdev, _pose12(extrinsic), float(truncation), float(max_dist))
+        cnt = C.c_int64(0)
+        check(self.L.chisel_hip_cloud_candidates(self.h, C.byref(pc), None, 0, C.byref(cnt)))
+        ids = np.zeros((max(1, cnt.value), 3), np.int32)
+        check(self.L.chisel_hip_cloud_candidates(self.h, C.byref(pc), ids.ctypes.data_as(C.POINTER(C.c_int)), cnt.value, C.byref(cnt)))
+        return ids[:cnt.value]
+
     def GarbageCollect(self, chunk_ids):
         ids = np.ascontiguousarray(np.asarray(chunk_ids, dtype=np.int32).reshape(-1, 3))
         check(self.L.chisel_hip_garbage_collect(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), len(ids)))

@@ -73,26 +73,16 @@ void launch_cloud_integrate(chisel_hip_map *m, const CloudParams &P, const Cloud
         hipLaunchKernelGGL((cloud_integrate_kernel<N, false>), dim3(CLOUD_GRID), dim3(64 * CloudGeom<N>::WAVES), 0, m->stream, P, m->view, m->view_dev, C);
 }
 
-}  // namespace
-
-extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_hip_pointcloud *cloud) {
-    if (m && m->is_group) return group::integrate_cloud(m, cloud);
-    if (!m || !cloud) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
-    if (cloud->n_points < 0 || (cloud->n_points > 0 && !cloud->points)) return fail(CHISEL_HIP_ERR_INVALID, "bad point list");
-    if (cloud->n_points > (int64_t)(0x7fffffff / (CLOUD_PAIRS_PER_POINT * 2)))
-        return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^26 points in one cloud");
-    if (cloud->n_points == 0) return CHISEL_HIP_OK;  // no chunk is listed: Chisel.cpp:112-113
-    HIP_TRY(hipSetDevice(m->device));
-    int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
-    if (rc) return rc;
-    rc = ensure_cloud_buffers(m, cloud->n_points);
+// what both entry points below need of a cloud: buffers, the points in HBM, the parameters of the per-point kernels
+int cloud_setup(chisel_hip_map *m, const chisel_hip_pointcloud *cloud, CloudParams &P, CloudView &C) {
+    int rc = ensure_cloud_buffers(m, cloud->n_points);
     if (rc) return rc;
     if (m->input_event) {  // chisel_hip_wait_event: a device cloud produced on another stream is ready behind this event
         HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
         m->input_event = nullptr;
     }
     const int n = (int)cloud->n_points;
-    CloudView C = m->cloud.view;
+    C = m->cloud.view;
     if (cloud->on_device) {
         C.points = cloud->points;
         C.colors = cloud->colors;
@@ -103,7 +93,6 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
         C.points = m->cloud.points;
         C.colors = cloud->colors ? m->cloud.colors : nullptr;
     }
-    CloudParams P;
     memset(&P, 0, sizeof(P));
     P.ip.trunc_kind = m->integ.truncator_kind;
     P.ip.trunc_param = m->integ.truncator_param;
@@ -131,6 +120,26 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
         P.jaxis = ay[0] >= ay[1] ? (ay[0] >= ay[2] ? 0 : 2) : (ay[1] >= ay[2] ? 1 : 2);
     }
     if (const char *e = getenv("CHISEL_HIP_CLOUD_AXIS")) P.jaxis = std::max(0, std::min(2, atoi(e)));  // test / tuning hook
+    return CHISEL_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_hip_pointcloud *cloud) {
+    if (m && m->is_group) return group::integrate_cloud(m, cloud);
+    if (!m || !cloud) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (cloud->n_points < 0 || (cloud->n_points > 0 && !cloud->points)) return fail(CHISEL_HIP_ERR_INVALID, "bad point list");
+    if (cloud->n_points > (int64_t)(0x7fffffff / (CLOUD_PAIRS_PER_POINT * 2)))
+        return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^26 points in one cloud");
+    if (cloud->n_points == 0) return CHISEL_HIP_OK;  // no chunk is listed: Chisel.cpp:112-113
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
+    if (rc) return rc;
+    CloudParams P;
+    CloudView C;
+    rc = cloud_setup(m, cloud, P, C);
+    if (rc) return rc;
+    const int n = (int)cloud->n_points;
 
     ProfScope ps(m, CHISEL_HIP_KERNEL_CLOUD);
     const int tiles = (n + CLOUD_TILE - 1) / CLOUD_TILE;
@@ -155,5 +164,44 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
     HIP_TRY(hipGetLastError());
     HIP_TRY(note_map_mutation(m));
     // the staging buffers (host clouds) and the per-cloud lists are reused by the next cloud: same stream, so no wait here
+    return CHISEL_HIP_OK;
+}
+
+// ChunkManager::GetChunkIDsIntersecting(cloud, cameraTransform, truncation, maxDist, chunkList) (ChunkManager.cpp:214-257): the chunks
+// the segments point -+ truncation along the viewing rays pass through -- the listing step of the call above on its own (the same
+// kernel), ids in ascending order (the reference's order is that of an unordered_map).  A shard lists the chunks it owns.
+extern "C" int chisel_hip_cloud_candidates(chisel_hip_map *m, const chisel_hip_pointcloud *cloud, int *ids, int64_t max_ids, int64_t *count) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "per-shard read-out");
+    if (!m || !cloud || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (cloud->n_points < 0 || (cloud->n_points > 0 && !cloud->points)) return fail(CHISEL_HIP_ERR_INVALID, "bad point list");
+    if (cloud->n_points > (int64_t)(0x7fffffff / (CLOUD_PAIRS_PER_POINT * 2)))
+        return fail(CHISEL_HIP_ERR_UNSUPPORTED, "more than 2^26 points in one cloud");
+    *count = 0;
+    if (cloud->n_points == 0) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    CloudParams P;
+    CloudView C;
+    int rc = cloud_setup(m, cloud, P, C);
+    if (rc) return rc;
+    P.with_color = 0;  // (colours play no part in the listing)
+    const int tiles = ((int)cloud->n_points + CLOUD_TILE - 1) / CLOUD_TILE;
+    HIP_TRY(hipMemsetAsync(C.table_keys, 0, m->cloud.zeroed_bytes, m->stream));
+    hipLaunchKernelGGL(cloud_prepare_kernel, dim3(tiles), dim3(CLOUD_TILE), 0, m->stream, P, C, m->view);
+    HIP_TRY(hipGetLastError());
+    rc = check_device_error(m);  // waits; too many chunks / a ray out of range are reported here
+    if (rc) return rc;
+    int n_listed = 0;
+    HIP_TRY(hipMemcpy(&n_listed, C.ctl, sizeof(int), hipMemcpyDeviceToHost));
+    n_listed = std::min(n_listed, CLOUD_MAX_LISTED);
+    std::vector<uint64_t> keys((size_t)n_listed);
+    if (n_listed) HIP_TRY(hipMemcpy(keys.data(), C.listed, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::vector<std::array<int, 3>> out(keys.size());
+    for (size_t i = 0; i < keys.size(); i++) unpack_id(keys[i], out[i][0], out[i][1], out[i][2]);
+    std::sort(out.begin(), out.end());
+    *count = (int64_t)out.size();
+    if (ids)
+        for (int64_t i = 0; i < std::min<int64_t>(max_ids, (int64_t)out.size()); i++) {
+            ids[3 * i] = out[(size_t)i][0]; ids[3 * i + 1] = out[(size_t)i][1]; ids[3 * i + 2] = out[(size_t)i][2];
+        }
     return CHISEL_HIP_OK;
 }

@@ -507,6 +507,39 @@ int chisel_hip_recompute_mesh(chisel_hip_map *m, const int id[3]) {
     return rc;
 }
 
+// ChunkManager::ExtractInsideVoxelMesh / ExtractBorderVoxelMesh (ChunkManager.cpp:259-379): the triangles of ONE cube of a resident
+// chunk (mesh_one_cube_kernel): up to 15 vertices and as many (face) normals; *occupied = a grid entry belongs to the cube.
+int chisel_hip_mesh_cube(chisel_hip_map *m, const int id[3], const int voxel[3], const float coords[3], float *vertices, float *normals, int *n_vertices,
+                         int *occupied) {
+    if (m && m->is_group) return id ? chisel_hip_mesh_cube(group::owner_map(m, id), id, voxel, coords, vertices, normals, n_vertices, occupied)
+                                    : fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (!m || !id || !voxel || !coords || !n_vertices || !occupied) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (m->cfg.n_shards > 1) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a shard does not hold the neighbours of its chunks");
+    for (int a = 0; a < 3; a++)
+        if (voxel[a] < -1 || voxel[a] >= m->N) return fail(CHISEL_HIP_ERR_INVALID, "voxel index outside the chunk");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_mesh_totals(m);
+    if (rc) return rc;
+    if (!m->mesh_buf.query) HIP_TRY(hipMalloc(&m->mesh_buf.query, 8 * sizeof(double)));
+    if (!m->mesh_buf.cube) HIP_TRY(hipMalloc(&m->mesh_buf.cube, 92 * sizeof(float)));
+    const MeshParams P = mesh_params(m);
+    float *out = m->mesh_buf.cube;
+    switch (m->N) {
+        case 8: hipLaunchKernelGGL(mesh_one_cube_kernel<8>, dim3(1), dim3(1), 0, m->stream, m->view, P, id[0], id[1], id[2], voxel[0], voxel[1], voxel[2], coords[0], coords[1], coords[2], out); break;
+        case 16: hipLaunchKernelGGL(mesh_one_cube_kernel<16>, dim3(1), dim3(1), 0, m->stream, m->view, P, id[0], id[1], id[2], voxel[0], voxel[1], voxel[2], coords[0], coords[1], coords[2], out); break;
+        case 32: hipLaunchKernelGGL(mesh_one_cube_kernel<32>, dim3(1), dim3(1), 0, m->stream, m->view, P, id[0], id[1], id[2], voxel[0], voxel[1], voxel[2], coords[0], coords[1], coords[2], out); break;
+    }
+    float host[92];
+    HIP_TRY(hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const int nv = (int)host[0];
+    *n_vertices = nv;
+    *occupied = host[1] != 0.0f ? 1 : 0;
+    if (vertices) memcpy(vertices, host + 2, (size_t)nv * 3 * sizeof(float));
+    if (normals) memcpy(normals, host + 2 + 45, (size_t)nv * 3 * sizeof(float));
+    return CHISEL_HIP_OK;
+}
+
 // ChunkManager::GenerateMesh(chunk, mesh) (ChunkManager.cpp:381-447) -- marching cubes of ONE chunk into the caller's arrays, face
 // normals, nothing else -- or, with stages, the whole of RecomputeMesh (bit 0: + ComputeNormalsFromGradients, bit 1: + ColorizeMesh)
 // without touching ChunkManager::allMeshes or meshesToUpdate.  The ordinary recompute runs with the dirty-flag housekeeping switched
@@ -649,7 +682,8 @@ int chisel_hip_get_sdf_and_gradient(chisel_hip_map *m, const float pos[3], doubl
 }  // extern "C"
 namespace {
 // SaveMeshPLYASCII (io/PLY.cpp:29-88) over the concatenated meshes: same text format, same number formatting (operator<< of float / int)
-void write_ply(std::ofstream &stream, const std::vector<MeshView> &views, size_t numPoints, bool any_color) {
+void write_ply(std::ofstream &stream, const std::vector<MeshView> &views, size_t numPoints, bool any_color, const int64_t *indices = nullptr,
+               size_t n_indices = 0) {
     stream << "ply" << std::endl;
     stream << "format ascii 1.0" << std::endl;
     stream << "element vertex " << numPoints << std::endl;
@@ -675,6 +709,14 @@ void write_ply(std::ofstream &stream, const std::vector<MeshView> &views, size_t
             }
             stream << std::endl;
         }
+    }
+    if (indices) {  // a caller's mesh: its own index list (PLY.cpp:74-84)
+        for (size_t i = 0; i + 2 < n_indices; i += 3) {
+            stream << "3 ";
+            for (int j = 0; j < 3; j++) stream << indices[i + j] << " ";
+            stream << std::endl;
+        }
+        return;
     }
     for (size_t i = 0; i < numPoints; i += 3) {
         stream << "3 ";
@@ -708,6 +750,21 @@ int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
         any_color = any_color || (views[i].n_v && views[i].c);
     }
     write_ply(stream, views, numPoints, any_color);
+    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("write failed: ") + path);
+    return CHISEL_HIP_OK;
+}
+
+// SaveMeshPLYASCII(fileName, mesh) (io/PLY.cpp:29-88) for a caller's own mesh: vertices (3 floats each), colours in [0, 1] or NULL,
+// the face list as the mesh's indices give it (three per face).  Host I/O only: no device is touched.
+int chisel_hip_write_mesh_ply(const char *path, const float *vertices, const float *colors, int64_t n_vertices, const int64_t *indices, int64_t n_indices) {
+    if (!path || n_vertices < 0 || n_indices < 0 || (n_vertices && !vertices) || (n_indices && !indices)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    std::ofstream stream(path);
+    if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("cannot open ") + path);
+    MeshView mv;
+    mv.v = vertices;
+    mv.c = colors;
+    mv.n_v = (size_t)n_vertices;
+    write_ply(stream, std::vector<MeshView>(1, mv), (size_t)n_vertices, colors != nullptr, indices, (size_t)n_indices);
     if (!stream) return fail(CHISEL_HIP_ERR_IO, std::string("write failed: ") + path);
     return CHISEL_HIP_OK;
 }

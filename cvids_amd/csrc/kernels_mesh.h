@@ -748,6 +748,56 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     }
 }
 
+// ChunkManager::ExtractInsideVoxelMesh / ExtractBorderVoxelMesh (ChunkManager.cpp:259-379) for ONE cube of a resident chunk: the eight
+// corners -- voxel `index` + cubeIndexOffsets, taken from the neighbour chunk where a coordinate leaves [0, N) on either side (:318-333) --,
+// all of them observed (weight > 0.5) or nothing; then MarchingCubes::MeshCube (MarchingCubes.h:73-106) with the caller's cube
+// coordinates.  One thread.  out: [0] vertices written (0, 3 .. 15), [1] IsOccupied (a grid entry follows), then 15 x 3 vertex floats and
+// 15 x 3 normal floats (the face normal of each triangle, thrice).
+template <int N>
+__global__ void mesh_one_cube_kernel(MapView M, MeshParams P, int jx, int jy, int jz, int ix, int iy, int iz, float cx, float cy, float cz, float *out) {
+    float sdf[8];
+    bool observed = true;
+    for (int i = 0; i < 8 && observed; i++) {
+        int c[3] = {ix + corner_ox(i), iy + corner_oy(i), iz + corner_oz(i)};
+        int off[3] = {0, 0, 0};
+        for (int a = 0; a < 3; a++) {
+            if (c[a] < 0) { off[a] = -1; c[a] = N - 1; }
+            else if (c[a] >= N) { off[a] = 1; c[a] = 0; }
+        }
+        const int slot = hash_find_quiescent(M, jx + off[0], jy + off[1], jz + off[2]);
+        if (slot < 0) { observed = false; break; }
+        const size_t o = (size_t)slot * (N * N * N) + (c[2] * N + c[1]) * N + c[0];
+        if (!(M.wgt[o] > 0.5f)) { observed = false; break; }
+        sdf[i] = M.sdf[o];
+    }
+    out[0] = 0.0f;
+    out[1] = 0.0f;
+    if (!observed) return;
+    int index = 0;
+    for (int i = 0; i < 8; i++) index |= (sdf[i] < 0.0f) ? (1 << i) : 0;  // CalculateVertexConfiguration MarchingCubes.h:108-118
+    const int nv = c_mc_counts[index];
+    const unsigned long long row = c_mc_cases[index];
+    const f3v coords = mk3(cx, cy, cz);
+    for (int t = 0; t < nv; t += 3) {
+        f3v p[3];
+        for (int a = 0; a < 3; a++) {
+            const int ed = (int)((row >> (4 * (t + 2 - a))) & 0xF);
+            const int e0 = c_mc_edges[ed] & 0xF, e1 = c_mc_edges[ed] >> 4;
+            const f3v c0 = add3(coords, mk3((float)corner_ox(e0) * P.res, (float)corner_oy(e0) * P.res, (float)corner_oz(e0) * P.res));
+            const f3v c1 = add3(coords, mk3((float)corner_ox(e1) * P.res, (float)corner_oy(e1) * P.res, (float)corner_oz(e1) * P.res));
+            p[a] = interpolate_vertex(c0, c1, sdf[e0], sdf[e1]);
+        }
+        const f3v fn = normalized3(cross3v(sub3(p[1], p[0]), sub3(p[2], p[0])));
+        for (int a = 0; a < 3; a++) {
+            float *v = out + 2 + 3 * (t + a), *n = out + 2 + 45 + 3 * (t + a);
+            v[0] = p[a].x; v[1] = p[a].y; v[2] = p[a].z;
+            n[0] = fn.x; n[1] = fn.y; n[2] = fn.z;
+        }
+    }
+    out[0] = (float)nv;
+    out[1] = nv ? 1.0f : 0.0f;  // IsOccupied (MarchingCubes.h:41-45): the case has a triangle
+}
+
 // ChunkManager::GetSDF / GetSDFAndGradient for one host-supplied position (chisel_hip_get_sdf*); one thread
 template <int N>
 __global__ void query_sdf_kernel(MapView M, MeshParams P, float x, float y, float z, int with_gradient, double *out /* dist, gx, gy, gz, found */) {
@@ -807,6 +857,7 @@ struct MeshBuffers {
     int capacity = 0;        // jobs
     unsigned *flags = nullptr;  // [max_chunks] "mesh this slot"
     double *query = nullptr;
+    float *cube = nullptr;      // result of mesh_one_cube_kernel
 };
 inline void free_mesh_buffers(MeshBuffers &b) {
     if (b.jobs) (void)hipFree(b.jobs);
@@ -817,6 +868,7 @@ inline void free_mesh_buffers(MeshBuffers &b) {
     if (b.corners) (void)hipFree(b.corners);
     if (b.flags) (void)hipFree(b.flags);
     if (b.query) (void)hipFree(b.query);
+    if (b.cube) (void)hipFree(b.cube);
     b = MeshBuffers();
 }
 

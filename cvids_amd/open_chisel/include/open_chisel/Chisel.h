@@ -80,6 +80,7 @@ class ColorVoxel {  // ColorVoxel.h:33-100
     void SetBlue(uint8_t v) { blue = v; }
     void SetWeight(uint8_t v) { weight = v; }
     void Reset() { red = green = blue = weight = 0; }
+    static float Saturate(float value) { return std::min(std::max(value, 0.0f), 255.0f); }  // ColorVoxel.h:39-42
     uint8_t red = 0, green = 0, blue = 0, weight = 0;
 };
 
@@ -130,6 +131,10 @@ inline chisel_hip_color_frame ColorFrame(const ColorImage<ColorType> &img, const
 }
 }  // namespace hipfacade
 
+struct ChunkStatistics {  // Chunk.h:39-45
+    size_t numKnownInside, numKnownOutside, numUnknown;
+    float totalWeight;
+};
 class Chunk {  // Chunk.h:47-140: a host object; either free-standing (to be added to a map) or the mirror of a device-resident chunk
   public:
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -162,6 +167,44 @@ class Chunk {  // Chunk.h:47-140: a host object; either free-standing (to be add
     const DistVoxel &GetDistVoxel(int x, int y, int z) const { return GetDistVoxel(GetVoxelID(x, y, z)); }
     const ColorVoxel &GetColorVoxel(int x, int y, int z) const { return GetColorVoxel(GetVoxelID(x, y, z)); }
     const Vec3 &GetOrigin() const { return origin; }
+    bool IsCoordValid(int x, int y, int z) const {  // Chunk.h:106-109
+        return x >= 0 && x < numVoxels(0) && y >= 0 && y < numVoxels(1) && z >= 0 && z < numVoxels(2);
+    }
+    // Chunk.cpp:46-63: (re)create the voxel arrays with default voxels -- of this host object; the map's voxels change through
+    // ChunkManager::AddChunk, which uploads them
+    void AllocateDistVoxels() {
+        loaded = true;
+        voxels.assign(GetTotalNumVoxels(), DistVoxel());
+    }
+    void AllocateColorVoxels() {
+        loaded = true;
+        hasColor = true;
+        if (voxels.size() != GetTotalNumVoxels()) voxels.assign(GetTotalNumVoxels(), DistVoxel());
+        colors.assign(GetTotalNumVoxels(), ColorVoxel());
+    }
+    void ComputeStatistics(ChunkStatistics *stats) const {  // Chunk.cpp:89-116 over this mirror (the whole map: ChunkManager::PrintMemoryStatistics)
+        for (const DistVoxel &vox : Load().voxels) {
+            const float weight = vox.GetWeight();
+            if (weight > 0) {
+                if (vox.GetSDF() < 0) stats->numKnownInside++;
+                else stats->numKnownOutside++;
+            } else {
+                stats->numUnknown++;
+            }
+            stats->totalWeight += weight;
+        }
+    }
+    Vec3 GetColorAt(const Vec3 &pos) const {  // Chunk.cpp:118-136: nearest voxel's colour in [0, 1], zero outside the chunk
+        if (hasColor && ComputeBoundingBox().Contains(pos)) {
+            const int x = static_cast<int>((pos(0) - origin(0)) / voxelResolutionMeters), y = static_cast<int>((pos(1) - origin(1)) / voxelResolutionMeters),
+                      z = static_cast<int>((pos(2) - origin(2)) / voxelResolutionMeters);
+            if (IsCoordValid(x, y, z)) {
+                const ColorVoxel &c = GetColorVoxel(x, y, z);
+                return Vec3(static_cast<float>(c.GetRed()) / 255.0f, static_cast<float>(c.GetGreen()) / 255.0f, static_cast<float>(c.GetBlue()) / 255.0f);
+            }
+        }
+        return Vec3(0.0f, 0.0f, 0.0f);
+    }
     AABB ComputeBoundingBox() const {  // Chunk.cpp:65-70
         const Vec3 pos = origin;
         const Vec3 size = numVoxels.cast<float>() * voxelResolutionMeters;
@@ -440,6 +483,23 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
             for (int y = minID(1); y < maxID(1); y++)
                 for (int z = minID(2); z < maxID(2); z++) chunkList->push_back(ChunkID(x, y, z));
     }
+    // ChunkManager.cpp:214-257 (chisel_hip_cloud_candidates: the ray walk over the chunk grid, on the GPU; ascending ids where the
+    // reference has the order of an unordered_map)
+    void GetChunkIDsIntersecting(const PointCloud &cloud, const Transform &cameraTransform, float truncation, float maxDist, ChunkIDList *chunkList) {
+        chunkList->clear();
+        chisel_hip_pointcloud pc;
+        std::memset(&pc, 0, sizeof(pc));
+        pc.n_points = (int64_t)cloud.GetPoints().size();
+        pc.points = pc.n_points ? reinterpret_cast<const float *>(cloud.GetPoints().data()) : nullptr;
+        hipfacade::Pose12(cameraTransform, pc.pose);
+        pc.truncation = truncation;
+        pc.max_dist = maxDist;
+        int64_t n = 0;
+        hip_check(chisel_hip_cloud_candidates(map, &pc, nullptr, 0, &n));
+        std::vector<int> ids((size_t)std::max<int64_t>(n, 1) * 3);
+        hip_check(chisel_hip_cloud_candidates(map, &pc, ids.data(), n, &n));
+        for (int64_t i = 0; i < n; i++) chunkList->push_back(ChunkID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
+    }
     // ChunkManager.cpp:182-212 (chisel_hip_candidates: the reference's range and plane test, its order)
     void GetChunkIDsIntersecting(const Frustum &frustum, ChunkIDList *chunkList) {
         float c[24], p[24];
@@ -461,6 +521,27 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
     // ChunkManager.cpp:381-447: marching cubes of one chunk into the caller's Mesh -- vertices, face normals, sequential indices, grids
     // (no colours, no gradient normals: those are ColorizeMesh / ComputeNormalsFromGradients below, as RecomputeMesh chains them)
     void GenerateMesh(const ChunkPtr &chunk, Mesh *mesh) { MeshChunk(chunk->GetID(), 0, mesh); }
+    // ChunkManager.cpp:259-379: the triangles of ONE cube (voxel `index` of `chunk`, cube origin `coordinates`) appended to the caller's
+    // Mesh -- vertices, face normals, indices from *nextMeshIndex on, a grid entry when the cube is occupied.  The voxels are the map's
+    // (chisel_hip_mesh_cube), not those of the host mirror `chunk` points to; both members read neighbour chunks where the cube leaves
+    // the chunk, the reference's "inside" form merely assumes it does not.
+    void ExtractBorderVoxelMesh(const ChunkPtr &chunk, const Eigen::Vector3i &index, const Vec3 &coordinates, VertIndex *nextMeshIndex, Mesh *mesh) {
+        const ChunkID id = chunk->GetID();
+        const int c[3] = {id(0), id(1), id(2)}, v[3] = {index(0), index(1), index(2)};
+        const float xyz[3] = {coordinates(0), coordinates(1), coordinates(2)};
+        float ve[45], no[45];
+        int nv = 0, occupied = 0;
+        hip_check(chisel_hip_mesh_cube(map, c, v, xyz, ve, no, &nv, &occupied));
+        for (int i = 0; i < nv; i++) {
+            mesh->vertices.push_back(Vec3(ve[3 * i], ve[3 * i + 1], ve[3 * i + 2]));
+            mesh->normals.push_back(Vec3(no[3 * i], no[3 * i + 1], no[3 * i + 2]));
+            mesh->indices.push_back((*nextMeshIndex)++);
+        }
+        if (occupied) mesh->grids.push_back(coordinates);
+    }
+    void ExtractInsideVoxelMesh(const ChunkPtr &chunk, const Eigen::Vector3i &index, const Vec3 &coords, VertIndex *nextMeshIndex, Mesh *mesh) {
+        ExtractBorderVoxelMesh(chunk, index, coords, nextMeshIndex, mesh);
+    }
     void ColorizeMesh(Mesh *mesh) {  // ChunkManager.cpp:628-639
         const size_t n = mesh->vertices.size();
         mesh->colors.clear();

@@ -9,18 +9,30 @@
 #include "../geometry/Frustum.h"
 #include "../geometry/Geometry.h"
 namespace chisel {
-class Intrinsics {  // Intrinsics.h:31-53
+// geometry/Interpolate.h:28-36 (its one caller is DepthImage::BilinearInterpolateDepth below)
+inline float LinearInterpolate(float s, float e, float t) { return s + (e - s) * t; }
+inline float BilinearInterpolate(float c00, float c10, float c01, float c11, float tx, float ty) {
+    return LinearInterpolate(LinearInterpolate(c00, c10, tx), LinearInterpolate(c01, c11, tx), ty);
+}
+class Intrinsics {  // Intrinsics.h:31-53: the 3x3 matrix K; fx, fy, cx, cy are entries of it
   public:
-    float GetFx() const { return fx; }
-    float GetFy() const { return fy; }
-    float GetCx() const { return cx; }
-    float GetCy() const { return cy; }
-    void SetFx(float v) { fx = v; }
-    void SetFy(float v) { fy = v; }
-    void SetCx(float v) { cx = v; }
-    void SetCy(float v) { cy = v; }
+    Intrinsics() {
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) matrix(r, c) = 0.0f;  // (the reference leaves K uninitialised)
+    }
+    float GetFx() const { return matrix(0, 0); }
+    float GetFy() const { return matrix(1, 1); }
+    float GetCx() const { return matrix(0, 2); }
+    float GetCy() const { return matrix(1, 2); }
+    void SetFx(float v) { matrix(0, 0) = v; }
+    void SetFy(float v) { matrix(1, 1) = v; }
+    void SetCx(float v) { matrix(0, 2) = v; }
+    void SetCy(float v) { matrix(1, 2) = v; }
+    const Mat3x3 &GetMatrix() const { return matrix; }
+    Mat3x3 &GetMutableMatrix() { return matrix; }
+    void SetMatrix(const Mat3x3 &m) { matrix = m; }
   private:
-    float fx = 0, fy = 0, cx = 0, cy = 0;
+    Mat3x3 matrix;
 };
 class PinholeCamera {  // PinholeCamera.h:35-69
   public:
@@ -40,6 +52,16 @@ class PinholeCamera {  // PinholeCamera.h:35-69
         frustum->SetFromParams(view, nearPlane, farPlane, intrinsics.GetFy(), intrinsics.GetFy(), intrinsics.GetCx(), intrinsics.GetCy(),
                                (float)width, (float)height);
     }
+    // PinholeCamera.cpp:38-64 for a caller's own points (the kernels inline the same arithmetic: chisel_device.h)
+    Vec3 ProjectPoint(const Vec3 &point) const {
+        const float invZ = 1.0f / point(2);
+        return Vec3(intrinsics.GetFx() * point(0) * invZ + intrinsics.GetCx(), intrinsics.GetFy() * point(1) * invZ + intrinsics.GetCy(), point(2));
+    }
+    Vec3 UnprojectPoint(const Vec3 &point) const {
+        const float z = point(2);
+        return Vec3(z * ((point(0) - intrinsics.GetCx()) / intrinsics.GetFx()), z * ((point(1) - intrinsics.GetCy()) / intrinsics.GetFy()), z);
+    }
+    bool IsPointOnImage(const Vec3 &point) const { return point(0) >= 0 && point(1) >= 0 && point(0) < width && point(1) < height; }
   private:
     Intrinsics intrinsics;
     int width = 640, height = 480;
@@ -52,7 +74,14 @@ class DepthImage {  // DepthImage.h:33-103 (row-major, Index = col + row * width
     DepthImage(int w, int h) : data((size_t)w * h), width(w), height(h) {}
     int Index(int row, int col) const { return col + row * width; }
     void SetDataAt(int row, int col, DataType d) { data[Index(row, col)] = d; }
-    const DataType &DepthAt(int row, int col) const { return data[Index(row, col)]; }
+    float DepthAt(int row, int col) const { return static_cast<float>(data[Index(row, col)]); }
+    const DataType &At(int row, int col) const { return data[Index(row, col)]; }
+    DataType &AtMutable(int row, int col) { return data[Index(row, col)]; }
+    bool IsInside(int row, int col) const { return row >= 0 && row < width && col >= 0 && col < height; }  // DepthImage.h:86-89 (rows against the width: sic)
+    float BilinearInterpolateDepth(float x, float y) const {  // DepthImage.h:59-68 (no caller on the live path: ProjectionIntegrator.h:72,131 are commented out)
+        const int gxi = static_cast<int>(x), gyi = static_cast<int>(y);
+        return BilinearInterpolate(DepthAt(gyi, gxi), DepthAt(gyi, gxi + 1), DepthAt(gyi + 1, gxi), DepthAt(gyi + 1, gxi + 1), x - gxi, y - gyi);
+    }
     DataType *GetMutableData() { return data.data(); }
     const DataType *GetData() const { return data.data(); }
     void SetData(const DataType *d) { data.assign(d, d + (size_t)width * height); }
@@ -62,12 +91,27 @@ class DepthImage {  // DepthImage.h:33-103 (row-major, Index = col + row * width
     std::vector<DataType> data;
     int width, height;
 };
+template <class DataType = uint8_t>
+struct Color {  // ColorImage.h:30-36
+    DataType red, green, blue, alpha;
+};
 template <class DataType>
 class ColorImage {  // ColorImage.h:38-134 (1 = mono, 3 = BGR, 4 = BGRA)
   public:
     ColorImage() : width(-1), height(-1), numChannels(0) {}
     ColorImage(int w, int h, int c) : data((size_t)w * h * c), width(w), height(h), numChannels(c) {}
     int Index(int row, int col, int channel) const { return (col + row * width) * numChannels + channel; }
+    // ColorImage.h:66-101: channel order by channel count -- what color_at() of the integration kernel decodes (chisel_device.h)
+    void At(int row, int col, Color<DataType> *out) const {
+        const DataType *p = &data[(size_t)Index(row, col, 0)];
+        if (numChannels == 1) { out->red = out->green = out->blue = out->alpha = p[0]; }
+        else if (numChannels == 2) { out->red = p[0]; out->green = out->blue = out->alpha = p[1]; }
+        else if (numChannels == 3) { out->red = p[2]; out->green = p[1]; out->blue = p[0]; out->alpha = p[2]; }
+        else if (numChannels == 4) { out->red = p[2]; out->green = p[1]; out->blue = p[0]; out->alpha = p[3]; }
+    }
+    const DataType &At(int row, int col, int channel) const { return data[(size_t)Index(row, col, channel)]; }
+    DataType &AtMutable(int row, int col, int channel) { return data[(size_t)Index(row, col, channel)]; }
+    bool IsInside(int row, int col) const { return row >= 0 && row < width && col >= 0 && col < height; }  // ColorImage.h:115-118 (sic)
     DataType *GetMutableData() { return data.data(); }
     const DataType *GetData() const { return data.data(); }
     int GetWidth() const { return width; }

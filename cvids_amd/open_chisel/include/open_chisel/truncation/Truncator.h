@@ -19,6 +19,7 @@ class ConstantTruncator : public Truncator {  // ConstantTruncator.h:31-56
     ConstantTruncator() = default;
     explicit ConstantTruncator(float value) : truncationDistance(value) {}
     float GetTruncationDistance(float) const override { return truncationDistance; }
+    void SetTruncationDistance(float value) { truncationDistance = value; }  // ConstantTruncator.h:46
     int HipKind() const override { return CHISEL_HIP_TRUNC_CONSTANT; }
     float HipParam() const override { return truncationDistance; }
   protected:
@@ -43,9 +44,12 @@ class QuadraticTruncator : public Truncator {  // QuadraticTruncator.h:31-73
     QuadraticTruncator() = default;
     explicit QuadraticTruncator(float scale) : scalingFactor(scale) {}
     float GetTruncationDistance(float reading) const override {
-        const float q = 0.0019 * 10, l = 0.00152 * 10, c = 0.001504 * 10;
-        return std::abs(q * std::pow(reading, 2) + l * reading + c) * scalingFactor;
+        return std::abs(GetQuadraticTerm() * std::pow(reading, 2) + GetLinearTerm() * reading + GetConstantTerm()) * scalingFactor;
     }
+    float GetQuadraticTerm() const { return 0.0019 * 10; }    // QuadraticTruncator.h:47-62 (the terms are constants of the class there too)
+    float GetLinearTerm() const { return 0.00152 * 10; }
+    float GetConstantTerm() const { return 0.001504 * 10; }
+    float GetScalingFactor() const { return scalingFactor; }
     int HipKind() const override { return CHISEL_HIP_TRUNC_QUADRATIC; }
     float HipParam() const override { return scalingFactor; }
   protected:

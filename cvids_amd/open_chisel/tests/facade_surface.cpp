@@ -6,6 +6,7 @@
 // reference's own code guarantees: RecomputeMesh == GenerateMesh -> ColorizeMesh -> ComputeNormalsFromGradients (ChunkManager.cpp:91-128),
 // per-chunk Integrate over the candidates of a frame == IntegrateDepthScanColor of that frame (Chisel.h:114-213), and so on.
 #include <open_chisel/Chisel.h>
+#include <open_chisel/io/PLY.h>
 
 #include <cmath>
 #include <cstdio>
@@ -46,6 +47,29 @@ int main() {
                 p[0] = (uint8_t)(u * 3); p[1] = (uint8_t)(v * 5); p[2] = (uint8_t)(u + v);
                 depth->SetDataAt(v, u, 1.5f + 0.004f * u - 0.003f * v);  // a tilted wall
             }
+        // ---- value types: camera projection, image accessors, truncators (PinholeCamera.cpp:38-64, DepthImage.h:59-89, ColorImage.h:66-118)
+        {
+            const Vec3 q = cam.ProjectPoint(Vec3(0.2f, -0.1f, 2.0f));
+            CHECK(q(0) == 52.5f * 0.2f * (1.0f / 2.0f) + 31.5f && q(1) == 52.5f * -0.1f * (1.0f / 2.0f) + 23.5f && q(2) == 2.0f);
+            const Vec3 back = cam.UnprojectPoint(q);
+            CHECK(std::fabs(back(0) - 0.2f) < 1e-6f && std::fabs(back(1) + 0.1f) < 1e-6f && back(2) == 2.0f);
+            CHECK(cam.IsPointOnImage(q) && !cam.IsPointOnImage(Vec3(-0.5f, 3.0f, 1.0f)) && !cam.IsPointOnImage(Vec3(64.0f, 3.0f, 1.0f)));
+            CHECK(cam.GetIntrinsics().GetMatrix()(0, 2) == 31.5f && cam.GetIntrinsics().GetMatrix()(1, 1) == 52.5f);
+            CHECK(depth->At(3, 5) == depth->DepthAt(3, 5) && depth->IsInside(3, 5) && !depth->IsInside(-1, 0));
+            depth->AtMutable(3, 5) = depth->At(3, 5);
+            const float mid = depth->BilinearInterpolateDepth(5.5f, 3.5f);
+            CHECK(std::fabs(mid - 0.25f * (depth->At(3, 5) + depth->At(3, 6) + depth->At(4, 5) + depth->At(4, 6))) < 1e-6f);
+            CHECK(BilinearInterpolate(1.0f, 3.0f, 5.0f, 7.0f, 0.5f, 0.5f) == 4.0f && LinearInterpolate(2.0f, 4.0f, 0.25f) == 2.5f);
+            Color<uint8_t> px = {0, 0, 0, 0};
+            color->At(7, 9, &px);  // BGR: red is byte 2
+            CHECK(px.red == color->At(7, 9, 2) && px.green == color->At(7, 9, 1) && px.blue == color->At(7, 9, 0) && px.alpha == px.red);
+            CHECK(ColorVoxel::Saturate(300.0f) == 255.0f && ColorVoxel::Saturate(-2.0f) == 0.0f && ColorVoxel::Saturate(17.5f) == 17.5f);
+            QuadraticTruncator qt(2.0f);
+            CHECK(qt.GetScalingFactor() == 2.0f && qt.GetTruncationDistance(1.0f) == std::abs(qt.GetQuadraticTerm() * std::pow(1.0f, 2) + qt.GetLinearTerm() * 1.0f + qt.GetConstantTerm()) * 2.0f);
+            ConstantTruncator ct(0.1f);
+            ct.SetTruncationDistance(0.3f);
+            CHECK(ct.GetTruncationDistance(5.0f) == 0.3f);
+        }
         Transform T;
         for (int k = 0; k < 2; k++) map.IntegrateDepthScanColor<float, uint8_t>(integ, depth, T, cam, color, T, cam);
         ChunkManager &cm = map.GetMutableChunkManager();
@@ -77,6 +101,18 @@ int main() {
         CHECK(dv->GetSDF() == want.GetSDF() && dv->GetWeight() == want.GetWeight());
         CHECK(cv->GetRed() == c->GetColorVoxel(3, 2, 5).GetRed() && cv->GetWeight() == c->GetColorVoxel(3, 2, 5).GetWeight());
         CHECK(cm.GetDistanceVoxel(Vec3(100.0f, 100.0f, 100.0f)) == nullptr);
+        {   // Chunk::IsCoordValid / GetColorAt / ComputeStatistics (Chunk.h:106-109, Chunk.cpp:89-136) on the mirror
+            CHECK(c->IsCoordValid(0, 0, N - 1) && !c->IsCoordValid(N, 0, 0) && !c->IsCoordValid(0, -1, 0));
+            const Vec3 col = c->GetColorAt(p);
+            CHECK(col(0) == (float)c->GetColorVoxel(3, 2, 5).GetRed() / 255.0f && col(2) == (float)c->GetColorVoxel(3, 2, 5).GetBlue() / 255.0f);
+            CHECK(same_bits(c->GetColorAt(c->GetOrigin() - Vec3(1.0f, 0.0f, 0.0f)), Vec3(0.0f, 0.0f, 0.0f)));
+            ChunkStatistics st = {0, 0, 0, 0.0f};
+            c->ComputeStatistics(&st);
+            CHECK(st.numKnownInside + st.numKnownOutside + st.numUnknown == c->GetTotalNumVoxels() && st.numKnownInside + st.numKnownOutside > 100 && st.totalWeight > 0.0f);
+            Chunk blank(ChunkID(9, 9, 9), Eigen::Vector3i(N, N, N), res, false);
+            blank.AllocateColorVoxels();
+            CHECK(blank.HasColors() && blank.GetColorVoxels().size() == blank.GetTotalNumVoxels() && blank.GetDistVoxel(0).GetWeight() == 0.0f);
+        }
 
         // ---- frustum: SetupFrustum -> Intersects / Contains, GetChunkIDsIntersecting (ChunkManager.cpp:72-89, 182-212)
         Frustum fr;
@@ -131,6 +167,27 @@ int main() {
         for (size_t t = 0; t + 2 < mine.normals.size(); t += 3)  // MeshCube: one face normal per triangle (MarchingCubes.h:95-101)
             CHECK(same_bits(mine.normals[t], mine.normals[t + 1]) && same_bits(mine.normals[t], mine.normals[t + 2]));
         CHECK(face_normals_kept < mine.vertices.size());  // gradient normals differ from face normals on a tilted wall
+        {
+            // GenerateMesh is this loop in the reference (ChunkManager.cpp:395-441): interior cubes, then the max-x, max-y and max-z planes
+            Mesh cubes;
+            VertIndex next = 0;
+            ChunkPtr ch = cm.GetChunk(meshed);
+            const Vec3 org = ch->GetOrigin();
+            auto centroid = [&](int x, int y, int z) { return Vec3((float)x * res + res * 0.5f, (float)y * res + res * 0.5f, (float)z * res + res * 0.5f) + org; };
+            for (int z = 0; z < N - 1; z++)
+                for (int y = 0; y < N - 1; y++)
+                    for (int x = 0; x < N - 1; x++) cm.ExtractInsideVoxelMesh(ch, Eigen::Vector3i(x, y, z), centroid(x, y, z), &next, &cubes);
+            for (int z = 0; z < N - 1; z++)
+                for (int y = 0; y < N; y++) cm.ExtractBorderVoxelMesh(ch, Eigen::Vector3i(N - 1, y, z), centroid(N - 1, y, z), &next, &cubes);
+            for (int z = 0; z < N - 1; z++)
+                for (int x = 0; x < N - 1; x++) cm.ExtractBorderVoxelMesh(ch, Eigen::Vector3i(x, N - 1, z), centroid(x, N - 1, z), &next, &cubes);
+            for (int y = 0; y < N; y++)
+                for (int x = 0; x < N; x++) cm.ExtractBorderVoxelMesh(ch, Eigen::Vector3i(x, y, N - 1), centroid(x, y, N - 1), &next, &cubes);
+            CHECK(cubes.vertices.size() == mine.vertices.size() && cubes.grids.size() == mine.grids.size() && next == mine.vertices.size());
+            for (size_t i = 0; i < cubes.vertices.size(); i++)
+                CHECK(same_bits(cubes.vertices[i], mine.vertices[i]) && same_bits(cubes.normals[i], mine.normals[i]) && cubes.indices[i] == i);
+            for (size_t i = 0; i < cubes.grids.size(); i++) CHECK(same_bits(cubes.grids[i], mine.grids[i]));
+        }
         cm.ColorizeMesh(&mine);
         cm.ComputeNormalsFromGradients(&mine);
         for (size_t i = 0; i < mine.vertices.size(); i++) {
@@ -138,6 +195,21 @@ int main() {
             CHECK(same_bits(mine.colors[i], stored->colors[i]));
         }
         CHECK(same_bits(cm.InterpolateColor(mine.vertices[0]), stored->colors[0]));
+        {   // SaveMeshPLYASCII of one mesh (io/PLY.cpp:29-88): header, one line per vertex with its colour bytes, one per face
+            const char *path = "/tmp/facade_surface_mesh.ply";
+            CHECK(SaveMeshPLYASCII(path, MeshConstPtr(stored)));
+            CHECK(!SaveMeshPLYASCII("/nonexistent-dir/x.ply", MeshConstPtr(stored)));
+            FILE *f = fopen(path, "r");
+            CHECK(f != nullptr);
+            char line[256];
+            size_t lines = 0, nv = 0, nf = 0;
+            while (fgets(line, sizeof(line), f)) {
+                lines++;
+                if (sscanf(line, "element vertex %zu", &nv) == 1 || sscanf(line, "element face %zu", &nf) == 1) continue;
+            }
+            fclose(f);
+            CHECK(nv == stored->vertices.size() && nf == nv / 3 && lines == 12 + nv + nf);
+        }
         CHECK(map.GetMeshesToUpdate().size() > 0);  // GenerateMesh left meshesToUpdate alone (RecomputeMesh above cleared only its own chunks)
 
         // ---- per-chunk ProjectionIntegrator::IntegrateColor over the candidates of a frame == Chisel::IntegrateDepthScanColor of it
@@ -171,6 +243,30 @@ int main() {
         if (touched) {
             ChunkPtr b = ref_map.GetChunkManager().GetChunk(meshed);
             for (size_t i = 0; i < loose.GetTotalNumVoxels(); i++) CHECK(loose.GetDistVoxel(i).GetSDF() == b->GetDistVoxel(i).GetSDF());
+        }
+        // ---- GetChunkIDsIntersecting(PointCloud, ...) (ChunkManager.cpp:214-257): the chunks Chisel::IntegratePointCloud lists; every chunk
+        // that call creates is one of them, and a cloud on a plane well inside the far limit lists at least the chunks of its own points
+        {
+            PointCloud cloud;
+            for (int v = 0; v < H; v += 2)
+                for (int u = 0; u < W; u += 2) {
+                    const float d = 1.2f + 0.002f * u;
+                    cloud.AddPoint(Vec3(((float)u - 31.5f) / 52.5f * d, ((float)v - 23.5f) / 52.5f * d, d));
+                }
+            ChunkIDList listed;
+            Chisel cloud_map(Eigen::Vector3i(N, N, N), res, false);
+            cloud_map.GetMutableChunkManager().GetChunkIDsIntersecting(cloud, T, 0.1f, 5.0f, &listed);
+            CHECK(listed.size() > 20);
+            for (size_t i = 1; i < listed.size(); i++) CHECK(!(listed[i] == listed[i - 1]));
+            cloud_map.IntegratePointCloud(integ, cloud, T, 0.1f, 5.0f);
+            size_t made = 0;
+            for (const auto &kv : cloud_map.GetChunkManager().GetChunks()) {
+                bool found = false;
+                for (const ChunkID &i : listed) found = found || i == kv.first;
+                CHECK(found);
+                made++;
+            }
+            CHECK(made > 5);
         }
         cm.PrintMemoryStatistics();
         printf("facade_surface ok: %zu candidates, %zu per-chunk integrations, %zu vertices\n", ids.size(), created, mine.vertices.size());

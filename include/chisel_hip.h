@@ -211,6 +211,10 @@ int chisel_hip_get_sdf(chisel_hip_map *map, const float pos[3], double *dist, in
 int chisel_hip_get_sdf_and_gradient(chisel_hip_map *map, const float pos[3], double *dist, float grad[3], int *found);
 /* Chisel::SaveAllMeshesToPLY Chisel.cpp:69-105 + SaveMeshPLYASCII io/PLY.cpp:29-88 */
 int chisel_hip_save_ply(chisel_hip_map *map, const char *path);
+/* SaveMeshPLYASCII(fileName, mesh) (src/io/PLY.cpp:29-88) for ONE mesh the caller holds: the same text format; colors (3 floats in
+ * [0, 1] per vertex) may be NULL; indices: three per face, as Mesh::indices.  Host I/O only. */
+int chisel_hip_write_mesh_ply(const char *path, const float *vertices, const float *colors, int64_t n_vertices, const int64_t *indices,
+                              int64_t n_indices);
 
 /* ---- meshing a sharded map (SURVEY.md 8e "meshing across shards") -------------------------------------------------
  * A chunk's mesh reads its 26 neighbours (cube corners: ChunkManager.cpp:316-357; gradient normals and colours of border
@@ -359,6 +363,12 @@ int chisel_hip_topology_epoch(chisel_hip_map *map, uint64_t *out);
  * reference's order (x outer, z inner).  ids may be NULL (count only); at most max_ids are written. */
 int chisel_hip_candidates(const float corners[24], const float planes[24], const int chunk_size[3], float voxel_resolution, int *ids,
                           int64_t max_ids, int64_t *count);
+/* ChunkManager::GetChunkIDsIntersecting(const PointCloud &, const Transform &, float truncation, float maxDist, ChunkIDList *)
+ * (src/ChunkManager.cpp:214-257): the chunks the segments point -+ truncation along the viewing rays pass through (Raycast over the
+ * chunk grid, points further than max_dist skipped) -- the listing step of chisel_hip_integrate_pointcloud on its own, same kernel.
+ * The reference returns them in the order of an unordered_map; here ascending (x, then y, then z).  A shard lists the chunks it owns.
+ * ids may be NULL (count only); at most max_ids are written. */
+int chisel_hip_cloud_candidates(chisel_hip_map *map, const chisel_hip_pointcloud *cloud, int *ids_xyz, int64_t max_ids, int64_t *count);
 /* ChunkManager::ComputeNormalsFromGradients (src/ChunkManager.cpp:609-626; stages bit 0: a normal is overwritten where the gradient
  * lookup of its vertex succeeds, kept otherwise) and ChunkManager::ColorizeMesh / InterpolateColor (:628-639, :501-573; stages bit 1)
  * for a caller's own vertex list (host arrays of 3 n floats). */
@@ -369,6 +379,13 @@ int chisel_hip_shade_vertices(chisel_hip_map *map, const float *vertices, int64_
  * changed").  CHISEL_HIP_ERR_NOT_FOUND when the chunk is not resident. */
 int chisel_hip_integrate_chunk(chisel_hip_map *map, const int id_xyz[3], const chisel_hip_depth_frame *frame, const chisel_hip_color_frame *color,
                                int *updated);
+/* ChunkManager::ExtractInsideVoxelMesh / ExtractBorderVoxelMesh(chunk, index, coordinates, nextMeshIndex, mesh) (src/ChunkManager.cpp:
+ * 259-379): the marching-cubes triangles of ONE cube of a resident chunk -- corner voxels index + cubeIndexOffsets, read from the
+ * neighbouring chunk where a coordinate leaves [0, N) (index components -1 .. N-1), none when a corner is unobserved (weight <= 0.5) or
+ * its chunk absent --, MarchingCubes::MeshCube with the caller's cube coordinates: up to 15 vertices (3 floats each) and their face
+ * normals; *occupied: MarchingCubes::IsOccupied (the caller pushes a grid entry).  vertices / normals may be NULL. */
+int chisel_hip_mesh_cube(chisel_hip_map *map, const int id_xyz[3], const int voxel_index[3], const float coordinates[3], float *vertices, float *normals,
+                         int *n_vertices, int *occupied);
 /* ChunkManager::RecomputeMesh(chunkID, mutex) (src/ChunkManager.cpp:91-128): the mesh of one chunk into ChunkManager::allMeshes, leaving
  * meshesToUpdate as it is (chisel_hip_update_meshes_of ends with the meshesToUpdate.clear() of Chisel::UpdateMeshes, Chisel.cpp:57) */
 int chisel_hip_recompute_mesh(chisel_hip_map *map, const int id_xyz[3]);

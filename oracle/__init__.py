@@ -59,6 +59,8 @@ def lib(variant=None):
                                            [u8p, C.c_int, C.c_int, C.c_int, f32p] + [C.c_float] * 4)
     L.oc_get_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.oc_integrate_pointcloud.argtypes = [vp, f32p, C.c_int, f32p, f32p, C.c_float, C.c_float]
+    L.oc_cloud_chunk_ids.restype = C.c_int
+    L.oc_cloud_chunk_ids.argtypes = [vp, f32p, C.c_int, f32p, C.c_float, C.c_float, i32p, C.c_int]
     L.oc_raycast.restype = C.c_int
     L.oc_raycast.argtypes = [f32p, f32p, i32p, i32p, i32p, C.c_int]
     L.oc_invert_pose.argtypes = [f32p, f32p]
@@ -168,6 +170,16 @@ class OracleMap:
         else:
             colp = None
         self.L.oc_integrate_pointcloud(self.h, ptp, pts.shape[0], colp, pp, float(truncation), float(max_dist))
+
+    def cloud_chunk_ids(self, points, pose, truncation=0.1, max_dist=5.0):
+        """ChunkManager::GetChunkIDsIntersecting(cloud, ...) (ChunkManager.cpp:214-257): ids (k, 3), sorted."""
+        pts, ptp = _f32(np.asarray(points).reshape(-1, 3))
+        p, pp = _f32(np.asarray(pose)[:3, :4])
+        k = self.L.oc_cloud_chunk_ids(self.h, ptp, pts.shape[0], pp, float(truncation), float(max_dist), None, 0)
+        ids = np.zeros((max(1, k), 3), np.int32)
+        self.L.oc_cloud_chunk_ids(self.h, ptp, pts.shape[0], pp, float(truncation), float(max_dist), ids.ctypes.data_as(C.POINTER(C.c_int)), k)
+        ids = ids[:k]
+        return ids[np.lexsort((ids[:, 2], ids[:, 1], ids[:, 0]))]
 
     def counters(self):
         out = (C.c_uint64 * len(COUNTER_NAMES))()

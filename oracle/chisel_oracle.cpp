@@ -1378,6 +1378,19 @@ void oc_integrate_pointcloud(oc_map *m, const float *points_xyz, int n_points, c
     m->IntegratePointCloudScan(pts.data(), pts.size(), colors_rgb ? cols.data() : nullptr, Pose::fromRowMajor3x4(pose), truncation,
                                max_dist);
 }
+// ChunkManager::GetChunkIDsIntersecting(cloud, cameraTransform, truncation, maxDist, chunkList) on its own (ChunkManager.cpp:214-257);
+// returns the number of ids (at most `capacity` are written, in the listing order of the oracle's own hash map)
+int oc_cloud_chunk_ids(oc_map *m, const float *points_xyz, int n_points, const float *pose, float truncation, float max_dist, int *ids_xyz,
+                       int capacity) {
+    std::vector<V3> pts((size_t)n_points);
+    for (int i = 0; i < n_points; i++) pts[i] = V3(points_xyz[3 * i], points_xyz[3 * i + 1], points_xyz[3 * i + 2]);
+    std::vector<I3> out;
+    m->GetChunkIDsIntersectingCloud(pts.data(), pts.size(), oc_map::Affine::fromPose(Pose::fromRowMajor3x4(pose)), truncation, max_dist, &out);
+    for (size_t i = 0; i < out.size() && (int)i < capacity; i++) {
+        ids_xyz[3 * i] = out[i].x; ids_xyz[3 * i + 1] = out[i].y; ids_xyz[3 * i + 2] = out[i].z;
+    }
+    return (int)out.size();
+}
 int oc_raycast(const float *start3, const float *end3, const int *min3, const int *max3, int *cells_xyz, int capacity) {
     std::vector<I3> out;
     oc_map::Raycast(V3(start3[0], start3[1], start3[2]), V3(end3[0], end3[1], end3[2]), I3(min3[0], min3[1], min3[2]),

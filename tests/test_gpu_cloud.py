@@ -384,3 +384,91 @@ def test_cloud_report_does_not_hide_pool_exhaustion(hip_lib):
     gm.Reset()
     gm.synchronize()
     gm.close()
+
+
+@pytest.mark.parametrize("N,res", [(8, 0.05), (16, 0.02), (32, 0.02)])
+def test_cloud_candidates_match_the_oracle(hip_lib, oracle_mod, N, res):
+    """ChunkManager::GetChunkIDsIntersecting(cloud, cameraTransform, truncation, maxDist, chunkList) (ChunkManager.cpp:214-257) on its own:
+    chisel_hip_cloud_candidates (the listing kernel of the point-cloud mode) against the oracle's restatement -- same set of ids for
+    organised clouds under yawed poses, random clouds under arbitrary poses, a far limit that drops points, and an empty cloud; the map
+    itself is left untouched."""
+    om, gm, integ = _mk(oracle_mod, N, res, False)
+    rng = np.random.default_rng(11)
+    cases = []
+    for k in range(3):
+        pts, _, pose = _cloud("sphere_room", k, 96, 72, 1.5, False)
+        cases.append((pts, pose, 0.1, 5.0))
+    cases.append((cases[0][0], cases[0][1], 0.25, 1.9))                      # longer segments, points beyond the far limit skipped
+    cases.append((rng.uniform(-1.5, 1.5, (3000, 3)).astype(np.float32), _random_pose(rng), 0.1, 2.0))
+    cases.append((np.zeros((0, 3), np.float32), synth.pose_yaw(0.0), 0.1, 5.0))
+    for i, (pts, pose, trunc, far) in enumerate(cases):
+        want = om.cloud_chunk_ids(pts, pose, trunc, far)
+        got = gm.CloudCandidates((pts, None), pose, trunc, far)
+        assert got.shape == want.shape and np.array_equal(got, want), "case %d: %d vs %d ids" % (i, len(got), len(want))
+        if len(pts):
+            assert len(want) > 10
+    assert gm.NumChunks() == 0
+
+
+@pytest.mark.parametrize("N", [8, 16])
+def test_mesh_of_one_cube_matches_the_oracle(hip_lib, oracle_mod, N):
+    """ChunkManager::ExtractInsideVoxelMesh / ExtractBorderVoxelMesh (ChunkManager.cpp:259-379) through chisel_hip_mesh_cube: for cubes inside
+    a chunk, on its +x / +y / +z faces (corners in the neighbour chunks) and with index -1 (corners in the -x neighbour), the vertices
+    and face normals are those of the oracle's MeshCube over the same eight corner distances; a cube with an unobserved corner or an
+    absent neighbour yields nothing."""
+    from tests.common import make_frames, small_camera
+    from cvids_amd import chisel as ch
+    res = 0.04
+    om, gm, integ = _mk(oracle_mod, N, res, False)
+    cam = small_camera(96, 72)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    for d, p in make_frames("sphere_room", 3, 96, 72):
+        om.integrate_depth(d, p, intr, cam.near_plane, cam.far_plane)
+        gm.IntegrateDepthScan(integ, d, p, cam)
+    ids = [tuple(i) for i in om.chunk_ids().tolist()]
+    chunks = {i: om.get_chunk(i) for i in ids}
+    off = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]  # cubeIndexOffsets, ChunkManager.cpp:67-69
+
+    def corners(cid, v):
+        s = []
+        for o in off:
+            c = [v[a] + o[a] for a in range(3)]
+            nid = list(cid)
+            for a in range(3):
+                if c[a] < 0:
+                    nid[a] -= 1
+                    c[a] = N - 1
+                elif c[a] >= N:
+                    nid[a] += 1
+                    c[a] = 0
+            ck = chunks.get(tuple(nid))
+            if ck is None:
+                return None
+            lin = (c[2] * N + c[1]) * N + c[0]
+            if not ck[1].reshape(-1)[lin] > 0.5:
+                return None
+            s.append(ck[0].reshape(-1)[lin])
+        return np.asarray(s, np.float32)
+
+    L, checked, empty = gm.L, 0, 0
+    rng = np.random.default_rng(5)
+    for cid in ids[:40]:
+        picks = [tuple(rng.integers(0, N - 1, 3)) for _ in range(6)] + [(N - 1, 2, 3), (1, N - 1, 2), (3, 1, N - 1), (N - 1, N - 1, N - 1), (-1, 2, 2)]
+        for v in picks:
+            coords = (np.asarray(v, np.float32) * np.float32(res) + np.float32(res * 0.5)) + np.asarray(cid, np.float32) * np.float32(N * res)
+            ve, no = np.zeros((15, 3), np.float32), np.zeros((15, 3), np.float32)
+            nv, occ = C.c_int(0), C.c_int(0)
+            idv, vv = (C.c_int * 3)(*cid), (C.c_int * 3)(*[int(x) for x in v])
+            fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+            rc = L.chisel_hip_mesh_cube(gm.h, idv, vv, fp(coords), fp(ve), fp(no), C.byref(nv), C.byref(occ))
+            assert rc == 0
+            s = corners(cid, v)
+            if s is None:
+                assert nv.value == 0 and occ.value == 0
+                empty += 1
+                continue
+            wv, wn = oracle_mod.mesh_cube(s, coords, res)
+            assert nv.value == len(wv) and occ.value == (1 if len(wv) else 0)
+            assert np.array_equal(ve[:nv.value].view(np.uint32), wv.view(np.uint32)) and np.array_equal(no[:nv.value].view(np.uint32), wn.view(np.uint32))
+            checked += len(wv) > 0
+    assert checked > 20 and empty > 5

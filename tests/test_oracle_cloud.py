@@ -136,3 +136,19 @@ def test_cloud_sequence_is_plausible(oracle_mod):
     ok2, d_back = om.get_sdf((0.01, 0.01, 1.23))
     assert ok and ok2 and d_front > 0 > d_back
     assert len(om.meshes_to_update()) > 0
+
+
+def test_cloud_chunk_listing_hand_derived(oracle_mod):
+    """ChunkManager.cpp:214-257 on its own (oc_cloud_chunk_ids): 8-voxel chunks of 5 cm = 0.4 m.  A point at z = 0.79 straight ahead with
+    truncation 0.1: the segment z in [0.69, 0.89] crosses the chunk boundary at 0.8 -> chunks (0,0,1) and (0,0,2); a point whose segment
+    stays inside one chunk lists nothing (Raycast.cpp:79-80); a point beyond maxDist is skipped (:231-234)."""
+    om = oracle_mod.OracleMap(8, 0.05, False)
+    pose = synth.pose_yaw(0.0)
+    ids = om.cloud_chunk_ids(np.array([[0.01, 0.01, 0.79]], np.float32), pose, 0.1, 5.0)
+    assert ids.tolist() == [[0, 0, 1], [0, 0, 2]]
+    assert len(om.cloud_chunk_ids(np.array([[0.01, 0.01, 0.60]], np.float32), pose, 0.1, 5.0)) == 0
+    assert len(om.cloud_chunk_ids(np.array([[0.01, 0.01, 0.79]], np.float32), pose, 0.1, 0.5)) == 0
+    # the listing is a set: two points through the same boundary list it once
+    ids = om.cloud_chunk_ids(np.array([[0.01, 0.01, 0.79], [0.02, 0.01, 0.81]], np.float32), pose, 0.1, 5.0)
+    assert ids.tolist() == [[0, 0, 1], [0, 0, 2]]
+    assert om.num_chunks() == 0
