@@ -65,7 +65,7 @@ int main() {
             CHECK(px.red == color->At(7, 9, 2) && px.green == color->At(7, 9, 1) && px.blue == color->At(7, 9, 0) && px.alpha == px.red);
             CHECK(ColorVoxel::Saturate(300.0f) == 255.0f && ColorVoxel::Saturate(-2.0f) == 0.0f && ColorVoxel::Saturate(17.5f) == 17.5f);
             QuadraticTruncator qt(2.0f);
-            CHECK(qt.GetScalingFactor() == 2.0f && qt.GetTruncationDistance(1.0f) == std::abs(qt.GetQuadraticTerm() * std::pow(1.0f, 2) + qt.GetLinearTerm() * 1.0f + qt.GetConstantTerm()) * 2.0f);
+            CHECK(qt.GetScalingFactor() == 2.0f && qt.GetTruncationDistance(1.0f) == (float)(std::abs(qt.GetQuadraticTerm() * std::pow(1.0f, 2) + qt.GetLinearTerm() * 1.0f + qt.GetConstantTerm()) * 2.0f));
             ConstantTruncator ct(0.1f);
             ct.SetTruncationDistance(0.3f);
             CHECK(ct.GetTruncationDistance(5.0f) == 0.3f);
