@@ -433,16 +433,16 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         }
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
         const int *force_flag = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : nullptr;
-        const dim3 rgrid((total + 255) / 256);
+        const dim3 rgrid((total + RESOLVE_BLOCK - 1) / RESOLVE_BLOCK);
         // one frame: nothing to order; and a work-list that fits the chip in one go (<= 256 items by the count a recent launch
         // reported: every unit starts at once, whatever its place in the list) is not worth a launch of its own either -- the
         // shards of a multi-GPU map are in this regime, where the front half is what a rank's rate hangs on
         const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
         const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= 256);
-        hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(256), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
+        hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
                            prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync);
         if (!direct)
-            hipLaunchKernelGGL(order_kernel, rgrid, dim3(256), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
+            hipLaunchKernelGGL(order_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
     }
     HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     }

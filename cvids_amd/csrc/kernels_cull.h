@@ -397,7 +397,13 @@ __device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
 // anyway), here in blocks of 4 x 4 x 4 ids per wave.  Sharded: only the ids this shard owns -- chunk_owner() is (bx + 3 by + 5 bz) mod n on
 // super-blocks of b^3 chunks, so for each (by, bz) the owned bx are one residue class: slot j of (by, bz) is the j-th owned bx
 // at or after the range's first super-block.  (Before, every shard walked the whole range with n - 1 of n lanes idle.)
+#ifndef RESOLVE_BLOCK
+#define RESOLVE_BLOCK 256   // threads per workgroup of resolve_kernel / order_kernel (they use wave-level primitives only)
+#endif
 constexpr int CULL_BLOCK = 4;
+#ifndef CULL_EARLY_EXIT
+#define CULL_EARLY_EXIT 1
+#endif
 struct CullSpace {
     int sharded;
     int b;                 // super-block edge in chunks
@@ -497,6 +503,17 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
     }
     fb.flags = fl;
     s_flags[k][lane] = fl;
+#if CULL_EARLY_EXIT
+    // A wave none of whose 64 chunks the frame can touch is done: its flags are in LDS, it owns no row of `boxes` (the integration
+    // kernel reads a box only for the frames of an item's mask), and wave 0 does the merge.  Leaving NOW instead of sitting through the
+    // two barriers below gives its slot back while the block's live waves -- with agents looking in different directions a quarter of
+    // them -- are still in cull_post (a barrier waits for the surviving waves of a workgroup only; a terminated wave's LDS write has
+    // retired).
+    if (k != 0 && !__any(fl != 0)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        return;
+    }
+#endif
     __syncthreads();
     if (k == 0) {
         // ---- merge the frames of each chunk, compact the candidates ----------------------------------------------
@@ -594,15 +611,15 @@ __device__ inline int cost_class(unsigned frame_mask) { return (KMAX - __popc(fr
 
 // items != nullptr: single-frame launch sets -- every work item is touched by exactly one frame, there is nothing to order,
 // so the survivors go straight into the work-list (one returning atomic per wave) and order_kernel is not launched.
-__global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
+__global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
                                                        int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
                                                        const uint64_t *__restrict__ prev2_pending, const int *__restrict__ force_uncertain,
                                                        uint64_t *my_pending, WorkItem *items, ItemSync *sync) {
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * RESOLVE_BLOCK + threadIdx.x;
     int n = counts_in[COUNT_CANDS];
     if (n > max_cands) n = max_cands;
-    if ((int)(blockIdx.x * 256) >= n) return;
+    if ((int)(blockIdx.x * RESOLVE_BLOCK) >= n) return;
     // a pending set of the batches in flight is incomplete (its overflow flag sits behind its last bucket), or the test hook
     const bool all_uncertain = (force_uncertain && *force_uncertain != 0) || (prev_pending && prev_pending[PENDING_CAPACITY] != 0) ||
                                (prev2_pending && prev2_pending[PENDING_CAPACITY] != 0);
@@ -670,13 +687,13 @@ __global__ __launch_bounds__(256) void resolve_kernel(MapView M, WorkItem *__res
     }
 }
 
-__global__ __launch_bounds__(256) void order_kernel(const WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
+__global__ __launch_bounds__(RESOLVE_BLOCK) void order_kernel(const WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
                                                      int max_cands, WorkItem *__restrict__ items, ItemSync *sync) {
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * RESOLVE_BLOCK + threadIdx.x;
     int n = counts_in[COUNT_CANDS];
     if (n > max_cands) n = max_cands;
-    if ((int)(blockIdx.x * 256) >= n && blockIdx.x != 0) return;
+    if ((int)(blockIdx.x * RESOLVE_BLOCK) >= n && blockIdx.x != 0) return;
     int start[8];
     int total = 0;
 #pragma unroll
