@@ -403,22 +403,32 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const CullSpace cspace(CP);
         static_assert(CULL_BLOCK * CULL_BLOCK * CULL_BLOCK == 64, "one wave per block of ids");
         const dim3 cgrid = cspace.sharded ? dim3((total + 63) / 64) : dim3(cspace.nsb[2], cspace.nsb[1], cspace.nsb[0]);
-#define CHISEL_LAUNCH_CULL(KLV, INL, OUT)                                                                                        \
-    hipLaunchKernelGGL((cull_kernel<N, KLV, INL>), cgrid, dim3(64 * KLV), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count,      \
+        // frames that look at different parts of the space (several agents in one launch): four waves per workgroup (kernels_cull.h)
+        bool narrow_cull = false;
+        {
+            double vmax = 0.0;
+            for (int k2 = 0; k2 < CP.n_frames; k2++) vmax = std::max(vmax, (double)CP.f[k2].range_dim[0] * CP.f[k2].range_dim[1] * CP.f[k2].range_dim[2]);
+            narrow_cull = m->cfg.n_shards <= 2 && (double)CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2] > 1.5 * vmax;  // (a shard's cull is an n-th of it: no gain measured at 8)
+            if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) narrow_cull = atoi(e) == 4;  // test hook: 4 / 16
+        }
+#define CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, WV)                                                                                   \
+    hipLaunchKernelGGL((cull_kernel<N, KLV, INL, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count, \
                        m->items_capacity, m->view, bs.pending, bs.sync)
+#define CHISEL_LAUNCH_CULL(KLV, INL, OUT) do { if (narrow_cull) CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 4); else CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 16); } while (0)
         if (inline_resolve) {
-            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL(1, true, bs.items);
-            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL(2, true, bs.items);
-            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL(4, true, bs.items);
+            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, true, bs.items, 16);
+            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL_W(2, true, bs.items, 16);
+            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL_W(4, true, bs.items, 16);
             else if (IP.n_frames <= 8) CHISEL_LAUNCH_CULL(8, true, bs.items);
             else CHISEL_LAUNCH_CULL(16, true, bs.items);
         } else {
-            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL(1, false, bs.cands);
-            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL(2, false, bs.cands);
-            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL(4, false, bs.cands);
+            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, false, bs.cands, 16);
+            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL_W(2, false, bs.cands, 16);
+            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL_W(4, false, bs.cands, 16);
             else if (IP.n_frames <= 8) CHISEL_LAUNCH_CULL(8, false, bs.cands);
             else CHISEL_LAUNCH_CULL(16, false, bs.cands);
         }
+#undef CHISEL_LAUNCH_CULL_W
 #undef CHISEL_LAUNCH_CULL
     }
     if (!inline_resolve) {

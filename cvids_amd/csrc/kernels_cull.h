@@ -465,14 +465,26 @@ struct CullSpace {
 // INLINE (the map is idle: nothing to run beside, the caller is waiting): the k == 0 wave also does resolve_kernel's job
 // for its survivors -- hash lookup, frame mask, compaction straight into the work-list -- and one launch set is three
 // kernels on one stream instead of five on two.
-template <int N, int KL, bool INLINE>
-__global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *counts,
+// WV = waves per workgroup at most; a launch of more frames gives each wave several (k, k + WV, ...).  One wave per frame (WV = 16) is
+// the shortest chain -- and a workgroup of sixteen waves, which needs sixteen free slots on ONE CU: beside an integration kernel whose
+// single-wave workgroups take every slot as it frees up it can wait for hundreds of microseconds (4 agents: every second batch of
+// the stream stood still for 85 us behind such a cull kernel, rocprofv3 timeline).  Four waves find room in what a 6-waves-per-SIMD
+// integration kernel leaves free.  The host picks 4 for launches whose frames look at different parts of the space (their common id
+// range is much larger than any frame's own: most (block, frame) pairs die in the range test anyway), 16 otherwise.
+template <int KL, int WV>
+struct CullGeom {
+    static constexpr int WAVES = KL < WV ? KL : WV;
+    static constexpr int FPW = KL / WAVES;  // frames per wave
+};
+template <int N, int KL, bool INLINE, int WV>
+__global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *counts,
                                                         int max_cands, MapView M, uint64_t *my_pending, ItemSync *sync) {
+    constexpr int WAVES = CullGeom<KL, WV>::WAVES, FPW = CullGeom<KL, WV>::FPW;
     int *cand_count = counts + (INLINE ? COUNT_ITEMS : COUNT_CANDS);
     __shared__ int s_flags[KL][64];
     __shared__ int s_pos[64];
     const int lane = threadIdx.x & 63;
-    const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave's frame
+    const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // this wave: frames k, k + WAVES, ...
     int cx = 0, cy = 0, cz = 0;
     bool have_id;
     if (P.ip.n_shards > 1) {
@@ -485,31 +497,38 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
         cx = P.range_min[0] + ix; cy = P.range_min[1] + iy; cz = P.range_min[2] + iz;
         have_id = ix < P.range_dim[0] && iy < P.range_dim[1] && iz < P.range_dim[2];
     }
-    FrameBox fb;
-    fb.flags = 0;
-    int fl = 0;
-    CullPre pre;
-    bool alive = false;
-    if (have_id) {
-        if (k < P.n_frames && chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank)
-            alive = cull_pre<N>(P.ip, P.f[k], cx, cy, cz, pre);
+    const bool mine = have_id && chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank;
+    FrameBox fbs[FPW];
+    int fls[FPW];
+    bool any_flag = false;
+#pragma unroll
+    for (int j = 0; j < FPW; j++) {
+        const int kf = k + j * WAVES;
+        FrameBox &fb = fbs[j];
+        fb.flags = 0;
+        int fl = 0;
+        CullPre pre;
+        bool alive = false;
+        if (mine && kf < P.n_frames) alive = cull_pre<N>(P.ip, P.f[kf], cx, cy, cz, pre);
+        if (__any(alive)) {  // wave-uniform: most (wave, frame) pairs stop here
+            // the extrema of the whole image (a wave-wide reduction of the coarsest pyramid level) only where a box is wider than three
+            // of its texels: chunks next to the camera
+            float2 whole = make_float2(INFINITY, -INFINITY);
+            if (__any(alive && box_needs_whole_image(pre.su0, pre.sv0, pre.su1, pre.sv1))) whole = whole_image_minmax(pyr, pyr.data + (size_t)kf * P.pyr_stride);
+            if (alive) fl = cull_post<N>(P.ip, P.f[kf], pyr, pyr.data + (size_t)kf * P.pyr_stride, whole, cx, cy, cz, pre, fb);
+        }
+        fb.flags = fl;
+        fls[j] = fl;
+        s_flags[kf][lane] = fl;
+        any_flag = any_flag || fl != 0;
     }
-    if (__any(alive)) {  // wave-uniform: most waves stop here
-        // the extrema of the whole image (a wave-wide reduction of the coarsest pyramid level) only where a box is wider than three
-        // of its texels: chunks next to the camera
-        float2 whole = make_float2(INFINITY, -INFINITY);
-        if (__any(alive && box_needs_whole_image(pre.su0, pre.sv0, pre.su1, pre.sv1))) whole = whole_image_minmax(pyr, pyr.data + (size_t)k * P.pyr_stride);
-        if (alive) fl = cull_post<N>(P.ip, P.f[k], pyr, pyr.data + (size_t)k * P.pyr_stride, whole, cx, cy, cz, pre, fb);
-    }
-    fb.flags = fl;
-    s_flags[k][lane] = fl;
 #if CULL_EARLY_EXIT
-    // A wave none of whose 64 chunks the frame can touch is done: its flags are in LDS, it owns no row of `boxes` (the integration
-    // kernel reads a box only for the frames of an item's mask), and wave 0 does the merge.  Leaving NOW instead of sitting through the
-    // two barriers below gives its slot back while the block's live waves -- with agents looking in different directions a quarter of
-    // them -- are still in cull_post (a barrier waits for the surviving waves of a workgroup only; a terminated wave's LDS write has
-    // retired).
-    if (k != 0 && !__any(fl != 0)) {
+    // A wave none of whose frames can touch any of its 64 chunks is done: its flags are in LDS, it owns no row of `boxes` (the
+    // integration kernel reads a box only for the frames of an item's mask), and wave 0 does the merge.  Leaving NOW instead of sitting
+    // through the two barriers below gives its slot back while the block's live waves -- with agents looking in different directions a
+    // quarter of them -- are still in cull_post (a barrier waits for the surviving waves of a workgroup only; a terminated wave's LDS
+    // write has retired).
+    if (k != 0 && !__any(any_flag)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         return;
     }
@@ -579,14 +598,19 @@ __global__ __launch_bounds__(64 * KL) void cull_kernel(CullParams P, PyramidView
     }
     __syncthreads();
     const int pos = s_pos[lane];
-    if (pos >= 0 && k < P.n_frames) {
-        if (fl == 0) {  // frames that cannot touch the chunk: a well-defined empty box
-            fb.u0 = fb.v0 = fb.u1 = fb.v1 = 0;
-            fb.magic = 0;
-            fb.z_near = fb.z_far = fb.z_carve = 0.0f;
-            fb.pad = 0;
+#pragma unroll
+    for (int j = 0; j < FPW; j++) {
+        const int kf = k + j * WAVES;
+        if (pos >= 0 && kf < P.n_frames) {
+            FrameBox fb = fbs[j];
+            if (fls[j] == 0) {  // frames that cannot touch the chunk: a well-defined empty box
+                fb.u0 = fb.v0 = fb.u1 = fb.v1 = 0;
+                fb.magic = 0;
+                fb.z_near = fb.z_far = fb.z_carve = 0.0f;
+                fb.pad = 0;
+            }
+            boxes[(size_t)pos * P.n_frames + kf] = fb;
         }
-        boxes[(size_t)pos * P.n_frames + k] = fb;
     }
 }
 
