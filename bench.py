@@ -34,6 +34,7 @@ stream during instrumented passes over the same frames from the same initial map
 16 threads as the reference hard-codes) on a bounded sample of the same frames.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -225,9 +226,10 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # (a collective that does not complete aborts the run after three minutes instead of the default ten)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(args.dist_backend)
+            dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(seconds=180))
 
     if args.mesh_every is None:
         args.mesh_every = 10  # the reference's keyframe cadence (Chisel.cpp:54), at every N
