@@ -277,7 +277,7 @@ class ShardedChisel:
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return 0
         torch, dist, world, rank, dev = self.x.torch, self.x.dist, self.x.world, self.x.rank, self.x.device
-        if world == 1:
+        if world == 1 and not getattr(self, "force_collectives", False):  # (force_collectives: tools/nccl_world1_check.py runs the N > 1 code on one rank)
             if ids is None:
                 self.map.UpdateMeshes(force=True)
             else:

@@ -51,3 +51,19 @@ def test_a_hung_rank_is_killed_and_reported():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--launch-timeout", "1",
                           "--steps", "20", "--warmup", "5"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=90)
     assert out.returncode == 124 and "killing it" in out.stderr
+
+
+def test_rccl_code_path_with_one_rank():
+    """tools/nccl_world1_check.py: the collectives of the N > 1 path over backend "nccl" (= RCCL) with a world of one rank -- the frame
+    all-gather on its own stream ordered by events, and the sharded mesher's all_gather_into_tensor / all_to_all_single sequence with
+    empty payloads -- give the map and the meshes of the direct calls.  (Two ranks need two GPUs: RCCL refuses to share a device.)"""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1_check.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "nccl world-1 check ok" in out.stdout and "sharded mesher over nccl, one rank" in out.stdout

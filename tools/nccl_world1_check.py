@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """RCCL code path of the N > 1 bench on ONE GPU (world size 1): FrameExchange over backend "nccl" on its own stream,
-ordered against the map with events (PipelinedExchange), checked against direct integration of the same frames.
+ordered against the map with events (PipelinedExchange), checked against direct integration of the same frames; then the sharded
+mesher's exchange (ShardedChisel.UpdateMeshes: all_gather_into_tensor of the dirty ids, all_to_all_single of the -- here empty --
+shell payloads, event ordering both ways) against the plain recompute.
     python3 tools/nccl_world1_check.py        (inside gpurun)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +12,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np, torch, torch.distributed as dist
 from cvids_amd import synth
 from cvids_amd.chisel import Chisel, ConstantWeighter, InverseTruncator, PinholeCamera, ProjectionIntegrator
-from cvids_amd.sharded import FrameExchange, PipelinedExchange, pack_meta
+from cvids_amd.sharded import FrameExchange, PipelinedExchange, ShardedChisel, pack_meta
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -42,6 +44,24 @@ got = m.fields()
 assert set(got) == set(want) and len(got) > 50, (len(got), len(want))
 for cid in want:
     assert np.array_equal(want[cid][0].view(np.uint32), got[cid][0].view(np.uint32)) and np.array_equal(want[cid][1].view(np.uint32), got[cid][1].view(np.uint32)), cid
+# the sharded mesher's collectives with one rank: every chunk is a job of rank 0, no ghost is needed, the payloads are empty
+xch.world = 1
+sh = ShardedChisel(m, xch, integ)
+sh.force_collectives = True
+for mm in (ref, m):
+    assert len(mm.GetMeshesToUpdate()) > 50
+moved = sh.UpdateMeshes(force=True)
+ref.UpdateMeshes(force=True)
+assert moved == 0 and len(m.GetMeshesToUpdate()) == 0
+ids_a, ids_b = sorted(map(tuple, ref.GetMeshIDs().tolist())), sorted(map(tuple, m.GetMeshIDs().tolist()))
+assert ids_a == ids_b and len(ids_a) > 20, (len(ids_a), len(ids_b))
+nv = 0
+for cid in ids_a:
+    a, b = ref.GetMesh(cid), m.GetMesh(cid)
+    for key in ("vertices", "normals", "grids"):
+        assert np.array_equal(np.asarray(a[key]).view(np.uint32), np.asarray(b[key]).view(np.uint32)), (cid, key)
+    nv += len(a["vertices"])
+print("sharded mesher over nccl, one rank: %d meshes, %d vertices identical" % (len(ids_a), nv))
 t = torch.tensor([1.0], device=dev)
 dist.all_reduce(t)
 dist.barrier()
