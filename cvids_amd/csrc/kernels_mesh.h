@@ -427,7 +427,9 @@ __device__ inline void block_scan2(int a, int b, int &oa, int &ob, int &ta, int 
 
 constexpr int MESH_BLOCK = MESH_BLOCK_THREADS;
 #ifndef MESH_COUNT_WAVES
-#define MESH_COUNT_WAVES 6  // waves per SIMD the count kernel leaves room for: three 512-thread workgroups per CU (<= 80 registers; 64 spill)
+#define MESH_COUNT_WAVES 5  // waves per SIMD the count kernel is compiled for: up to 96 registers, two 512-thread workgroups per CU.  (6 -- 80 registers,
+                            // three workgroups per CU -- spills 32 bytes per lane and is slower although a third more jobs are resident: 22.5 against
+                            // 21.4 us per recompute on the default window, 33.8 against 29.3 us on the driver's; 4 -- 128 registers -- 21.9 / 30.1)
 #endif
 constexpr int MESH_TRI_BLOCK = 256;  // per-triangle kernel
 
@@ -531,7 +533,10 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
         // Classification with neighbouring lanes on neighbouring cubes (rank k * MESH_BLOCK + thread: consecutive corners, no LDS
         // bank conflicts -- with a thread's own CPT consecutive cubes the lanes sit 8 corners apart, an 8-way conflict on every one
         // of the 64 corner reads); the case bytes go through LDS to the thread that owns the cube in the traversal order.
-#pragma unroll 2  // (two cubes' sixteen corner reads in flight; all of them at once would cost a workgroup per CU in registers)
+#ifndef MESH_CLASSIFY_UNROLL
+#define MESH_CLASSIFY_UNROLL 2
+#endif
+#pragma unroll MESH_CLASSIFY_UNROLL  // (two cubes' sixteen corner reads in flight; all of them at once would cost a workgroup per CU in registers)
         for (int k = 0; k < CPT; k++) {
             const int r = k * MESH_BLOCK + (int)threadIdx.x;
             if (r < V) {
