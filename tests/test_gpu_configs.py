@@ -109,14 +109,16 @@ def test_config3_full_size_voxels_and_meshes(oracle_mod):
 
 
 # ---- config 4: four agents, eight shards ---------------------------------------------------------------------------------
-def test_config4_four_agents_eight_shards_on_one_gpu(monkeypatch):
+@pytest.mark.parametrize("n_shards", [8, 2])
+def test_config4_four_agents_eight_shards_on_one_gpu(monkeypatch, n_shards):
     """4-agent 640x480 depth + colour streams (global order a0f0, a1f0, a2f0, a3f0, a0f1, ...), 1 cm voxels, through EIGHT
     n_shards maps on one GPU: the union of the shards is the unsharded map bit for bit, the shards are disjoint and own what
     chunk_owner() says, and neither the launch-set size nor the schedule (two-stream pipeline / conservative look-up mode)
-    changes a bit."""
+    changes a bit.  With TWO shards the cull kernel takes its four-waves-per-workgroup shape for these launches (frames looking in
+    four directions), over the sharded id enumeration."""
     import torch
     from cvids_amd import chisel as ch
-    W, H, N, res, n_shards = 640, 480, 16, 0.01, 8
+    W, H, N, res = 640, 480, 16, 0.01
     intr = synth.intrinsics(W, H)
     cam = ch.PinholeCamera(*intr, W, H, 0.05, 5.0)
     integ = ch.ProjectionIntegrator(ch.InverseTruncator(1.0), ch.ConstantWeighter(1.0), 0.05, True)
