@@ -70,7 +70,8 @@ struct MapView {
     uint64_t hash_mask;      // capacity - 1 (power of two)
     uint64_t *slot_key;
     uint32_t *slot_dirty;    // [max_chunks] "updated since the last mesh recompute"; behind them [max_chunks] the slots whose flag went 0 -> 1
-                             // since the flags were last cleared, in order of appearance, and [2 * max_chunks] their number (mark_slot_dirty)
+                             // since the flags were last cleared, in order of appearance, and [2 * max_chunks] their number (mark_slot_dirty);
+                             // from [2 * max_chunks + 16] on [max_chunks] sign summaries (slot_summary)
     int *free_list;
     int *free_top;
     unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS (filled by reduce_counters_kernel)
@@ -78,6 +79,15 @@ struct MapView {
     int *error_flag;         // two words in pinned host memory, see raise_error
     int max_chunks;
 };
+
+// Per slot, behind the dirty list: which signs the OBSERVED voxels (weight > 0.5: what a marching cube asks of a corner,
+// ChunkManager.cpp:271 / :352) a chunk has ever held can have -- SUM_POS: some voxel with sdf >= 0, SUM_NEG: some with sdf < 0.  Sticky (a
+// carved voxel leaves its bit behind: the summary may say more than is there, never less); every writer of voxels ORs into it, freeing a
+// slot clears it.  The mesher skips a chunk that holds no observed voxel (corner 0 of every cube is the chunk's own voxel) or whose
+// cubes -- the chunk and its seven "+" neighbours -- cannot see both signs.
+constexpr unsigned SUM_POS = 1u, SUM_NEG = 2u, SUM_ANY = 3u;
+constexpr size_t SLOT_SUMMARY_PAD = 16;
+__device__ inline uint32_t *slot_summary(const MapView &M) { return M.slot_dirty + 2 * (size_t)M.max_chunks + SLOT_SUMMARY_PAD; }
 
 // A chunk was updated (Chisel.h:85 / :167 needsUpdate -> meshesToUpdate, Chisel.h:175-189): its flag, and -- for the mesher, which must
 // not have to scan a pool of millions of slots for a few hundred dirty ones -- its slot into the list of dirty slots, once.
@@ -196,6 +206,16 @@ struct FrameBox {            // one per (work item, frame)
     // conservative camera-z bounds from the depth range under the box: a voxel can be in band only if
     // z_near < z < z_far and can take the carve test only if z < z_carve (-inf when carving is off)
     float z_near, z_far, z_carve;
+    int pad;
+};
+// What a unit (wave) of the integration kernel needs to know about one (work item, frame) pair, in work-list order (written by
+// refine_kernel, kernels_cull.h): which of the chunk's 4 x 4 x 4 CELLS (N/4 voxels on a side; bit (cz * 4 + cy) * 4 + cx) hold a voxel that
+// the frame may integrate or carve-test -- the cull kernel's conservative test repeated at cell scale, where the depth range under
+// the (much smaller) pixel box is tight -- and the cull kernel's flags for the chunk.  A unit visits a frame only if one of its own
+// cells is set, and a lane fetches a pixel record only if its own cell is.
+struct alignas(16) CellRec {
+    unsigned long long need;
+    int flags;
     int pad;
 };
 constexpr int WI_INBAND = 1;   // some voxel may take the in-band branch

@@ -161,6 +161,7 @@ struct chisel_hip_map {
         int *cand_count = nullptr;       // [COUNT_INTS] device counters of the batch (COUNT_* in kernels_cull.h)
         WorkItem *items = nullptr;       // [items_capacity]: the work-list
         ItemSync *sync = nullptr;        // [items_capacity]: chunk-level state of the work items while the integration kernel runs
+        CellRec *cells = nullptr;        // [items_capacity][KMAX]: per (work item, frame) the cells the frame can touch + the cull flags (refine_kernel)
         uint64_t *pending = nullptr;     // chunks this batch may create: one of pending_ring (assigned per batch)
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
         hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's work-list (and with it its pending set) is complete
@@ -174,6 +175,7 @@ struct chisel_hip_map {
     hipEvent_t input_event = nullptr;    // chisel_hip_wait_event: the next batch's frames are ready behind this (caller's) event
     bool force_pipeline = false;         // test hook (CHISEL_HIP_FORCE_PIPELINE at creation): the front half always runs on the auxiliary stream
     bool mesh_tiny = false;              // test hook (CHISEL_HIP_MESH_TINY at creation): triangle list and arena start far too small, so every recompute takes the grow-and-emit-again paths
+    bool refine_off = false;             // test / A-B hook (CHISEL_HIP_REFINE=0 at creation): every cell of every frame of an item's mask counts as needed
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % 3] and pending_ring[b % 4]
     unsigned recomputes = 0, recomputes_seen = 0;  // mesh recomputes issued / as of the previous batch (front-stream choice)
@@ -454,6 +456,16 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         if (!direct)
             hipLaunchKernelGGL(order_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
     }
+    {
+        // per (work item, frame): which cells of the chunk the frame can touch (the cull test again at cell scale, kernels_cull.h).
+        // A persistent grid over the (item, frame) pairs: their number is only known on the device.
+        ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
+        const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
+        const long long pairs = (long long)(items_hint > 0 ? items_hint + items_hint / 4 + 16 : 1024) * IP.n_frames;
+        const int rgrid = (int)std::max<long long>(64, std::min<long long>(4096, (pairs + 3) / 4));
+        hipLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(256), 0, front, IP, pyr, m->pyr_stride, bs.items, bs.boxes, bs.cand_count + COUNT_ITEMS,
+                           m->items_capacity, bs.cells, m->refine_off ? 1 : 0);
+    }
     HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     }
     g_host_timer.lap(4);
@@ -524,7 +536,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
 #define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
     hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
-                       bs.boxes, bs.sync, wc, queues, m->items_capacity, split)
+                       bs.cells, bs.sync, wc, queues, m->items_capacity, split)
         if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
             if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);
             else CHISEL_LAUNCH_INTEGRATE(true, true, 4);
@@ -742,6 +754,8 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
             if (b2.boxes) HIP_TRY(hipFree(b2.boxes));
             if (b2.items) HIP_TRY(hipFree(b2.items));
             if (b2.sync) HIP_TRY(hipFree(b2.sync));
+            if (b2.cells) HIP_TRY(hipFree(b2.cells));
+            b2.cells = nullptr;
             b2.cands = nullptr;
             b2.boxes = nullptr;
             b2.items = nullptr;
@@ -750,6 +764,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
             HIP_TRY(hipMalloc(&b2.items, (size_t)cap * sizeof(WorkItem)));
             HIP_TRY(hipMalloc(&b2.sync, (size_t)cap * sizeof(ItemSync)));
             HIP_TRY(hipMalloc(&b2.boxes, (size_t)cap * KMAX * sizeof(FrameBox)));
+            HIP_TRY(hipMalloc(&b2.cells, (size_t)cap * KMAX * sizeof(CellRec)));
         }
         m->items_capacity = cap;
     }
@@ -976,6 +991,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipEventCreateWithFlags(&m->mutation_event, hipEventDisableTiming));
     m->mesh_tiny = getenv("CHISEL_HIP_MESH_TINY") != nullptr;
     m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
+    if (const char *e = getenv("CHISEL_HIP_REFINE")) m->refine_off = atoi(e) == 0;
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
         const int one = 1;
@@ -990,7 +1006,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.hash_keys, hc * sizeof(uint64_t)));
     HIP_TRY_C(hipMalloc(&v.hash_vals, hc * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.slot_key, (size_t)C * sizeof(uint64_t)));
-    HIP_TRY_C(hipMalloc(&v.slot_dirty, (2 * (size_t)C + 4) * sizeof(uint32_t)));  // flags, list of dirty slots, its length
+    HIP_TRY_C(hipMalloc(&v.slot_dirty, (3 * (size_t)C + SLOT_SUMMARY_PAD) * sizeof(uint32_t)));  // flags, list of dirty slots, its length; sign summaries
     HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.counters, 32 * sizeof(unsigned long long)));
@@ -1002,7 +1018,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
     HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));
     HIP_TRY_C(hipMemcpyAsync(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
+    hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V, 1);
     HIP_TRY_C(hipGetLastError());
     HIP_TRY_C(hipStreamSynchronize(m->stream));
 #undef HIP_TRY_C
@@ -1025,7 +1041,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
-        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.sync};
+        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.sync, bs.cells};
         for (void *p : bp)
             if (p) (void)hipFree(p);
         if (bs.front_done) (void)hipEventDestroy(bs.front_done);
@@ -1060,7 +1076,7 @@ int chisel_hip_reset(chisel_hip_map *m) {
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
     m->topology_epoch++;
-    hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V);
+    hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(note_map_mutation(m));
     clear_meshes(m);
@@ -1867,7 +1883,6 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
         return fail(CHISEL_HIP_ERR_INVALID, "chunk belongs to another shard");
     HIP_TRY(hipSetDevice(m->device));
     m->topology_epoch++;
-    m->topology_epoch++;
     int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
     if (rc) return rc;
     rc = ensure_scratch(m, 16);
@@ -1878,6 +1893,10 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
     HIP_TRY(hipStreamSynchronize(m->stream));
     if (slot < 0) return check_device_error(m) ? CHISEL_HIP_ERR_POOL_FULL : fail(CHISEL_HIP_ERR_POOL_FULL, "no slot");
     const size_t off = (size_t)slot * m->V;
+    {
+        const uint32_t any = SUM_ANY;  // (voxels from outside: the mesher looks at the chunk)
+        HIP_TRY(hipMemcpy(m->view.slot_dirty + 2 * (size_t)m->view.max_chunks + SLOT_SUMMARY_PAD + slot, &any, sizeof(any), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(m->view.sdf + off, sdf, (size_t)m->V * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->view.wgt + off, weight, (size_t)m->V * sizeof(float), hipMemcpyHostToDevice));
     if (m->view.rgbw) {

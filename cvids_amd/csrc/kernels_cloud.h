@@ -722,6 +722,7 @@ __global__ __launch_bounds__(64 * CloudGeom<N>::WAVES) void cloud_integrate_kern
         __syncthreads();
         if (tid == 0 && s_upd != 0u && slot >= 0) {
             mark_slot_dirty(M, slot);  // Chisel.cpp:135-147 (27 neighbours: expanded by the mesher)
+            slot_summary(M)[slot] = SUM_ANY;  // (this path does not classify what it writes: the mesher looks at the chunk)
             n_updated++;
         }
     }

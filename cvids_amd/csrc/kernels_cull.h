@@ -158,13 +158,15 @@ __device__ inline void truncation_range(int kind, float param, float d0, float d
 
 // min / max of the valid depth over pixel box (u0, v0) .. (u1, v1): the finest pyramid level that covers the box with
 // at most 3 x 3 texels, read as nine unconditional (clamped, possibly repeated) loads so that they are in flight together
+// (T = texels per side, 3 for the chunks of the cull kernel; the cells of refine_kernel take 4: a finer level, a tighter range)
+template <int T = 3>
 __device__ inline void pyramid_minmax(const PyramidView &pyr, const float2 *__restrict__ pdata, float2 whole, int u0, int v0, int u1,
                                       int v1, float &dmin, float &dmax) {
     int l = PYR_LEVELS - 1;
 #pragma unroll
     for (int k = PYR_LEVELS - 2; k >= 0; k--) {
         const int s = PYR_L0 + k;
-        if (((u1 >> s) - (u0 >> s)) <= 2 && ((v1 >> s) - (v0 >> s)) <= 2) l = k;
+        if (((u1 >> s) - (u0 >> s)) <= T - 1 && ((v1 >> s) - (v0 >> s)) <= T - 1) l = k;
     }
     const int s = PYR_L0 + l;
     const float2 *lvl = pdata + pyr.off[l];
@@ -172,16 +174,16 @@ __device__ inline void pyramid_minmax(const PyramidView &pyr, const float2 *__re
     const int tx0 = u0 >> s, ty0 = v0 >> s, tx1 = u1 >> s, ty1 = v1 >> s;
     dmin = INFINITY;
     dmax = -INFINITY;
-    if (tx1 - tx0 <= 2 && ty1 - ty0 <= 2) {
-        float2 t[9];
+    if (tx1 - tx0 <= T - 1 && ty1 - ty0 <= T - 1) {
+        float2 t[T * T];
 #pragma unroll
-        for (int i = 0; i < 9; i++) t[i] = lvl[min(ty0 + i / 3, ty1) * lw + min(tx0 + i % 3, tx1)];
+        for (int i = 0; i < T * T; i++) t[i] = lvl[min(ty0 + i / T, ty1) * lw + min(tx0 + i % T, tx1)];
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
+        for (int i = 0; i < T * T; i++) {
             dmin = fminf(dmin, t[i].x);
             dmax = fmaxf(dmax, t[i].y);
         }
-    } else {  // box wider than 3 texels of the coarsest level (near-camera chunks): the extrema of the whole image
+    } else {  // box wider than T texels of the coarsest level (near-camera chunks): the extrema of the whole image
         dmin = whole.x;
         dmax = whole.y;
     }
@@ -216,12 +218,18 @@ struct CullPre {
     int su0, sv0, su1, sv1;   // pixel box under the bounding sphere (the whole image when the sphere reaches behind the camera)
     float zs0, zs1, slack;    // camera-z interval of the sphere, rounding slack
 };
+// the geometric part for the axis-aligned box of N^3 voxels with index (cx, cy, cz) in units of N voxels: a chunk, or (refine_kernel) a cell
+template <int N>
+__device__ inline bool box_pre(const IntegratorParams &ip, const CameraParams &C, int cx, int cy, int cz, CullPre &pre);
 template <int N>
 __device__ inline bool cull_pre(const IntegratorParams &ip, const CullFrame &F, int cx, int cy, int cz, CullPre &pre) {
     if ((unsigned)(cx - F.range_min[0]) >= (unsigned)F.range_dim[0] || (unsigned)(cy - F.range_min[1]) >= (unsigned)F.range_dim[1] ||
         (unsigned)(cz - F.range_min[2]) >= (unsigned)F.range_dim[2])
         return false;
-    const CameraParams &C = F.cam;
+    return box_pre<N>(ip, F.cam, cx, cy, cz, pre);
+}
+template <int N>
+__device__ inline bool box_pre(const IntegratorParams &ip, const CameraParams &C, int cx, int cy, int cz, CullPre &pre) {
     const float bminx = (float)(cx * N) * ip.res, bminy = (float)(cy * N) * ip.res, bminz = (float)(cz * N) * ip.res;
     const float ext = (float)N * ip.res;
     const float hx = 0.5f * ext;
@@ -242,6 +250,40 @@ __device__ inline bool cull_pre(const IntegratorParams &ip, const CullFrame &F, 
         const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
         const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
         const float fu0 = floorf(ul) - 3.0f, fu1 = floorf(uh) + 3.0f, fv0 = floorf(vl) - 3.0f, fv1 = floorf(vh) + 3.0f;
+        if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1)) return false;  // off the image
+        pre.su0 = (int)fmaxf(fu0, 0.0f); pre.sv0 = (int)fmaxf(fv0, 0.0f);
+        pre.su1 = (int)fminf(fu1, (float)(C.W - 1)); pre.sv1 = (int)fminf(fv1, (float)(C.H - 1));
+    }
+    pre.zs0 = zs0; pre.zs1 = zs1; pre.slack = slack;
+    return true;
+}
+// The same for a CELL of refine_kernel: what has to be bounded are the CENTRES of its voxels -- a box of half-extent h = (E - 1) / 2 voxels
+// around the cell's centre -- and the box is bounded per camera axis (half-extent along camera axis i = h * sum_j |R_ji|: the exact
+// extent of the rotated box; `ar` = those three sums, wave-uniform) instead of by its bounding sphere: at 4 voxels per cell the sphere
+// around the whole cell is 3.5 voxels, this 1.5 to 2.6.
+template <int E>
+__device__ inline bool cell_pre(const IntegratorParams &ip, const CameraParams &C, const float (&ar)[3], int cx, int cy, int cz, CullPre &pre) {
+    const float h = 0.5f * (float)(E - 1) * ip.res;
+    // centre of the voxel centres: ((E c + (E - 1) / 2) + 0.5) res
+    const float wx = ((float)(cx * E) * ip.res + (h + ip.half_res)) - C.t[0], wy = ((float)(cy * E) * ip.res + (h + ip.half_res)) - C.t[1],
+                wz = ((float)(cz * E) * ip.res + (h + ip.half_res)) - C.t[2];
+    const float px = C.R[0] * wx + C.R[3] * wy + C.R[6] * wz;
+    const float py = C.R[1] * wx + C.R[4] * wy + C.R[7] * wz;
+    const float pz = C.R[2] * wx + C.R[5] * wy + C.R[8] * wz;
+    // rounding: the integration kernel builds its camera coordinates from products of magnitude <= |p| + h (a few ulp each), and the
+    // voxel centres themselves carry an ulp or two of (id * res): 1e-4 relative is three orders of magnitude more than that
+    const float slack = 1e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + 3.0f * h) + 1e-6f;
+    const float hx = h * ar[0] * 1.001f + slack, hy = h * ar[1] * 1.001f + slack, hz = h * ar[2] * 1.001f + slack;
+    const float zs1 = pz + hz;
+    if (zs1 < 0.0f) return false;  // every voxel has z < 0 (ProjectionIntegrator.h:68)
+    const float zs0 = pz - hz;
+    pre.su0 = 0; pre.sv0 = 0; pre.su1 = C.W - 1; pre.sv1 = C.H - 1;
+    if (zs0 > 0.25f * ip.res) {
+        const float i0 = __builtin_amdgcn_rcpf(zs0) * 1.00001f, i1 = __builtin_amdgcn_rcpf(zs1) * 0.99999f;
+        const float xl = px - hx, xh = px + hx, yl = py - hy, yh = py + hy;
+        const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
+        const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
+        const float fu0 = floorf(ul) - 2.0f, fu1 = floorf(uh) + 2.0f, fv0 = floorf(vl) - 2.0f, fv1 = floorf(vh) + 2.0f;
         if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1)) return false;  // off the image
         pre.su0 = (int)fmaxf(fu0, 0.0f); pre.sv0 = (int)fmaxf(fv0, 0.0f);
         pre.su1 = (int)fminf(fu1, (float)(C.W - 1)); pre.sv1 = (int)fminf(fv1, (float)(C.H - 1));
@@ -373,6 +415,79 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
     const bool inside = box_inside && fastz && (zmin >= 1e-5f * span * mag);
     return (inband ? WI_INBAND : 0) | (carve ? WI_CARVE : 0) | (tile ? WI_TILE : 0) | (fastz ? WI_FASTZ : 0) | (fastwu ? WI_FASTWU : 0) |
            (inside ? WI_INSIDE : 0);
+}
+
+// The cull kernel's depth test again, per CELL of a work item (4 x 4 x 4 cells of N/4 voxels on a side) -> CellRec, in work-list order.
+// The chunk-level test looks at the depth range under the whole chunk's pixel box (40-60 pixels wide at 1 cm / 2 m, fetched as
+// 3 x 3 texels of a pyramid level that covers more than that): its camera-z bounds let 40-45 % more voxel-frames into the integration
+// kernel than take the band or the carve branch.  A cell's box is a quarter of that on a side; the depth range under it is tight, and the
+// integration kernel's waves own whole cells (a unit = 8 x 8 x 4 or 4 x 8 x 4 voxels), so "does this frame touch my cells" is one AND.
+// One wave per (work item, frame of its mask), lane = cell.  A cell is needed by frame k if one of its voxels may integrate, or may take
+// the carve test while the chunk is resident: resident now, or (conservatively, as resolve_kernel has it) created by an earlier
+// frame of the launch; SLOT_LOOKUP items count as resident (the integration kernel drops what it must once it knows).
+// `full` (launches not worth refining, test hook): every cell of every frame of the mask.
+#ifndef REFINE_TEXELS
+#define REFINE_TEXELS 4
+#endif
+template <int N>
+__global__ __launch_bounds__(256) void refine_kernel(IntegrateParams P, PyramidView pyr, int pyr_stride,
+                                                     const WorkItem *__restrict__ items, const FrameBox *__restrict__ boxes, const int *__restrict__ work_count,
+                                                     int max_items, CellRec *__restrict__ cells, int full) {
+    constexpr int CELL = N / 4;
+    const IntegratorParams &ip = P.ip;
+    const int n_frames = P.n_frames;
+    const int lane = threadIdx.x & 63;
+    int n_items = *work_count;
+    if (n_items > max_items) n_items = max_items;
+    const int n_pairs = n_items * n_frames;
+    const int waves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    for (int p = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); p < n_pairs; p += waves) {
+        const int it = p / n_frames, k = p - it * n_frames;
+        const WorkItem wi = items[it];
+        const unsigned fmask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
+        CellRec out;
+        out.need = 0ull;
+        out.flags = 0;
+        out.pad = 0;
+        if ((fmask >> k) & 1u) {  // wave-uniform
+            const int row = __builtin_amdgcn_readfirstlane(wi.box);
+            const int flags = boxes[(size_t)row * n_frames + k].flags;
+            out.flags = __builtin_amdgcn_readfirstlane(flags);
+            if (full) {
+                out.need = ~0ull;
+            } else {
+                const int slot = __builtin_amdgcn_readfirstlane(wi.slot);
+                const unsigned inband_before = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.inband_mask) & ((1u << k) - 1u);
+                const bool resident = slot >= 0 || slot == SLOT_LOOKUP || inband_before != 0u;
+                const CameraParams &C = P.f[k].cam;
+                const float ar[3] = {fabsf(C.R[0]) + fabsf(C.R[3]) + fabsf(C.R[6]), fabsf(C.R[1]) + fabsf(C.R[4]) + fabsf(C.R[7]),
+                                     fabsf(C.R[2]) + fabsf(C.R[5]) + fabsf(C.R[8])};
+                const int cx = 4 * __builtin_amdgcn_readfirstlane(wi.x) + (lane & 3), cy = 4 * __builtin_amdgcn_readfirstlane(wi.y) + ((lane >> 2) & 3),
+                          cz = 4 * __builtin_amdgcn_readfirstlane(wi.z) + (lane >> 4);
+                CullPre pre;
+                bool need = false;
+                if (cell_pre<CELL>(ip, C, ar, cx, cy, cz, pre)) {
+                    if (box_needs_whole_image(pre.su0, pre.sv0, pre.su1, pre.sv1)) {
+                        need = true;  // (a cell next to the camera: not worth the reduction over the image)
+                    } else {
+                        float dmin, dmax;
+                        pyramid_minmax<REFINE_TEXELS>(pyr, pyr.data + (size_t)k * pyr_stride, make_float2(INFINITY, -INFINITY), pre.su0, pre.sv0, pre.su1, pre.sv1, dmin, dmax);
+                        if (dmin <= dmax) {
+                            float tmin, tmax;
+                            truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
+                            const float zlo = fmaxf(pre.zs0, 0.0f) - pre.slack;
+                            const float band = tmax + ip.diag;
+                            const bool inband = (dmin - band < pre.zs1) && (dmax + band > zlo);
+                            const bool carve = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
+                            need = inband || (carve && resident);
+                        }
+                    }
+                }
+                out.need = __ballot(need);
+            }
+        }
+        if (lane == 0) cells[(size_t)it * n_frames + k] = out;
+    }
 }
 
 __device__ inline bool pending_contains(const uint64_t *__restrict__ set, uint64_t key, uint64_t h) {

@@ -90,6 +90,15 @@ struct Geom {
     static constexpr int LAYER_QUADS = QX * N;       // quads per z-layer
     static constexpr int WPC = QUADS / 64;           // wave units per chunk at 4 voxels per lane: 2 (8^3), 16 (16^3), 128 (32^3)
     static_assert(QUADS % 64 == 0, "whole waves");
+    // A unit is a BRICK of 2 quads x 8 rows x 4 layers (8 x 8 x 4 voxels at 4 per lane, 4 x 8 x 4 at 2): compact in every direction, so
+    // that the band shell cuts few of them whatever the viewing direction (a z-layer of 16 x 16 x 1 is cut by every frame that looks
+    // along x or y), and a union of whole cells of the refine kernel's per-cell test (CellRec; cells are N/4 voxels on a side).
+    // Lanes 2i, 2i + 1 hold 2 * VPL * 4 contiguous bytes of one x-row per array.
+    static constexpr int BX = 2 * VPL, BY = 8, BZ = 4;
+    static constexpr int NBX = N / BX, NBY = N / BY, NBZ = N / BZ;
+    static_assert(NBX * NBY * NBZ == WPC && NBX >= 1 && NBY >= 1 && NBZ >= 1, "bricks tile the chunk");
+    static constexpr int CELL = N / 4;               // voxels per cell edge
+    static_assert(BZ <= 2 * CELL, "a brick's cells lie in one 32-bit half of the 64-bit cell mask");
     static constexpr int WPB = INTEGRATE_WPB;         // waves per workgroup
     static constexpr int BLOCK = 64 * WPB;
     static constexpr int GRID = 256 * INTEGRATE_BLOCKS_PER_CU * (4 / WPB);  // persistent grid: what is resident at once
@@ -207,7 +216,7 @@ template <int N, bool COLOR, bool SAMECAM, int VPL0>
 #endif
 __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 : INTEGRATE_WAVES)) INTEGRATE_SGPR_ATTR void integrate_kernel(IntegrateParams P, MapView M, const MapView *__restrict__ Mc,
                                                                           const WorkItem *__restrict__ items,
-                                                                          const FrameBox *__restrict__ boxes, ItemSync *sync,
+                                                                          const CellRec *__restrict__ cells, ItemSync *sync,
                                                                           const int *__restrict__ work_count, int *queues,
                                                                           int max_items, int split) {
     using G = Geom<N, VPL0>;   // the launch's own granularity: what the grid and the queue heads are laid out for
@@ -275,11 +284,31 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             using QuadF = QuadFT<VPL>;
             using QuadU = QuadUT<VPL>;
             const WorkItem wi = items[it];
+            // lane k: what frame k needs of this chunk (refine_kernel), requested together with the work item
+            CellRec cr;
+            cr.need = 0ull;
+            cr.flags = 0;
+            if (lane < P.n_frames) cr = cells[(size_t)it * P.n_frames + lane];
             const int cxi = __builtin_amdgcn_readfirstlane(wi.x), cyi = __builtin_amdgcn_readfirstlane(wi.y),
                       czi = __builtin_amdgcn_readfirstlane(wi.z);
             int slot = __builtin_amdgcn_readfirstlane(wi.slot);
             unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
-            const int box_row = __builtin_amdgcn_readfirstlane(wi.box);
+            // the brick of this unit, the lane's quad in it, and the cells they lie in: bit (cz * 4 + cy) * 4 + cx of a 64-bit mask, of
+            // which a brick occupies one 32-bit half (its layers span at most two cell layers cz, and those are 2j, 2j + 1)
+            const int bx = wq % G::NBX, by = (wq / G::NBX) % G::NBY, bz = wq / (G::NBX * G::NBY);  // wave-uniform
+            const int vx0 = bx * G::BX + (lane & 1) * VPL, vy = by * G::BY + ((lane >> 1) & 7), vz = bz * G::BZ + (lane >> 4);
+            const int cell_half = ((bz * G::BZ) / G::CELL) >> 1;  // wave-uniform
+            unsigned lane_cells;  // this lane's cells (one, or two when the quad straddles a cell boundary: 8^3 chunks at 4 voxels per lane)
+            {
+                const int crow = ((vz / G::CELL) * 4 + vy / G::CELL) * 4 - 32 * cell_half;
+                lane_cells = (1u << (crow + vx0 / G::CELL)) | (1u << (crow + (vx0 + VPL - 1) / G::CELL));
+            }
+            unsigned unit_cells = lane_cells;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) unit_cells |= (unsigned)__shfl_xor((int)unit_cells, o);
+            const unsigned need_half = cell_half ? (unsigned)(cr.need >> 32) : (unsigned)cr.need;  // lane k: frame k's cells of this brick's half
+            const unsigned unit_frames = (unsigned)__ballot((need_half & unit_cells) != 0u);  // frames that can touch this brick (lanes >= n_frames hold 0)
+            if (slot >= 0 && (mask & unit_frames) == 0u) return;  // a resident chunk, and no frame of the launch can touch this brick
             if (slot == SLOT_LOOKUP) {
                 // the previous batch may have created this chunk while the work-list was built: it has finished now
                 // (a sibling wave of THIS launch may have allocated it meanwhile -- its claim on the item precedes its hash entry,
@@ -297,21 +326,23 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                     mask &= ~((1u << __builtin_ctz(inband)) - 1u);
                 }
             }
-            if (mask == 0u) return;
+            if (mask == 0u) return;  // (the item's mask: every unit of the item takes this exit, or none)
             const bool existed = slot >= 0;  // memory of `slot` holds this chunk's voxels
             ItemSync *sy = sync + it;
+            // from here on the unit's own frames.  A unit of a chunk without a slot that has none still counts itself in below: the
+            // unit that arrives last settles the chunk's `probe` figure
+            mask &= unit_frames;
+            if (mask == 0u && existed) return;
 
             // voxelCenter = centroids[i] + origin (ChunkManager.cpp:61: Vec3(x,y,z)*res + half; ProjectionIntegrator.h:63),
             // origin = numVoxels * ID (int) * resolution (Chunk.cpp:43)
-            const int q = wq * 64 + lane;
             float wx[VPL], wy, wz;
             {
                 const float ox = (float)(N * cxi) * ip.res, oy = (float)(N * cyi) * ip.res, oz = (float)(N * czi) * ip.res;
-                const int xq = q % G::QX, y = (q / G::QX) % N, z = q / G::LAYER_QUADS;
-                wy = ((float)y * ip.res + ip.half_res) + oy;
-                wz = ((float)z * ip.res + ip.half_res) + oz;
+                wy = ((float)vy * ip.res + ip.half_res) + oy;
+                wz = ((float)vz * ip.res + ip.half_res) + oz;
 #pragma unroll
-                for (int j = 0; j < VPL; j++) wx[j] = ((float)(xq * VPL + j) * ip.res + ip.half_res) + ox;
+                for (int j = 0; j < VPL; j++) wx[j] = ((float)(vx0 + j) * ip.res + ip.half_res) + ox;
             }
             PHASE(0);
 #ifdef CHISEL_PHASES
@@ -337,28 +368,22 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             // voxel addresses as a wave-uniform base (the slot: scalar registers) plus a 32-bit lane offset (one vector register
             // instead of three 64-bit addresses)
             const size_t slot_base = (size_t)(existed ? slot : 0) * G::V;
-            const unsigned lane_off = (unsigned)(VPL * q);
+            const unsigned lane_off = (unsigned)((vz * N + vy) * N + vx0);
             unsigned bm = 0u, cm = 0u;  // frames in which this wave integrated / changed a voxel (wave-uniform)
             int carve_v = 0;            // lane k: this wave's carve tests of frame k (items without a slot)
 
-            // camera-z bounds from the cull kernel (conservative): a voxel can be in band only if z_near < z < z_far and can
-            // take the carve test only if z < z_carve.  The next frame's bounds are requested while this frame is applied.
-            const FrameBox *fbp = boxes + (size_t)box_row * P.n_frames;
-            int k = __builtin_ctz(mask);
-            mask &= mask - 1u;
-            FrameBox fb = fbp[k];
-            while (true) {
+            // Frames of the mask: each can touch one of this brick's cells (refine_kernel's conservative test).  A lane whose own cell
+            // it cannot touch reads the all-NaN record instead of a pixel and fails every test.
+            const int cr_flags = cr.flags;  // lane k: the cull kernel's flags of (chunk, frame k)
+            while (mask) {
+                const int k = __builtin_ctz(mask);
+                mask &= mask - 1u;
 #ifdef CHISEL_PHASES
                 const unsigned long long fr_t = __builtin_amdgcn_s_memrealtime();
                 ph_visit++;
 #endif
-                const int flags = __builtin_amdgcn_readfirstlane(fb.flags);
-                const float z_near = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_near)));
-                const float z_far = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_far)));
-                const float z_carve = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb.z_carve)));
-                const int k_next = mask ? __builtin_ctz(mask) : -1;
-                mask &= mask - 1u;
-                if (k_next >= 0) fb = fbp[k_next];
+                const int flags = __builtin_amdgcn_readlane(cr_flags, k);
+                const unsigned frame_cells = (unsigned)__builtin_amdgcn_readlane((int)need_half, k);
                 const FrameCam &F = P.f[k];
                 const CameraParams &C = F.cam;
                 // inCamera = R^T * (voxelCenter - t) (ProjectionIntegrator.h:64), row i of R^T summed as a0 + (a1 + a2)
@@ -370,13 +395,9 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                     dx[j] = wx[j] - C.t[0];
                     pcz[j] = C.R[2] * dx[j] + s2;
                 }
-                // z is monotone along the quad: wx[j] grows with j, and subtracting a constant, multiplying by a constant and adding a
-                // constant are each monotone (weakly, after rounding) -- the extrema sit at the end voxels
-                const float zlo = (VPL == 4 && !OPT_ENDZ) ? fminf(fminf(pcz[0], pcz[1]), fminf(pcz[VPL - 2], pcz[VPL - 1])) : fminf(pcz[0], pcz[VPL - 1]);
-                const float zhi = (VPL == 4 && !OPT_ENDZ) ? fmaxf(fmaxf(pcz[0], pcz[1]), fmaxf(pcz[VPL - 2], pcz[VPL - 1])) : fmaxf(pcz[0], pcz[VPL - 1]);
-                const bool may_band = (zhi > z_near) & (zlo < z_far);
-                const bool may_carve = zlo < z_carve;
-                const bool need = may_band | may_carve;
+                const bool need = (frame_cells & lane_cells) != 0u;
+                const bool may_band = need;
+                const bool may_carve = need && ip.carving;
                 // Branches below are wave-uniform (__any) and the lanes are predicated, so that the counters stay scalar.
                 // From here on a lane's verdicts live in vector registers -- bit masks over its four voxels, per-lane counters that
                 // are summed over the wave once, when the wave retires -- and branches are wave-uniform (__any): the scalar unit
@@ -618,8 +639,6 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
 #ifdef CHISEL_PHASES
                 if (__any(need)) { FSTAMP(4, f4(s4, 0)); ph_exec++; ph_exec_t += __builtin_amdgcn_s_memrealtime() - fr_t; }
 #endif
-                if (k_next < 0) break;
-                k = k_next;
             }
 
             PHASE(1);
@@ -658,6 +677,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                 PHASE(2);
                 if (slot < 0) return;  // never integrated here, or no slot left (error raised)
             }
+            unsigned signs = 0u;  // SUM_POS | SUM_NEG over the observed voxels this wave writes (wave-uniform)
             {
                 const size_t out_base = (size_t)slot * G::V;  // wave-uniform
                 if (st & DCHG) {
@@ -665,6 +685,14 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                     *reinterpret_cast<QuadF *>((M.wgt + out_base) + lane_off) = w4;
                 }
                 if (COLOR && (st & CCHG)) *reinterpret_cast<QuadU *>((M.rgbw + out_base) + lane_off) = c4;
+                bool pos = false, neg = false;
+#pragma unroll
+                for (int j = 0; j < VPL; j++) {
+                    const bool seen = (st & DCHG) && f4(w4, j) > 0.5f;
+                    neg = neg || (seen && f4(s4, j) < 0.0f);
+                    pos = pos || (seen && !(f4(s4, j) < 0.0f));
+                }
+                signs = (__any(pos) ? SUM_POS : 0u) | (__any(neg) ? SUM_NEG : 0u);
             }
             if (cm) {
                 // "needsUpdate" of the chunk per frame (Chisel.h:85 / :167): each frame counts once per chunk -- by the wave
@@ -673,6 +701,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                 if (lane == 0) {
                     old = atomicOr(&sy->changed, cm);
                     mark_slot_dirty(M, slot);
+                    if (signs) atomicOr(&slot_summary(M)[slot], signs);  // (a wave that wrote a voxel changed one: cm != 0)
                 }
                 old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
                 n_updated += (unsigned)__popc(cm & ~old);

@@ -21,25 +21,36 @@ __device__ inline void fill_default_chunk(const MapView &M, int slot, int V) {
     }
 }
 
-// Chisel::Reset / ChunkManager::Reset (Chisel.cpp:44-48, ChunkManager.cpp:176-180) and initial state:
-// empty hash, full free list, default voxels in every slot (the pool invariant of chisel_device.h)
-__global__ void reset_map_kernel(MapView M, int V) {
+// Chisel::Reset / ChunkManager::Reset (Chisel.cpp:44-48, ChunkManager.cpp:176-180) and the initial state: empty hash, full free list,
+// default voxels in every slot (the pool invariant of chisel_device.h).  A reset restores only the slots that hold a chunk -- free slots
+// hold default voxels already -- so its cost follows what is resident, not the size of the pool (all_slots = 0; 1 at creation, when
+// the pool's memory is fresh: 1.04 ms and 6.3 GB written per /Chisel/Reset before, for 48 MB of resident chunks).  Slots are dealt to
+// the workgroups in a stride (slot s belongs to workgroup s mod gridDim: the resident slots are the low-numbered ones, popped first),
+// 256 at a time: the keys of a batch are read together, the occupied slots of the batch are then restored by the whole workgroup.
+__global__ __launch_bounds__(256) void reset_map_kernel(MapView M, int V, int all_slots) {
+    __shared__ int s_list[256];
+    __shared__ int s_n;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = gid; i <= M.hash_mask; i += stride) M.hash_keys[i] = KEY_EMPTY;
     for (uint64_t i = gid; i < (uint64_t)M.max_chunks; i += stride) {
-        M.slot_key[i] = KEY_EMPTY;
         M.slot_dirty[i] = 0;
+        slot_summary(M)[i] = 0;
         M.free_list[i] = M.max_chunks - 1 - (int)i;  // slot 0 is popped first
     }
-    const uint64_t quads = (uint64_t)M.max_chunks * (uint64_t)(V / 4);
-    float4 *s4 = reinterpret_cast<float4 *>(M.sdf);
-    float4 *w4 = reinterpret_cast<float4 *>(M.wgt);
-    uint4 *c4 = reinterpret_cast<uint4 *>(M.rgbw);
-    for (uint64_t i = gid; i < quads; i += stride) {
-        s4[i] = make_float4(99999.0f, 99999.0f, 99999.0f, 99999.0f);
-        w4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (c4) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (long long base = 0; base < (long long)M.max_chunks; base += (long long)gridDim.x * 256) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const long long slot = base + (long long)threadIdx.x * gridDim.x + blockIdx.x;
+        if (slot < (long long)M.max_chunks) {
+            const bool used = all_slots || M.slot_key[slot] != KEY_EMPTY;
+            M.slot_key[slot] = KEY_EMPTY;
+            if (used) s_list[atomicAdd(&s_n, 1)] = (int)slot;
+        }
+        __syncthreads();
+        const int n = s_n;
+        for (int i = 0; i < n; i++) fill_default_chunk(M, s_list[i], V);
+        __syncthreads();
     }
     if (gid == 0) {
         M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // the list of dirty slots is empty
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(256) void remove_chunks_kernel(MapView M, const int
             if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) == key) {
                 M.slot_key[slot] = KEY_EMPTY;
                 M.slot_dirty[slot] = 0;
+                slot_summary(M)[slot] = 0;
                 s_slot = slot;
             }
         }
@@ -306,6 +318,7 @@ __global__ __launch_bounds__(256) void import_chunks_kernel(MapView M, const int
     const int slot = s_slot;
     if (slot < 0) return;
     const size_t dst = (size_t)slot * V, src = (size_t)j * V;
+    if (threadIdx.x == 0) slot_summary(M)[slot] = SUM_ANY;  // (voxels from outside: anything)
     for (int v = threadIdx.x; v < V; v += 256) {
         M.sdf[dst + v] = sdf[src + v];
         M.wgt[dst + v] = wgt[src + v];
@@ -391,6 +404,7 @@ __global__ __launch_bounds__(256) void import_shells_kernel(MapView M, const int
     const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
     const long long base = offs[j];
     const size_t dst = (size_t)slot * N * N * N;
+    if (threadIdx.x == 0) slot_summary(M)[slot] = SUM_ANY;  // (voxels from outside: anything)
     for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
         const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
         const size_t i = dst + (size_t)(z * N + y) * N + x;

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
                                                                  JobInfo *info, int *totals, TriRec *tris, CubeCorners *corners, int tri_capacity, unsigned *mesh_flag, int keep_dirty) {
     __shared__ int s_scan[MESH_BLOCK / 64][2];
     __shared__ int s_nb[27];
+    __shared__ unsigned s_sum[8];  // sign summaries of the chunk and its seven "+" neighbours (slot_summary)
     __shared__ int s_base[2];
     __shared__ float s_vox[CornerTile<N>::SIZE];
     __shared__ __attribute__((aligned(16))) unsigned char s_case[N * N * N];  // case index per cube, by traversal rank
@@ -506,9 +507,11 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
     const int jx = first ? jx0 : ids[3 * j], jy = first ? jy0 : ids[3 * j + 1], jz = first ? jz0 : ids[3 * j + 2];
     if (threadIdx.x < 27) {
         const int o = threadIdx.x;
-        const int slot = hash_find_quiescent(M, jx + o % 3 - 1, jy + (o / 3) % 3 - 1, jz + o / 9 - 1);
+        const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+        const int slot = hash_find_quiescent(M, jx + dx, jy + dy, jz + dz);
         s_nb[o] = slot;
         jobs[j].nb[o] = slot;
+        if (dx >= 0 && dy >= 0 && dz >= 0) s_sum[dx + 2 * dy + 4 * dz] = slot >= 0 ? slot_summary(M)[slot] : 0u;  // the chunks that hold cube corners
     } else if (threadIdx.x == 27) {
         jobs[j].x = jx;
         jobs[j].y = jy;
@@ -517,19 +520,28 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
     }
     __syncthreads();
     const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
+    // Can any cube of this chunk carry a triangle?  Corner 0 of every cube is a voxel of the chunk itself and must be observed
+    // (ChunkManager.cpp:271 / :352), and a case other than 0 / 255 needs both signs among the cube's corners, which lie in the chunk
+    // and its seven "+" neighbours.  About half of the jobs of a recompute -- chunks inside the band but away from the surface --
+    // stop here: no corners staged, nothing classified.
+    bool can = present;
+    {
+        const unsigned seen = (s_sum[0] | s_sum[1]) | (s_sum[2] | s_sum[3]) | (s_sum[4] | s_sum[5]) | (s_sum[6] | s_sum[7]);
+        can = can && s_sum[0] != 0u && seen == SUM_ANY;
+    }
     if (threadIdx.x == 28 && present && !keep_dirty) {
         // meshesToUpdate.clear() (Chisel.cpp:57) and the job flag of mesh_mark_kernel, which has finished: this job's own
         if (mesh_flag) mesh_flag[s_nb[NB_SELF]] = 0u;
         M.slot_dirty[s_nb[NB_SELF]] = 0u;
     }
     MSTAMP(0);
-    if (present) stage_corners<N>(M, s_nb, s_vox);
+    if (can) stage_corners<N>(M, s_nb, s_vox);
     MSTAMP(1);
     int nv = 0, ng = 0;
     unsigned char cases[CPT];  // case index of the thread's cubes that carry triangles (0: none -- case 0 has no triangles either)
 #pragma unroll
     for (int k = 0; k < CPT; k++) cases[k] = 0;
-    if (present) {
+    if (can) {
         // Classification with neighbouring lanes on neighbouring cubes (rank k * MESH_BLOCK + thread: consecutive corners, no LDS
         // bank conflicts -- with a thread's own CPT consecutive cubes the lanes sit 8 corners apart, an 8-way conflict on every one
         // of the 64 corner reads); the case bytes go through LDS to the thread that owns the cube in the traversal order.
