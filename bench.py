@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--res", type=float, default=0.01)
     ap.add_argument("--chunk", type=int, default=16)
     ap.add_argument("--scene", default="sphere_room")
+    ap.add_argument("--noise", action="store_true", help="depth noise 0.002 d^2 (SURVEY.md 8d)")
+    ap.add_argument("--nan-fraction", type=float, default=0.0, help="share of the depth pixels that are NaN (SURVEY.md 8d: 0.02)")
     ap.add_argument("--no-color", action="store_true", help="depth-only path (IntegrateDepthScan)")
     ap.add_argument("--agents", type=int, default=1)
     ap.add_argument("--trunc-scale", type=float, default=None, help="InverseTruncator scale (default: 100*res)")
@@ -79,6 +81,11 @@ def parse():
     ap.add_argument("--sim-shards", type=int, default=0, help="diagnostic, 1 GPU: integrate only the chunks of one shard of an N-way sharded map "
                                                                "(what one rank of an N-GPU run computes; every rank sees every frame)")
     ap.add_argument("--sim-rank", type=int, default=0)
+    ap.add_argument("--exchange-color", action="store_true", help="N > 1: every frame's colour image travels with its depth (a second all-gather per batch), as the "
+                                                                    "caller delivers it (ChiselServer.cpp:379-421); default: depth only (BASELINE config 4: \"RCCL depth broadcast\"), "
+                                                                    "one static colour image resident on every rank")
+    ap.add_argument("--group", type=int, default=0, help="1 process: one map over N shards through the in-library group handle (chisel_hip_create_group: what a "
+                                                          "single-process C++ caller like chisel_ros gets) -- on devices 0..N-1 when the node has them, else N shards on device 0")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (functional check of the N > 1 logic on one GPU)")
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5),
                     help="BASELINE.json configuration: 2 = depth only @ 2 cm; 3 = depth + colour @ 1 cm, meshes every 10th frame (the metric's); "
@@ -245,7 +252,7 @@ def main():
     channels = 3 if use_color else 0
     total = args.warmup + args.steps
     n_traj = (total + args.agents - 1) // args.agents
-    frames = list(synth.stream(args.scene, n_traj, W, H, agents=args.agents))[:total]
+    frames = list(synth.stream(args.scene, n_traj, W, H, agents=args.agents, noise=args.noise, nan_fraction=args.nan_fraction))[:total]
     color_img = synth.render_color(W, H, 3) if use_color else None
 
     # frames are handed over a batch at a time; with N ranks frame j of a batch is ingested by rank j * N / K and its
@@ -260,7 +267,8 @@ def main():
     bounds = [(lo, min(lo + K, args.warmup)) for lo in range(0, args.warmup, K)] + \
              [(lo, min(lo + K, total)) for lo in range(args.warmup, total, K)]
     c_dev = torch.from_numpy(color_img).to(dev) if use_color else None  # static colour pattern, resident on every rank
-    xch = FrameExchange(W, H, K, dev, dist, channels=0) if world > 1 else None
+    xcolor = bool(args.exchange_color and use_color and world > 1)
+    xch = FrameExchange(W, H, K, dev, dist, channels=3 if xcolor else 0) if world > 1 else None
     if world == 1:
         stack = [torch.from_numpy(np.stack([frames[i][0] for i in range(lo, hi)])).to(dev) for lo, hi in bounds]
     else:
@@ -269,6 +277,7 @@ def main():
         blank = np.zeros((H, W), np.float32)
         stack = [torch.from_numpy(np.stack([frames[lo + j][0] if lo + j < hi else blank for j in mine])).to(dev) for lo, hi in bounds]
         meta = [torch.from_numpy(np.stack([pack_meta(frames[min(lo + j, hi - 1)][1], cam) for j in mine])).to(dev) for lo, hi in bounds]
+        color_slots = c_dev.unsqueeze(0).repeat(len(mine), 1, 1, 1).contiguous() if xcolor else None  # this rank's frames' colour images
 
     host_src = None
     if args.host_frames and world == 1:
@@ -290,16 +299,23 @@ def main():
             fa[j], k1 = depth_frame(host_src[lo + j] if (args.host_frames and world == 1) else src[j], frames[lo + j][1], cam)
             keep.append(k1)
             if use_color:
-                ca[j], k2 = color_frame(c_dev, frames[lo + j][1], cam)
+                ca[j], k2 = color_frame(xch.color[b & 1][j] if xcolor else c_dev, frames[lo + j][1], cam)
                 keep.append(k2)
         calls.append((n, fa, ca))
     first_timed = next(b for b, (lo, hi) in enumerate(bounds) if lo >= args.warmup) if args.steps else len(bounds)
     calls_ref = [calls]
 
+    group_devices = None
+    if args.group and world == 1:
+        group_devices = list(range(args.group)) if torch.cuda.device_count() >= args.group else [local_rank] * args.group
+
     def new_map():
-        m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
-                   n_shards=args.sim_shards if (args.sim_shards and world == 1) else world,
-                   shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank)
+        if group_devices:
+            m = Chisel((args.chunk,) * 3, args.res, use_color, max_chunks=args.max_chunks, devices=group_devices)
+        else:
+            m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
+                       n_shards=args.sim_shards if (args.sim_shards and world == 1) else world,
+                       shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank)
         m._use(integ)
         m.px = PipelinedExchange(xch, m) if world > 1 else None  # RCCL -> integrate ordering: events, no host wait
         m.sharded = ShardedChisel(m, xch, integ) if world > 1 else None  # Chisel::UpdateMeshes of the sharded map
@@ -337,7 +353,7 @@ def main():
         for b in range(b_lo, b_hi):
             n, fa, ca = calls_ref[0][b]
             if world > 1:
-                m.px.exchange(b, stack[b], meta[b])  # RCCL all-gather on the communication stream; the map waits for its event
+                m.px.exchange(b, stack[b], meta[b], color_slots)  # RCCL all-gather on the communication stream; the map waits for its event
             rc = L.chisel_hip_integrate_batch(h, n, fa, ca)
             if rc:
                 capi.check(rc)
@@ -358,8 +374,11 @@ def main():
         run(m, 0, first_timed)
         m.synchronize()
         m.counters(reset=True)
+        m.launch_stats(reset=True)
         if instrumented:
             m.set_profiling(True)
+            if m.px is not None:
+                m.px.measure(True)
         fence()
         t0 = time.perf_counter()
         run(m, first_timed, len(bounds))
@@ -368,7 +387,10 @@ def main():
         dt = time.perf_counter() - t0
         m.synchronize()  # surfaces pool exhaustion
         prof = m.profile(reset=True) if instrumented else None
+        if instrumented and m.px is not None:
+            prof["allgather_us"] = m.px.measure(False)  # per batch, events on the communication stream
         cnt = m.counters()
+        cnt["launch_shapes"] = {k: v for k, v in m.launch_stats().items() if v}  # which shapes the launch heuristics picked in the timed region
         if instrumented:
             m.set_profiling(False)
         n_chunks = m.NumChunks()
@@ -423,7 +445,12 @@ def main():
     dt, t_issue = median(ts), median(issues)
     vals = torch.tensor([cnt["sdf"] + cnt["carved"], cnt["sdf"], cnt["col"], cnt["col_sat"], cnt["probe"], cnt["carved"],
                          cnt["work_chunks"], n_chunks], dtype=torch.float64, device=dev)
+    per_rank_sdf = None
     if world > 1:
+        mine_sdf = torch.tensor([float(cnt["sdf"])], dtype=torch.float64, device=dev)
+        all_sdf = [torch.zeros_like(mine_sdf) for _ in range(world)]
+        dist.all_gather(all_sdf, mine_sdf)
+        per_rank_sdf = [float(t.item()) for t in all_sdf]
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
     vals = [float(v) for v in vals.tolist()]
 
@@ -437,6 +464,8 @@ def main():
             k = prof["integrate"]
             avgs.append(k["ms"] / max(k["launches"], 1))
             others.append({n: (prof[n]["ms"] / max(prof[n]["launches"], 1)) * 1e3 for n in ("pyramid", "cull", "resolve", "mesh") if prof[n]["launches"]})
+            if prof.get("allgather_us"):
+                others[-1]["allgather"] = median(prof["allgather_us"])
             dts_b.append(dt_b)
         avg_ms = median(avgs)
         launches = k["launches"]
@@ -572,16 +601,25 @@ def main():
                                                                         args.res * 100, args.chunk, scale,
                                                                         (" + marching cubes every %d frames" % args.mesh_every) if args.mesh_every else ""),
                        "baseline_config": args.config, "image": "%dx%d" % (W, H), "voxel_m": args.res, "chunk": args.chunk, "color": use_color, "frames_per_call": K, "mesh_every": args.mesh_every,
-                       "parallelism": "spatial chunk-hash shards x%d, RCCL all-gather of each %d-frame batch" % (world, K) if world > 1 else "1 GPU"},
+                       "parallelism": "spatial chunk-hash shards x%d, RCCL all-gather of each %d-frame batch" % (world, K) if world > 1 else
+                                      ("1 process, in-library group of %d shards on devices %s (one issuing host thread per shard)" % (args.group, group_devices) if group_devices else "1 GPU")},
             "per_frame": {"voxel_updates": vals[0] / args.steps, "n_sdf": vals[1] / args.steps, "n_col": vals[2] / args.steps,
                           "n_probe": vals[4] / args.steps, "n_carved": vals[5] / args.steps,
                           "work_chunks": vals[6] / args.steps, "resident_chunks_end": vals[7]},
+            "launch_shapes": cnt.get("launch_shapes"),
         }
+        if args.noise or args.nan_fraction:
+            out["config"]["workload"] += " (depth noise 0.002 d^2: %s, NaN pixels: %g)" % ("yes" if args.noise else "no", args.nan_fraction)
         if world > 1:
             out["sharded_meshing"] = {"recomputes": mesh_stats["recomputes"],
                                       "ghost_bytes_per_recompute_rank0": mesh_stats["ghost_bytes"] / max(1, mesh_stats["recomputes"]),
                                       "whole_ghost_chunks_would_be": sharded_totals[1] / max(1, mesh_stats["recomputes"]),
                                       "shells_over_whole_chunks": sharded_totals[0] / max(1, sharded_totals[1])}
+            out["load_balance"] = {"n_sdf_per_rank_max_over_mean": max(per_rank_sdf) / max(1e-9, sum(per_rank_sdf) / world), "n_sdf_per_rank": per_rank_sdf}
+            out["exchange"] = {"payload": "depth + colour" if xcolor else "depth only (one static colour image resident on every rank)",
+                               "bytes_per_batch": K * (W * H * 4 + 128 + (W * H * 3 if xcolor else 0)),
+                               "allgather_us_per_batch_rank0": (roof or {}).get("other_kernels_us", {}).get("allgather"),
+                               "hardware_curve": "none yet: no run of this path on two or more physical GPUs exists (tools/first_contact.sh is the list of first commands)"}
             out["note"] = ("N > 1: one map sharded over the ranks (total work fixed); every batch is all-gathered, every rank integrates the chunks it "
                            "owns and meshes them with ghost copies of the neighbours other ranks own")
         if roof:

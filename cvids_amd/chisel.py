@@ -354,14 +354,24 @@ class Chisel:
             ptr = lambda a: a.ctypes.data if a is not None else None
         check(self.L.chisel_hip_import_ghost_shells(self.h, items.ctypes.data_as(C.POINTER(C.c_int)), n, ptr(sdf), ptr(wgt), ptr(col), ptr(found),
                                                     int(on_device)))
-        self._keep = [items, sdf, wgt, col, found]
+        # the import is only queued (device payloads are read in place, nothing is waited for): the payload must outlive it.  Kept until
+        # DropGhostChunks, which returns after the recompute behind the imports has started (it looks at that recompute's totals).
+        self._ghost_keep = getattr(self, "_ghost_keep", []) + [(items, sdf, wgt, col, found)]
 
     def DropGhostChunks(self):
         check(self.L.chisel_hip_drop_ghost_chunks(self.h))
+        if getattr(self, "_ghost_keep", None):
+            # a recompute queued behind the imports (UpdateMeshesOf): the call above has looked at its totals, which the device publishes
+            # after everything in front of it -- the imports have read their payload.  Without one nothing has told the host so: wait.
+            if not getattr(self, "_imports_fenced", False):
+                self.synchronize()
+            self._ghost_keep = []
+        self._imports_fenced = False
 
     def UpdateMeshesOf(self, ids):
         ids = np.ascontiguousarray(np.asarray(ids, np.int32).reshape(-1, 3))
         check(self.L.chisel_hip_update_meshes_of(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), len(ids)))
+        self._imports_fenced = True
 
     def SaveMap(self, filename):
         """binary dump of every resident chunk (chisel_hip_save_map): checkpoint"""
@@ -515,6 +525,15 @@ class Chisel:
         n = (C.c_int64 * capi.NUM_KERNELS)()
         check(self.L.chisel_hip_get_profile(self.h, ms, n, int(reset)))
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(capi.KERNEL_NAMES)}
+
+    LAUNCH_STATS = ("integrate_2_per_lane", "integrate_4_per_lane", "integrate_4_with_2_tail", "cull_4_waves", "cull_wave_per_frame",
+                    "unordered_worklists", "single_stream_sets", "launch_sets")
+
+    def launch_stats(self, reset=False):
+        """which shapes the launch heuristics picked (chisel_hip_get_launch_stats)"""
+        out = (C.c_int64 * len(self.LAUNCH_STATS))()
+        check(self.L.chisel_hip_get_launch_stats(self.h, out, int(reset)))
+        return dict(zip(self.LAUNCH_STATS, [int(v) for v in out]))
 
 
 class DepthFilter:

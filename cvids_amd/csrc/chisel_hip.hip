@@ -11,6 +11,10 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -133,6 +137,8 @@ struct chisel_hip_map {
     bool is_group = false;
     std::vector<chisel_hip_map *> shards;
     void *stages = nullptr;  // std::vector<group::Stage>*: staging of device frames for shards on other devices
+    void *pool = nullptr;    // group::Pool*: one issuing host thread per shard
+    void *mesh_stages_group = nullptr;  // group::MeshStages*: persistent shell staging of update_meshes, per (meshing shard, owner)
     chisel_hip_config cfg;
     int N = 0, V = 0;
     int device = 0;
@@ -175,6 +181,24 @@ struct chisel_hip_map {
     hipEvent_t input_event = nullptr;    // chisel_hip_wait_event: the next batch's frames are ready behind this (caller's) event
     bool force_pipeline = false;         // test hook (CHISEL_HIP_FORCE_PIPELINE at creation): the front half always runs on the auxiliary stream
     bool mesh_tiny = false;              // test hook (CHISEL_HIP_MESH_TINY at creation): triangle list and arena start far too small, so every recompute takes the grow-and-emit-again paths
+    // The launch heuristics in one place, with the hooks that override them; read ONCE, in chisel_hip_create (they sat in the per-launch
+    // host path as getenv calls).  The numbers were fitted on the 640x480 / 1 cm streams of bench.py (sphere room, one and four agents)
+    // and are checked on the other scenes, with noise and missing pixels, by tools/measure_table.sh -> profiles/r04_scene_table.txt.
+    struct Tuning {
+        int fine_below = INTEGRATE_FINE_BELOW;  // work items (16^3-chunk equivalents) below which a launch of >= 4 frames runs at 2 voxels per lane ...
+        int fine_min_frames_per_item = 6;       // ... if its items see at least this many frames on average (chains worth shortening)
+        int tail_percent = 15;                  // share of a large 4-voxel launch's cost-ordered work-list (the cheap end) that runs at 2 voxels per lane
+        double narrow_cull_ratio = 1.5;         // frames look at different parts of space (union id range > ratio x the largest frame's): cull with four waves per workgroup ...
+        int narrow_cull_max_shards = 2;         // ... on maps of at most this many shards (a shard's cull is an n-th of it: no gain measured at 8)
+        int direct_items_max = 256;             // work-lists up to this size are not cost-ordered (every unit starts at once): no order_kernel launch
+        // test / A-B hooks (environment, at creation)
+        int force_vpl = 0;                      // CHISEL_HIP_VPL=2|4
+        int force_cull_waves = 0;               // CHISEL_HIP_CULL_WAVES=4|16
+        bool persistent_grid = false;           // CHISEL_HIP_PERSISTENT=1: a resident grid pulling units from the queue heads
+        bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
+        bool always_wait_packet = false;        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
+    } tune;
+    int64_t launch_stats[CHISEL_HIP_NUM_LAUNCH_STATS] = {};  // chisel_hip_get_launch_stats
     bool refine_off = false;             // test / A-B hook (CHISEL_HIP_REFINE=0 at creation): every cell of every frame of an item's mask counts as needed
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % 3] and pending_ring[b % 4]
@@ -213,6 +237,8 @@ struct chisel_hip_map {
     int *shell_items_dev = nullptr;                                    // staging of the items / offsets of chisel_hip_export_shells / import_ghost_shells
     long long *shell_offs_dev = nullptr;
     int shell_capacity = 0;
+    int *shell_first_dev = nullptr;                                    // chisel_hip_import_ghost_shells: first item of every distinct ghost
+    int shell_first_capacity = 0;
     bool single_chunk = false;                                         // chisel_hip_integrate_chunk: the next integrate call sees this id only
     int single_id[3] = {0, 0, 0};
     int mesh_stages = 3;                                               // MeshParams::stages of the next recompute (chisel_hip_generate_mesh lowers it)
@@ -410,8 +436,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         {
             double vmax = 0.0;
             for (int k2 = 0; k2 < CP.n_frames; k2++) vmax = std::max(vmax, (double)CP.f[k2].range_dim[0] * CP.f[k2].range_dim[1] * CP.f[k2].range_dim[2]);
-            narrow_cull = m->cfg.n_shards <= 2 && (double)CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2] > 1.5 * vmax;  // (a shard's cull is an n-th of it: no gain measured at 8)
-            if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) narrow_cull = atoi(e) == 4;  // test hook: 4 / 16
+            narrow_cull = m->cfg.n_shards <= m->tune.narrow_cull_max_shards && (double)CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2] > m->tune.narrow_cull_ratio * vmax;
+            if (m->tune.force_cull_waves) narrow_cull = m->tune.force_cull_waves == 4;
+            m->launch_stats[(narrow_cull && IP.n_frames > 4) ? 3 : 4]++;
         }
 #define CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, WV)                                                                                   \
     hipLaunchKernelGGL((cull_kernel<N, KLV, INL, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count, \
@@ -450,9 +477,10 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // reported: every unit starts at once, whatever its place in the list) is not worth a launch of its own either -- the
         // shards of a multi-GPU map are in this regime, where the front half is what a rank's rate hangs on
         const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
-        const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= 256);
+        const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= m->tune.direct_items_max);
         hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
                            prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync);
+        if (direct) m->launch_stats[5]++;
         if (!direct)
             hipLaunchKernelGGL(order_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
     }
@@ -483,7 +511,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // in flight the host has just waited for its triangle kernel to START (check_mesh_totals), that kernel has another 15-25 us
         // to run and this batch's front half, queued before that wait, is over or about to be: worth a short look.  (Default window
         // 87.8 -> 89.9 k frames/s; nothing on streams without recomputes, where the host runs batches ahead of the device.)
-        static const bool never = getenv("CHISEL_HIP_ALWAYS_WAIT_PACKET") != nullptr;
+        const bool never = m->tune.always_wait_packet;
         bool done = !never && hipEventQuery(bs.front_done) == hipSuccess;
         if (!done && !never && recompute_in_flight) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -505,21 +533,22 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // (about three rounds of the chip at 4 voxels per lane), 4 otherwise (kernels_integrate.h).
         const long long hint = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[2];
         const long long pairs = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[3];  // (item, frame) pairs of that launch, 0 = unknown
-        int vpl = (IP.n_frames >= 4 && hint > 0 && hint * (long long)(N * N * N) < (long long)INTEGRATE_FINE_BELOW * 4096 && (pairs == 0 || pairs >= 6 * hint)) ? 2 : 4;
-        if (const char *e = getenv("CHISEL_HIP_VPL")) vpl = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : vpl);
+        int vpl = (IP.n_frames >= 4 && hint > 0 && hint * (long long)(N * N * N) < (long long)m->tune.fine_below * 4096 &&
+                   (pairs == 0 || pairs >= (long long)m->tune.fine_min_frames_per_item * hint)) ? 2 : 4;
+        if (m->tune.force_vpl) vpl = m->tune.force_vpl;
         const int wpc = vpl == 2 ? Geom<N, 2>::WPC : Geom<N, 4>::WPC;
         const int step = vpl == 2 ? Geom<N, 2>::GRID_STEP : Geom<N, 4>::GRID_STEP;
         const long long units = (long long)total * wpc;
         constexpr int WPB = Geom<N, 4>::WPB;
         long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * wpc + WPB - 1) / WPB : (long long)Geom<N, 4>::GRID;
-        if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) blocks = atoi(e) ? (long long)Geom<N, 4>::GRID : blocks;
+        if (m->tune.persistent_grid) blocks = (long long)Geom<N, 4>::GRID;
         blocks = std::min<long long>(blocks, (units + WPB - 1) / WPB);
         // Two granularities in one launch: the last seventh of the (cost-ordered) items at 2 voxels per lane -- units of half the length
         // where the launch drains -- when the launch is long enough to have a tail worth shortening (>= 2 rounds of the chip).  The
         // kernel takes the split only if the grid covers every unit (it knows the true item count), so the grid is sized for it.
         int split = -1;
         if (vpl == 4 && hint > 0 && hint * (long long)Geom<N, 4>::WPC >= 2ll * Geom<N, 4>::GRID * WPB) {
-            static const int tail_percent = getenv("CHISEL_HIP_TAIL_PERCENT") ? atoi(getenv("CHISEL_HIP_TAIL_PERCENT")) : 15;  // (driver window: 97.8 us without, 95.7 with 15 %, 98.9 with 25 %, 104 with 50 %; no effect late in the stream)
+            const int tail_percent = m->tune.tail_percent;  // (driver window, round 3: 97.8 us without, 95.7 with 15 %, 98.9 with 25 %, 104 with 50 %; no effect late in the stream)
             if (tail_percent > 0) {
                 const long long n_est = hint + hint / 8 + 8;
                 split = (int)std::max<long long>(0, hint - hint * tail_percent / 100);
@@ -531,6 +560,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         }
         blocks = std::min<long long>(blocks, (long long)INTEGRATE_GRID_CAP);
         const int grid = (int)std::max<long long>(step, (blocks + step - 1) / step * step);
+        m->launch_stats[vpl == 2 ? 0 : (split >= 0 ? 2 : 1)]++;
+        m->launch_stats[7]++;
+        if (inline_resolve) m->launch_stats[6]++;
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
@@ -553,7 +585,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     HIP_TRY(hipEventRecord(bs.back_done, m->stream));
     m->batch_seq++;
     g_host_timer.lap(5);
-    g_host_timer.calls++;
+    if (g_host_timer.on) g_host_timer.calls++;
     return CHISEL_HIP_OK;
 }
 
@@ -695,7 +727,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
                 mapped = static_cast<const float *>(attr.devicePointer);
             else
                 (void)hipGetLastError();  // not a registered pointer: plain pageable memory
-            if (mapped && !getenv("CHISEL_HIP_NO_ZERO_COPY")) {
+            if (mapped && !m->tune.no_zero_copy) {
                 PP.depth[k] = mapped;
             } else {
                 float *dst = bs.depth_stage + (size_t)k * m->depth_stage_elems;
@@ -992,6 +1024,13 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     m->mesh_tiny = getenv("CHISEL_HIP_MESH_TINY") != nullptr;
     m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
     if (const char *e = getenv("CHISEL_HIP_REFINE")) m->refine_off = atoi(e) == 0;
+    if (const char *e = getenv("CHISEL_HIP_VPL")) m->tune.force_vpl = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 0);
+    if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) m->tune.force_cull_waves = atoi(e) == 4 ? 4 : 16;
+    if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) m->tune.persistent_grid = atoi(e) != 0;
+    if (const char *e = getenv("CHISEL_HIP_TAIL_PERCENT")) m->tune.tail_percent = atoi(e);
+    if (const char *e = getenv("CHISEL_HIP_FINE_BELOW")) m->tune.fine_below = atoi(e);
+    m->tune.no_zero_copy = getenv("CHISEL_HIP_NO_ZERO_COPY") != nullptr;
+    m->tune.always_wait_packet = getenv("CHISEL_HIP_ALWAYS_WAIT_PACKET") != nullptr;
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
         const int one = 1;
@@ -1037,7 +1076,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->stream) (void)sync_all(m);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.block_counters, m->view_dev, m->scratch_i, m->shell_items_dev, m->shell_offs_dev};
+                    v.counters, v.block_counters, m->view_dev, m->scratch_i, m->shell_items_dev, m->shell_offs_dev, m->shell_first_dev};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
@@ -1555,7 +1594,7 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     HIP_TRY(hipMemcpyAsync(d_ids, m->ghost_ids.data(), (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(remove_chunks_kernel, dim3(n), dim3(256), 0, m->stream, m->view, d_ids, n, d_cnt, m->V);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(note_map_mutation(m));  // (stream-ordered; the next batch's front half waits for it -- nothing is waited for here)
     m->ghost_ids.clear();
     return CHISEL_HIP_OK;
 }
@@ -1600,13 +1639,17 @@ int chisel_hip_dirty_ids_device(chisel_hip_map *m, int *out_dev, int capacity) {
         HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
         m->input_event = nullptr;
     }
-    std::vector<int> head(1, 0);
+    // out[0] is the TRUE number of entries -- host-held ones and the kernel's appends -- also when it exceeds `capacity` (only the first
+    // `capacity` are stored): a caller that reads out[0] > capacity grows its buffer and asks again; a count capped at the capacity
+    // would have looked like a list that just fits, and the entries beyond it would have been dropped for good
+    std::vector<int> head(1, (int)std::min<size_t>(m->pending_mesh_ids.size(), (size_t)INT32_MAX / 8));
+    int stored = 0;
     for (uint64_t key : m->pending_mesh_ids) {
-        if (head[0] >= capacity) break;
+        if (stored >= capacity) break;
         int x, y, z;
         unpack_id(key, x, y, z);
         head.push_back(x); head.push_back(y); head.push_back(z); head.push_back(1);
-        head[0]++;
+        stored++;
     }
     HIP_TRY(hipMemcpyAsync(out_dev, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(list_dirty_ids_kernel, dim3(256), dim3(256), 0, m->stream, m->view, out_dev, capacity);
@@ -1695,18 +1738,20 @@ int chisel_hip_import_ghost_shells(chisel_hip_map *m, const int *items, int n, c
         }
         d_s = st.sdf; d_w = st.wgt; d_c = st.col; d_f = st.flags;
     }
-    // phase 1: one thread block per distinct ghost creates the chunk (distinct ids never collide); phase 2: every box is written
-    int *d_first = nullptr;
-    HIP_TRY(hipMalloc(&d_first, first.size() * sizeof(int)));
-    hipError_t e1 = hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, m->stream);
-    if (e1 == hipSuccess) {
-        hipLaunchKernelGGL(ensure_ghosts_kernel, dim3((unsigned)first.size()), dim3(64), 0, m->stream, m->view, m->shell_items_dev, d_first, d_f);
-        hipLaunchKernelGGL(import_shells_kernel, dim3(n), dim3(256), 0, m->stream, m->view, m->shell_items_dev, m->shell_offs_dev, d_f, m->N, d_s, d_w, d_c);
-        e1 = hipGetLastError();
+    // phase 1: one thread block per distinct ghost creates the chunk (distinct ids never collide); phase 2: every box is written.
+    // The list of first items travels through a staging buffer the map keeps (stream-ordered like the item list): nothing is
+    // allocated, freed or waited for here when the payload is already on the device.
+    if ((int)first.size() > m->shell_first_capacity) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (m->shell_first_dev) HIP_TRY(hipFree(m->shell_first_dev));
+        m->shell_first_dev = nullptr;
+        const int cap = std::max(4096, 2 * (int)first.size());
+        HIP_TRY(hipMalloc(&m->shell_first_dev, (size_t)cap * sizeof(int)));
+        m->shell_first_capacity = cap;
     }
-    if (e1 == hipSuccess) e1 = hipStreamSynchronize(m->stream);  // (d_first is freed below; the payload has been read)
-    (void)hipFree(d_first);
-    if (e1 != hipSuccess) return fail(CHISEL_HIP_ERR_HIP, std::string("chisel_hip_import_ghost_shells: ") + hipGetErrorString(e1));
+    HIP_TRY(hipMemcpyAsync(m->shell_first_dev, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(ensure_ghosts_kernel, dim3((unsigned)first.size()), dim3(64), 0, m->stream, m->view, m->shell_items_dev, m->shell_first_dev, d_f);
+    hipLaunchKernelGGL(import_shells_kernel, dim3(n), dim3(256), 0, m->stream, m->view, m->shell_items_dev, m->shell_offs_dev, d_f, m->N, d_s, d_w, d_c);
     HIP_TRY(hipGetLastError());
     // every item may have become a ghost (which of them were resident at their owner is known on the device only): all are dropped
     // again by chisel_hip_drop_ghost_chunks (removing an absent id does nothing)
@@ -2002,6 +2047,103 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
         fprintf(stderr, "   (meaningful for ONE launch) first wave start -> last wave end %.1f us; last unit started at %.1f us; longest unit %.1f us (%d frames executed, wid %d = item %d unit %d)\n",
                 (ph[22] - ph[21]) * 0.01, (ph[23] - ph[21]) * 0.01, (ph[24] >> 32) * 0.01, (int)(ph[24] & 255), (int)((ph[24] >> 8) & 0xffffff), (int)((ph[24] >> 8) & 0xffffff) / 16, (int)((ph[24] >> 8) & 0xffffff) % 16);
 #endif
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_mc_tables(int *triangle_table, int *edge_index_pairs) {
+    static const unsigned long long cases[256] = CHISEL_MC_PACKED_CASES;
+    static const unsigned char edges[12] = CHISEL_MC_EDGE_CORNERS;
+    if (triangle_table)
+        for (int i = 0; i < 256; i++)
+            for (int k = 0; k < 16; k++) {
+                const int e = (int)((cases[i] >> (4 * k)) & 0xF);
+                triangle_table[16 * i + k] = e == 0xF ? -1 : e;
+            }
+    if (edge_index_pairs)
+        for (int e = 0; e < 12; e++) {
+            edge_index_pairs[2 * e] = edges[e] & 0xF;
+            edge_index_pairs[2 * e + 1] = edges[e] >> 4;
+        }
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_mesh_cube_values(const float *vertex_coords, const float *vertex_sdf, float *edge_coords, int *configuration, float *vertices,
+                                float *normals, int *n_vertices) {
+    if (!vertex_coords || !vertex_sdf) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(&d, (32 + 2 + 36 + 90) * sizeof(float)));
+    float in[32];
+    memcpy(in, vertex_coords, 24 * sizeof(float));
+    memcpy(in + 24, vertex_sdf, 8 * sizeof(float));
+    hipError_t e = hipMemcpy(d, in, sizeof(in), hipMemcpyHostToDevice);
+    float out[2 + 36 + 90];
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mesh_cube_values_kernel, dim3(1), dim3(1), 0, 0, (const float *)d, (const float *)(d + 24), d + 32);
+        e = hipMemcpy(out, d + 32, sizeof(out), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CHISEL_HIP_ERR_HIP, std::string("chisel_hip_mesh_cube_values: ") + hipGetErrorString(e));
+    const int nv = (int)out[1];
+    if (configuration) *configuration = (int)out[0];
+    if (n_vertices) *n_vertices = nv;
+    if (edge_coords) memcpy(edge_coords, out + 2, 36 * sizeof(float));
+    if (vertices) memcpy(vertices, out + 2 + 36, (size_t)nv * 3 * sizeof(float));
+    if (normals) memcpy(normals, out + 2 + 36 + 45, (size_t)nv * 3 * sizeof(float));
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_interpolate_vertex(const float v1[3], const float v2[3], float sdf1, float sdf2, float out[3]) {
+    if (!v1 || !v2 || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 12 * sizeof(float)));
+    const float in[8] = {v1[0], v1[1], v1[2], v2[0], v2[1], v2[2], sdf1, sdf2};
+    hipError_t e = hipMemcpy(d, in, sizeof(in), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(interpolate_vertex_kernel, dim3(1), dim3(1), 0, 0, (const float *)d, d + 8);
+        e = hipMemcpy(out, d + 8, 3 * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CHISEL_HIP_ERR_HIP, std::string("chisel_hip_interpolate_vertex: ") + hipGetErrorString(e));
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_raycast(const float start[3], const float end[3], const int min_xyz[3], const int max_xyz[3], int *cells, int64_t capacity,
+                       int64_t *count) {
+    if (!start || !end || !min_xyz || !max_xyz || !count || capacity < 0 || (capacity > 0 && !cells)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    const int cap = (int)std::min<int64_t>(capacity, 1 << 24);
+    float *d_in = nullptr;
+    int *d_cells = nullptr, *d_count = nullptr;
+    HIP_TRY(hipMalloc(&d_in, 6 * sizeof(float)));
+    HIP_TRY(hipMalloc(&d_cells, ((size_t)cap * 3 + 4) * sizeof(int)));
+    HIP_TRY(hipMalloc(&d_count, sizeof(int)));
+    const float in[6] = {start[0], start[1], start[2], end[0], end[1], end[2]};
+    hipError_t e = hipMemcpy(d_in, in, sizeof(in), hipMemcpyHostToDevice);
+    int c = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kat_raycast_kernel, dim3(1), dim3(64), 0, 0, (const float *)d_in, 1, make_int3(min_xyz[0], min_xyz[1], min_xyz[2]),
+                           make_int3(max_xyz[0], max_xyz[1], max_xyz[2]), d_cells, cap, d_count);
+        e = hipMemcpy(&c, d_count, sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && cap > 0 && c > 0) e = hipMemcpy(cells, d_cells, (size_t)std::min(c, cap) * 3 * sizeof(int), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_in); (void)hipFree(d_cells); (void)hipFree(d_count);
+    if (e != hipSuccess) return fail(CHISEL_HIP_ERR_HIP, std::string("chisel_hip_raycast: ") + hipGetErrorString(e));
+    *count = c;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_get_launch_stats(chisel_hip_map *m, int64_t *out, int reset_stats) {
+    if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    for (int k = 0; k < CHISEL_HIP_NUM_LAUNCH_STATS; k++) out[k] = 0;
+    auto take = [&](chisel_hip_map *s) {
+        for (int k = 0; k < CHISEL_HIP_NUM_LAUNCH_STATS; k++) {
+            out[k] += s->launch_stats[k];
+            if (reset_stats) s->launch_stats[k] = 0;
+        }
+    };
+    if (m->is_group)
+        for (chisel_hip_map *s : m->shards) take(s);
+    else
+        take(m);
     return CHISEL_HIP_OK;
 }
 

@@ -29,7 +29,92 @@ struct Stage {                       // device frames copied to a shard on anoth
     unsigned turn = 0;
 };
 
+// One issuing host thread per shard.  A launch set costs the host 35-120 us to issue (five to six kernel launches, a handful of event
+// calls); eight shards issued in turn by the caller's thread cost eight times that per batch, which capped a group below the rate of ONE
+// map.  The shard maps share nothing, so every call that fans out over the shards -- integrate, the phases of update_meshes, the id
+// listings -- hands shard i's part to worker i and joins.  Workers spin for a while after a job (a stream of frames keeps them hot: a
+// condition-variable wake-up costs as much as the job) and then sleep; shard 0's part runs on the calling thread.
+// CHISEL_HIP_GROUP_THREADS=0: everything on the calling thread, in turn (A/B, debugging).
+struct Pool {
+    std::vector<std::thread> workers;           // worker w serves shard w + 1
+    std::function<int(int)> job;
+    std::atomic<uint64_t> seq{0};               // bumped once per fan-out
+    std::atomic<int> done{0};
+    std::atomic<int> sleepers{0};
+    std::atomic<bool> stop{false};
+    std::vector<int> rc;
+    std::vector<std::string> err;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool serial = false;
+    void loop(int shard) {
+        uint64_t seen = 0;
+        for (;;) {
+            const auto idle = std::chrono::steady_clock::now();
+            while (seq.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+                if (std::chrono::steady_clock::now() - idle > std::chrono::microseconds(500)) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleepers.fetch_add(1);
+                    cv.wait(lk, [&] { return seq.load(std::memory_order_acquire) != seen || stop.load(); });
+                    sleepers.fetch_sub(1);
+                } else {
+                    __builtin_ia32_pause();
+                }
+            }
+            if (stop.load()) return;
+            seen = seq.load(std::memory_order_acquire);
+            const int r = job(shard);
+            rc[(size_t)shard] = r;
+            if (r) err[(size_t)shard] = g_last_error;
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+};
+// staging of one (meshing shard r, owner o) pair of update_meshes: the shells o packs for r, on o's device and -- when r lives on another
+// device -- their copy on r's; grow-only, reused by every recompute; `imported` (recorded on r's stream behind the import) guards reuse
+struct PairStage {
+    float *sdf[2] = {nullptr, nullptr}, *wgt[2] = {nullptr, nullptr};   // [0] on the owner's device, [1] on the meshing shard's (other device only)
+    uint8_t *rgbw[2] = {nullptr, nullptr};
+    int *found[2] = {nullptr, nullptr};
+    long long cap_vox[2] = {0, 0};
+    int cap_items[2] = {0, 0};
+    hipEvent_t exported = nullptr, copied = nullptr, imported = nullptr;
+    bool armed = false;
+};
+struct MeshStages {
+    std::vector<PairStage> pair;               // [r * W + o]
+    std::vector<hipStream_t> copy;             // [r]: peer copies into shard r's device
+};
+
 inline int n_shards(const chisel_hip_map *g) { return (int)g->shards.size(); }
+inline Pool *pool_of(const chisel_hip_map *g) { return static_cast<Pool *>(g->pool); }
+
+// fn(i) for every shard i, concurrently (shard 0 on the calling thread); the first failure's code and message
+template <class F>
+int run_shards(chisel_hip_map *g, F fn) {
+    Pool *P = pool_of(g);
+    const int W = n_shards(g);
+    if (!P || P->serial || W == 1) {
+        for (int i = 0; i < W; i++) {
+            const int rc = fn(i);
+            if (rc) return rc;
+        }
+        return CHISEL_HIP_OK;
+    }
+    P->job = fn;
+    P->done.store(0, std::memory_order_relaxed);
+    P->seq.fetch_add(1, std::memory_order_release);
+    if (P->sleepers.load() > 0) {
+        std::lock_guard<std::mutex> lk(P->mu);
+        P->cv.notify_all();
+    }
+    const int rc0 = fn(0);
+    while (P->done.load(std::memory_order_acquire) < W - 1) __builtin_ia32_pause();
+    if (rc0) return rc0;
+    for (int i = 1; i < W; i++)
+        if (P->rc[(size_t)i]) return fail(P->rc[(size_t)i], P->err[(size_t)i]);
+    return CHISEL_HIP_OK;
+}
 inline int owner_of(const chisel_hip_map *g, const int id[3]) { return chunk_owner(id[0], id[1], id[2], n_shards(g), g->cfg.shard_block); }
 inline bool id_less(const int *a, const int *b) { return a[0] != b[0] ? a[0] < b[0] : (a[1] != b[1] ? a[1] < b[1] : a[2] < b[2]); }
 
@@ -60,6 +145,19 @@ int create(const chisel_hip_config *cfg, const int *device_ids, int n, chisel_hi
     g->V = g->shards[0]->V;
     g->device = g->shards[0]->device;
     g->stages = new std::vector<Stage>(n);
+    {
+        Pool *P = new Pool();
+        P->rc.assign((size_t)n, 0);
+        P->err.assign((size_t)n, std::string());
+        if (const char *e = getenv("CHISEL_HIP_GROUP_THREADS")) P->serial = atoi(e) == 0;
+        if (!P->serial)
+            for (int i = 1; i < n; i++) P->workers.emplace_back([P, i] { P->loop(i); });
+        g->pool = P;
+        MeshStages *MS = new MeshStages();
+        MS->pair.resize((size_t)n * n);
+        MS->copy.assign((size_t)n, nullptr);
+        g->mesh_stages_group = MS;
+    }
     // peer access between the devices of the group (a failure here only costs the copies their direct path)
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++)
@@ -76,6 +174,41 @@ int create(const chisel_hip_config *cfg, const int *device_ids, int n, chisel_hi
 }
 
 int destroy(chisel_hip_map *g) {
+    if (Pool *P = pool_of(g)) {
+        {
+            std::lock_guard<std::mutex> lk(P->mu);
+            P->stop.store(true);
+            P->cv.notify_all();
+        }
+        for (std::thread &t : P->workers) t.join();
+        delete P;
+        g->pool = nullptr;
+    }
+    if (MeshStages *MS = static_cast<MeshStages *>(g->mesh_stages_group)) {
+        for (chisel_hip_map *sh : g->shards) (void)chisel_hip_synchronize(sh);
+        const int W = n_shards(g);
+        for (int r = 0; r < W; r++)
+            for (int o = 0; o < W; o++) {
+                PairStage &S = MS->pair[(size_t)r * W + o];
+                for (int side = 0; side < 2; side++) {
+                    (void)hipSetDevice(g->shards[side ? r : o]->device);
+                    if (S.sdf[side]) (void)hipFree(S.sdf[side]);
+                    if (S.wgt[side]) (void)hipFree(S.wgt[side]);
+                    if (S.rgbw[side]) (void)hipFree(S.rgbw[side]);
+                    if (S.found[side]) (void)hipFree(S.found[side]);
+                }
+                if (S.exported) (void)hipEventDestroy(S.exported);
+                if (S.copied) (void)hipEventDestroy(S.copied);
+                if (S.imported) (void)hipEventDestroy(S.imported);
+            }
+        for (int r = 0; r < W; r++)
+            if (MS->copy[(size_t)r]) {
+                (void)hipSetDevice(g->shards[r]->device);
+                (void)hipStreamDestroy(MS->copy[(size_t)r]);
+            }
+        delete MS;
+        g->mesh_stages_group = nullptr;
+    }
     std::vector<Stage> *st = static_cast<std::vector<Stage> *>(g->stages);
     for (size_t i = 0; i < g->shards.size(); i++) {
         if (st) {
@@ -123,8 +256,8 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
     size_t cbytes = 0;
     if (colors)
         for (int k = 0; k < n; k++) cbytes = std::max(cbytes, (size_t)colors[k].width * colors[k].height * colors[k].channels);
-    for (size_t i = 0; i < g->shards.size(); i++) {
-        chisel_hip_map *s = g->shards[i];
+    return run_shards(g, [&](int i) -> int {
+        chisel_hip_map *s = g->shards[(size_t)i];
         std::vector<chisel_hip_depth_frame> f(frames, frames + n);
         std::vector<chisel_hip_color_frame> c;
         if (colors) c.assign(colors, colors + n);
@@ -133,7 +266,7 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
             foreign |= f[k].on_device && (force_stage || device_of(f[k].depth, s->device) != s->device);
             if (colors) foreign |= c[k].on_device && (force_stage || device_of(c[k].color, s->device) != s->device);
         }
-        Stage &S = st[i];
+        Stage &S = st[(size_t)i];
         int b = -1;
         if (foreign) {
             HIP_TRY(hipSetDevice(s->device));
@@ -194,8 +327,8 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
             if (rc) return rc;
             S.armed[b] = true;
         }
-    }
-    return CHISEL_HIP_OK;
+        return CHISEL_HIP_OK;
+    });
 }
 
 // frames in order; consecutive frames of one image size go out KMAX at a time (as integrate_frames cuts them for one map)
@@ -249,18 +382,25 @@ int garbage_collect(chisel_hip_map *g, const int *ids, int n) {
 // sorted union / concatenation of per-shard id listings
 template <class F>
 int gather_ids(chisel_hip_map *g, F list_fn, bool unique, std::vector<int> &out) {
-    std::vector<std::array<int, 3>> all;
-    for (chisel_hip_map *s : g->shards) {
+    std::vector<std::vector<int>> per(g->shards.size());
+    int rc_all = run_shards(g, [&](int i) -> int {
+        chisel_hip_map *s = g->shards[(size_t)i];
         int64_t n = 0;
         int rc = list_fn(s, nullptr, 0, &n);
         if (rc) return rc;
-        std::vector<int> ids((size_t)n * 3);
+        std::vector<int> &ids = per[(size_t)i];
+        ids.resize((size_t)n * 3);
         if (n) {
             rc = list_fn(s, ids.data(), n, &n);
             if (rc) return rc;
+            ids.resize((size_t)n * 3);
         }
-        for (int64_t j = 0; j < n; j++) all.push_back({ids[3 * j], ids[3 * j + 1], ids[3 * j + 2]});
-    }
+        return CHISEL_HIP_OK;
+    });
+    if (rc_all) return rc_all;
+    std::vector<std::array<int, 3>> all;
+    for (const std::vector<int> &ids : per)
+        for (size_t j = 0; j + 2 < ids.size(); j += 3) all.push_back({ids[j], ids[j + 1], ids[j + 2]});
     std::sort(all.begin(), all.end());
     if (unique) all.erase(std::unique(all.begin(), all.end()), all.end());
     out.clear();
@@ -274,12 +414,45 @@ int emit_ids(const std::vector<int> &all, int *ids, int64_t max_ids, int64_t *co
     return CHISEL_HIP_OK;
 }
 
-// Chisel::UpdateMeshes of the group: cvids_amd/sharded.py: ShardedChisel.UpdateMeshes, with direct calls for the collectives
+// Chisel::UpdateMeshes of the group: cvids_amd/sharded.py: ShardedChisel.UpdateMeshes, with direct calls for the collectives.
+// Three fan-outs over the shards, nothing allocated and no stream waited for once the staging buffers have their size:
+//   A  every shard lists its meshesToUpdate (one host read per shard, concurrently); the union is the plan's input, the plan of every
+//      shard (its jobs; per owner the shells it needs) is pure host arithmetic;
+//   B  every OWNER packs, for every shard that asked, the shells into that pair's staging buffer on its own device and records the
+//      pair's `exported` event on its stream;
+//   C  every MESHING shard waits (on its stream, not on the host) for its owners' events -- with a peer copy on a copy stream in between
+//      when the owner lives on another device --, installs the ghosts, recomputes its jobs, drops the ghosts and records `imported`,
+//      behind which the owner's next export into the same buffer is ordered.
+int ensure_pair(chisel_hip_map *g, PairStage &S, int side, int device, long long vox, int n_items, bool color) {
+    if (vox <= S.cap_vox[side] && n_items <= S.cap_items[side]) return CHISEL_HIP_OK;
+    HIP_TRY(hipSetDevice(device));
+    // (the buffers may still be read by the previous recompute's import / copy: wait for that pair only)
+    if (S.armed && S.imported) HIP_TRY(hipEventSynchronize(S.imported));
+    if (S.sdf[side]) HIP_TRY(hipFree(S.sdf[side]));
+    if (S.wgt[side]) HIP_TRY(hipFree(S.wgt[side]));
+    if (S.rgbw[side]) HIP_TRY(hipFree(S.rgbw[side]));
+    if (S.found[side]) HIP_TRY(hipFree(S.found[side]));
+    S.sdf[side] = S.wgt[side] = nullptr;
+    S.rgbw[side] = nullptr;
+    S.found[side] = nullptr;
+    const long long cv = std::max<long long>(vox + vox / 2, 1 << 16);
+    const int ci = std::max(n_items + n_items / 2, 1024);
+    HIP_TRY(hipMalloc(&S.sdf[side], (size_t)cv * sizeof(float)));
+    HIP_TRY(hipMalloc(&S.wgt[side], (size_t)cv * sizeof(float)));
+    if (color) HIP_TRY(hipMalloc(&S.rgbw[side], (size_t)cv * 4));
+    HIP_TRY(hipMalloc(&S.found[side], (size_t)ci * sizeof(int)));
+    S.cap_vox[side] = cv;
+    S.cap_items[side] = ci;
+    (void)g;
+    return CHISEL_HIP_OK;
+}
+
 int update_meshes(chisel_hip_map *g, int force) {
     if (!force && (g->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;  // Chisel.cpp:53-58: every 10th call
     const int W = n_shards(g);
     if (W == 1) return chisel_hip_update_meshes(g->shards[0], 1);
-    // meshesToUpdate of the whole map, as (x, y, z, 1) entries (already the 27-neighbourhoods: chisel_hip_meshes_to_update expands)
+    MeshStages &MS = *static_cast<MeshStages *>(g->mesh_stages_group);
+    // ---- A: meshesToUpdate of the whole map, as (x, y, z, 1) entries (already the 27-neighbourhoods: chisel_hip_meshes_to_update expands)
     std::vector<int> uni;
     int rc = gather_ids(g, chisel_hip_meshes_to_update, true, uni);
     if (rc) return rc;
@@ -290,77 +463,99 @@ int update_meshes(chisel_hip_map *g, int force) {
         entries.push_back(1);
     }
     const bool color = g->cfg.use_color != 0;
-    for (int r = 0; r < W; r++) {
-        // the plan of shard r: its jobs and, per ghost it needs, the shell that travels (chisel_hip_mesh_shell_plan: one item per ghost,
-        // ascending by owner)
+    struct Ask {            // what shard r needs of owner o
+        std::vector<int> it4;
+        long long vox = 0;
+    };
+    std::vector<std::vector<int>> jobs((size_t)W);
+    std::vector<Ask> ask((size_t)W * W);
+    rc = run_shards(g, [&](int r) -> int {  // (the plans are independent of each other: one per thread)
         int64_t nj = 0, ni = 0;
-        rc = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, nullptr, 0, &nj, nullptr, 0, &ni);
-        if (rc) return rc;
-        std::vector<int> jobs((size_t)nj * 3), items((size_t)ni * 5);
-        rc = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, jobs.data(), nj, &nj, items.data(), ni, &ni);
-        if (rc) return rc;
-        chisel_hip_map *dst = g->shards[r];
-        for (int64_t lo = 0; lo < ni;) {
-            const int o = items[5 * lo];
-            int64_t hi = lo;
-            std::vector<int> it4;
-            long long vox = 0;
-            while (hi < ni && items[5 * hi] == o) {
-                it4.insert(it4.end(), items.begin() + 5 * hi + 1, items.begin() + 5 * hi + 5);
-                vox += shell_volume(items[5 * hi + 4], g->N);
-                hi++;
-            }
-            const int n = (int)(hi - lo);
-            lo = hi;
-            chisel_hip_map *src = g->shards[o];
-            // payload: packed into HBM on the owner's device, brought to the meshing shard's device, installed from HBM
-            float *sdf = nullptr, *wgt = nullptr;
-            uint8_t *rgbw = nullptr;
-            int *found = nullptr;
-            HIP_TRY(hipSetDevice(src->device));
-            HIP_TRY(hipMalloc(&sdf, (size_t)vox * sizeof(float)));
-            HIP_TRY(hipMalloc(&wgt, (size_t)vox * sizeof(float)));
-            HIP_TRY(hipMalloc(&found, (size_t)n * sizeof(int)));
-            if (color) HIP_TRY(hipMalloc(&rgbw, (size_t)vox * 4));
-            rc = chisel_hip_export_shells(src, it4.data(), n, sdf, wgt, rgbw, found, 1);
-            if (!rc) rc = chisel_hip_synchronize(src);  // the payload is complete (the peer copies below run on no stream of the owner)
-            float *sdf2 = sdf, *wgt2 = wgt;
-            uint8_t *rgbw2 = rgbw;
-            int *found2 = found;
-            if (!rc && src->device != dst->device) {
-                HIP_TRY(hipSetDevice(dst->device));
-                HIP_TRY(hipMalloc(&sdf2, (size_t)vox * sizeof(float)));
-                HIP_TRY(hipMalloc(&wgt2, (size_t)vox * sizeof(float)));
-                HIP_TRY(hipMalloc(&found2, (size_t)n * sizeof(int)));
-                if (color) HIP_TRY(hipMalloc(&rgbw2, (size_t)vox * 4));
-                HIP_TRY(hipMemcpyPeer(sdf2, dst->device, sdf, src->device, (size_t)vox * sizeof(float)));
-                HIP_TRY(hipMemcpyPeer(wgt2, dst->device, wgt, src->device, (size_t)vox * sizeof(float)));
-                HIP_TRY(hipMemcpyPeer(found2, dst->device, found, src->device, (size_t)n * sizeof(int)));
-                if (color) HIP_TRY(hipMemcpyPeer(rgbw2, dst->device, rgbw, src->device, (size_t)vox * 4));
-            }
-            if (!rc) rc = chisel_hip_import_ghost_shells(dst, it4.data(), n, sdf2, wgt2, rgbw2, found2, 1);
-            if (!rc) rc = chisel_hip_synchronize(dst);  // the import has read the payload
-            if (sdf2 != sdf) {
-                (void)hipSetDevice(dst->device);
-                (void)hipFree(sdf2);
-                (void)hipFree(wgt2);
-                (void)hipFree(found2);
-                if (rgbw2) (void)hipFree(rgbw2);
-            }
-            (void)hipSetDevice(src->device);
-            (void)hipFree(sdf);
-            (void)hipFree(wgt);
-            (void)hipFree(found);
-            if (rgbw) (void)hipFree(rgbw);
-            if (rc) return rc;
-            g->ghost_bytes += (uint64_t)vox * (color ? 12 : 8);
+        int rc2 = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, nullptr, 0, &nj, nullptr, 0, &ni);
+        if (rc2) return rc2;
+        std::vector<int> items((size_t)ni * 5);
+        jobs[(size_t)r].resize((size_t)nj * 3);
+        rc2 = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, jobs[(size_t)r].data(), nj, &nj, items.data(), ni, &ni);
+        if (rc2) return rc2;
+        for (int64_t k = 0; k < ni; k++) {
+            Ask &A = ask[(size_t)r * W + items[5 * k]];
+            A.it4.insert(A.it4.end(), items.begin() + 5 * k + 1, items.begin() + 5 * k + 5);
+            A.vox += shell_volume(items[5 * k + 4], g->N);
         }
-        rc = chisel_hip_update_meshes_of(dst, jobs.data(), (int)nj);
-        if (rc) return rc;
-        rc = chisel_hip_drop_ghost_chunks(dst);
-        if (rc) return rc;
-    }
-    return CHISEL_HIP_OK;
+        return CHISEL_HIP_OK;
+    });
+    if (rc) return rc;
+    // ---- B: owners pack
+    rc = run_shards(g, [&](int o) -> int {
+        chisel_hip_map *src = g->shards[(size_t)o];
+        for (int r = 0; r < W; r++) {
+            const Ask &A = ask[(size_t)r * W + o];
+            if (A.it4.empty()) continue;
+            PairStage &S = MS.pair[(size_t)r * W + o];
+            const int n = (int)(A.it4.size() / 4);
+            int rc2 = ensure_pair(g, S, 0, src->device, A.vox, n, color);
+            if (rc2) return rc2;
+            HIP_TRY(hipSetDevice(src->device));
+            if (!S.exported) {
+                HIP_TRY(hipEventCreateWithFlags(&S.exported, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&S.imported, hipEventDisableTiming));
+            }
+            if (S.armed) {  // the previous recompute's consumer of this buffer
+                rc2 = chisel_hip_wait_event(src, S.imported);
+                if (rc2) return rc2;
+            }
+            rc2 = chisel_hip_export_shells(src, A.it4.data(), n, S.sdf[0], S.wgt[0], S.rgbw[0], S.found[0], 1);
+            if (rc2) return rc2;
+            rc2 = chisel_hip_record_event(src, S.exported);
+            if (rc2) return rc2;
+        }
+        return CHISEL_HIP_OK;
+    });
+    if (rc) return rc;
+    // ---- C: meshing shards install, mesh, drop
+    std::vector<uint64_t> moved((size_t)W, 0);
+    rc = run_shards(g, [&](int r) -> int {
+        chisel_hip_map *dst = g->shards[(size_t)r];
+        for (int o = 0; o < W; o++) {
+            const Ask &A = ask[(size_t)r * W + o];
+            if (A.it4.empty()) continue;
+            PairStage &S = MS.pair[(size_t)r * W + o];
+            chisel_hip_map *src = g->shards[(size_t)o];
+            const int n = (int)(A.it4.size() / 4);
+            int side = 0;
+            hipEvent_t ready = S.exported;
+            if (src->device != dst->device) {
+                side = 1;
+                int rc2 = ensure_pair(g, S, 1, dst->device, A.vox, n, color);
+                if (rc2) return rc2;
+                HIP_TRY(hipSetDevice(dst->device));
+                hipStream_t &cs = MS.copy[(size_t)r];
+                if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                HIP_TRY(hipStreamWaitEvent(cs, S.exported, 0));
+                if (S.armed) HIP_TRY(hipStreamWaitEvent(cs, S.imported, 0));
+                HIP_TRY(hipMemcpyPeerAsync(S.sdf[1], dst->device, S.sdf[0], src->device, (size_t)A.vox * sizeof(float), cs));
+                HIP_TRY(hipMemcpyPeerAsync(S.wgt[1], dst->device, S.wgt[0], src->device, (size_t)A.vox * sizeof(float), cs));
+                HIP_TRY(hipMemcpyPeerAsync(S.found[1], dst->device, S.found[0], src->device, (size_t)n * sizeof(int), cs));
+                if (color) HIP_TRY(hipMemcpyPeerAsync(S.rgbw[1], dst->device, S.rgbw[0], src->device, (size_t)A.vox * 4, cs));
+                HIP_TRY(hipEventRecord(S.copied, cs));
+                ready = S.copied;
+            }
+            int rc2 = chisel_hip_wait_event(dst, ready);
+            if (rc2) return rc2;
+            rc2 = chisel_hip_import_ghost_shells(dst, A.it4.data(), n, S.sdf[side], S.wgt[side], S.rgbw[side], S.found[side], 1);
+            if (rc2) return rc2;
+            rc2 = chisel_hip_record_event(dst, S.imported);
+            if (rc2) return rc2;
+            S.armed = true;
+            moved[(size_t)r] += (uint64_t)A.vox * (color ? 12 : 8);
+        }
+        int rc2 = chisel_hip_update_meshes_of(dst, jobs[(size_t)r].data(), (int)(jobs[(size_t)r].size() / 3));
+        if (rc2) return rc2;
+        return chisel_hip_drop_ghost_chunks(dst);
+    });
+    for (uint64_t v : moved) g->ghost_bytes += v;
+    return rc;
 }
 
 int list_meshes(chisel_hip_map *g, int *ids, int64_t max_ids, int64_t *count) {

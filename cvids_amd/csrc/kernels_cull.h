@@ -519,6 +519,14 @@ constexpr int CULL_BLOCK = 4;
 #ifndef CULL_EARLY_EXIT
 #define CULL_EARLY_EXIT 1
 #endif
+// CULL_EARLY_EXIT lets waves of cull_kernel leave in front of the workgroup's barriers.  That is sound on GCN / CDNA, where s_barrier
+// counts the waves of the workgroup that are still alive and a terminated wave's LDS writes have retired -- a property of this hardware
+// family, not of the HIP programming model.  This library is built for gfx950 only; any other target must either be vetted for the same
+// behaviour or build with -DCULL_EARLY_EXIT=0 (the exiting waves then sit through the barriers).  The forced-shape tests
+// (CHISEL_HIP_CULL_WAVES, tests/test_gpu_parity.py::test_integration_schedules[cull4 / cull16]) are the guard on the GPU.
+#if CULL_EARLY_EXIT && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "CULL_EARLY_EXIT relies on CDNA barrier semantics (s_barrier counts surviving waves only): build this target with -DCULL_EARLY_EXIT=0"
+#endif
 struct CullSpace {
     int sharded;
     int b;                 // super-block edge in chunks

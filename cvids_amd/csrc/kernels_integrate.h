@@ -65,6 +65,9 @@ namespace chisel_hip {
 #endif
 
 // Round-3 instruction-count work, each switchable for A/B builds (all on by default):
+#ifndef INTEGRATE_PIPE
+#define INTEGRATE_PIPE 0  // records of frame k + 1 requested before frame k is applied (see run_unit)
+#endif
 #ifndef OPT_INSIDE
 #define OPT_INSIDE 1     // chunks whose voxels all project onto the image (WI_INSIDE): no per-voxel image tests, offset by one mad
 #endif
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
 #ifdef CHISEL_PHASES
     unsigned long long ph_last_start = 0, ph_max_unit = 0, ph_exec0 = 0;
     int ph_wid = 0;
-    unsigned long long ph_visit = 0, ph_exec = 0, ph_exec_t = 0, ph_units = 0, ph_band = 0;
+    unsigned long long ph_visit = 0, ph_exec = 0, ph_exec_t = 0, ph_units = 0, ph_band = 0, ph_fr_t = 0;
     unsigned long long ph_f[5] = {0, 0, 0, 0, 0}, ph_ft = 0;
 #define FSTAMP(i, dep) do { asm volatile("" ::"v"(dep)); const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph_f[i] += n_ - ph_ft; ph_ft = n_; } while (0)
     unsigned long long ph_need_l = 0, ph_vox = 0, ph_band_l = 0, ph_carve_w = 0, ph_carve_l = 0, ph_bandcarve_v = 0;
@@ -374,272 +377,309 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
 
             // Frames of the mask: each can touch one of this brick's cells (refine_kernel's conservative test).  A lane whose own cell
             // it cannot touch reads the all-NaN record instead of a pixel and fails every test.
+            // A frame has two halves.  project(): the lane's voxels in the frame's camera, their pixel records requested -- geometry only,
+            // nothing of it depends on the voxels' state.  apply(): verdicts and updates, in frame order.  INTEGRATE_PIPE: the records of
+            // frame k + 1 are requested before frame k is applied, so that their round trip runs beside frame k's arithmetic (for launches
+            // that do not fill the chip: what such a launch takes is the length of its units' chains, and registers are not scarce there).
             const int cr_flags = cr.flags;  // lane k: the cull kernel's flags of (chunk, frame k)
-            while (mask) {
-                const int k = __builtin_ctz(mask);
-                mask &= mask - 1u;
+            struct Proj {
+                int k, flags;         // wave-uniform
+                bool need;            // this lane's cell can be touched by the frame
+                float pcz[VPL];       // camera z of the lane's voxels
+                unsigned off[VPL];    // byte offsets of their records (0: the all-NaN record)
+                PixelRec r[VPL];
+            };
+            auto project = [&](const int k) -> Proj {
+                Proj pj;
+                pj.k = k;
 #ifdef CHISEL_PHASES
-                const unsigned long long fr_t = __builtin_amdgcn_s_memrealtime();
+                ph_ft = __builtin_amdgcn_s_memrealtime();
+                ph_fr_t = ph_ft;
                 ph_visit++;
 #endif
                 const int flags = __builtin_amdgcn_readlane(cr_flags, k);
+                pj.flags = flags;
                 const unsigned frame_cells = (unsigned)__builtin_amdgcn_readlane((int)need_half, k);
                 const FrameCam &F = P.f[k];
                 const CameraParams &C = F.cam;
                 // inCamera = R^T * (voxelCenter - t) (ProjectionIntegrator.h:64), row i of R^T summed as a0 + (a1 + a2)
                 const float dy = wy - C.t[1], dz = wz - C.t[2];
                 const float s2 = C.R[5] * dy + C.R[8] * dz;
-                float dx[VPL], pcz[VPL];
+                float dx[VPL];
+                float (&pcz)[VPL] = pj.pcz;
 #pragma unroll
                 for (int j = 0; j < VPL; j++) {
                     dx[j] = wx[j] - C.t[0];
                     pcz[j] = C.R[2] * dx[j] + s2;
                 }
                 const bool need = (frame_cells & lane_cells) != 0u;
-                const bool may_band = need;
-                const bool may_carve = need && ip.carving;
-                // Branches below are wave-uniform (__any) and the lanes are predicated, so that the counters stay scalar.
-                // From here on a lane's verdicts live in vector registers -- bit masks over its four voxels, per-lane counters that
-                // are summed over the wave once, when the wave retires -- and branches are wave-uniform (__any): the scalar unit
-                // serves all four SIMDs of a CU at about half the vector rate per SIMD, and lane-mask logic (one scalar AND / OR /
-                // popcount per predicate) made it as busy as the vector units.
-                if (__any(need)) {  // else: the whole layer lies outside this frame's band and carve region
-#ifdef CHISEL_PHASES
-                    ph_ft = fr_t;
-#endif
-                    FSTAMP(0, (int)need);
-                    // the quad's state, at the first frame that can touch it (straight into the tuples: no use, no wait)
-                    if (need && !(st & HAVE)) {
-                        s4 = *reinterpret_cast<const QuadF *>((M.sdf + slot_base) + lane_off);
-                        w4 = *reinterpret_cast<const QuadF *>((M.wgt + slot_base) + lane_off);
-                        st |= HAVE;
-                    }
-                    if (COLOR && need && may_band && !(st & HAVEC)) {
-                        c4 = *reinterpret_cast<const QuadU *>((M.rgbw + slot_base) + lane_off);
-                        st |= HAVEC;
-                    }
-                    const float s0 = C.R[3] * dy + C.R[6] * dz;
-                    const float s1 = C.R[4] * dy + C.R[7] * dz;
-                    // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45): invZ = 1.0f / z
-                    float inv_z[VPL];
-                    if (flags & WI_FASTZ) {  // wave-uniform
+                pj.need = need;
+                FSTAMP(0, (int)need);
+                // the quad's state, at the first frame that can touch it (straight into the tuples: no use, no wait)
+                if (need && !(st & HAVE)) {
+                    s4 = *reinterpret_cast<const QuadF *>((M.sdf + slot_base) + lane_off);
+                    w4 = *reinterpret_cast<const QuadF *>((M.wgt + slot_base) + lane_off);
+                    st |= HAVE;
+                }
+                if (COLOR && need && !(st & HAVEC)) {
+                    c4 = *reinterpret_cast<const QuadU *>((M.rgbw + slot_base) + lane_off);
+                    st |= HAVEC;
+                }
+                unsigned (&off)[VPL] = pj.off;
+                PixelRec (&r)[VPL] = pj.r;
+                const float s0 = C.R[3] * dy + C.R[6] * dz;
+                const float s1 = C.R[4] * dy + C.R[7] * dz;
+                // PinholeCamera::ProjectPoint (PinholeCamera.cpp:38-45): invZ = 1.0f / z
+                float inv_z[VPL];
+                if (flags & WI_FASTZ) {  // wave-uniform
 #pragma unroll
-                        for (int j = 0; j < VPL; j++) inv_z[j] = reciprocal_in_range(pcz[j]);
-                    } else {
+                    for (int j = 0; j < VPL; j++) inv_z[j] = reciprocal_in_range(pcz[j]);
+                } else {
 #pragma unroll
-                        for (int j = 0; j < VPL; j++) inv_z[j] = 1.0f / pcz[j];
-                    }
-                    // ---- geometry + projection -> record of every voxel of the quad, the four gathers in flight together --------
-                    // Record offsets are 32 bits against a scalar base; the base is the all-NaN record in front of the frame's image,
-                    // which a voxel that is off the image (or not wanted) reads: it fails the band and the carve test like a skipped
-                    // pixel.  IsPointOnImage (PinholeCamera.cpp:61-64) is 0 <= u < W && 0 <= v < H, and the integrator skips z < 0
-                    // (ProjectionIntegrator.h:68 / :126).  With iu = floor(u) (as int, saturating; INT_MIN for NaN) the image test is
-                    // (unsigned)iu < W && (unsigned)iv < H -- there floor(u) == (int)u (:72 / :131) -- and z == +-0 or NaN gives
-                    // u, v = +-inf / NaN, which fail it, so "z > 0" is the remaining predicate.  The three tests are chained through
-                    // selects (no lane-mask arithmetic).
-                    const char *rec_base = reinterpret_cast<const char *>(F.rec - 1);
-                    const unsigned row_bytes = (unsigned)C.W * (unsigned)sizeof(PixelRec);
-                    unsigned off[VPL];
-                    PixelRec r[VPL];
-                    float zn[VPL];  // camera z, or -1 for a quad this frame cannot touch
-                    if (OPT_INSIDE && (flags & WI_INSIDE)) {  // wave-uniform
-                        // Every voxel of the chunk lies in front of the camera and projects onto the image (cull_chunk_frame): the three
-                        // tests hold, the offset is row * row_bytes + (col + 1) * 8.  A lane this frame cannot touch (`need`, from the cull
-                        // kernel's conservative bounds: its verdicts would fail anyway) reads the NaN record instead of a pixel.
-                        const unsigned nm = need ? 0xffffffffu : 0u;
-#pragma unroll
-                        for (int j = 0; j < VPL; j++) {
-                            const float pcx = C.R[0] * dx[j] + s0, pcy = C.R[1] * dx[j] + s1;
-                            const float u = C.fx * pcx * inv_z[j] + C.cx;
-                            const float v = C.fy * pcy * inv_z[j] + C.cy;
-                            const unsigned iu = (unsigned)floor_to_int(u), iv = (unsigned)floor_to_int(v);
-                            off[j] = (__umul24(iv, row_bytes) + ((iu << 3) + 8u)) & nm;
-                            r[j] = *reinterpret_cast<const PixelRec *>(rec_base + off[j]);
-                        }
-                    } else {
-#pragma unroll
-                    for (int j = 0; j < VPL; j++) zn[j] = need ? pcz[j] : -1.0f;
+                    for (int j = 0; j < VPL; j++) inv_z[j] = 1.0f / pcz[j];
+                }
+                // ---- geometry + projection -> record of every voxel of the quad, the four gathers in flight together --------
+                // Record offsets are 32 bits against a scalar base; the base is the all-NaN record in front of the frame's image,
+                // which a voxel that is off the image (or not wanted) reads: it fails the band and the carve test like a skipped
+                // pixel.  IsPointOnImage (PinholeCamera.cpp:61-64) is 0 <= u < W && 0 <= v < H, and the integrator skips z < 0
+                // (ProjectionIntegrator.h:68 / :126).  With iu = floor(u) (as int, saturating; INT_MIN for NaN) the image test is
+                // (unsigned)iu < W && (unsigned)iv < H -- there floor(u) == (int)u (:72 / :131) -- and z == +-0 or NaN gives
+                // u, v = +-inf / NaN, which fail it, so "z > 0" is the remaining predicate.  The three tests are chained through
+                // selects (no lane-mask arithmetic).
+                const char *rec_base = reinterpret_cast<const char *>(F.rec - 1);
+                const unsigned row_bytes = (unsigned)C.W * (unsigned)sizeof(PixelRec);
+                float zn[VPL];  // camera z, or -1 for a quad this frame cannot touch
+                if (OPT_INSIDE && (flags & WI_INSIDE)) {  // wave-uniform
+                    // Every voxel of the chunk lies in front of the camera and projects onto the image (cull_chunk_frame): the three
+                    // tests hold, the offset is row * row_bytes + (col + 1) * 8.  A lane this frame cannot touch (`need`, from the cull
+                    // kernel's conservative bounds: its verdicts would fail anyway) reads the NaN record instead of a pixel.
+                    const unsigned nm = need ? 0xffffffffu : 0u;
 #pragma unroll
                     for (int j = 0; j < VPL; j++) {
                         const float pcx = C.R[0] * dx[j] + s0, pcy = C.R[1] * dx[j] + s1;
                         const float u = C.fx * pcx * inv_z[j] + C.cx;
                         const float v = C.fy * pcy * inv_z[j] + C.cy;
-                        const int iu = floor_to_int(u), iv = floor_to_int(v);
-                        const int iv_ok = ((unsigned)iu < (unsigned)C.W) ? iv : -1;
-                        const float z_ok = ((unsigned)iv_ok < (unsigned)C.H) ? zn[j] : -1.0f;
-                        // DepthAt(row, col) DepthImage.h:72-76
-                        off[j] = (z_ok > 0.0f) ? __umul24((unsigned)iv, row_bytes) + ((unsigned)iu + 1u) * (unsigned)sizeof(PixelRec) : 0u;
-#ifdef CHISEL_ABLATE_GATHER  // diagnostic (wrong results): what would the kernel cost if the record gathers were coalesced?
-                        r[j] = *reinterpret_cast<const PixelRec *>(rec_base + (off[j] ? (unsigned)((lane * VPL + j + 1) * sizeof(PixelRec)) : 0u));
-#else
+                        const unsigned iu = (unsigned)floor_to_int(u), iv = (unsigned)floor_to_int(v);
+                        off[j] = (__umul24(iv, row_bytes) + ((iu << 3) + 8u)) & nm;
                         r[j] = *reinterpret_cast<const PixelRec *>(rec_base + off[j]);
+                    }
+                } else {
+#pragma unroll
+                for (int j = 0; j < VPL; j++) zn[j] = need ? pcz[j] : -1.0f;
+#pragma unroll
+                for (int j = 0; j < VPL; j++) {
+                    const float pcx = C.R[0] * dx[j] + s0, pcy = C.R[1] * dx[j] + s1;
+                    const float u = C.fx * pcx * inv_z[j] + C.cx;
+                    const float v = C.fy * pcy * inv_z[j] + C.cy;
+                    const int iu = floor_to_int(u), iv = floor_to_int(v);
+                    const int iv_ok = ((unsigned)iu < (unsigned)C.W) ? iv : -1;
+                    const float z_ok = ((unsigned)iv_ok < (unsigned)C.H) ? zn[j] : -1.0f;
+                    // DepthAt(row, col) DepthImage.h:72-76
+                    off[j] = (z_ok > 0.0f) ? __umul24((unsigned)iv, row_bytes) + ((unsigned)iu + 1u) * (unsigned)sizeof(PixelRec) : 0u;
+#ifdef CHISEL_ABLATE_GATHER  // diagnostic (wrong results): what would the kernel cost if the record gathers were coalesced?
+                    r[j] = *reinterpret_cast<const PixelRec *>(rec_base + (off[j] ? (unsigned)((lane * VPL + j + 1) * sizeof(PixelRec)) : 0u));
+#else
+                    r[j] = *reinterpret_cast<const PixelRec *>(rec_base + off[j]);
 #endif
-                    }
-                    }
-                    FSTAMP(1, off[VPL - 1]);
-                    // ---- band tests: bit j of bandm / carvem = voxel j takes the in-band / the carve branch -------------------------
-                    // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail.
-                    float sd[VPL];
-                    unsigned bandm = 0u, carvem = 0u;
+                }
+                }
+                FSTAMP(1, off[VPL - 1]);
+                return pj;
+            };
+            // Branches are wave-uniform (__any) and the lanes predicated; a lane's verdicts are bit masks over its voxels and its counters
+            // per-lane adds, summed over the wave once, when the wave retires: the scalar unit serves all four SIMDs of a CU at about half the
+            // vector rate per SIMD, and lane-mask logic (one scalar AND / OR / popcount per predicate) made it as busy as the vector units.
+            auto apply = [&](const Proj &pj) {
+                const int k = pj.k, flags = pj.flags;
+                const FrameCam &F = P.f[k];
+                const float (&pcz)[VPL] = pj.pcz;
+                const unsigned (&off)[VPL] = pj.off;
+                const PixelRec (&r)[VPL] = pj.r;
+                // ---- band tests: bit j of bandm / carvem = voxel j takes the in-band / the carve branch -------------------------
+                // r.x is NaN for the pixels the reference skips (:74 depth > 50 / :134 isnan / :141 depth > 100): both tests fail.
+                float sd[VPL];
+                unsigned bandm = 0u, carvem = 0u;
 #if OPT_CARVESKIP
-                    // No lane's z interval reaches the carve region (the band) of this frame -- bounds from the cull kernel, conservative:
-                    // the tests would fail for every voxel -- : the verdict stays 0 without the compares.
 #pragma unroll
-                    for (int j = 0; j < VPL; j++) sd[j] = r[j].x - pcz[j];                              // surfaceDist :79 / :139
-                    if (__any(may_band)) {
+                for (int j = 0; j < VPL; j++) sd[j] = r[j].x - pcz[j];                              // surfaceDist :79 / :139
+                {
 #pragma unroll
-                        for (int j = 0; j < VPL; j++) bandm |= (fabsf(sd[j]) < r[j].y + ip.diag) ? (1u << j) : 0u;  // :81 / :144
-                    }
-                    if (__any(may_carve)) {  // (z_carve is -inf when carving is off)
+                    for (int j = 0; j < VPL; j++) bandm |= (fabsf(sd[j]) < r[j].y + ip.diag) ? (1u << j) : 0u;  // :81 / :144
+                }
+                if (ip.carving) {
 #pragma unroll
-                        for (int j = 0; j < VPL; j++) carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;  // :86 / :164 (else branch)
-                        carvem &= ~bandm;
-                    }
+                    for (int j = 0; j < VPL; j++) carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;  // :86 / :164 (else branch)
+                    carvem &= ~bandm;
+                }
 #else
 #pragma unroll
-                    for (int j = 0; j < VPL; j++) {
-                        sd[j] = r[j].x - pcz[j];                                                        // surfaceDist :79 / :139
-                        bandm |= (fabsf(sd[j]) < r[j].y + ip.diag) ? (1u << j) : 0u;                    // :81 / :144
-                        carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;                  // :86 / :164 (else branch)
-                    }
-                    carvem = ip.carving ? (carvem & ~bandm) : 0u;
+                for (int j = 0; j < VPL; j++) {
+                    sd[j] = r[j].x - pcz[j];                                                        // surfaceDist :79 / :139
+                    bandm |= (fabsf(sd[j]) < r[j].y + ip.diag) ? (1u << j) : 0u;                    // :81 / :144
+                    carvem |= (sd[j] > r[j].y + ip.carving_dist) ? (1u << j) : 0u;                  // :86 / :164 (else branch)
+                }
+                carvem = ip.carving ? (carvem & ~bandm) : 0u;
 #endif
-                    FSTAMP(2, bandm | carvem);
-                    t_sdf += (unsigned)__popc(bandm);
+                FSTAMP(2, bandm | carvem);
+                t_sdf += (unsigned)__popc(bandm);
 #ifdef CHISEL_PHASES
-                    ph_need_l += __builtin_popcountll(__ballot(need));
-                    for (int j = 0; j < VPL; j++) ph_vox += __builtin_popcountll(__ballot(off[j] != 0u));
-                    ph_band_l += __builtin_popcountll(__ballot(bandm != 0u));
-                    ph_carve_l += __builtin_popcountll(__ballot(carvem != 0u));
-                    for (int j = 0; j < VPL; j++) ph_bandcarve_v += __builtin_popcountll(__ballot(((bandm | carvem) >> j) & 1u));
-                    if (__any(carvem != 0u)) ph_carve_w++;
+                ph_need_l += __builtin_popcountll(__ballot(pj.need));
+                for (int j = 0; j < VPL; j++) ph_vox += __builtin_popcountll(__ballot(off[j] != 0u));
+                ph_band_l += __builtin_popcountll(__ballot(bandm != 0u));
+                ph_carve_l += __builtin_popcountll(__ballot(carvem != 0u));
+                for (int j = 0; j < VPL; j++) ph_bandcarve_v += __builtin_popcountll(__ballot(((bandm | carvem) >> j) & 1u));
+                if (__any(carvem != 0u)) ph_carve_w++;
 #endif
-                    // `probe`: carve tests on a chunk the reference's map holds before this frame
-                    if (existed) {
-                        t_probe += (unsigned)__popc(carvem);
-                    } else {
-                        unsigned frame_carve = 0u;  // wave-uniform
+                // `probe`: carve tests on a chunk the reference's map holds before this frame
+                if (existed) {
+                    t_probe += (unsigned)__popc(carvem);
+                } else {
+                    unsigned frame_carve = 0u;  // wave-uniform
 #pragma unroll
-                        for (int j = 0; j < VPL; j++) frame_carve += wave_count((carvem >> j) & 1u);
-                        carve_v += (lane == k) ? (int)frame_carve : 0;
-                    }
-                    if (__any(bandm != 0u)) {
+                    for (int j = 0; j < VPL; j++) frame_carve += wave_count((carvem >> j) & 1u);
+                    carve_v = (lane == k) ? (int)frame_carve : carve_v;  // (a frame is visited once)
+                }
+                if (__any(bandm != 0u)) {
 #ifdef CHISEL_PHASES
-                        ph_band++;
+                    ph_band++;
 #endif
-                        bm |= 1u << k;
-                        cm |= 1u << k;
-                        // colour first: the pixels of the in-band voxels whose colour weight is below 8 are requested now (one 4-byte
-                        // gather per voxel, all in flight) and consumed after the sdf arithmetic
-                        unsigned cw[VPL], csh[VPL];
-                        unsigned lastm = 0u;  // OPT_COLOR2: bit j = the word of voxel j was read one byte low (last pixel of a 3-channel image)
-                        int cpix[VPL];
-                        unsigned freshm = 0u;  // bit j: voxel j takes a colour sample
-                        const bool word_gather = COLOR && F.color_channels >= 3;  // wave-uniform
-                        if (COLOR) {
-                            const unsigned image_bytes = (unsigned)(F.ccam.W * F.ccam.H * F.color_channels);
-                            unsigned hasm = 0u;
+                    bm |= 1u << k;
+                    cm |= 1u << k;
+                    // colour first: the pixels of the in-band voxels whose colour weight is below 8 are requested now (one 4-byte
+                    // gather per voxel, all in flight) and consumed after the sdf arithmetic
+                    unsigned cw[VPL], csh[VPL];
+                    unsigned lastm = 0u;  // OPT_COLOR2: bit j = the word of voxel j was read one byte low (last pixel of a 3-channel image)
+                    int cpix[VPL];
+                    unsigned freshm = 0u;  // bit j: voxel j takes a colour sample
+                    const bool word_gather = COLOR && F.color_channels >= 3;  // wave-uniform
+                    if (COLOR) {
+                        const unsigned image_bytes = (unsigned)(F.ccam.W * F.ccam.H * F.color_channels);
+                        unsigned hasm = 0u;
+#pragma unroll
+                        for (int j = 0; j < VPL; j++) {
+                            // one camera: the colour pixel is the depth pixel (its index back from the record offset; in band => on the image)
+                            cpix[j] = SAMECAM ? (int)(off[j] / (unsigned)sizeof(PixelRec)) - 1
+                                              : (((bandm >> j) & 1u) ? color_pixel(F.ccam, wx[j], wy, wz) : -1);
+                            if (!SAMECAM) hasm |= (cpix[j] >= 0) ? (1u << j) : 0u;
+                            freshm |= ((u4(c4, j) >> 24) < 8u) ? (1u << j) : 0u;  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
+                        }
+                        if (SAMECAM) hasm = bandm;
+                        else hasm &= bandm;
+                        freshm &= hasm;
+                        t_col += (unsigned)__popc(freshm);
+                        if (!SAMECAM) t_colsat += (unsigned)__popc(hasm & ~freshm);  // one camera: colsat = sdf - col
+                        if (OPT_COLOR2 && word_gather && __any(freshm != 0u)) {
+                            // (the shift of the image's last pixel is kept as one bit per voxel: the words stay in registers
+                            // through the sdf arithmetic, four shift counts beside them cost the kernel a wave per SIMD)
+                            const unsigned last_word = image_bytes - 4u;
+                            lastm = 0u;
 #pragma unroll
                             for (int j = 0; j < VPL; j++) {
-                                // one camera: the colour pixel is the depth pixel (its index back from the record offset; in band => on the image)
-                                cpix[j] = SAMECAM ? (int)(off[j] / (unsigned)sizeof(PixelRec)) - 1
-                                                  : (((bandm >> j) & 1u) ? color_pixel(F.ccam, wx[j], wy, wz) : -1);
-                                if (!SAMECAM) hasm |= (cpix[j] >= 0) ? (1u << j) : 0u;
-                                freshm |= ((u4(c4, j) >> 24) < 8u) ? (1u << j) : 0u;  // colorVoxel.GetWeight() < 8, ProjectionIntegrator.h:152
+                                unsigned sh;
+                                cw[j] = color_gather2(F.color, ((freshm >> j) & 1u) ? (unsigned)cpix[j] : 0u, (unsigned)F.color_channels, last_word, sh);
+                                lastm |= sh ? (1u << j) : 0u;
                             }
-                            if (SAMECAM) hasm = bandm;
-                            else hasm &= bandm;
-                            freshm &= hasm;
-                            t_col += (unsigned)__popc(freshm);
-                            if (!SAMECAM) t_colsat += (unsigned)__popc(hasm & ~freshm);  // one camera: colsat = sdf - col
-                            if (OPT_COLOR2 && word_gather && __any(freshm != 0u)) {
-                                // (the shift of the image's last pixel is kept as one bit per voxel: the words stay in registers
-                                // through the sdf arithmetic, four shift counts beside them cost the kernel a wave per SIMD)
-                                const unsigned last_word = image_bytes - 4u;
-                                lastm = 0u;
+                        } else if (word_gather && __any(freshm != 0u)) {
 #pragma unroll
-                                for (int j = 0; j < VPL; j++) {
-                                    unsigned sh;
-                                    cw[j] = color_gather2(F.color, ((freshm >> j) & 1u) ? (unsigned)cpix[j] : 0u, (unsigned)F.color_channels, last_word, sh);
-                                    lastm |= sh ? (1u << j) : 0u;
-                                }
-                            } else if (word_gather && __any(freshm != 0u)) {
-#pragma unroll
-                                for (int j = 0; j < VPL; j++)
+                            for (int j = 0; j < VPL; j++)
 #ifdef CHISEL_ABLATE_GATHER
-                                    cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? lane * VPL + j : 0, F.color_channels, image_bytes, csh[j]);
+                                cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? lane * VPL + j : 0, F.color_channels, image_bytes, csh[j]);
 #else
-                                    cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? cpix[j] : 0, F.color_channels, image_bytes, csh[j]);
+                                cw[j] = color_gather(F.color, ((freshm >> j) & 1u) ? cpix[j] : 0, F.color_channels, image_bytes, csh[j]);
 #endif
-                            }
-                        }
-                        // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84; IntegrateColor: weighter->GetWeight(.., truncation) :161-162 --
-                        // weight / (5 * truncation), an IEEE division (11 instructions) unless the cull kernel has established that the
-                        // weight is 1 and 5 * truncation of every pixel under the chunk is in the range where the 4-instruction reciprocal
-                        // is exact (WI_FASTWU; wave-uniform)
-                        float wu[VPL];
-                        if (COLOR && (flags & WI_FASTWU)) {
-#pragma unroll
-                            for (int j = 0; j < VPL; j++) wu[j] = reciprocal_in_range(5.0f * r[j].y);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < VPL; j++) wu[j] = COLOR ? constant_weight(ip.weight, r[j].y) : 1.0f;
-                        }
-#pragma unroll
-                        for (int j = 0; j < VPL; j++) {
-                            float ns = f4(s4, j), nw = f4(w4, j);
-                            dist_integrate(ns, nw, sd[j], wu[j]);
-                            const bool in_band = ((bandm >> j) & 1u) != 0u;
-                            f4(s4, j) = in_band ? ns : f4(s4, j);
-                            f4(w4, j) = in_band ? nw : f4(w4, j);
-                        }
-                        st |= bandm ? DCHG : 0u;
-                        if (COLOR && __any(freshm != 0u)) {
-                            if (word_gather) {
-#pragma unroll
-                                for (int j = 0; j < VPL; j++) {
-                                    const unsigned nc = OPT_COLOR2 ? color_integrate_fresh_bgr(u4(c4, j), cw[j] >> (((lastm >> j) & 1u) * 8u))
-                                                                   : color_integrate_fresh(u4(c4, j), color_word(cw[j], csh[j]));
-                                    u4(c4, j) = ((freshm >> j) & 1u) ? nc : u4(c4, j);
-                                }
-                            } else {  // 1 / 2 channel images
-#pragma unroll
-                                for (int j = 0; j < VPL; j++) {
-                                    if ((freshm >> j) & 1u) {
-                                        unsigned cbits = u4(c4, j);
-                                        uchar4 cv = *reinterpret_cast<uchar4 *>(&cbits);
-                                        uint8_t cr, cg, cb;
-                                        color_at(F.color, cpix[j], F.color_channels, cr, cg, cb);
-                                        cv = color_integrate(cv, cr, cg, cb, 1);
-                                        u4(c4, j) = *reinterpret_cast<unsigned *>(&cv);
-                                    }
-                                }
-                            }
-                            st |= freshm ? CCHG : 0u;
                         }
                     }
-                    FSTAMP(3, f4(s4, 0));
-                    if (__any(carvem != 0u)) {
-                        unsigned hitm = 0u;
+                    // Integrate: voxel.Integrate(surfaceDist, 1.0f) :84; IntegrateColor: weighter->GetWeight(.., truncation) :161-162 --
+                    // weight / (5 * truncation), an IEEE division (11 instructions) unless the cull kernel has established that the
+                    // weight is 1 and 5 * truncation of every pixel under the chunk is in the range where the 4-instruction reciprocal
+                    // is exact (WI_FASTWU; wave-uniform)
+                    float wu[VPL];
+                    if (COLOR && (flags & WI_FASTWU)) {
 #pragma unroll
-                        for (int j = 0; j < VPL; j++) {
-                            const bool hit = ((carvem >> j) & 1u) && (f4(w4, j) > 0.0f) && sdf_below_carve_threshold(f4(s4, j));
-                            hitm |= hit ? (1u << j) : 0u;
-                            const bool decay = COLOR && !(f4(w4, j) < 5.0f);      // :166-177: decay
-                            const float cw_ = decay ? f4(w4, j) - 1.0f : 0.0f;    // else :88-95 / :170 Carve() == Reset()
-                            const float cs_ = decay ? f4(s4, j) : 99999.0f;
-                            f4(w4, j) = hit ? cw_ : f4(w4, j);
-                            f4(s4, j) = hit ? cs_ : f4(s4, j);
+                        for (int j = 0; j < VPL; j++) wu[j] = reciprocal_in_range(5.0f * r[j].y);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < VPL; j++) wu[j] = COLOR ? constant_weight(ip.weight, r[j].y) : 1.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < VPL; j++) {
+                        float ns = f4(s4, j), nw = f4(w4, j);
+                        dist_integrate(ns, nw, sd[j], wu[j]);
+                        const bool in_band = ((bandm >> j) & 1u) != 0u;
+                        f4(s4, j) = in_band ? ns : f4(s4, j);
+                        f4(w4, j) = in_band ? nw : f4(w4, j);
+                    }
+                    st |= bandm ? DCHG : 0u;
+                    if (COLOR && __any(freshm != 0u)) {
+                        if (word_gather) {
+#pragma unroll
+                            for (int j = 0; j < VPL; j++) {
+                                const unsigned nc = OPT_COLOR2 ? color_integrate_fresh_bgr(u4(c4, j), cw[j] >> (((lastm >> j) & 1u) * 8u))
+                                                               : color_integrate_fresh(u4(c4, j), color_word(cw[j], csh[j]));
+                                u4(c4, j) = ((freshm >> j) & 1u) ? nc : u4(c4, j);
+                            }
+                        } else {  // 1 / 2 channel images
+#pragma unroll
+                            for (int j = 0; j < VPL; j++) {
+                                if ((freshm >> j) & 1u) {
+                                    unsigned cbits = u4(c4, j);
+                                    uchar4 cv = *reinterpret_cast<uchar4 *>(&cbits);
+                                    uint8_t cr, cg, cb;
+                                    color_at(F.color, cpix[j], F.color_channels, cr, cg, cb);
+                                    cv = color_integrate(cv, cr, cg, cb, 1);
+                                    u4(c4, j) = *reinterpret_cast<unsigned *>(&cv);
+                                }
+                            }
                         }
-                        t_carved += (unsigned)__popc(hitm);
-                        st |= hitm ? DCHG : 0u;
-                        if (__any(hitm != 0u)) cm |= 1u << k;
+                        st |= freshm ? CCHG : 0u;
                     }
                 }
+                FSTAMP(3, f4(s4, 0));
+                if (__any(carvem != 0u)) {
+                    unsigned hitm = 0u;
+#pragma unroll
+                    for (int j = 0; j < VPL; j++) {
+                        const bool hit = ((carvem >> j) & 1u) && (f4(w4, j) > 0.0f) && sdf_below_carve_threshold(f4(s4, j));
+                        hitm |= hit ? (1u << j) : 0u;
+                        const bool decay = COLOR && !(f4(w4, j) < 5.0f);      // :166-177: decay
+                        const float cw_ = decay ? f4(w4, j) - 1.0f : 0.0f;    // else :88-95 / :170 Carve() == Reset()
+                        const float cs_ = decay ? f4(s4, j) : 99999.0f;
+                        f4(w4, j) = hit ? cw_ : f4(w4, j);
+                        f4(s4, j) = hit ? cs_ : f4(s4, j);
+                    }
+                    t_carved += (unsigned)__popc(hitm);
+                    st |= hitm ? DCHG : 0u;
+                    if (__any(hitm != 0u)) cm |= 1u << k;
+                }
 #ifdef CHISEL_PHASES
-                if (__any(need)) { FSTAMP(4, f4(s4, 0)); ph_exec++; ph_exec_t += __builtin_amdgcn_s_memrealtime() - fr_t; }
+                FSTAMP(4, f4(s4, 0));
+                ph_exec++;
+                ph_exec_t += __builtin_amdgcn_s_memrealtime() - ph_fr_t;
 #endif
+            };
+#if INTEGRATE_PIPE
+            if (mask) {  // (a unit of a chunk without a slot may have no frame of its own: it only counts itself in below)
+                Proj cur = project(__builtin_ctz(mask));
+                mask &= mask - 1u;
+                while (true) {
+                    const bool more = mask != 0u;  // wave-uniform
+                    Proj nxt = cur;
+                    if (more) {
+                        nxt = project(__builtin_ctz(mask));
+                        mask &= mask - 1u;
+                    }
+                    apply(cur);
+                    if (!more) break;
+                    cur = nxt;
+                }
             }
+#else
+            while (mask) {
+                const int k = __builtin_ctz(mask);
+                mask &= mask - 1u;
+                apply(project(k));
+            }
+#endif
 
             PHASE(1);
             // ---- the unit's results -------------------------------------------------------------------------------------

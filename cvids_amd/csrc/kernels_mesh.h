@@ -815,6 +815,52 @@ __global__ void mesh_one_cube_kernel(MapView M, MeshParams P, int jx, int jy, in
     out[1] = nv ? 1.0f : 0.0f;  // IsOccupied (MarchingCubes.h:41-45): the case has a triangle
 }
 
+// MarchingCubes::MeshCube (MarchingCubes.h:73-106), ::InterpolateEdgeVertices (:120-132) and ::CalculateVertexConfiguration (:108-118) for a
+// caller's own cube: eight corner coordinates (3 x 8, column-major as Eigen stores Matrix<float, 3, 8>) and eight distances, no map
+// involved (the statics of the reference's class are public).  One thread.  out: [0] case index, [1] vertices written (0, 3 .. 15),
+// then 12 x 3 edge coordinates (an edge without a sign change keeps zeros: the reference leaves that column unset), 15 x 3 vertex
+// floats in the order MeshCube pushes them (t + 2, t + 1, t) and 15 x 3 normal floats (each triangle's face normal, thrice).
+__global__ void mesh_cube_values_kernel(const float *coords, const float *sdf_in, float *out) {
+    float sdf[8];
+    f3v c[8];
+    for (int i = 0; i < 8; i++) {
+        sdf[i] = sdf_in[i];
+        c[i] = mk3(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]);
+    }
+    int index = 0;
+    for (int i = 0; i < 8; i++) index |= (sdf[i] < 0.0f) ? (1 << i) : 0;
+    f3v edge[12];
+    for (int e = 0; e < 12; e++) {
+        const int e0 = c_mc_edges[e] & 0xF, e1 = c_mc_edges[e] >> 4;
+        edge[e] = mk3(0.0f, 0.0f, 0.0f);
+        if ((sdf[e0] < 0.0f && sdf[e1] >= 0.0f) || (sdf[e0] >= 0.0f && sdf[e1] < 0.0f)) edge[e] = interpolate_vertex(c[e0], c[e1], sdf[e0], sdf[e1]);
+        out[2 + 3 * e] = edge[e].x;
+        out[2 + 3 * e + 1] = edge[e].y;
+        out[2 + 3 * e + 2] = edge[e].z;
+    }
+    const int nv = c_mc_counts[index];
+    const unsigned long long row = c_mc_cases[index];
+    float *v = out + 2 + 36, *n = out + 2 + 36 + 45;
+    for (int t = 0; t < nv; t += 3) {
+        f3v p[3];
+        for (int a = 0; a < 3; a++) p[a] = edge[(int)((row >> (4 * (t + 2 - a))) & 0xF)];
+        const f3v fn = normalized3(cross3v(sub3(p[1], p[0]), sub3(p[2], p[0])));
+        for (int a = 0; a < 3; a++) {
+            v[3 * (t + a)] = p[a].x; v[3 * (t + a) + 1] = p[a].y; v[3 * (t + a) + 2] = p[a].z;
+            n[3 * (t + a)] = fn.x; n[3 * (t + a) + 1] = fn.y; n[3 * (t + a) + 2] = fn.z;
+        }
+    }
+    out[0] = (float)index;
+    out[1] = (float)nv;
+}
+// MarchingCubes::InterpolateVertex (MarchingCubes.h:135-146) for one pair; one thread
+__global__ void interpolate_vertex_kernel(const float *in /* v1 xyz, v2 xyz, sdf1, sdf2 */, float *out) {
+    const f3v r = interpolate_vertex(mk3(in[0], in[1], in[2]), mk3(in[3], in[4], in[5]), in[6], in[7]);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+}
+
 // ChunkManager::GetSDF / GetSDFAndGradient for one host-supplied position (chisel_hip_get_sdf*); one thread
 template <int N>
 __global__ void query_sdf_kernel(MapView M, MeshParams P, float x, float y, float z, int with_gradient, double *out /* dist, gx, gy, gz, found */) {

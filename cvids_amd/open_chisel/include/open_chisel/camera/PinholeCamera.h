@@ -8,12 +8,8 @@
 #include <vector>
 #include "../geometry/Frustum.h"
 #include "../geometry/Geometry.h"
+#include "../geometry/Interpolate.h"  // (its one caller is DepthImage::BilinearInterpolateDepth below)
 namespace chisel {
-// geometry/Interpolate.h:28-36 (its one caller is DepthImage::BilinearInterpolateDepth below)
-inline float LinearInterpolate(float s, float e, float t) { return s + (e - s) * t; }
-inline float BilinearInterpolate(float c00, float c10, float c01, float c11, float tx, float ty) {
-    return LinearInterpolate(LinearInterpolate(c00, c10, tx), LinearInterpolate(c01, c11, tx), ty);
-}
 class Intrinsics {  // Intrinsics.h:31-53: the 3x3 matrix K; fx, fy, cx, cy are entries of it
   public:
     Intrinsics() {

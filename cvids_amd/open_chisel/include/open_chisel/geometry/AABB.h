@@ -22,25 +22,21 @@ class AABB {
         if (max.z() < other.min.z()) return false;
         return true;
     }
-    Plane::IntersectionType Intersects(const Plane &plane) const {  // AABB.cpp:37-70
-        const Vec3 ext = GetExtents();
-        Vec3 corners[8];
-        corners[0] = max;
-        corners[1] = min;
-        corners[2] = min + Vec3(ext(0), 0, 0);
-        corners[3] = min + Vec3(0, ext(1), 0);
-        corners[4] = min + Vec3(0, 0, ext(2));
-        corners[5] = min + Vec3(ext(0), 0, ext(2));
-        corners[6] = min + Vec3(ext(0), ext(1), 0);
-        corners[7] = min + Vec3(0, ext(1), ext(2));
-        float lastdistance = plane.normal.dot(corners[0]) + plane.distance;
-        for (int i = 1; i < 8; i++) {
-            const float distance = plane.normal.dot(corners[i]) + plane.distance;
-            if ((distance <= 0.0f && lastdistance > 0.0f) || (distance >= 0.0f && lastdistance < 0.0f)) return Plane::IntersectionType::Intersects;
-            lastdistance = distance;
+    // AABB.cpp:37-70: the signed distances of eight points, taken in the reference's order -- max, min, then min moved by the (half!)
+    // extents along x, y, z, xz, xy, yz -- and "Intersects" as soon as two consecutive ones lie on different sides
+    Plane::IntersectionType Intersects(const Plane &plane) const {
+        static const unsigned char moved[8] = {0, 0, 1, 2, 4, 5, 3, 6};  // bit a: the point is min + extents along axis a (entry 0 stands for max)
+        const Vec3 half = GetExtents();
+        float previous = 0.0f;
+        for (int i = 0; i < 8; i++) {
+            Vec3 p = i == 0 ? max : min;
+            for (int a = 0; a < 3; a++)
+                if (i > 0 && ((moved[i] >> a) & 1)) p(a) = min(a) + half(a);
+            const float d = plane.normal.dot(p) + plane.distance;
+            if (i > 0 && ((d <= 0.0f && previous > 0.0f) || (d >= 0.0f && previous < 0.0f))) return Plane::IntersectionType::Intersects;
+            previous = d;
         }
-        if (lastdistance > 0.0f) return Plane::IntersectionType::Outside;
-        return Plane::IntersectionType::Inside;
+        return previous > 0.0f ? Plane::IntersectionType::Outside : Plane::IntersectionType::Inside;
     }
     Vec3 GetCenter() const { return (max + min) * 0.5f; }  // AABB.h:60-63
     Vec3 GetExtents() const { return (max - min) * 0.5f; }

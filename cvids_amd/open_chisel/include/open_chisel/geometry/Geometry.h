@@ -196,6 +196,41 @@ struct Affine3f {  // camera -> world rigid transform
     Vector3f operator*(const Vector3f &p) const { return R * p + t; }
     static Affine3f Identity() { return Affine3f(); }
 };
+// Matrix<float, R, C> as marching_cubes/MarchingCubes.h uses it (3 x 8 corner coordinates, 8 x 1 distances, 3 x 12 edge vertices):
+// column-major storage like Eigen's default, (r, c) / (i) access, col(c) as a three-vector
+template <class T, int R, int C>
+struct Matrix {
+    T m[R * C];
+    Matrix() {
+        for (int i = 0; i < R * C; i++) m[i] = T(0);
+    }
+    T &operator()(int r, int c) { return m[c * R + r]; }
+    const T &operator()(int r, int c) const { return m[c * R + r]; }
+    T &operator()(int i) { return m[i]; }
+    const T &operator()(int i) const { return m[i]; }
+    struct Col {
+        T *p;
+        operator VecT<T, 3>() const { return VecT<T, 3>(p[0], p[1], p[2]); }
+        Col &operator=(const VecT<T, 3> &v) {
+            p[0] = v(0); p[1] = v(1); p[2] = v(2);
+            return *this;
+        }
+    };
+    struct ConstCol {
+        const T *p;
+        operator VecT<T, 3>() const { return VecT<T, 3>(p[0], p[1], p[2]); }
+    };
+    Col col(int c) {
+        static_assert(R == 3, "columns of three-row matrices");
+        return Col{m + c * R};
+    }
+    ConstCol col(int c) const {
+        static_assert(R == 3, "columns of three-row matrices");
+        return ConstCol{m + c * R};
+    }
+    const T *data() const { return m; }
+    T *data() { return m; }
+};
 template <class T>
 using aligned_allocator = std::allocator<T>;
 }  // namespace Eigen

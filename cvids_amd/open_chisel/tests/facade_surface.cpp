@@ -6,7 +6,12 @@
 // reference's own code guarantees: RecomputeMesh == GenerateMesh -> ColorizeMesh -> ComputeNormalsFromGradients (ChunkManager.cpp:91-128),
 // per-chunk Integrate over the candidates of a frame == IntegrateDepthScanColor of that frame (Chisel.h:114-213), and so on.
 #include <open_chisel/Chisel.h>
+#include <open_chisel/FixedPointFloat.h>
+#include <open_chisel/geometry/Interpolate.h>
+#include <open_chisel/geometry/Raycast.h>
 #include <open_chisel/io/PLY.h>
+#include <open_chisel/marching_cubes/MarchingCubes.h>
+#include <open_chisel/threading/Threading.h>
 
 #include <cmath>
 #include <cstdio>
@@ -267,6 +272,76 @@ int main() {
                 made++;
             }
             CHECK(made > 5);
+        }
+        // ---- marching_cubes/MarchingCubes.h:41-146: the public statics for a cube of the caller's own.  A unit cube cut by the plane
+        // x = 0.25 (corners 0, 3, 4, 7 at x = 0 inside, cubeIndexOffsets order): case 0x99, two triangles, every vertex on the plane, the
+        // normals along x; MeshCube(.., TriangleVector*) holds the same triangles with the vertex order reversed.
+        {
+            MarchingCubes::CornerCoords cc;
+            MarchingCubes::CornerSDF sd;
+            const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+            for (int i = 0; i < 8; i++) {
+                cc.col(i) = Vec3((float)ox[i], (float)oy[i], (float)oz[i]);
+                sd(i) = (float)ox[i] - 0.25f;
+            }
+            CHECK(MarchingCubes::CalculateVertexConfiguration(sd) == 0x99 && MarchingCubes::IsOccupied(sd));
+            CHECK(MarchingCubes::triangleTable()[0][0] == -1 && MarchingCubes::triangleTable()[0x99][6] == -1 && MarchingCubes::edgeIndexPairs()[0][1] == 1);
+            Mesh one;
+            VertIndex next = 0;
+            MarchingCubes::MeshCube(cc, sd, &next, &one);
+            CHECK(next == 6 && one.vertices.size() == 6 && one.normals.size() == 6 && one.indices.size() == 6 && one.indices[5] == 5);
+            for (size_t i = 0; i < 6; i++) CHECK(one.vertices[i](0) == 0.25f && std::fabs(std::fabs(one.normals[i](0)) - 1.0f) < 1e-6f);
+            TriangleVector tris;
+            MarchingCubes::MeshCube(cc, sd, &tris);
+            CHECK(tris.size() == 2);
+            for (int t = 0; t < 2; t++)
+                for (int c = 0; c < 3; c++)
+                    for (int r = 0; r < 3; r++) CHECK(tris[t](r, c) == one.vertices[3 * t + 2 - c](r));
+            MarchingCubes::EdgeCoords ec;
+            MarchingCubes::InterpolateEdgeVertices(cc, sd, &ec);
+            const Vec3 e0 = ec.col(0);  // edge 0 joins corners 0 and 1
+            CHECK(e0(0) == 0.25f && e0(1) == 0.0f && e0(2) == 0.0f);
+            const Vec3 iv = MarchingCubes::InterpolateVertex(Vec3(0, 0, 0), Vec3(1, 0, 0), -0.25f, 0.75f);
+            CHECK(iv(0) == 0.25f);
+            const Vec3 flat = MarchingCubes::InterpolateVertex(Vec3(1, 2, 3), Vec3(2, 2, 2), 0.5f, 0.5f);  // "vertex1 + 0.5 * vertex2" (MarchingCubes.h:141)
+            CHECK(flat(0) == 2.0f && flat(1) == 3.0f && flat(2) == 4.0f);
+            sd(0) = 1.0f; sd(3) = 1.0f; sd(4) = 1.0f; sd(7) = 1.0f;
+            CHECK(!MarchingCubes::IsOccupied(sd));
+        }
+        // ---- geometry/Raycast.h: a diagonal through a 4 x 4 x 4 window, against the chunks Chisel lists for a one-point cloud along the same segment
+        {
+            Point3List cells;
+            Raycast(Vec3(0.5f, 0.5f, 0.5f), Vec3(3.5f, 0.5f, 0.5f), Point3(0, 0, 0), Point3(4, 4, 4), &cells);
+            CHECK(cells.size() == 4 && cells[0] == Point3(0, 0, 0) && cells[3] == Point3(3, 0, 0));
+            cells.clear();
+            Raycast(Vec3(-2.5f, 1.2f, 0.3f), Vec3(5.5f, 1.2f, 0.3f), Point3(0, 0, 0), Point3(4, 4, 4), &cells);  // clipped to the window
+            CHECK(cells.size() == 4 && cells[0] == Point3(0, 1, 0));
+            cells.clear();
+            Raycast(Vec3(0.2f, 0.2f, 0.2f), Vec3(0.8f, 0.7f, 0.1f), Point3(0, 0, 0), Point3(4, 4, 4), &cells);  // inside one cell: nothing (Raycast.cpp:79-80)
+            CHECK(cells.empty());
+            CHECK(signum(-3) == -1.0f && signum(0) == 0.0f && mod(-0.25f, 1.0f) == 0.75f && intbound(0.25f, 1) == 0.75f && intbound(0.25f, -1) == 0.25f);
+        }
+        // ---- geometry/Interpolate.h, FixedPointFloat.h, threading/Threading.h
+        {
+            CHECK(LinearInterpolate(1.0f, 3.0f, 0.25f) == 1.5f && BilinearInterpolate(0.0f, 1.0f, 2.0f, 3.0f, 0.5f, 0.5f) == 1.5f);
+            CHECK(FloatToFixedFloat16(-1000.0f) == 0 && FloatToFixedFloat16(5000.0f) == 65535 && FloatToUFixedFloat16(-3.0f) == 0);
+            CHECK(std::fabs(FixedFloat16ToFloat(FloatToFixedFloat16(12.5f)) - 12.5f) < 0.04f && std::fabs(UFixedFloat16ToFloat(FloatToUFixedFloat16(12.5f)) - 12.5f) < 0.02f);
+            std::vector<int> v(5000, 1);
+            std::mutex mu;
+            long sum = 0;
+            parallel_for(v.begin(), v.end(), [&](int &x) { x += 1; std::lock_guard<std::mutex> g(mu); sum += x; }, 4, 1000);
+            CHECK(sum == 10000);
+            sum = 0;
+            parallel_for(v.begin(), v.begin() + 3, [&](int &x) { sum += x; });  // fewer elements than one group: the calling thread alone
+            CHECK(sum == 6);
+        }
+        // ---- AABB::Intersects(Plane) (AABB.cpp:37-70)
+        {
+            const AABB unit(Vec3(0, 0, 0), Vec3(1, 1, 1));
+            CHECK(unit.Intersects(Plane(1.0f, 0.0f, 0.0f, -0.25f)) == Plane::IntersectionType::Intersects);
+            CHECK(unit.Intersects(Plane(1.0f, 0.0f, 0.0f, 1.0f)) == Plane::IntersectionType::Outside);
+            CHECK(unit.Intersects(Plane(1.0f, 0.0f, 0.0f, -2.0f)) == Plane::IntersectionType::Inside);
+            CHECK(unit.Intersects(Plane(0.0f, 1.0f, 0.0f, -0.75f)) == Plane::IntersectionType::Intersects);  // between min + half extent and max
         }
         cm.PrintMemoryStatistics();
         printf("facade_surface ok: %zu candidates, %zu per-chunk integrations, %zu vertices\n", ids.size(), created, mine.vertices.size());

@@ -121,16 +121,35 @@ class PipelinedExchange:
         self.free = [torch.cuda.Event() for _ in range(2)]
         for e in self.ready + self.free:  # a first record creates the hipEvent_t behind the torch object
             e.record(self.comm)
+        self.timing = False   # measure(): pairs of timing events around every collective, on the communication stream
+        self.timed = []
 
     def exchange(self, b, local_depth, local_meta, local_color=None):
         torch = self.torch
         self.comm.wait_stream(torch.cuda.current_stream())  # the local slots were produced on the caller's stream
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.free[b & 1])
+            if self.timing:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.comm)
             out = self.x.exchange(local_depth, local_meta, local_color, buffer=b & 1)
+            if self.timing:
+                t1.record(self.comm)
+                self.timed.append((t0, t1))
             self.ready[b & 1].record(self.comm)
         self.map.wait_event(self.ready[b & 1].cuda_event)
         return out
+
+    def measure(self, on):
+        """switch the timing of the collectives on / off; switching off returns their durations in microseconds (after a device sync)"""
+        self.timing = bool(on)
+        if on:
+            self.timed = []
+            return None
+        self.torch.cuda.synchronize()
+        us = [a.elapsed_time(b) * 1e3 for a, b in self.timed]
+        self.timed = []
+        return us
 
     def consumed(self, b):
         self.map.record_event(self.free[b & 1].cuda_event)

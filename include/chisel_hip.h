@@ -328,8 +328,9 @@ int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, 
  *                                every rank can evaluate it for every other rank, so the request lists need no exchange
  *   chisel_hip_export_shells     the boxes of the listed chunks of this shard, packed (device pointers with on_device: no wait);
  *                                found[j] = 0 and default voxels for a chunk that is not resident
- *   chisel_hip_import_ghost_shells  installs them as ghost chunks (only the box is written; honours chisel_hip_wait_event);
- *                                chisel_hip_drop_ghost_chunks removes them again */
+ *   chisel_hip_import_ghost_shells  installs them as ghost chunks (only the box is written; honours chisel_hip_wait_event; with
+ *                                on_device nothing is allocated or waited for: queued on the map's stream);
+ *                                chisel_hip_drop_ghost_chunks removes them again (queued as well) */
 int chisel_hip_dirty_ids_device(chisel_hip_map *map, int *out_dev, int capacity);
 int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shards, int rank, int shard_block, int *jobs, int64_t max_jobs,
                                int64_t *n_jobs, int *items, int64_t max_items, int64_t *n_items);
@@ -399,6 +400,28 @@ int chisel_hip_generate_mesh(chisel_hip_map *map, const int id_xyz[3], int stage
 int chisel_hip_set_profiling(chisel_hip_map *map, int enable);
 /* total milliseconds and launch counts per CHISEL_HIP_KERNEL_* since enabled / last reset */
 int chisel_hip_get_profile(chisel_hip_map *map, double *ms_total, int64_t *launches, int reset_profile);
+/* The public statics of marching_cubes/MarchingCubes.h:41-146 for a caller's own cube, on the device (no map involved; the current
+ * HIP device):
+ *   chisel_hip_mc_tables          triangleTable[256][16] (-1 terminated rows) and edgeIndexPairs[12][2] (MarchingCubes.cpp:29-302)
+ *   chisel_hip_mesh_cube_values   vertex_coords: 3 x 8 column-major, vertex_sdf: 8 -> CalculateVertexConfiguration (:108-118),
+ *                                 InterpolateEdgeVertices (:120-132; edge_coords 3 x 12 column-major, zeros where the reference leaves a
+ *                                 column unset; may be null) and MeshCube(.., Mesh*) (:73-106): up to 15 vertices in push order
+ *                                 (t + 2, t + 1, t) with each triangle's face normal thrice (vertices / normals: 45 floats each; may be null)
+ *   chisel_hip_interpolate_vertex InterpolateVertex (:135-146), "vertex1 + 0.5 * vertex2" included
+ * and geometry/Raycast.h:9 / Raycast.cpp:35-128: the cells of [min, max) the segment start -> end meets, in order (cells: capacity x 3
+ * ints; *count = cells met, which may exceed capacity). */
+int chisel_hip_mc_tables(int *triangle_table, int *edge_index_pairs);
+int chisel_hip_mesh_cube_values(const float *vertex_coords, const float *vertex_sdf, float *edge_coords, int *configuration, float *vertices,
+                                float *normals, int *n_vertices);
+int chisel_hip_interpolate_vertex(const float v1[3], const float v2[3], float sdf1, float sdf2, float out[3]);
+int chisel_hip_raycast(const float start[3], const float end[3], const int min_xyz[3], const int max_xyz[3], int *cells, int64_t capacity,
+                       int64_t *count);
+/* Which shapes the launch heuristics picked since the map was created / last reset of these figures (no reference counterpart: a
+ * diagnostic beside chisel_hip_get_profile): out[0..7] = integration launches at 2 voxels per lane, at 4, at 4 with a 2-voxel tail;
+ * cull launches with four waves per workgroup, with one wave per frame; launch sets without an order kernel; launch sets in the
+ * short single-stream form; launch sets in all.  A group handle sums its shards. */
+#define CHISEL_HIP_NUM_LAUNCH_STATS 8
+int chisel_hip_get_launch_stats(chisel_hip_map *map, int64_t *out, int reset_stats);
 /* owner shard of a chunk id under (n_shards, shard_block); pure function, same on every rank */
 int chisel_hip_chunk_owner(const int id_xyz[3], int n_shards, int shard_block);
 

@@ -38,6 +38,37 @@ def test_two_ranks_launched_by_bench_itself_equal_one_rank():
     assert two["value"] > 0 and two["steps"] == 20 and two["warmup"] == 5
 
 
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="two RCCL ranks need two GPUs (RCCL refuses to share a device); the GPU test box has one")
+def test_two_rccl_ranks_equal_one_rank():
+    """The same equality over backend "nccl" (= RCCL) on two physical GPUs: the first run of the sharded mesher's device all_to_all with
+    non-empty payloads and event-ordered buffers, and of the frame all-gather between two devices.  Skipped on a one-GPU box -- which is
+    every box these tests have run on so far: until this test has passed somewhere, the N > 1 RCCL path is covered by world-1 RCCL,
+    world-2 gloo and the in-process group only."""
+    common = ["--steps", "20", "--warmup", "5", "--width", "320", "--height", "240", "--res", "0.02", "--no-cpu-baseline", "--no-roofline",
+              "--repeats", "2"]
+    one = _bench("--gpus", "1", *common)
+    two = _bench("--gpus", "2", "--dist-backend", "nccl", *common)
+    assert two["n_gpus"] == 2 and two["sharded_meshing"]["recomputes"] > 0
+    for k in ("voxel_updates", "n_sdf", "n_col", "n_probe", "n_carved", "resident_chunks_end"):
+        assert one["per_frame"][k] == two["per_frame"][k], (k, one["per_frame"][k], two["per_frame"][k])
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
+def test_group_on_two_devices_equals_one_map():
+    """chisel_hip_create_group over devices [0, 1]: peer copies of device frames and of the mesher's shells between two physical GPUs."""
+    common = ["--steps", "20", "--warmup", "5", "--width", "320", "--height", "240", "--res", "0.02", "--no-cpu-baseline", "--no-roofline",
+              "--repeats", "2"]
+    one = _bench("--gpus", "1", *common)
+    two = _bench("--gpus", "1", "--group", "2", *common)
+    for k in ("voxel_updates", "n_sdf", "n_col", "n_probe", "n_carved", "resident_chunks_end"):
+        assert one["per_frame"][k] == two["per_frame"][k], (k, one["per_frame"][k], two["per_frame"][k])
+
+
 def test_config5_line_carries_gc_and_full_extraction():
     line = _bench("--gpus", "1", "--config", "5", "--steps", "8", "--warmup", "4", "--width", "320", "--height", "180", "--res", "0.02",
                   "--trunc-scale", "2.0", "--no-roofline", "--repeats", "1")

@@ -18,12 +18,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _devices(n):
+    """device ordinal of every shard: all on device 0 (the test boxes have one GPU), or dealt over CHISEL_HIP_TEST_DEVICES=0,1,...
+    (tools/first_contact.sh on a multi-GPU node: the peer copies between devices then run for real)"""
+    listed = [int(v) for v in os.environ.get("CHISEL_HIP_TEST_DEVICES", "0").split(",") if v.strip() != ""] or [0]
+    return [listed[i % len(listed)] for i in range(n)]
+
+
 @pytest.mark.parametrize("n_shards", [2, 4, 8])
 def test_group_equals_oracle_and_single_map(oracle_mod, tmp_path, n_shards):
     from cvids_amd import chisel as ch
     N, res, W, H = 16, 0.04, 96, 72
     om, single, integ = _mk(oracle_mod, N, res, True, max_chunks=4096)
-    grp = ch.Chisel((N,) * 3, res, True, max_chunks=4096, devices=[0] * n_shards)
+    grp = ch.Chisel((N,) * 3, res, True, max_chunks=4096, devices=_devices(n_shards))
     cam = small_camera(W, H)
     intr = (cam.fx, cam.fy, cam.cx, cam.cy)
     color = synth.render_color(W, H, 3)
@@ -73,7 +80,7 @@ def test_group_equals_oracle_and_single_map(oracle_mod, tmp_path, n_shards):
     single.SaveMap(str(tmp_path / "s.map"))
     grp.SaveMap(str(tmp_path / "g.map"))
     assert open(tmp_path / "s.map", "rb").read() == open(tmp_path / "g.map", "rb").read()
-    grp2 = ch.Chisel((N,) * 3, res, True, max_chunks=4096, devices=[0] * n_shards)
+    grp2 = ch.Chisel((N,) * 3, res, True, max_chunks=4096, devices=_devices(n_shards))
     grp2.LoadMap(str(tmp_path / "s.map"))
     compare_fields(om.fields(), grp2.fields(), om.V, True, what="group loaded from a single map's dump")
     # garbage collection is routed to the owners
