@@ -67,7 +67,7 @@ EXPORTS = [
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
-    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_cloud_candidates", "chisel_hip_mesh_cube", "chisel_hip_write_mesh_ply", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan",
+    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_cloud_candidates", "chisel_hip_mesh_cube", "chisel_hip_write_mesh_ply", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan", "chisel_hip_mesh_shell_plan_all",
     "chisel_hip_shell_volume", "chisel_hip_export_shells", "chisel_hip_import_ghost_shells", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_get_launch_stats", "chisel_hip_mc_tables", "chisel_hip_mesh_cube_values", "chisel_hip_interpolate_vertex", "chisel_hip_raycast", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
 ]
 # the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
@@ -167,6 +167,7 @@ def load_library():
         L.chisel_hip_recompute_mesh.argtypes = [vp, i32p]
         L.chisel_hip_dirty_ids_device.argtypes = [vp, vp, C.c_int]
         L.chisel_hip_mesh_shell_plan.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]
+        L.chisel_hip_mesh_shell_plan_all.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]
         L.chisel_hip_shell_volume.argtypes = [C.c_int, C.c_int]
         L.chisel_hip_shell_volume.restype = C.c_int64
         L.chisel_hip_export_shells.argtypes = [vp, i32p, C.c_int, vp, vp, vp, vp, C.c_int]

@@ -651,5 +651,21 @@ def mesh_shell_plan(entries, n_shards, rank, shard_block=2):
     return jobs, items
 
 
+def mesh_shell_plan_all(entries, n_shards, shard_block=2):
+    """chisel_hip_mesh_shell_plan_all: the plans of all ranks in one pass ->
+    (jobs: list per rank of (nj, 3) arrays, items: dict (r, o) -> (n, 4) array of (x, y, z, box) that r asks of o)"""
+    L = capi.load_library()
+    e = np.ascontiguousarray(np.asarray(entries, np.int32).reshape(-1, 4))
+    W = int(n_shards)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+    jo, io = np.zeros(W + 1, np.int64), np.zeros(W * W + 1, np.int64)
+    lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    check(L.chisel_hip_mesh_shell_plan_all(ip(e), len(e), W, int(shard_block), None, 0, lp(jo), None, 0, lp(io)))
+    jobs, items = np.zeros((int(jo[W]), 3), np.int32), np.zeros((int(io[W * W]), 4), np.int32)
+    check(L.chisel_hip_mesh_shell_plan_all(ip(e), len(e), W, int(shard_block), ip(jobs), len(jobs), lp(jo), ip(items), len(items), lp(io)))
+    return ([jobs[jo[r]:jo[r + 1]] for r in range(W)],
+            {(r, o): items[io[r * W + o]:io[r * W + o + 1]] for r in range(W) for o in range(W) if io[r * W + o + 1] > io[r * W + o]})
+
+
 def shell_volume(box, chunk_edge):
     return int(capi.load_library().chisel_hip_shell_volume(int(box), int(chunk_edge)))

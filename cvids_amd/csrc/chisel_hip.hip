@@ -1844,6 +1844,185 @@ int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shar
             }
     return CHISEL_HIP_OK;
 }
+// The plans of ALL ranks in one pass (what every rank of the multi-process form and the in-library group need per recompute: their
+// own jobs, what they ask of every owner and what every other rank asks of them).  Same result, rank by rank, as
+// chisel_hip_mesh_shell_plan -- which walks std::set / std::map node by node, once per rank: 1-2 ms per rank and recompute at
+// 640x480 / 1 cm, i.e. 10-15 ms of host time per recompute on 8 ranks, against the 0.1 ms the GPUs need per step -- in 0.2-0.4 ms for
+// all of them: one dense grid over the bounding box of the entries (job flags, "next to a job" flags), one owner per 2x2x2 super-block,
+// and a single sweep over the cells next to a job in ascending id order: cell G, owned by o, is asked for by rank r through direction
+// d whenever J = G - d is a job of r -- so every (r, o) list comes out sorted by id without a sort.
+//   jobs:  ids, rank by rank (job_offsets[r] .. job_offsets[r + 1], in ids), ascending (x, y, z) within a rank
+//   items: (x, y, z, box) of pair p = r * n_shards + o = what r asks of o (item_offsets[p] .. item_offsets[p + 1]), ascending id, then box
+// Counts are always written (offsets hold n_shards + 1 and n_shards^2 + 1 entries); the arrays only when both capacities suffice.
+int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_shards, int shard_block, int *jobs, int64_t max_jobs, int64_t *job_offsets,
+                                   int *items, int64_t max_items, int64_t *item_offsets) {
+    if ((n_entries > 0 && !entries) || n_shards < 1 || n_shards > 64 || !job_offsets || !item_offsets) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    const int W = n_shards, sb = shard_block < 1 ? 2 : shard_block;
+    // bounding box of the jobs (entries, flag 0 expanded by one), plus two more cells (below)
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (int64_t i = 0; i < n_entries; i++) {
+        const int *e = entries + 4 * i, r = e[3] ? 0 : 1;
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], e[a] - r);
+            hi[a] = std::max(hi[a], e[a] + r);
+        }
+    }
+    thread_local std::vector<std::vector<int>> job_of, item_of;  // per rank / per pair, kept between calls (capacity, and the result itself)
+    // a caller asks twice -- sizes, then contents --: the second call finds the first one's result (same thread, same entries)
+    thread_local uint64_t cached_key = 0;
+    uint64_t key = 1469598103934665603ull ^ (uint64_t)W ^ ((uint64_t)sb << 8) ^ ((uint64_t)n_entries << 16);
+    for (int64_t i = 0; i < 4 * n_entries; i++) key = (key ^ (uint64_t)(uint32_t)entries[i]) * 1099511628211ull;
+    const bool cached = key == cached_key && (int)job_of.size() == W && (int)item_of.size() == W * W;
+    cached_key = 0;  // (set again below once the result is complete)
+    if (!cached) {
+    job_of.resize((size_t)W);
+    item_of.resize((size_t)W * W);
+    for (auto &v : job_of) v.clear();
+    for (auto &v : item_of) v.clear();
+    }
+    if (n_entries > 0 && !cached) {
+        int dim[3];
+        double cells_d = 1.0;
+        for (int a = 0; a < 3; a++) {
+            lo[a] -= 2;  // (the jobs' neighbours G, and the neighbours J = G - d of those)
+            hi[a] += 2;
+            dim[a] = hi[a] - lo[a] + 1;
+            cells_d *= (double)dim[a];
+        }
+        if (cells_d > 2.5e8) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "mesh plan: the updated chunks span more than 2.5e8 cells");
+        const size_t cells = (size_t)cells_d;
+        thread_local std::vector<unsigned char> flag;  // bit 0: job, bit 1: next to a job (or one itself)
+        flag.assign(cells, 0);
+        const size_t sy = (size_t)dim[2], sx = (size_t)dim[1] * dim[2];
+        auto cell = [&](int x, int y, int z) { return (size_t)(x - lo[0]) * sx + (size_t)(y - lo[1]) * sy + (size_t)(z - lo[2]); };
+        for (int64_t i = 0; i < n_entries; i++) {
+            const int *e = entries + 4 * i, r = e[3] ? 0 : 1;
+            for (int dx = -r; dx <= r; dx++)
+                for (int dy = -r; dy <= r; dy++)
+                    for (int dz = -r; dz <= r; dz++) {
+                        const size_t c = cell(e[0] + dx, e[1] + dy, e[2] + dz);
+                        if (flag[c] & 1) continue;
+                        flag[c] |= 1;
+                        for (int ax = -1; ax <= 1; ax++)
+                            for (int ay = -1; ay <= 1; ay++) {
+                                unsigned char *row = &flag[c + (size_t)((long)ax * (long)sx + (long)ay * (long)sy)];
+                                row[-1] |= 2; row[0] |= 2; row[1] |= 2;
+                            }
+                    }
+        }
+        // owner of a cell through its super-block: per axis the block index of every coordinate, per block the owner (chunk_owner's arithmetic)
+        std::vector<int> bidx[3];
+        int b0[3], nb[3];
+        for (int a = 0; a < 3; a++) {
+            b0[a] = floor_div(lo[a], sb);
+            nb[a] = floor_div(hi[a], sb) - b0[a] + 1;
+            bidx[a].resize((size_t)dim[a]);
+            for (int k = 0; k < dim[a]; k++) bidx[a][(size_t)k] = floor_div(lo[a] + k, sb) - b0[a];
+        }
+        std::vector<unsigned char> bowner((size_t)nb[0] * nb[1] * nb[2]);
+        for (int bx = 0; bx < nb[0]; bx++)
+            for (int by = 0; by < nb[1]; by++)
+                for (int bz = 0; bz < nb[2]; bz++)
+                    bowner[((size_t)bx * nb[1] + by) * nb[2] + bz] = (unsigned char)chunk_owner((b0[0] + bx) * sb, (b0[1] + by) * sb, (b0[2] + bz) * sb, W, sb);
+        auto owner_at = [&](int ix, int iy, int iz) { return (int)bowner[((size_t)bidx[0][(size_t)ix] * nb[1] + bidx[1][(size_t)iy]) * nb[2] + bidx[2][(size_t)iz]]; };
+        // box code of direction d = G - J (what J reads of G): per axis d > 0 -> {0, 1} (1), d < 0 -> {N - 1} (2), 0 -> all (0)
+        auto axis_within = [](int a, int b) { return b == 0 || a == b || (b == 3 && a != 0); };
+        auto box_within = [&](int a, int b) { return axis_within(a & 3, b & 3) && axis_within((a >> 2) & 3, (b >> 2) & 3) && axis_within((a >> 4) & 3, (b >> 4) & 3); };
+        unsigned asked[64];  // per requesting rank: the directions (bit (dx + 1) * 9 + (dy + 1) * 3 + dz + 1) through which G is asked for
+        for (int ix = 0; ix < dim[0]; ix++)
+            for (int iy = 0; iy < dim[1]; iy++) {
+                const unsigned char *row = &flag[(size_t)ix * sx + (size_t)iy * sy];
+                for (int iz = 0; iz < dim[2]; iz++) {
+                    if (!row[iz]) continue;
+                    const int gx = lo[0] + ix, gy = lo[1] + iy, gz = lo[2] + iz;
+                    const int o = owner_at(ix, iy, iz);
+                    if (row[iz] & 1) {
+                        std::vector<int> &jv = job_of[(size_t)o];
+                        jv.push_back(gx); jv.push_back(gy); jv.push_back(gz);
+                    }
+                    // (cells on the rim of the grid are never next to a job: the box was widened by two beyond the jobs' own rim)
+                    if (ix == 0 || iy == 0 || iz == 0 || ix == dim[0] - 1 || iy == dim[1] - 1 || iz == dim[2] - 1) continue;
+                    unsigned long long who = 0ull;
+                    for (int dx = -1; dx <= 1; dx++)
+                        for (int dy = -1; dy <= 1; dy++)
+                            for (int dz = -1; dz <= 1; dz++) {
+                                if (!dx && !dy && !dz) continue;
+                                const int jx = ix - dx, jy = iy - dy, jz = iz - dz;  // J = G - d
+                                if (!(flag[(size_t)jx * sx + (size_t)jy * sy + (size_t)jz] & 1)) continue;
+                                const int r = owner_at(jx, jy, jz);
+                                if (r == o) continue;
+                                if (!((who >> r) & 1ull)) {
+                                    who |= 1ull << r;
+                                    asked[r] = 0u;
+                                }
+                                asked[r] |= 1u << ((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1));
+                            }
+                    while (who) {
+                        const int r = __builtin_ctzll(who);
+                        who &= who - 1ull;
+                        // the boxes of (r, G): as chisel_hip_mesh_shell_plan builds them, in its order of arrival -- the jobs ascending, i.e. the
+                        // directions d = G - J descending -- : a box another one contains is dropped, then the two ends of one axis become one box
+                        int v[26], nv = 0;
+                        for (int dx = 1; dx >= -1; dx--)
+                            for (int dy = 1; dy >= -1; dy--)
+                                for (int dz = 1; dz >= -1; dz--) {
+                                    if (!((asked[r] >> ((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1))) & 1u)) continue;
+                                    const int d[3] = {dx, dy, dz};
+                                    int box = 0;
+                                    for (int a = 0; a < 3; a++) box |= (d[a] > 0 ? 1 : (d[a] < 0 ? 2 : 0)) << (2 * a);
+                                    bool covered = false;
+                                    for (int k = 0; k < nv; k++) covered = covered || box_within(box, v[k]);
+                                    if (covered) continue;
+                                    int keep = 0;
+                                    for (int k = 0; k < nv; k++)
+                                        if (!box_within(v[k], box)) v[keep++] = v[k];
+                                    nv = keep;
+                                    v[nv++] = box;
+                                }
+                        bool merged = true;
+                        while (merged) {
+                            merged = false;
+                            for (int i = 0; i < nv && !merged; i++)
+                                for (int k = i + 1; k < nv && !merged; k++)
+                                    for (int a = 0; a < 3 && !merged; a++) {
+                                        const int m3 = 3 << (2 * a), ca = (v[i] >> (2 * a)) & 3, cb = (v[k] >> (2 * a)) & 3;
+                                        if ((v[i] & ~m3) == (v[k] & ~m3) && ca != 0 && cb != 0 && ca != cb) {
+                                            v[i] = (v[i] & ~m3) | (3 << (2 * a));
+                                            for (int q = k; q + 1 < nv; q++) v[q] = v[q + 1];
+                                            nv--;
+                                            merged = true;
+                                        }
+                                    }
+                        }
+                        std::sort(v, v + nv);
+                        std::vector<int> &iv = item_of[(size_t)r * W + o];
+                        for (int k = 0; k < nv; k++) {
+                            iv.push_back(gx); iv.push_back(gy); iv.push_back(gz); iv.push_back(v[k]);
+                        }
+                    }
+                }
+            }
+    }
+    cached_key = key;
+    int64_t tj = 0, ti = 0;
+    for (int r = 0; r < W; r++) {
+        job_offsets[r] = tj;
+        tj += (int64_t)job_of[(size_t)r].size() / 3;
+    }
+    job_offsets[W] = tj;
+    for (int p2 = 0; p2 < W * W; p2++) {
+        item_offsets[p2] = ti;
+        ti += (int64_t)item_of[(size_t)p2].size() / 4;
+    }
+    item_offsets[W * W] = ti;
+    if (jobs && items && tj <= max_jobs && ti <= max_items) {
+        for (int r = 0; r < W; r++)
+            if (!job_of[(size_t)r].empty()) memcpy(jobs + 3 * job_offsets[r], job_of[(size_t)r].data(), job_of[(size_t)r].size() * sizeof(int));
+        for (int p2 = 0; p2 < W * W; p2++)
+            if (!item_of[(size_t)p2].empty()) memcpy(items + 4 * item_offsets[p2], item_of[(size_t)p2].data(), item_of[(size_t)p2].size() * sizeof(int));
+    }
+    return CHISEL_HIP_OK;
+}
 // voxels in the payload of a box of a chunk of edge n
 int64_t chisel_hip_shell_volume(int box, int chunk_edge) { return (int64_t)shell_volume(box, chunk_edge); }
 

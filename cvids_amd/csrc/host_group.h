@@ -469,22 +469,22 @@ int update_meshes(chisel_hip_map *g, int force) {
     };
     std::vector<std::vector<int>> jobs((size_t)W);
     std::vector<Ask> ask((size_t)W * W);
-    rc = run_shards(g, [&](int r) -> int {  // (the plans are independent of each other: one per thread)
-        int64_t nj = 0, ni = 0;
-        int rc2 = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, nullptr, 0, &nj, nullptr, 0, &ni);
-        if (rc2) return rc2;
-        std::vector<int> items((size_t)ni * 5);
-        jobs[(size_t)r].resize((size_t)nj * 3);
-        rc2 = chisel_hip_mesh_shell_plan(entries.data(), (int64_t)entries.size() / 4, W, r, g->cfg.shard_block, jobs[(size_t)r].data(), nj, &nj, items.data(), ni, &ni);
-        if (rc2) return rc2;
-        for (int64_t k = 0; k < ni; k++) {
-            Ask &A = ask[(size_t)r * W + items[5 * k]];
-            A.it4.insert(A.it4.end(), items.begin() + 5 * k + 1, items.begin() + 5 * k + 5);
-            A.vox += shell_volume(items[5 * k + 4], g->N);
+    {
+        // the plans of all shards in one pass (chisel_hip_mesh_shell_plan_all)
+        std::vector<int64_t> jo((size_t)W + 1), io((size_t)W * W + 1);
+        rc = chisel_hip_mesh_shell_plan_all(entries.data(), (int64_t)entries.size() / 4, W, g->cfg.shard_block, nullptr, 0, jo.data(), nullptr, 0, io.data());
+        if (rc) return rc;
+        std::vector<int> jflat((size_t)jo[(size_t)W] * 3 + 1), iflat((size_t)io[(size_t)W * W] * 4 + 1);
+        rc = chisel_hip_mesh_shell_plan_all(entries.data(), (int64_t)entries.size() / 4, W, g->cfg.shard_block, jflat.data(), jo[(size_t)W], jo.data(), iflat.data(),
+                                            io[(size_t)W * W], io.data());
+        if (rc) return rc;
+        for (int r = 0; r < W; r++) jobs[(size_t)r].assign(jflat.begin() + 3 * jo[(size_t)r], jflat.begin() + 3 * jo[(size_t)r + 1]);
+        for (int p2 = 0; p2 < W * W; p2++) {
+            Ask &A = ask[(size_t)p2];
+            A.it4.assign(iflat.begin() + 4 * io[(size_t)p2], iflat.begin() + 4 * io[(size_t)p2 + 1]);
+            for (size_t k = 3; k < A.it4.size(); k += 4) A.vox += shell_volume(A.it4[k], g->N);
         }
-        return CHISEL_HIP_OK;
-    });
-    if (rc) return rc;
+    }
     // ---- B: owners pack
     rc = run_shards(g, [&](int o) -> int {
         chisel_hip_map *src = g->shards[(size_t)o];

@@ -291,7 +291,7 @@ class ShardedChisel:
         4. every rank recomputes its jobs and drops the ghosts.
         ids: mesh these chunks (every rank passes ids of its own choice, the union is meshed) instead of meshesToUpdate.
         -> bytes of ghost voxels this rank received"""
-        from .chisel import mesh_shell_plan, shell_volume
+        from .chisel import mesh_shell_plan_all, shell_volume
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return 0
@@ -332,16 +332,15 @@ class ShardedChisel:
             self._dirty_cap = 2 * int(g[:, 0].max())  # (every rank sees the same counts and takes the same turn)
         entries = np.concatenate([g[r, 1:1 + 4 * int(g[r, 0])].reshape(-1, 4) for r in range(world)], axis=0)
         # ---- 2. the plans
-        jobs, items = mesh_shell_plan(entries, world, rank)
-        recv_items = items[:, 1:5]
-        n_recv = [int(np.count_nonzero(items[:, 0] == o)) for o in range(world)]
-        send_parts = []
-        for q in range(world):
-            if q == rank:
-                send_parts.append(np.zeros((0, 4), np.int32))
-            else:
-                it_q = mesh_shell_plan(entries, world, q)[1]
-                send_parts.append(it_q[it_q[:, 0] == rank][:, 1:5])
+        # (all ranks' plans in ONE pass of the planner: chisel_hip_mesh_shell_plan_all -- evaluating chisel_hip_mesh_shell_plan once per
+        # rank cost every rank 1-2 ms per rank and recompute)
+        all_jobs, all_items = mesh_shell_plan_all(entries, world)
+        none = np.zeros((0, 4), np.int32)
+        jobs = all_jobs[rank]
+        recv_parts = [all_items.get((rank, o), none) for o in range(world)]   # what this rank asks of owner o
+        recv_items = np.concatenate(recv_parts, axis=0)
+        n_recv = [len(p) for p in recv_parts]
+        send_parts = [all_items.get((q, rank), none) for q in range(world)]   # what rank q asks of this rank
         send_items = np.concatenate(send_parts, axis=0)
         n_send = [len(p) for p in send_parts]
         vol = lambda it: int(sum(shell_volume(int(b), edge) for b in it[:, 3])) if len(it) else 0

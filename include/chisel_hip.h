@@ -334,6 +334,11 @@ int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, 
 int chisel_hip_dirty_ids_device(chisel_hip_map *map, int *out_dev, int capacity);
 int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shards, int rank, int shard_block, int *jobs, int64_t max_jobs,
                                int64_t *n_jobs, int *items, int64_t max_items, int64_t *n_items);
+/* the plans of ALL ranks in one pass, rank by rank the result of chisel_hip_mesh_shell_plan: jobs of rank r at job_offsets[r] ..
+ * job_offsets[r + 1] (n_shards + 1 offsets, in ids), items (x, y, z, box) that r asks of o at item_offsets[r * n_shards + o] .. [+ 1]
+ * (n_shards^2 + 1 offsets, in items); offsets are always written, the arrays when both capacities suffice */
+int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_shards, int shard_block, int *jobs, int64_t max_jobs,
+                                   int64_t *job_offsets, int *items, int64_t max_items, int64_t *item_offsets);
 int64_t chisel_hip_shell_volume(int box, int chunk_edge);
 int chisel_hip_export_shells(chisel_hip_map *map, const int *items, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device);
 int chisel_hip_import_ghost_shells(chisel_hip_map *map, const int *items, int n, const float *sdf, const float *weight, const uint8_t *rgbw,

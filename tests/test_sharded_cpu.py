@@ -409,3 +409,26 @@ def test_cull_space_enumerates_exactly_the_owned_ids(hip_lib):
         assert seen == set(box)
         if n > 1:
             assert slots <= len(box) + 8 * n * (dim[1] // 2 + 2) * (dim[2] // 2 + 2) * 2   # partial super-blocks and the rounded-up rows only
+
+
+def test_all_ranks_planner_equals_the_per_rank_planner(hip_lib):
+    """chisel_hip_mesh_shell_plan_all (one dense-grid sweep for all ranks) gives, rank by rank, exactly what chisel_hip_mesh_shell_plan
+    (std::set / std::map, one rank per call) gives: jobs, items, box codes and their order -- scattered and contiguous dirty sets, entries
+    of both flags, 1 to 16 shards, two super-block sizes."""
+    from cvids_amd.chisel import mesh_shell_plan, mesh_shell_plan_all
+    rng = np.random.default_rng(11)
+    shell = rng.normal(size=(300, 3))
+    shell = np.unique(np.floor(shell / np.linalg.norm(shell, axis=1)[:, None] * 9.3).astype(np.int32), axis=0)
+    slab = np.stack(np.meshgrid(np.arange(-3, 4), np.arange(-2, 3), [5, 6], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
+    for ids in (shell, slab, np.array([[0, 0, 0]], np.int32), np.zeros((0, 3), np.int32)):
+        ent = np.concatenate([ids, np.zeros((len(ids), 1), np.int32)], 1)
+        ent[::5, 3] = 1
+        for world in (1, 2, 3, 8, 16):
+            for sb in (2, 3):
+                jobs, items = mesh_shell_plan_all(ent, world, sb)
+                for r in range(world):
+                    rj, ri = mesh_shell_plan(ent, world, r, sb)
+                    assert np.array_equal(rj, jobs[r]), (world, sb, r)
+                    got = [np.concatenate([np.full((len(items[(r, o)]), 1), o, np.int32), items[(r, o)]], 1) for o in range(world) if (r, o) in items]
+                    got = np.concatenate(got) if got else np.zeros((0, 5), np.int32)
+                    assert np.array_equal(ri, got), (world, sb, r, len(ri), len(got))
