@@ -199,6 +199,7 @@ struct chisel_hip_map {
         bool always_wait_packet = false;        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
     } tune;
     int64_t launch_stats[CHISEL_HIP_NUM_LAUNCH_STATS] = {};  // chisel_hip_get_launch_stats
+    bool refine_always = false;          // test / A-B hook (CHISEL_HIP_REFINE=2): also one-frame launches of the short form are refined
     bool refine_off = false;             // test / A-B hook (CHISEL_HIP_REFINE=0 at creation): every cell of every frame of an item's mask counts as needed
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % 3] and pending_ring[b % 4]
@@ -418,6 +419,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     // `front` was decided in integrate_group (it also routes the staging copies).
     hipStream_t front = bs.front_stream;
     const bool inline_resolve = front == m->stream;
+    bool skip_refine = false;  // the short form of a one-frame launch: the cull kernel fills the CellRecs itself (4 us of launch for 2 us of integration)
     {
     RoctxRange front_range("chisel_hip front half: pyramid, cull, resolve, order");
     {
@@ -432,6 +434,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         static_assert(CULL_BLOCK * CULL_BLOCK * CULL_BLOCK == 64, "one wave per block of ids");
         const dim3 cgrid = cspace.sharded ? dim3((total + 63) / 64) : dim3(cspace.nsb[2], cspace.nsb[1], cspace.nsb[0]);
         // frames that look at different parts of the space (several agents in one launch): four waves per workgroup (kernels_cull.h)
+        skip_refine = inline_resolve && IP.n_frames == 1 && !m->refine_always;
         bool narrow_cull = false;
         {
             double vmax = 0.0;
@@ -442,7 +445,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         }
 #define CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, WV)                                                                                   \
     hipLaunchKernelGGL((cull_kernel<N, KLV, INL, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count, \
-                       m->items_capacity, m->view, bs.pending, bs.sync)
+                       m->items_capacity, m->view, bs.pending, bs.sync, skip_refine ? bs.cells : nullptr)
 #define CHISEL_LAUNCH_CULL(KLV, INL, OUT) do { if (narrow_cull) CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 4); else CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 16); } while (0)
         if (inline_resolve) {
             if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, true, bs.items, 16);
@@ -484,7 +487,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         if (!direct)
             hipLaunchKernelGGL(order_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
     }
-    {
+    if (!skip_refine) {
         // per (work item, frame): which cells of the chunk the frame can touch (the cull test again at cell scale, kernels_cull.h).
         // A persistent grid over the (item, frame) pairs: their number is only known on the device.
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
@@ -1023,7 +1026,10 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipEventCreateWithFlags(&m->mutation_event, hipEventDisableTiming));
     m->mesh_tiny = getenv("CHISEL_HIP_MESH_TINY") != nullptr;
     m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
-    if (const char *e = getenv("CHISEL_HIP_REFINE")) m->refine_off = atoi(e) == 0;
+    if (const char *e = getenv("CHISEL_HIP_REFINE")) {
+        m->refine_off = atoi(e) == 0;
+        m->refine_always = atoi(e) == 2;
+    }
     if (const char *e = getenv("CHISEL_HIP_VPL")) m->tune.force_vpl = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 0);
     if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) m->tune.force_cull_waves = atoi(e) == 4 ? 4 : 16;
     if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) m->tune.persistent_grid = atoi(e) != 0;

@@ -601,7 +601,7 @@ struct CullGeom {
 };
 template <int N, int KL, bool INLINE, int WV>
 __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *counts,
-                                                        int max_cands, MapView M, uint64_t *my_pending, ItemSync *sync) {
+                                                        int max_cands, MapView M, uint64_t *my_pending, ItemSync *sync, CellRec *cells) {
     constexpr int WAVES = CullGeom<KL, WV>::WAVES, FPW = CullGeom<KL, WV>::FPW;
     int *cand_count = counts + (INLINE ? COUNT_ITEMS : COUNT_CANDS);
     __shared__ int s_flags[KL][64];
@@ -733,6 +733,15 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
                 fb.pad = 0;
             }
             boxes[(size_t)pos * P.n_frames + kf] = fb;
+            // INLINE with `cells`: the candidate list is the work-list and the launch is not worth refining (one frame, a caller that
+            // waits): every cell of a frame that can touch the chunk counts as needed, and no refine_kernel is launched
+            if (INLINE && cells) {
+                CellRec cr;
+                cr.need = fls[j] ? ~0ull : 0ull;
+                cr.flags = fls[j];
+                cr.pad = 0;
+                cells[(size_t)pos * P.n_frames + kf] = cr;
+            }
         }
     }
 }
@@ -787,10 +796,19 @@ __global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(MapView M, WorkI
             if (kk == KEY_EMPTY) break;
         }
         const unsigned inband = wi.frame_mask & 0xffffu, carve = wi.frame_mask >> 16;
-        // While the previous batch is being integrated a key can already be visible whose slot value is not: the lookup
-        // result only counts for chunks that batch cannot be creating.  If its pending set is incomplete, that is nobody.
-        const bool uncertain = all_uncertain || (prev_pending && pending_contains(prev_pending, key, h0)) ||
-                               (prev2_pending && pending_contains(prev2_pending, key, h0));
+        // While the previous batches are being integrated a key can already be visible whose slot value is not (create_chunk writes
+        // key, then value, then slot_key[slot]): a lookup result that does not check out against slot_key only counts for chunks
+        // those batches cannot be creating.  One that does check out is final, whoever is in flight -- the value read IS the slot
+        // that holds this key -- and such a chunk is resident for good: without this, a chunk created by some batch stayed
+        // "uncertain" for as long as it stayed in view (an uncertain item has no slot here, so it went into this batch's pending set and
+        // was uncertain again for the next two: most items of a steady stream were looked up again by every one of their units in the
+        // integration kernel, 4 us of dependent round trips at the head of each).
+        const bool forced = force_uncertain && *force_uncertain != 0;  // (test hook: everything through the look-up path of the integration kernel)
+        const bool verified = !forced && slot >= 0 && slot < M.max_chunks && M.slot_key[slot] == key;
+        if (!verified && slot >= 0) slot = -1;
+        const bool uncertain = !verified &&
+                               (all_uncertain || (prev_pending && pending_contains(prev_pending, key, h0)) ||
+                                (prev2_pending && pending_contains(prev2_pending, key, h0)));
         unsigned mask = 0;
         if (uncertain) {
             slot = SLOT_LOOKUP;

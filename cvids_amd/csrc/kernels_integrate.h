@@ -635,7 +635,16 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                     }
                 }
                 FSTAMP(3, f4(s4, 0));
+                // (a voxel that takes the carve branch is only touched if it holds a weight: most do not -- free space in front of the band
+                // was never integrated -- and then nothing below can hit)
+                bool may_hit = false;  // wave-uniform
                 if (__any(carvem != 0u)) {
+                    unsigned heldm = 0u;
+#pragma unroll
+                    for (int j = 0; j < VPL; j++) heldm |= (f4(w4, j) > 0.0f) ? (1u << j) : 0u;
+                    may_hit = __any((carvem & heldm) != 0u);
+                }
+                if (may_hit) {
                     unsigned hitm = 0u;
 #pragma unroll
                     for (int j = 0; j < VPL; j++) {
@@ -740,7 +749,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                 unsigned old = 0u;
                 if (lane == 0) {
                     old = atomicOr(&sy->changed, cm);
-                    mark_slot_dirty(M, slot);
+                    if (old == 0u) mark_slot_dirty(M, slot);  // (the first unit of the chunk to report a change in this launch: its siblings need not repeat it)
                     if (signs) atomicOr(&slot_summary(M)[slot], signs);  // (a wave that wrote a voxel changed one: cm != 0)
                 }
                 old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
