@@ -60,8 +60,9 @@ namespace chisel_hip {
 // 1 500+ items (318 against 272 us) and 20 % on one-frame launches (nothing to shorten: 21 against 17 us); and 9 % on a 16-frame
 // launch of the 4-agent stream, where a chunk is seen by 4-5 of the frames: the choice also asks for >= 6 frames per item on average.
 #ifndef INTEGRATE_FINE_BELOW
-#define INTEGRATE_FINE_BELOW 900   // work items (16^3 chunks; scaled by voxels per chunk) below which a launch of >= 4 frames runs with 2 voxels per lane
-                                   // (round 3, one wave per workgroup: at 1 257 items 4 voxels per lane take 98 us, 2 take 100-106; at 540 items 63.2 against 62.6)
+#define INTEGRATE_FINE_BELOW 600   // work items (16^3 chunks; scaled by voxels per chunk) below which a launch of >= 4 frames runs with 2 voxels per lane
+                                   // (round 3, one wave per workgroup: at 1 257 items 4 voxels per lane take 98 us, 2 take 100-106; at 540 items 63.2 against 62.6;
+                                   // round 4, bricks + cell masks: default window 48.0 us with 600, 50.3 with 900, 53.5 with 1 300; driver's window 73.7 / 73.6 / 86.6)
 #endif
 
 // Round-3 instruction-count work, each switchable for A/B builds (all on by default):
