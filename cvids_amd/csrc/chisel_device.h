@@ -78,6 +78,12 @@ struct MapView {
     unsigned long long *block_counters;  // [INTEGRATE_MAX_GRID][16] per-workgroup partial sums
     int *error_flag;         // two words in pinned host memory, see raise_error
     int max_chunks;
+    // meshesToUpdate as a job list kept on the device while integrating (kernels_mesh.h: mesh_expand_dirty): the wave that first dirties
+    // a slot appends the resident chunks of its 27-neighbourhood (Chisel.h:175-189), so that a recompute starts with its count kernel
+    unsigned *mesh_flag;     // [max_chunks] "this slot is in the job list"
+    int *mesh_jobs;          // [mesh_jobs_capacity][3] chunk ids
+    int *mesh_ctl;           // [0..3] totals of the recompute in flight (triangles, grids, overflow, jobs), [4] entries of the job list
+    int mesh_jobs_capacity;
 };
 
 // Per slot, behind the dirty list: which signs the OBSERVED voxels (weight > 0.5: what a marching cube asks of a corner,
@@ -91,11 +97,14 @@ __device__ inline uint32_t *slot_summary(const MapView &M) { return M.slot_dirty
 
 // A chunk was updated (Chisel.h:85 / :167 needsUpdate -> meshesToUpdate, Chisel.h:175-189): its flag, and -- for the mesher, which must
 // not have to scan a pool of millions of slots for a few hundred dirty ones -- its slot into the list of dirty slots, once.
-__device__ inline void mark_slot_dirty(const MapView &M, int slot) {
+// -> true for the caller whose exchange raised the flag
+__device__ inline bool mark_slot_dirty(const MapView &M, int slot) {
     if (atomicExch(&M.slot_dirty[slot], 1u) == 0u) {
         const unsigned p = atomicAdd(&M.slot_dirty[2 * (size_t)M.max_chunks], 1u);
         if (p < (unsigned)M.max_chunks) M.slot_dirty[(size_t)M.max_chunks + p] = (unsigned)slot;  // (else: the mesher scans the flags)
+        return true;
     }
+    return false;
 }
 
 // depth min/max pyramid: level l (PYR_L0 <= l <= PYR_L1) has ceil(W/2^l) x ceil(H/2^l) texels of
@@ -273,6 +282,14 @@ __host__ __device__ inline float truncation_distance(int kind, float param, floa
 __device__ inline float reciprocal_in_range(float z) {
     const float r = __builtin_amdgcn_rcpf(z);
     return __builtin_fmaf(__builtin_fmaf(-z, r, 1.0f), r, r);
+}
+// (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32).  Checked against that pair
+// for every float that is not a NaN on the device, and that no NaN comes out as a possible pixel coordinate
+// (chisel_hip_kat_floor, tests/test_gpu_parity.py).
+__device__ inline int floor_to_int(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 constexpr float FASTZ_MIN = 9.094947017729282e-13f;  // 2^-40
 constexpr float FASTZ_MAX = 1099511627776.0f;        // 2^40

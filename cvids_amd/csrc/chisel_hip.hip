@@ -242,6 +242,9 @@ struct chisel_hip_map {
     int shell_first_capacity = 0;
     bool single_chunk = false;                                         // chisel_hip_integrate_chunk: the next integrate call sees this id only
     int single_id[3] = {0, 0, 0};
+    bool mesh_mark_needed = false;                                     // slots were dirtied by something other than integrate_kernel (point clouds), or the kept job list was given up: the next recompute runs mesh_mark_kernel
+    bool mesh_totals_clean = true;                                     // an integration launch has been queued since the last recompute (it zeroes the recompute totals)
+    int64_t removed_since_recompute = 0;                               // chunks removed since: each may have left a dead entry in the kept job list
     int mesh_stages = 3;                                               // MeshParams::stages of the next recompute (chisel_hip_generate_mesh lowers it)
     bool mesh_detached = false;                                        // the next recompute leaves meshesToUpdate alone (chisel_hip_generate_mesh)
     uint64_t topology_epoch = 0;                                       // bumped by everything but integration that adds or removes chunks (chisel_hip_topology_epoch)
@@ -405,6 +408,7 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
 }
 
 int check_mesh_totals(chisel_hip_map *m);  // host_mesh.h
+void give_up_job_list(chisel_hip_map *m);  // host_mesh.h
 
 // The launch set of one batch.  Front half on the auxiliary stream, back half on the map's stream (see BatchSet).
 template <int N>
@@ -482,7 +486,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
         const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= m->tune.direct_items_max);
         hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
-                           prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync);
+                           prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync, bs.boxes, (skip_refine = IP.n_frames == 1 && !m->refine_always) ? bs.cells : nullptr);
         if (direct) m->launch_stats[5]++;
         if (!direct)
             hipLaunchKernelGGL(order_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
@@ -585,6 +589,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
 #undef CHISEL_LAUNCH_INTEGRATE
     }
     HIP_TRY(hipGetLastError());
+    m->mesh_totals_clean = true;  // (integrate_kernel's first thread zeroes the next recompute's totals)
     HIP_TRY(hipEventRecord(bs.back_done, m->stream));
     m->batch_seq++;
     g_host_timer.lap(5);
@@ -1061,6 +1066,16 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     m->error_flag_host[0] = m->error_flag_host[1] = m->error_flag_host[2] = m->error_flag_host[3] = 0;
     HIP_TRY_C(hipHostGetDevicePointer((void **)&v.error_flag, m->error_flag_host, 0));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
+    // the mesh recompute's job list, kept by the integration kernels (kernels_map.h: mesh_expand_dirty): a flag per slot, the ids of the
+    // listed chunks (twice the pool: a removed chunk leaves its entry behind), the recompute totals + the list's length
+    v.mesh_jobs_capacity = (int)std::min<size_t>(2 * C, (size_t)INT32_MAX / 4);
+    HIP_TRY_C(hipMalloc(&v.mesh_flag, C * sizeof(unsigned)));
+    HIP_TRY_C(hipMemsetAsync(v.mesh_flag, 0, C * sizeof(unsigned), m->stream));
+    HIP_TRY_C(hipMalloc(&v.mesh_jobs, (size_t)v.mesh_jobs_capacity * 3 * sizeof(int)));
+    HIP_TRY_C(hipMalloc(&v.mesh_ctl, 8 * sizeof(int)));
+    HIP_TRY_C(hipMemsetAsync(v.mesh_ctl, 0, 8 * sizeof(int), m->stream));
+    m->mesh_buf.flags = v.mesh_flag;
+    m->mesh_buf.totals = v.mesh_ctl;
     HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));
     HIP_TRY_C(hipMemcpyAsync(m->view_dev, &m->view, sizeof(MapView), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V, 1);
@@ -1082,7 +1097,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->stream) (void)sync_all(m);
     MapView &v = m->view;
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
-                    v.counters, v.block_counters, m->view_dev, m->scratch_i, m->shell_items_dev, m->shell_offs_dev, m->shell_first_dev};
+                    v.counters, v.block_counters, m->view_dev, m->scratch_i, m->shell_items_dev, m->shell_offs_dev, m->shell_first_dev, v.mesh_jobs};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
@@ -1253,6 +1268,10 @@ int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
     HIP_TRY(hipMemcpyAsync(d_ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(remove_chunks_kernel, dim3(n), dim3(256), 0, m->stream, m->view, d_ids, n, d_cnt, m->V);
     HIP_TRY(hipGetLastError());
+    // every removed chunk may leave a dead entry in the job list the integration kernels keep (its slot can be listed again): long
+    // before the list could run full it is dropped and rebuilt from the dirty flags at the next recompute
+    m->removed_since_recompute += n;
+    if (m->removed_since_recompute >= (int64_t)m->view.max_chunks / 2) give_up_job_list(m);
     HIP_TRY(hipStreamSynchronize(m->stream));
     return CHISEL_HIP_OK;
 }

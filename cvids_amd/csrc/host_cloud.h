@@ -67,6 +67,7 @@ int ensure_cloud_buffers(chisel_hip_map *m, int64_t n) {
 
 template <int N>
 void launch_cloud_integrate(chisel_hip_map *m, const CloudParams &P, const CloudView &C) {
+    m->mesh_mark_needed = true;  // (this kernel dirties slots without listing their neighbourhoods: the next recompute runs mesh_mark_kernel)
     if (m->cfg.use_color)
         hipLaunchKernelGGL((cloud_integrate_kernel<N, true>), dim3(CLOUD_GRID), dim3(64 * CloudGeom<N>::WAVES), 0, m->stream, P, m->view, m->view_dev, C);
     else

@@ -17,6 +17,8 @@ MeshParams mesh_params(const chisel_hip_map *m) {
     return P;
 }
 
+// publish: bit 0 = the totals go to the host (the first emission of a recompute), bit 1 = the job list kept by the integration kernels was
+// this recompute's input and is empty from here on
 void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena, size_t arena_floats, int publish = 0) {
     MeshBuffers &B = m->mesh_buf;
     const JobInfo *bases = B.info;
@@ -45,10 +47,6 @@ int ensure_mesh_jobs(chisel_hip_map *m, int n) {
     HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
     HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
     HIP_TRY(hipMalloc(&B.info, (size_t)cap * sizeof(JobInfo)));
-    if (!B.totals) {
-        HIP_TRY(hipMalloc(&B.totals, 8 * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(B.totals, 0, 8 * sizeof(int), m->stream));
-    }
     B.capacity = cap;
     return CHISEL_HIP_OK;
 }
@@ -57,25 +55,28 @@ int ensure_mesh_jobs(chisel_hip_map *m, int n) {
 enum { MT_TRIS = 0, MT_GRIDS = 1, MT_OVERFLOW = 2, MT_JOBS = 3 };
 int *mesh_totals(chisel_hip_map *m) { return m->mesh_buf.totals; }
 
-// ids of the resident chunks to mesh, built on the device: the 27-neighbourhoods of the dirty slots, de-duplicated
-// through one flag per slot, plus `extra` host-side ids (neighbourhoods of chunks that were removed while dirty).
-// The number of ids stays on the device (one of two alternating counters behind the totals, copied to mesh_totals()[MT_JOBS] by
-// the count kernel); nothing here waits for the stream unless `extra` is used.
+// The job list of a recompute: the resident chunks of the 27-neighbourhoods of the slots dirtied since the last one, de-duplicated
+// through one flag per slot.  The integration kernels keep it as they go (mesh_expand_dirty: the wave that first dirties a slot
+// appends its neighbourhood), so a recompute normally starts with its count kernel; mesh_mark_kernel builds the same entries from the
+// dirty flags when something else has dirtied slots since (point clouds), when the kept list has been given up (`rebuild`), or
+// completes it with `extra` host-side ids (neighbourhoods of chunks that were removed while dirty).  The number of entries stays on
+// the device (mesh_ctl[4], copied to the totals by the count kernel); nothing here waits for the stream unless `extra` is used.
 int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
     MeshBuffers &B = m->mesh_buf;
     const int C = m->view.max_chunks;
-    int rc = ensure_mesh_jobs(m, C);  // worst case: every resident chunk
+    int rc = ensure_mesh_jobs(m, C);  // (MeshJob / JobInfo records: worst case every resident chunk)
     if (rc) return rc;
-    if (!B.flags) {
-        HIP_TRY(hipMalloc(&B.flags, (size_t)C * sizeof(unsigned)));
-        HIP_TRY(hipMemsetAsync(B.flags, 0, (size_t)C * sizeof(unsigned), m->stream));
-    }
-    // (the mark kernel also zeroes the totals; its grid is persistent: the number of dirty slots is read on the device)
-    int *n_jobs = mesh_totals(m) + 4 + (B.mark_turn & 1), *n_jobs_next = mesh_totals(m) + 4 + ((B.mark_turn + 1) & 1);
-    B.mark_turn++;
+    int *n_jobs = mesh_totals(m) + 4;
     B.n_jobs = n_jobs;
-    hipLaunchKernelGGL(mesh_mark_kernel, dim3(1024), dim3(256), 0, m->stream, m->view, B.flags, mesh_totals(m), B.ids,
-                       n_jobs, n_jobs_next);
+    if (m->mesh_mark_needed) {
+        hipLaunchKernelGGL(mesh_mark_kernel, dim3(1024), dim3(256), 0, m->stream, m->view, B.flags, m->view.mesh_jobs, n_jobs);
+        m->mesh_mark_needed = false;
+    }
+    if (!m->mesh_totals_clean) {
+        // (two recomputes without an integration launch in between: its first thread is what zeroes the totals otherwise)
+        HIP_TRY(hipMemsetAsync(mesh_totals(m), 0, 3 * sizeof(int), m->stream));
+    }
+    m->mesh_totals_clean = false;
     if (!extra.empty()) {
         // (rare) ids kept on the host: the ones that are resident join the job list
         const int ne = (int)(extra.size() / 3);
@@ -85,7 +86,7 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
         int *d_slots = nullptr;
         HIP_TRY(hipMalloc(&d_slots, (size_t)ne * sizeof(int)));
         HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), (size_t)ne * sizeof(int), hipMemcpyHostToDevice, m->stream));
-        hipLaunchKernelGGL(mesh_append_kernel, dim3((ne + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, (const int *)d_slots, ne, B.ids, n_jobs);
+        hipLaunchKernelGGL(mesh_append_kernel, dim3((ne + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, (const int *)d_slots, ne, m->view.mesh_jobs, n_jobs);
         HIP_TRY(hipStreamSynchronize(m->stream));
         HIP_TRY(hipFree(d_slots));
     }
@@ -146,16 +147,25 @@ void release_arena_pool(chisel_hip_map *m) {
     m->arena_pool.clear();
 }
 
+// the job list kept by the integration kernels is dropped; the next recompute rebuilds it from the dirty flags (mesh_mark_kernel)
+void give_up_job_list(chisel_hip_map *m) {
+    if (m->mesh_buf.flags) (void)hipMemsetAsync(m->mesh_buf.flags, 0, (size_t)m->view.max_chunks * sizeof(unsigned), m->stream);
+    if (m->mesh_buf.totals) (void)hipMemsetAsync(m->mesh_buf.totals + 4, 0, sizeof(int), m->stream);
+    m->mesh_mark_needed = true;
+    m->removed_since_recompute = 0;
+}
+
 void launch_mesh_count(chisel_hip_map *m) {
     MeshBuffers &B = m->mesh_buf;
     int *d_totals = mesh_totals(m);
-    int *n_jobs = B.n_jobs ? B.n_jobs : d_totals + MT_JOBS;  // the mark kernel's counter, or the count a caller put into the totals
+    int *n_jobs = B.n_jobs ? B.n_jobs : d_totals + MT_JOBS;  // the kept job list's counter, or the count a caller put into the totals
+    const int *ids = B.n_jobs ? m->view.mesh_jobs : B.ids;   // ... and its entries, or the caller's ids
     ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
     const dim3 grid(2048);
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, B.ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
     }
 }
 
@@ -196,7 +206,7 @@ int recompute_meshes(chisel_hip_map *m) {
     m->recomputes++;
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
-        launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity, 1);
+        launch_mesh_triangles(m, P, m->arenas[arena_id].dev, m->arenas[arena_id].capacity, 1 | (B.n_jobs ? 2 : 0));
     }
     HIP_TRY(hipGetLastError());
     m->pending_meshes.unchecked = true;
@@ -260,7 +270,14 @@ int check_mesh_totals(chisel_hip_map *m) {
         HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
         HIP_TRY(hipMalloc(&B.corners, (size_t)B.tri_capacity * sizeof(CubeCorners)));
         HIP_TRY(hipMemsetAsync(d_totals, 0, 3 * sizeof(int), m->stream));  // keeps MT_JOBS
+        // (the kept job list's counter has been emptied by the first emission; its entries are untouched -- nothing has integrated since --
+        // and their number is in the totals)
+        if (B.n_jobs) {
+            const int n_again = totals[MT_JOBS];
+            HIP_TRY(hipMemcpyAsync(B.n_jobs, &n_again, sizeof(int), hipMemcpyHostToDevice, m->stream));
+        }
         launch_mesh_count(m);
+        if (B.n_jobs) HIP_TRY(hipMemsetAsync(B.n_jobs, 0, sizeof(int), m->stream));
         HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
         if (totals[MT_OVERFLOW]) return fail(CHISEL_HIP_ERR_HIP, "mesh triangle list overflow after growing it");
@@ -465,10 +482,11 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
     if (rc) {
         // the mark kernel may have flagged slots that no count kernel will now reset: a slot whose flag stays set could never
         // become a job again
-        if (m->mesh_buf.flags) (void)hipMemsetAsync(m->mesh_buf.flags, 0, (size_t)m->view.max_chunks * sizeof(unsigned), m->stream);
+        give_up_job_list(m);
         return rc;
     }
     m->pending_mesh_ids.clear();
+    m->removed_since_recompute = 0;
     return CHISEL_HIP_OK;
 }
 

@@ -770,7 +770,7 @@ __device__ inline int cost_class(unsigned frame_mask) { return (KMAX - __popc(fr
 __global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
                                                        int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
                                                        const uint64_t *__restrict__ prev2_pending, const int *__restrict__ force_uncertain,
-                                                       uint64_t *my_pending, WorkItem *items, ItemSync *sync) {
+                                                       uint64_t *my_pending, WorkItem *items, ItemSync *sync, const FrameBox *__restrict__ boxes, CellRec *cells) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * RESOLVE_BLOCK + threadIdx.x;
     int n = counts_in[COUNT_CANDS];
@@ -841,6 +841,14 @@ __global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(MapView M, WorkI
                 const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
                 items[pos] = wi;
                 item_sync_init(sync + pos);
+                // one-frame launch sets are not refined (a launch for a kernel's worth of nothing): every cell of the frame counts
+                if (cells) {
+                    CellRec cr;
+                    cr.need = ~0ull;
+                    cr.flags = boxes[(size_t)wi.box * n_frames].flags;
+                    cr.pad = 0;
+                    cells[(size_t)pos * n_frames] = cr;
+                }
             }
         }
     }

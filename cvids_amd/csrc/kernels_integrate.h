@@ -36,6 +36,7 @@
 
 #include "chisel_device.h"
 #include "kernels_cull.h"  // COUNT_* (the batch counters the work-list builders leave behind)
+#include "kernels_map.h"   // mesh_expand_dirty
 
 namespace chisel_hip {
 
@@ -134,14 +135,6 @@ template <int VPL>
 __device__ inline float &f4(QuadFT<VPL> &q, int j) { return q.v[j]; }
 template <int VPL>
 __device__ inline unsigned &u4(QuadUT<VPL> &q, int j) { return q.v[j]; }
-// (int)floorf(x) in one instruction (v_cvt_flr_i32_f32; the compiler emits v_floor_f32 + v_cvt_i32_f32).  Checked against that pair
-// for every float that is not a NaN on the device, and that no NaN comes out as a possible pixel coordinate
-// (chisel_hip_kat_floor, tests/test_gpu_parity.py).
-__device__ inline int floor_to_int(float x) {
-    int r;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
 __device__ inline unsigned wave_count(bool p) { return (unsigned)__popcll(__ballot(p)); }  // active lanes with p, wave-uniform
 
 // ChunkManager::CreateChunk (ChunkManager.cpp:171-174) on the device; one thread.  Returns the slot or -1.
@@ -245,6 +238,12 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
         for (int c = 0; c < 8; c++) pairs += cls[c] * (KMAX - 2 * c);
         report[2] = n_items;
         report[3] = pairs;
+        // the totals of the next mesh recompute start from zero (no recompute is in flight while this kernel runs: same stream)
+        if (M.mesh_ctl) {
+            M.mesh_ctl[0] = 0;
+            M.mesh_ctl[1] = 0;
+            M.mesh_ctl[2] = 0;
+        }
     }
     const int grid_waves = nb * G::WPB;
     // Two granularities in one launch (VPL0 == 4): the items behind `split` -- the tail of the cost-ordered list -- run with 2 voxels per
@@ -748,13 +747,17 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                 // "needsUpdate" of the chunk per frame (Chisel.h:85 / :167): each frame counts once per chunk -- by the wave
                 // whose OR sets its bit first -- and the slot is marked for the mesher (Chisel.h:175-189)
                 unsigned old = 0u;
+                int newly_dirty = 0;
                 if (lane == 0) {
                     old = atomicOr(&sy->changed, cm);
-                    if (old == 0u) mark_slot_dirty(M, slot);  // (the first unit of the chunk to report a change in this launch: its siblings need not repeat it)
+                    if (old == 0u) newly_dirty = mark_slot_dirty(M, slot) ? 1 : 0;  // (the first unit of the chunk to report a change in this launch: its siblings need not repeat it)
                     if (signs) atomicOr(&slot_summary(M)[slot], signs);  // (a wave that wrote a voxel changed one: cm != 0)
                 }
                 old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
                 n_updated += (unsigned)__popc(cm & ~old);
+                // first update of this chunk since the last mesh recompute: its 27-neighbourhood joins the recompute's job list now
+                // (Chisel.h:175-189), so that the recompute needs no pass over the dirty slots of its own
+                if (__builtin_amdgcn_readfirstlane(newly_dirty)) mesh_expand_dirty(Mc, slot, cxi, cyi, czi, lane);
             }
     };
     if (mixed) {  // one unit per wave, all of them dealt statically

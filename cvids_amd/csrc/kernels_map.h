@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void reset_map_kernel(MapView M, int V, int al
     for (uint64_t i = gid; i < (uint64_t)M.max_chunks; i += stride) {
         M.slot_dirty[i] = 0;
         slot_summary(M)[i] = 0;
+        if (M.mesh_flag) M.mesh_flag[i] = 0;
         M.free_list[i] = M.max_chunks - 1 - (int)i;  // slot 0 is popped first
     }
     for (long long base = 0; base < (long long)M.max_chunks; base += (long long)gridDim.x * 256) {
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void reset_map_kernel(MapView M, int V, int al
     }
     if (gid == 0) {
         M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // the list of dirty slots is empty
+        if (M.mesh_ctl) M.mesh_ctl[4] = 0;           // and so is the job list
         *M.free_top = M.max_chunks;
         M.error_flag[0] = 0;
         M.error_flag[1] = 0;
@@ -93,6 +95,38 @@ __device__ inline int hash_find_quiescent(const MapView &M, int x, int y, int z)
     return -1;
 }
 
+// ---- meshesToUpdate on the device: the job list of the next mesh recompute (kernels_mesh.h) -----------------------------------------
+// one resident chunk becomes a job: the caller whose exchange sets the slot's flag first appends its id
+__device__ inline void mesh_append_job(const MapView &M, unsigned *mesh_flag, int slot, int *ids, int *n_jobs) {
+    if (atomicExch(&mesh_flag[slot], 1u) != 0u) return;
+    const uint64_t key = M.slot_key[slot];
+    if (key == KEY_EMPTY) return;
+    const int pos = atomicAdd(n_jobs, 1);
+    if (pos >= M.mesh_jobs_capacity) return;  // (the host rebuilds the list from the dirty flags long before this: host_mesh.h)
+    int x, y, z;
+    unpack_id(key, x, y, z);
+    ids[3 * pos] = x;
+    ids[3 * pos + 1] = y;
+    ids[3 * pos + 2] = z;
+}
+// The same expansion at the moment a slot is first dirtied, by the wave that dirtied it (integrate_kernel's epilogue: the wave has
+// nothing else left to do): lanes 0-26 look the neighbourhood up and append what is resident.  The chunk hash may be receiving
+// insertions from other waves of this launch: a hit only counts if slot_key confirms it (create_chunk writes key, value, slot_key in
+// that order), and a neighbour that is missed because it is being created right now is dirty itself and lists itself.  Everything
+// here is an accelerator for mesh_mark_kernel, which can rebuild the list from the dirty flags at any time.
+// (out of line, the map view read from device memory: the integration kernel's registers are spoken for)
+__device__ __attribute__((noinline)) void mesh_expand_dirty(const MapView *__restrict__ Mc, int slot, int x, int y, int z, int lane) {
+    const MapView M = *Mc;
+    if (!M.mesh_flag || lane >= 27) return;
+    int ns = slot;
+    if (lane != 13) {
+        const int nx = x + lane % 3 - 1, ny = y + (lane / 3) % 3 - 1, nz = z + lane / 9 - 1;
+        ns = hash_find(M, nx, ny, nz);
+        if (ns >= 0 && (ns >= M.max_chunks || M.slot_key[ns] != pack_id(nx, ny, nz))) ns = -1;
+    }
+    if (ns >= 0) mesh_append_job(M, M.mesh_flag, ns, M.mesh_jobs, M.mesh_ctl + 4);
+}
+
 // HasChunk / GetChunk (ChunkManager.h:79-87): slot per id, -1 when absent
 __global__ void lookup_kernel(MapView M, const int *ids, int n, int *slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,6 +150,7 @@ __global__ __launch_bounds__(256) void remove_chunks_kernel(MapView M, const int
                 M.slot_key[slot] = KEY_EMPTY;
                 M.slot_dirty[slot] = 0;
                 slot_summary(M)[slot] = 0;
+                if (M.mesh_flag) M.mesh_flag[slot] = 0;  // (its entry of the job list, if any, names an id that is now absent: skipped by the count kernel)
                 s_slot = slot;
             }
         }
@@ -434,8 +469,14 @@ __global__ void list_dirty_ids_kernel(MapView M, int *out, int capacity) {
 }
 __global__ void clear_dirty_kernel(MapView M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M.max_chunks) M.slot_dirty[i] = 0;
-    if (i == 0) M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // and their list
+    if (i < M.max_chunks) {
+        M.slot_dirty[i] = 0;
+        if (M.mesh_flag) M.mesh_flag[i] = 0;
+    }
+    if (i == 0) {
+        M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // and their list
+        if (M.mesh_ctl) M.mesh_ctl[4] = 0;           // and the job list kept while integrating
+    }
 }
 
 // ---- PublishDenseInfo's image conditioning (collaborative_server_system.cpp:213-214, :255-269) -------------------------

@@ -276,21 +276,10 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
 // at once: ChunkManager.cpp:93-96).  The job counter `n_jobs` was zeroed by the previous recompute's launch of this kernel,
 // which zeroes `n_jobs_next` for the next one (two counters alternate: zeroing the one in use here would race with the
 // appends); flags and dirty bits are reset by the count kernel, job by job (every dirty slot is a job: offset 13 is itself).
-__device__ inline void mesh_append_job(const MapView &M, unsigned *mesh_flag, int slot, int *ids, int *n_jobs) {
-    if (atomicExch(&mesh_flag[slot], 1u) != 0u) return;
-    const uint64_t key = M.slot_key[slot];
-    if (key == KEY_EMPTY) return;
-    const int pos = atomicAdd(n_jobs, 1);
-    int x, y, z;
-    unpack_id(key, x, y, z);
-    ids[3 * pos] = x;
-    ids[3 * pos + 1] = y;
-    ids[3 * pos + 2] = z;
-}
-__global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag, int *totals, int *ids, int *n_jobs, int *n_jobs_next) {
+// (rebuilds / completes the job list from the dirty flags: after point clouds, uploads, or when the list kept by the integration kernel
+// has been given up)
+__global__ void mesh_mark_kernel(MapView M, unsigned *mesh_flag, int *ids, int *n_jobs) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-    if (gid < 3) totals[gid] = 0;  // triangles, grids, overflow: the count kernel's (the next launch's) counters
-    if (gid == 3) *n_jobs_next = 0;
     // the dirty slots come from the list the integration kernels keep (mark_slot_dirty): the work here is proportional to what
     // changed, not to the size of the pool; a list that overflowed (slots dirtied, removed and dirtied again many times over
     // without a recompute in between) falls back to the flags of all slots
@@ -708,7 +697,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
                                                                     volatile int *host_flags, int max_jobs, int seq, int publish) {
     const int n_tris = totals[0];
     const int n_jobs = totals[3];
-    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((publish & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // (publish: bit 0 = totals to the host, bit 1 = the kept job list was this recompute's input)
         // The recompute's totals, straight into pinned host memory as ONE 16-byte store -- {triangles, grids, jobs | overflow << 31,
         // sequence number} -- before anything else: the host polls word 3 for this recompute's sequence number when the caller next
         // touches the map.  No copy engine, no event, no stream wait and no kernel of its own in between (an event record on the
@@ -723,6 +712,8 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         // as one piece is how the bus behaves, not a guarantee (this thread alone pays the few hundred nanoseconds)
         __threadfence_system();
         host_flags[5] = seq;
+        // the job list the integration kernels keep has been consumed by the count kernel (its number is in totals[3]): empty again
+        if ((publish & 2) && M.mesh_ctl) M.mesh_ctl[4] = 0;
     }
     const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[1] * 3;
     // a triangle list that overflowed (totals[2]) is incomplete: nothing is emitted, the host lists and emits again
