@@ -318,7 +318,7 @@ class Chisel:
         items = np.ascontiguousarray(np.asarray(items, np.int32).reshape(-1, 4))
         n = len(items)
         edge = self.chunk_size[0]
-        vox = int(sum(self.L.chisel_hip_shell_volume(int(b), edge) for b in items[:, 3])) if n else 0
+        vox = int(shell_volumes(items[:, 3], edge).sum()) if n else 0
         if device:
             import torch
             dev = torch.device("cuda", torch.cuda.current_device())
@@ -669,3 +669,15 @@ def mesh_shell_plan_all(entries, n_shards, shard_block=2):
 
 def shell_volume(box, chunk_edge):
     return int(capi.load_library().chisel_hip_shell_volume(int(box), int(chunk_edge)))
+
+
+_SHELL_VOLUMES = {}
+
+
+def shell_volumes(boxes, chunk_edge):
+    """voxels in the payload of every box code of an array (a table of the 64 codes per chunk edge: one library call per code and
+    edge, not one per item -- a recompute lists thousands of items)"""
+    table = _SHELL_VOLUMES.get(int(chunk_edge))
+    if table is None:
+        table = _SHELL_VOLUMES[int(chunk_edge)] = np.array([shell_volume(b, chunk_edge) for b in range(64)], np.int64)
+    return table[np.asarray(boxes, np.int64)]

@@ -291,7 +291,7 @@ class ShardedChisel:
         4. every rank recomputes its jobs and drops the ghosts.
         ids: mesh these chunks (every rank passes ids of its own choice, the union is meshed) instead of meshesToUpdate.
         -> bytes of ghost voxels this rank received"""
-        from .chisel import mesh_shell_plan_all, shell_volume
+        from .chisel import mesh_shell_plan_all, shell_volumes
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return 0
@@ -343,7 +343,7 @@ class ShardedChisel:
         send_parts = [all_items.get((q, rank), none) for q in range(world)]   # what rank q asks of this rank
         send_items = np.concatenate(send_parts, axis=0)
         n_send = [len(p) for p in send_parts]
-        vol = lambda it: int(sum(shell_volume(int(b), edge) for b in it[:, 3])) if len(it) else 0
+        vol = lambda it: int(shell_volumes(it[:, 3], edge).sum()) if len(it) else 0
         v_send = [vol(p) for p in send_parts]
         v_recv = [vol(recv_items[sum(n_recv[:o]):sum(n_recv[:o + 1])]) for o in range(world)]
         # ---- 3. shells: export -> all_to_all -> import
@@ -378,7 +378,7 @@ class ShardedChisel:
         self.map.DropGhostChunks()
         per_voxel = 12 if col_r is not None else 8
         # for the record: what whole ghost chunks (the round-2 protocol) would have moved for the same ghosts
-        self.whole_chunk_bytes = getattr(self, "whole_chunk_bytes", 0) + len({tuple(i[:3]) for i in recv_items.tolist()}) * edge ** 3 * per_voxel
+        self.whole_chunk_bytes = getattr(self, "whole_chunk_bytes", 0) + (len(np.unique(recv_items[:, :3], axis=0)) if len(recv_items) else 0) * edge ** 3 * per_voxel
         self.shell_bytes = getattr(self, "shell_bytes", 0) + int(total * per_voxel)
         return int(total * per_voxel)
 
