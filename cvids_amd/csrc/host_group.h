@@ -70,8 +70,7 @@ struct Pool {
         }
     }
 };
-// staging of one (meshing shard r, owner o) pair of update_meshes: the shells o packs for r, on o's device and -- when r lives on another
-// device -- their copy on r's; grow-only, reused by every recompute; `imported` (recorded on r's stream behind the import) guards reuse
+// a staging buffer of update_meshes (four arrays, grow-only, reused by every recompute) with the events that guard it
 struct PairStage {
     float *sdf[2] = {nullptr, nullptr}, *wgt[2] = {nullptr, nullptr};   // [0] on the owner's device, [1] on the meshing shard's (other device only)
     uint8_t *rgbw[2] = {nullptr, nullptr};
@@ -82,8 +81,9 @@ struct PairStage {
     bool armed = false;
 };
 struct MeshStages {
-    std::vector<PairStage> pair;               // [r * W + o]
-    std::vector<hipStream_t> copy;             // [r]: peer copies into shard r's device
+    std::vector<PairStage> out;                // [o]: what owner o packs for ALL requesters, requester by requester (side 0, o's device; `exported`)
+    std::vector<PairStage> in;                 // [r]: what meshing shard r installs, owner by owner (side 0, r's device; `copied`, `imported`)
+    std::vector<hipStream_t> copy;             // [r]: the copies that assemble in[r] from the owners' out[o]
 };
 
 inline int n_shards(const chisel_hip_map *g) { return (int)g->shards.size(); }
@@ -154,7 +154,8 @@ int create(const chisel_hip_config *cfg, const int *device_ids, int n, chisel_hi
             for (int i = 1; i < n; i++) P->workers.emplace_back([P, i] { P->loop(i); });
         g->pool = P;
         MeshStages *MS = new MeshStages();
-        MS->pair.resize((size_t)n * n);
+        MS->out.resize((size_t)n);
+        MS->in.resize((size_t)n);
         MS->copy.assign((size_t)n, nullptr);
         g->mesh_stages_group = MS;
     }
@@ -187,16 +188,14 @@ int destroy(chisel_hip_map *g) {
     if (MeshStages *MS = static_cast<MeshStages *>(g->mesh_stages_group)) {
         for (chisel_hip_map *sh : g->shards) (void)chisel_hip_synchronize(sh);
         const int W = n_shards(g);
-        for (int r = 0; r < W; r++)
-            for (int o = 0; o < W; o++) {
-                PairStage &S = MS->pair[(size_t)r * W + o];
-                for (int side = 0; side < 2; side++) {
-                    (void)hipSetDevice(g->shards[side ? r : o]->device);
-                    if (S.sdf[side]) (void)hipFree(S.sdf[side]);
-                    if (S.wgt[side]) (void)hipFree(S.wgt[side]);
-                    if (S.rgbw[side]) (void)hipFree(S.rgbw[side]);
-                    if (S.found[side]) (void)hipFree(S.found[side]);
-                }
+        for (int side = 0; side < 2; side++)
+            for (int i = 0; i < W; i++) {
+                PairStage &S = side ? MS->in[(size_t)i] : MS->out[(size_t)i];
+                (void)hipSetDevice(g->shards[(size_t)i]->device);
+                if (S.sdf[0]) (void)hipFree(S.sdf[0]);
+                if (S.wgt[0]) (void)hipFree(S.wgt[0]);
+                if (S.rgbw[0]) (void)hipFree(S.rgbw[0]);
+                if (S.found[0]) (void)hipFree(S.found[0]);
                 if (S.exported) (void)hipEventDestroy(S.exported);
                 if (S.copied) (void)hipEventDestroy(S.copied);
                 if (S.imported) (void)hipEventDestroy(S.imported);
@@ -485,70 +484,100 @@ int update_meshes(chisel_hip_map *g, int force) {
             for (size_t k = 3; k < A.it4.size(); k += 4) A.vox += shell_volume(A.it4[k], g->N);
         }
     }
-    // ---- B: owners pack
-    rc = run_shards(g, [&](int o) -> int {
-        chisel_hip_map *src = g->shards[(size_t)o];
+    // what goes where: owner o packs requester by requester, meshing shard r installs owner by owner
+    std::vector<long long> vox_out((size_t)W, 0), vox_in((size_t)W, 0);
+    std::vector<int> n_out((size_t)W, 0), n_in((size_t)W, 0);
+    std::vector<long long> voff_out((size_t)W * W, 0), voff_in((size_t)W * W, 0);   // [r * W + o]: where pair (r, o) starts in out[o] / in[r] (voxels)
+    std::vector<int> noff_out((size_t)W * W, 0), noff_in((size_t)W * W, 0);         // ... (items)
+    for (int o = 0; o < W; o++)
         for (int r = 0; r < W; r++) {
             const Ask &A = ask[(size_t)r * W + o];
-            if (A.it4.empty()) continue;
-            PairStage &S = MS.pair[(size_t)r * W + o];
-            const int n = (int)(A.it4.size() / 4);
-            int rc2 = ensure_pair(g, S, 0, src->device, A.vox, n, color);
-            if (rc2) return rc2;
-            HIP_TRY(hipSetDevice(src->device));
-            if (!S.exported) {
-                HIP_TRY(hipEventCreateWithFlags(&S.exported, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&S.imported, hipEventDisableTiming));
-            }
-            if (S.armed) {  // the previous recompute's consumer of this buffer
-                rc2 = chisel_hip_wait_event(src, S.imported);
-                if (rc2) return rc2;
-            }
-            rc2 = chisel_hip_export_shells(src, A.it4.data(), n, S.sdf[0], S.wgt[0], S.rgbw[0], S.found[0], 1);
-            if (rc2) return rc2;
-            rc2 = chisel_hip_record_event(src, S.exported);
-            if (rc2) return rc2;
+            voff_out[(size_t)r * W + o] = vox_out[(size_t)o];
+            noff_out[(size_t)r * W + o] = n_out[(size_t)o];
+            vox_out[(size_t)o] += A.vox;
+            n_out[(size_t)o] += (int)(A.it4.size() / 4);
         }
+    for (int r = 0; r < W; r++)
+        for (int o = 0; o < W; o++) {
+            const Ask &A = ask[(size_t)r * W + o];
+            voff_in[(size_t)r * W + o] = vox_in[(size_t)r];
+            noff_in[(size_t)r * W + o] = n_in[(size_t)r];
+            vox_in[(size_t)r] += A.vox;
+            n_in[(size_t)r] += (int)(A.it4.size() / 4);
+        }
+    auto make_events = [](PairStage &S) -> int {
+        if (S.exported) return CHISEL_HIP_OK;
+        HIP_TRY(hipEventCreateWithFlags(&S.exported, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&S.imported, hipEventDisableTiming));
         return CHISEL_HIP_OK;
+    };
+    // ---- B: every owner packs the shells of ALL requesters with one call (2 W export / import calls per recompute, not 2 W^2)
+    rc = run_shards(g, [&](int o) -> int {
+        chisel_hip_map *src = g->shards[(size_t)o];
+        if (n_out[(size_t)o] == 0) return CHISEL_HIP_OK;
+        PairStage &S = MS.out[(size_t)o];
+        if (vox_out[(size_t)o] > S.cap_vox[0] || n_out[(size_t)o] > S.cap_items[0])  // (about to be reallocated: its readers are the meshing shards' copies)
+            for (int r = 0; r < W; r++)
+                if (MS.in[(size_t)r].armed) HIP_TRY(hipEventSynchronize(MS.in[(size_t)r].copied));
+        int rc2 = ensure_pair(g, S, 0, src->device, vox_out[(size_t)o], n_out[(size_t)o], color);
+        if (rc2) return rc2;
+        HIP_TRY(hipSetDevice(src->device));
+        rc2 = make_events(S);
+        if (rc2) return rc2;
+        std::vector<int> items;
+        items.reserve((size_t)n_out[(size_t)o] * 4);
+        for (int r = 0; r < W; r++) {
+            const Ask &A = ask[(size_t)r * W + o];
+            items.insert(items.end(), A.it4.begin(), A.it4.end());
+            // the previous recompute's readers of this buffer: the copies of every meshing shard
+            if (MS.in[(size_t)r].armed) HIP_TRY(hipStreamWaitEvent(src->stream, MS.in[(size_t)r].copied, 0));
+        }
+        rc2 = chisel_hip_export_shells(src, items.data(), n_out[(size_t)o], S.sdf[0], S.wgt[0], S.rgbw[0], S.found[0], 1);
+        if (rc2) return rc2;
+        return chisel_hip_record_event(src, S.exported);
     });
     if (rc) return rc;
-    // ---- C: meshing shards install, mesh, drop
+    // ---- C: every meshing shard assembles its payload from the owners' buffers (copies on its copy stream, behind the owners'
+    // events), installs the ghosts with one call, recomputes its jobs, drops the ghosts
     std::vector<uint64_t> moved((size_t)W, 0);
     rc = run_shards(g, [&](int r) -> int {
         chisel_hip_map *dst = g->shards[(size_t)r];
-        for (int o = 0; o < W; o++) {
-            const Ask &A = ask[(size_t)r * W + o];
-            if (A.it4.empty()) continue;
-            PairStage &S = MS.pair[(size_t)r * W + o];
-            chisel_hip_map *src = g->shards[(size_t)o];
-            const int n = (int)(A.it4.size() / 4);
-            int side = 0;
-            hipEvent_t ready = S.exported;
-            if (src->device != dst->device) {
-                side = 1;
-                int rc2 = ensure_pair(g, S, 1, dst->device, A.vox, n, color);
-                if (rc2) return rc2;
-                HIP_TRY(hipSetDevice(dst->device));
-                hipStream_t &cs = MS.copy[(size_t)r];
-                if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-                HIP_TRY(hipStreamWaitEvent(cs, S.exported, 0));
-                if (S.armed) HIP_TRY(hipStreamWaitEvent(cs, S.imported, 0));
-                HIP_TRY(hipMemcpyPeerAsync(S.sdf[1], dst->device, S.sdf[0], src->device, (size_t)A.vox * sizeof(float), cs));
-                HIP_TRY(hipMemcpyPeerAsync(S.wgt[1], dst->device, S.wgt[0], src->device, (size_t)A.vox * sizeof(float), cs));
-                HIP_TRY(hipMemcpyPeerAsync(S.found[1], dst->device, S.found[0], src->device, (size_t)n * sizeof(int), cs));
-                if (color) HIP_TRY(hipMemcpyPeerAsync(S.rgbw[1], dst->device, S.rgbw[0], src->device, (size_t)A.vox * 4, cs));
-                HIP_TRY(hipEventRecord(S.copied, cs));
-                ready = S.copied;
-            }
-            int rc2 = chisel_hip_wait_event(dst, ready);
+        if (n_in[(size_t)r] > 0) {
+            PairStage &S = MS.in[(size_t)r];
+            int rc2 = ensure_pair(g, S, 0, dst->device, vox_in[(size_t)r], n_in[(size_t)r], color);
             if (rc2) return rc2;
-            rc2 = chisel_hip_import_ghost_shells(dst, A.it4.data(), n, S.sdf[side], S.wgt[side], S.rgbw[side], S.found[side], 1);
+            HIP_TRY(hipSetDevice(dst->device));
+            rc2 = make_events(S);
+            if (rc2) return rc2;
+            hipStream_t &cs = MS.copy[(size_t)r];
+            if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            if (S.armed) HIP_TRY(hipStreamWaitEvent(cs, S.imported, 0));  // the previous recompute's import has read the buffer
+            std::vector<int> items;
+            items.reserve((size_t)n_in[(size_t)r] * 4);
+            for (int o = 0; o < W; o++) {
+                const Ask &A = ask[(size_t)r * W + o];
+                if (A.it4.empty()) continue;
+                items.insert(items.end(), A.it4.begin(), A.it4.end());
+                const PairStage &O = MS.out[(size_t)o];
+                chisel_hip_map *src = g->shards[(size_t)o];
+                const long long vo = voff_out[(size_t)r * W + o], vi = voff_in[(size_t)r * W + o];
+                const int no = noff_out[(size_t)r * W + o], ni = noff_in[(size_t)r * W + o], n = (int)(A.it4.size() / 4);
+                HIP_TRY(hipStreamWaitEvent(cs, O.exported, 0));
+                HIP_TRY(hipMemcpyPeerAsync(S.sdf[0] + vi, dst->device, O.sdf[0] + vo, src->device, (size_t)A.vox * sizeof(float), cs));
+                HIP_TRY(hipMemcpyPeerAsync(S.wgt[0] + vi, dst->device, O.wgt[0] + vo, src->device, (size_t)A.vox * sizeof(float), cs));
+                HIP_TRY(hipMemcpyPeerAsync(S.found[0] + ni, dst->device, O.found[0] + no, src->device, (size_t)n * sizeof(int), cs));
+                if (color) HIP_TRY(hipMemcpyPeerAsync(S.rgbw[0] + 4 * vi, dst->device, O.rgbw[0] + 4 * vo, src->device, (size_t)A.vox * 4, cs));
+                moved[(size_t)r] += (uint64_t)A.vox * (color ? 12 : 8);
+            }
+            HIP_TRY(hipEventRecord(S.copied, cs));
+            rc2 = chisel_hip_wait_event(dst, S.copied);
+            if (rc2) return rc2;
+            rc2 = chisel_hip_import_ghost_shells(dst, items.data(), n_in[(size_t)r], S.sdf[0], S.wgt[0], S.rgbw[0], S.found[0], 1);
             if (rc2) return rc2;
             rc2 = chisel_hip_record_event(dst, S.imported);
             if (rc2) return rc2;
             S.armed = true;
-            moved[(size_t)r] += (uint64_t)A.vox * (color ? 12 : 8);
         }
         int rc2 = chisel_hip_update_meshes_of(dst, jobs[(size_t)r].data(), (int)(jobs[(size_t)r].size() / 3));
         if (rc2) return rc2;
