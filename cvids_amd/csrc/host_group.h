@@ -451,16 +451,44 @@ int update_meshes(chisel_hip_map *g, int force) {
     const int W = n_shards(g);
     if (W == 1) return chisel_hip_update_meshes(g->shards[0], 1);
     MeshStages &MS = *static_cast<MeshStages *>(g->mesh_stages_group);
-    // ---- A: meshesToUpdate of the whole map, as (x, y, z, 1) entries (already the 27-neighbourhoods: chisel_hip_meshes_to_update expands)
-    std::vector<int> uni;
-    int rc = gather_ids(g, chisel_hip_meshes_to_update, true, uni);
+    const bool timing = g_host_timer.on;
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_phase[5] = {0, 0, 0, 0, 0};
+    auto lap = [&](int i) {
+        if (!timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        t_phase[i] += std::chrono::duration<double, std::micro>(n - t_prev).count();
+        t_prev = n;
+    };
+    // ---- A: what the shards have updated since the last recompute, as the planner's entries: (x, y, z, 0) per dirty chunk -- the planner
+    // expands the 27-neighbourhoods itself (Chisel.h:175-189), on its grid, cheaper than a host set per shard -- and (x, y, z, 1) per
+    // id the host holds (neighbourhoods of chunks that were removed while dirty).  Duplicates are the planner's business.
+    std::vector<std::vector<int>> part((size_t)W);
+    int rc = run_shards(g, [&](int i) -> int {
+        chisel_hip_map *sh = g->shards[(size_t)i];
+        HIP_TRY(hipSetDevice(sh->device));
+        int rc2 = check_mesh_totals(sh);
+        if (rc2) return rc2;
+        std::vector<int> dirty;
+        rc2 = fetch_listed(sh, true, dirty, nullptr);
+        if (rc2) return rc2;
+        std::vector<int> &e = part[(size_t)i];
+        e.reserve(dirty.size() / 3 * 4 + sh->pending_mesh_ids.size() * 4);
+        for (size_t j = 0; j + 2 < dirty.size(); j += 3) {
+            e.insert(e.end(), dirty.begin() + j, dirty.begin() + j + 3);
+            e.push_back(0);
+        }
+        for (uint64_t key : sh->pending_mesh_ids) {
+            int x, y, z;
+            unpack_id(key, x, y, z);
+            e.push_back(x); e.push_back(y); e.push_back(z); e.push_back(1);
+        }
+        return CHISEL_HIP_OK;
+    });
     if (rc) return rc;
     std::vector<int> entries;
-    entries.reserve(uni.size() / 3 * 4);
-    for (size_t j = 0; j + 2 < uni.size(); j += 3) {
-        entries.insert(entries.end(), uni.begin() + j, uni.begin() + j + 3);
-        entries.push_back(1);
-    }
+    for (const std::vector<int> &e : part) entries.insert(entries.end(), e.begin(), e.end());
+    lap(0);
     const bool color = g->cfg.use_color != 0;
     struct Ask {            // what shard r needs of owner o
         std::vector<int> it4;
@@ -484,6 +512,7 @@ int update_meshes(chisel_hip_map *g, int force) {
             for (size_t k = 3; k < A.it4.size(); k += 4) A.vox += shell_volume(A.it4[k], g->N);
         }
     }
+    lap(1);
     // what goes where: owner o packs requester by requester, meshing shard r installs owner by owner
     std::vector<long long> vox_out((size_t)W, 0), vox_in((size_t)W, 0);
     std::vector<int> n_out((size_t)W, 0), n_in((size_t)W, 0);
@@ -538,6 +567,7 @@ int update_meshes(chisel_hip_map *g, int force) {
         return chisel_hip_record_event(src, S.exported);
     });
     if (rc) return rc;
+    lap(2);
     // ---- C: every meshing shard assembles its payload from the owners' buffers (copies on its copy stream, behind the owners'
     // events), installs the ghosts with one call, recomputes its jobs, drops the ghosts
     std::vector<uint64_t> moved((size_t)W, 0);
@@ -583,6 +613,10 @@ int update_meshes(chisel_hip_map *g, int force) {
         if (rc2) return rc2;
         return chisel_hip_drop_ghost_chunks(dst);
     });
+    lap(3);
+    if (timing)
+        fprintf(stderr, "chisel_hip group recompute, host us: dirty lists %.0f | plan %.0f | exports %.0f | copies + imports + recompute + drop %.0f (%zu entries)\n",
+                t_phase[0], t_phase[1], t_phase[2], t_phase[3], entries.size() / 4);
     for (uint64_t v : moved) g->ghost_bytes += v;
     return rc;
 }
