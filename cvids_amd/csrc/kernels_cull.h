@@ -429,6 +429,9 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
 #ifndef REFINE_TEXELS
 #define REFINE_TEXELS 4
 #endif
+#ifndef REFINE_BLOCK
+#define REFINE_BLOCK 256   // threads per workgroup of refine_kernel (one wave per (item, frame) pair; the waves of a workgroup never meet)
+#endif
 template <int N>
 __global__ __launch_bounds__(256) void refine_kernel(IntegrateParams P, PyramidView pyr, int pyr_stride,
                                                      const WorkItem *__restrict__ items, const FrameBox *__restrict__ boxes, const int *__restrict__ work_count,

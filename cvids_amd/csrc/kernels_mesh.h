@@ -512,7 +512,8 @@ __global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void m
     // (the first job's id is requested together with the job count: the id buffer holds at least 4096 entries -- more than the
     // grid has workgroups -- whatever the count; ensure_mesh_jobs)
     int jx0 = ids[3 * blockIdx.x], jy0 = ids[3 * blockIdx.x + 1], jz0 = ids[3 * blockIdx.x + 2];
-    const int n = *n_jobs;  // the job count stays on the device: the grid is persistent
+    int n = *n_jobs;  // the job count stays on the device: the grid is persistent
+    if (ids == M.mesh_jobs && n > M.mesh_jobs_capacity) n = M.mesh_jobs_capacity;  // (the kept list never gets there: the host gives it up first)
     if (blockIdx.x == 0 && threadIdx.x == 0) totals[3] = n;  // where the kernels behind this one (and a second emission) read it
     if (threadIdx.x < 64) s_counts[threadIdx.x] = reinterpret_cast<const unsigned *>(c_mc_counts)[threadIdx.x];  // (first barrier below)
     // the list of dirty slots has been consumed by the mark kernel -- also when none of them became a job (every listed chunk
@@ -936,14 +937,13 @@ struct MeshBuffers {
     MeshJob *jobs = nullptr;
     int *ids = nullptr;
     JobInfo *info = nullptr; // [capacity] per-job results of a recompute
-    int *totals = nullptr;   // [8]: triangles, grids, triangle-list overflow flag, jobs; [4], [5]: the mark kernel's alternating job counters
-    int *n_jobs = nullptr;   // where the count kernel finds the number of jobs (one of the two counters, or null: totals[3])
-    unsigned mark_turn = 0;  // which of the two counters the next mark kernel fills
+    int *totals = nullptr;   // [8] = MapView::mesh_ctl: triangles, grids, triangle-list overflow flag, jobs; [4]: entries of the job list the integration kernels keep
+    int *n_jobs = nullptr;   // where the count kernel finds the number of jobs (the kept list's length, or null: totals[3] and the caller's ids)
     TriRec *tris = nullptr;  // triangle list of one recompute
     CubeCorners *corners = nullptr;  // [tri_capacity] corner distances of its occupied cubes
     int tri_capacity = 0;
     int capacity = 0;        // jobs
-    unsigned *flags = nullptr;  // [max_chunks] "mesh this slot"
+    unsigned *flags = nullptr;  // [max_chunks] "this slot is in the job list" = MapView::mesh_flag
     double *query = nullptr;
     float *cube = nullptr;      // result of mesh_one_cube_kernel
 };
