@@ -1002,10 +1002,22 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         if (e_ != hipSuccess)                                                                                 \
             return cleanup(fail(CHISEL_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)));      \
     } while (0)
-    HIP_TRY_C(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
-    if (getenv("CHISEL_HIP_SERIAL")) {
+    // Diagnostic CHISEL_HIP_FRONT_CUS=k: k compute units of every XCD set aside for the front half's streams, the map's own stream on
+    // the others (bit i of a CU mask = CU i / 8 of XCD i % 8 on this part).  Measured in round 4 (profiles/r04_cu_partition.txt,
+    // tools/ab_cus.sh): slower at every k on every stream -- the front half is a third of the chip's work, not a latency problem.
+    const int front_cus = getenv("CHISEL_HIP_FRONT_CUS") ? atoi(getenv("CHISEL_HIP_FRONT_CUS")) : 0;
+    if (front_cus > 0 && front_cus < 32 && !getenv("CHISEL_HIP_SERIAL")) {
+        uint32_t mask_front[8] = {0}, mask_back[8] = {0};
+        for (int i = 0; i < 256; i++) ((i / 8 < front_cus) ? mask_front : mask_back)[i / 32] |= 1u << (i % 32);
+        if (getenv("CHISEL_HIP_BACK_ALL_CUS")) for (auto &w : mask_back) w = ~0u;
+        HIP_TRY_C(hipExtStreamCreateWithCUMask(&m->own_stream, 8, mask_back));
+        HIP_TRY_C(hipExtStreamCreateWithCUMask(&m->aux, 8, mask_front));
+        HIP_TRY_C(hipExtStreamCreateWithCUMask(&m->aux2, 8, mask_front));
+    } else if (getenv("CHISEL_HIP_SERIAL")) {
+        HIP_TRY_C(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
         m->aux = m->own_stream;  // diagnostic: both halves on one stream, nothing overlaps
     } else {
+        HIP_TRY_C(hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
         // the front half is short and feeds the long integration kernel of the next batch: let its workgroups go first
         int least = 0, greatest = 0;
         HIP_TRY_C(hipDeviceGetStreamPriorityRange(&least, &greatest));
