@@ -97,12 +97,12 @@ def parse():
     preset = {2: {"res": 0.02, "no_color": True, "mesh_every": 0},
               3: {},
               4: {"agents": 4},
-              5: {"width": 1280, "height": 720, "res": 0.005, "mesh_every": 0, "batch": 8, "max_chunks": 1 << 18}}[args.config]
+              5: {"width": 1280, "height": 720, "res": 0.005, "mesh_every": 0, "batch": 16, "max_chunks": 1 << 18}}[args.config]
     for k, v in preset.items():
         if "--" + k.replace("_", "-") not in given:
             setattr(args, k, v)
     if args.config == 5 and "--steps" not in given:
-        args.steps, args.warmup = 40, 8
+        args.steps, args.warmup = 48, 16
     return args
 
 

@@ -55,7 +55,9 @@ struct Pool {
                 if (std::chrono::steady_clock::now() - idle > std::chrono::microseconds(500)) {
                     std::unique_lock<std::mutex> lk(mu);
                     sleepers.fetch_add(1);
-                    cv.wait(lk, [&] { return seq.load(std::memory_order_acquire) != seen || stop.load(); });
+                    // (sleepers += 1, then seq read; the issuing side: seq += 1, then sleepers read -- all four sequentially consistent, so one
+                    // of the two sees the other: no lost wake-up)
+                    cv.wait(lk, [&] { return seq.load() != seen || stop.load(); });
                     sleepers.fetch_sub(1);
                 } else {
                     __builtin_ia32_pause();
@@ -103,7 +105,7 @@ int run_shards(chisel_hip_map *g, F fn) {
     }
     P->job = fn;
     P->done.store(0, std::memory_order_relaxed);
-    P->seq.fetch_add(1, std::memory_order_release);
+    P->seq.fetch_add(1);
     if (P->sleepers.load() > 0) {
         std::lock_guard<std::mutex> lk(P->mu);
         P->cv.notify_all();

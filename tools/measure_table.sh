@@ -30,7 +30,7 @@ row "no mesh, 16 per call, depth only" --mesh-every 0 --batch 16 --no-color
 row "frame by frame" --mesh-every 0 --batch 1
 row "late window (420-620)" --steps 200 --warmup 400
 row "late window, no mesh" --steps 200 --warmup 400 --mesh-every 0
-row "1280x720 @ 0.5 cm" --width 1280 --height 720 --res 0.005 --mesh-every 0 --batch 8 --steps 64 --warmup 16
+row "1280x720 @ 0.5 cm" --width 1280 --height 720 --res 0.005 --mesh-every 0 --batch 16 --steps 64 --warmup 16
 row "640x480 @ 2 cm depth only" --res 0.02 --no-color --mesh-every 0 --batch 8
 row "4 agents" --agents 4 --mesh-every 0 --batch 16 --steps 320 --warmup 64
 scenes

@@ -3,7 +3,7 @@
 # bash tools/shard_table_c5.sh      (integration only: the end-of-stream GC + full mesh extraction is not part of the per-rank rate)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for n in ${SHARDS:-1 2 4 8}; do
-  python3 bench.py --sim-shards $n --sim-rank 0 --width 1280 --height 720 --res 0.005 --trunc-scale 0.5 --max-chunks 262144 --mesh-every 0 --batch 8 \
+  python3 bench.py --sim-shards $n --sim-rank 0 --width 1280 --height 720 --res 0.005 --trunc-scale 0.5 --max-chunks 262144 --mesh-every 0 --batch ${BATCH:-16} \
       --steps ${STEPS:-64} --warmup ${WARMUP:-16} --no-cpu-baseline --no-pcie-leg --no-e2e-leg --repeats 3 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
