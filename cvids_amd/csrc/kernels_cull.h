@@ -311,9 +311,6 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
         const bool inband = (dmin - band < pre.zs1) && (dmax + band > zlo);
         const bool carve = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
         if (!inband && !carve) return 0;
-#ifdef CULL_ABLATE_CARVE_ONLY  // (incorrect, an ablation: what the exact bounds of candidates that can only be carved cost)
-        if (!inband) return 0;
-#endif
     }
     // chunk box exactly as the reference builds it (ChunkManager.cpp:201-203)
     const float bminx = (float)(cx * N) * ip.res, bminy = (float)(cy * N) * ip.res, bminz = (float)(cz * N) * ip.res;
