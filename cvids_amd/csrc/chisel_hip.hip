@@ -132,6 +132,16 @@ struct ProfEvent {
 
 }  // namespace
 
+// Buffer sets of the front half (a batch's front may start once the batch that used its set has been integrated) and pending sets
+// (batch b reads those of b - 1 and b - 2; its pyramid kernel clears its own, last used by b - CHISEL_PENDING_RING).  3 / 4: two
+// front halves in flight beside an integration.  4 / 8 (-DCHISEL_FRONT_SETS=4 -DCHISEL_PENDING_RING=8): three, on three streams.
+#ifndef CHISEL_FRONT_SETS
+#define CHISEL_FRONT_SETS 3
+#endif
+#ifndef CHISEL_PENDING_RING
+#define CHISEL_PENDING_RING 4
+#endif
+static_assert(CHISEL_FRONT_SETS >= 3 && (CHISEL_PENDING_RING & (CHISEL_PENDING_RING - 1)) == 0 && CHISEL_PENDING_RING >= 4, "front-half rings");
 struct chisel_hip_map {
     // a group handle (chisel_hip_create_group, host_group.h): no device state of its own, one shard map per GPU
     bool is_group = false;
@@ -172,9 +182,9 @@ struct chisel_hip_map {
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
         hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's work-list (and with it its pending set) is complete
         hipEvent_t back_done = nullptr;   // recorded on the map's stream after the set's integration
-    } sets[3];
-    uint64_t *pending_ring[4] = {nullptr, nullptr, nullptr, nullptr};  // [PENDING_CAPACITY + 1] each: the set, then its overflow flag
-    hipStream_t aux = nullptr, aux2 = nullptr;  // the front halves of even / odd batches
+    } sets[CHISEL_FRONT_SETS];
+    uint64_t *pending_ring[CHISEL_PENDING_RING] = {};  // [PENDING_CAPACITY + 1] each: the set, then its overflow flag
+    hipStream_t aux = nullptr, aux2 = nullptr, aux3 = nullptr;  // the front halves of consecutive batches take them in turn (aux3: CHISEL_FRONT_SETS >= 4 only)
     hipEvent_t call_event = nullptr;     // caller-provided stream: orders the front after the caller's producers
     hipEvent_t mutation_event = nullptr; // map changed outside the integration path (reset, upload): the next front waits
     bool mutation_pending = false;
@@ -273,6 +283,7 @@ int sync_all(chisel_hip_map *m) {
     for (int pass = 0; pass < 2; pass++) {
         if (m->aux) HIP_TRY(hipStreamSynchronize(m->aux));
         if (m->aux2) HIP_TRY(hipStreamSynchronize(m->aux2));
+        if (m->aux3) HIP_TRY(hipStreamSynchronize(m->aux3));
         if (!pass) HIP_TRY(hipStreamSynchronize(m->stream));
     }
     return CHISEL_HIP_OK;
@@ -474,11 +485,11 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // the chunks the batches in flight may create: the pending sets of the previous two (complete once the previous batch's
         // resolve step is through: the one wait between consecutive front halves)
         const unsigned b = m->batch_seq;
-        const uint64_t *prev_pending = (b >= 1 || m->force_uncertain) ? m->pending_ring[(b + 3u) & 3u] : nullptr;
-        const uint64_t *prev2_pending = b >= 2 ? m->pending_ring[(b + 2u) & 3u] : nullptr;
-        if (b >= 1 && hipEventQuery(m->sets[(b + 2u) % 3u].front_done) != hipSuccess) {  // (no wait packet for what is over: below)
+        const uint64_t *prev_pending = (b >= 1 || m->force_uncertain) ? m->pending_ring[(b + CHISEL_PENDING_RING - 1u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
+        const uint64_t *prev2_pending = b >= 2 ? m->pending_ring[(b + CHISEL_PENDING_RING - 2u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
+        if (b >= 1 && hipEventQuery(m->sets[(b + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS].front_done) != hipSuccess) {  // (no wait packet for what is over: below)
             (void)hipGetLastError();
-            HIP_TRY(hipStreamWaitEvent(front, m->sets[(b + 2u) % 3u].front_done, 0));
+            HIP_TRY(hipStreamWaitEvent(front, m->sets[(b + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS].front_done, 0));
         }
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
         const int *force_flag = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : nullptr;
@@ -648,8 +659,8 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     PP.ip = CP.ip = IP.ip = ip;
     PP.W = W;
     PP.H = H;
-    chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq % 3u];
-    bs.pending = m->pending_ring[m->batch_seq & 3u];
+    chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq % CHISEL_FRONT_SETS];
+    bs.pending = m->pending_ring[m->batch_seq & (CHISEL_PENDING_RING - 1u)];
     PP.rec_stride = (int)npx + 2;
     PP.pyr_stride = m->pyr_stride;
     PP.rec = bs.rec_data + 2;
@@ -693,13 +704,14 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     const bool meshing = m->recomputes != m->recomputes_seen;  // a mesh recompute was issued since the previous batch
     m->recomputes_seen = m->recomputes;
     {
-        const chisel_hip_map::BatchSet &prev = m->sets[(m->batch_seq + 2u) % 3u];  // the previous batch's (integrations complete in order)
+        const chisel_hip_map::BatchSet &prev = m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS];  // the previous batch's (integrations complete in order)
         const bool idle = (m->batch_seq == 0 || hipEventQuery(prev.back_done) == hipSuccess) && !m->pending_meshes.unchecked &&
                           !m->force_pipeline;
         // Two auxiliary streams, taken in turn, double the rate of the front halves -- which is what a stream without meshing
         // hangs on (98 -> 122 k frames/s) -- but a stream that recomputes meshes between its batches is paced by integration +
         // meshing on the map's stream, and a second front half beside them only takes 3 % from it: one stream then.
         hipStream_t side = (m->batch_seq & 1u) && m->aux2 && !meshing ? m->aux2 : m->aux;
+        if (m->aux3 && !meshing) side = (m->batch_seq % 3u) == 2u ? m->aux3 : ((m->batch_seq % 3u) == 1u ? m->aux2 : m->aux);
         bs.front_stream = (idle || m->stream != m->own_stream || m->aux == m->own_stream) ? m->stream : side;
     }
     hipStream_t front = bs.front_stream;
@@ -709,10 +721,12 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         // stream (short form): what it wrote must be complete before this one's kernels read the candidates' neighbours' state
         HIP_TRY(hipStreamWaitEvent(front, bs.back_done, 0));
         // this batch's pyramid kernel clears the pending buffer that the resolve step of batch b-2 still reads (as its b-4)
-        if (m->batch_seq >= 2) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + 1u) % 3u].front_done, 0));
+        // (with a pending ring of NSETS + 3 or more the buffer's last readers finished before the set came free: no such wait)
+        if (m->batch_seq >= 2 && CHISEL_PENDING_RING < CHISEL_FRONT_SETS + 3)
+            HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].front_done, 0));
         // a stream paced by integration + meshing gains nothing from a front half that starts a batch earlier (it only runs
         // beside more of the kernels that set the pace): the two-set rule for it
-        if (meshing && m->batch_seq >= 2) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + 1u) % 3u].back_done, 0));
+        if (meshing && m->batch_seq >= 2) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].back_done, 0));
         if (m->mutation_pending) HIP_TRY(hipStreamWaitEvent(front, m->mutation_event, 0));
     }
     m->mutation_pending = false;
@@ -1025,6 +1039,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         const int prio = pr && !strcmp(pr, "low") ? least : (pr && !strcmp(pr, "normal") ? (least + greatest) / 2 : greatest);
         HIP_TRY_C(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, prio));
         if (!getenv("CHISEL_HIP_ONE_FRONT_STREAM")) HIP_TRY_C(hipStreamCreateWithPriority(&m->aux2, hipStreamNonBlocking, prio));
+        if (CHISEL_FRONT_SETS >= 4 && m->aux2) HIP_TRY_C(hipStreamCreateWithPriority(&m->aux3, hipStreamNonBlocking, prio));
     }
     m->stream = m->own_stream;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
@@ -1132,6 +1147,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
     if (m->aux2) (void)hipStreamDestroy(m->aux2);
+    if (m->aux3) (void)hipStreamDestroy(m->aux3);
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     if (m->mesh_totals_host) (void)hipHostFree(m->mesh_totals_host);
     if (m->error_flag_host) (void)hipHostFree(m->error_flag_host);

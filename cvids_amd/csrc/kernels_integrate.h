@@ -246,6 +246,11 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
         }
     }
     const int grid_waves = nb * G::WPB;
+#if defined(CHISEL_PHASES) && defined(PHASE0_AT)
+#define PHASE0(at, dep) do { if (PHASE0_AT == at) { asm volatile("" ::"s"(dep)); PHASE(0); } } while (0)  // diagnostic: where inside the "item" stage the first stamp sits
+#else
+#define PHASE0(at, dep) do { } while (0)
+#endif
     // Two granularities in one launch (VPL0 == 4): the items behind `split` -- the tail of the cost-ordered list -- run with 2 voxels per
     // lane: twice as many units of half the length, so that the stretch in which the chip drains (one unit long) is half as long.  Only
     // when the grid covers every unit statically (sized by the host from a recent launch's item count); a launch that turns out
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             using G = Geom<N, VPL>;
             using QuadF = QuadFT<VPL>;
             using QuadU = QuadUT<VPL>;
+            PHASE0(1, n_items);
             const WorkItem wi = items[it];
             // lane k: what frame k needs of this chunk (refine_kernel), requested together with the work item
             CellRec cr;
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             for (int o = 32; o > 0; o >>= 1) unit_cells |= (unsigned)__shfl_xor((int)unit_cells, o);
             const unsigned need_half = cell_half ? (unsigned)(cr.need >> 32) : (unsigned)cr.need;  // lane k: frame k's cells of this brick's half
             const unsigned unit_frames = (unsigned)__ballot((need_half & unit_cells) != 0u);  // frames that can touch this brick (lanes >= n_frames hold 0)
+            PHASE0(2, (int)unit_frames);
             if (slot >= 0 && (mask & unit_frames) == 0u) return;  // a resident chunk, and no frame of the launch can touch this brick
             if (slot == SLOT_LOOKUP) {
                 // the previous batch may have created this chunk while the work-list was built: it has finished now
@@ -347,7 +354,9 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
 #pragma unroll
                 for (int j = 0; j < VPL; j++) wx[j] = ((float)(vx0 + j) * ip.res + ip.half_res) + ox;
             }
+#if !defined(PHASE0_AT)
             PHASE(0);
+#endif
 #ifdef CHISEL_PHASES
             ph_units++;
             ph_last_start = ph_t;
