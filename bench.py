@@ -615,6 +615,9 @@ def main():
                                       "ghost_bytes_per_recompute_rank0": mesh_stats["ghost_bytes"] / max(1, mesh_stats["recomputes"]),
                                       "whole_ghost_chunks_would_be": sharded_totals[1] / max(1, mesh_stats["recomputes"]),
                                       "shells_over_whole_chunks": sharded_totals[0] / max(1, sharded_totals[1])}
+            if getattr(m.sharded, "phase_us", None):  # CHISEL_HIP_HOST_TIMING=1: rank 0's host time per sharded recompute, by phase
+                n_rc = max(1, m.sharded.phase_us.get("recomputes", 1))
+                out["sharded_meshing"]["host_us_per_recompute_rank0"] = {k: round(v / n_rc, 1) for k, v in m.sharded.phase_us.items() if k != "recomputes"}
             out["load_balance"] = {"n_sdf_per_rank_max_over_mean": max(per_rank_sdf) / max(1e-9, sum(per_rank_sdf) / world), "n_sdf_per_rank": per_rank_sdf}
             out["exchange"] = {"payload": "depth + colour" if xcolor else "depth only (one static colour image resident on every rank)",
                                "bytes_per_batch": K * (W * H * 4 + 128 + (W * H * 3 if xcolor else 0)),

@@ -132,14 +132,19 @@ struct ProfEvent {
 
 }  // namespace
 
-// Buffer sets of the front half (a batch's front may start once the batch that used its set has been integrated) and pending sets
-// (batch b reads those of b - 1 and b - 2; its pyramid kernel clears its own, last used by b - CHISEL_PENDING_RING).  3 / 4: two
-// front halves in flight beside an integration.  4 / 8 (-DCHISEL_FRONT_SETS=4 -DCHISEL_PENDING_RING=8): three, on three streams.
+// Buffer sets of the front half (a batch's front may start once the batch that used its set has been integrated), pending sets
+// (batch b reads those of b - 1 and b - 2; its pyramid kernel clears its own, last used by b - CHISEL_PENDING_RING) and front streams.
+// 4 / 8 / 2 since the end of round 4: with a pending ring of SETS + 3 or more a front half no longer waits for the one two batches
+// back, and its buffer set comes free a batch earlier (one rank of eight + 6-8 %, nothing elsewhere; 3 / 4 / 2 before).  A third
+// front stream (4 / 8 / 3) costs what it gains (profiles/r04_front_sets.txt).
 #ifndef CHISEL_FRONT_SETS
-#define CHISEL_FRONT_SETS 3
+#define CHISEL_FRONT_SETS 4
 #endif
 #ifndef CHISEL_PENDING_RING
-#define CHISEL_PENDING_RING 4
+#define CHISEL_PENDING_RING 8
+#endif
+#ifndef CHISEL_FRONT_STREAMS
+#define CHISEL_FRONT_STREAMS 2
 #endif
 static_assert(CHISEL_FRONT_SETS >= 3 && (CHISEL_PENDING_RING & (CHISEL_PENDING_RING - 1)) == 0 && CHISEL_PENDING_RING >= 4, "front-half rings");
 struct chisel_hip_map {
@@ -164,9 +169,9 @@ struct chisel_hip_map {
     //   back  (the map's stream): integrate_kernel
     // The fronts of batches b+1 and b+2 run while the back of batch b is still executing -- on two auxiliary streams, so that
     // consecutive fronts overlap each other too (each is a chain of four short kernels: one stream runs them at half the rate the
-    // chip could) -- so every buffer the front writes exists three times (sets rotate per batch); events order the halves.
-    // The pending sets (chunks a batch may create) rotate over four buffers of their own: batch b reads those of b-1 and b-2
-    // while b+1 is already filling its own, and b+2's pyramid kernel may be clearing the fourth.
+    // chip could) -- so every buffer the front writes exists CHISEL_FRONT_SETS times (sets rotate per batch); events order the halves.
+    // The pending sets (chunks a batch may create) rotate over CHISEL_PENDING_RING buffers of their own: batch b reads those of b-1
+    // and b-2 while later batches fill theirs; a batch's pyramid kernel clears the one it is about to use.
     struct BatchSet {
         float2 *pyr_data = nullptr;      // [KMAX][pyr_stride]
         PixelRec *rec_data = nullptr;    // [KMAX][2 + W*H]: per frame two all-NaN records, then the image
@@ -215,7 +220,7 @@ struct chisel_hip_map {
     bool refine_always = false;          // test / A-B hook (CHISEL_HIP_REFINE=2): also one-frame launches of the short form are refined
     bool refine_off = false;             // test / A-B hook (CHISEL_HIP_REFINE=0 at creation): every cell of every frame of an item's mask counts as needed
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
-    unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % 3] and pending_ring[b % 4]
+    unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % CHISEL_FRONT_SETS] and pending_ring[b % CHISEL_PENDING_RING]
     unsigned recomputes = 0, recomputes_seen = 0;  // mesh recomputes issued / as of the previous batch (front-stream choice)
     int items_capacity = 0;
     int pyr_w = 0, pyr_h = 0, pyr_stride = 0;
@@ -716,7 +721,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     }
     hipStream_t front = bs.front_stream;
     if (front != m->stream) {
-        // the front half may start as soon as the batch that last used this buffer set (three batches ago) has been integrated;
+        // the front half may start as soon as the batch that last used this buffer set (CHISEL_FRONT_SETS batches ago) has been integrated;
         // only its resolve step waits for the previous batch's (launch_group).  The previous front half may have run on the map's
         // stream (short form): what it wrote must be complete before this one's kernels read the candidates' neighbours' state
         HIP_TRY(hipStreamWaitEvent(front, bs.back_done, 0));
@@ -1039,7 +1044,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         const int prio = pr && !strcmp(pr, "low") ? least : (pr && !strcmp(pr, "normal") ? (least + greatest) / 2 : greatest);
         HIP_TRY_C(hipStreamCreateWithPriority(&m->aux, hipStreamNonBlocking, prio));
         if (!getenv("CHISEL_HIP_ONE_FRONT_STREAM")) HIP_TRY_C(hipStreamCreateWithPriority(&m->aux2, hipStreamNonBlocking, prio));
-        if (CHISEL_FRONT_SETS >= 4 && m->aux2) HIP_TRY_C(hipStreamCreateWithPriority(&m->aux3, hipStreamNonBlocking, prio));
+        if (CHISEL_FRONT_SETS >= 4 && CHISEL_FRONT_STREAMS >= 3 && m->aux2) HIP_TRY_C(hipStreamCreateWithPriority(&m->aux3, hipStreamNonBlocking, prio));
     }
     m->stream = m->own_stream;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));

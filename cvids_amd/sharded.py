@@ -304,6 +304,15 @@ class ShardedChisel:
             return 0
         on_gpu = dev.type == "cuda"
         edge = int(self.map.chunk_size[0])
+        import os, time
+        timing = os.environ.get("CHISEL_HIP_HOST_TIMING") is not None  # host phases of a sharded recompute, summed in self.phase_us
+        t_prev = [time.perf_counter()]
+        def lap(name):
+            if timing:
+                now = time.perf_counter()
+                self.phase_us = getattr(self, "phase_us", {})
+                self.phase_us[name] = self.phase_us.get(name, 0.0) + (now - t_prev[0]) * 1e6
+                t_prev[0] = now
         # ---- 1. the ranks' dirty chunks
         while True:
             cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 14)
@@ -331,6 +340,7 @@ class ShardedChisel:
                 break
             self._dirty_cap = 2 * int(g[:, 0].max())  # (every rank sees the same counts and takes the same turn)
         entries = np.concatenate([g[r, 1:1 + 4 * int(g[r, 0])].reshape(-1, 4) for r in range(world)], axis=0)
+        lap("dirty ids + all_gather + host copy")
         # ---- 2. the plans
         # (all ranks' plans in ONE pass of the planner: chisel_hip_mesh_shell_plan_all -- evaluating chisel_hip_mesh_shell_plan once per
         # rank cost every rank 1-2 ms per rank and recompute)
@@ -346,6 +356,7 @@ class ShardedChisel:
         vol = lambda it: int(shell_volumes(it[:, 3], edge).sum()) if len(it) else 0
         v_send = [vol(p) for p in send_parts]
         v_recv = [vol(recv_items[sum(n_recv[:o]):sum(n_recv[:o + 1])]) for o in range(world)]
+        lap("plan")
         # ---- 3. shells: export -> all_to_all -> import
         if on_gpu:
             self._order_map_after_collectives()
@@ -356,6 +367,7 @@ class ShardedChisel:
             sdf_s, wgt_s = torch.from_numpy(np.ascontiguousarray(a, np.float32)), torch.from_numpy(np.ascontiguousarray(b, np.float32))
             col_s = torch.from_numpy(np.ascontiguousarray(c, np.uint8)) if c is not None else None
             found_s = torch.from_numpy(np.ascontiguousarray(f, np.int32))
+        lap("export")
         total = sum(v_recv)
         sdf_r = torch.empty((total,), dtype=torch.float32, device=dev)
         wgt_r = torch.empty((total,), dtype=torch.float32, device=dev)
@@ -367,6 +379,7 @@ class ShardedChisel:
         if col_s is not None:
             col_r = torch.empty((total, 4), dtype=torch.uint8, device=dev)
             self._all_to_all(col_r, col_s, v_recv, v_send)
+        lap("all_to_all x 3-4 (issue)")
         if len(recv_items):
             if on_gpu:
                 self._order_map_after_collectives()
@@ -374,8 +387,12 @@ class ShardedChisel:
             else:
                 self.map.ImportGhostShells(recv_items, sdf_r.numpy(), wgt_r.numpy(), None if col_r is None else col_r.numpy(), found_r.numpy())
         # ---- 4.
+        lap("import")
         self.map.UpdateMeshesOf(jobs)
         self.map.DropGhostChunks()
+        lap("recompute + drop (issue)")
+        if timing:
+            self.phase_us["recomputes"] = self.phase_us.get("recomputes", 0) + 1
         per_voxel = 12 if col_r is not None else 8
         # for the record: what whole ghost chunks (the round-2 protocol) would have moved for the same ghosts
         self.whole_chunk_bytes = getattr(self, "whole_chunk_bytes", 0) + (len(np.unique(recv_items[:, :3], axis=0)) if len(recv_items) else 0) * edge ** 3 * per_voxel
