@@ -304,8 +304,8 @@ class ShardedChisel:
             return 0
         on_gpu = dev.type == "cuda"
         edge = int(self.map.chunk_size[0])
-        import os, time
-        timing = os.environ.get("CHISEL_HIP_HOST_TIMING") is not None  # host phases of a sharded recompute, summed in self.phase_us
+        import time
+        timing = True  # host phases of a sharded recompute, summed in self.phase_us (six perf_counter calls per recompute)
         t_prev = [time.perf_counter()]
         def lap(name):
             if timing:
@@ -315,7 +315,7 @@ class ShardedChisel:
                 t_prev[0] = now
         # ---- 1. the ranks' dirty chunks
         while True:
-            cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 14)
+            cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 12)  # (entries per rank in the gathered tensor; doubled below when a rank has more)
             buf = torch.zeros((1 + 4 * cap,), dtype=torch.int32, device=dev)
             if ids is None and on_gpu:
                 self._order_map_after_collectives()  # (the buffer was zeroed on torch's stream)
