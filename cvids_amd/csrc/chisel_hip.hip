@@ -5,6 +5,7 @@
 #include "../../include/chisel_hip_selftest.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -214,7 +215,8 @@ struct chisel_hip_map {
         int force_cull_waves = 0;               // CHISEL_HIP_CULL_WAVES=4|16
         bool persistent_grid = false;           // CHISEL_HIP_PERSISTENT=1: a resident grid pulling units from the queue heads
         bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
-        bool always_wait_packet = false;        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
+        bool always_wait_packet = false;
+        bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: sharded maps        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
     } tune;
     int64_t launch_stats[CHISEL_HIP_NUM_LAUNCH_STATS] = {};  // chisel_hip_get_launch_stats
     bool refine_always = false;          // test / A-B hook (CHISEL_HIP_REFINE=2): also one-frame launches of the short form are refined
@@ -442,6 +444,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     // `front` was decided in integrate_group (it also routes the staging copies).
     hipStream_t front = bs.front_stream;
     const bool inline_resolve = front == m->stream;
+    bool front_recorded = false;
     bool skip_refine = false;  // the short form of a one-frame launch: the cull kernel fills the CellRecs itself (4 us of launch for 2 us of integration)
     {
     RoctxRange front_range("chisel_hip front half: pyramid, cull, resolve, order");
@@ -520,10 +523,15 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // the moment it frees up; four-wave ones wait for four free slots on ONE CU -- 45 us instead of 13 on the 4-agent stream)
         const int rwaves = REFINE_BLOCK / 64;
         const int rgrid = (int)std::max<long long>(64, std::min<long long>(4096 * 4 / rwaves, (pairs + rwaves - 1) / rwaves));
+        front_recorded = m->tune.ext_events && !m->profiling;
+        if (front_recorded)  // the set's front_done event is the refinement kernel's own completion: no record packet behind it
+            hipExtLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(REFINE_BLOCK), 0, front, nullptr, bs.front_done, 0, IP, pyr, m->pyr_stride, (const WorkItem *)bs.items,
+                                  (const FrameBox *)bs.boxes, (const int *)(bs.cand_count + COUNT_ITEMS), m->items_capacity, bs.cells, m->refine_off ? 1 : 0);
+        else
         hipLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(REFINE_BLOCK), 0, front, IP, pyr, m->pyr_stride, bs.items, bs.boxes, bs.cand_count + COUNT_ITEMS,
                            m->items_capacity, bs.cells, m->refine_off ? 1 : 0);
     }
-    HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
+    if (!front_recorded) HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     }
     g_host_timer.lap(4);
     RoctxRange back_range("chisel_hip back half: integrate");
@@ -595,9 +603,17 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
+        const bool back_recorded = m->tune.ext_events && !m->profiling;  // back_done = the integration kernel's own completion
 #define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
-    hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
-                       bs.cells, bs.sync, wc, queues, m->items_capacity, split)
+    do {                                                                                                                             \
+        if (back_recorded)                                                                                                           \
+            hipExtLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, nullptr, bs.back_done, 0, IP, m->view, \
+                                  (const MapView *)m->view_dev, (const WorkItem *)bs.items, (const CellRec *)bs.cells, bs.sync, (const int *)wc, queues,       \
+                                  m->items_capacity, split);                                                                         \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
+                               bs.cells, bs.sync, wc, queues, m->items_capacity, split);                                             \
+    } while (0)
         if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
             if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);
             else CHISEL_LAUNCH_INTEGRATE(true, true, 4);
@@ -612,7 +628,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     }
     HIP_TRY(hipGetLastError());
     m->mesh_totals_clean = true;  // (integrate_kernel's first thread zeroes the next recompute's totals)
-    HIP_TRY(hipEventRecord(bs.back_done, m->stream));
+    if (!(m->tune.ext_events && !m->profiling)) HIP_TRY(hipEventRecord(bs.back_done, m->stream));
     m->batch_seq++;
     g_host_timer.lap(5);
     if (g_host_timer.on) g_host_timer.calls++;
@@ -1081,6 +1097,10 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     if (const char *e = getenv("CHISEL_HIP_DIRECT_MAX")) m->tune.direct_items_max = atoi(e);
     m->tune.no_zero_copy = getenv("CHISEL_HIP_NO_ZERO_COPY") != nullptr;
     m->tune.always_wait_packet = getenv("CHISEL_HIP_ALWAYS_WAIT_PACKET") != nullptr;
+    // (measured at the end of round 4, tools/ab_ext_events.sh: one rank of eight 404 -> 419 k and 259 -> 265 k frames/s, two runtime calls and
+    // two barrier packets fewer per launch set; nothing on a single map: on by default for the shards of a map only)
+    m->tune.ext_events = cfg->n_shards > 1;
+    if (const char *e = getenv("CHISEL_HIP_EXT_EVENTS")) m->tune.ext_events = atoi(e) != 0;
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
         const int one = 1;
