@@ -2013,6 +2013,15 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
         // box code of direction d = G - J (what J reads of G): per axis d > 0 -> {0, 1} (1), d < 0 -> {N - 1} (2), 0 -> all (0)
         auto axis_within = [](int a, int b) { return b == 0 || a == b || (b == 3 && a != 0); };
         auto box_within = [&](int a, int b) { return axis_within(a & 3, b & 3) && axis_within((a >> 2) & 3, (b >> 2) & 3) && axis_within((a >> 4) & 3, (b >> 4) & 3); };
+        // the owner of every cell that is a job or next to one, once (the sweep below asks for a job neighbour's owner 13 times per cell)
+        thread_local std::vector<unsigned char> own;
+        own.resize(cells);
+        for (int ix = 0; ix < dim[0]; ix++)
+            for (int iy = 0; iy < dim[1]; iy++) {
+                const size_t base = (size_t)ix * sx + (size_t)iy * sy;
+                for (int iz = 0; iz < dim[2]; iz++)
+                    if (flag[base + (size_t)iz]) own[base + (size_t)iz] = (unsigned char)owner_at(ix, iy, iz);
+            }
         unsigned asked[64];  // per requesting rank: the directions (bit (dx + 1) * 9 + (dy + 1) * 3 + dz + 1) through which G is asked for
         for (int ix = 0; ix < dim[0]; ix++)
             for (int iy = 0; iy < dim[1]; iy++) {
@@ -2020,7 +2029,7 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                 for (int iz = 0; iz < dim[2]; iz++) {
                     if (!row[iz]) continue;
                     const int gx = lo[0] + ix, gy = lo[1] + iy, gz = lo[2] + iz;
-                    const int o = owner_at(ix, iy, iz);
+                    const int o = own[(size_t)ix * sx + (size_t)iy * sy + (size_t)iz];
                     if (row[iz] & 1) {
                         std::vector<int> &jv = job_of[(size_t)o];
                         jv.push_back(gx); jv.push_back(gy); jv.push_back(gz);
@@ -2033,8 +2042,9 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                             for (int dz = -1; dz <= 1; dz++) {
                                 if (!dx && !dy && !dz) continue;
                                 const int jx = ix - dx, jy = iy - dy, jz = iz - dz;  // J = G - d
-                                if (!(flag[(size_t)jx * sx + (size_t)jy * sy + (size_t)jz] & 1)) continue;
-                                const int r = owner_at(jx, jy, jz);
+                                const size_t jc = (size_t)jx * sx + (size_t)jy * sy + (size_t)jz;
+                                if (!(flag[jc] & 1)) continue;
+                                const int r = own[jc];
                                 if (r == o) continue;
                                 if (!((who >> r) & 1ull)) {
                                     who |= 1ull << r;
@@ -2047,6 +2057,12 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                         who &= who - 1ull;
                         // the boxes of (r, G): as chisel_hip_mesh_shell_plan builds them, in its order of arrival -- the jobs ascending, i.e. the
                         // directions d = G - J descending -- : a box another one contains is dropped, then the two ends of one axis become one box
+                        // (the boxes are a function of the direction mask alone, and a recompute sees a few hundred distinct masks for tens of
+                        // thousands of (r, G) pairs: built once per mask and thread)
+                        struct Boxes { int n; int v[26]; };
+                        thread_local std::unordered_map<unsigned, Boxes> memo;
+                        auto hit = memo.find(asked[r]);
+                        if (hit == memo.end()) {
                         int v[26], nv = 0;
                         for (int dx = 1; dx >= -1; dx--)
                             for (int dy = 1; dy >= -1; dy--)
@@ -2080,9 +2096,15 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                                     }
                         }
                         std::sort(v, v + nv);
+                        Boxes bx;
+                        bx.n = nv;
+                        for (int k = 0; k < nv; k++) bx.v[k] = v[k];
+                        hit = memo.emplace(asked[r], bx).first;
+                        }
+                        const Boxes &B = hit->second;
                         std::vector<int> &iv = item_of[(size_t)r * W + o];
-                        for (int k = 0; k < nv; k++) {
-                            iv.push_back(gx); iv.push_back(gy); iv.push_back(gz); iv.push_back(v[k]);
+                        for (int k = 0; k < B.n; k++) {
+                            iv.push_back(gx); iv.push_back(gy); iv.push_back(gz); iv.push_back(B.v[k]);
                         }
                     }
                 }
