@@ -2023,6 +2023,10 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                     if (flag[base + (size_t)iz]) own[base + (size_t)iz] = (unsigned char)owner_at(ix, iy, iz);
             }
         unsigned asked[64];  // per requesting rank: the directions (bit (dx + 1) * 9 + (dy + 1) * 3 + dz + 1) through which G is asked for
+        long nb_off[27];     // cell offset of direction bit (dx + 1) * 9 + (dy + 1) * 3 + dz + 1
+        for (int dx = -1; dx <= 1; dx++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dz = -1; dz <= 1; dz++) nb_off[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = (long)dx * (long)sx + (long)dy * (long)sy + (long)dz;
         for (int ix = 0; ix < dim[0]; ix++)
             for (int iy = 0; iy < dim[1]; iy++) {
                 const unsigned char *row = &flag[(size_t)ix * sx + (size_t)iy * sy];
@@ -2036,22 +2040,25 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                     }
                     // (cells on the rim of the grid are never next to a job: the box was widened by two beyond the jobs' own rim)
                     if (ix == 0 || iy == 0 || iz == 0 || ix == dim[0] - 1 || iy == dim[1] - 1 || iz == dim[2] - 1) continue;
+                    // which of the 26 neighbours J = G - d are jobs: one bit per direction, gathered without a branch (the flags are as good
+                    // as random to a branch predictor: the tested form of this loop spent most of its time mispredicting), then only the
+                    // set bits are visited
+                    const size_t gc = (size_t)ix * sx + (size_t)iy * sy + (size_t)iz;
+                    unsigned jm = 0u;
+                    for (int bit = 0; bit < 27; bit++) jm |= (unsigned)(flag[(size_t)((long)gc - nb_off[bit])] & 1) << bit;
+                    jm &= ~(1u << 13);
                     unsigned long long who = 0ull;
-                    for (int dx = -1; dx <= 1; dx++)
-                        for (int dy = -1; dy <= 1; dy++)
-                            for (int dz = -1; dz <= 1; dz++) {
-                                if (!dx && !dy && !dz) continue;
-                                const int jx = ix - dx, jy = iy - dy, jz = iz - dz;  // J = G - d
-                                const size_t jc = (size_t)jx * sx + (size_t)jy * sy + (size_t)jz;
-                                if (!(flag[jc] & 1)) continue;
-                                const int r = own[jc];
-                                if (r == o) continue;
-                                if (!((who >> r) & 1ull)) {
-                                    who |= 1ull << r;
-                                    asked[r] = 0u;
-                                }
-                                asked[r] |= 1u << ((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1));
-                            }
+                    while (jm) {
+                        const int bit = __builtin_ctz(jm);
+                        jm &= jm - 1u;
+                        const int r = own[(size_t)((long)gc - nb_off[bit])];
+                        if (r == o) continue;
+                        if (!((who >> r) & 1ull)) {
+                            who |= 1ull << r;
+                            asked[r] = 0u;
+                        }
+                        asked[r] |= 1u << bit;
+                    }
                     while (who) {
                         const int r = __builtin_ctzll(who);
                         who &= who - 1ull;
@@ -2059,10 +2066,13 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                         // directions d = G - J descending -- : a box another one contains is dropped, then the two ends of one axis become one box
                         // (the boxes are a function of the direction mask alone, and a recompute sees a few hundred distinct masks for tens of
                         // thousands of (r, G) pairs: built once per mask and thread)
-                        struct Boxes { int n; int v[26]; };
-                        thread_local std::unordered_map<unsigned, Boxes> memo;
-                        auto hit = memo.find(asked[r]);
-                        if (hit == memo.end()) {
+                        struct Boxes { unsigned mask; int n; int v[14]; };  // (mask 0 = empty entry: a direction mask is never 0 here)
+                        constexpr unsigned MEMO = 1u << 13;
+                        thread_local std::vector<Boxes> memo(MEMO, Boxes{0u, 0, {0}});
+                        unsigned mh = (asked[r] * 2654435761u) >> 19;
+                        while (memo[mh].mask != 0u && memo[mh].mask != asked[r]) mh = (mh + 1u) & (MEMO - 1u);
+                        Boxes *hit = &memo[mh];
+                        if (hit->mask == 0u) {
                         int v[26], nv = 0;
                         for (int dx = 1; dx >= -1; dx--)
                             for (int dy = 1; dy >= -1; dy--)
@@ -2096,15 +2106,25 @@ int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_
                                     }
                         }
                         std::sort(v, v + nv);
-                        Boxes bx;
-                        bx.n = nv;
-                        for (int k = 0; k < nv; k++) bx.v[k] = v[k];
-                        hit = memo.emplace(asked[r], bx).first;
+                        if (nv > 14) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "mesh plan: more than 14 boxes for one ghost");  // (cannot happen: at most 8 disjoint corner boxes survive the covering rule)
+                        thread_local unsigned memo_used = 0;
+                        if (++memo_used > MEMO / 2) {  // (never seen: a few hundred distinct masks exist) start over rather than fill up
+                            for (Boxes &e2 : memo) e2.mask = 0u;
+                            memo_used = 1;
+                            mh = (asked[r] * 2654435761u) >> 19;
+                            hit = &memo[mh];
                         }
-                        const Boxes &B = hit->second;
+                        hit->mask = asked[r];
+                        hit->n = nv;
+                        for (int k = 0; k < nv; k++) hit->v[k] = v[k];
+                        }
+                        const Boxes &B = *hit;
                         std::vector<int> &iv = item_of[(size_t)r * W + o];
+                        const size_t at = iv.size();
+                        iv.resize(at + 4 * (size_t)B.n);
+                        int *out4 = iv.data() + at;
                         for (int k = 0; k < B.n; k++) {
-                            iv.push_back(gx); iv.push_back(gy); iv.push_back(gz); iv.push_back(B.v[k]);
+                            out4[4 * k] = gx; out4[4 * k + 1] = gy; out4[4 * k + 2] = gz; out4[4 * k + 3] = B.v[k];
                         }
                     }
                 }
