@@ -208,15 +208,9 @@ struct WorkItem {
 constexpr int SLOT_LOOKUP = -2;
 // chunks the previous batch may create (open-addressing set of packed ids, one per batch buffer set)
 constexpr unsigned PENDING_CAPACITY = 1u << 14;
-struct FrameBox {            // one per (work item, frame)
-    short u0, v0, u1, v1;    // conservative pixel bounding box of the chunk (inclusive), depth camera
-    int flags;
-    unsigned magic;          // ceil(2^32 / ((u1 - u0 + 1) / 2)): division by the tile width in record pairs (staging loop)
-    // conservative camera-z bounds from the depth range under the box: a voxel can be in band only if
-    // z_near < z < z_far and can take the carve test only if z < z_carve (-inf when carving is off)
-    float z_near, z_far, z_carve;
-    int pad;
-};
+struct FrameBox {            // one per (candidate, frame): the cull kernel's verdict (WI_* flags; 0 = the frame cannot touch the chunk).
+    int flags;               // (Until round 3 also the chunk's pixel box and camera-z bounds, which the integration kernel staged and
+};                           // pre-tested with; since round 4 its units read CellRec -- cell masks -- and the box went.)
 // What a unit (wave) of the integration kernel needs to know about one (work item, frame) pair, in work-list order (written by
 // refine_kernel, kernels_cull.h): which of the chunk's 4 x 4 x 4 CELLS (N/4 voxels on a side; bit (cz * 4 + cy) * 4 + cx) hold a voxel that
 // the frame may integrate or carve-test -- the cull kernel's conservative test repeated at cell scale, where the depth range under

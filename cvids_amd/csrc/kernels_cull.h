@@ -381,23 +381,8 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
     const bool inband = (dmin - band < zmax) && (dmax + band > zlo);
     // d - z > t + carvingDist for some pair  =>  dmax - zlo > tmin + carvingDist
     const bool carve = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
-    // the same bounds per voxel for the integration kernel's prefilter, widened by the z slack of this test
-    fb.z_near = dmin - band - zslack;
-    fb.z_far = dmax + band + zslack;
-    fb.z_carve = ip.carving ? (dmax - (tmin + ip.carving_dist - 1e-6f) + zslack) : -INFINITY;
-    fb.pad = 0;
-    // the integration kernel stages the box with 16-byte LDS-DMA transfers (two records): even start, even width
-    if (tile && !(C.W & 1)) {
-        u0 &= ~1;
-        u1 |= 1;
-    } else {
-        tile = false;
-    }
-    fb.u0 = (short)u0; fb.v0 = (short)v0; fb.u1 = (short)u1; fb.v1 = (short)v1;
-    {
-        const unsigned long long half_w = (unsigned long long)((u1 - u0 + 1) >> 1);
-        fb.magic = half_w ? (unsigned)((0x100000000ull + half_w - 1ull) / half_w) : 0u;  // ceil(2^32 / (width / 2))
-    }
+    // (`tile`: all corners in front and an even image width -- kept as a flag of the verdict, WI_TILE)
+    if (C.W & 1) tile = false;
     // all corners at least a quarter voxel in front of the camera: every voxel centre's camera z lies between the corner
     // extrema (widened by the slack above), so the short reciprocal of the projection is exact for this chunk.  The
     // kernel's own z carries the rounding of three products of magnitude <= mag: keep well clear of it.
@@ -728,14 +713,7 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
     for (int j = 0; j < FPW; j++) {
         const int kf = k + j * WAVES;
         if (pos >= 0 && kf < P.n_frames) {
-            FrameBox fb = fbs[j];
-            if (fls[j] == 0) {  // frames that cannot touch the chunk: a well-defined empty box
-                fb.u0 = fb.v0 = fb.u1 = fb.v1 = 0;
-                fb.magic = 0;
-                fb.z_near = fb.z_far = fb.z_carve = 0.0f;
-                fb.pad = 0;
-            }
-            boxes[(size_t)pos * P.n_frames + kf] = fb;
+            boxes[(size_t)pos * P.n_frames + kf] = fbs[j];
             // INLINE with `cells`: the candidate list is the work-list and the launch is not worth refining (one frame, a caller that
             // waits): every cell of a frame that can touch the chunk counts as needed, and no refine_kernel is launched
             if (INLINE && cells) {
