@@ -17,5 +17,6 @@ step "4. the in-library group on devices 0,1 against one map, bit for bit (first
      env CHISEL_HIP_TEST_DEVICES=0,1 python3 -m pytest tests/test_gpu_group.py -q -m gpu
 step "5. the headline line at N = 2 (small: 40 frames)" python3 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline
 step "6. the scaling curve the driver records" bash -c "for n in 1 2 4 8; do [ \$n -le $N ] && python3 bench.py --gpus \$n --no-cpu-baseline | tail -1; done"
+step "6b. the same curve without the sharded recomputes (what the shard tables of DESIGN.md section 6 predict)" bash -c "for n in 1 2 4 8; do [ \$n -le $N ] && python3 bench.py --gpus \$n --mesh-every 0 --batch 16 --steps 320 --warmup 64 --no-cpu-baseline | tail -1; done"
 step "7. the same map in ONE process (chisel_ros' shape): group of $N" python3 bench.py --group "$N" --agents 4 --batch 16 --steps 320 --warmup 64 --no-cpu-baseline
 echo; echo "first_contact: all steps passed on $N GPUs"
