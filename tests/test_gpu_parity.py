@@ -421,6 +421,39 @@ def test_back_to_back_batches_pipeline(oracle_mod, batch, force_lookup, monkeypa
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+def test_launch_statistics_account_for_every_launch_set(oracle_mod, monkeypatch):
+    """chisel_hip_get_launch_stats: every launch set is counted once under a granularity and once under a cull shape; a caller that
+    waits after every call gets the single-stream form every time; the forced granularities show up where they were forced; a reset
+    starts the count again."""
+    cam = small_camera(96, 72)
+    color = synth.render_color(96, 72, 3)
+    frames = make_frames("sphere_room", 24, 96, 72)
+
+    def run(wait):
+        _, gm, integ = _mk(oracle_mod, 16, 0.04, True, max_chunks=4096)
+        for lo in range(0, 24, 4):
+            part = frames[lo:lo + 4]
+            gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+            if wait:
+                gm.synchronize()
+        gm.synchronize()
+        return gm, gm.launch_stats()
+
+    gm, st = run(wait=True)
+    assert st["launch_sets"] == 6 and st["single_stream_sets"] == 6
+    assert st["integrate_2_per_lane"] + st["integrate_4_per_lane"] + st["integrate_4_with_2_tail"] == 6
+    assert st["cull_4_waves"] + st["cull_wave_per_frame"] == 6
+    assert gm.launch_stats(reset=True)["launch_sets"] == 6 and gm.launch_stats()["launch_sets"] == 0
+    _, st = run(wait=False)
+    assert st["launch_sets"] == 6 and 1 <= st["single_stream_sets"] <= 6  # (the first set finds the map idle; the rest depends on timing)
+    monkeypatch.setenv("CHISEL_HIP_VPL", "2")
+    _, st = run(wait=True)
+    assert st["integrate_2_per_lane"] == 6
+    monkeypatch.setenv("CHISEL_HIP_VPL", "4")
+    _, st = run(wait=True)
+    assert st["integrate_2_per_lane"] == 0
+
+
 @pytest.mark.parametrize("chunk", [8, 16, 32])
 @pytest.mark.parametrize("mode", ["vpl2", "vpl4", "persistent", "growing", "cull4", "cull16"])
 def test_integration_schedules(oracle_mod, chunk, mode, monkeypatch):
