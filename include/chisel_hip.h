@@ -324,7 +324,8 @@ int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, 
  *                                flag 1: an entry of meshesToUpdate kept on the host; nothing is waited for (record_event orders the
  *                                collective that gathers the ranks' arrays)
  *   chisel_hip_mesh_shell_plan   host arithmetic, identical on every rank: from the gathered entries the ids `rank` meshes (jobs) and
- *                                the ghosts it needs as items (owner, x, y, z, box), one per ghost, ascending by owner then id --
+ *                                the ghosts it needs as items (owner, x, y, z, box) -- one or more boxes per ghost, ascending by owner, id, box;
+ *                                chisel_hip_import_ghost_shells creates a ghost once, from its first item --,
  *                                every rank can evaluate it for every other rank, so the request lists need no exchange
  *   chisel_hip_export_shells     the boxes of the listed chunks of this shard, packed (device pointers with on_device: no wait);
  *                                found[j] = 0 and default voxels for a chunk that is not resident
