@@ -644,6 +644,28 @@ def test_batch_mixed_image_sizes(oracle_mod):
     compare_fields(om.fields(), gm.fields(), om.V, False)
 
 
+def test_image_size_changes_between_pipelined_batches(oracle_mod):
+    """Twelve batches issued back to back whose image size changes three times (growing, then shrinking): the pixel-record and pyramid
+    buffers of ALL buffer sets are reallocated while earlier batches are still in flight (the library waits for them first), the host
+    staging rings grow, and the rings of buffer sets / pending sets go round more than once; host frames with colour."""
+    from cvids_amd.chisel import PinholeCamera
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, max_chunks=8192)
+    sizes = [(64, 48)] * 3 + [(96, 72)] * 3 + [(128, 96)] * 3 + [(80, 60)] * 3
+    k = 0
+    for W, H in sizes:
+        intr = synth.intrinsics(W, H)
+        cam = PinholeCamera(*intr, W, H)
+        color = synth.render_color(W, H, 3)
+        part = make_frames("sphere_room", 3, W, H, start=k, nan_fraction=0.01)
+        k += 3
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])  # asynchronous: nothing waited for
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+    assert gm.counters()["frames"] == 36
+
+
 @pytest.mark.parametrize("n_shards", [2, 4, 8])
 def test_spatial_shards_reproduce_the_unsharded_map(oracle_mod, n_shards):
     """every voxel has one owner -> the union of the shards' chunks is bit-identical to one map (and to the
