@@ -173,3 +173,36 @@ print("staged ok")
     env = dict(os.environ, CHISEL_HIP_GROUP_FORCE_STAGE="1", CHISEL_HIP_FORCE_PIPELINE="1")
     out = subprocess.run([os.sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "staged ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_group_workers_sleep_and_wake_between_calls(oracle_mod):
+    """The group's issuing threads spin for 0.5 ms after a job and then sleep on a condition variable: calls that come in a burst (the
+    workers are spinning), after 2 ms (they have just gone to sleep) and after 20 ms (long asleep), interleaved with routed queries and
+    recomputes, give the single map's voxels and meshes -- no job lost, none run twice."""
+    import time
+    from cvids_amd import chisel as ch
+    N, res, W, H = 8, 0.05, 64, 48
+    om, single, integ = _mk(oracle_mod, N, res, True, max_chunks=4096)
+    grp = ch.Chisel((N,) * 3, res, True, max_chunks=4096, devices=_devices(4))
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(W, H, 3)
+    frames = make_frames("sphere_room", 24, W, H, nan_fraction=0.01)
+    pauses = [0.0, 0.0, 0.002, 0.0, 0.02, 0.002, 0.0, 0.02, 0.0, 0.002, 0.02, 0.0]
+    for i, pause in enumerate(pauses):
+        part = frames[2 * i:2 * i + 2]
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        for m in (single, grp):
+            m.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        if i % 4 == 3:
+            om.update_meshes(force=True)
+            single.UpdateMeshes(force=True)
+            grp.UpdateMeshes(force=True)
+        assert grp.NumChunks() == single.NumChunks()
+        time.sleep(pause)
+    compare_fields(om.fields(), grp.fields(), om.V, True, what="group with sleeping workers")
+    _compare_meshes(om, grp, True)
+    cg, cs = grp.counters(), single.counters()
+    for k in ("sdf", "col", "col_sat", "probe", "carved", "new_chunks", "updated_chunks", "frames"):
+        assert cg[k] == cs[k], (k, cg[k], cs[k])
