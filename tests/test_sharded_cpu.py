@@ -207,7 +207,7 @@ class MeshRecordingMap(RecordingMap):
         self.ghosts = {}
 
 
-def _mesh_worker(rank, world, port, out):
+def _mesh_worker(rank, world, port, out, dirty_cap=None):
     import torch
     import torch.distributed as dist
     from cvids_amd.sharded import FrameExchange, ShardedChisel
@@ -218,14 +218,19 @@ def _mesh_worker(rank, world, port, out):
         x = FrameExchange(W, H, K, torch.device("cpu"), dist, channels=0)
         local = MeshRecordingMap(rank, world)
         sm = ShardedChisel(local, x, integrator=None)
+        if dirty_cap is not None:
+            sm._dirty_cap = dirty_cap  # far too small: the gathered tensor overflows and every rank takes the same second turn
         nbytes = sm.UpdateMeshes(force=True)
+        if dirty_cap is not None:
+            assert sm._dirty_cap > dirty_cap
         jobs, ghosts = local.meshed
         out.put((rank, jobs, ghosts, local.dropped, len(local.ghosts), nbytes))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_update_meshes_protocol_world2(hip_lib):
+@pytest.mark.parametrize("dirty_cap", [None, 4])
+def test_sharded_update_meshes_protocol_world2(hip_lib, dirty_cap):
     """The shell protocol between two processes (gloo): every rank meshes the owned part of the union of the 27-neighbourhoods, every
     neighbour another rank holds arrives as a ghost with exactly the voxel box its position asks for -- coordinates {0, 1} where the
     ghost lies on the + side of a job, {N - 1} on the - side, all along an axis they share -- carrying the owner's values, and far
@@ -236,7 +241,7 @@ def test_sharded_update_meshes_protocol_world2(hip_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, q, dirty_cap)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=170) for _ in range(world)), key=lambda r: r[0])  # before the joins: a child blocks in put() until its data is read
