@@ -419,7 +419,7 @@ def test_cull_space_enumerates_exactly_the_owned_ids(hip_lib):
 def test_all_ranks_planner_equals_the_per_rank_planner(hip_lib):
     """chisel_hip_mesh_shell_plan_all (one dense-grid sweep for all ranks) gives, rank by rank, exactly what chisel_hip_mesh_shell_plan
     (std::set / std::map, one rank per call) gives: jobs, items, box codes and their order -- scattered and contiguous dirty sets, entries
-    of both flags, 1 to 16 shards, two super-block sizes."""
+    of both flags, 1 to 16 shards, three super-block sizes."""
     from cvids_amd.chisel import mesh_shell_plan, mesh_shell_plan_all
     rng = np.random.default_rng(11)
     shell = rng.normal(size=(300, 3))
@@ -429,7 +429,7 @@ def test_all_ranks_planner_equals_the_per_rank_planner(hip_lib):
         ent = np.concatenate([ids, np.zeros((len(ids), 1), np.int32)], 1)
         ent[::5, 3] = 1
         for world in (1, 2, 3, 8, 16):
-            for sb in (2, 3):
+            for sb in (1, 2, 3):
                 jobs, items = mesh_shell_plan_all(ent, world, sb)
                 for r in range(world):
                     rj, ri = mesh_shell_plan(ent, world, r, sb)
