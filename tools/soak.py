@@ -1,5 +1,5 @@
 """Soak: a long stream with recomputes, garbage collection, mesh downloads and resets; free device memory and pool state must settle.
-python3 tools/soak.py [frames]"""
+python3 tools/soak.py [frames] [group shards]"""
 import os
 import sys
 import time
@@ -9,12 +9,13 @@ import torch
 from cvids_amd import chisel as ch, synth
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+n_group = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # > 0: an in-library group of that many shards on device 0
 W, H, N, res = 320, 240, 16, 0.02
 intr = synth.intrinsics(W, H)
 cam = ch.PinholeCamera(*intr, W, H, 0.05, 5.0)
 integ = ch.ProjectionIntegrator(ch.InverseTruncator(2.0), ch.ConstantWeighter(1.0), 0.05, True)
 color = synth.render_color(W, H, 3)
-m = ch.Chisel((N,) * 3, res, True, max_chunks=1 << 14)
+m = ch.Chisel((N,) * 3, res, True, max_chunks=1 << 14, **({"devices": [0] * n_group} if n_group else {}))
 frames = list(synth.stream("sphere_room", 300, W, H, agents=2))
 dev = torch.device("cuda:0")
 free0 = None
