@@ -1,3 +1,5 @@
+#!/bin/bash
+# config 5's workload (1280x720 @ 0.5 cm) at 8 and 16 frames per launch, one shard and one rank of eight
 cd $GRAFT_REPO_ROOT
 for b in 8 16; do for n in 1 8; do
   python3 bench.py --sim-shards $n --sim-rank 0 --width 1280 --height 720 --res 0.005 --trunc-scale 0.5 --max-chunks 262144 --mesh-every 0 --batch $b --steps 64 --warmup 16 --no-cpu-baseline --no-pcie-leg --no-e2e-leg --repeats 3 2>/dev/null | tail -1 | python3 -c "

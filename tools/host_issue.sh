@@ -1,3 +1,5 @@
+#!/bin/bash
+# host time to issue a launch set against its wall time (CHISEL_HIP_HOST_TIMING): is a stream bound by its issuing thread?
 cd $GRAFT_REPO_ROOT
 for a in "--sim-shards 8 --sim-rank 0 --mesh-every 0 --batch 16 --steps 320 --warmup 64" "--sim-shards 8 --sim-rank 0 --agents 4 --mesh-every 0 --batch 16 --steps 320 --warmup 64" "--mesh-every 0 --batch 16 --steps 320 --warmup 64" "--steps 200 --warmup 20"; do
   echo "== $a"

@@ -1,3 +1,5 @@
+#!/bin/bash
+# after a kernel change: the two parity files, the two headline windows, the 4-agent stream
 cd $GRAFT_REPO_ROOT
 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -x -q 2>&1 | tail -2
 bash tools/ab_env.sh - 2>&1 | tail -2
