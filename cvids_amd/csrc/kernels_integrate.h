@@ -184,14 +184,16 @@ __device__ __attribute__((noinline)) int find_chunk(const MapView *__restrict__ 
 // The slot of a chunk that had none when the work-list was built, for a wave that integrated one of its voxels: the first
 // such wave allocates (ChunkManager::CreateChunk), the others wait for its verdict.  The wait is on a wave that is running.
 // Lane 0 only; returns the slot or -1; *created = 1 for the allocating wave.
-__device__ __attribute__((noinline)) int claim_slot(const MapView *__restrict__ Mc, ItemSync *sy, int x, int y, int z, unsigned *created) {
+// -> the slot (or -1), with CLAIM_CREATED set when THIS call allocated it (a flag in the result, not an out-parameter: the address of a
+// local handed to a function that is not inlined puts that local into scratch memory -- a store, a wait and a load per call)
+constexpr int CLAIM_CREATED = 1 << 30;
+__device__ __attribute__((noinline)) int claim_slot(const MapView *__restrict__ Mc, ItemSync *sy, int x, int y, int z) {
     int s = atomicCAS(&sy->slot, 0, 1);
     if (s == 0) {
         const int slot = create_chunk(Mc, x, y, z);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hash entry written before the slot can be seen
         atomicExch(&sy->slot, slot >= 0 ? slot + 2 : -1);
-        *created = slot >= 0 ? 1u : 0u;
-        return slot;
+        return slot >= 0 ? (slot | CLAIM_CREATED) : slot;
     }
     for (int spin = 0; s == 1 && spin < (1 << 22); spin++) {
         __builtin_amdgcn_s_sleep(8);
@@ -707,10 +709,11 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                 // no voxel integrates (Chisel.h:133-143, 202-207): the outcome is "exists from the first such frame on".
                 if (bm) {
                     int s = 0;
-                    unsigned created = 0u;
-                    if (lane == 0) s = claim_slot(Mc, sy, cxi, cyi, czi, &created);
-                    slot = __builtin_amdgcn_readfirstlane(s);
-                    n_new += (unsigned)__builtin_amdgcn_readfirstlane((int)created);
+                    if (lane == 0) s = claim_slot(Mc, sy, cxi, cyi, czi);
+                    s = __builtin_amdgcn_readfirstlane(s);
+                    const bool created = s >= 0 && (s & CLAIM_CREATED) != 0;
+                    slot = s >= 0 ? (s & ~CLAIM_CREATED) : s;
+                    n_new += created ? 1u : 0u;
                 }
                 // deposit what the chunk-level `probe` figure needs, then count this wave in; the last one settles it.
                 // Returning atomics: the arrival is issued only after the deposits have been performed.
