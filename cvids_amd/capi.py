@@ -57,12 +57,12 @@ class Statistics(C.Structure):
 
 
 EXPORTS = [
-    "chisel_hip_abi_version", "chisel_hip_last_error", "chisel_hip_device_count", "chisel_hip_create",
+    "chisel_hip_abi_version", "chisel_hip_last_error", "chisel_hip_device_count", "chisel_hip_host_alloc", "chisel_hip_host_free", "chisel_hip_create",
     "chisel_hip_destroy", "chisel_hip_reset", "chisel_hip_set_integrator", "chisel_hip_set_stream",
     "chisel_hip_synchronize", "chisel_hip_wait_event", "chisel_hip_record_event", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
     "chisel_hip_integrate_batch", "chisel_hip_integrate_pointcloud", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
     "chisel_hip_list_chunks", "chisel_hip_has_chunk", "chisel_hip_download_chunk", "chisel_hip_upload_chunk",
-    "chisel_hip_meshes_to_update", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
+    "chisel_hip_meshes_to_update", "chisel_hip_meshes_to_update_since", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
     "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
@@ -134,6 +134,11 @@ def load_library():
     L.chisel_hip_download_chunk.argtypes = [vp, i32p, f32p, f32p, u8p]
     L.chisel_hip_upload_chunk.argtypes = [vp, i32p, f32p, f32p, u8p]
     L.chisel_hip_meshes_to_update.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.chisel_hip_meshes_to_update_since.argtypes = [vp, C.POINTER(C.c_uint64), i32p, C.c_int64, i64p, i32p]
+    L.chisel_hip_host_alloc.argtypes = [C.c_size_t]
+    L.chisel_hip_host_alloc.restype = C.c_void_p
+    L.chisel_hip_host_free.argtypes = [vp]
+    L.chisel_hip_host_free.restype = None
     L.chisel_hip_num_meshes.argtypes = [vp, i64p]
     L.chisel_hip_list_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
     L.chisel_hip_mesh_size.argtypes = [vp, i32p, i64p, i64p]

@@ -396,6 +396,17 @@ class Chisel:
             check(self.L.chisel_hip_meshes_to_update(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n.value, C.byref(n)))
         return ids
 
+    def GetMeshesToUpdateSince(self, cursor, capacity=8192):
+        """chisel_hip_meshes_to_update_since: (ids that joined the set since `cursor` [n, 3], cleared) -- `cursor` is a (C.c_uint64 * 2)
+        the caller keeps (zero before the first call); what the C++ facade's GetMeshesToUpdate is built on"""
+        n, cleared = C.c_int64(0), C.c_int(0)
+        while True:
+            ids = np.zeros((capacity, 3), np.int32)
+            check(self.L.chisel_hip_meshes_to_update_since(self.h, cursor, ids.ctypes.data_as(C.POINTER(C.c_int)), capacity, C.byref(n), C.byref(cleared)))
+            if n.value <= capacity:
+                return ids[:n.value], bool(cleared.value)
+            capacity = n.value + 64
+
     # ---- ChunkManager.h -----------------------------------------------------------------------------
     def synchronize(self):
         check(self.L.chisel_hip_synchronize(self.h))

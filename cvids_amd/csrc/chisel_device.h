@@ -86,6 +86,22 @@ struct MapView {
     int mesh_jobs_capacity;
 };
 
+// The bounding box of the ids of every chunk created since the last reset (never shrinks: removals leave it as it is), kept in
+// mesh_ctl[MC_BBOX .. +5] = min x, y, z, max x, y, z by everything that creates a chunk.  A superset of what is resident, and an exact
+// "absent" verdict for ids outside it: ChunkManager::InterpolateColor's eight look-ups (ChunkManager.cpp:506-520) take integer VOXEL
+// indices for metric positions and land hundreds of chunks away, where one compare answers what was a hash probe per vertex.
+constexpr int MC_BBOX = 136;
+__device__ inline void bbox_include(int *mesh_ctl, int x, int y, int z) {
+    if (!mesh_ctl) return;
+    int *b = mesh_ctl + MC_BBOX;
+    if (x < b[0]) atomicMin(&b[0], x);
+    if (y < b[1]) atomicMin(&b[1], y);
+    if (z < b[2]) atomicMin(&b[2], z);
+    if (x > b[3]) atomicMax(&b[3], x);
+    if (y > b[4]) atomicMax(&b[4], y);
+    if (z > b[5]) atomicMax(&b[5], z);
+}
+
 // Per slot, behind the dirty list: which signs the OBSERVED voxels (weight > 0.5: what a marching cube asks of a corner,
 // ChunkManager.cpp:271 / :352) a chunk has ever held can have -- SUM_POS: some voxel with sdf >= 0, SUM_NEG: some with sdf < 0.  Sticky (a
 // carved voxel leaves its bit behind: the summary may say more than is there, never less); every writer of voxels ORs into it, freeing a

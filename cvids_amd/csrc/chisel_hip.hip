@@ -253,6 +253,9 @@ struct chisel_hip_map {
     hipStream_t copy_stream = nullptr;                                 // small device->host copies that must not wait for queued batches
     std::vector<int> ghost_ids;                                        // chunks of other shards imported for meshing (x, y, z triples)
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
+    uint64_t pending_version = 1;                                      // bumped when entries join pending_mesh_ids (chisel_hip_meshes_to_update_since)
+    uint32_t dirty_epoch = 0;                                          // bumped when the device's dirty list is emptied (recompute, reset)
+    int *dirty_tail_host = nullptr, *dirty_tail_dev = nullptr;         // pinned: where list_dirty_tail_kernel leaves the new entries of the dirty list
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
     uint64_t ghost_bytes = 0;                                          // group handle: ghost voxel bytes its recomputes have moved between shards
     int *shell_items_dev = nullptr;                                    // staging of the items / offsets of chisel_hip_export_shells / import_ghost_shells
@@ -265,6 +268,7 @@ struct chisel_hip_map {
     bool mesh_mark_needed = false;                                     // slots were dirtied by something other than integrate_kernel (point clouds), or the kept job list was given up: the next recompute runs mesh_mark_kernel
     bool mesh_totals_clean = true;                                     // an integration launch has been queued since the last recompute (it zeroes the recompute totals)
     int64_t removed_since_recompute = 0;                               // chunks removed since: each may have left a dead entry in the kept job list
+    int mesh_jobs_hint = 0;                                            // jobs of the previous recompute (sizes the count kernel's grid)
     int mesh_stages = 3;                                               // MeshParams::stages of the next recompute (chisel_hip_generate_mesh lowers it)
     bool mesh_detached = false;                                        // the next recompute leaves meshesToUpdate alone (chisel_hip_generate_mesh)
     uint64_t topology_epoch = 0;                                       // bumped by everything but integration that adds or removes chunks (chisel_hip_topology_epoch)
@@ -984,6 +988,38 @@ int chisel_hip_device_count(void) {
     return ok;
 }
 
+// DepthImage / ColorImage buffers (DepthImage.h:42-52, ColorImage.h:44-58): page-locked, so that an integrate call reads them without the
+// staged copy of pageable memory (integrate_group: hipPointerGetAttributes finds the mapping).  Which pointers came from hipHostMalloc
+// is remembered here (free() of the others).
+namespace {
+std::mutex g_host_alloc_mutex;
+std::unordered_set<void *> g_host_pinned;
+}  // namespace
+void *chisel_hip_host_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
+            std::lock_guard<std::mutex> lock(g_host_alloc_mutex);
+            g_host_pinned.insert(p);
+            return p;
+        }
+    }
+    (void)hipGetLastError();
+    return malloc(bytes);
+}
+void chisel_hip_host_free(void *p) {
+    if (!p) return;
+    bool pinned = false;
+    {
+        std::lock_guard<std::mutex> lock(g_host_alloc_mutex);
+        pinned = g_host_pinned.erase(p) != 0;
+    }
+    if (pinned) (void)hipHostFree(p);
+    else free(p);
+}
+
 int chisel_hip_chunk_owner(const int id[3], int n_shards, int shard_block) {
     return chunk_owner(id[0], id[1], id[2], n_shards < 1 ? 1 : n_shards, shard_block < 1 ? 2 : shard_block);
 }
@@ -1131,8 +1167,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.mesh_flag, C * sizeof(unsigned)));
     HIP_TRY_C(hipMemsetAsync(v.mesh_flag, 0, C * sizeof(unsigned), m->stream));
     HIP_TRY_C(hipMalloc(&v.mesh_jobs, (size_t)v.mesh_jobs_capacity * 3 * sizeof(int)));
-    HIP_TRY_C(hipMalloc(&v.mesh_ctl, 8 * sizeof(int)));
-    HIP_TRY_C(hipMemsetAsync(v.mesh_ctl, 0, 8 * sizeof(int), m->stream));
+    HIP_TRY_C(hipMalloc(&v.mesh_ctl, MC_INTS * sizeof(int)));
+    HIP_TRY_C(hipMemsetAsync(v.mesh_ctl, 0, MC_INTS * sizeof(int), m->stream));
     m->mesh_buf.flags = v.mesh_flag;
     m->mesh_buf.totals = v.mesh_ctl;
     HIP_TRY_C(hipMalloc(&m->view_dev, sizeof(MapView)));
@@ -1177,6 +1213,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->mesh_totals_host) (void)hipHostFree(m->mesh_totals_host);
     if (m->error_flag_host) (void)hipHostFree(m->error_flag_host);
     if (m->mesh_info_host) (void)hipHostFree(m->mesh_info_host);
+    if (m->dirty_tail_host) (void)hipHostFree(m->dirty_tail_host);
     clear_meshes(m);
     release_arena_pool(m);
     free_mesh_buffers(m->mesh_buf);
@@ -1201,6 +1238,7 @@ int chisel_hip_reset(chisel_hip_map *m) {
     HIP_TRY(note_map_mutation(m));
     clear_meshes(m);
     m->pending_mesh_ids.clear();
+    m->dirty_epoch++;
     return CHISEL_HIP_OK;
 }
 
@@ -1320,6 +1358,7 @@ int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
                 gone.push_back(dirty[i]); gone.push_back(dirty[i + 1]); gone.push_back(dirty[i + 2]);
             }
         expand27(gone, m->pending_mesh_ids);
+        if (!gone.empty()) m->pending_version++;
     }
     rc = ensure_scratch(m, (size_t)n * 3 + 16);
     if (rc) return rc;
@@ -2282,6 +2321,57 @@ int chisel_hip_meshes_to_update(chisel_hip_map *m, int *ids, int64_t max_ids, in
     return CHISEL_HIP_OK;
 }
 
+// Chisel::GetMeshesToUpdate for a caller that keeps its copy of the set (see chisel_hip.h).  The device lists the slots whose dirty flag
+// went 0 -> 1 in order of appearance (mark_slot_dirty): what joined since the caller's cursor is the tail of that list, expanded to the
+// 27-neighbourhoods (Chisel.h:175-189) here, plus the entries kept on the host for chunks that were removed while dirty.
+constexpr int DIRTY_TAIL_CAP = 16384;
+int chisel_hip_meshes_to_update_since(chisel_hip_map *m, uint64_t cursor[2], int *ids, int64_t max_ids, int64_t *count, int *cleared) {
+    if (!m || !cursor || !count || !cleared || max_ids < 0 || (max_ids > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (m->is_group) {  // (a group's shards keep a list each: the whole set every time)
+        *cleared = 1;
+        return chisel_hip_meshes_to_update(m, ids, max_ids, count);
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    const uint64_t epoch_tag = (uint64_t)m->dirty_epoch + 1u;  // (a zero cursor matches no epoch)
+    const bool restart = (cursor[0] >> 32) != epoch_tag;
+    unsigned from = restart ? 0u : (unsigned)(cursor[0] & 0xffffffffull);
+    if (!m->dirty_tail_host) {
+        HIP_TRY(hipHostMalloc((void **)&m->dirty_tail_host, (2 + 3 * (size_t)DIRTY_TAIL_CAP) * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer((void **)&m->dirty_tail_dev, m->dirty_tail_host, 0));
+    }
+    hipLaunchKernelGGL(list_dirty_tail_kernel, dim3(1), dim3(256), 0, m->stream, m->view, from, m->dirty_tail_dev, DIRTY_TAIL_CAP);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(wait_stream_spinning(m->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const unsigned listed = (unsigned)m->dirty_tail_host[0];
+    const int n_new = m->dirty_tail_host[1];
+    std::unordered_set<uint64_t, IdHash> joined;
+    bool whole = restart;
+    if (listed > (unsigned)m->view.max_chunks || n_new > DIRTY_TAIL_CAP) {
+        // the list overflowed (or the tail does not fit the staging buffer): the whole set from the flags
+        std::vector<int> dirty;
+        int rc = fetch_listed(m, true, dirty, nullptr);
+        if (rc) return rc;
+        expand27(dirty, joined);
+        whole = true;
+    } else {
+        std::vector<int> fresh(m->dirty_tail_host + 2, m->dirty_tail_host + 2 + 3 * (size_t)n_new);
+        expand27(fresh, joined);
+    }
+    if (whole || cursor[1] != m->pending_version) joined.insert(m->pending_mesh_ids.begin(), m->pending_mesh_ids.end());
+    *count = (int64_t)joined.size();
+    *cleared = whole ? 1 : 0;
+    if (*count > max_ids) return CHISEL_HIP_OK;  // nothing consumed: the caller comes back with room for *count ids
+    int64_t k = 0;
+    for (uint64_t key : joined) {
+        unpack_id(key, ids[3 * k], ids[3 * k + 1], ids[3 * k + 2]);
+        k++;
+    }
+    cursor[0] = (epoch_tag << 32) | (uint64_t)std::min(listed, (unsigned)m->view.max_chunks);
+    cursor[1] = m->pending_version;
+    return CHISEL_HIP_OK;
+}
+
 int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters) {
     if (m && m->is_group) return out ? group::get_counters(m, out, reset_counters) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
@@ -2318,7 +2408,11 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
         if (hipMemcpyFromSymbol(mp, HIP_SYMBOL(g_mesh_phase), sizeof(mp)) == hipSuccess && mp[7]) {
             fprintf(stderr, "mesh_count_kernel, us per job (thread 0): lookups %.2f | corners staged %.2f | cubes classified %.2f | scan %.2f | reserve %.2f | records %.2f | jobs %llu\n",
                     mp[0] * 0.01 / mp[7], mp[1] * 0.01 / mp[7], mp[2] * 0.01 / mp[7], mp[3] * 0.01 / mp[7], mp[4] * 0.01 / mp[7], mp[5] * 0.01 / mp[7], mp[7]);
-            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, life[4];
+            if (hipMemcpyFromSymbol(life, HIP_SYMBOL(g_mesh_life), sizeof(life)) == hipSuccess)
+                fprintf(stderr, "   working waves %llu, life avg %.2f us; (ONE launch) first entry -> last exit %.2f us\n", life[1], life[1] ? life[0] * 0.01 / life[1] : 0.0,
+                        (life[3] - ((1ull << 62) - life[2])) * 0.01);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_life), z, sizeof(life));
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_phase), z, sizeof(z));
         }
     }

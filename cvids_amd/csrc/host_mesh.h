@@ -25,35 +25,46 @@ void launch_mesh_triangles(chisel_hip_map *m, const MeshParams &P, float *arena,
     const int *totals = B.totals;
     int *host_info = m->mesh_info_dev;
     volatile int *host_flags = (volatile int *)m->mesh_totals_dev;
-    const int max_jobs = std::min(MESH_INFO_PREFETCH, B.capacity), seq = m->mesh_seq;
-    const dim3 grid(4096), block(MESH_TRI_BLOCK);  // persistent: the number of triangles is read on the device
+    const int max_jobs = std::min(MESH_INFO_PREFETCH, B.capacity), seq = m->mesh_seq, part = B.tri_capacity / MESH_PARTS;
+    const dim3 grid(4096), block(MESH_TRI_BLOCK);  // persistent: the number of triangles (per partition of the list) is read on the device
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
-        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
-        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 8: hipLaunchKernelGGL(mesh_triangle_kernel<8>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, B.cnt, part, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 16: hipLaunchKernelGGL(mesh_triangle_kernel<16>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, B.cnt, part, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
+        case 32: hipLaunchKernelGGL(mesh_triangle_kernel<32>, grid, block, 0, m->stream, m->view, P, B.jobs, bases, B.tris, B.corners, totals, B.cnt, part, arena, arena_floats, host_info, host_flags, max_jobs, seq, publish); break;
     }
 }
 
+int mesh_subjobs(const chisel_hip_map *m) { return m->N == 8 ? MeshGeom<8>::S : (m->N == 16 ? MeshGeom<16>::S : MeshGeom<32>::S); }
+int mesh_row_ints(const chisel_hip_map *m) { return m->N == 8 ? MeshGeom<8>::ROW : (m->N == 16 ? MeshGeom<16>::ROW : MeshGeom<32>::ROW); }
 int ensure_mesh_jobs(chisel_hip_map *m, int n) {
     MeshBuffers &B = m->mesh_buf;
     if (n <= B.capacity) return CHISEL_HIP_OK;
     HIP_TRY(hipStreamSynchronize(m->stream));
-    if (B.jobs) HIP_TRY(hipFree(B.jobs));
-    if (B.ids) HIP_TRY(hipFree(B.ids));
-    if (B.info) HIP_TRY(hipFree(B.info));
-    B.jobs = nullptr; B.ids = nullptr; B.info = nullptr;
+    for (void *p : {(void *)B.jobs, (void *)B.ids, (void *)B.info, (void *)B.cnt, (void *)B.job_acc})
+        if (p) HIP_TRY(hipFree(p));
+    B.jobs = nullptr; B.ids = nullptr; B.info = nullptr; B.cnt = nullptr; B.job_acc = nullptr;
     int cap = std::max(4096, B.capacity);
     while (cap < n) cap *= 2;
     HIP_TRY(hipMalloc(&B.jobs, (size_t)cap * sizeof(MeshJob)));
     HIP_TRY(hipMalloc(&B.ids, (size_t)cap * 3 * sizeof(int)));
     HIP_TRY(hipMalloc(&B.info, (size_t)cap * sizeof(JobInfo)));
+    HIP_TRY(hipMalloc(&B.cnt, (size_t)cap * mesh_row_ints(m) * sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&B.job_acc, (size_t)cap * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(B.job_acc, 0, (size_t)cap * sizeof(unsigned long long), m->stream));  // (the count kernel's last arrivers keep them at zero)
     B.capacity = cap;
     return CHISEL_HIP_OK;
 }
 
 // device counters of a recompute (mesh_buf.totals)
-enum { MT_TRIS = 0, MT_GRIDS = 1, MT_OVERFLOW = 2, MT_JOBS = 3 };
+enum { MT_TRIS = MC_TRIS, MT_GRIDS = MC_GRIDS, MT_OVERFLOW = MC_OVERFLOW, MT_JOBS = MC_JOBS };
 int *mesh_totals(chisel_hip_map *m) { return m->mesh_buf.totals; }
+// a recompute's totals and the cursors of its record lists start from zero: normally the first wave of the integration launch in
+// front of it has seen to that (kernels_integrate.h); this is for the recomputes that have no such launch in front of them
+hipError_t zero_mesh_counters(chisel_hip_map *m) {
+    hipError_t e = hipMemsetAsync(mesh_totals(m), 0, 3 * sizeof(int), m->stream);  // keeps MT_JOBS and the kept list's length
+    if (e == hipSuccess) e = hipMemsetAsync(mesh_totals(m) + MC_CURSORS, 0, 2 * MESH_PARTS * sizeof(int), m->stream);
+    return e;
+}
 
 // The job list of a recompute: the resident chunks of the 27-neighbourhoods of the slots dirtied since the last one, de-duplicated
 // through one flag per slot.  The integration kernels keep it as they go (mesh_expand_dirty: the wave that first dirties a slot
@@ -66,7 +77,7 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
     const int C = m->view.max_chunks;
     int rc = ensure_mesh_jobs(m, C);  // (MeshJob / JobInfo records: worst case every resident chunk)
     if (rc) return rc;
-    int *n_jobs = mesh_totals(m) + 4;
+    int *n_jobs = mesh_totals(m) + MC_KEPT;
     B.n_jobs = n_jobs;
     if (m->mesh_mark_needed) {
         hipLaunchKernelGGL(mesh_mark_kernel, dim3(1024), dim3(256), 0, m->stream, m->view, B.flags, m->view.mesh_jobs, n_jobs);
@@ -74,7 +85,7 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
     }
     if (!m->mesh_totals_clean) {
         // (two recomputes without an integration launch in between: its first thread is what zeroes the totals otherwise)
-        HIP_TRY(hipMemsetAsync(mesh_totals(m), 0, 3 * sizeof(int), m->stream));
+        HIP_TRY(zero_mesh_counters(m));
     }
     m->mesh_totals_clean = false;
     if (!extra.empty()) {
@@ -150,7 +161,8 @@ void release_arena_pool(chisel_hip_map *m) {
 // the job list kept by the integration kernels is dropped; the next recompute rebuilds it from the dirty flags (mesh_mark_kernel)
 void give_up_job_list(chisel_hip_map *m) {
     if (m->mesh_buf.flags) (void)hipMemsetAsync(m->mesh_buf.flags, 0, (size_t)m->view.max_chunks * sizeof(unsigned), m->stream);
-    if (m->mesh_buf.totals) (void)hipMemsetAsync(m->mesh_buf.totals + 4, 0, sizeof(int), m->stream);
+    if (m->mesh_buf.totals) (void)hipMemsetAsync(m->mesh_buf.totals + MC_KEPT, 0, sizeof(int), m->stream);
+    if (m->mesh_buf.job_acc) (void)hipMemsetAsync(m->mesh_buf.job_acc, 0, (size_t)m->mesh_buf.capacity * sizeof(unsigned long long), m->stream);  // (a count kernel that never ran to its end)
     m->mesh_mark_needed = true;
     m->removed_since_recompute = 0;
 }
@@ -160,12 +172,17 @@ void launch_mesh_count(chisel_hip_map *m) {
     int *d_totals = mesh_totals(m);
     int *n_jobs = B.n_jobs ? B.n_jobs : d_totals + MT_JOBS;  // the kept job list's counter, or the count a caller put into the totals
     const int *ids = B.n_jobs ? m->view.mesh_jobs : B.ids;   // ... and its entries, or the caller's ids
+    const int ids_capacity = B.n_jobs ? m->view.mesh_jobs_capacity : B.capacity;
     ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
-    const dim3 grid(2048);
+    // one single-wave workgroup per (job, sub-job): the number of jobs is only known on the device, so the grid is sized from what the
+    // previous recompute had (+ 1/4) -- a shortfall is made up by the workgroups taking a second unit, surplus ones leave at once
+    const long long units = (long long)(m->mesh_jobs_hint > 0 ? m->mesh_jobs_hint + m->mesh_jobs_hint / 4 + 8 : 1024) * mesh_subjobs(m);
+    const dim3 grid((unsigned)(std::min<long long>(std::max<long long>(units, 2048), 1 << 17) + 7) / 8 * 8);
+    const int part = B.tri_capacity / MESH_PARTS, keep = m->mesh_detached ? 1 : 0;
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel<8>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel<16>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel<32>, grid, dim3(MESH_BLOCK), 0, m->stream, m->view, ids, B.jobs, n_jobs, B.info, d_totals, B.tris, B.corners, B.tri_capacity, B.flags, m->mesh_detached ? 1 : 0); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel_8, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel_16, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel_32, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep); break;
     }
 }
 
@@ -180,7 +197,7 @@ int recompute_meshes(chisel_hip_map *m) {
     MeshBuffers &B = m->mesh_buf;
     const MeshParams P = mesh_params(m);
     if (!B.tris) {
-        B.tri_capacity = std::max(B.tri_capacity, m->mesh_tiny ? 256 : 1 << 20);
+        B.tri_capacity = std::max(B.tri_capacity, m->mesh_tiny ? 4 * MESH_PARTS : 1 << 20);
         HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
         HIP_TRY(hipMalloc(&B.corners, (size_t)B.tri_capacity * sizeof(CubeCorners)));
     }
@@ -199,6 +216,7 @@ int recompute_meshes(chisel_hip_map *m) {
         if (rc_a) return rc_a;
     }
     launch_mesh_count(m);
+    if (!m->mesh_detached) m->dirty_epoch++;  // (the count kernel empties the list of dirty slots: meshesToUpdate.clear(), Chisel.cpp:57)
     // the totals go straight into pinned memory from the first thread of the triangle kernel; they are looked at when the caller
     // next touches the map (check_mesh_totals polls the sequence number): until then the host is free to queue the next batch's
     // front half, and by then the triangle kernel is usually still running, so the next integration queues up behind it without a gap
@@ -260,27 +278,31 @@ int check_mesh_totals(chisel_hip_map *m) {
     const int pool_error = reinterpret_cast<volatile int *>(m->error_flag_host)[0];
     bool redo = false;
     if (totals[MT_OVERFLOW]) {
-        // the triangle list was too small: grow it to what this batch needs and list again (dirty flags are not read by the count)
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        HIP_TRY(hipFree(B.tris));
-        HIP_TRY(hipFree(B.corners));
-        B.tris = nullptr;
-        B.corners = nullptr;
-        while (B.tri_capacity < totals[MT_TRIS]) B.tri_capacity *= 2;
-        HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
-        HIP_TRY(hipMalloc(&B.corners, (size_t)B.tri_capacity * sizeof(CubeCorners)));
-        HIP_TRY(hipMemsetAsync(d_totals, 0, 3 * sizeof(int), m->stream));  // keeps MT_JOBS
-        // (the kept job list's counter has been emptied by the first emission; its entries are untouched -- nothing has integrated since --
-        // and their number is in the totals)
-        if (B.n_jobs) {
-            const int n_again = totals[MT_JOBS];
-            HIP_TRY(hipMemcpyAsync(B.n_jobs, &n_again, sizeof(int), hipMemcpyHostToDevice, m->stream));
+        // a partition of the record lists was too small: grow them to (at least) twice what this batch needs and list again, until every
+        // partition holds its share (dirty flags are not read by the count kernel; the map has not changed: nothing else was queued)
+        const int n_again = totals[MT_JOBS];
+        for (int attempt = 0;; attempt++) {
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            HIP_TRY(hipFree(B.tris));
+            HIP_TRY(hipFree(B.corners));
+            B.tris = nullptr;
+            B.corners = nullptr;
+            const long long want = std::max<long long>(2ll * B.tri_capacity, 2ll * std::max(totals[MT_TRIS], totals[MT_GRIDS]) + 16 * MESH_PARTS);
+            if (want > (1ll << 30)) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "mesh record lists beyond 2^30 entries");
+            B.tri_capacity = (int)((want + MESH_PARTS - 1) / MESH_PARTS * MESH_PARTS);
+            HIP_TRY(hipMalloc(&B.tris, (size_t)B.tri_capacity * sizeof(TriRec)));
+            HIP_TRY(hipMalloc(&B.corners, (size_t)B.tri_capacity * sizeof(CubeCorners)));
+            HIP_TRY(zero_mesh_counters(m));
+            // (the kept job list's counter has been emptied by the first emission; its entries are untouched -- nothing has integrated since --
+            // and their number is in the totals)
+            if (B.n_jobs) HIP_TRY(hipMemcpyAsync(B.n_jobs, &n_again, sizeof(int), hipMemcpyHostToDevice, m->stream));
+            launch_mesh_count(m);
+            if (B.n_jobs) HIP_TRY(hipMemsetAsync(B.n_jobs, 0, sizeof(int), m->stream));
+            HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (!totals[MT_OVERFLOW]) break;
+            if (attempt == 12) return fail(CHISEL_HIP_ERR_HIP, "mesh record lists overflow after growing them");
         }
-        launch_mesh_count(m);
-        if (B.n_jobs) HIP_TRY(hipMemsetAsync(B.n_jobs, 0, sizeof(int), m->stream));
-        HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        if (totals[MT_OVERFLOW]) return fail(CHISEL_HIP_ERR_HIP, "mesh triangle list overflow after growing it");
         redo = true;
         HIP_TRY(hipMemcpy(m->mesh_info_host, B.info, (size_t)std::min(MESH_INFO_PREFETCH, B.capacity) * sizeof(JobInfo), hipMemcpyDeviceToHost));
     }
@@ -311,6 +333,7 @@ int check_mesh_totals(chisel_hip_map *m) {
             arena_id = -1;
         }
     }
+    m->mesh_jobs_hint = n;
     if (n != 0) {
         // The per-chunk results (sizes, positions in the arena, ids) stay on the device for now: the bookkeeping follows when
         // a mesh is next asked for or recomputed (resolve_pending_meshes).
@@ -505,6 +528,8 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
     const int totals[4] = {0, 0, 0, n};
     B.n_jobs = nullptr;  // the count is the one written here
     HIP_TRY(hipMemcpyAsync(mesh_totals(m), totals, sizeof(totals), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemsetAsync(mesh_totals(m) + MC_CURSORS, 0, 2 * MESH_PARTS * sizeof(int), m->stream));
+    m->mesh_jobs_hint = n;
     if (n) HIP_TRY(hipMemcpyAsync(B.ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
     if (!m->mesh_detached) hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
     HIP_TRY(hipGetLastError());

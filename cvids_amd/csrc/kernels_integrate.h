@@ -159,6 +159,7 @@ __device__ __attribute__((noinline)) int create_chunk(const MapView *__restrict_
             if (atomicCAS((unsigned long long *)&M.hash_keys[idx], (unsigned long long)cur, (unsigned long long)key) == cur) {
                 M.hash_vals[idx] = s;
                 M.slot_key[s] = key;
+                bbox_include(M.mesh_ctl, x, y, z);
                 return s;
             }
         }
@@ -247,6 +248,8 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             M.mesh_ctl[2] = 0;
         }
     }
+    // ... and so do the cursors of its record lists (kernels_mesh.h: MC_CURSORS = 8 ints in, MESH_PARTS = 64 64-bit words)
+    if (blockIdx.x == 0 && threadIdx.x < 64 && M.mesh_ctl) reinterpret_cast<unsigned long long *>(M.mesh_ctl + 8)[threadIdx.x] = 0ull;
     const int grid_waves = nb * G::WPB;
 #if defined(CHISEL_PHASES) && defined(PHASE0_AT)
 #define PHASE0(at, dep) do { if (PHASE0_AT == at) { asm volatile("" ::"s"(dep)); PHASE(0); } } while (0)  // diagnostic: where inside the "item" stage the first stamp sits

@@ -55,7 +55,13 @@ __global__ __launch_bounds__(256) void reset_map_kernel(MapView M, int V, int al
     }
     if (gid == 0) {
         M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // the list of dirty slots is empty
-        if (M.mesh_ctl) M.mesh_ctl[4] = 0;           // and so is the job list
+        if (M.mesh_ctl) {
+            M.mesh_ctl[4] = 0;                       // and so is the job list
+            for (int a = 0; a < 3; a++) {            // the box of created ids: empty
+                M.mesh_ctl[MC_BBOX + a] = INT32_MAX;
+                M.mesh_ctl[MC_BBOX + 3 + a] = INT32_MIN;
+            }
+        }
         *M.free_top = M.max_chunks;
         M.error_flag[0] = 0;
         M.error_flag[1] = 0;
@@ -192,6 +198,7 @@ __global__ void ensure_chunk_kernel(MapView M, int x, int y, int z, int *out_slo
             }
             if (placed) {
                 M.slot_key[slot] = key;
+                bbox_include(M.mesh_ctl, x, y, z);
             } else {
                 raise_error(M.error_flag, 2);
                 slot = -1;
@@ -341,6 +348,7 @@ __global__ __launch_bounds__(256) void import_chunks_kernel(MapView M, const int
                 }
                 if (placed) {
                     M.slot_key[slot] = key;
+                    bbox_include(M.mesh_ctl, x, y, z);
                 } else {
                     raise_error(M.error_flag, 2);
                     slot = -1;
@@ -420,6 +428,7 @@ __global__ void ensure_ghosts_kernel(MapView M, const int *items, const int *fir
             atomicCAS((unsigned long long *)&M.hash_keys[idx], (unsigned long long)cur, (unsigned long long)key) == cur) {
             M.hash_vals[idx] = slot;
             M.slot_key[slot] = key;
+            bbox_include(M.mesh_ctl, x, y, z);
             return;
         }
     }
@@ -465,6 +474,34 @@ __global__ void list_dirty_ids_kernel(MapView M, int *out, int capacity) {
             unpack_id(key, x, y, z);
             out[1 + 4 * pos] = x; out[2 + 4 * pos] = y; out[3 + 4 * pos] = z; out[4 + 4 * pos] = 0;
         }
+    }
+}
+// The tail of the dirty list: the chunks dirtied since entry `from` (chisel_hip_meshes_to_update_since), into page-locked host memory:
+// out[0] = entries of the list now, out[1] = ids written, then (x, y, z) each.  One workgroup.
+__global__ __launch_bounds__(256) void list_dirty_tail_kernel(MapView M, unsigned from, int *out, int capacity) {
+    __shared__ int s_n;
+    const unsigned listed = M.slot_dirty[2 * (size_t)M.max_chunks];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (listed <= (unsigned)M.max_chunks) {
+        for (unsigned t = from + threadIdx.x; t < listed; t += blockDim.x) {
+            const int slot = (int)M.slot_dirty[(size_t)M.max_chunks + t];
+            if (!M.slot_dirty[slot]) continue;  // (removed since it was listed: the host keeps those ids itself)
+            const uint64_t key = M.slot_key[slot];
+            if (key == KEY_EMPTY) continue;
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < capacity) {
+                int x, y, z;
+                unpack_id(key, x, y, z);
+                out[2 + 3 * pos] = x; out[3 + 3 * pos] = y; out[4 + 3 * pos] = z;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[1] = s_n;
+        __threadfence_system();
+        out[0] = (int)listed;
     }
 }
 __global__ void clear_dirty_kernel(MapView M) {

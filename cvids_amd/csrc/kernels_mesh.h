@@ -60,32 +60,6 @@ __device__ inline f3v normalized3(f3v a) {  // Eigen 3.3 MatrixBase::normalized(
     return a;
 }
 
-// the reference's traversal position `r` (0 .. N^3-1) -> cube index (ChunkManager.cpp:395-441)
-template <int N>
-__device__ inline void cube_of_rank(int r, int &x, int &y, int &z) {
-    constexpr int A = (N - 1) * (N - 1) * (N - 1), B = (N - 1) * N, C = (N - 1) * (N - 1);
-    if (r < A) {  // interior: z, y, x < N-1, x fastest
-        x = r % (N - 1);
-        y = (r / (N - 1)) % (N - 1);
-        z = r / ((N - 1) * (N - 1));
-    } else if (r < A + B) {  // max x plane: z < N-1 outer, y < N inner
-        r -= A;
-        x = N - 1;
-        y = r % N;
-        z = r / N;
-    } else if (r < A + B + C) {  // max y plane: z < N-1 outer, x < N-1 inner
-        r -= A + B;
-        y = N - 1;
-        x = r % (N - 1);
-        z = r / (N - 1);
-    } else {  // max z plane: y < N outer, x < N inner
-        r -= A + B + C;
-        z = N - 1;
-        x = r % N;
-        y = r / N;
-    }
-}
-
 // ChunkManager::GetIDAt (ChunkManager.h:136-145)
 __device__ inline void id_at(const MeshParams &P, f3v pos, int &ix, int &iy, int &iz) {
     ix = (int)floorf(pos.x * P.rf_chunk);
@@ -196,6 +170,16 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
     const int x0 = (int)floorf(cp.x / r), y0 = (int)floorf(cp.y / r), z0 = (int)floorf(cp.z / r);
     const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
     uchar4 v000, v001, v011, v111, v110, v100, v010, v101;
+    // The first of the eight look-ups asks for the chunk at "position" (x0, y0, z0) -- voxel INDICES taken for metres (:506-508), i.e.
+    // a chunk 1 / res chunks further out than the vertex -- and the reference stops at the first failure.  An id outside the box of
+    // every id ever created is absent: no hash probe for (nearly) every vertex of a map that does not span hundreds of metres.
+    bool first_may_exist = true;
+    if (M.mesh_ctl) {
+        int ix, iy, iz;
+        id_at(P, mk3((float)x0, (float)y0, (float)z0), ix, iy, iz);
+        const int *bb = M.mesh_ctl + MC_BBOX;
+        first_may_exist = ix >= bb[0] && iy >= bb[1] && iz >= bb[2] && ix <= bb[3] && iy <= bb[4] && iz <= bb[5];
+    }
 #if MESH_COLOR_BATCH
     // The reference makes the eight GetColorVoxel calls one after the other and stops at the first failure (:506-520); a lookup has no
     // side effect and the blend below needs all eight, so the eight voxels are located first (eight neighbour-table reads in flight),
@@ -224,7 +208,7 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
         v000 = c[0]; v001 = c[1]; v011 = c[2]; v111 = c[3]; v110 = c[4]; v100 = c[5]; v010 = c[6]; v101 = c[7];
     }
 #else
-    bool all = get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z0), hx, hy, hz, nb, v000);
+    bool all = first_may_exist && get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z0), hx, hy, hz, nb, v000);
     all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z1), hx, hy, hz, nb, v001);
     all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y1, (float)z1), hx, hy, hz, nb, v011);
     all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y1, (float)z1), hx, hy, hz, nb, v111);
@@ -304,11 +288,6 @@ __global__ void mesh_append_kernel(MapView M, unsigned *mesh_flag, const int *sl
     if (i < n && slots[i] >= 0) mesh_append_job(M, mesh_flag, slots[i], ids, n_jobs);
 }
 
-#ifndef MESH_THREADS
-#define MESH_THREADS 512
-#endif
-constexpr int MESH_BLOCK_THREADS = MESH_THREADS;  // per-chunk kernel: 8 cubes (16^3) per thread (256: 33 us, 512: 24 us, 1024: 35 us per recompute)
-
 // corner voxel (cx, cy, cz), each in 0..N, of the cube grid of a job: (sdf, weight); absent chunk -> weight 0
 template <int N>
 __device__ inline float2 corner_voxel(const MapView &M, const int *nb, int cx, int cy, int cz) {
@@ -318,141 +297,68 @@ __device__ inline float2 corner_voxel(const MapView &M, const int *nb, int cx, i
     const size_t off = (size_t)slot * (N * N * N) + (lz * N + ly) * N + lx;
     return make_float2(M.sdf[off], M.wgt[off]);
 }
-
-// The (N+1)^3 corner voxels a chunk's cubes read -- the chunk plus one layer of its "+" neighbours -- staged once in LDS:
-// every voxel is fetched from HBM once per kernel instead of once per cube corner (8x).  What the cubes need of a corner is its
-// distance and whether it has been observed (weight > 0.5: ChunkManager.cpp:271 / :352), so one float per corner carries both:
-// the distance, or NaN for "not observed" (19.6 KiB per 16^3 chunk instead of 39 KiB of (sdf, weight) pairs: four chunks per CU
-// are in flight instead of two).  [A stored distance that is itself NaN under a weight above 0.5 would read as unobserved here
-// and as a NaN vertex in the reference; integration cannot produce one: invalid depth pixels never update a voxel.]
-// The chunk's own N^3 voxels arrive as 16-byte loads (x rows are contiguous in the pool), the 3 N^2 + 3 N + 1 border corners of
-// the "+" neighbours one by one.  32^3 chunks (140 KiB) stay in L2 and fold on the fly.
-template <int N>
-struct CornerTile {
-    static constexpr bool STAGED = (N <= 16);
-    static constexpr int E = N + 1;
-    static constexpr int SIZE = STAGED ? E * E * E : 1;
-};
+// What the cubes need of a corner is its distance and whether it has been observed (weight > 0.5: ChunkManager.cpp:271 / :352), so
+// one float per corner carries both: the distance, or NaN for "not observed".  [A stored distance that is itself NaN under a weight
+// above 0.5 would read as unobserved here and as a NaN vertex in the reference; integration cannot produce one: invalid depth pixels
+// never update a voxel.]
 __device__ inline float fold_corner(float sdf, float weight) { return weight > 0.5f ? sdf : __builtin_nanf(""); }
 
+// ---- mesh_count_kernel: one WAVE per sub-job ------------------------------------------------------------------------------------
+// Rounds 1-4 gave a chunk to one 512-thread workgroup (look-ups -> stage (N+1)^3 corners -> classify -> block scan -> reserve -> list,
+// five barriers): a recompute lasted as long as its longest job plus a second generation of workgroups (850 jobs on 512 resident), 0.10-0.14
+// of the HBM roofline.  Round 5: a job is cut into SUB-JOBS along the reference's traversal order (ChunkManager.cpp:395-441: interior cubes
+// x fastest, then y, then z; then the max-x, max-y and max-z planes), each a box of cubes whose own order "x fastest, then y, then z" IS
+// the traversal order of its section:
+//     sub-jobs 0 .. NI-1   interior cubes of ZL consecutive z-layers (16^3: 8 slabs of 2 layers = 450 cubes; their corners are voxels of
+//                          the chunk itself and contiguous in the pool: staged as 16-byte loads, no neighbour needed)
+//     NI, NI+1, NI+2       the max-x, max-y, max-z plane (240 / 225 / 256 cubes; corners in up to 4 / 2 / 8 chunks)
+// One single-wave workgroup per sub-job (several thousand per recompute, all resident at once: a slot is refilled the moment its wave
+// retires), no barrier between waves, 8 (16 for 32^3 chunks) cubes per lane.  What ties the sub-jobs of a job together travels through
+// memory-side atomics only:
+//   * cnt[job][s] = the sub-job's triangles | occupied cubes << 16 (a plain store: its readers are the NEXT kernel's threads, which add
+//     up the entries in front of their own sub-job -- the position of a triangle in its chunk's arrays is its job's base + that prefix +
+//     its position in the sub-job, so the arrays come out element for element in the reference's order whatever order the waves ran in);
+//   * job_acc[job] += arrivals << 48 | cubes << 24 | triangles (one returning atomic): the wave that arrives last knows the job's totals,
+//     reserves the job's range of the recompute's triangle / grid numbering (one atomic on the totals), writes the job's JobInfo and
+//     leaves the accumulator at zero for the next recompute;
+//   * the records the triangle kernel works from -- per occupied cube its eight corner distances, per triangle a 16-byte TriRec -- go
+//     into UNORDERED lists: MESH_PARTS partitions with a cursor each (a single cursor would take ~ 88 atomics per us: 6 000 sub-jobs =
+//     70 us), sub-job u appends to partition u mod MESH_PARTS with one returning 64-bit atomic issued beside the arrival (lane 0 / lane 1
+//     of ONE instruction: one round trip).
 template <int N>
-__device__ inline void stage_corners(const MapView &M, const int *nb, float *s_vox) {
-    if (!CornerTile<N>::STAGED) return;
-    constexpr int E = N + 1, V = N * N * N, Q = V / 4, QU = (Q + MESH_BLOCK_THREADS - 1) / MESH_BLOCK_THREADS;
-    constexpr int BORDER = E * E * E - V, BU = (BORDER + MESH_BLOCK_THREADS - 1) / MESH_BLOCK_THREADS;
-    const int self = nb[NB_SELF];
-    const float4 *sp = reinterpret_cast<const float4 *>(M.sdf + (size_t)self * V);
-    const float4 *wp = reinterpret_cast<const float4 *>(M.wgt + (size_t)self * V);
-    float4 vs[QU], vw[QU];
-    float2 vb[BU];
-    // every load of the thread is requested before the first is used: one round trip
-#pragma unroll
-    for (int u = 0; u < QU; u++) {
-        const int q = min((int)threadIdx.x + u * MESH_BLOCK_THREADS, Q - 1);
-        vs[u] = sp[q];
-        vw[u] = wp[q];
-    }
-#pragma unroll
-    for (int u = 0; u < BU; u++) {
-        // border corners in three groups: the plane cz = N (E x E, its edges included), the plane cy = N below it (E x N), the plane
-        // cx = N below both (N x N)
-        const int b = min((int)threadIdx.x + u * MESH_BLOCK_THREADS, BORDER - 1);
-        int cx, cy, cz;
-        if (b < E * E) { cx = b % E; cy = b / E; cz = N; }
-        else if (b < E * E + N * E) { const int t = b - E * E; cx = t % E; cy = N; cz = t / E; }
-        else { const int t = b - E * E - N * E; cx = N; cy = t % N; cz = t / N; }
-        vb[u] = corner_voxel<N>(M, nb, cx, cy, cz);
-    }
-#pragma unroll
-    for (int u = 0; u < QU; u++) {
-        const int q = (int)threadIdx.x + u * MESH_BLOCK_THREADS;
-        if (q < Q) {
-            const int i = 4 * q, x = i % N, y = (i / N) % N, z = i / (N * N);
-            float *d = s_vox + (z * E + y) * E + x;
-            d[0] = fold_corner(vs[u].x, vw[u].x);
-            d[1] = fold_corner(vs[u].y, vw[u].y);
-            d[2] = fold_corner(vs[u].z, vw[u].z);
-            d[3] = fold_corner(vs[u].w, vw[u].w);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < BU; u++) {
-        const int b = (int)threadIdx.x + u * MESH_BLOCK_THREADS;
-        if (b < BORDER) {
-            int cx, cy, cz;
-            if (b < E * E) { cx = b % E; cy = b / E; cz = N; }
-            else if (b < E * E + N * E) { const int t = b - E * E; cx = t % E; cy = N; cz = t / E; }
-            else { const int t = b - E * E - N * E; cx = N; cy = t % N; cz = t / N; }
-            s_vox[(cz * E + cy) * E + cx] = fold_corner(vb[u].x, vb[u].y);
-        }
-    }
-    __syncthreads();
-}
+struct MeshGeom {
+    static constexpr int ZL = N == 16 ? 2 : (N == 8 ? 7 : 1);  // z-layers of interior cubes per sub-job
+    static constexpr int NI = (N - 1 + ZL - 1) / ZL;           // interior sub-jobs
+    static constexpr int S = NI + 3;                           // sub-jobs per job: 4 (8^3), 11 (16^3), 34 (32^3)
+    static constexpr int CPL = N == 32 ? 16 : 8;               // cubes per lane
+    static constexpr int MAXC = 64 * CPL;                      // >= cubes of any sub-job (343 / 450 / 1024)
+    static constexpr int TILE = N == 32 ? 33 * 33 * 2 : N * N * (ZL + 1);  // >= corners of any sub-job's box
+    static constexpr int ROW = (2 + S + 3) / 4 * 4;            // ints of a job's row of `cnt`: its triangle / grid base, then the sub-jobs' figures (16^3: one 64-byte line)
+    static_assert((N - 1) * (N - 1) * ZL <= MAXC && N * N <= MAXC, "cubes per sub-job");
+};
+// cube box (BX x BY x bz cubes from (X0, Y0, z0)) and corner tile (TX x TY x (bz + 1)) of a sub-job type: 0 interior slab, 1 max-x, 2 max-y, 3 max-z
+template <int N, int TYPE>
+struct MeshBox {
+    static constexpr int BX = TYPE == 1 ? 1 : (TYPE == 3 ? N : N - 1);
+    static constexpr int BY = TYPE == 2 ? 1 : (TYPE == 0 ? N - 1 : N);
+    static constexpr int TX = BX + 1, TY = BY + 1;
+    static constexpr int X0 = TYPE == 1 ? N - 1 : 0, Y0 = TYPE == 2 ? N - 1 : 0;
+    static constexpr unsigned PLUS = TYPE == 0 ? 0x01u : (TYPE == 1 ? 0x0Fu : (TYPE == 2 ? 0x05u : 0xFFu));  // "+" chunks (bit dx + 2 dy + 4 dz) that hold its corners
+};
+constexpr int MESH_PARTS = 64;  // partitions of the unordered record lists
+// MapView::mesh_ctl / MeshBuffers::totals (ints): the recompute's totals -- [0] triangles and [1] grids are ONE 64-bit word for the
+// last arrivers' atomic --, [2] record-list overflow, [3] jobs; [4] entries of the job list the integration kernels keep;
+// from [8] on MESH_PARTS 64-bit cursors (triangles | cubes << 32).  [0..2] and the cursors start every recompute at zero.
+enum { MC_TRIS = 0, MC_GRIDS = 1, MC_OVERFLOW = 2, MC_JOBS = 3, MC_KEPT = 4, MC_CURSORS = 8, MC_INTS = MC_BBOX + 8 };  // (MC_BBOX: chisel_device.h)
+static_assert(MC_BBOX == MC_CURSORS + 2 * MESH_PARTS, "the created-id box sits behind the cursors");
+static_assert(MC_CURSORS == 8 && MESH_PARTS == 64 && MC_KEPT == 4, "kernels_integrate.h / kernels_map.h address these words by number");
 
-// cube (x, y, z): corner sdf values and the case index; false when a corner is unobserved (weight <= 0.5)
-template <int N>
-__device__ inline bool cube_config(const MapView &M, const int *nb, const float *s_vox, int x, int y, int z, float (&s)[8],
-                                   int &index) {
-    // cubeIndexOffsets (ChunkManager.cpp:67-69)
-    const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
-    constexpr int E = N + 1;
-    index = 0;
-    bool observed = true;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        float v;
-        if (CornerTile<N>::STAGED) {
-            v = s_vox[((z + oz[i]) * E + (y + oy[i])) * E + (x + ox[i])];
-        } else {
-            const float2 c = corner_voxel<N>(M, nb, x + ox[i], y + oy[i], z + oz[i]);
-            v = fold_corner(c.x, c.y);
-        }
-        observed = observed && (v == v);  // :271 / :352 "weight <= 0.5 -> not observed"
-        s[i] = v;
-        index |= (v < 0.0f) ? (1 << i) : 0;  // MarchingCubes::CalculateVertexConfiguration MarchingCubes.h:108-118
-    }
-    return observed;
-}
-
-// exclusive block scan of (a, b) pairs over BLOCK threads; returns this thread's offsets, totals in (ta, tb)
-template <int BLOCK>
-__device__ inline void block_scan2(int a, int b, int &oa, int &ob, int &ta, int &tb, int (*s_a)[2]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int ia = a, ib = b;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int na = __shfl_up(ia, o), nb = __shfl_up(ib, o);
-        if (lane >= o) {
-            ia += na;
-            ib += nb;
-        }
-    }
-    if (lane == 63) {
-        s_a[wave][0] = ia;
-        s_a[wave][1] = ib;
-    }
-    __syncthreads();
-    int wa = 0, wb = 0;
-    ta = tb = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; w++) {
-        if (w < wave) {
-            wa += s_a[w][0];
-            wb += s_a[w][1];
-        }
-        ta += s_a[w][0];
-        tb += s_a[w][1];
-    }
-    oa = wa + ia - a;
-    ob = wb + ib - b;
-    __syncthreads();
-}
-
-constexpr int MESH_BLOCK = MESH_BLOCK_THREADS;
 #ifndef MESH_COUNT_WAVES
-#define MESH_COUNT_WAVES 5  // waves per SIMD the count kernel is compiled for: up to 96 registers, two 512-thread workgroups per CU.  (6 -- 80 registers,
-                            // three workgroups per CU -- spills 32 bytes per lane and is slower although a third more jobs are resident: 22.5 against
-                            // 21.4 us per recompute on the default window, 33.8 against 29.3 us on the driver's; 4 -- 128 registers -- 21.9 / 30.1)
+#define MESH_COUNT_WAVES 6  // waves per SIMD the count kernel is compiled for (its 6 KB of LDS per wave allow 27 per CU of 160 KB)
+#endif
+#ifndef MESH_COUNT_VGPRS
+#define MESH_COUNT_VGPRS 80  // ... said in registers as well: the compiler prices the LDS against 64 KB per CU (three waves per SIMD) and then
+                             // spends 151 registers
 #endif
 constexpr int MESH_TRI_BLOCK = 256;  // per-triangle kernel
 
@@ -465,20 +371,19 @@ struct JobInfo {
     int grid_base;     // first grid entry
 };
 
-// One triangle of the batch: which job, which cube (rank in the reference's traversal order), which case, which of the
-// cube's triangles; gidx = position of the cube among the job's occupied cubes (its entry in Mesh::grids).
-struct TriRec {
+// One triangle of the batch (an entry of the unordered list): which job and sub-job, which cube, which case, which of the cube's triangles,
+// and where it goes: rel = position among its sub-job's triangles | position of its cube among the sub-job's occupied cubes << 16.
+struct alignas(16) TriRec {
     unsigned job;
-    unsigned code;   // rank << 11 | case index << 3 | triangle number
-    unsigned gidx;   // the cube's entry in the batch's grid numbering (job's grid base + position among the job's occupied cubes)
+    unsigned code;   // cube x | y << 5 | z << 10 | case index << 15 | triangle number << 23 | sub-job << 26
+    unsigned cube;   // the cube's CubeCorners entry
+    unsigned rel;
 };
-// Beside the triangle list, per occupied cube (indexed like the grids): its eight corner distances (all observed: the cube carries
-// triangles).  The count kernel has them in LDS; the triangle kernel would fetch each through two dependent loads (neighbour
-// table, then voxel).
+// Per occupied cube: its eight corner distances (all observed: the cube carries triangles).  The count kernel has them in LDS; the
+// triangle kernel would fetch each through two dependent loads (neighbour table, then voxel).
 struct alignas(16) CubeCorners {
     float s[8];
 };
-constexpr int MESH_LIST_CAP = 1024;  // occupied cubes of a job listed in LDS at a time
 // s[e] for a per-lane e (a register array cannot be indexed per lane: seven selects)
 __device__ inline float pick8(const float (&s)[8], int e) {
     const float a0 = (e & 1) ? s[1] : s[0], a1 = (e & 1) ? s[3] : s[2], a2 = (e & 1) ? s[5] : s[4], a3 = (e & 1) ? s[7] : s[6];
@@ -486,184 +391,298 @@ __device__ inline float pick8(const float (&s)[8], int e) {
     return (e & 4) ? b1 : b0;
 }
 
-// Per chunk (one workgroup): stage the corners, count (case table popcount) and scan the cubes in the reference's
-// traversal order, reserve the chunk's range of the batch's triangle / grid numbering with one atomic each and list its
-// triangles.  info[j] = what the host keeps of job j: sizes and its first triangle / grid in the batch (the chunks' ranges
-// follow one another in completion order; within a chunk the order is the reference's).
-// totals[0..1] = running totals (the atomics), totals[2] = set when the triangle list is too small (the host retries).
 #ifdef CHISEL_PHASES
-__device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per stage of mesh_count_kernel (thread 0 of every workgroup), [7] = jobs
-#define MSTAMP(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_mesh_phase[i], n_ - mt_); mt_ = n_; } } while (0)
+__device__ unsigned long long g_mesh_life[4];   // diagnostic: [0] sum of the working waves' lives, [1] their number, [2] 2^62 - earliest entry, [3] latest exit
+__device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per stage of mesh_count_kernel (lane 0 of every wave), [7] = sub-jobs
+#define MSTAMP(i) do { if (lane == 0 && (blockIdx.x & 31) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_mesh_phase[i], n_ - mt_); mt_ = n_; } } while (0)  // (every 32nd wave: the atomics of all of them on six words would be what is measured)
 #else
 #define MSTAMP(i) do { } while (0)
 #endif
+
+// info[j] = what the host keeps of job j: sizes and its first triangle / grid in the batch (the chunks' ranges follow one another in
+// completion order; within a chunk the order is the reference's).  ctl: see MC_*.  `ids` holds ids_capacity entries.
 template <int N>
-__global__ __launch_bounds__(MESH_BLOCK, (N > 16 ? 4 : MESH_COUNT_WAVES)) void mesh_count_kernel(MapView M, const int *__restrict__ ids, MeshJob *jobs, const int *__restrict__ n_jobs,
-                                                                 JobInfo *info, int *totals, TriRec *tris, CubeCorners *corners, int tri_capacity, unsigned *mesh_flag, int keep_dirty) {
-    __shared__ int s_scan[MESH_BLOCK / 64][2];
+__device__ __forceinline__ void mesh_count_body(const MapView &M, const int *__restrict__ ids, int ids_capacity, MeshJob *jobs, const int *__restrict__ n_jobs,
+                                                JobInfo *info, int *ctl, unsigned *cnt, unsigned long long *job_acc, TriRec *tris, CubeCorners *corners,
+                                                int part_capacity, unsigned *mesh_flag, int keep_dirty) {
+    using G = MeshGeom<N>;
+    __shared__ __attribute__((aligned(16))) float s_tile[G::TILE];
+    __shared__ unsigned s_list[G::MAXC];  // occupied cubes of the sub-job in traversal order: cube | case << 10 | first triangle (relative) << 18
+    __shared__ __attribute__((aligned(16))) unsigned char s_case[G::MAXC];  // case index per cube (0: no triangle)
     __shared__ int s_nb[27];
-    __shared__ unsigned s_sum[8];  // sign summaries of the chunk and its seven "+" neighbours (slot_summary)
-    __shared__ int s_base[2];
-    __shared__ float s_vox[CornerTile<N>::SIZE];
-    __shared__ __attribute__((aligned(16))) unsigned char s_case[N * N * N];  // case index per cube, by traversal rank
-    __shared__ unsigned s_list_a[MESH_LIST_CAP], s_list_t[MESH_LIST_CAP];  // occupied cubes of the job: rank | case << 16, first triangle (relative)
     __shared__ unsigned s_counts[64];  // the 256 vertex counts of the case table, four to a word (a per-lane index into constant memory is a global load)
-    constexpr int V = N * N * N, CPT = (V + MESH_BLOCK - 1) / MESH_BLOCK;
-    // (the first job's id is requested together with the job count: the id buffer holds at least 4096 entries -- more than the
-    // grid has workgroups -- whatever the count; ensure_mesh_jobs)
-    int jx0 = ids[3 * blockIdx.x], jy0 = ids[3 * blockIdx.x + 1], jz0 = ids[3 * blockIdx.x + 2];
-    int n = *n_jobs;  // the job count stays on the device: the grid is persistent
-    if (ids == M.mesh_jobs && n > M.mesh_jobs_capacity) n = M.mesh_jobs_capacity;  // (the kept list never gets there: the host gives it up first)
-    if (blockIdx.x == 0 && threadIdx.x == 0) totals[3] = n;  // where the kernels behind this one (and a second emission) read it
-    if (threadIdx.x < 64) s_counts[threadIdx.x] = reinterpret_cast<const unsigned *>(c_mc_counts)[threadIdx.x];  // (first barrier below)
-    // the list of dirty slots has been consumed by the mark kernel -- also when none of them became a job (every listed chunk
-    // removed since): reset outside the job loop
-    if (blockIdx.x == 0 && threadIdx.x == 29 && !keep_dirty) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;
-    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    int lane = threadIdx.x;
 #ifdef CHISEL_PHASES
-    unsigned long long mt_ = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) atomicAdd(&g_mesh_phase[7], 1ull);
+    const unsigned long long mt0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    __syncthreads();  // the previous job's LDS contents are no longer read
-    // the job record: the chunk id and the pool slots of its 27-neighbourhood (27 hash lookups, one per thread); kept for
-    // the triangle kernel and the host
-    const bool first = j == (int)blockIdx.x;
-    const int jx = first ? jx0 : ids[3 * j], jy = first ? jy0 : ids[3 * j + 1], jz = first ? jz0 : ids[3 * j + 2];
-    if (threadIdx.x < 27) {
-        const int o = threadIdx.x;
-        const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
-        const int slot = hash_find_quiescent(M, jx + dx, jy + dy, jz + dz);
-        s_nb[o] = slot;
-        jobs[j].nb[o] = slot;
-        if (dx >= 0 && dy >= 0 && dz >= 0) s_sum[dx + 2 * dy + 4 * dz] = slot >= 0 ? slot_summary(M)[slot] : 0u;  // the chunks that hold cube corners
-    } else if (threadIdx.x == 27) {
-        jobs[j].x = jx;
-        jobs[j].y = jy;
-        jobs[j].z = jz;
-        jobs[j].pad[0] = jobs[j].pad[1] = 0;
-    }
-    __syncthreads();
-    const bool present = s_nb[NB_SELF] >= 0;  // block-uniform
-    // Can any cube of this chunk carry a triangle?  Corner 0 of every cube is a voxel of the chunk itself and must be observed
-    // (ChunkManager.cpp:271 / :352), and a case other than 0 / 255 needs both signs among the cube's corners, which lie in the chunk
-    // and its seven "+" neighbours.  About half of the jobs of a recompute -- chunks inside the band but away from the surface --
-    // stop here: no corners staged, nothing classified.
-    bool can = present;
-    {
-        const unsigned seen = (s_sum[0] | s_sum[1]) | (s_sum[2] | s_sum[3]) | (s_sum[4] | s_sum[5]) | (s_sum[6] | s_sum[7]);
-        can = can && s_sum[0] != 0u && seen == SUM_ANY;
-    }
-    if (threadIdx.x == 28 && present && !keep_dirty) {
-        // meshesToUpdate.clear() (Chisel.cpp:57) and the job flag of mesh_mark_kernel, which has finished: this job's own
-        if (mesh_flag) mesh_flag[s_nb[NB_SELF]] = 0u;
-        M.slot_dirty[s_nb[NB_SELF]] = 0u;
-    }
-    MSTAMP(0);
-    if (can) stage_corners<N>(M, s_nb, s_vox);
-    MSTAMP(1);
-    int nv = 0, ng = 0;
-    unsigned char cases[CPT];  // case index of the thread's cubes that carry triangles (0: none -- case 0 has no triangles either)
-#pragma unroll
-    for (int k = 0; k < CPT; k++) cases[k] = 0;
-    if (can) {
-        // Classification with neighbouring lanes on neighbouring cubes (rank k * MESH_BLOCK + thread: consecutive corners, no LDS
-        // bank conflicts -- with a thread's own CPT consecutive cubes the lanes sit 8 corners apart, an 8-way conflict on every one
-        // of the 64 corner reads); the case bytes go through LDS to the thread that owns the cube in the traversal order.
-#ifndef MESH_CLASSIFY_UNROLL
-#define MESH_CLASSIFY_UNROLL 2
+    int n = *n_jobs;  // the job count stays on the device: the grid is persistent
+    if (n > ids_capacity) n = ids_capacity;  // (the kept list never gets there: the host gives it up first)
+    if (blockIdx.x == 0 && lane == 0) ctl[MC_JOBS] = n;  // where the kernels behind this one (and a second emission) read it
+    // the list of dirty slots has been consumed -- also when none of them became a job (every listed chunk removed since)
+    if (blockIdx.x == 0 && lane == 1 && !keep_dirty) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;
+    s_counts[lane] = reinterpret_cast<const unsigned *>(c_mc_counts)[lane];
+    auto n_verts = [&](int index) -> int { return (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu); };
+    unsigned long long *cursors = reinterpret_cast<unsigned long long *>(ctl + MC_CURSORS);
+    // workgroups b and b + 8 share an XCD (observed dispatch order; speed only): the sub-jobs of a job run on one XCD, back to back --
+    // the slabs' shared corner layers and the planes' rows meet in one L2
+    const int xcd = (int)blockIdx.x & 7, stride = (int)gridDim.x >> 3;
+    for (int q = (int)blockIdx.x >> 3;; q += stride) {
+        const int jl = q / G::S, s = q - jl * G::S, j = jl * 8 + xcd;
+#ifdef CHISEL_PHASES
+        if (j >= n && lane == 0 && q != ((int)blockIdx.x >> 3)) {  // this wave had work: its life, and the launch's span (meaningful for ONE launch)
+            const unsigned long long e_ = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(&g_mesh_life[0], e_ - mt0_);
+            atomicAdd(&g_mesh_life[1], 1ull);
+            atomicMax(&g_mesh_life[2], (1ull << 62) - mt0_);
+            atomicMax(&g_mesh_life[3], e_);
+        }
 #endif
-#pragma unroll MESH_CLASSIFY_UNROLL  // (two cubes' sixteen corner reads in flight; all of them at once would cost a workgroup per CU in registers)
-        for (int k = 0; k < CPT; k++) {
-            const int r = k * MESH_BLOCK + (int)threadIdx.x;
-            if (r < V) {
-                int x, y, z, index;
-                float sc[8];
-                cube_of_rank<N>(r, x, y, z);
-                unsigned char cs = 0;
-                if (cube_config<N>(M, s_nb, s_vox, x, y, z, sc, index)) {
-                    const int c = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu);
-                    cs = c ? (unsigned char)index : 0;
-                }
-                s_case[r] = cs;
+        if (j >= n) break;
+#ifdef CHISEL_PHASES
+        unsigned long long mt_ = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && (blockIdx.x & 31) == 0) atomicAdd(&g_mesh_phase[7], 1ull);
+#endif
+        __syncthreads();  // the previous sub-job's LDS contents are no longer read
+        // (a workgroup rarely takes a second unit; what the lanes derive from their number -- tile offsets of eight cubes for four box
+        // shapes -- must not be hoisted in front of the loop, where it cost 150 registers and 250 bytes of scratch: opaque per iteration)
+        asm volatile("" : "+v"(lane));
+        const int jx = ids[3 * j], jy = ids[3 * j + 1], jz = ids[3 * j + 2];
+        const int type = s < G::NI ? 0 : s - G::NI + 1;  // wave-uniform
+        const unsigned plus_needed = type == 0 ? MeshBox<N, 0>::PLUS : (type == 1 ? MeshBox<N, 1>::PLUS : (type == 2 ? MeshBox<N, 2>::PLUS : MeshBox<N, 3>::PLUS));
+        // The neighbourhood: sub-job 0 looks all 27 slots up (one lane each) and leaves the job record for the triangle kernel and the
+        // host; the others only the chunks their corners lie in (an interior slab: the chunk itself).
+        const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+        const bool plus = lane < 27 && dx >= 0 && dy >= 0 && dz >= 0;
+        const bool counted = plus && ((plus_needed >> (dx + 2 * dy + 4 * dz)) & 1u);
+        int slot = -1;
+        unsigned sum = 0u;
+        if (lane < 27 && (s == 0 || counted)) slot = hash_find_quiescent(M, jx + dx, jy + dy, jz + dz);
+        if (counted && slot >= 0) sum = slot_summary(M)[slot];
+        if (lane < 27) s_nb[lane] = slot;
+        if (s == 0) {
+            if (lane < 27) jobs[j].nb[lane] = slot;
+            else if (lane == 27) {
+                jobs[j].x = jx;
+                jobs[j].y = jy;
+                jobs[j].z = jz;
+                jobs[j].pad[0] = jobs[j].pad[1] = 0;
             }
         }
-        __syncthreads();
+        const int self = __shfl(slot, NB_SELF);
+        const bool present = self >= 0;
+        // Can any cube of this sub-job carry a triangle?  Corner 0 of every cube is a voxel of the chunk itself and must be observed
+        // (ChunkManager.cpp:271 / :352), and a case other than 0 / 255 needs both signs among the cubes' corners, which lie in the chunks
+        // counted above (slot_summary).  About half of the jobs of a recompute -- chunks inside the band but away from the surface --
+        // stop here: no corners staged, nothing classified.
+        const bool can = present && (unsigned)__shfl((int)sum, NB_SELF) != 0u && __ballot(counted && (sum & SUM_POS)) != 0ull && __ballot(counted && (sum & SUM_NEG)) != 0ull;
+        if (s == 0 && lane == 28 && present && !keep_dirty) {
+            // meshesToUpdate.clear() (Chisel.cpp:57) and the slot's "is in the job list" flag: this job's own
+            if (mesh_flag) mesh_flag[self] = 0u;
+            M.slot_dirty[self] = 0u;
+        }
+        MSTAMP(0);
+        // lane 1 deposits the sub-job's figures: its entry of cnt, and the job's accumulator; the wave whose deposit is the job's last
+        // allots the job its range.  (lane 0 takes the sub-job's stretch of the unordered lists in the same instruction.)
+        auto deposit = [&](int my_nt, int my_ng, int part) -> unsigned long long {
+            unsigned long long old = 0ull;
+            if (lane == 1) cnt[(size_t)j * G::ROW + 2 + s] = (unsigned)my_nt | ((unsigned)my_ng << 16);
+            if (lane == 1 || (lane == 0 && my_ng)) {
+                unsigned long long *addr = lane == 0 ? cursors + part : job_acc + j;
+                const unsigned long long inc = lane == 0 ? ((unsigned long long)my_ng << 32) | (unsigned long long)my_nt
+                                                         : (1ull << 48) | ((unsigned long long)my_ng << 24) | (unsigned long long)my_nt;
+                old = atomicAdd(addr, inc);
+                if (lane == 1 && (int)(old >> 48) == G::S - 1) {
+                    const unsigned long long tot = old + inc;
+                    const int tnt = (int)(tot & 0xffffffull), tng = (int)((tot >> 24) & 0xffffffull);
+                    unsigned long long base = 0ull;
+                    if (tnt | tng) base = atomicAdd(reinterpret_cast<unsigned long long *>(ctl + MC_TRIS), ((unsigned long long)tng << 32) | (unsigned long long)tnt);
+                    JobInfo ji;
+                    ji.x = jx; ji.y = jy; ji.z = jz;
+                    ji.present = present ? 1 : 0;
+                    ji.n_vertices = 3 * tnt;
+                    ji.n_grids = tng;
+                    ji.tri_base = (int)(base & 0xffffffffull);
+                    ji.grid_base = (int)(base >> 32);
+                    info[j] = ji;
+                    cnt[(size_t)j * G::ROW] = (unsigned)ji.tri_base;
+                    cnt[(size_t)j * G::ROW + 1] = (unsigned)ji.grid_base;
+                    job_acc[j] = 0ull;  // (every other sub-job of the job has been here: the accumulator is this wave's to reset)
+                }
+            }
+            return old;
+        };
+        if (!can) {
+            (void)deposit(0, 0, 0);
+            continue;
+        }
+        auto run = [&](auto type_tag) {
+            constexpr int T = decltype(type_tag)::value;
+            using B = MeshBox<N, T>;
+            const int z0 = T == 0 ? s * G::ZL : (T == 3 ? N - 1 : 0);
+            const int bz = T == 0 ? min(G::ZL, N - 1 - z0) : (T == 3 ? 1 : N - 1);
+            const int ncubes = B::BX * B::BY * bz;
+            // ---- the box's corners into LDS, one float each (fold_corner), every load of a pass requested before the first is used
+            if (T == 0) {
+                // voxels [z0 N^2, (z0 + bz + 1) N^2) of the chunk itself: contiguous in the pool
+                constexpr int PASS = N == 32 ? 4 : ((G::ZL + 1) * N * N / 4 + 63) / 64;  // 16^3: three 16-byte loads per lane and array
+                const int n4 = (bz + 1) * N * N / 4;
+                const float4 *sp = reinterpret_cast<const float4 *>(M.sdf + (size_t)self * (N * N * N) + (size_t)z0 * N * N);
+                const float4 *wp = reinterpret_cast<const float4 *>(M.wgt + (size_t)self * (N * N * N) + (size_t)z0 * N * N);
+                for (int base = 0; base < n4; base += 64 * PASS) {
+                    float4 vs[PASS], vw[PASS];
 #pragma unroll
-        for (int k = 0; k < CPT; k++) {
-            const int r = threadIdx.x * CPT + k;
-            if (r < V) {
-                const int index = s_case[r];
-                const int c = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu);  // (case 0 has no vertices)
+                    for (int u = 0; u < PASS; u++) {
+                        const int i = min(base + u * 64 + lane, n4 - 1);
+                        vs[u] = sp[i];
+                        vw[u] = wp[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < PASS; u++) {
+                        const int i = base + u * 64 + lane;
+                        if (i < n4)
+                            reinterpret_cast<float4 *>(s_tile)[i] = make_float4(fold_corner(vs[u].x, vw[u].x), fold_corner(vs[u].y, vw[u].y),
+                                                                                fold_corner(vs[u].z, vw[u].z), fold_corner(vs[u].w, vw[u].w));
+                    }
+                }
+            } else {
+                constexpr int PASS = 5;
+                const int nc = B::TX * B::TY * (bz + 1);
+                for (int base = 0; base < nc; base += 64 * PASS) {
+                    float2 v[PASS];
+#pragma unroll
+                    for (int u = 0; u < PASS; u++) {
+                        const int i = min(base + u * 64 + lane, nc - 1);
+                        v[u] = corner_voxel<N>(M, s_nb, B::X0 + i % B::TX, B::Y0 + (i / B::TX) % B::TY, z0 + i / (B::TX * B::TY));
+                    }
+#pragma unroll
+                    for (int u = 0; u < PASS; u++) {
+                        const int i = base + u * 64 + lane;
+                        if (i < nc) s_tile[i] = fold_corner(v[u].x, v[u].y);
+                    }
+                }
+            }
+            __syncthreads();
+            MSTAMP(1);
+            // corner i of the cube whose corner 0 is tile entry t0: cubeIndexOffsets (ChunkManager.cpp:67-69)
+            auto cube_corners = [&](int c, float (&sc)[8], int &index) -> bool {
+                const int lx = c % B::BX, ly = (c / B::BX) % B::BY, lz = c / (B::BX * B::BY);
+                const int t0 = (lz * B::TY + ly) * B::TX + lx;
+                const int ox[8] = {0, 1, 1, 0, 0, 1, 1, 0}, oy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, oz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+                index = 0;
+                bool observed = true;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float v = s_tile[t0 + ox[i] + oy[i] * B::TX + oz[i] * (B::TX * B::TY)];
+                    observed = observed && (v == v);        // :271 / :352 "weight <= 0.5 -> not observed"
+                    sc[i] = v;
+                    index |= (v < 0.0f) ? (1 << i) : 0;     // MarchingCubes::CalculateVertexConfiguration MarchingCubes.h:108-118
+                }
+                return observed;
+            };
+            // Classification with neighbouring lanes on neighbouring cubes (cube k * 64 + lane: consecutive corners, no LDS bank
+            // conflicts); the case bytes go through LDS to the lane that owns the cube in the traversal order (cubes lane * CPL ...).
+#pragma unroll 2
+            for (int k = 0; k < G::CPL; k++) {
+                const int c = k * 64 + lane;
+                if (c < ncubes) {
+                    float sc[8];
+                    int index;
+                    unsigned char cs = 0;
+                    if (cube_corners(c, sc, index)) cs = n_verts(index) ? (unsigned char)index : 0;
+                    s_case[c] = cs;
+                }
+            }
+            __syncthreads();
+            int nv = 0, ng = 0;
+            unsigned cw[G::CPL / 4];
+#pragma unroll
+            for (int w = 0; w < G::CPL / 4; w++) cw[w] = reinterpret_cast<const unsigned *>(s_case)[lane * (G::CPL / 4) + w];
+#pragma unroll
+            for (int k = 0; k < G::CPL; k++) {
+                const int index = (lane * G::CPL + k < ncubes) ? (int)((cw[k >> 2] >> ((k & 3) * 8)) & 0xffu) : 0;
+                const int c = n_verts(index);  // (case 0 has no vertices)
                 nv += c;
                 ng += (c != 0);  // IsOccupied (MarchingCubes.h:41-45)
-                cases[k] = (unsigned char)index;
             }
-        }
-    }
-    int ov, og, tv, tg;
-    asm volatile("" ::"v"(nv));
-    MSTAMP(2);
-    block_scan2<MESH_BLOCK>(nv, ng, ov, og, tv, tg, s_scan);
-    MSTAMP(3);
-    if (threadIdx.x == 0) {
-        const int tb = tv ? atomicAdd(&totals[0], tv / 3) : 0;
-        const int gb = tg ? atomicAdd(&totals[1], tg) : 0;
-        JobInfo ji;
-        ji.x = jx; ji.y = jy; ji.z = jz;
-        ji.present = present ? 1 : 0;
-        ji.n_vertices = tv;
-        ji.n_grids = tg;
-        ji.tri_base = tb;
-        ji.grid_base = gb;
-        info[j] = ji;
-        s_base[0] = tb;
-        s_base[1] = gb;
-        if (tb + tv / 3 > tri_capacity || gb + tg > tri_capacity) totals[2] = 1;  // (a cube has at least one triangle: the host grows both lists by the triangle total)
-    }
-    if (tv == 0) continue;  // block-uniform
-    __syncthreads();
-    MSTAMP(4);
-    const int tb = s_base[0], gb = s_base[1];
-    if (tb + tv / 3 > tri_capacity || gb + tg > tri_capacity) continue;  // block-uniform
-    // The occupied cubes (a few hundred of the 4096, unevenly spread over the threads) are listed in LDS and emitted by all threads
-    // together -- one cube each instead of up to CPT in a row on a few lanes --, MESH_LIST_CAP of them per round.
-    for (int base = 0; base < tg; base += MESH_LIST_CAP) {
-        if (base) __syncthreads();  // the previous round's list has been read
-        int trel = ov / 3, gidx = og;
+            MSTAMP(2);
+            // wave scan of (vertices, occupied cubes) in traversal order
+            int iv = nv, ig = ng;
 #pragma unroll
-        for (int k = 0; k < CPT; k++) {
-            const int index = cases[k];
-            if (index == 0) continue;
-            if ((unsigned)(gidx - base) < (unsigned)MESH_LIST_CAP) {
-                s_list_a[gidx - base] = (unsigned)(threadIdx.x * CPT + k) | ((unsigned)index << 16);
-                s_list_t[gidx - base] = (unsigned)trel;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int a = __shfl_up(iv, o), b = __shfl_up(ig, o);
+                if (lane >= o) {
+                    iv += a;
+                    ig += b;
+                }
             }
-            trel += (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu) / 3;
-            gidx++;
-        }
-        __syncthreads();
-        const int n_round = min(tg - base, MESH_LIST_CAP);
-        for (int e = threadIdx.x; e < n_round; e += MESH_BLOCK) {
-            const unsigned a = s_list_a[e];
-            const int r = (int)(a & 0xffffu), index = (int)(a >> 16), t0 = tb + (int)s_list_t[e];
-            const int nt = (int)((s_counts[index >> 2] >> ((index & 3) * 8)) & 0xffu) / 3;
-            CubeCorners cc;
-            int x, y, z, idx2;
-            cube_of_rank<N>(r, x, y, z);
-            (void)cube_config<N>(M, s_nb, s_vox, x, y, z, cc.s, idx2);
-            corners[gb + base + e] = cc;
-            for (int t = 0; t < nt; t++) {
+            const int tv = __shfl(iv, 63), tg = __shfl(ig, 63);
+            MSTAMP(3);
+            const int part = (j * G::S + s) & (MESH_PARTS - 1);
+            const unsigned long long old = deposit(tv / 3, tg, part);
+            if (tg == 0) return;
+            const unsigned long long cur = (unsigned long long)__shfl((long long)old, 0);
+            const int cur_t = (int)(cur & 0xffffffffull), cur_g = (int)(cur >> 32);
+            MSTAMP(4);
+            if (cur_t + tv / 3 > part_capacity || cur_g + tg > part_capacity) {  // wave-uniform
+                if (lane == 0) ctl[MC_OVERFLOW] = 1;  // (the host grows both lists and runs the recompute's kernels again)
+                return;
+            }
+            // The occupied cubes (a few dozen of the sub-job's, unevenly spread over the lanes) are listed in LDS and emitted by all
+            // lanes together, one cube each.
+            {
+                int trel = (iv - nv) / 3, gidx = ig - ng;
+#pragma unroll
+                for (int k = 0; k < G::CPL; k++) {
+                    const int c = lane * G::CPL + k;
+                    const int index = (c < ncubes) ? (int)((cw[k >> 2] >> ((k & 3) * 8)) & 0xffu) : 0;
+                    if (index == 0) continue;
+                    s_list[gidx] = (unsigned)c | ((unsigned)index << 10) | ((unsigned)trel << 18);
+                    trel += n_verts(index) / 3;
+                    gidx++;
+                }
+            }
+            __syncthreads();
+            const size_t base_t = (size_t)part * part_capacity + cur_t, base_g = (size_t)part * part_capacity + cur_g;
+            for (int e = lane; e < tg; e += 64) {
+                const unsigned a = s_list[e];
+                const int c = (int)(a & 1023u), index = (int)((a >> 10) & 255u), trel = (int)(a >> 18);
+                CubeCorners cc;
+                int idx2;
+                (void)cube_corners(c, cc.s, idx2);
+                corners[base_g + e] = cc;
+                const int x = B::X0 + c % B::BX, y = B::Y0 + (c / B::BX) % B::BY, z = z0 + c / (B::BX * B::BY);
+                const int nt = n_verts(index) / 3;
                 TriRec rec;
                 rec.job = (unsigned)j;
-                rec.code = ((unsigned)r << 11) | ((unsigned)index << 3) | (unsigned)t;
-                rec.gidx = (unsigned)(gb + base + e);
-                tris[t0 + t] = rec;
+                rec.cube = (unsigned)(base_g + e);
+                for (int t = 0; t < nt; t++) {
+                    rec.code = (unsigned)x | ((unsigned)y << 5) | ((unsigned)z << 10) | ((unsigned)index << 15) | ((unsigned)t << 23) | ((unsigned)s << 26);
+                    rec.rel = (unsigned)(trel + t) | ((unsigned)e << 16);
+                    tris[base_t + trel + t] = rec;
+                }
             }
+            MSTAMP(5);
+        };
+        switch (type) {
+            case 0: run(std::integral_constant<int, 0>()); break;
+            case 1: run(std::integral_constant<int, 1>()); break;
+            case 2: run(std::integral_constant<int, 2>()); break;
+            default: run(std::integral_constant<int, 3>()); break;
         }
     }
-    MSTAMP(5);
-    }
 }
+
+// (the register cap is an attribute that takes a literal: one kernel per chunk size around the common body)
+#define CHISEL_MESH_COUNT_KERNEL(NN, VGPRS, WAVES)                                                                                                    \
+    __global__ __launch_bounds__(64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void mesh_count_kernel_##NN(                                 \
+        MapView M, const int *__restrict__ ids, int ids_capacity, MeshJob *jobs, const int *__restrict__ n_jobs, JobInfo *info, int *ctl, unsigned *cnt, \
+        unsigned long long *job_acc, TriRec *tris, CubeCorners *corners, int part_capacity, unsigned *mesh_flag, int keep_dirty) {              \
+        mesh_count_body<NN>(M, ids, ids_capacity, jobs, n_jobs, info, ctl, cnt, job_acc, tris, corners, part_capacity, mesh_flag, keep_dirty);   \
+    }
+CHISEL_MESH_COUNT_KERNEL(8, MESH_COUNT_VGPRS, MESH_COUNT_WAVES)
+CHISEL_MESH_COUNT_KERNEL(16, MESH_COUNT_VGPRS, MESH_COUNT_WAVES)
+CHISEL_MESH_COUNT_KERNEL(32, 128, 3)
+#undef CHISEL_MESH_COUNT_KERNEL
 
 // MarchingCubes::InterpolateVertex (MarchingCubes.h:135-146), including "vertex1 + 0.5 * vertex2" (sic)
 __device__ inline f3v interpolate_vertex(f3v v1, f3v v2, float sdf1, float sdf2) {
@@ -694,10 +713,27 @@ template <int N>
 // host needs them at the next recompute) and then `seq` into host_flags[6].
 __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
                                                                     const JobInfo *__restrict__ info, const TriRec *__restrict__ tris,
-                                                                    const CubeCorners *__restrict__ corners, const int *__restrict__ totals, float *arena, size_t arena_floats, int *host_info,
+                                                                    const CubeCorners *__restrict__ corners, const int *__restrict__ totals,
+                                                                    const unsigned *__restrict__ cnt, int part_capacity, float *arena, size_t arena_floats, int *host_info,
                                                                     volatile int *host_flags, int max_jobs, int seq, int publish) {
-    const int n_tris = totals[0];
-    const int n_jobs = totals[3];
+    // The unordered triangle list: MESH_PARTS partitions of part_capacity entries, each filled up to its cursor.  Entry i of their
+    // concatenation is this grid's i-th triangle: where the partitions begin in that numbering, once per workgroup.  (A partition per
+    // workgroup -- no table, no search -- was 1-7 us slower: the workgroups that find nothing to do then sit between the others in dispatch order.)
+    __shared__ int s_off[MESH_PARTS + 1];
+    if (threadIdx.x < MESH_PARTS) {
+        int v = totals[MC_CURSORS + 2 * threadIdx.x];
+#pragma unroll
+        for (int o = 1; o < MESH_PARTS; o <<= 1) {
+            const int a = __shfl_up(v, o);
+            if ((int)threadIdx.x >= o) v += a;
+        }
+        s_off[threadIdx.x + 1] = v;
+        if (threadIdx.x == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    const int part_tris = s_off[MESH_PARTS];
+    const int n_tris = totals[MC_TRIS];  // (= the sum of the cursors unless a partition overflowed)
+    const int n_jobs = totals[MC_JOBS];
     if ((publish & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // (publish: bit 0 = totals to the host, bit 1 = the kept job list was this recompute's input)
         // The recompute's totals, straight into pinned host memory as ONE 16-byte store -- {triangles, grids, jobs | overflow << 31,
         // sequence number} -- before anything else: the host polls word 3 for this recompute's sequence number when the caller next
@@ -705,8 +741,8 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         // map's stream costs a barrier packet of 7-12 us in front of the next kernel, a one-thread kernel 5 us).
         uint4 v;
         v.x = (unsigned)n_tris;
-        v.y = (unsigned)totals[1];
-        v.z = (unsigned)n_jobs | (totals[2] ? 0x80000000u : 0u);
+        v.y = (unsigned)totals[MC_GRIDS];
+        v.z = (unsigned)n_jobs | (totals[MC_OVERFLOW] ? 0x80000000u : 0u);
         v.w = (unsigned)seq;
         *reinterpret_cast<uint4 *>(const_cast<int *>(host_flags)) = v;
         // what the host polls is a second copy of the sequence number behind a system-scope fence: that the 16 bytes above arrive
@@ -714,11 +750,11 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         __threadfence_system();
         host_flags[5] = seq;
         // the job list the integration kernels keep has been consumed by the count kernel (its number is in totals[3]): empty again
-        if ((publish & 2) && M.mesh_ctl) M.mesh_ctl[4] = 0;
+        if ((publish & 2) && M.mesh_ctl) M.mesh_ctl[MC_KEPT] = 0;
     }
-    const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[1] * 3;
+    const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[MC_GRIDS] * 3;
     // a triangle list that overflowed (totals[2]) is incomplete: nothing is emitted, the host lists and emits again
-    const bool fits = totals[2] == 0 && nv3 * (P.use_color ? 3 : 2) + ng3 <= arena_floats;
+    const bool fits = totals[MC_OVERFLOW] == 0 && nv3 * (P.use_color ? 3 : 2) + ng3 <= arena_floats;
     if (blockIdx.x == 0) {
         const int *src = reinterpret_cast<const int *>(info);
         const int n = min(n_jobs, max_jobs) * 8;
@@ -732,22 +768,48 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     float *grids = arena + nv3 * (P.use_color ? 3 : 2);
     // one thread per VERTEX: all three vertices of its triangle (the face normal needs them: three cheap interpolations),
     // then the costly part -- seven voxel lookups for the gradient, the colour lookups -- for its own vertex only
-    for (int vi = blockIdx.x * MESH_TRI_BLOCK + threadIdx.x; vi < 3 * n_tris; vi += gridDim.x * MESH_TRI_BLOCK) {
-    const int i = vi / 3, mine = vi - 3 * i;
-    const TriRec rec = tris[i];
+    constexpr int ROW = MeshGeom<N>::ROW;
+    for (int ti = (int)blockIdx.x * MESH_TRI_BLOCK + threadIdx.x; ti < 3 * part_tris; ti += (int)gridDim.x * MESH_TRI_BLOCK) {
+    int i = ti / 3;
+    const int mine = ti - 3 * i;
+    int part = 0;
+#pragma unroll
+    for (int o = MESH_PARTS / 2; o > 0; o >>= 1)
+        if (s_off[part + o] <= i) part += o;
+    i -= s_off[part];
+    const TriRec rec = tris[(size_t)part * part_capacity + i];
     const MeshJob &job = jobs[rec.job];  // stays in memory (L1 / L2): its neighbour table is indexed per lane
     const int *nb = job.nb;
     const int jx = job.x, jy = job.y, jz = job.z;
-    const int r = (int)(rec.code >> 11), index = (int)((rec.code >> 3) & 0xffu), t = 3 * (int)(rec.code & 7u);
-    int x, y, z;
-    cube_of_rank<N>(r, x, y, z);
+    const int x = (int)(rec.code & 31u), y = (int)((rec.code >> 5) & 31u), z = (int)((rec.code >> 10) & 31u);
+    const int index = (int)((rec.code >> 15) & 0xffu), t = 3 * (int)((rec.code >> 23) & 7u), sub = (int)(rec.code >> 26);
+    // where the triangle goes: its job's base + the triangles of the sub-jobs in front of its own + its place in the sub-job
+    // (mesh_count_kernel: the traversal order of ChunkManager.cpp:395-441); likewise the cube's grid entry.  The job's row of `cnt`
+    // -- bases, then the sub-jobs' figures -- arrives as 16-byte loads issued together.
+    int tri_pos = (int)(rec.rel & 0xffffu), grid_pos = (int)(rec.rel >> 16);
+    {
+        const uint4 *row4 = reinterpret_cast<const uint4 *>(cnt + (size_t)rec.job * ROW);
+        uint4 r[ROW / 4];
+#pragma unroll
+        for (int q = 0; q < ROW / 4; q++) r[q] = row4[q];
+        tri_pos += (int)r[0].x;
+        grid_pos += (int)r[0].y;
+#pragma unroll
+        for (int q = 2; q < ROW; q++) {
+            const unsigned c = (q & 3) == 0 ? r[q >> 2].x : ((q & 3) == 1 ? r[q >> 2].y : ((q & 3) == 2 ? r[q >> 2].z : r[q >> 2].w));
+            const unsigned cc = (q - 2 < sub) ? c : 0u;
+            tri_pos += (int)(cc & 0xffffu);
+            grid_pos += (int)(cc >> 16);
+        }
+    }
+    const int vi = 3 * tri_pos + mine;
     const unsigned long long row = c_mc_cases[index];
     const f3v origin = mk3((float)(N * jx) * P.res, (float)(N * jy) * P.res, (float)(N * jz) * P.res);  // Chunk.cpp:43
     // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
     const f3v coords = add3(mk3((float)x * P.res + P.half_res, (float)y * P.res + P.half_res, (float)z * P.res + P.half_res), origin);
-    const CubeCorners cc = corners[rec.gidx];
+    const CubeCorners cc = corners[rec.cube];
     if (t == 0 && mine == 0) {
-        const size_t g = (size_t)rec.gidx;
+        const size_t g = (size_t)grid_pos;
         grids[3 * g] = coords.x;
         grids[3 * g + 1] = coords.y;
         grids[3 * g + 2] = coords.z;
@@ -937,11 +999,13 @@ struct MeshBuffers {
     MeshJob *jobs = nullptr;
     int *ids = nullptr;
     JobInfo *info = nullptr; // [capacity] per-job results of a recompute
-    int *totals = nullptr;   // [8] = MapView::mesh_ctl: triangles, grids, triangle-list overflow flag, jobs; [4]: entries of the job list the integration kernels keep
+    int *totals = nullptr;   // = MapView::mesh_ctl (MC_*): triangles, grids, record-list overflow flag, jobs; the kept job list's length; the partition cursors
     int *n_jobs = nullptr;   // where the count kernel finds the number of jobs (the kept list's length, or null: totals[3] and the caller's ids)
-    TriRec *tris = nullptr;  // triangle list of one recompute
-    CubeCorners *corners = nullptr;  // [tri_capacity] corner distances of its occupied cubes
+    TriRec *tris = nullptr;  // [tri_capacity] triangle list of one recompute: MESH_PARTS partitions of tri_capacity / MESH_PARTS entries
+    CubeCorners *corners = nullptr;  // [tri_capacity] corner distances of its occupied cubes, partitioned likewise
     int tri_capacity = 0;
+    unsigned *cnt = nullptr;             // [capacity][S] triangles | occupied cubes << 16 of every sub-job (mesh_count_kernel)
+    unsigned long long *job_acc = nullptr;  // [capacity] per-job accumulators of the count kernel's waves; zero between recomputes
     int capacity = 0;        // jobs
     unsigned *flags = nullptr;  // [max_chunks] "this slot is in the job list" = MapView::mesh_flag
     double *query = nullptr;
@@ -954,6 +1018,8 @@ inline void free_mesh_buffers(MeshBuffers &b) {
     if (b.totals) (void)hipFree(b.totals);
     if (b.tris) (void)hipFree(b.tris);
     if (b.corners) (void)hipFree(b.corners);
+    if (b.cnt) (void)hipFree(b.cnt);
+    if (b.job_acc) (void)hipFree(b.job_acc);
     if (b.flags) (void)hipFree(b.flags);
     if (b.query) (void)hipFree(b.query);
     if (b.cube) (void)hipFree(b.cube);

@@ -837,14 +837,22 @@ class Chisel {  // Chisel.h:38-230
         hip_check(chisel_hip_reset(map));
         meshesToUpdate.clear();
     }
-    const ChunkSet &GetMeshesToUpdate() const {  // Chisel.h:220-223
-        int64_t n = 0;
-        hip_check(chisel_hip_meshes_to_update(map, nullptr, 0, &n));
-        std::vector<int> ids((size_t)n * 3);
-        if (n) hip_check(chisel_hip_meshes_to_update(map, ids.data(), n, &n));
-        meshesToUpdate.clear();
-        for (int64_t i = 0; i < n; i++) meshesToUpdate[ChunkID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2])] = true;
-        return meshesToUpdate;
+    // Chisel.h:220-223.  chisel_ros reads it after every frame (ChiselServer.cpp:346): the copy kept here is brought up to date with
+    // what joined the set since the previous call (chisel_hip_meshes_to_update_since), not rebuilt.
+    const ChunkSet &GetMeshesToUpdate() const {
+        if (updateIds.empty()) updateIds.resize(3 * 8192);
+        for (;;) {
+            int64_t n = 0;
+            int cleared = 0;
+            hip_check(chisel_hip_meshes_to_update_since(map, updateCursor, updateIds.data(), (int64_t)(updateIds.size() / 3), &n, &cleared));
+            if ((size_t)n * 3 > updateIds.size()) {
+                updateIds.resize((size_t)n * 3 + 3 * 1024);
+                continue;
+            }
+            if (cleared) meshesToUpdate.clear();
+            for (int64_t i = 0; i < n; i++) meshesToUpdate[ChunkID(updateIds[3 * i], updateIds[3 * i + 1], updateIds[3 * i + 2])] = true;
+            return meshesToUpdate;
+        }
     }
     chisel_hip_map *HipMap() const { return map; }
 
@@ -853,6 +861,8 @@ class Chisel {  // Chisel.h:38-230
     chisel_hip_map *map;
     ChunkManager chunkManager;
     mutable ChunkSet meshesToUpdate;
+    mutable uint64_t updateCursor[2] = {0, 0};
+    mutable std::vector<int> updateIds;
 };
 typedef std::shared_ptr<Chisel> ChiselPtr;
 typedef std::shared_ptr<const Chisel> ChiselConstPtr;

@@ -2,10 +2,12 @@
 // projection and frustum construction happen inside libchisel_hip.so, SetupFrustum asks it for the result).
 #ifndef CHISEL_HIP_FACADE_CAMERA_H_
 #define CHISEL_HIP_FACADE_CAMERA_H_
+#include <chisel_hip.h>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <memory>
-#include <vector>
+#include <new>
 #include "../geometry/Frustum.h"
 #include "../geometry/Geometry.h"
 #include "../geometry/Interpolate.h"  // (its one caller is DepthImage::BilinearInterpolateDepth below)
@@ -63,6 +65,48 @@ class PinholeCamera {  // PinholeCamera.h:35-69
     int width = 640, height = 480;
     float nearPlane = 0.05f, farPlane = 5.0f;
 };
+// The pixel buffer of an image: the reference's `new DataType[n]` (DepthImage.h:42-52, ColorImage.h:44-58), here page-locked host memory
+// from the library (chisel_hip_host_alloc).  chisel_ros allocates its images once and refills them every frame
+// (ChiselServer.cpp:268-273,287-292): an integrate call then reads the frame without the runtime's staged copy of pageable memory.
+template <class T>
+class ImageBuffer {
+  public:
+    ImageBuffer() : p(nullptr), n(0) {}
+    explicit ImageBuffer(size_t count) : p(nullptr), n(0) { resize(count); }
+    ImageBuffer(const ImageBuffer &o) : p(nullptr), n(0) { assign(o.p, o.p + o.n); }
+    ImageBuffer &operator=(const ImageBuffer &o) {
+        if (this != &o) assign(o.p, o.p + o.n);
+        return *this;
+    }
+    ~ImageBuffer() { chisel_hip_host_free(p); }
+    void resize(size_t count) {  // (value-initialised, like std::vector)
+        if (count != n) {
+            chisel_hip_host_free(p);
+            p = count ? static_cast<T *>(chisel_hip_host_alloc(count * sizeof(T))) : nullptr;
+            if (count && !p) throw std::bad_alloc();
+            n = count;
+        }
+        for (size_t i = 0; i < n; i++) p[i] = T();
+    }
+    void assign(const T *first, const T *last) {
+        const size_t count = (size_t)(last - first);
+        if (count != n) {
+            chisel_hip_host_free(p);
+            p = count ? static_cast<T *>(chisel_hip_host_alloc(count * sizeof(T))) : nullptr;
+            if (count && !p) throw std::bad_alloc();
+            n = count;
+        }
+        if (count) std::memcpy(p, first, count * sizeof(T));
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+  private:
+    T *p;
+    size_t n;
+};
 template <class DataType>
 class DepthImage {  // DepthImage.h:33-103 (row-major, Index = col + row * width)
   public:
@@ -84,7 +128,7 @@ class DepthImage {  // DepthImage.h:33-103 (row-major, Index = col + row * width
     int GetWidth() const { return width; }
     int GetHeight() const { return height; }
   protected:
-    std::vector<DataType> data;
+    ImageBuffer<DataType> data;
     int width, height;
 };
 template <class DataType = uint8_t>
@@ -114,7 +158,7 @@ class ColorImage {  // ColorImage.h:38-134 (1 = mono, 3 = BGR, 4 = BGRA)
     int GetHeight() const { return height; }
     int GetNumChannels() const { return numChannels; }
   protected:
-    std::vector<DataType> data;
+    ImageBuffer<DataType> data;
     int width, height, numChannels;
 };
 }  // namespace chisel

@@ -140,6 +140,12 @@ int chisel_hip_abi_version(void);
 const char *chisel_hip_last_error(void);
 /* number of visible gfx950 devices (0 when there is none) */
 int chisel_hip_device_count(void);
+/* Image buffers of the caller (DepthImage.h:42-52 / ColorImage.h:44-58: `new DataType[...]`, allocated once by chisel_ros and refilled
+ * every frame, ChiselServer.cpp:268-273,287-292): page-locked host memory, which the integrate calls read without the runtime's staged
+ * copy of pageable memory (depth straight over the bus, colour as one asynchronous copy).  The facade's DepthImage / ColorImage allocate
+ * through these; plain malloc / free when no HIP device is present (the buffer is then ordinary memory -- nothing computes on the CPU). */
+void *chisel_hip_host_alloc(size_t bytes);
+void chisel_hip_host_free(void *ptr);
 /* Chisel::Chisel Chisel.h:41 */
 int chisel_hip_create(const chisel_hip_config *config, chisel_hip_map **out);
 int chisel_hip_destroy(chisel_hip_map *map);
@@ -197,6 +203,12 @@ int chisel_hip_upload_chunk(chisel_hip_map *map, const int id_xyz[3], const floa
                             const uint8_t *rgbw);
 /* Chisel::GetMeshesToUpdate Chisel.h:220-223: ids flagged since the last recompute (27-neighbourhoods) */
 int chisel_hip_meshes_to_update(chisel_hip_map *map, int *ids_xyz, int64_t max_ids, int64_t *count);
+/* The same set for a caller that keeps its own copy between calls (the facade's Chisel::GetMeshesToUpdate, read after every frame:
+ * ChiselServer.cpp:346): the ids that joined Chisel::meshesToUpdate (Chisel.h:175-189, :228) since the state `cursor` stands for -- two
+ * words, zero before the first call, updated by the call.  *cleared != 0: the set was emptied in between (Chisel::UpdateMeshes' recompute,
+ * Chisel.cpp:57, or Reset): the caller empties its copy first.  When more than max_ids ids are due nothing is consumed: *count says how
+ * many, call again with room for them.  Cost: proportional to what changed since the cursor, not to the map. */
+int chisel_hip_meshes_to_update_since(chisel_hip_map *map, uint64_t cursor[2], int *ids_xyz, int64_t max_ids, int64_t *count, int *cleared);
 /* ChunkManager::GetAllMeshes ChunkManager.h:163-166 */
 int chisel_hip_num_meshes(chisel_hip_map *map, int64_t *out);
 int chisel_hip_list_meshes(chisel_hip_map *map, int *ids_xyz, int64_t max_ids, int64_t *count);

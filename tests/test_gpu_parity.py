@@ -262,6 +262,51 @@ def test_reset_and_garbage_collect(oracle_mod):
     _run(om, gm, integ, frames, cam)
 
 
+def test_meshes_to_update_kept_incrementally(oracle_mod):
+    """chisel_hip_meshes_to_update_since (what the C++ facade's GetMeshesToUpdate keeps its set with, read after every frame:
+    ChiselServer.cpp:346) against the full listing and the oracle's meshesToUpdate, across frames, a garbage collection of dirty
+    chunks, a recompute (Chisel.cpp:57 clears the set), a tiny staging capacity (the grow-and-retry path) and a reset."""
+    import ctypes as C
+    om, gm, integ = _mk(oracle_mod, 8, 0.05, True, carving=True, carving_dist=0.02)
+    cam = small_camera(64, 48)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(64, 48, 3)
+    frames = make_frames("sphere_room", 14, 64, 48)
+    cursor = (C.c_uint64 * 2)(0, 0)
+    mine = set()
+
+    def step(capacity=8192):
+        ids, cleared = gm.GetMeshesToUpdateSince(cursor, capacity)
+        if cleared:
+            mine.clear()
+        mine.update(map(tuple, ids.tolist()))
+        full = set(map(tuple, gm.GetMeshesToUpdate().tolist()))
+        assert mine == full, (len(mine), len(full))
+        assert full == set(map(tuple, om.meshes_to_update().tolist())), (len(full), len(om.meshes_to_update()))
+
+    for k, (d, p) in enumerate(frames):
+        om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        gm.IntegrateDepthScanColor(integ, d, p, cam, color, p, cam)
+        step(8 if k == 2 else 8192)
+        if k == 4:  # dirty chunks disappear: their neighbourhoods stay in the set (Chisel.h:228 lives on the host)
+            victims = gm.GetChunkIDs()[::3]
+            gm.GarbageCollect(victims)
+            for v in victims:
+                om.remove_chunk(v)
+            step()
+        if k == 8:
+            gm.UpdateMeshes(force=True)
+            om.update_meshes()
+            step()
+            assert not mine
+        if k == 11:
+            gm.Reset()
+            om.reset()
+            step()
+            assert not mine
+    assert len(mine) > 20
+
+
 def test_reset_and_garbage_collect_between_batches_in_flight(oracle_mod, monkeypatch):
     """Reset and GarbageCollect issued while batches are queued on all three streams (no synchronisation by the caller): the front
     halves of the batches that follow must see the map as those calls left it (pending sets of batches before the reset are
