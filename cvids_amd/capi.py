@@ -62,7 +62,7 @@ EXPORTS = [
     "chisel_hip_synchronize", "chisel_hip_wait_event", "chisel_hip_record_event", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
     "chisel_hip_integrate_batch", "chisel_hip_integrate_pointcloud", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
     "chisel_hip_list_chunks", "chisel_hip_has_chunk", "chisel_hip_download_chunk", "chisel_hip_upload_chunk",
-    "chisel_hip_meshes_to_update", "chisel_hip_meshes_to_update_since", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
+    "chisel_hip_meshes_to_update", "chisel_hip_meshes_to_update_since", "chisel_hip_shell_plan_device", "chisel_hip_shell_segment_bytes", "chisel_hip_export_shells_packed", "chisel_hip_import_shells_packed", "chisel_hip_update_meshes_planned", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
     "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
@@ -171,6 +171,12 @@ def load_library():
         L.chisel_hip_integrate_chunk.argtypes = [vp, i32p, C.POINTER(DepthFrame), C.POINTER(ColorFrame), i32p]
         L.chisel_hip_recompute_mesh.argtypes = [vp, i32p]
         L.chisel_hip_dirty_ids_device.argtypes = [vp, vp, C.c_int]
+        L.chisel_hip_shell_plan_device.argtypes = [vp, vp, C.c_int, C.c_int, i64p]
+        L.chisel_hip_shell_segment_bytes.argtypes = [vp, C.c_int64, C.c_int64]
+        L.chisel_hip_shell_segment_bytes.restype = C.c_int64
+        L.chisel_hip_export_shells_packed.argtypes = [vp, vp, C.c_int64]
+        L.chisel_hip_import_shells_packed.argtypes = [vp, vp, C.c_int64]
+        L.chisel_hip_update_meshes_planned.argtypes = [vp]
         L.chisel_hip_mesh_shell_plan.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]
         L.chisel_hip_mesh_shell_plan_all.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]
         L.chisel_hip_shell_volume.argtypes = [C.c_int, C.c_int]

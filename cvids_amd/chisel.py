@@ -358,6 +358,35 @@ class Chisel:
         # DropGhostChunks, which returns after the recompute behind the imports has started (it looks at that recompute's totals).
         self._ghost_keep = getattr(self, "_ghost_keep", []) + [(items, sdf, wgt, col, found)]
 
+    # ---- the sharded recompute planned on the device (chisel_hip.h: chisel_hip_shell_plan_device ...) -------------------------------
+    def PlanShellsDevice(self, gathered, world, cap):
+        """gathered: int32 CUDA tensor, per rank 1 + 4 * cap ints (count, then (x, y, z, flag) entries).  -> dict: jobs (of this shard),
+        max_count (largest per-rank count: > cap means entries were cut off and nothing else counts), send / recv: (world, 2) int64 arrays
+        of (items, voxels) per peer.  Waits for those figures: the one host wait of a sharded recompute."""
+        out = np.zeros(4 + 4 * world, np.int64)
+        check(self.L.chisel_hip_shell_plan_device(self.h, gathered.data_ptr(), int(world), int(cap), out.ctypes.data_as(C.POINTER(C.c_int64))))
+        self._plan_keep = gathered  # (read by the plan kernels, which the call has waited for; kept for symmetry with the buffers below)
+        self._packed_keep = []      # the previous recompute's buffers: its drop kernel ran before the wait above returned
+        return {"jobs": int(out[0]), "ghosts_before": int(out[1]), "max_count": int(out[2]), "send_items": int(out[3]),
+                "send": out[4:4 + 2 * world].reshape(world, 2).copy(), "recv": out[4 + 2 * world:4 + 4 * world].reshape(world, 2).copy()}
+
+    def ShellSegmentBytes(self, items, voxels):
+        return int(self.L.chisel_hip_shell_segment_bytes(self.h, int(items), int(voxels)))
+
+    def ExportShellsPacked(self, out):
+        """out: uint8 CUDA tensor of the plan's send size; nothing is waited for (record_event orders the collective)"""
+        check(self.L.chisel_hip_export_shells_packed(self.h, out.data_ptr() if out.numel() else None, int(out.numel())))
+        self._packed_keep = getattr(self, "_packed_keep", []) + [out]
+
+    def ImportShellsPacked(self, buf):
+        """buf: uint8 CUDA tensor holding the received segments (read in place behind wait_event; kept until the next plan)"""
+        check(self.L.chisel_hip_import_shells_packed(self.h, buf.data_ptr() if buf.numel() else None, int(buf.numel())))
+        self._packed_keep = getattr(self, "_packed_keep", []) + [buf]
+
+    def UpdateMeshesPlanned(self):
+        check(self.L.chisel_hip_update_meshes_planned(self.h))
+        self._imports_fenced = True
+
     def DropGhostChunks(self):
         check(self.L.chisel_hip_drop_ghost_chunks(self.h))
         if getattr(self, "_ghost_keep", None):

@@ -252,6 +252,14 @@ struct chisel_hip_map {
     JobInfo *mesh_info_host = nullptr;                                 // pinned: its first MESH_INFO_PREFETCH per-job records
     hipStream_t copy_stream = nullptr;                                 // small device->host copies that must not wait for queued batches
     std::vector<int> ghost_ids;                                        // chunks of other shards imported for meshing (x, y, z triples)
+    // the plan of a sharded recompute, made on the device (kernels_map.h: ShellPlan; chisel_hip_shell_plan_device ...)
+    ShellPlan shell_plan{};
+    int *shell_plan_host = nullptr, *shell_plan_host_dev = nullptr;    // pinned: where the plan's figures reach the host (the one wait of a sharded recompute)
+    int64_t shell_send[SHELL_MAX_SHARDS][2] = {}, shell_recv[SHELL_MAX_SHARDS][2] = {};  // (items, voxels) per peer of the latest plan
+    int shell_jobs = 0, shell_send_items = 0;
+    const unsigned char *ghost_packed = nullptr;                       // the received segments the current ghosts came from (chisel_hip_import_shells_packed): dropped from there
+    ShellSegments ghost_segments{};
+    int ghost_packed_items = 0;
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     uint64_t pending_version = 1;                                      // bumped when entries join pending_mesh_ids (chisel_hip_meshes_to_update_since)
     uint32_t dirty_epoch = 0;                                          // bumped when the device's dirty list is emptied (recompute, reset)
@@ -1214,6 +1222,9 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     if (m->error_flag_host) (void)hipHostFree(m->error_flag_host);
     if (m->mesh_info_host) (void)hipHostFree(m->mesh_info_host);
     if (m->dirty_tail_host) (void)hipHostFree(m->dirty_tail_host);
+    if (m->shell_plan_host) (void)hipHostFree(m->shell_plan_host);
+    for (void *p : {(void *)m->shell_plan.jobset, (void *)m->shell_plan.my_jobs, (void *)m->shell_plan.ctl, (void *)m->shell_plan.send_items})
+        if (p) (void)hipFree(p);
     clear_meshes(m);
     release_arena_pool(m);
     free_mesh_buffers(m->mesh_buf);
@@ -1705,6 +1716,19 @@ int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, con
 int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_drop_ghost_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    if (m->ghost_packed) {
+        // the ghosts of chisel_hip_import_shells_packed: named by the items of the received segments, which the caller still holds
+        HIP_TRY(hipSetDevice(m->device));
+        m->topology_epoch++;
+        int rc_p = check_mesh_totals(m);  // a recompute in flight may still read them
+        if (rc_p) return rc_p;
+        if (m->ghost_packed_items > 0)
+            hipLaunchKernelGGL(shell_drop_ghosts_kernel, dim3((unsigned)m->ghost_packed_items), dim3(256), 0, m->stream, m->view, m->ghost_packed, m->ghost_segments, m->cfg.n_shards, m->V);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(note_map_mutation(m));
+        m->ghost_packed = nullptr;
+        m->ghost_packed_items = 0;
+    }
     if (m->ghost_ids.empty()) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
     m->topology_epoch++;
@@ -1882,6 +1906,167 @@ int chisel_hip_import_ghost_shells(chisel_hip_map *m, const int *items, int n, c
     for (int j = 0; j < n; j++) m->ghost_ids.insert(m->ghost_ids.end(), items + 4 * j, items + 4 * j + 3);
     if (!on_device) HIP_TRY(hipStreamSynchronize(m->stream));  // (the staging buffers above are freed on return)
     HIP_TRY(note_map_mutation(m));
+    return CHISEL_HIP_OK;
+}
+
+// ---- the sharded recompute without host planning (kernels_map.h: ShellPlan) ------------------------------------------------------
+namespace {
+int ensure_shell_plan(chisel_hip_map *m, int jobset_capacity, int send_capacity) {
+    ShellPlan &S = m->shell_plan;
+    if (!S.ctl) {
+        HIP_TRY(hipMalloc(&S.ctl, (16 + 4 * SHELL_MAX_SHARDS + 4) * sizeof(int)));  // ctl[16] | send_cur[64] (64-bit) | recv_cnt[64] (64-bit) | ghost chunks created so far (64-bit, never zeroed)
+        HIP_TRY(hipMemsetAsync(S.ctl, 0, (16 + 4 * SHELL_MAX_SHARDS + 4) * sizeof(int), m->stream));
+        S.send_cur = reinterpret_cast<unsigned long long *>(S.ctl + 16);
+        S.recv_cnt = S.send_cur + SHELL_MAX_SHARDS;
+        HIP_TRY(hipHostMalloc((void **)&m->shell_plan_host, (16 + 4 * SHELL_MAX_SHARDS + 4) * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer((void **)&m->shell_plan_host_dev, m->shell_plan_host, 0));
+    }
+    if (jobset_capacity > S.jobset_capacity) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (S.jobset) HIP_TRY(hipFree(S.jobset));
+        S.jobset = nullptr;
+        HIP_TRY(hipMalloc(&S.jobset, (size_t)jobset_capacity * sizeof(unsigned long long)));
+        S.jobset_capacity = jobset_capacity;
+    }
+    if (send_capacity > S.send_capacity) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (S.send_items) HIP_TRY(hipFree(S.send_items));
+        S.send_items = nullptr;
+        HIP_TRY(hipMalloc(&S.send_items, (size_t)send_capacity * 8 * sizeof(int)));
+        S.send_capacity = send_capacity;
+    }
+    return CHISEL_HIP_OK;
+}
+}  // namespace
+
+// Step 2 of a sharded recompute, on the device: from the all-gathered list of updated chunks (`gathered_dev`: per rank 1 + 4 * cap
+// ints -- count, then (x, y, z, flag) entries: chisel_hip_dirty_ids_device) this shard's jobs, the shells it sends and how much it
+// receives (kernels_map.h).  out[0] = its jobs, out[1] = ghost chunks this shard's EARLIER recomputes created (for the record), out[2] = the largest per-rank count of the gathered list (> cap: entries
+// were cut off -- the caller gathers again with more room; nothing else of `out` counts then), out[3] = items it sends; then per peer p
+// out[4 + 2 p], out[5 + 2 p] = (items, voxels) sent to p, out[4 + 2 W + 2 p], ... = received from p.  The call waits for these figures:
+// the one host wait of a sharded recompute.  A buffer that was ready behind an event: chisel_hip_wait_event first.
+int chisel_hip_shell_plan_device(chisel_hip_map *m, const int *gathered_dev, int world, int cap, int64_t *out) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || !gathered_dev || !out || cap < 1 || world < 1 || world != m->cfg.n_shards || world > SHELL_MAX_SHARDS) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = ensure_mesh_jobs(m, m->view.max_chunks);
+    if (rc) return rc;
+    if (m->input_event) {
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    int jobset_capacity = std::max(m->shell_plan.jobset_capacity, 1 << 15), send_capacity = std::max(m->shell_plan.send_capacity, 1 << 15);
+    for (int attempt = 0;; attempt++) {
+        rc = ensure_shell_plan(m, jobset_capacity, send_capacity);
+        if (rc) return rc;
+        ShellPlan &S = m->shell_plan;
+        if (!S.my_jobs || S.max_jobs < m->mesh_buf.capacity) {
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (S.my_jobs) HIP_TRY(hipFree(S.my_jobs));
+            S.my_jobs = nullptr;
+            HIP_TRY(hipMalloc(&S.my_jobs, (size_t)m->mesh_buf.capacity * 3 * sizeof(int)));
+            S.max_jobs = m->mesh_buf.capacity;
+        }
+        HIP_TRY(hipMemsetAsync(S.jobset, 0xff, (size_t)S.jobset_capacity * sizeof(unsigned long long), m->stream));
+        HIP_TRY(hipMemsetAsync(S.ctl, 0, (16 + 4 * SHELL_MAX_SHARDS) * sizeof(int), m->stream));
+        const long long threads = 27ll * cap * world;
+        hipLaunchKernelGGL(shell_jobs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, gathered_dev, world, cap, S, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
+        hipLaunchKernelGGL(shell_items_kernel, dim3((unsigned)(S.jobset_capacity / 8)), dim3(256), 0, m->stream, S, m->N, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(m->shell_plan_host_dev, S.ctl, (16 + 4 * SHELL_MAX_SHARDS + 4) * sizeof(int), hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(wait_stream_spinning(m->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const int *h = m->shell_plan_host;
+        if (h[2] > cap) {  // the gathered list itself was cut off: the caller's turn
+            out[0] = out[1] = out[3] = 0;
+            out[2] = h[2];
+            return CHISEL_HIP_OK;
+        }
+        if (h[1] == 0 && h[3] <= S.send_capacity) break;
+        if (attempt == 8) return fail(CHISEL_HIP_ERR_POOL_FULL, "sharded mesh plan: job set / job list / item list overflow after growing them (raise chisel_hip_config.max_chunks)");
+        jobset_capacity = 2 * S.jobset_capacity;
+        send_capacity = std::max(2 * S.send_capacity, 2 * h[3]);
+    }
+    const int *h = m->shell_plan_host;
+    const unsigned long long *cur = reinterpret_cast<const unsigned long long *>(h + 16);
+    m->shell_jobs = h[0];
+    m->shell_send_items = h[3];
+    out[0] = h[0]; out[2] = h[2]; out[3] = h[3];
+    out[1] = (int64_t)*reinterpret_cast<const unsigned long long *>(h + 16 + 4 * SHELL_MAX_SHARDS);  // ghost chunks the earlier recomputes created (for the record)
+    for (int p = 0; p < world; p++) {
+        m->shell_send[p][0] = out[4 + 2 * p] = (int64_t)(cur[p] & 0xffffffffull);
+        m->shell_send[p][1] = out[5 + 2 * p] = (int64_t)(cur[p] >> 32);
+        m->shell_recv[p][0] = out[4 + 2 * world + 2 * p] = (int64_t)(cur[SHELL_MAX_SHARDS + p] & 0xffffffffull);
+        m->shell_recv[p][1] = out[5 + 2 * world + 2 * p] = (int64_t)(cur[SHELL_MAX_SHARDS + p] >> 32);
+    }
+    return CHISEL_HIP_OK;
+}
+// bytes of the segment that carries `items` shell items with `voxels` voxels between two shards of this map (kernels_map.h)
+int64_t chisel_hip_shell_segment_bytes(chisel_hip_map *m, int64_t items, int64_t voxels) {
+    if (!m) return -1;
+    const chisel_hip_map *s = m->is_group ? m->shards[0] : m;
+    return (int64_t)shell_segment_bytes(items, voxels, s->view.rgbw != nullptr);
+}
+// Step 3, owner side: the segments of the latest plan -- one per peer, in rank order, back to back -- into `out_dev` (`bytes` = their
+// sum: checked).  Nothing is waited for (chisel_hip_record_event orders the collective behind it).
+int chisel_hip_export_shells_packed(chisel_hip_map *m, void *out_dev, int64_t bytes) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || (bytes > 0 && !out_dev)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int64_t want = 0;
+    for (int p = 0; p < m->cfg.n_shards; p++) want += (int64_t)shell_segment_bytes(m->shell_send[p][0], m->shell_send[p][1], m->view.rgbw != nullptr);
+    if (want != bytes) return fail(CHISEL_HIP_ERR_INVALID, "chisel_hip_export_shells_packed: the buffer is not the size the plan gives");
+    {
+        int rc_m = check_mesh_totals(m);
+        if (rc_m) return rc_m;
+    }
+    if (m->input_event) {
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    hipLaunchKernelGGL(shell_export_kernel, dim3((unsigned)std::max(1, m->shell_send_items)), dim3(256), 0, m->stream, m->view, m->shell_plan, m->N, m->cfg.n_shards,
+                       static_cast<unsigned char *>(out_dev));
+    HIP_TRY(hipGetLastError());
+    return CHISEL_HIP_OK;
+}
+// Step 4, requester side: the received segments (one per owner, in rank order, back to back: what the all-to-all of the exported
+// buffers leaves) become ghost chunks.  The buffer must stay as it is until chisel_hip_drop_ghost_chunks has been queued (the ghosts are
+// dropped by the ids it holds).  A buffer that is ready behind an event: chisel_hip_wait_event first.
+int chisel_hip_import_shells_packed(chisel_hip_map *m, const void *in_dev, int64_t bytes) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || (bytes > 0 && !in_dev)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    ShellSegments G;
+    memset(&G, 0, sizeof(G));
+    int64_t off = 0;
+    int items = 0;
+    for (int p = 0; p < m->cfg.n_shards; p++) {
+        G.off[p] = off;
+        G.first_item[p] = items;
+        off += (int64_t)shell_segment_bytes(m->shell_recv[p][0], m->shell_recv[p][1], m->view.rgbw != nullptr);
+        items += (int)m->shell_recv[p][0];
+    }
+    G.off[m->cfg.n_shards] = off;
+    G.first_item[m->cfg.n_shards] = items;
+    if (off != bytes) return fail(CHISEL_HIP_ERR_INVALID, "chisel_hip_import_shells_packed: the buffer is not the size the plan gives");
+    m->topology_epoch++;
+    int rc = check_mesh_totals(m);
+    if (rc) return rc;
+    if (m->input_event) {
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    if (items > 0) {
+        const unsigned char *in = static_cast<const unsigned char *>(in_dev);
+        hipLaunchKernelGGL(shell_ensure_ghosts_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, m->stream, m->view, in, G, m->cfg.n_shards, items,
+                           reinterpret_cast<unsigned long long *>(m->shell_plan.ctl + 16 + 4 * SHELL_MAX_SHARDS));
+        hipLaunchKernelGGL(shell_import_kernel, dim3((unsigned)items), dim3(256), 0, m->stream, m->view, in, G, m->cfg.n_shards, m->N);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(note_map_mutation(m));
+        m->ghost_packed = in;
+        m->ghost_segments = G;
+        m->ghost_packed_items = items;
+    }
     return CHISEL_HIP_OK;
 }
 

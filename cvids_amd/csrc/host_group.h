@@ -72,20 +72,20 @@ struct Pool {
         }
     }
 };
-// a staging buffer of update_meshes (four arrays, grow-only, reused by every recompute) with the events that guard it
-struct PairStage {
-    float *sdf[2] = {nullptr, nullptr}, *wgt[2] = {nullptr, nullptr};   // [0] on the owner's device, [1] on the meshing shard's (other device only)
-    uint8_t *rgbw[2] = {nullptr, nullptr};
-    int *found[2] = {nullptr, nullptr};
-    long long cap_vox[2] = {0, 0};
-    int cap_items[2] = {0, 0};
-    hipEvent_t exported = nullptr, copied = nullptr, imported = nullptr;
-    bool armed = false;
+// what a shard keeps for the group's recomputes (all on its own device, grow-only, reused by every recompute) with the events that
+// order the steps between the shards' streams: the gathered list of updated chunks, the segments it sends and the segments it receives
+struct MeshStage {
+    int *gathered = nullptr;                   // [W][1 + 4 * cap] ints: every shard's dirty list (its own block is written by its own kernel)
+    int cap = 0;
+    unsigned char *send = nullptr, *recv = nullptr;
+    long long send_cap = 0, recv_cap = 0;
+    hipEvent_t listed = nullptr, gathered_ev = nullptr, exported = nullptr, copied = nullptr, imported = nullptr;
+    bool armed = false;                        // `copied` / `imported` have been recorded at least once
 };
 struct MeshStages {
-    std::vector<PairStage> out;                // [o]: what owner o packs for ALL requesters, requester by requester (side 0, o's device; `exported`)
-    std::vector<PairStage> in;                 // [r]: what meshing shard r installs, owner by owner (side 0, r's device; `copied`, `imported`)
-    std::vector<hipStream_t> copy;             // [r]: the copies that assemble in[r] from the owners' out[o]
+    std::vector<MeshStage> of;                 // [shard]
+    std::vector<hipStream_t> copy;             // [r]: the peer copies that bring the other shards' lists and segments to shard r
+    int cap = 1 << 12;                         // entries per shard in the gathered list (doubled when a shard has more)
 };
 
 inline int n_shards(const chisel_hip_map *g) { return (int)g->shards.size(); }
@@ -156,8 +156,7 @@ int create(const chisel_hip_config *cfg, const int *device_ids, int n, chisel_hi
             for (int i = 1; i < n; i++) P->workers.emplace_back([P, i] { P->loop(i); });
         g->pool = P;
         MeshStages *MS = new MeshStages();
-        MS->out.resize((size_t)n);
-        MS->in.resize((size_t)n);
+        MS->of.resize((size_t)n);
         MS->copy.assign((size_t)n, nullptr);
         g->mesh_stages_group = MS;
     }
@@ -190,18 +189,14 @@ int destroy(chisel_hip_map *g) {
     if (MeshStages *MS = static_cast<MeshStages *>(g->mesh_stages_group)) {
         for (chisel_hip_map *sh : g->shards) (void)chisel_hip_synchronize(sh);
         const int W = n_shards(g);
-        for (int side = 0; side < 2; side++)
-            for (int i = 0; i < W; i++) {
-                PairStage &S = side ? MS->in[(size_t)i] : MS->out[(size_t)i];
-                (void)hipSetDevice(g->shards[(size_t)i]->device);
-                if (S.sdf[0]) (void)hipFree(S.sdf[0]);
-                if (S.wgt[0]) (void)hipFree(S.wgt[0]);
-                if (S.rgbw[0]) (void)hipFree(S.rgbw[0]);
-                if (S.found[0]) (void)hipFree(S.found[0]);
-                if (S.exported) (void)hipEventDestroy(S.exported);
-                if (S.copied) (void)hipEventDestroy(S.copied);
-                if (S.imported) (void)hipEventDestroy(S.imported);
-            }
+        for (int i = 0; i < W; i++) {
+            MeshStage &S = MS->of[(size_t)i];
+            (void)hipSetDevice(g->shards[(size_t)i]->device);
+            for (void *p : {(void *)S.gathered, (void *)S.send, (void *)S.recv})
+                if (p) (void)hipFree(p);
+            for (hipEvent_t e : {S.listed, S.gathered_ev, S.exported, S.copied, S.imported})
+                if (e) (void)hipEventDestroy(e);
+        }
         for (int r = 0; r < W; r++)
             if (MS->copy[(size_t)r]) {
                 (void)hipSetDevice(g->shards[r]->device);
@@ -415,39 +410,15 @@ int emit_ids(const std::vector<int> &all, int *ids, int64_t max_ids, int64_t *co
     return CHISEL_HIP_OK;
 }
 
-// Chisel::UpdateMeshes of the group: cvids_amd/sharded.py: ShardedChisel.UpdateMeshes, with direct calls for the collectives.
-// Three fan-outs over the shards, nothing allocated and no stream waited for once the staging buffers have their size:
-//   A  every shard lists its meshesToUpdate (one host read per shard, concurrently); the union is the plan's input, the plan of every
-//      shard (its jobs; per owner the shells it needs) is pure host arithmetic;
-//   B  every OWNER packs, for every shard that asked, the shells into that pair's staging buffer on its own device and records the
-//      pair's `exported` event on its stream;
-//   C  every MESHING shard waits (on its stream, not on the host) for its owners' events -- with a peer copy on a copy stream in between
-//      when the owner lives on another device --, installs the ghosts, recomputes its jobs, drops the ghosts and records `imported`,
-//      behind which the owner's next export into the same buffer is ordered.
-int ensure_pair(chisel_hip_map *g, PairStage &S, int side, int device, long long vox, int n_items, bool color) {
-    if (vox <= S.cap_vox[side] && n_items <= S.cap_items[side]) return CHISEL_HIP_OK;
-    HIP_TRY(hipSetDevice(device));
-    // (the buffers may still be read by the previous recompute's import / copy: wait for that pair only)
-    if (S.armed && S.imported) HIP_TRY(hipEventSynchronize(S.imported));
-    if (S.sdf[side]) HIP_TRY(hipFree(S.sdf[side]));
-    if (S.wgt[side]) HIP_TRY(hipFree(S.wgt[side]));
-    if (S.rgbw[side]) HIP_TRY(hipFree(S.rgbw[side]));
-    if (S.found[side]) HIP_TRY(hipFree(S.found[side]));
-    S.sdf[side] = S.wgt[side] = nullptr;
-    S.rgbw[side] = nullptr;
-    S.found[side] = nullptr;
-    const long long cv = std::max<long long>(vox + vox / 2, 1 << 16);
-    const int ci = std::max(n_items + n_items / 2, 1024);
-    HIP_TRY(hipMalloc(&S.sdf[side], (size_t)cv * sizeof(float)));
-    HIP_TRY(hipMalloc(&S.wgt[side], (size_t)cv * sizeof(float)));
-    if (color) HIP_TRY(hipMalloc(&S.rgbw[side], (size_t)cv * 4));
-    HIP_TRY(hipMalloc(&S.found[side], (size_t)ci * sizeof(int)));
-    S.cap_vox[side] = cv;
-    S.cap_items[side] = ci;
-    (void)g;
-    return CHISEL_HIP_OK;
-}
-
+// Chisel::UpdateMeshes of the group: the protocol of cvids_amd/sharded.py: ShardedChisel.UpdateMeshes -- planned on the device
+// (kernels_map.h: ShellPlan) -- with peer copies between the shards' devices where the multi-process form has its two collectives.
+// Four fan-outs over the shards (one issuing thread each); the only host wait of a shard is the one inside its plan call:
+//   A  every shard lists its updated chunks into its block of its gathered list (chisel_hip_dirty_ids_device) and records `listed`;
+//   B  every shard copies the other shards' blocks into its own list (its copy stream, behind their `listed` events) and plans:
+//      its jobs, the segments it owes every other shard, how much every owner owes it (chisel_hip_shell_plan_device);
+//   C  every OWNER packs its segments (chisel_hip_export_shells_packed) and records `exported`;
+//   D  every MESHING shard copies its segments out of the owners' buffers (behind their `exported`), installs the ghosts, recomputes
+//      its jobs, drops the ghosts and records `imported`, behind which the next recompute's copies into the same buffer are ordered.
 int update_meshes(chisel_hip_map *g, int force) {
     if (!force && (g->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;  // Chisel.cpp:53-58: every 10th call
     const int W = n_shards(g);
@@ -462,163 +433,146 @@ int update_meshes(chisel_hip_map *g, int force) {
         t_phase[i] += std::chrono::duration<double, std::micro>(n - t_prev).count();
         t_prev = n;
     };
-    // ---- A: what the shards have updated since the last recompute, as the planner's entries: (x, y, z, 0) per dirty chunk -- the planner
-    // expands the 27-neighbourhoods itself (Chisel.h:175-189), on its grid, cheaper than a host set per shard -- and (x, y, z, 1) per
-    // id the host holds (neighbourhoods of chunks that were removed while dirty).  Duplicates are the planner's business.
-    std::vector<std::vector<int>> part((size_t)W);
-    int rc = run_shards(g, [&](int i) -> int {
-        chisel_hip_map *sh = g->shards[(size_t)i];
-        HIP_TRY(hipSetDevice(sh->device));
-        int rc2 = check_mesh_totals(sh);
-        if (rc2) return rc2;
-        std::vector<int> dirty;
-        rc2 = fetch_listed(sh, true, dirty, nullptr);
-        if (rc2) return rc2;
-        std::vector<int> &e = part[(size_t)i];
-        e.reserve(dirty.size() / 3 * 4 + sh->pending_mesh_ids.size() * 4);
-        for (size_t j = 0; j + 2 < dirty.size(); j += 3) {
-            e.insert(e.end(), dirty.begin() + j, dirty.begin() + j + 3);
-            e.push_back(0);
-        }
-        for (uint64_t key : sh->pending_mesh_ids) {
-            int x, y, z;
-            unpack_id(key, x, y, z);
-            e.push_back(x); e.push_back(y); e.push_back(z); e.push_back(1);
-        }
-        return CHISEL_HIP_OK;
-    });
-    if (rc) return rc;
-    std::vector<int> entries;
-    for (const std::vector<int> &e : part) entries.insert(entries.end(), e.begin(), e.end());
-    lap(0);
     const bool color = g->cfg.use_color != 0;
-    struct Ask {            // what shard r needs of owner o
-        std::vector<int> it4;
-        long long vox = 0;
-    };
-    std::vector<std::vector<int>> jobs((size_t)W);
-    std::vector<Ask> ask((size_t)W * W);
-    {
-        // the plans of all shards in one pass (chisel_hip_mesh_shell_plan_all)
-        std::vector<int64_t> jo((size_t)W + 1), io((size_t)W * W + 1);
-        rc = chisel_hip_mesh_shell_plan_all(entries.data(), (int64_t)entries.size() / 4, W, g->cfg.shard_block, nullptr, 0, jo.data(), nullptr, 0, io.data());
-        if (rc) return rc;
-        std::vector<int> jflat((size_t)jo[(size_t)W] * 3 + 1), iflat((size_t)io[(size_t)W * W] * 4 + 1);
-        rc = chisel_hip_mesh_shell_plan_all(entries.data(), (int64_t)entries.size() / 4, W, g->cfg.shard_block, jflat.data(), jo[(size_t)W], jo.data(), iflat.data(),
-                                            io[(size_t)W * W], io.data());
-        if (rc) return rc;
-        for (int r = 0; r < W; r++) jobs[(size_t)r].assign(jflat.begin() + 3 * jo[(size_t)r], jflat.begin() + 3 * jo[(size_t)r + 1]);
-        for (int p2 = 0; p2 < W * W; p2++) {
-            Ask &A = ask[(size_t)p2];
-            A.it4.assign(iflat.begin() + 4 * io[(size_t)p2], iflat.begin() + 4 * io[(size_t)p2 + 1]);
-            for (size_t k = 3; k < A.it4.size(); k += 4) A.vox += shell_volume(A.it4[k], g->N);
-        }
-    }
-    lap(1);
-    // what goes where: owner o packs requester by requester, meshing shard r installs owner by owner
-    std::vector<long long> vox_out((size_t)W, 0), vox_in((size_t)W, 0);
-    std::vector<int> n_out((size_t)W, 0), n_in((size_t)W, 0);
-    std::vector<long long> voff_out((size_t)W * W, 0), voff_in((size_t)W * W, 0);   // [r * W + o]: where pair (r, o) starts in out[o] / in[r] (voxels)
-    std::vector<int> noff_out((size_t)W * W, 0), noff_in((size_t)W * W, 0);         // ... (items)
-    for (int o = 0; o < W; o++)
-        for (int r = 0; r < W; r++) {
-            const Ask &A = ask[(size_t)r * W + o];
-            voff_out[(size_t)r * W + o] = vox_out[(size_t)o];
-            noff_out[(size_t)r * W + o] = n_out[(size_t)o];
-            vox_out[(size_t)o] += A.vox;
-            n_out[(size_t)o] += (int)(A.it4.size() / 4);
-        }
-    for (int r = 0; r < W; r++)
-        for (int o = 0; o < W; o++) {
-            const Ask &A = ask[(size_t)r * W + o];
-            voff_in[(size_t)r * W + o] = vox_in[(size_t)r];
-            noff_in[(size_t)r * W + o] = n_in[(size_t)r];
-            vox_in[(size_t)r] += A.vox;
-            n_in[(size_t)r] += (int)(A.it4.size() / 4);
-        }
-    auto make_events = [](PairStage &S) -> int {
-        if (S.exported) return CHISEL_HIP_OK;
-        HIP_TRY(hipEventCreateWithFlags(&S.exported, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&S.imported, hipEventDisableTiming));
+    auto make_events = [](MeshStage &S) -> int {
+        if (S.listed) return CHISEL_HIP_OK;
+        for (hipEvent_t *e : {&S.listed, &S.gathered_ev, &S.exported, &S.copied, &S.imported}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         return CHISEL_HIP_OK;
     };
-    // ---- B: every owner packs the shells of ALL requesters with one call (2 W export / import calls per recompute, not 2 W^2)
-    rc = run_shards(g, [&](int o) -> int {
+    std::vector<std::array<int64_t, 4 + 4 * SHELL_MAX_SHARDS>> plan((size_t)W);
+    for (;;) {
+        const int cap = MS.cap, blk = 1 + 4 * cap;
+        // ---- A
+        int rc = run_shards(g, [&](int i) -> int {
+            chisel_hip_map *sh = g->shards[(size_t)i];
+            MeshStage &S = MS.of[(size_t)i];
+            HIP_TRY(hipSetDevice(sh->device));
+            int rc2 = make_events(S);
+            if (rc2) return rc2;
+            if (!MS.copy[(size_t)i]) HIP_TRY(hipStreamCreateWithFlags(&MS.copy[(size_t)i], hipStreamNonBlocking));
+            if (S.cap < cap) {
+                rc2 = chisel_hip_synchronize(sh);  // (the previous recompute's plan kernels have read the old list; the other shards' copies out of it too: below)
+                if (rc2) return rc2;
+                for (int r = 0; r < W; r++)
+                    if (MS.copy[(size_t)r]) {
+                        HIP_TRY(hipSetDevice(g->shards[(size_t)r]->device));
+                        HIP_TRY(hipStreamSynchronize(MS.copy[(size_t)r]));
+                    }
+                HIP_TRY(hipSetDevice(sh->device));
+                if (S.gathered) HIP_TRY(hipFree(S.gathered));
+                S.gathered = nullptr;
+                HIP_TRY(hipMalloc(&S.gathered, (size_t)W * blk * sizeof(int)));
+                S.cap = cap;
+            }
+            rc2 = chisel_hip_dirty_ids_device(sh, S.gathered + (size_t)i * blk, cap);
+            if (rc2) return rc2;
+            return chisel_hip_record_event(sh, S.listed);
+        });
+        if (rc) return rc;
+        lap(0);
+        // ---- B
+        rc = run_shards(g, [&](int r) -> int {
+            chisel_hip_map *sh = g->shards[(size_t)r];
+            MeshStage &S = MS.of[(size_t)r];
+            HIP_TRY(hipSetDevice(sh->device));
+            hipStream_t cs = MS.copy[(size_t)r];
+            for (int o = 0; o < W; o++) {
+                if (o == r) continue;
+                HIP_TRY(hipStreamWaitEvent(cs, MS.of[(size_t)o].listed, 0));
+                HIP_TRY(hipMemcpyPeerAsync(S.gathered + (size_t)o * blk, sh->device, MS.of[(size_t)o].gathered + (size_t)o * blk, g->shards[(size_t)o]->device, (size_t)blk * sizeof(int), cs));
+            }
+            HIP_TRY(hipEventRecord(S.gathered_ev, cs));
+            int rc2 = chisel_hip_wait_event(sh, S.gathered_ev);
+            if (rc2) return rc2;
+            return chisel_hip_shell_plan_device(sh, S.gathered, W, cap, plan[(size_t)r].data());
+        });
+        if (rc) return rc;
+        lap(1);
+        int64_t mx = 0;
+        for (int r = 0; r < W; r++) mx = std::max(mx, plan[(size_t)r][2]);
+        if (mx <= cap) break;
+        MS.cap = (int)std::min<int64_t>(2 * mx, 1 << 26);  // a shard had more entries than a block holds: gather again with room for them
+    }
+    // where the segment of pair (owner o -> meshing shard r) lies in send[o] and in recv[r]: bytes from the plans' counts (what o plans
+    // to send r is what r plans to receive from o: the same enumeration from both sides)
+    auto seg = [&](int o, int r) { return (long long)shell_segment_bytes(plan[(size_t)o][4 + 2 * r], plan[(size_t)o][5 + 2 * r], color); };
+    for (int o = 0; o < W; o++)
+        for (int r = 0; r < W; r++)
+            if (plan[(size_t)o][4 + 2 * r] != plan[(size_t)r][4 + 2 * W + 2 * o] || plan[(size_t)o][5 + 2 * r] != plan[(size_t)r][5 + 2 * W + 2 * o])
+                return fail(CHISEL_HIP_ERR_HIP, "group recompute: two shards' plans disagree on a segment");
+    // ---- C
+    int rc = run_shards(g, [&](int o) -> int {
         chisel_hip_map *src = g->shards[(size_t)o];
-        if (n_out[(size_t)o] == 0) return CHISEL_HIP_OK;
-        PairStage &S = MS.out[(size_t)o];
-        if (vox_out[(size_t)o] > S.cap_vox[0] || n_out[(size_t)o] > S.cap_items[0])  // (about to be reallocated: its readers are the meshing shards' copies)
-            for (int r = 0; r < W; r++)
-                if (MS.in[(size_t)r].armed) HIP_TRY(hipEventSynchronize(MS.in[(size_t)r].copied));
-        int rc2 = ensure_pair(g, S, 0, src->device, vox_out[(size_t)o], n_out[(size_t)o], color);
-        if (rc2) return rc2;
+        MeshStage &S = MS.of[(size_t)o];
         HIP_TRY(hipSetDevice(src->device));
-        rc2 = make_events(S);
-        if (rc2) return rc2;
-        std::vector<int> items;
-        items.reserve((size_t)n_out[(size_t)o] * 4);
-        for (int r = 0; r < W; r++) {
-            const Ask &A = ask[(size_t)r * W + o];
-            items.insert(items.end(), A.it4.begin(), A.it4.end());
-            // the previous recompute's readers of this buffer: the copies of every meshing shard
-            if (MS.in[(size_t)r].armed) HIP_TRY(hipStreamWaitEvent(src->stream, MS.in[(size_t)r].copied, 0));
+        long long bytes = 0;
+        for (int r = 0; r < W; r++) bytes += seg(o, r);
+        // the previous recompute's readers of this buffer: the copies of every meshing shard
+        for (int r = 0; r < W; r++)
+            if (MS.of[(size_t)r].armed) {
+                if (bytes > S.send_cap) HIP_TRY(hipEventSynchronize(MS.of[(size_t)r].copied));
+                else HIP_TRY(hipStreamWaitEvent(src->stream, MS.of[(size_t)r].copied, 0));
+            }
+        if (bytes > S.send_cap) {
+            if (S.send) HIP_TRY(hipFree(S.send));
+            S.send = nullptr;
+            S.send_cap = std::max<long long>(bytes + bytes / 2, 1 << 20);
+            HIP_TRY(hipMalloc(&S.send, (size_t)S.send_cap));
         }
-        rc2 = chisel_hip_export_shells(src, items.data(), n_out[(size_t)o], S.sdf[0], S.wgt[0], S.rgbw[0], S.found[0], 1);
+        int rc2 = chisel_hip_export_shells_packed(src, S.send, bytes);
         if (rc2) return rc2;
         return chisel_hip_record_event(src, S.exported);
     });
     if (rc) return rc;
     lap(2);
-    // ---- C: every meshing shard assembles its payload from the owners' buffers (copies on its copy stream, behind the owners'
-    // events), installs the ghosts with one call, recomputes its jobs, drops the ghosts
+    // ---- D
     std::vector<uint64_t> moved((size_t)W, 0);
     rc = run_shards(g, [&](int r) -> int {
         chisel_hip_map *dst = g->shards[(size_t)r];
-        if (n_in[(size_t)r] > 0) {
-            PairStage &S = MS.in[(size_t)r];
-            int rc2 = ensure_pair(g, S, 0, dst->device, vox_in[(size_t)r], n_in[(size_t)r], color);
+        MeshStage &S = MS.of[(size_t)r];
+        HIP_TRY(hipSetDevice(dst->device));
+        long long bytes = 0;
+        for (int o = 0; o < W; o++) bytes += seg(o, r);
+        hipStream_t cs = MS.copy[(size_t)r];
+        if (bytes > S.recv_cap) {
+            if (S.armed) HIP_TRY(hipEventSynchronize(S.imported));
+            int rc2 = chisel_hip_synchronize(dst);  // (the previous recompute's drop kernel reads the old buffer)
             if (rc2) return rc2;
-            HIP_TRY(hipSetDevice(dst->device));
-            rc2 = make_events(S);
-            if (rc2) return rc2;
-            hipStream_t &cs = MS.copy[(size_t)r];
-            if (!cs) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-            if (S.armed) HIP_TRY(hipStreamWaitEvent(cs, S.imported, 0));  // the previous recompute's import has read the buffer
-            std::vector<int> items;
-            items.reserve((size_t)n_in[(size_t)r] * 4);
-            for (int o = 0; o < W; o++) {
-                const Ask &A = ask[(size_t)r * W + o];
-                if (A.it4.empty()) continue;
-                items.insert(items.end(), A.it4.begin(), A.it4.end());
-                const PairStage &O = MS.out[(size_t)o];
-                chisel_hip_map *src = g->shards[(size_t)o];
-                const long long vo = voff_out[(size_t)r * W + o], vi = voff_in[(size_t)r * W + o];
-                const int no = noff_out[(size_t)r * W + o], ni = noff_in[(size_t)r * W + o], n = (int)(A.it4.size() / 4);
-                HIP_TRY(hipStreamWaitEvent(cs, O.exported, 0));
-                HIP_TRY(hipMemcpyPeerAsync(S.sdf[0] + vi, dst->device, O.sdf[0] + vo, src->device, (size_t)A.vox * sizeof(float), cs));
-                HIP_TRY(hipMemcpyPeerAsync(S.wgt[0] + vi, dst->device, O.wgt[0] + vo, src->device, (size_t)A.vox * sizeof(float), cs));
-                HIP_TRY(hipMemcpyPeerAsync(S.found[0] + ni, dst->device, O.found[0] + no, src->device, (size_t)n * sizeof(int), cs));
-                if (color) HIP_TRY(hipMemcpyPeerAsync(S.rgbw[0] + 4 * vi, dst->device, O.rgbw[0] + 4 * vo, src->device, (size_t)A.vox * 4, cs));
-                moved[(size_t)r] += (uint64_t)A.vox * (color ? 12 : 8);
-            }
-            HIP_TRY(hipEventRecord(S.copied, cs));
-            rc2 = chisel_hip_wait_event(dst, S.copied);
-            if (rc2) return rc2;
-            rc2 = chisel_hip_import_ghost_shells(dst, items.data(), n_in[(size_t)r], S.sdf[0], S.wgt[0], S.rgbw[0], S.found[0], 1);
-            if (rc2) return rc2;
-            rc2 = chisel_hip_record_event(dst, S.imported);
-            if (rc2) return rc2;
-            S.armed = true;
+            if (S.recv) HIP_TRY(hipFree(S.recv));
+            S.recv = nullptr;
+            S.recv_cap = std::max<long long>(bytes + bytes / 2, 1 << 20);
+            HIP_TRY(hipMalloc(&S.recv, (size_t)S.recv_cap));
+        } else if (S.armed) {
+            HIP_TRY(hipStreamWaitEvent(cs, S.imported, 0));  // the previous recompute's import and drop have read the buffer
         }
-        int rc2 = chisel_hip_update_meshes_of(dst, jobs[(size_t)r].data(), (int)(jobs[(size_t)r].size() / 3));
+        long long at = 0;
+        for (int o = 0; o < W; o++) {
+            const long long n = seg(o, r);
+            long long from = 0;
+            for (int q = 0; q < r; q++) from += seg(o, q);
+            HIP_TRY(hipStreamWaitEvent(cs, MS.of[(size_t)o].exported, 0));
+            HIP_TRY(hipMemcpyPeerAsync(S.recv + at, dst->device, MS.of[(size_t)o].send + from, g->shards[(size_t)o]->device, (size_t)n, cs));
+            at += n;
+            moved[(size_t)r] += (uint64_t)plan[(size_t)r][5 + 2 * W + 2 * o] * (color ? 12 : 8);
+        }
+        HIP_TRY(hipEventRecord(S.copied, cs));
+        int rc2 = chisel_hip_wait_event(dst, S.copied);
         if (rc2) return rc2;
-        return chisel_hip_drop_ghost_chunks(dst);
+        rc2 = chisel_hip_import_shells_packed(dst, S.recv, bytes);
+        if (rc2) return rc2;
+        rc2 = chisel_hip_update_meshes_planned(dst);
+        if (rc2) return rc2;
+        rc2 = chisel_hip_drop_ghost_chunks(dst);
+        if (rc2) return rc2;
+        rc2 = chisel_hip_record_event(dst, S.imported);
+        if (rc2) return rc2;
+        S.armed = true;
+        return CHISEL_HIP_OK;
     });
     lap(3);
     if (timing)
-        fprintf(stderr, "chisel_hip group recompute, host us: dirty lists %.0f | plan %.0f | exports %.0f | copies + imports + recompute + drop %.0f (%zu entries)\n",
-                t_phase[0], t_phase[1], t_phase[2], t_phase[3], entries.size() / 4);
+        fprintf(stderr, "chisel_hip group recompute, host us: dirty lists %.0f | list copies + plan (device) + wait %.0f | exports %.0f | copies + imports + recompute + drop %.0f\n",
+                t_phase[0], t_phase[1], t_phase[2], t_phase[3]);
     for (uint64_t v : moved) g->ghost_bytes += v;
     return rc;
 }

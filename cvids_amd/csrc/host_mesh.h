@@ -79,6 +79,7 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
     if (rc) return rc;
     int *n_jobs = mesh_totals(m) + MC_KEPT;
     B.n_jobs = n_jobs;
+    B.ext_ids = nullptr;
     if (m->mesh_mark_needed) {
         hipLaunchKernelGGL(mesh_mark_kernel, dim3(1024), dim3(256), 0, m->stream, m->view, B.flags, m->view.mesh_jobs, n_jobs);
         m->mesh_mark_needed = false;
@@ -170,9 +171,9 @@ void give_up_job_list(chisel_hip_map *m) {
 void launch_mesh_count(chisel_hip_map *m) {
     MeshBuffers &B = m->mesh_buf;
     int *d_totals = mesh_totals(m);
-    int *n_jobs = B.n_jobs ? B.n_jobs : d_totals + MT_JOBS;  // the kept job list's counter, or the count a caller put into the totals
-    const int *ids = B.n_jobs ? m->view.mesh_jobs : B.ids;   // ... and its entries, or the caller's ids
-    const int ids_capacity = B.n_jobs ? m->view.mesh_jobs_capacity : B.capacity;
+    int *n_jobs = B.ext_ids ? B.ext_n : (B.n_jobs ? B.n_jobs : d_totals + MT_JOBS);  // a plan's job count, the kept job list's counter, or the count a caller put into the totals
+    const int *ids = B.ext_ids ? B.ext_ids : (B.n_jobs ? m->view.mesh_jobs : B.ids);   // ... and the entries that go with it
+    const int ids_capacity = B.ext_ids ? B.ext_capacity : (B.n_jobs ? m->view.mesh_jobs_capacity : B.capacity);
     ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
     // one single-wave workgroup per (job, sub-job): the number of jobs is only known on the device, so the grid is sized from what the
     // previous recompute had (+ 1/4) -- a shortfall is made up by the workgroups taking a second unit, surplus ones leave at once
@@ -527,6 +528,7 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
     if (rc) return rc;
     const int totals[4] = {0, 0, 0, n};
     B.n_jobs = nullptr;  // the count is the one written here
+    B.ext_ids = nullptr;
     HIP_TRY(hipMemcpyAsync(mesh_totals(m), totals, sizeof(totals), hipMemcpyHostToDevice, m->stream));
     HIP_TRY(hipMemsetAsync(mesh_totals(m) + MC_CURSORS, 0, 2 * MESH_PARTS * sizeof(int), m->stream));
     m->mesh_jobs_hint = n;
@@ -536,6 +538,31 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
     rc = recompute_meshes(m);
     if (rc) return rc;
     if (!m->mesh_detached) m->pending_mesh_ids.clear();
+    return CHISEL_HIP_OK;
+}
+
+// Step 5 of a sharded recompute: the jobs of the latest plan (chisel_hip_shell_plan_device) -- a list that never left the device.
+int chisel_hip_update_meshes_planned(chisel_hip_map *m) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
+    if (!m || !m->shell_plan.my_jobs) return fail(CHISEL_HIP_ERR_INVALID, "no plan: chisel_hip_shell_plan_device first");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = resolve_pending_meshes(m);  // the device buffers of the previous recompute are about to be reused
+    if (rc) return rc;
+    MeshBuffers &B = m->mesh_buf;
+    rc = ensure_mesh_jobs(m, m->view.max_chunks);
+    if (rc) return rc;
+    B.n_jobs = nullptr;
+    B.ext_ids = m->shell_plan.my_jobs;
+    B.ext_n = m->shell_plan.ctl;
+    B.ext_capacity = m->shell_plan.max_jobs;
+    HIP_TRY(zero_mesh_counters(m));
+    m->mesh_totals_clean = false;
+    m->mesh_jobs_hint = m->shell_jobs;
+    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    HIP_TRY(hipGetLastError());
+    rc = recompute_meshes(m);
+    if (rc) return rc;
+    m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;
 }
 

@@ -457,6 +457,285 @@ __global__ __launch_bounds__(256) void import_shells_kernel(MapView M, const int
         if (M.rgbw) M.rgbw[i] = rgbw ? rgbw[base + v] : make_uchar4(0, 0, 0, 0);
     }
 }
+// ---- the plan of a sharded recompute ON THE DEVICE (round 5) -----------------------------------------------------------------------
+// Rounds 3-4 planned on the host (chisel_hip_mesh_shell_plan[_all]: 0.4-1.1 ms per recompute and rank, against ~0.1 ms of GPU work per
+// step).  Here every rank derives, from the all-gathered list of updated chunks alone and without leaving the device:
+//   * its own jobs (the 27-neighbourhoods of the updated chunks, de-duplicated in a hash set; those it owns);
+//   * the shells it must SEND: for every job J of another rank r and every neighbour G = J + d that this rank owns, the box of G that J
+//     reads (box code of d: shell_len above) -- one item per (J, d), no merging of boxes (a face box contains the edge and corner boxes
+//     its neighbours ask for: ~20 % more voxels travel, and nobody has to agree on a merge order);
+//   * how much it will RECEIVE from every owner (the same enumeration, counted from the other side).
+// One small device-to-host copy -- per peer (items, voxels) to send and to receive, the job count -- is the only host wait of a sharded
+// recompute.  What travels is a byte SEGMENT per (sender, receiver):
+//     int32 head[4] = {items, voxels, 0, 0};  int32 item[items][8] = {x, y, z, box, found, first voxel, 0, 0};
+//     float sdf[voxels];  float weight[voxels];  [uint32 rgbw[voxels]]
+// The items sit in the order the sender's atomics produced: each one says where its voxels are, so the receiver needs no plan of its own.
+struct ShellPlan {
+    unsigned long long *jobset;    // [jobset_capacity] packed ids of all jobs (KEY_EMPTY = free)
+    int jobset_capacity;           // power of two
+    int *my_jobs;                  // [max_jobs][3] the jobs this rank owns
+    int max_jobs;
+    int *ctl;                      // [0] jobs of this rank, [1] overflow (job set / job list / item list), [2] largest per-rank entry count of the gathered list, [3] send items
+    unsigned long long *send_cur;  // [n_shards] items | voxels << 32 this rank sends to each peer
+    unsigned long long *recv_cnt;  // [n_shards] ... and receives from each
+    int *send_items;               // [send_capacity][8]: x, y, z, box, destination, index within the destination's segment, first voxel, 0
+    int send_capacity;
+};
+constexpr int SHELL_MAX_SHARDS = 64;
+__host__ __device__ inline long long shell_segment_bytes(long long items, long long voxels, bool color) { return 16 + 32 * items + (color ? 12 : 8) * voxels; }
+// box code of direction d = G - J (what job J reads of its neighbour G): per axis d > 0 -> {0, 1} (1), d < 0 -> {N - 1} (2), 0 -> all (0)
+__host__ __device__ inline int shell_box_of(int dx, int dy, int dz) {
+    return (dx > 0 ? 1 : (dx < 0 ? 2 : 0)) | ((dy > 0 ? 1 : (dy < 0 ? 2 : 0)) << 2) | ((dz > 0 ? 1 : (dz < 0 ? 2 : 0)) << 4);
+}
+// step 1: the job set.  gathered: per rank a block of 1 + 4 * cap ints -- count, then (x, y, z, flag) entries; flag 0 = an updated chunk
+// (its 27-neighbourhood is meshed, Chisel.h:175-189), flag 1 = an id meshed as it is.  One thread per (entry, offset).
+__global__ void shell_jobs_kernel(const int *__restrict__ gathered, int world, int cap, ShellPlan S, int n_shards, int shard_rank, int shard_block) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        int mx = 0;
+        for (int r = 0; r < world; r++) mx = max(mx, gathered[(size_t)r * (1 + 4 * (size_t)cap)]);
+        S.ctl[2] = mx;
+    }
+    const long long per_rank = 27ll * cap;
+    if (t >= per_rank * world) return;
+    const int r = (int)(t / per_rank), e = (int)((t % per_rank) / 27), o = (int)(t % 27);
+    const int *blk = gathered + (size_t)r * (1 + 4 * (size_t)cap);
+    if (e >= min(blk[0], cap)) return;
+    const int *en = blk + 1 + 4 * e;
+    if (en[3] != 0 && o != 13) return;
+    const int x = en[0] + (en[3] ? 0 : o % 3 - 1), y = en[1] + (en[3] ? 0 : (o / 3) % 3 - 1), z = en[2] + (en[3] ? 0 : o / 9 - 1);
+    const unsigned long long key = pack_id(x, y, z);
+    const unsigned mask = (unsigned)S.jobset_capacity - 1u;
+    unsigned h = (unsigned)(chunk_hash(x, y, z) * 0x9E3779B97F4A7C15ull >> 40) & mask;
+    for (int probe = 0; probe < S.jobset_capacity; probe++, h = (h + 1u) & mask) {
+        const unsigned long long cur = S.jobset[h];
+        if (cur == key) return;
+        if (cur == KEY_EMPTY) {
+            const unsigned long long old = atomicCAS(&S.jobset[h], KEY_EMPTY, key);
+            if (old == key) return;
+            if (old != KEY_EMPTY) continue;  // (somebody else's id: next bucket)
+            if (chunk_owner(x, y, z, n_shards, shard_block) == shard_rank) {
+                const int pos = atomicAdd(&S.ctl[0], 1);
+                if (pos < S.max_jobs) {
+                    S.my_jobs[3 * pos] = x; S.my_jobs[3 * pos + 1] = y; S.my_jobs[3 * pos + 2] = z;
+                } else {
+                    S.ctl[1] = 1;
+                }
+            }
+            return;
+        }
+    }
+    S.ctl[1] = 1;  // the set is full
+}
+// step 2: the items.  32 threads per bucket of the job set (26 directions); counts and positions are reserved per workgroup in LDS,
+// then once per (workgroup, peer) in memory.
+__global__ __launch_bounds__(256) void shell_items_kernel(ShellPlan S, int N, int n_shards, int shard_rank, int shard_block) {
+    __shared__ unsigned long long s_send[SHELL_MAX_SHARDS], s_recv[SHELL_MAX_SHARDS], s_base[SHELL_MAX_SHARDS];
+    __shared__ int s_n, s_pos;
+    if (threadIdx.x < SHELL_MAX_SHARDS) s_send[threadIdx.x] = s_recv[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int bucket = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+    bool sends = false;
+    int gx = 0, gy = 0, gz = 0, box = 0, dest = 0, local = 0;
+    unsigned long long mine = 0ull;
+    if (bucket < S.jobset_capacity && d < 26) {
+        const unsigned long long key = S.jobset[bucket];
+        if (key != KEY_EMPTY) {
+            int jx, jy, jz;
+            unpack_id(key, jx, jy, jz);
+            const int dd = d < 13 ? d : d + 1;  // (skip the job itself)
+            const int dx = dd % 3 - 1, dy = (dd / 3) % 3 - 1, dz = dd / 9 - 1;
+            gx = jx + dx; gy = jy + dy; gz = jz + dz;
+            const int r = chunk_owner(jx, jy, jz, n_shards, shard_block), o = chunk_owner(gx, gy, gz, n_shards, shard_block);
+            if (r != o) {
+                box = shell_box_of(dx, dy, dz);
+                const unsigned long long inc = 1ull | ((unsigned long long)shell_volume(box, N) << 32);
+                if (o == shard_rank) {
+                    sends = true;
+                    dest = r;
+                    mine = atomicAdd(&s_send[r], inc);  // this item's place among the workgroup's items for that peer
+                    local = atomicAdd(&s_n, 1);
+                } else if (r == shard_rank) {
+                    atomicAdd(&s_recv[o], inc);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_shards) {
+        if (s_send[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&S.send_cur[threadIdx.x], s_send[threadIdx.x]);
+        if (s_recv[threadIdx.x]) atomicAdd(&S.recv_cnt[threadIdx.x], s_recv[threadIdx.x]);
+    }
+    if (threadIdx.x == 0 && s_n) s_pos = atomicAdd(&S.ctl[3], s_n);
+    __syncthreads();
+    if (sends) {
+        const unsigned long long at = s_base[dest] + mine;
+        const int pos = s_pos + local;
+        if (pos < S.send_capacity) {
+            int *it = S.send_items + 8 * (size_t)pos;
+            it[0] = gx; it[1] = gy; it[2] = gz; it[3] = box; it[4] = dest; it[5] = (int)(at & 0xffffffffull); it[6] = (int)(at >> 32); it[7] = 0;
+        } else {
+            S.ctl[1] = 1;
+        }
+    }
+}
+// where segment `peer` begins in a buffer of consecutive segments, and its counts (cur: items | voxels << 32 per peer)
+__device__ inline long long shell_segment_at(const unsigned long long *cur, int peer, bool color, int &items, long long &voxels) {
+    long long off = 0;
+    for (int p = 0; p < peer; p++) off += shell_segment_bytes((long long)(cur[p] & 0xffffffffull), (long long)(cur[p] >> 32), color);
+    items = (int)(cur[peer] & 0xffffffffull);
+    voxels = (long long)(cur[peer] >> 32);
+    return off;
+}
+// step 3 (owner): one workgroup per send item packs its box into the destination's segment; workgroup 0 also writes the segment heads
+__global__ __launch_bounds__(256) void shell_export_kernel(MapView M, ShellPlan S, int N, int n_shards, unsigned char *out) {
+    __shared__ int s_slot;
+    const bool color = M.rgbw != nullptr;
+    if (blockIdx.x == 0 && threadIdx.x < n_shards) {
+        int items;
+        long long voxels;
+        const long long off = shell_segment_at(S.send_cur, threadIdx.x, color, items, voxels);
+        int *head = reinterpret_cast<int *>(out + off);
+        head[0] = items; head[1] = (int)voxels; head[2] = 0; head[3] = 0;
+    }
+    const int j = blockIdx.x;
+    if (j >= min(S.ctl[3], S.send_capacity)) return;
+    const int *it = S.send_items + 8 * (size_t)j;
+    int items;
+    long long voxels;
+    const long long off = shell_segment_at(S.send_cur, it[4], color, items, voxels);
+    if (threadIdx.x == 0) {
+        s_slot = hash_find(M, it[0], it[1], it[2]);
+        int *rec = reinterpret_cast<int *>(out + off + 16 + 32 * (long long)it[5]);
+        rec[0] = it[0]; rec[1] = it[1]; rec[2] = it[2]; rec[3] = it[3]; rec[4] = s_slot >= 0 ? 1 : 0; rec[5] = it[6]; rec[6] = 0; rec[7] = 0;
+    }
+    __syncthreads();
+    const int slot = s_slot, box = it[3];
+    if (slot < 0) return;  // (an absent chunk: the receiver skips the item, its voxels stay unwritten)
+    const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
+    const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
+    float *sdf = reinterpret_cast<float *>(out + off + 16 + 32 * (long long)items) + it[6];
+    float *wgt = sdf + voxels;
+    unsigned *col = reinterpret_cast<unsigned *>(wgt + voxels);
+    const size_t src = (size_t)slot * N * N * N;
+    for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
+        const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
+        const size_t i = src + (size_t)(z * N + y) * N + x;
+        sdf[v] = M.sdf[i];
+        wgt[v] = M.wgt[i];
+        if (color) col[v] = reinterpret_cast<const unsigned *>(M.rgbw)[i];
+    }
+}
+// The received buffer: consecutive segments, one per owner (empty for this rank itself), at byte offsets seg[peer].
+struct ShellSegments {
+    long long off[SHELL_MAX_SHARDS + 1];
+    int first_item[SHELL_MAX_SHARDS + 1];  // items of the segments in front of each one (from the plan's receive counts)
+};
+__device__ inline const int *shell_received_item(const unsigned char *in, const ShellSegments &G, int n_shards, int j, int &peer) {
+    peer = 0;
+    while (peer + 1 < n_shards && G.first_item[peer + 1] <= j) peer++;
+    return reinterpret_cast<const int *>(in + G.off[peer] + 16 + 32 * (long long)(j - G.first_item[peer]));
+}
+// step 4a (requester): a ghost chunk for every received item whose chunk was found at its owner -- several items may name one ghost, the
+// thread whose compare-and-swap enters the key creates it.  (The ids are absent before: ghosts are dropped after every recompute.)
+__global__ void shell_ensure_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int n_items, unsigned long long *ghosts_created) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_items) return;
+    int peer;
+    const int *it = shell_received_item(in, G, n_shards, j, peer);
+    if (!it[4]) return;
+    const int x = it[0], y = it[1], z = it[2];
+    const uint64_t key = pack_id(x, y, z);
+    const uint64_t h = chunk_hash(x, y, z) & M.hash_mask;
+    for (uint64_t i = 0; i <= M.hash_mask; i++) {
+        const uint64_t idx = (h + i) & M.hash_mask;
+        const uint64_t cur = M.hash_keys[idx];
+        if (cur == key) return;
+        if (cur != KEY_EMPTY && cur != KEY_TOMB) continue;
+        const uint64_t old = atomicCAS((unsigned long long *)&M.hash_keys[idx], (unsigned long long)cur, (unsigned long long)key);
+        if (old == key) return;
+        if (old != cur) {  // the bucket went to another id meanwhile: look at it again
+            i--;
+            continue;
+        }
+        const int top = atomicSub(M.free_top, 1) - 1;
+        if (top < 0) {
+            atomicAdd(M.free_top, 1);
+            M.hash_keys[idx] = KEY_TOMB;
+            raise_error(M.error_flag, 1);
+            return;
+        }
+        const int slot = M.free_list[top];
+        M.hash_vals[idx] = slot;
+        M.slot_key[slot] = key;
+        bbox_include(M.mesh_ctl, x, y, z);
+        if (ghosts_created) atomicAdd(ghosts_created, 1ull);
+        return;
+    }
+    raise_error(M.error_flag, 2);
+}
+// step 4b (the next launch): one workgroup per received item writes its box into the ghost
+__global__ __launch_bounds__(256) void shell_import_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int N) {
+    __shared__ int s_slot;
+    int peer;
+    const int *it = shell_received_item(in, G, n_shards, blockIdx.x, peer);
+    if (!it[4]) return;
+    if (threadIdx.x == 0) s_slot = hash_find(M, it[0], it[1], it[2]);
+    __syncthreads();
+    const int slot = s_slot, box = it[3];
+    if (slot < 0) return;
+    const int *head = reinterpret_cast<const int *>(in + G.off[peer]);
+    const long long items = head[0], voxels = head[1];
+    const float *sdf = reinterpret_cast<const float *>(in + G.off[peer] + 16 + 32 * items) + it[5];
+    const float *wgt = sdf + voxels;
+    const unsigned *col = reinterpret_cast<const unsigned *>(wgt + voxels);
+    const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
+    const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
+    const size_t dst = (size_t)slot * N * N * N;
+    if (threadIdx.x == 0) slot_summary(M)[slot] = SUM_ANY;  // (voxels from outside: anything)
+    for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
+        const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
+        const size_t i = dst + (size_t)(z * N + y) * N + x;
+        M.sdf[i] = sdf[v];
+        M.wgt[i] = wgt[v];
+        if (M.rgbw) reinterpret_cast<unsigned *>(M.rgbw)[i] = col[v];
+    }
+}
+// step 6: the ghosts go again -- one workgroup per received item; of the items that name one ghost the one whose swap takes the key out
+// frees the slot (as remove_chunks_kernel does for a list with duplicates)
+__global__ __launch_bounds__(256) void shell_drop_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int V) {
+    __shared__ int s_slot;
+    int peer;
+    const int *it = shell_received_item(in, G, n_shards, blockIdx.x, peer);
+    if (!it[4]) return;
+    if (threadIdx.x == 0) {
+        s_slot = -1;
+        uint64_t where = 0;
+        const int slot = hash_find(M, it[0], it[1], it[2], &where);
+        if (slot >= 0) {
+            const uint64_t key = pack_id(it[0], it[1], it[2]);
+            if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) == key) {
+                M.slot_key[slot] = KEY_EMPTY;
+                M.slot_dirty[slot] = 0;
+                slot_summary(M)[slot] = 0;
+                if (M.mesh_flag) M.mesh_flag[slot] = 0;
+                s_slot = slot;
+            }
+        }
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot < 0) return;
+    fill_default_chunk(M, slot, V);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int pos = atomicAdd(M.free_top, 1);
+        M.free_list[pos] = slot;
+    }
+}
+
 // the chunks updated since the last recompute (Chisel.h:175-189 marks their 27-neighbourhoods; the expansion is the planner's), as
 // (x, y, z, 0) entries behind a count, for the all-gather of a sharded recompute: out[0] = n, out[1 + 4 i ...] = entry i
 __global__ void list_dirty_ids_kernel(MapView M, int *out, int capacity) {

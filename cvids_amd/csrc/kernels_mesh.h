@@ -1001,6 +1001,9 @@ struct MeshBuffers {
     JobInfo *info = nullptr; // [capacity] per-job results of a recompute
     int *totals = nullptr;   // = MapView::mesh_ctl (MC_*): triangles, grids, record-list overflow flag, jobs; the kept job list's length; the partition cursors
     int *n_jobs = nullptr;   // where the count kernel finds the number of jobs (the kept list's length, or null: totals[3] and the caller's ids)
+    const int *ext_ids = nullptr;  // a job list on the device that is neither the kept one nor `ids` (the sharded recompute's plan: chisel_hip_update_meshes_planned) ...
+    int *ext_n = nullptr;          // ... its length (device) ...
+    int ext_capacity = 0;          // ... and its capacity in ids
     TriRec *tris = nullptr;  // [tri_capacity] triangle list of one recompute: MESH_PARTS partitions of tri_capacity / MESH_PARTS entries
     CubeCorners *corners = nullptr;  // [tri_capacity] corner distances of its occupied cubes, partitioned likewise
     int tri_capacity = 0;

@@ -179,6 +179,74 @@ def mesh_plan(union_ids, rank, world, owner_of):
     return jobs, {o: sorted(v) for o, v in requests.items()}
 
 
+# ---- the device plan restated in numpy (tests: CPU stand-in maps, and the check of chisel_hip_shell_plan_device on the GPU) ----------
+def shell_box_of(d):
+    """box code of direction d = G - J (what job J reads of its neighbour G): per axis d > 0 -> {0, 1} (1), d < 0 -> {N - 1} (2), 0 -> all (0)"""
+    return sum((1 if v > 0 else (2 if v < 0 else 0)) << (2 * a) for a, v in enumerate(d))
+
+
+def shell_box_coords(code, n):
+    rng = lambda c: range(n) if c == 0 else (range(0, 2) if c == 1 else (range(n - 1, n) if c == 2 else (0, 1, n - 1)))
+    return [(x, y, z) for z in rng((code >> 4) & 3) for y in rng((code >> 2) & 3) for x in rng(code & 3)]
+
+
+def plan_shells_reference(entries, world, rank, owner_of):
+    """entries: (n, 4) (x, y, z, flag) of ALL ranks.  -> (jobs: sorted ids this rank owns, send: {peer: [(x, y, z, box), ...]} -- what this
+    rank owns and the jobs of `peer` read --, recv: {owner: [(x, y, z, box), ...]}): one item per (job, direction), nothing merged."""
+    jobset = set()
+    for x, y, z, flag in np.asarray(entries, np.int64).reshape(-1, 4).tolist():
+        r = 0 if flag else 1
+        jobset.update((x + dx, y + dy, z + dz) for dx in range(-r, r + 1) for dy in range(-r, r + 1) for dz in range(-r, r + 1))
+    jobs = sorted(j for j in jobset if owner_of(j) == rank)
+    send, recv = {}, {}
+    for j in sorted(jobset):
+        r = owner_of(j)
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    if not (dx or dy or dz):
+                        continue
+                    g = (j[0] + dx, j[1] + dy, j[2] + dz)
+                    o = owner_of(g)
+                    if o == r:
+                        continue
+                    item = g + (shell_box_of((dx, dy, dz)),)
+                    if o == rank:
+                        send.setdefault(r, []).append(item)
+                    elif r == rank:
+                        recv.setdefault(o, []).append(item)
+    return jobs, send, recv
+
+
+def segment_bytes(items, voxels, color):
+    return 16 + 32 * items + (12 if color else 8) * voxels
+
+
+def pack_segment(items, found, sdf, wgt, col):
+    """one segment (bytes): items (n, 4), found (n,), the boxes' voxels back to back in item order (sdf, wgt: float32; col: uint32 or None)"""
+    items = np.asarray(items, np.int32).reshape(-1, 4)
+    n, vox = len(items), len(sdf)
+    head = np.array([n, vox, 0, 0], np.int32)
+    rec = np.zeros((n, 8), np.int32)
+    rec[:, :4] = items
+    rec[:, 4] = found
+    return head.tobytes() + rec.tobytes() + np.asarray(sdf, np.float32).tobytes() + np.asarray(wgt, np.float32).tobytes() + \
+        (np.asarray(col, np.uint32).tobytes() if col is not None else b"")
+
+
+def unpack_segment(buf, color):
+    """-> (rec (n, 8) int32: x, y, z, box, found, first voxel, 0, 0; sdf, wgt, col or None) of one segment given as a uint8 array"""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    head = buf[:16].view(np.int32)
+    n, vox = int(head[0]), int(head[1])
+    rec = buf[16:16 + 32 * n].view(np.int32).reshape(n, 8)
+    at = 16 + 32 * n
+    sdf = buf[at:at + 4 * vox].view(np.float32)
+    wgt = buf[at + 4 * vox:at + 8 * vox].view(np.float32)
+    col = buf[at + 8 * vox:at + 12 * vox].view(np.uint32) if color else None
+    return rec, sdf, wgt, col
+
+
 class LocalShardGroup:
     """All shards of a map in ONE process (tests; a single GPU holding several shards): the same protocol as
     ShardedChisel.UpdateMeshes with the exchange done by direct calls."""
@@ -195,24 +263,47 @@ class LocalShardGroup:
             s_.IntegratePointCloud(integrator, cloud, extrinsic, truncation, max_dist)
 
     def UpdateMeshes(self, force=False):
-        from .chisel import mesh_shell_plan
+        """the protocol of ShardedChisel.UpdateMeshes with the two collectives done by copies between the shards' buffers"""
+        import torch
         self.calls += 1
         if not force and (self.calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return
-        entries = np.concatenate([s_.DirtyEntries() for s_ in self.shards], axis=0)
-        plans = [mesh_shell_plan(entries, self.world, r) for r in range(self.world)]
+        W = self.world
+        dev = torch.device("cuda", torch.cuda.current_device())
+        cap = getattr(self, "_dirty_cap", 1 << 12)
+        while True:
+            gathered = torch.zeros((W, 1 + 4 * cap), dtype=torch.int32, device=dev)
+            torch.cuda.current_stream().synchronize()
+            for r, s_ in enumerate(self.shards):
+                s_.DirtyIdsDevice(gathered[r])
+                s_.synchronize()
+            plans = [s_.PlanShellsDevice(gathered.view(-1), W, cap) for s_ in self.shards]
+            mx = max(p["max_count"] for p in plans)
+            if mx <= cap:
+                break
+            cap = self._dirty_cap = 2 * mx
+        self.plans = plans
+        send = []
+        for r, s_ in enumerate(self.shards):
+            sizes = [s_.ShellSegmentBytes(*plans[r]["send"][p]) for p in range(W)]
+            buf = torch.empty((sum(sizes),), dtype=torch.uint8, device=dev)
+            torch.cuda.current_stream().synchronize()
+            s_.ExportShellsPacked(buf)
+            s_.synchronize()
+            send.append((buf, np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)))
         self.ghost_bytes = 0
-        for r, (jobs, items) in enumerate(plans):
-            for o in sorted(set(items[:, 0].tolist())):
-                it = items[items[:, 0] == o][:, 1:5]
-                sdf, wgt, col, found = self.shards[o].ExportShells(it, device=self.device_payload)  # payload stays in HBM
-                if self.device_payload:
-                    self.shards[o].synchronize()
-                self.shards[r].ImportGhostShells(it, sdf, wgt, col, found)
-                self.ghost_bytes += int(sdf.nbytes if isinstance(sdf, np.ndarray) else sdf.numel() * 4) * (3 if col is not None else 2)
-        for r, (jobs, _) in enumerate(plans):
-            self.shards[r].UpdateMeshesOf(jobs)
-            self.shards[r].DropGhostChunks()
+        for r, s_ in enumerate(self.shards):
+            sizes = [s_.ShellSegmentBytes(*plans[r]["recv"][o]) for o in range(W)]
+            # what the all-to-all does: segment (o -> r) of every owner's send buffer, in owner order
+            parts = [send[o][0][int(send[o][1][r]):int(send[o][1][r + 1])] for o in range(W)]
+            assert [int(p.numel()) for p in parts] == sizes, (r, [int(p.numel()) for p in parts], sizes)
+            recv = torch.cat(parts) if parts else torch.empty((0,), dtype=torch.uint8, device=dev)
+            torch.cuda.current_stream().synchronize()
+            s_.ImportShellsPacked(recv)
+            self.ghost_bytes += int(plans[r]["recv"][:, 1].sum()) * (12 if s_.use_color else 8)
+        for s_ in self.shards:
+            s_.UpdateMeshesPlanned()
+            s_.DropGhostChunks()
 
 
 class ShardedChisel:
@@ -282,16 +373,14 @@ class ShardedChisel:
 
         1. every rank lists the chunks it has updated since the last recompute as a device int array (chisel_hip_dirty_ids_device) and
            ONE all_gather hands every rank all of them (a fixed-capacity int tensor: no pickled objects, no sizes to agree on first);
-        2. the plan is host arithmetic every rank evaluates for every rank (chisel_hip_mesh_shell_plan): its own jobs, the ghosts it
-           needs, and what the others will ask of it -- the request lists are never exchanged;
-        3. the owners pack the requested SHELLS (the one or two voxel layers a neighbour's mesh reads, not whole chunks:
-           chisel_hip_export_shells), one all_to_all per voxel array moves them, the receivers install them as ghost chunks
-           (chisel_hip_import_ghost_shells); map stream and collective stream are ordered by events (record_event / wait_event),
-           the host waits once, for the gathered id list of step 1;
-        4. every rank recomputes its jobs and drops the ghosts.
+        2. the plan is made ON THE DEVICE from that tensor (chisel_hip_shell_plan_device: this rank's jobs, the shells it owes every
+           peer, how much every owner owes it) -- the host reads 4 W + 4 numbers, its one wait of the recompute;
+        3. the owners pack the SHELLS (the one or two voxel layers a neighbour's mesh reads, not whole chunks) into one byte segment
+           per peer whose items say where their voxels are, ONE all_to_all moves the segments, the receivers install what arrived as
+           ghost chunks; map stream and collective stream are ordered by events (record_event / wait_event);
+        4. every rank recomputes its jobs (a list that never left the device) and drops the ghosts.
         ids: mesh these chunks (every rank passes ids of its own choice, the union is meshed) instead of meshesToUpdate.
         -> bytes of ghost voxels this rank received"""
-        from .chisel import mesh_shell_plan_all, shell_volumes
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return 0
@@ -303,9 +392,10 @@ class ShardedChisel:
                 self.map.UpdateMeshesOf(np.asarray(ids, np.int32).reshape(-1, 3))
             return 0
         on_gpu = dev.type == "cuda"
-        edge = int(self.map.chunk_size[0])
+        bounce = dist.get_backend() == "gloo" and on_gpu  # functional check only: gloo has no device collectives
+        import os
         import time
-        timing = True  # host phases of a sharded recompute, summed in self.phase_us (six perf_counter calls per recompute)
+        timing = bool(os.environ.get("CHISEL_HIP_HOST_TIMING"))  # host phases of a sharded recompute, summed in self.phase_us
         t_prev = [time.perf_counter()]
         def lap(name):
             if timing:
@@ -313,13 +403,17 @@ class ShardedChisel:
                 self.phase_us = getattr(self, "phase_us", {})
                 self.phase_us[name] = self.phase_us.get(name, 0.0) + (now - t_prev[0]) * 1e6
                 t_prev[0] = now
-        # ---- 1. the ranks' dirty chunks
+        # ---- 1. the ranks' dirty chunks, 2. the plan
         while True:
             cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 12)  # (entries per rank in the gathered tensor; doubled below when a rank has more)
-            buf = torch.zeros((1 + 4 * cap,), dtype=torch.int32, device=dev)
+            key = (cap, world)
+            if getattr(self, "_mesh_bufs_key", None) != key:  # the two int tensors of step 1, kept between recomputes
+                self._mesh_bufs_key = key
+                self._dirty_buf = torch.zeros((1 + 4 * cap,), dtype=torch.int32, device=dev)
+                self._gathered = torch.zeros((world * (1 + 4 * cap),), dtype=torch.int32, device=dev)
+            buf, gathered = self._dirty_buf, self._gathered
             if ids is None and on_gpu:
-                self._order_map_after_collectives()  # (the buffer was zeroed on torch's stream)
-                self.map.DirtyIdsDevice(buf)
+                self.map.DirtyIdsDevice(buf)  # (writes the count itself; the buffer's last reader, the previous recompute's all-gather, is long through)
                 self._order_after_map()
             else:
                 e = np.asarray(self.map.DirtyEntries(), np.int32).reshape(-1, 4) if ids is None else \
@@ -328,75 +422,59 @@ class ShardedChisel:
                 head[0] = len(e)
                 head[1:1 + 4 * min(len(e), cap)] = e[:cap].reshape(-1)
                 buf.copy_(torch.from_numpy(head))
-            gathered = torch.empty((world * (1 + 4 * cap),), dtype=torch.int32, device=dev)
-            if dist.get_backend() == "gloo" and on_gpu:  # functional check only: gloo has no device collectives
+            if bounce:
                 host = torch.empty(gathered.shape, dtype=torch.int32)
                 dist.all_gather_into_tensor(host, buf.cpu())
+                gathered.copy_(host)
             else:
                 dist.all_gather_into_tensor(gathered, buf)
-                host = gathered.cpu()  # the one host wait of a recompute
-            g = host.numpy().reshape(world, 1 + 4 * cap)
-            if int(g[:, 0].max()) <= cap:
-                break
-            self._dirty_cap = 2 * int(g[:, 0].max())  # (every rank sees the same counts and takes the same turn)
-        entries = np.concatenate([g[r, 1:1 + 4 * int(g[r, 0])].reshape(-1, 4) for r in range(world)], axis=0)
-        lap("dirty ids + all_gather + host copy")
-        # ---- 2. the plans
-        # (all ranks' plans in ONE pass of the planner: chisel_hip_mesh_shell_plan_all -- evaluating chisel_hip_mesh_shell_plan once per
-        # rank cost every rank 1-2 ms per rank and recompute)
-        all_jobs, all_items = mesh_shell_plan_all(entries, world)
-        none = np.zeros((0, 4), np.int32)
-        jobs = all_jobs[rank]
-        recv_parts = [all_items.get((rank, o), none) for o in range(world)]   # what this rank asks of owner o
-        recv_items = np.concatenate(recv_parts, axis=0)
-        n_recv = [len(p) for p in recv_parts]
-        send_parts = [all_items.get((q, rank), none) for q in range(world)]   # what rank q asks of this rank
-        send_items = np.concatenate(send_parts, axis=0)
-        n_send = [len(p) for p in send_parts]
-        vol = lambda it: int(shell_volumes(it[:, 3], edge).sum()) if len(it) else 0
-        v_send = [vol(p) for p in send_parts]
-        v_recv = [vol(recv_items[sum(n_recv[:o]):sum(n_recv[:o + 1])]) for o in range(world)]
-        lap("plan")
-        # ---- 3. shells: export -> all_to_all -> import
-        if on_gpu:
-            self._order_map_after_collectives()
-            sdf_s, wgt_s, col_s, found_s = self.map.ExportShells(send_items, device=True)
-            self._order_after_map()
-        else:
-            a, b, c, f = self.map.ExportShells(send_items)
-            sdf_s, wgt_s = torch.from_numpy(np.ascontiguousarray(a, np.float32)), torch.from_numpy(np.ascontiguousarray(b, np.float32))
-            col_s = torch.from_numpy(np.ascontiguousarray(c, np.uint8)) if c is not None else None
-            found_s = torch.from_numpy(np.ascontiguousarray(f, np.int32))
-        lap("export")
-        total = sum(v_recv)
-        sdf_r = torch.empty((total,), dtype=torch.float32, device=dev)
-        wgt_r = torch.empty((total,), dtype=torch.float32, device=dev)
-        found_r = torch.empty((sum(n_recv),), dtype=torch.int32, device=dev)
-        self._all_to_all(sdf_r, sdf_s, v_recv, v_send)
-        self._all_to_all(wgt_r, wgt_s, v_recv, v_send)
-        self._all_to_all(found_r, found_s, n_recv, n_send)
-        col_r = None
-        if col_s is not None:
-            col_r = torch.empty((total, 4), dtype=torch.uint8, device=dev)
-            self._all_to_all(col_r, col_s, v_recv, v_send)
-        lap("all_to_all x 3-4 (issue)")
-        if len(recv_items):
+            lap("dirty ids + all_gather (issue)")
             if on_gpu:
                 self._order_map_after_collectives()
-                self.map.ImportGhostShells(recv_items, sdf_r, wgt_r, col_r, found_r)
-            else:
-                self.map.ImportGhostShells(recv_items, sdf_r.numpy(), wgt_r.numpy(), None if col_r is None else col_r.numpy(), found_r.numpy())
+            plan = self.map.PlanShellsDevice(gathered, world, cap)  # the one host wait of a recompute
+            lap("plan (device) + wait")
+            if plan["max_count"] <= cap:
+                break
+            self._dirty_cap = 2 * plan["max_count"]  # (every rank sees the same counts and takes the same turn)
+        # ---- 3. shells: export -> all_to_all -> import
+        color = bool(getattr(self.map, "use_color", False))
+        s_bytes = [segment_bytes(int(i), int(v), color) for i, v in plan["send"]]
+        r_bytes = [segment_bytes(int(i), int(v), color) for i, v in plan["recv"]]
+        # the two byte buffers are kept between recomputes and only ever grow (their last readers -- the previous recompute's
+        # all-to-all and its drop kernel -- finished before the plan's wait above returned)
+        need = (sum(s_bytes), sum(r_bytes))
+        if getattr(self, "_seg_cap", (0, 0))[0] < need[0] or self._seg_cap[1] < need[1]:
+            self._seg_cap = (max(2 * need[0], 1 << 20), max(2 * need[1], 1 << 20))
+            self._seg_send = torch.empty((self._seg_cap[0],), dtype=torch.uint8, device=dev)
+            self._seg_recv = torch.empty((self._seg_cap[1],), dtype=torch.uint8, device=dev)
+            if on_gpu:
+                self._order_map_after_collectives()  # (torch's allocator hands out memory its own stream may still be using)
+        send, recv = self._seg_send[:need[0]], self._seg_recv[:need[1]]
+        self.map.ExportShellsPacked(send)
+        if on_gpu:
+            self._order_after_map()
+        lap("export (issue)")
+        self._all_to_all(recv, send, r_bytes, s_bytes)
+        lap("all_to_all (issue)")
+        if on_gpu:
+            self._order_map_after_collectives()
+        self.map.ImportShellsPacked(recv)
+        lap("import (issue)")
         # ---- 4.
-        lap("import")
-        self.map.UpdateMeshesOf(jobs)
+        self.map.UpdateMeshesPlanned()
         self.map.DropGhostChunks()
         lap("recompute + drop (issue)")
         if timing:
             self.phase_us["recomputes"] = self.phase_us.get("recomputes", 0) + 1
-        per_voxel = 12 if col_r is not None else 8
-        # for the record: what whole ghost chunks (the round-2 protocol) would have moved for the same ghosts
-        self.whole_chunk_bytes = getattr(self, "whole_chunk_bytes", 0) + (len(np.unique(recv_items[:, :3], axis=0)) if len(recv_items) else 0) * edge ** 3 * per_voxel
-        self.shell_bytes = getattr(self, "shell_bytes", 0) + int(total * per_voxel)
+        per_voxel = 12 if getattr(self.map, "use_color", False) else 8
+        total = int(plan["recv"][:, 1].sum())
+        edge = int(self.map.chunk_size[0])
+        # for the record: what whole ghost chunks (the round-2 protocol) would have moved for the same ghosts.  The number of distinct
+        # ghosts is counted on the device and reaches the host with the NEXT plan: both figures cover the recomputes before this one.
+        self.whole_chunk_bytes = int(plan.get("ghosts_before", 0)) * edge ** 3 * per_voxel
+        self.shell_bytes = getattr(self, "_shell_bytes_all", 0)
+        self._shell_bytes_all = self.shell_bytes + int(total * per_voxel)
+        self.last_plan = plan
         return int(total * per_voxel)
 
     def _order_after_map(self):

@@ -347,6 +347,20 @@ int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, 
 int chisel_hip_dirty_ids_device(chisel_hip_map *map, int *out_dev, int capacity);
 int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shards, int rank, int shard_block, int *jobs, int64_t max_jobs,
                                int64_t *n_jobs, int *items, int64_t max_items, int64_t *n_items);
+/* The sharded recompute without host planning (round 5; cvids_amd/sharded.py: ShardedChisel.UpdateMeshes): from the
+ * all-gathered list of updated chunks (per rank 1 + 4 * cap ints: count, then (x, y, z, flag) entries -- chisel_hip_dirty_ids_device)
+ * every shard derives ON THE DEVICE its own jobs, the shells it sends to every peer and how much it receives from each.
+ * chisel_hip_shell_plan_device: out[0] = jobs of this shard, out[1] = ghost chunks its earlier recomputes created (a running total), out[2] = largest per-rank count of the list (> cap: gather again with more
+ * room), out[3] = items sent, then (items, voxels) per peer sent, then per peer received -- the one host wait of a sharded recompute.
+ * chisel_hip_export_shells_packed writes one byte segment per peer, back to back in rank order (chisel_hip_shell_segment_bytes each:
+ * heads, items that say where their voxels are, sdf | weight | rgbw), the caller's all-to-all moves them, chisel_hip_import_shells_packed
+ * turns what arrived into ghost chunks (the buffer stays untouched until chisel_hip_drop_ghost_chunks), chisel_hip_update_meshes_planned
+ * recomputes the plan's jobs.  No reference counterpart: the reference has one process and one map (Chisel.h:150-195). */
+int chisel_hip_shell_plan_device(chisel_hip_map *map, const int *gathered_dev, int world, int capacity, int64_t *out);
+int64_t chisel_hip_shell_segment_bytes(chisel_hip_map *map, int64_t items, int64_t voxels);
+int chisel_hip_export_shells_packed(chisel_hip_map *map, void *out_dev, int64_t bytes);
+int chisel_hip_import_shells_packed(chisel_hip_map *map, const void *in_dev, int64_t bytes);
+int chisel_hip_update_meshes_planned(chisel_hip_map *map);
 /* the plans of ALL ranks in one pass, rank by rank the result of chisel_hip_mesh_shell_plan: jobs of rank r at job_offsets[r] ..
  * job_offsets[r + 1] (n_shards + 1 offsets, in ids), items (x, y, z, box) that r asks of o at item_offsets[r * n_shards + o] .. [+ 1]
  * (n_shards^2 + 1 offsets, in items); offsets are always written, the arrays when both capacities suffice */

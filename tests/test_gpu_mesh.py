@@ -112,6 +112,75 @@ def test_sharded_map_meshes_equal_the_unsharded_map(oracle_mod, n_shards):
             assert len(s_.GetMeshesToUpdate()) == 0
 
 
+@pytest.mark.parametrize("n_shards", [2, 8])
+def test_device_shell_plan_equals_the_reference(n_shards):
+    """chisel_hip_shell_plan_device (the plan of a sharded recompute, made on the device from the all-gathered dirty list) against its
+    numpy restatement (cvids_amd.sharded.plan_shells_reference): job counts, per-peer item and voxel counts in both directions, and --
+    through the exported segments -- the items themselves (as a set: their order is whatever the device's atomics produced), their
+    payload offsets (disjoint, covering the segment) and the exported voxels of resident chunks."""
+    import torch
+    from cvids_amd import chisel as ch
+    from cvids_amd.sharded import plan_shells_reference, segment_bytes, shell_box_coords, unpack_segment
+    N = 8
+    shards = [ch.Chisel((N, N, N), 0.05, True, max_chunks=8192, n_shards=n_shards, shard_rank=r) for r in range(n_shards)]
+    integ = ch.ProjectionIntegrator(ch.InverseTruncator(2.0), ch.ConstantWeighter(1.0), 0.05, True)
+    cam = small_camera(64, 48)
+    color = synth.render_color(64, 48, 3)
+    part = make_frames("sphere_room", 3, 64, 48)
+    for s_ in shards:
+        s_.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+    owner = lambda i: ch.chunk_owner(i, n_shards, 2)
+    dev = torch.device("cuda", 0)
+    cap = 1 << 10
+    gathered = torch.zeros((n_shards, 1 + 4 * cap), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for r, s_ in enumerate(shards):
+        s_.DirtyIdsDevice(gathered[r])
+        s_.synchronize()
+    g = gathered.cpu().numpy()
+    entries = np.concatenate([g[r, 1:1 + 4 * int(g[r, 0])].reshape(-1, 4) for r in range(n_shards)], axis=0)
+    entries = np.concatenate([entries, np.array([[40, 40, 40, 1]], np.int32)])  # an id taken as it is (flag 1), owned by somebody
+    extra = torch.from_numpy(np.array([40, 40, 40, 1], np.int32)).to(dev)
+    gathered[0, 1 + 4 * int(g[0, 0]):5 + 4 * int(g[0, 0])] = extra
+    gathered[0, 0] += 1
+    torch.cuda.synchronize()
+    assert len(entries) > 20
+    for r, s_ in enumerate(shards):
+        plan = s_.PlanShellsDevice(gathered.view(-1), n_shards, cap)
+        jobs, send, recv = plan_shells_reference(entries, n_shards, r, owner)
+        assert plan["max_count"] >= int(g[:, 0].max())
+        assert plan["jobs"] == len(jobs)
+        vol = lambda its: sum(len(shell_box_coords(it[3], N)) for it in its)
+        for p in range(n_shards):
+            assert tuple(plan["send"][p]) == (len(send.get(p, [])), vol(send.get(p, []))), (r, p)
+            assert tuple(plan["recv"][p]) == (len(recv.get(p, [])), vol(recv.get(p, []))), (r, p)
+        sizes = [s_.ShellSegmentBytes(*plan["send"][p]) for p in range(n_shards)]
+        assert sizes == [segment_bytes(len(send.get(p, [])), vol(send.get(p, [])), True) for p in range(n_shards)]
+        buf = torch.empty((sum(sizes),), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        s_.ExportShellsPacked(buf)
+        s_.synchronize()
+        raw = buf.cpu().numpy()
+        resident = set(map(tuple, s_.GetChunkIDs().tolist()))
+        at = 0
+        for p in range(n_shards):
+            rec, sdf, wgt, col = unpack_segment(raw[at:at + sizes[p]], True)
+            at += sizes[p]
+            assert sorted(map(tuple, rec[:, :4].tolist())) == sorted(send.get(p, []))
+            spans = sorted((int(f), int(f) + len(shell_box_coords(int(b), N))) for f, b in zip(rec[:, 5], rec[:, 3]))
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and (not spans or (spans[0][0] == 0 and spans[-1][1] == len(sdf)))
+            for x, y, z, box, found, first, _, _ in rec.tolist()[:40]:
+                assert found == (1 if (x, y, z) in resident else 0)
+                if found:
+                    cs, cw, cc = s_.GetChunk((x, y, z))
+                    vox = shell_box_coords(box, N)
+                    idx = np.array([(vz * N + vy) * N + vx for vx, vy, vz in vox])
+                    assert np.array_equal(sdf[first:first + len(vox)], cs.reshape(-1)[idx]) and np.array_equal(wgt[first:first + len(vox)], cw.reshape(-1)[idx])
+                    assert np.array_equal(col[first:first + len(vox)], cc.reshape(-1, 4)[idx].view(np.uint32).reshape(-1))
+    for s_ in shards:
+        s_.close()
+
+
 def test_stream_with_keyframe_meshing_no_waits(oracle_mod):
     """The bench's call pattern on a small map: batches of 7 frames queued back to back, UpdateMeshes() after every frame
     count that crosses a multiple of 10 (the recompute is queued whole, its totals are looked at by the next batch), no

@@ -179,25 +179,73 @@ class MeshRecordingMap(RecordingMap):
     def voxel_value(cls, cid, owner, v):
         return float(((cid[0] * 31 + cid[1]) * 31 + cid[2]) * 1000 + owner * 512 + (v[2] * cls.EDGE + v[1]) * cls.EDGE + v[0])
 
-    def ExportShells(self, items):
-        res = self._resident()
-        sdf, found = [], []
-        for x, y, z, code in np.asarray(items).reshape(-1, 4).tolist():
-            found.append(1 if (x, y, z) in res else 0)
-            sdf.extend(self.voxel_value((x, y, z), self.rank, v) for v in self._box(code, self.EDGE))
-        sdf = np.array(sdf, np.float32)
-        return sdf, sdf + 0.5, None, np.array(found, np.int32)
+    # the device protocol of ShardedChisel.UpdateMeshes (chisel_hip_shell_plan_device ...) restated with numpy: cvids_amd/sharded.py
+    use_color = False
 
-    def ImportGhostShells(self, items, sdf, wgt, col, found):
-        off = 0
-        for j, (x, y, z, code) in enumerate(np.asarray(items).reshape(-1, 4).tolist()):
-            box = self._box(code, self.EDGE)
-            if found[j]:
+    def PlanShellsDevice(self, gathered, world, cap):
+        from cvids_amd.chisel import chunk_owner
+        from cvids_amd.sharded import plan_shells_reference, shell_box_coords
+        g = np.asarray(gathered).reshape(world, 1 + 4 * cap)
+        mx = int(g[:, 0].max())
+        if mx > cap:
+            return {"jobs": 0, "max_count": mx, "send_items": 0, "send": np.zeros((world, 2), np.int64), "recv": np.zeros((world, 2), np.int64)}
+        entries = np.concatenate([g[r, 1:1 + 4 * int(g[r, 0])].reshape(-1, 4) for r in range(world)], axis=0)
+        jobs, send, recv = plan_shells_reference(entries, world, self.rank, lambda i: chunk_owner(i, world, 2))
+        self._plan = (jobs, send, recv)
+        count = lambda d, p: (len(d.get(p, [])), sum(len(shell_box_coords(it[3], self.EDGE)) for it in d.get(p, [])))
+        return {"jobs": len(jobs), "max_count": mx, "send_items": sum(len(v) for v in send.values()),
+                "send": np.array([count(send, p) for p in range(world)], np.int64), "recv": np.array([count(recv, p) for p in range(world)], np.int64)}
+
+    def ShellSegmentBytes(self, items, voxels):
+        from cvids_amd.sharded import segment_bytes
+        return segment_bytes(int(items), int(voxels), False)
+
+    def ExportShellsPacked(self, out):
+        from cvids_amd.sharded import pack_segment, shell_box_coords
+        res = self._resident()
+        _, send, _ = self._plan
+        blob = b""
+        rng = np.random.default_rng(self.rank)
+        for p in range(self.world):
+            items = list(send.get(p, []))
+            rng.shuffle(items)  # (the device emits them in the order its atomics happen to run: the receiver must not care)
+            sdf, found, first, at = [], [], [], 0
+            for x, y, z, code in items:
+                box = shell_box_coords(code, self.EDGE)
+                found.append(1 if (x, y, z) in res else 0)
+                first.append(at)
+                sdf.extend(self.voxel_value((x, y, z), self.rank, v) for v in box)
+                at += len(box)
+            sdf = np.array(sdf, np.float32)
+            seg = bytearray(pack_segment(np.array(items, np.int32).reshape(-1, 4), np.array(found, np.int32), sdf, sdf + np.float32(0.5), None))
+            rec = np.frombuffer(seg, np.int32, 8 * len(items), 16).reshape(-1, 8)
+            rec[:, 5] = first
+            blob += bytes(seg)
+        assert len(blob) == out.numel()
+        out.copy_(__import__("torch").from_numpy(np.frombuffer(blob, np.uint8).copy()))
+
+    def ImportShellsPacked(self, buf):
+        from cvids_amd.sharded import segment_bytes, shell_box_coords, unpack_segment
+        _, _, recv = self._plan
+        raw = np.asarray(buf)
+        at = 0
+        for o in range(self.world):
+            n = len(recv.get(o, []))
+            vox = sum(len(shell_box_coords(it[3], self.EDGE)) for it in recv.get(o, []))
+            size = segment_bytes(n, vox, False)
+            rec, sdf, wgt, _ = unpack_segment(raw[at:at + size], False)
+            at += size
+            assert sorted(map(tuple, rec[:, :4].tolist())) == sorted(recv.get(o, []))  # what this rank counted on is what the owner sent
+            for x, y, z, code, found, first, _, _ in rec.tolist():
+                if not found:
+                    continue
                 cells = self.ghosts.setdefault((x, y, z), {})
-                for k, v in enumerate(box):
-                    cells[v] = (float(sdf[off + k]), float(wgt[off + k]))
-            off += len(box)
-        assert off == len(sdf)
+                for k, v in enumerate(shell_box_coords(code, self.EDGE)):
+                    cells[v] = (float(sdf[first + k]), float(wgt[first + k]))
+        assert at == len(raw)
+
+    def UpdateMeshesPlanned(self):
+        self.meshed = (list(self._plan[0]), dict(self.ghosts))
 
     def UpdateMeshesOf(self, ids):
         self.meshed = ([tuple(int(v) for v in i) for i in np.asarray(ids).reshape(-1, 3)], dict(self.ghosts))
@@ -236,7 +284,8 @@ def test_sharded_update_meshes_protocol_world2(hip_lib, dirty_cap):
     ghost lies on the + side of a job, {N - 1} on the - side, all along an axis they share -- carrying the owner's values, and far
     fewer bytes travel than whole chunks would take."""
     import torch.multiprocessing as mp
-    from cvids_amd.chisel import chunk_owner, mesh_shell_plan
+    from cvids_amd.chisel import chunk_owner
+    from cvids_amd.sharded import plan_shells_reference
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -281,8 +330,9 @@ def test_sharded_update_meshes_protocol_world2(hip_lib, dirty_cap):
                 assert sd == np.float32(MeshRecordingMap.voxel_value(g, o, v)) and wg == np.float32(np.float32(MeshRecordingMap.voxel_value(g, o, v)) + np.float32(0.5))
             total_vox += len(cells)
         assert nbytes >= 8 * total_vox  # (boxes of chunks that turned out not to be resident travel too)
-        n_items = len(mesh_shell_plan(np.concatenate([MeshRecordingMap(r, world).DirtyEntries() for r in range(world)]), world, rank)[1])
-        assert nbytes < 0.5 * 8 * E ** 3 * n_items  # less than half of what whole ghost chunks would take, even with two shards and 8^3 chunks
+        n_ghost_ids = len({it[:3] for o in range(world) for it in plan_shells_reference(
+            np.concatenate([MeshRecordingMap(r, world).DirtyEntries() for r in range(world)]), world, rank, lambda i: chunk_owner(i, world, 2))[2].get(o, [])})
+        assert nbytes < 0.7 * 8 * E ** 3 * n_ghost_ids  # less than whole ghost chunks would take, even with two shards, 8^3 chunks and unmerged boxes
         assert all(chunk_owner(g, world, 2) != rank for g in ghosts)
     assert all_jobs == union
 

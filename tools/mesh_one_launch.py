@@ -14,10 +14,13 @@ cam = PinholeCamera(*intr, W, H, 0.05, 5.0)
 color = synth.render_color(W, H, 3)
 gm = Chisel((16, 16, 16), 0.01, True, device_id=0)
 integ = ProjectionIntegrator(InverseTruncator(1.0), ConstantWeighter(1.0), 0.05, True)
-frames = list(synth.stream("sphere_room", n, W, H))
-gm.IntegrateBatch(integ, [(d, p, cam) for d, p in frames[:10]], [(color, p, cam) for _, p in frames[:10]])
-gm.synchronize()
-gm.counters(reset=True)  # prints and zeroes the diagnostics so far
-gm.UpdateMeshes(force=True)
-gm.synchronize()
-gm.counters(reset=True)
+frames = list(synth.stream("sphere_room", n + 10, W, H))
+for lo in range(0, n + 10, 10):  # the last ten frames and their recompute are the measured ones (everything before warms the code up)
+    part = frames[lo:lo + 10]
+    gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+    gm.synchronize()
+    gm.counters(reset=True)  # prints and zeroes the diagnostics so far
+    gm.UpdateMeshes(force=True)
+    gm.synchronize()
+    print("--- recompute after frame %d" % (lo + 10), file=sys.stderr)
+    gm.counters(reset=True)
