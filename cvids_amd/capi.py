@@ -62,12 +62,12 @@ EXPORTS = [
     "chisel_hip_synchronize", "chisel_hip_wait_event", "chisel_hip_record_event", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
     "chisel_hip_integrate_batch", "chisel_hip_integrate_pointcloud", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
     "chisel_hip_list_chunks", "chisel_hip_has_chunk", "chisel_hip_download_chunk", "chisel_hip_upload_chunk",
-    "chisel_hip_meshes_to_update", "chisel_hip_meshes_to_update_since", "chisel_hip_shell_plan_device", "chisel_hip_shell_segment_bytes", "chisel_hip_export_shells_packed", "chisel_hip_import_shells_packed", "chisel_hip_update_meshes_planned", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
+    "chisel_hip_meshes_to_update", "chisel_hip_meshes_to_update_since", "chisel_hip_meshes_to_update_prefetch", "chisel_hip_shell_plan_device", "chisel_hip_shell_segment_bytes", "chisel_hip_export_shells_packed", "chisel_hip_import_shells_packed", "chisel_hip_update_meshes_planned", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
     "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
-    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_cloud_candidates", "chisel_hip_mesh_cube", "chisel_hip_write_mesh_ply", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan", "chisel_hip_mesh_shell_plan_all",
+    "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_cloud_candidates", "chisel_hip_mesh_cube", "chisel_hip_write_mesh_ply", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan",
     "chisel_hip_shell_volume", "chisel_hip_export_shells", "chisel_hip_import_ghost_shells", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_get_launch_stats", "chisel_hip_mc_tables", "chisel_hip_mesh_cube_values", "chisel_hip_interpolate_vertex", "chisel_hip_raycast", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
 ]
 # the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
@@ -135,6 +135,7 @@ def load_library():
     L.chisel_hip_upload_chunk.argtypes = [vp, i32p, f32p, f32p, u8p]
     L.chisel_hip_meshes_to_update.argtypes = [vp, i32p, C.c_int64, i64p]
     L.chisel_hip_meshes_to_update_since.argtypes = [vp, C.POINTER(C.c_uint64), i32p, C.c_int64, i64p, i32p]
+    L.chisel_hip_meshes_to_update_prefetch.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.chisel_hip_host_alloc.argtypes = [C.c_size_t]
     L.chisel_hip_host_alloc.restype = C.c_void_p
     L.chisel_hip_host_free.argtypes = [vp]
@@ -178,7 +179,6 @@ def load_library():
         L.chisel_hip_import_shells_packed.argtypes = [vp, vp, C.c_int64]
         L.chisel_hip_update_meshes_planned.argtypes = [vp]
         L.chisel_hip_mesh_shell_plan.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]
-        L.chisel_hip_mesh_shell_plan_all.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]
         L.chisel_hip_shell_volume.argtypes = [C.c_int, C.c_int]
         L.chisel_hip_shell_volume.restype = C.c_int64
         L.chisel_hip_export_shells.argtypes = [vp, i32p, C.c_int, vp, vp, vp, vp, C.c_int]

@@ -357,6 +357,7 @@ class Chisel:
         # the import is only queued (device payloads are read in place, nothing is waited for): the payload must outlive it.  Kept until
         # DropGhostChunks, which returns after the recompute behind the imports has started (it looks at that recompute's totals).
         self._ghost_keep = getattr(self, "_ghost_keep", []) + [(items, sdf, wgt, col, found)]
+        self._imports_fenced = False  # (only a recompute queued BEHIND this import tells the host that it has read its payload)
 
     # ---- the sharded recompute planned on the device (chisel_hip.h: chisel_hip_shell_plan_device ...) -------------------------------
     def PlanShellsDevice(self, gathered, world, cap):
@@ -424,6 +425,10 @@ class Chisel:
         if n.value:
             check(self.L.chisel_hip_meshes_to_update(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), n.value, C.byref(n)))
         return ids
+
+    def PrefetchMeshesToUpdate(self, cursor):
+        """chisel_hip_meshes_to_update_prefetch: queue the listing behind the integration just issued (no wait)"""
+        check(self.L.chisel_hip_meshes_to_update_prefetch(self.h, cursor))
 
     def GetMeshesToUpdateSince(self, cursor, capacity=8192):
         """chisel_hip_meshes_to_update_since: (ids that joined the set since `cursor` [n, 3], cleared) -- `cursor` is a (C.c_uint64 * 2)
@@ -689,22 +694,6 @@ def mesh_shell_plan(entries, n_shards, rank, shard_block=2):
     check(L.chisel_hip_mesh_shell_plan(ip(e), len(e), int(n_shards), int(rank), int(shard_block), ip(jobs), nj.value, C.byref(nj), ip(items), ni.value,
                                        C.byref(ni)))
     return jobs, items
-
-
-def mesh_shell_plan_all(entries, n_shards, shard_block=2):
-    """chisel_hip_mesh_shell_plan_all: the plans of all ranks in one pass ->
-    (jobs: list per rank of (nj, 3) arrays, items: dict (r, o) -> (n, 4) array of (x, y, z, box) that r asks of o)"""
-    L = capi.load_library()
-    e = np.ascontiguousarray(np.asarray(entries, np.int32).reshape(-1, 4))
-    W = int(n_shards)
-    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
-    jo, io = np.zeros(W + 1, np.int64), np.zeros(W * W + 1, np.int64)
-    lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
-    check(L.chisel_hip_mesh_shell_plan_all(ip(e), len(e), W, int(shard_block), None, 0, lp(jo), None, 0, lp(io)))
-    jobs, items = np.zeros((int(jo[W]), 3), np.int32), np.zeros((int(io[W * W]), 4), np.int32)
-    check(L.chisel_hip_mesh_shell_plan_all(ip(e), len(e), W, int(shard_block), ip(jobs), len(jobs), lp(jo), ip(items), len(items), lp(io)))
-    return ([jobs[jo[r]:jo[r + 1]] for r in range(W)],
-            {(r, o): items[io[r * W + o]:io[r * W + o + 1]] for r in range(W) for o in range(W) if io[r * W + o + 1] > io[r * W + o]})
 
 
 def shell_volume(box, chunk_edge):

@@ -153,6 +153,7 @@ struct chisel_hip_map {
     bool is_group = false;
     std::vector<chisel_hip_map *> shards;
     void *stages = nullptr;  // std::vector<group::Stage>*: staging of device frames for shards on other devices
+    void *host_fanout = nullptr;  // group::HostFanout*: host frames staged once per launch set and broadcast to the group's devices
     void *pool = nullptr;    // group::Pool*: one issuing host thread per shard
     void *mesh_stages_group = nullptr;  // group::MeshStages*: persistent shell staging of update_meshes, per (meshing shard, owner)
     chisel_hip_config cfg;
@@ -263,6 +264,9 @@ struct chisel_hip_map {
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     uint64_t pending_version = 1;                                      // bumped when entries join pending_mesh_ids (chisel_hip_meshes_to_update_since)
     uint32_t dirty_epoch = 0;                                          // bumped when the device's dirty list is emptied (recompute, reset)
+    bool dirty_tail_queued = false;                                    // chisel_hip_meshes_to_update_prefetch: the listing kernel is queued (or done) for ...
+    uint64_t dirty_tail_cursor = 0;                                    // ... this cursor word and ...
+    unsigned dirty_tail_batch = 0;                                     // ... this many batches issued
     int *dirty_tail_host = nullptr, *dirty_tail_dev = nullptr;         // pinned: where list_dirty_tail_kernel leaves the new entries of the dirty list
     int batch_frames = KMAX;                                           // frames per launch set in chisel_hip_integrate_batch
     uint64_t ghost_bytes = 0;                                          // group handle: ghost voxel bytes its recomputes have moved between shards
@@ -519,8 +523,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // shards of a multi-GPU map are in this regime, where the front half is what a rank's rate hangs on
         const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
         const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= m->tune.direct_items_max);
+        skip_refine = IP.n_frames == 1 && !m->refine_always;  // (a one-frame launch: the resolve kernel fills the CellRecs itself)
         hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
-                           prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync, bs.boxes, (skip_refine = IP.n_frames == 1 && !m->refine_always) ? bs.cells : nullptr);
+                           prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync, bs.boxes, skip_refine ? bs.cells : nullptr);
         if (direct) m->launch_stats[5]++;
         if (!direct)
             hipLaunchKernelGGL(order_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
@@ -642,8 +647,10 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     m->mesh_totals_clean = true;  // (integrate_kernel's first thread zeroes the next recompute's totals)
     if (!(m->tune.ext_events && !m->profiling)) HIP_TRY(hipEventRecord(bs.back_done, m->stream));
     m->batch_seq++;
-    g_host_timer.lap(5);
-    if (g_host_timer.on) g_host_timer.calls++;
+    if (m->cfg.n_shards <= 1) {  // (the shards of a group are issued by a thread each: one unsynchronised timer would only record their race)
+        g_host_timer.lap(5);
+        if (g_host_timer.on) g_host_timer.calls++;
+    }
     return CHISEL_HIP_OK;
 }
 
@@ -1172,8 +1179,12 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     // the mesh recompute's job list, kept by the integration kernels (kernels_map.h: mesh_expand_dirty): a flag per slot, the ids of the
     // listed chunks (twice the pool: a removed chunk leaves its entry behind), the recompute totals + the list's length
     v.mesh_jobs_capacity = (int)std::min<size_t>(2 * C, (size_t)INT32_MAX / 4);
-    HIP_TRY_C(hipMalloc(&v.mesh_flag, C * sizeof(unsigned)));
-    HIP_TRY_C(hipMemsetAsync(v.mesh_flag, 0, C * sizeof(unsigned), m->stream));
+    // (a shard of a sharded map is meshed from a plan's job list, never from the kept one: without the flags mesh_expand_dirty returns at
+    // once, and a newly dirtied chunk costs its wave no 27 hash probes)
+    if (n_shards == 1) {
+        HIP_TRY_C(hipMalloc(&v.mesh_flag, C * sizeof(unsigned)));
+        HIP_TRY_C(hipMemsetAsync(v.mesh_flag, 0, C * sizeof(unsigned), m->stream));
+    }
     HIP_TRY_C(hipMalloc(&v.mesh_jobs, (size_t)v.mesh_jobs_capacity * 3 * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.mesh_ctl, MC_INTS * sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(v.mesh_ctl, 0, MC_INTS * sizeof(int), m->stream));
@@ -2153,227 +2164,6 @@ int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shar
             }
     return CHISEL_HIP_OK;
 }
-// The plans of ALL ranks in one pass (what every rank of the multi-process form and the in-library group need per recompute: their
-// own jobs, what they ask of every owner and what every other rank asks of them).  Same result, rank by rank, as
-// chisel_hip_mesh_shell_plan -- which walks std::set / std::map node by node, once per rank: 1-2 ms per rank and recompute at
-// 640x480 / 1 cm, i.e. 10-15 ms of host time per recompute on 8 ranks, against the 0.1 ms the GPUs need per step -- in 0.2-0.4 ms for
-// all of them: one dense grid over the bounding box of the entries (job flags, "next to a job" flags), one owner per 2x2x2 super-block,
-// and a single sweep over the cells next to a job in ascending id order: cell G, owned by o, is asked for by rank r through direction
-// d whenever J = G - d is a job of r -- so every (r, o) list comes out sorted by id without a sort.
-//   jobs:  ids, rank by rank (job_offsets[r] .. job_offsets[r + 1], in ids), ascending (x, y, z) within a rank
-//   items: (x, y, z, box) of pair p = r * n_shards + o = what r asks of o (item_offsets[p] .. item_offsets[p + 1]), ascending id, then box
-// Counts are always written (offsets hold n_shards + 1 and n_shards^2 + 1 entries); the arrays only when both capacities suffice.
-int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_shards, int shard_block, int *jobs, int64_t max_jobs, int64_t *job_offsets,
-                                   int *items, int64_t max_items, int64_t *item_offsets) {
-    if ((n_entries > 0 && !entries) || n_shards < 1 || n_shards > 64 || !job_offsets || !item_offsets) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
-    const int W = n_shards, sb = shard_block < 1 ? 2 : shard_block;
-    // bounding box of the jobs (entries, flag 0 expanded by one), plus two more cells (below)
-    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-    for (int64_t i = 0; i < n_entries; i++) {
-        const int *e = entries + 4 * i, r = e[3] ? 0 : 1;
-        for (int a = 0; a < 3; a++) {
-            lo[a] = std::min(lo[a], e[a] - r);
-            hi[a] = std::max(hi[a], e[a] + r);
-        }
-    }
-    thread_local std::vector<std::vector<int>> job_of, item_of;  // per rank / per pair, kept between calls (capacity, and the result itself)
-    // a caller asks twice -- sizes, then contents --: the second call finds the first one's result (same thread, same entries)
-    thread_local uint64_t cached_key = 0;
-    uint64_t key = 1469598103934665603ull ^ (uint64_t)W ^ ((uint64_t)sb << 8) ^ ((uint64_t)n_entries << 16);
-    for (int64_t i = 0; i < 4 * n_entries; i++) key = (key ^ (uint64_t)(uint32_t)entries[i]) * 1099511628211ull;
-    const bool cached = key == cached_key && (int)job_of.size() == W && (int)item_of.size() == W * W;
-    cached_key = 0;  // (set again below once the result is complete)
-    if (!cached) {
-    job_of.resize((size_t)W);
-    item_of.resize((size_t)W * W);
-    for (auto &v : job_of) v.clear();
-    for (auto &v : item_of) v.clear();
-    }
-    if (n_entries > 0 && !cached) {
-        int dim[3];
-        double cells_d = 1.0;
-        for (int a = 0; a < 3; a++) {
-            lo[a] -= 2;  // (the jobs' neighbours G, and the neighbours J = G - d of those)
-            hi[a] += 2;
-            dim[a] = hi[a] - lo[a] + 1;
-            cells_d *= (double)dim[a];
-        }
-        if (cells_d > 2.5e8) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "mesh plan: the updated chunks span more than 2.5e8 cells");
-        const size_t cells = (size_t)cells_d;
-        thread_local std::vector<unsigned char> flag;  // bit 0: job, bit 1: next to a job (or one itself)
-        flag.assign(cells, 0);
-        const size_t sy = (size_t)dim[2], sx = (size_t)dim[1] * dim[2];
-        auto cell = [&](int x, int y, int z) { return (size_t)(x - lo[0]) * sx + (size_t)(y - lo[1]) * sy + (size_t)(z - lo[2]); };
-        for (int64_t i = 0; i < n_entries; i++) {
-            const int *e = entries + 4 * i, r = e[3] ? 0 : 1;
-            for (int dx = -r; dx <= r; dx++)
-                for (int dy = -r; dy <= r; dy++)
-                    for (int dz = -r; dz <= r; dz++) {
-                        const size_t c = cell(e[0] + dx, e[1] + dy, e[2] + dz);
-                        if (flag[c] & 1) continue;
-                        flag[c] |= 1;
-                        for (int ax = -1; ax <= 1; ax++)
-                            for (int ay = -1; ay <= 1; ay++) {
-                                unsigned char *row = &flag[c + (size_t)((long)ax * (long)sx + (long)ay * (long)sy)];
-                                row[-1] |= 2; row[0] |= 2; row[1] |= 2;
-                            }
-                    }
-        }
-        // owner of a cell through its super-block: per axis the block index of every coordinate, per block the owner (chunk_owner's arithmetic)
-        std::vector<int> bidx[3];
-        int b0[3], nb[3];
-        for (int a = 0; a < 3; a++) {
-            b0[a] = floor_div(lo[a], sb);
-            nb[a] = floor_div(hi[a], sb) - b0[a] + 1;
-            bidx[a].resize((size_t)dim[a]);
-            for (int k = 0; k < dim[a]; k++) bidx[a][(size_t)k] = floor_div(lo[a] + k, sb) - b0[a];
-        }
-        std::vector<unsigned char> bowner((size_t)nb[0] * nb[1] * nb[2]);
-        for (int bx = 0; bx < nb[0]; bx++)
-            for (int by = 0; by < nb[1]; by++)
-                for (int bz = 0; bz < nb[2]; bz++)
-                    bowner[((size_t)bx * nb[1] + by) * nb[2] + bz] = (unsigned char)chunk_owner((b0[0] + bx) * sb, (b0[1] + by) * sb, (b0[2] + bz) * sb, W, sb);
-        auto owner_at = [&](int ix, int iy, int iz) { return (int)bowner[((size_t)bidx[0][(size_t)ix] * nb[1] + bidx[1][(size_t)iy]) * nb[2] + bidx[2][(size_t)iz]]; };
-        // box code of direction d = G - J (what J reads of G): per axis d > 0 -> {0, 1} (1), d < 0 -> {N - 1} (2), 0 -> all (0)
-        auto axis_within = [](int a, int b) { return b == 0 || a == b || (b == 3 && a != 0); };
-        auto box_within = [&](int a, int b) { return axis_within(a & 3, b & 3) && axis_within((a >> 2) & 3, (b >> 2) & 3) && axis_within((a >> 4) & 3, (b >> 4) & 3); };
-        // the owner of every cell that is a job or next to one, once (the sweep below asks for a job neighbour's owner 13 times per cell)
-        thread_local std::vector<unsigned char> own;
-        own.resize(cells);
-        for (int ix = 0; ix < dim[0]; ix++)
-            for (int iy = 0; iy < dim[1]; iy++) {
-                const size_t base = (size_t)ix * sx + (size_t)iy * sy;
-                for (int iz = 0; iz < dim[2]; iz++)
-                    if (flag[base + (size_t)iz]) own[base + (size_t)iz] = (unsigned char)owner_at(ix, iy, iz);
-            }
-        unsigned asked[64];  // per requesting rank: the directions (bit (dx + 1) * 9 + (dy + 1) * 3 + dz + 1) through which G is asked for
-        long nb_off[27];     // cell offset of direction bit (dx + 1) * 9 + (dy + 1) * 3 + dz + 1
-        for (int dx = -1; dx <= 1; dx++)
-            for (int dy = -1; dy <= 1; dy++)
-                for (int dz = -1; dz <= 1; dz++) nb_off[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = (long)dx * (long)sx + (long)dy * (long)sy + (long)dz;
-        for (int ix = 0; ix < dim[0]; ix++)
-            for (int iy = 0; iy < dim[1]; iy++) {
-                const unsigned char *row = &flag[(size_t)ix * sx + (size_t)iy * sy];
-                for (int iz = 0; iz < dim[2]; iz++) {
-                    if (!row[iz]) continue;
-                    const int gx = lo[0] + ix, gy = lo[1] + iy, gz = lo[2] + iz;
-                    const int o = own[(size_t)ix * sx + (size_t)iy * sy + (size_t)iz];
-                    if (row[iz] & 1) {
-                        std::vector<int> &jv = job_of[(size_t)o];
-                        jv.push_back(gx); jv.push_back(gy); jv.push_back(gz);
-                    }
-                    // (cells on the rim of the grid are never next to a job: the box was widened by two beyond the jobs' own rim)
-                    if (ix == 0 || iy == 0 || iz == 0 || ix == dim[0] - 1 || iy == dim[1] - 1 || iz == dim[2] - 1) continue;
-                    // which of the 26 neighbours J = G - d are jobs: one bit per direction, gathered without a branch (the flags are as good
-                    // as random to a branch predictor: the tested form of this loop spent most of its time mispredicting), then only the
-                    // set bits are visited
-                    const size_t gc = (size_t)ix * sx + (size_t)iy * sy + (size_t)iz;
-                    unsigned jm = 0u;
-                    for (int bit = 0; bit < 27; bit++) jm |= (unsigned)(flag[(size_t)((long)gc - nb_off[bit])] & 1) << bit;
-                    jm &= ~(1u << 13);
-                    unsigned long long who = 0ull;
-                    while (jm) {
-                        const int bit = __builtin_ctz(jm);
-                        jm &= jm - 1u;
-                        const int r = own[(size_t)((long)gc - nb_off[bit])];
-                        if (r == o) continue;
-                        if (!((who >> r) & 1ull)) {
-                            who |= 1ull << r;
-                            asked[r] = 0u;
-                        }
-                        asked[r] |= 1u << bit;
-                    }
-                    while (who) {
-                        const int r = __builtin_ctzll(who);
-                        who &= who - 1ull;
-                        // the boxes of (r, G): as chisel_hip_mesh_shell_plan builds them, in its order of arrival -- the jobs ascending, i.e. the
-                        // directions d = G - J descending -- : a box another one contains is dropped, then the two ends of one axis become one box
-                        // (the boxes are a function of the direction mask alone, and a recompute sees a few hundred distinct masks for tens of
-                        // thousands of (r, G) pairs: built once per mask and thread)
-                        struct Boxes { unsigned mask; int n; int v[14]; };  // (mask 0 = empty entry: a direction mask is never 0 here)
-                        constexpr unsigned MEMO = 1u << 13;
-                        thread_local std::vector<Boxes> memo(MEMO, Boxes{0u, 0, {0}});
-                        unsigned mh = (asked[r] * 2654435761u) >> 19;
-                        while (memo[mh].mask != 0u && memo[mh].mask != asked[r]) mh = (mh + 1u) & (MEMO - 1u);
-                        Boxes *hit = &memo[mh];
-                        if (hit->mask == 0u) {
-                        int v[26], nv = 0;
-                        for (int dx = 1; dx >= -1; dx--)
-                            for (int dy = 1; dy >= -1; dy--)
-                                for (int dz = 1; dz >= -1; dz--) {
-                                    if (!((asked[r] >> ((dx + 1) * 9 + (dy + 1) * 3 + (dz + 1))) & 1u)) continue;
-                                    const int d[3] = {dx, dy, dz};
-                                    int box = 0;
-                                    for (int a = 0; a < 3; a++) box |= (d[a] > 0 ? 1 : (d[a] < 0 ? 2 : 0)) << (2 * a);
-                                    bool covered = false;
-                                    for (int k = 0; k < nv; k++) covered = covered || box_within(box, v[k]);
-                                    if (covered) continue;
-                                    int keep = 0;
-                                    for (int k = 0; k < nv; k++)
-                                        if (!box_within(v[k], box)) v[keep++] = v[k];
-                                    nv = keep;
-                                    v[nv++] = box;
-                                }
-                        bool merged = true;
-                        while (merged) {
-                            merged = false;
-                            for (int i = 0; i < nv && !merged; i++)
-                                for (int k = i + 1; k < nv && !merged; k++)
-                                    for (int a = 0; a < 3 && !merged; a++) {
-                                        const int m3 = 3 << (2 * a), ca = (v[i] >> (2 * a)) & 3, cb = (v[k] >> (2 * a)) & 3;
-                                        if ((v[i] & ~m3) == (v[k] & ~m3) && ca != 0 && cb != 0 && ca != cb) {
-                                            v[i] = (v[i] & ~m3) | (3 << (2 * a));
-                                            for (int q = k; q + 1 < nv; q++) v[q] = v[q + 1];
-                                            nv--;
-                                            merged = true;
-                                        }
-                                    }
-                        }
-                        std::sort(v, v + nv);
-                        if (nv > 14) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "mesh plan: more than 14 boxes for one ghost");  // (cannot happen: at most 8 disjoint corner boxes survive the covering rule)
-                        thread_local unsigned memo_used = 0;
-                        if (++memo_used > MEMO / 2) {  // (never seen: a few hundred distinct masks exist) start over rather than fill up
-                            for (Boxes &e2 : memo) e2.mask = 0u;
-                            memo_used = 1;
-                            mh = (asked[r] * 2654435761u) >> 19;
-                            hit = &memo[mh];
-                        }
-                        hit->mask = asked[r];
-                        hit->n = nv;
-                        for (int k = 0; k < nv; k++) hit->v[k] = v[k];
-                        }
-                        const Boxes &B = *hit;
-                        std::vector<int> &iv = item_of[(size_t)r * W + o];
-                        const size_t at = iv.size();
-                        iv.resize(at + 4 * (size_t)B.n);
-                        int *out4 = iv.data() + at;
-                        for (int k = 0; k < B.n; k++) {
-                            out4[4 * k] = gx; out4[4 * k + 1] = gy; out4[4 * k + 2] = gz; out4[4 * k + 3] = B.v[k];
-                        }
-                    }
-                }
-            }
-    }
-    cached_key = key;
-    int64_t tj = 0, ti = 0;
-    for (int r = 0; r < W; r++) {
-        job_offsets[r] = tj;
-        tj += (int64_t)job_of[(size_t)r].size() / 3;
-    }
-    job_offsets[W] = tj;
-    for (int p2 = 0; p2 < W * W; p2++) {
-        item_offsets[p2] = ti;
-        ti += (int64_t)item_of[(size_t)p2].size() / 4;
-    }
-    item_offsets[W * W] = ti;
-    if (jobs && items && tj <= max_jobs && ti <= max_items) {
-        for (int r = 0; r < W; r++)
-            if (!job_of[(size_t)r].empty()) memcpy(jobs + 3 * job_offsets[r], job_of[(size_t)r].data(), job_of[(size_t)r].size() * sizeof(int));
-        for (int p2 = 0; p2 < W * W; p2++)
-            if (!item_of[(size_t)p2].empty()) memcpy(items + 4 * item_offsets[p2], item_of[(size_t)p2].data(), item_of[(size_t)p2].size() * sizeof(int));
-    }
-    return CHISEL_HIP_OK;
-}
 // voxels in the payload of a box of a chunk of edge n
 int64_t chisel_hip_shell_volume(int box, int chunk_edge) { return (int64_t)shell_volume(box, chunk_edge); }
 
@@ -2524,8 +2314,14 @@ int chisel_hip_meshes_to_update_since(chisel_hip_map *m, uint64_t cursor[2], int
         HIP_TRY(hipHostMalloc((void **)&m->dirty_tail_host, (2 + 3 * (size_t)DIRTY_TAIL_CAP) * sizeof(int), hipHostMallocDefault));
         HIP_TRY(hipHostGetDevicePointer((void **)&m->dirty_tail_dev, m->dirty_tail_host, 0));
     }
-    hipLaunchKernelGGL(list_dirty_tail_kernel, dim3(1), dim3(256), 0, m->stream, m->view, from, m->dirty_tail_dev, DIRTY_TAIL_CAP);
-    HIP_TRY(hipGetLastError());
+    // (the kernel may have been queued behind the integration already -- chisel_hip_meshes_to_update_prefetch -- and the caller's wait for the
+    // integration then covered it: no launch and no second wait here)
+    const bool prefetched = m->dirty_tail_queued && !restart && m->dirty_tail_cursor == cursor[0] && m->dirty_tail_batch == m->batch_seq;
+    m->dirty_tail_queued = false;
+    if (!prefetched) {
+        hipLaunchKernelGGL(list_dirty_tail_kernel, dim3(1), dim3(256), 0, m->stream, m->view, from, m->dirty_tail_dev, DIRTY_TAIL_CAP);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(wait_stream_spinning(m->stream));
     std::atomic_thread_fence(std::memory_order_acquire);
     const unsigned listed = (unsigned)m->dirty_tail_host[0];
@@ -2554,6 +2350,26 @@ int chisel_hip_meshes_to_update_since(chisel_hip_map *m, uint64_t cursor[2], int
     }
     cursor[0] = (epoch_tag << 32) | (uint64_t)std::min(listed, (unsigned)m->view.max_chunks);
     cursor[1] = m->pending_version;
+    return CHISEL_HIP_OK;
+}
+
+// Queues the listing of chisel_hip_meshes_to_update_since behind what the map has queued so far (the integration of the frame just
+// handed over) without waiting: the caller's own wait for that integration (chisel_hip_synchronize: the reference's calls are synchronous)
+// then covers the listing too, and the _since call that follows finds its result.  Nothing happens for a cursor of another epoch.
+int chisel_hip_meshes_to_update_prefetch(chisel_hip_map *m, const uint64_t cursor[2]) {
+    if (!m || !cursor) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    if (m->is_group) return CHISEL_HIP_OK;
+    if ((cursor[0] >> 32) != (uint64_t)m->dirty_epoch + 1u) return CHISEL_HIP_OK;  // (the set was emptied since: the _since call starts over)
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->dirty_tail_host) {
+        HIP_TRY(hipHostMalloc((void **)&m->dirty_tail_host, (2 + 3 * (size_t)DIRTY_TAIL_CAP) * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(hipHostGetDevicePointer((void **)&m->dirty_tail_dev, m->dirty_tail_host, 0));
+    }
+    hipLaunchKernelGGL(list_dirty_tail_kernel, dim3(1), dim3(256), 0, m->stream, m->view, (unsigned)(cursor[0] & 0xffffffffull), m->dirty_tail_dev, DIRTY_TAIL_CAP);
+    HIP_TRY(hipGetLastError());
+    m->dirty_tail_queued = true;
+    m->dirty_tail_cursor = cursor[0];
+    m->dirty_tail_batch = m->batch_seq;
     return CHISEL_HIP_OK;
 }
 

@@ -29,14 +29,67 @@ struct Stage {                       // device frames copied to a shard on anoth
     unsigned turn = 0;
 };
 
+// HOST frames of a group (what chisel_ros hands over: Conversions.h:107-200) reach the devices ONCE: one copy over the bus into a staging
+// set on the launch set's ingest device (the devices take turns), from there RCCL broadcasts it to the other devices of the group over
+// xGMI (ncclBroadcast on every device's copy stream, one grouped call), and the shards that share a device read the same staged copy.
+// Before round 5 every shard staged its own copy: eight shards, eight reads of one 2.1 MB frame over PCIe.  RCCL is loaded at run time
+// (librccl.so, only when the group spans two or more devices: a process that also holds torch's copy of the library meets it once).
+struct Rccl {
+    typedef int (*InitAll)(void **, int, const int *);
+    typedef int (*Bcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*Void)();
+    typedef int (*Destroy)(void *);
+    InitAll comm_init_all = nullptr;
+    Bcast broadcast = nullptr;
+    Void group_start = nullptr, group_end = nullptr;
+    Destroy comm_destroy = nullptr;
+    bool load() {
+        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return false;
+        comm_init_all = reinterpret_cast<InitAll>(dlsym(h, "ncclCommInitAll"));
+        broadcast = reinterpret_cast<Bcast>(dlsym(h, "ncclBroadcast"));
+        group_start = reinterpret_cast<Void>(dlsym(h, "ncclGroupStart"));
+        group_end = reinterpret_cast<Void>(dlsym(h, "ncclGroupEnd"));
+        comm_destroy = reinterpret_cast<Destroy>(dlsym(h, "ncclCommDestroy"));
+        return comm_init_all && broadcast && group_start && group_end && comm_destroy;
+    }
+};
+struct DeviceStage {                 // per distinct device of the group: two staging sets that alternate per launch set
+    int device = 0;
+    float *depth[2] = {nullptr, nullptr};
+    uint8_t *color[2] = {nullptr, nullptr};
+    hipStream_t copy = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr};
+    void *comm = nullptr;            // ncclComm_t of this device (groups over two or more devices)
+};
+struct HostFanout {
+    std::vector<DeviceStage> dev;    // distinct devices, in order of first appearance
+    std::vector<int> dev_of_shard;   // index into dev
+    std::vector<hipEvent_t> consumed[2];  // [set][shard]: the shard has integrated the launch set that used this staging set
+    bool armed[2] = {false, false};
+    size_t depth_elems = 0, color_bytes = 0;  // per frame
+    unsigned turn = 0;
+    Rccl rccl;
+    bool rccl_ready = false;
+};
+
 // One issuing host thread per shard.  A launch set costs the host 35-120 us to issue (five to six kernel launches, a handful of event
 // calls); eight shards issued in turn by the caller's thread cost eight times that per batch, which capped a group below the rate of ONE
 // map.  The shard maps share nothing, so every call that fans out over the shards -- integrate, the phases of update_meshes, the id
 // listings -- hands shard i's part to worker i and joins.  Workers spin for a while after a job (a stream of frames keeps them hot: a
 // condition-variable wake-up costs as much as the job) and then sleep; shard 0's part runs on the calling thread.
 // CHISEL_HIP_GROUP_THREADS=0: everything on the calling thread, in turn (A/B, debugging).
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
 struct Pool {
     std::vector<std::thread> workers;           // worker w serves shard w + 1
+    std::mutex fan;                             // one fan-out at a time: a second caller thread (a mesh / publish thread beside the integrating one) waits its turn
     std::function<int(int)> job;
     std::atomic<uint64_t> seq{0};               // bumped once per fan-out
     std::atomic<int> done{0};
@@ -60,12 +113,17 @@ struct Pool {
                     cv.wait(lk, [&] { return seq.load() != seen || stop.load(); });
                     sleepers.fetch_sub(1);
                 } else {
-                    __builtin_ia32_pause();
+                    cpu_relax();
                 }
             }
             if (stop.load()) return;
             seen = seq.load(std::memory_order_acquire);
-            const int r = job(shard);
+            int r;
+            try {
+                r = job(shard);
+            } catch (const std::exception &e) {  // (bad_alloc from a vector inside a job: an error of the call, not the end of the process)
+                r = fail(CHISEL_HIP_ERR_INVALID, std::string("group worker: ") + e.what());
+            }
             rc[(size_t)shard] = r;
             if (r) err[(size_t)shard] = g_last_error;
             done.fetch_add(1, std::memory_order_release);
@@ -103,6 +161,7 @@ int run_shards(chisel_hip_map *g, F fn) {
         }
         return CHISEL_HIP_OK;
     }
+    std::lock_guard<std::mutex> one_at_a_time(P->fan);
     P->job = fn;
     P->done.store(0, std::memory_order_relaxed);
     P->seq.fetch_add(1);
@@ -110,8 +169,16 @@ int run_shards(chisel_hip_map *g, F fn) {
         std::lock_guard<std::mutex> lk(P->mu);
         P->cv.notify_all();
     }
-    const int rc0 = fn(0);
-    while (P->done.load(std::memory_order_acquire) < W - 1) __builtin_ia32_pause();
+    int rc0;
+    try {
+        rc0 = fn(0);
+    } catch (const std::exception &e) {
+        rc0 = fail(CHISEL_HIP_ERR_INVALID, std::string("group: ") + e.what());
+    }
+    for (unsigned spins = 0; P->done.load(std::memory_order_acquire) < W - 1; spins++) {
+        if (spins < (1u << 14)) cpu_relax();
+        else std::this_thread::yield();  // (a worker that was descheduled: give it the core)
+    }
     if (rc0) return rc0;
     for (int i = 1; i < W; i++)
         if (P->rc[(size_t)i]) return fail(P->rc[(size_t)i], P->err[(size_t)i]);
@@ -147,6 +214,23 @@ int create(const chisel_hip_config *cfg, const int *device_ids, int n, chisel_hi
     g->V = g->shards[0]->V;
     g->device = g->shards[0]->device;
     g->stages = new std::vector<Stage>(n);
+    {
+        HostFanout *F = new HostFanout();
+        for (int i = 0; i < n; i++) {
+            int k = -1;
+            for (size_t d = 0; d < F->dev.size(); d++)
+                if (F->dev[d].device == g->shards[(size_t)i]->device) k = (int)d;
+            if (k < 0) {
+                F->dev.emplace_back();
+                F->dev.back().device = g->shards[(size_t)i]->device;
+                k = (int)F->dev.size() - 1;
+            }
+            F->dev_of_shard.push_back(k);
+        }
+        F->consumed[0].assign((size_t)n, nullptr);
+        F->consumed[1].assign((size_t)n, nullptr);
+        g->host_fanout = F;
+    }
     {
         Pool *P = new Pool();
         P->rc.assign((size_t)n, 0);
@@ -205,6 +289,28 @@ int destroy(chisel_hip_map *g) {
         delete MS;
         g->mesh_stages_group = nullptr;
     }
+    if (HostFanout *F = static_cast<HostFanout *>(g->host_fanout)) {
+        for (chisel_hip_map *sh : g->shards) (void)chisel_hip_synchronize(sh);
+        for (DeviceStage &D : F->dev) {
+            (void)hipSetDevice(D.device);
+            if (D.copy) (void)hipStreamSynchronize(D.copy);
+            if (D.comm && F->rccl.comm_destroy) (void)F->rccl.comm_destroy(D.comm);
+            for (int b = 0; b < 2; b++) {
+                if (D.depth[b]) (void)hipFree(D.depth[b]);
+                if (D.color[b]) (void)hipFree(D.color[b]);
+                if (D.ready[b]) (void)hipEventDestroy(D.ready[b]);
+            }
+            if (D.copy) (void)hipStreamDestroy(D.copy);
+        }
+        for (int b = 0; b < 2; b++)
+            for (size_t i = 0; i < F->consumed[b].size(); i++)
+                if (F->consumed[b][i]) {
+                    (void)hipSetDevice(g->shards[i]->device);
+                    (void)hipEventDestroy(F->consumed[b][i]);
+                }
+        delete F;
+        g->host_fanout = nullptr;
+    }
     std::vector<Stage> *st = static_cast<std::vector<Stage> *>(g->stages);
     for (size_t i = 0; i < g->shards.size(); i++) {
         if (st) {
@@ -252,11 +358,113 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
     size_t cbytes = 0;
     if (colors)
         for (int k = 0; k < n; k++) cbytes = std::max(cbytes, (size_t)colors[k].width * colors[k].height * colors[k].channels);
-    return run_shards(g, [&](int i) -> int {
+    // ---- host frames: staged once (HostFanout), every shard then sees device frames of its own device
+    HostFanout &F = *static_cast<HostFanout *>(g->host_fanout);
+    bool host_frames = n_shards(g) > 1;
+    for (int k = 0; k < n; k++) host_frames = host_frames && !frames[k].on_device && (!colors || !colors[k].on_device);
+    int fb = -1;
+    if (host_frames) {
+        const int ND = (int)F.dev.size();
+        if (ND > 1 && !F.rccl_ready) {
+            if (!F.rccl.load()) return fail(CHISEL_HIP_ERR_HIP, "group over several devices: librccl.so could not be loaded (frame fan-out over xGMI)");
+            std::vector<void *> comms((size_t)ND, nullptr);
+            std::vector<int> devs;
+            for (const DeviceStage &D : F.dev) devs.push_back(D.device);
+            if (F.rccl.comm_init_all(comms.data(), ND, devs.data()) != 0) return fail(CHISEL_HIP_ERR_HIP, "ncclCommInitAll failed for the group's devices");
+            for (int d = 0; d < ND; d++) F.dev[(size_t)d].comm = comms[(size_t)d];
+            F.rccl_ready = true;
+        }
+        // buffers (both sets of every device) and events
+        if (npx > F.depth_elems || cbytes > F.color_bytes || !F.dev[0].copy) {
+            for (chisel_hip_map *sh : g->shards) {
+                int rc = chisel_hip_synchronize(sh);
+                if (rc) return rc;
+            }
+            const size_t de = std::max(npx, F.depth_elems), cb = std::max(cbytes, F.color_bytes);
+            for (DeviceStage &D : F.dev) {
+                HIP_TRY(hipSetDevice(D.device));
+                if (!D.copy) {
+                    HIP_TRY(hipStreamCreateWithFlags(&D.copy, hipStreamNonBlocking));
+                    for (int b = 0; b < 2; b++) HIP_TRY(hipEventCreateWithFlags(&D.ready[b], hipEventDisableTiming));
+                }
+                HIP_TRY(hipStreamSynchronize(D.copy));
+                for (int b = 0; b < 2; b++) {
+                    if (D.depth[b]) HIP_TRY(hipFree(D.depth[b]));
+                    if (D.color[b]) HIP_TRY(hipFree(D.color[b]));
+                    D.depth[b] = nullptr;
+                    D.color[b] = nullptr;
+                    HIP_TRY(hipMalloc(&D.depth[b], de * KMAX * sizeof(float)));
+                    if (cb) HIP_TRY(hipMalloc(&D.color[b], cb * KMAX));
+                }
+            }
+            for (int b = 0; b < 2; b++) {
+                F.armed[b] = false;
+                for (size_t i = 0; i < g->shards.size(); i++)
+                    if (!F.consumed[b][i]) {
+                        HIP_TRY(hipSetDevice(g->shards[i]->device));
+                        HIP_TRY(hipEventCreateWithFlags(&F.consumed[b][i], hipEventDisableTiming));
+                    }
+            }
+            F.depth_elems = de;
+            F.color_bytes = cb;
+        }
+        fb = (int)(F.turn & 1u);
+        const int root = (int)((F.turn >> 1) % (unsigned)ND);  // the ingest device: the devices take turns
+        F.turn++;
+        // the launch set that last used this staging set has been integrated by every shard
+        for (DeviceStage &D : F.dev) {
+            HIP_TRY(hipSetDevice(D.device));
+            if (F.armed[fb])
+                for (size_t i = 0; i < g->shards.size(); i++) HIP_TRY(hipStreamWaitEvent(D.copy, F.consumed[fb][i], 0));
+        }
+        DeviceStage &R = F.dev[(size_t)root];
+        HIP_TRY(hipSetDevice(R.device));
+        for (int k = 0; k < n; k++) {
+            HIP_TRY(hipMemcpyAsync(R.depth[fb] + (size_t)k * F.depth_elems, frames[k].depth, npx * sizeof(float), hipMemcpyHostToDevice, R.copy));
+            if (colors)
+                HIP_TRY(hipMemcpyAsync(R.color[fb] + (size_t)k * F.color_bytes, colors[k].color, (size_t)colors[k].width * colors[k].height * colors[k].channels,
+                                       hipMemcpyHostToDevice, R.copy));
+        }
+        if (ND > 1) {
+            // xGMI fan-out: one broadcast of the depth block and one of the colour block per device, all in one group call
+            if (F.rccl.group_start() != 0) return fail(CHISEL_HIP_ERR_HIP, "ncclGroupStart failed");
+            for (int d = 0; d < ND; d++) {
+                DeviceStage &D = F.dev[(size_t)d];
+                if (F.rccl.broadcast(R.depth[fb], D.depth[fb], (size_t)n * F.depth_elems, /* ncclFloat32 */ 7, root, D.comm, D.copy) != 0)
+                    return fail(CHISEL_HIP_ERR_HIP, "ncclBroadcast (depth) failed");
+                if (colors && F.rccl.broadcast(R.color[fb], D.color[fb], (size_t)n * F.color_bytes, /* ncclUint8 */ 1, root, D.comm, D.copy) != 0)
+                    return fail(CHISEL_HIP_ERR_HIP, "ncclBroadcast (colour) failed");
+            }
+            if (F.rccl.group_end() != 0) return fail(CHISEL_HIP_ERR_HIP, "ncclGroupEnd failed");
+        }
+        for (DeviceStage &D : F.dev) {
+            HIP_TRY(hipSetDevice(D.device));
+            HIP_TRY(hipEventRecord(D.ready[fb], D.copy));
+        }
+    }
+    const int rc_all = run_shards(g, [&](int i) -> int {
         chisel_hip_map *s = g->shards[(size_t)i];
         std::vector<chisel_hip_depth_frame> f(frames, frames + n);
         std::vector<chisel_hip_color_frame> c;
         if (colors) c.assign(colors, colors + n);
+        if (host_frames) {
+            // the staged copy on this shard's device, ready behind the device's event; `consumed` tells the next user of the staging set
+            const DeviceStage &D = F.dev[(size_t)F.dev_of_shard[(size_t)i]];
+            HIP_TRY(hipSetDevice(s->device));
+            for (int k = 0; k < n; k++) {
+                f[k].depth = D.depth[fb] + (size_t)k * F.depth_elems;
+                f[k].on_device = 1;
+                if (colors) {
+                    c[k].color = D.color[fb] + (size_t)k * F.color_bytes;
+                    c[k].on_device = 1;
+                }
+            }
+            int rc = chisel_hip_wait_event(s, D.ready[fb]);
+            if (rc) return rc;
+            rc = chisel_hip_integrate_batch(s, n, f.data(), colors ? c.data() : nullptr);
+            if (rc) return rc;
+            return chisel_hip_record_event(s, F.consumed[fb][(size_t)i]);
+        }
         bool foreign = false;
         for (int k = 0; k < n; k++) {
             foreign |= f[k].on_device && (force_stage || device_of(f[k].depth, s->device) != s->device);
@@ -325,6 +533,8 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
         }
         return CHISEL_HIP_OK;
     });
+    if (!rc_all && fb >= 0) F.armed[fb] = true;
+    return rc_all;
 }
 
 // frames in order; consecutive frames of one image size go out KMAX at a time (as integrate_frames cuts them for one map)

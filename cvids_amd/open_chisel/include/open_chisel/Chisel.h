@@ -773,6 +773,7 @@ class Chisel {  // Chisel.h:38-230
         hip_check(chisel_hip_set_integrator(map, &in));
         chisel_hip_depth_frame f = hipfacade::DepthFrame(*depthImage, extrinsic, camera);
         hip_check(chisel_hip_integrate_depth(map, &f));
+        hip_check(chisel_hip_meshes_to_update_prefetch(map, updateCursor));  // (GetMeshesToUpdate is what chisel_ros asks next: its listing rides on the wait below)
         hip_check(chisel_hip_synchronize(map));  // the reference returns with every voxel update visible
     }
     template <class DataType, class ColorType>
@@ -796,6 +797,7 @@ class Chisel {  // Chisel.h:38-230
         c.cx = colorCamera.GetIntrinsics().GetCx();
         c.cy = colorCamera.GetIntrinsics().GetCy();
         hip_check(chisel_hip_integrate_depth_color(map, &f, &c));
+        hip_check(chisel_hip_meshes_to_update_prefetch(map, updateCursor));  // (GetMeshesToUpdate is what chisel_ros asks next, ChiselServer.cpp:346: its listing rides on the wait below)
         hip_check(chisel_hip_synchronize(map));
     }
     // Chisel.cpp:107-157 (fusion_mode = PointCloud, ChiselServer.cpp:523; CVIDS itself launches DepthImage mode, sample.launch:21)

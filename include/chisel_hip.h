@@ -209,6 +209,9 @@ int chisel_hip_meshes_to_update(chisel_hip_map *map, int *ids_xyz, int64_t max_i
  * Chisel.cpp:57, or Reset): the caller empties its copy first.  When more than max_ids ids are due nothing is consumed: *count says how
  * many, call again with room for them.  Cost: proportional to what changed since the cursor, not to the map. */
 int chisel_hip_meshes_to_update_since(chisel_hip_map *map, uint64_t cursor[2], int *ids_xyz, int64_t max_ids, int64_t *count, int *cleared);
+/* queues that listing behind the integration just handed over, without waiting: the caller's chisel_hip_synchronize then covers it and the
+ * _since call that follows (same cursor, nothing integrated in between) neither launches nor waits */
+int chisel_hip_meshes_to_update_prefetch(chisel_hip_map *map, const uint64_t cursor[2]);
 /* ChunkManager::GetAllMeshes ChunkManager.h:163-166 */
 int chisel_hip_num_meshes(chisel_hip_map *map, int64_t *out);
 int chisel_hip_list_meshes(chisel_hip_map *map, int *ids_xyz, int64_t max_ids, int64_t *count);
@@ -361,11 +364,6 @@ int64_t chisel_hip_shell_segment_bytes(chisel_hip_map *map, int64_t items, int64
 int chisel_hip_export_shells_packed(chisel_hip_map *map, void *out_dev, int64_t bytes);
 int chisel_hip_import_shells_packed(chisel_hip_map *map, const void *in_dev, int64_t bytes);
 int chisel_hip_update_meshes_planned(chisel_hip_map *map);
-/* the plans of ALL ranks in one pass, rank by rank the result of chisel_hip_mesh_shell_plan: jobs of rank r at job_offsets[r] ..
- * job_offsets[r + 1] (n_shards + 1 offsets, in ids), items (x, y, z, box) that r asks of o at item_offsets[r * n_shards + o] .. [+ 1]
- * (n_shards^2 + 1 offsets, in items); offsets are always written, the arrays when both capacities suffice */
-int chisel_hip_mesh_shell_plan_all(const int *entries, int64_t n_entries, int n_shards, int shard_block, int *jobs, int64_t max_jobs,
-                                   int64_t *job_offsets, int *items, int64_t max_items, int64_t *item_offsets);
 int64_t chisel_hip_shell_volume(int box, int chunk_edge);
 int chisel_hip_export_shells(chisel_hip_map *map, const int *items, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device);
 int chisel_hip_import_ghost_shells(chisel_hip_map *map, const int *items, int n, const float *sdf, const float *weight, const uint8_t *rgbw,

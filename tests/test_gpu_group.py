@@ -206,3 +206,25 @@ def test_group_workers_sleep_and_wake_between_calls(oracle_mod):
     cg, cs = grp.counters(), single.counters()
     for k in ("sdf", "col", "col_sat", "probe", "carved", "new_chunks", "updated_chunks", "frames"):
         assert cg[k] == cs[k], (k, cg[k], cs[k])
+
+
+def test_group_rate_on_one_device():
+    """A regression guard, not a target: two shards of a group on ONE device (each runs the whole front half for every frame, and both
+    contend for one device's runtime lock) must keep at least 0.4 x the rate of a single map on the 4-agent stream without meshing
+    (measured in round 5: 0.73 x; 0.35 x before the group had an issuing thread per shard).  Eight devices are the deployment this is
+    for; the one-GPU box cannot say anything about them (multi-GPU)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def rate(group):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--agents", "4", "--mesh-every", "0", "--batch", "16", "--steps", "160", "--warmup", "32",
+                              "--group", str(group), "--no-cpu-baseline", "--no-roofline", "--no-pcie-leg", "--no-e2e-leg", "--repeats", "3"],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["value"]
+
+    one, two = rate(0), rate(2)
+    assert two >= 0.4 * one, (one, two)

@@ -287,6 +287,9 @@ def test_meshes_to_update_kept_incrementally(oracle_mod):
     for k, (d, p) in enumerate(frames):
         om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
         gm.IntegrateDepthScanColor(integ, d, p, cam, color, p, cam)
+        if k % 2:  # the facade's form: the listing queued behind the integration, one wait for both
+            gm.PrefetchMeshesToUpdate(cursor)
+            gm.synchronize()
         step(8 if k == 2 else 8192)
         if k == 4:  # dirty chunks disappear: their neighbourhoods stay in the set (Chisel.h:228 lives on the host)
             victims = gm.GetChunkIDs()[::3]

@@ -466,24 +466,35 @@ def test_cull_space_enumerates_exactly_the_owned_ids(hip_lib):
             assert slots <= len(box) + 8 * n * (dim[1] // 2 + 2) * (dim[2] // 2 + 2) * 2   # partial super-blocks and the rounded-up rows only
 
 
-def test_all_ranks_planner_equals_the_per_rank_planner(hip_lib):
-    """chisel_hip_mesh_shell_plan_all (one dense-grid sweep for all ranks) gives, rank by rank, exactly what chisel_hip_mesh_shell_plan
-    (std::set / std::map, one rank per call) gives: jobs, items, box codes and their order -- scattered and contiguous dirty sets, entries
-    of both flags, 1 to 16 shards, three super-block sizes."""
-    from cvids_amd.chisel import mesh_shell_plan, mesh_shell_plan_all
+def test_unmerged_device_plan_covers_what_the_merging_host_planner_asks_for(hip_lib):
+    """The plan of round 5 (cvids_amd.sharded.plan_shells_reference = what chisel_hip_shell_plan_device computes: one item per (job,
+    direction), nothing merged) against chisel_hip_mesh_shell_plan (the host planner of rounds 3-4: a box another one contains is dropped,
+    the two ends of one axis become one box): the same jobs, the same ghosts per owner, and per ghost the same set of voxels -- the
+    unmerged items overlap, their union is what the merged boxes hold.  Scattered and contiguous dirty sets, entries of both flags."""
+    from cvids_amd.chisel import chunk_owner, mesh_shell_plan
+    from cvids_amd.sharded import plan_shells_reference, shell_box_coords
     rng = np.random.default_rng(11)
-    shell = rng.normal(size=(300, 3))
-    shell = np.unique(np.floor(shell / np.linalg.norm(shell, axis=1)[:, None] * 9.3).astype(np.int32), axis=0)
+    shell = rng.normal(size=(120, 3))
+    shell = np.unique(np.floor(shell / np.linalg.norm(shell, axis=1)[:, None] * 6.3).astype(np.int32), axis=0)
     slab = np.stack(np.meshgrid(np.arange(-3, 4), np.arange(-2, 3), [5, 6], indexing="ij"), -1).reshape(-1, 3).astype(np.int32)
-    for ids in (shell, slab, np.array([[0, 0, 0]], np.int32), np.zeros((0, 3), np.int32)):
+    E = 8
+    for ids in (shell, slab, np.array([[0, 0, 0]], np.int32)):
         ent = np.concatenate([ids, np.zeros((len(ids), 1), np.int32)], 1)
         ent[::5, 3] = 1
-        for world in (1, 2, 3, 8, 16):
-            for sb in (1, 2, 3):
-                jobs, items = mesh_shell_plan_all(ent, world, sb)
-                for r in range(world):
-                    rj, ri = mesh_shell_plan(ent, world, r, sb)
-                    assert np.array_equal(rj, jobs[r]), (world, sb, r)
-                    got = [np.concatenate([np.full((len(items[(r, o)]), 1), o, np.int32), items[(r, o)]], 1) for o in range(world) if (r, o) in items]
-                    got = np.concatenate(got) if got else np.zeros((0, 5), np.int32)
-                    assert np.array_equal(ri, got), (world, sb, r, len(ri), len(got))
+        for world in (2, 3, 8):
+            owner = lambda i: chunk_owner(i, world, 2)
+            for r in range(world):
+                rj, ri = mesh_shell_plan(ent, world, r, 2)
+                jobs, send, recv = plan_shells_reference(ent, world, r, owner)
+                assert [tuple(j) for j in rj.tolist()] == jobs
+                merged, plain = {}, {}
+                for o, x, y, z, box in ri.tolist():
+                    merged.setdefault((o, x, y, z), set()).update(shell_box_coords(box, E))
+                for o, items in recv.items():
+                    for x, y, z, box in items:
+                        plain.setdefault((o, x, y, z), set()).update(shell_box_coords(box, E))
+                assert merged == plain, (world, r)
+                # what r plans to receive from o is what o plans to send r
+                for o in range(world):
+                    if o != r:
+                        assert sorted(recv.get(o, [])) == sorted(plan_shells_reference(ent, world, o, owner)[1].get(r, []))
