@@ -81,9 +81,11 @@ def parse():
     ap.add_argument("--sim-shards", type=int, default=0, help="diagnostic, 1 GPU: integrate only the chunks of one shard of an N-way sharded map "
                                                                "(what one rank of an N-GPU run computes; every rank sees every frame)")
     ap.add_argument("--sim-rank", type=int, default=0)
-    ap.add_argument("--exchange-color", action="store_true", help="N > 1: every frame's colour image travels with its depth (a second all-gather per batch), as the "
-                                                                    "caller delivers it (ChiselServer.cpp:379-421); default: depth only (BASELINE config 4: \"RCCL depth broadcast\"), "
-                                                                    "one static colour image resident on every rank")
+    ap.add_argument("--exchange-color", action="store_true", default=None,
+                    help="N > 1: every frame's colour image travels with its depth (a second all-gather per batch), as the caller delivers it "
+                         "(ChiselServer.cpp:379-421); the default with --config 4 (its four agents deliver depth AND colour per frame).  Otherwise: depth "
+                         "only, one static colour image resident on every rank")
+    ap.add_argument("--no-exchange-color", dest="exchange_color", action="store_false", help="N > 1: depth only (the letter of BASELINE config 4: \"RCCL depth broadcast\")")
     ap.add_argument("--group", type=int, default=0, help="1 process: one map over N shards through the in-library group handle (chisel_hip_create_group: what a "
                                                           "single-process C++ caller like chisel_ros gets) -- on devices 0..N-1 when the node has them, else N shards on device 0")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (functional check of the N > 1 logic on one GPU)")
@@ -103,6 +105,8 @@ def parse():
             setattr(args, k, v)
     if args.config == 5 and "--steps" not in given:
         args.steps, args.warmup = 48, 16
+    if args.exchange_color is None:
+        args.exchange_color = args.config == 4  # config 4's agents hand over depth and colour per frame: both travel (the N > 1 line says which)
     return args
 
 
