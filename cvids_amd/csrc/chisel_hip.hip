@@ -2409,11 +2409,7 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
         if (hipMemcpyFromSymbol(mp, HIP_SYMBOL(g_mesh_phase), sizeof(mp)) == hipSuccess && mp[7]) {
             fprintf(stderr, "mesh_count_kernel, us per job (thread 0): lookups %.2f | corners staged %.2f | cubes classified %.2f | scan %.2f | reserve %.2f | records %.2f | jobs %llu\n",
                     mp[0] * 0.01 / mp[7], mp[1] * 0.01 / mp[7], mp[2] * 0.01 / mp[7], mp[3] * 0.01 / mp[7], mp[4] * 0.01 / mp[7], mp[5] * 0.01 / mp[7], mp[7]);
-            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, life[4];
-            if (hipMemcpyFromSymbol(life, HIP_SYMBOL(g_mesh_life), sizeof(life)) == hipSuccess)
-                fprintf(stderr, "   working waves %llu, life avg %.2f us; (ONE launch) first entry -> last exit %.2f us\n", life[1], life[1] ? life[0] * 0.01 / life[1] : 0.0,
-                        (life[3] - ((1ull << 62) - life[2])) * 0.01);
-            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_life), z, sizeof(life));
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_phase), z, sizeof(z));
         }
     }

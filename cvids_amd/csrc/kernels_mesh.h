@@ -157,11 +157,6 @@ __device__ inline bool get_color_voxel(const MapView &M, const MeshParams &P, f3
     return false;
 }
 
-#ifndef MESH_COLOR_BATCH
-#define MESH_COLOR_BATCH 0  // (round 4: the eight colour lookups located and requested together instead of one after the other -- two dependent round
-                            // trips instead of sixteen, and SLOWER: mesh_triangle_kernel 18.2 -> 23.9 us on the default window, 21.8 -> 29.0 us on the
-                            // driver's.  The sequential form stops at the first absent neighbour and touches one line at a time; kept.)
-#endif
 // ChunkManager::InterpolateColor (ChunkManager.cpp:501-573), including its use of integer voxel indices as metric
 // positions for the 8 neighbour lookups (:506-520) and the nearest-voxel fallback Chunk::GetColorAt (Chunk.cpp:118-136)
 template <int N>
@@ -180,34 +175,6 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
         const int *bb = M.mesh_ctl + MC_BBOX;
         first_may_exist = ix >= bb[0] && iy >= bb[1] && iz >= bb[2] && ix <= bb[3] && iy <= bb[4] && iz <= bb[5];
     }
-#if MESH_COLOR_BATCH
-    // The reference makes the eight GetColorVoxel calls one after the other and stops at the first failure (:506-520); a lookup has no
-    // side effect and the blend below needs all eight, so the eight voxels are located first (eight neighbour-table reads in flight),
-    // their colours requested together (eight more), and the verdict taken afterwards: two dependent round trips instead of sixteen.
-    bool all;
-    {
-        const int qx[8] = {x0, x0, x0, x1, x1, x1, x0, x1}, qy[8] = {y0, y0, y1, y1, y1, y0, y1, y0}, qz[8] = {z0, z1, z1, z1, z0, z0, z0, z1};
-        int slot[8], id[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const f3v q = mk3((float)qx[i], (float)qy[i], (float)qz[i]);
-            f3v origin;
-            slot[i] = chunk_at<N>(M, P, q, hx, hy, hz, nb, origin);
-            const f3v rel = sub3(q, origin);
-            const int cx = (int)floorf(rel.x * P.rf_voxel), cy = (int)floorf(rel.y * P.rf_voxel), cz = (int)floorf(rel.z * P.rf_voxel);
-            id[i] = (cz * N + cy) * N + cx;
-        }
-        uchar4 c[8];
-        all = true;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const bool ok = slot[i] >= 0 && id[i] >= 0 && id[i] < N * N * N;  // GetColorVoxel: chunk present, linear voxel id in range (:588-607)
-            c[i] = M.rgbw[ok ? (size_t)slot[i] * (N * N * N) + id[i] : 0];
-            all = all && ok;
-        }
-        v000 = c[0]; v001 = c[1]; v011 = c[2]; v111 = c[3]; v110 = c[4]; v100 = c[5]; v010 = c[6]; v101 = c[7];
-    }
-#else
     bool all = first_may_exist && get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z0), hx, hy, hz, nb, v000);
     all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y0, (float)z1), hx, hy, hz, nb, v001);
     all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y1, (float)z1), hx, hy, hz, nb, v011);
@@ -216,7 +183,6 @@ __device__ inline f3v interpolate_color(const MapView &M, const MeshParams &P, f
     all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y0, (float)z0), hx, hy, hz, nb, v100);
     all = all && get_color_voxel<N>(M, P, mk3((float)x0, (float)y1, (float)z0), hx, hy, hz, nb, v010);
     all = all && get_color_voxel<N>(M, P, mk3((float)x1, (float)y0, (float)z1), hx, hy, hz, nb, v101);
-#endif
     if (!all) {
         f3v origin;
         const int slot = chunk_at<N>(M, P, cp, hx, hy, hz, nb, origin);
@@ -392,7 +358,6 @@ __device__ inline float pick8(const float (&s)[8], int e) {
 }
 
 #ifdef CHISEL_PHASES
-__device__ unsigned long long g_mesh_life[4];   // diagnostic: [0] sum of the working waves' lives, [1] their number, [2] 2^62 - earliest entry, [3] latest exit
 __device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per stage of mesh_count_kernel (lane 0 of every wave), [7] = sub-jobs
 #define MSTAMP(i) do { if (lane == 0 && (blockIdx.x & 31) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_mesh_phase[i], n_ - mt_); mt_ = n_; } } while (0)  // (every 32nd wave: the atomics of all of them on six words would be what is measured)
 #else
@@ -412,9 +377,6 @@ __device__ __forceinline__ void mesh_count_body(const MapView &M, const int *__r
     __shared__ int s_nb[27];
     __shared__ unsigned s_counts[64];  // the 256 vertex counts of the case table, four to a word (a per-lane index into constant memory is a global load)
     int lane = threadIdx.x;
-#ifdef CHISEL_PHASES
-    const unsigned long long mt0_ = __builtin_amdgcn_s_memrealtime();
-#endif
     int n = *n_jobs;  // the job count stays on the device: the grid is persistent
     if (n > ids_capacity) n = ids_capacity;  // (the kept list never gets there: the host gives it up first)
     if (blockIdx.x == 0 && lane == 0) ctl[MC_JOBS] = n;  // where the kernels behind this one (and a second emission) read it
@@ -428,15 +390,6 @@ __device__ __forceinline__ void mesh_count_body(const MapView &M, const int *__r
     const int xcd = (int)blockIdx.x & 7, stride = (int)gridDim.x >> 3;
     for (int q = (int)blockIdx.x >> 3;; q += stride) {
         const int jl = q / G::S, s = q - jl * G::S, j = jl * 8 + xcd;
-#ifdef CHISEL_PHASES
-        if (j >= n && lane == 0 && q != ((int)blockIdx.x >> 3)) {  // this wave had work: its life, and the launch's span (meaningful for ONE launch)
-            const unsigned long long e_ = __builtin_amdgcn_s_memrealtime();
-            atomicAdd(&g_mesh_life[0], e_ - mt0_);
-            atomicAdd(&g_mesh_life[1], 1ull);
-            atomicMax(&g_mesh_life[2], (1ull << 62) - mt0_);
-            atomicMax(&g_mesh_life[3], e_);
-        }
-#endif
         if (j >= n) break;
 #ifdef CHISEL_PHASES
         unsigned long long mt_ = __builtin_amdgcn_s_memrealtime();

@@ -39,4 +39,6 @@ import sys, json
 d = json.loads(sys.stdin.read()); print('pcie_inclusive', d.get('pcie_inclusive')); print('e2e', d.get('e2e'))"
 echo "== the reference's call pattern: one frame per call, the caller waits after each (tools/sync_latency_abi.cpp)"
 for mode in device pinned pageable; do ./tools/sync_latency_abi 140 $mode; done
+echo "== the same through the C++ facade (chisel::Chisel, images allocated by the facade's own classes; tools/sync_latency_facade.cpp)"
+./tools/sync_latency_facade 140
 python3 tools/sync_latency.py 2>/dev/null | tail -4
