@@ -213,8 +213,11 @@ struct chisel_hip_map {
                                                 // 4 agents 65.5 -> 67.2 k, driver's and late windows unchanged; CHISEL_HIP_DIRECT_MAX=256 restores the ordering)
         // test / A-B hooks (environment, at creation)
         int force_vpl = 0;                      // CHISEL_HIP_VPL=2|4
-        int force_cull_waves = 0;               // CHISEL_HIP_CULL_WAVES=4|16
-        bool persistent_grid = false;           // CHISEL_HIP_PERSISTENT=1: a resident grid pulling units from the queue heads
+        int force_cull_waves = 0;               // CHISEL_HIP_CULL_WAVES=1|4|16
+        int refine_prompt = -1;                 // CHISEL_HIP_REFINE_PROMPT=0|1: single-wave workgroups for refine_kernel (default: launches of frames that look apart)
+        int refine_fpg = 0;                     // CHISEL_HIP_REFINE_FPG=1|2|4|8|16: frames per wave of refine_kernel (default 1, 4 for such launches)
+        int force_cull_contig = -1;             // CHISEL_HIP_CULL_CONTIG=0|1: which frames a wave of the four-wave cull takes (default: by the frames' ranges)
+        int persistent_grid = 0;                // CHISEL_HIP_PERSISTENT=n: a resident grid of n workgroups per SIMD (1 = the build's INTEGRATE_BLOCKS_PER_CU) pulling units from the queue heads
         bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
         bool always_wait_packet = false;
         bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: sharded maps        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
@@ -461,6 +464,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     hipStream_t front = bs.front_stream;
     const bool inline_resolve = front == m->stream;
     bool front_recorded = false;
+    bool narrow_cull_set = false;  // this launch's frames look at different parts of the space (decided where the cull kernel is launched)
     bool skip_refine = false;  // the short form of a one-frame launch: the cull kernel fills the CellRecs itself (4 us of launch for 2 us of integration)
     {
     RoctxRange front_range("chisel_hip front half: pyramid, cull, resolve, order");
@@ -482,13 +486,33 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
             double vmax = 0.0;
             for (int k2 = 0; k2 < CP.n_frames; k2++) vmax = std::max(vmax, (double)CP.f[k2].range_dim[0] * CP.f[k2].range_dim[1] * CP.f[k2].range_dim[2]);
             narrow_cull = m->cfg.n_shards <= m->tune.narrow_cull_max_shards && (double)CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2] > m->tune.narrow_cull_ratio * vmax;
-            if (m->tune.force_cull_waves) narrow_cull = m->tune.force_cull_waves == 4;
+            if (m->tune.force_cull_waves) narrow_cull = m->tune.force_cull_waves != 16;
             m->launch_stats[(narrow_cull && IP.n_frames > 4) ? 3 : 4]++;
+            narrow_cull_set = narrow_cull;
+        }
+        // a wave of the four-wave form takes several frames: the ones that share least (kernels_cull.h).  Frames 0 and 1 against frames 0
+        // and `waves` by the ids their ranges have in common: interleaved agents share less with their neighbour in the launch
+        // ... and one wave per workgroup where the front half runs beside an integration kernel that refills every slot as it frees up: a
+        // single-wave workgroup gets in at once, one of four waits for four free slots on ONE CU (tools/micro/beside.hip)
+        const bool cull_one_wave = m->tune.force_cull_waves ? m->tune.force_cull_waves == 1 : !inline_resolve;
+        int cull_contig = 0;
+        if (narrow_cull && CP.n_frames > 4) {
+            const int waves = 4, far = waves < CP.n_frames ? waves : CP.n_frames - 1;
+            const auto common = [&](const CullFrame &a, const CullFrame &b) {
+                double v = 1.0;
+                for (int ax = 0; ax < 3; ax++) {
+                    const int lo = std::max(a.range_min[ax], b.range_min[ax]), hi = std::min(a.range_min[ax] + a.range_dim[ax], b.range_min[ax] + b.range_dim[ax]);
+                    v *= hi > lo ? (double)(hi - lo) : 0.0;
+                }
+                return v;
+            };
+            cull_contig = common(CP.f[0], CP.f[1]) < common(CP.f[0], CP.f[far]) ? 1 : 0;
+            if (m->tune.force_cull_contig >= 0) cull_contig = m->tune.force_cull_contig;
         }
 #define CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, WV)                                                                                   \
     hipLaunchKernelGGL((cull_kernel<N, KLV, INL, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count, \
-                       m->items_capacity, m->view, bs.pending, bs.sync, skip_refine ? bs.cells : nullptr)
-#define CHISEL_LAUNCH_CULL(KLV, INL, OUT) do { if (narrow_cull) CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 4); else CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 16); } while (0)
+                       m->items_capacity, m->view, bs.pending, bs.sync, skip_refine ? bs.cells : nullptr, cull_contig)
+#define CHISEL_LAUNCH_CULL(KLV, INL, OUT) do { if (narrow_cull && cull_one_wave) CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 1); else if (narrow_cull) CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 4); else CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 16); } while (0)
         if (inline_resolve) {
             if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, true, bs.items, 16);
             else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL_W(2, true, bs.items, 16);
@@ -535,18 +559,26 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // A persistent grid over the (item, frame) pairs: their number is only known on the device.
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
         const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
-        const long long pairs = (long long)(items_hint > 0 ? items_hint + items_hint / 4 + 16 : 1024) * IP.n_frames;
-        // (REFINE_BLOCK threads per workgroup: single-wave workgroups find a slot beside an integration kernel that refills every slot
-        // the moment it frees up; four-wave ones wait for four free slots on ONE CU -- 45 us instead of 13 on the 4-agent stream)
-        const int rwaves = REFINE_BLOCK / 64;
+        // Shape.  Beside an integration kernel (80 registers, six single-wave workgroups per SIMD, every slot refilled the moment it frees up)
+        // a workgroup of four waves waits for four free slots on ONE CU, i.e. for that kernel to drain (tools/micro/beside.hip: 145 us
+        // instead of 17); single-wave workgroups get in at once -- and take the slots from the integration kernel for as long as they run.
+        // Worth it when the front half is what the stream waits for: launches whose frames look at different parts of the space (the
+        // interleaved agents of one map: each integration waited 50 us for a refinement that could not start before the previous
+        // integration drained).  Those also take four frames per wave (kernels_cull.h).
+        const bool prompt = m->tune.refine_prompt >= 0 ? m->tune.refine_prompt != 0 : narrow_cull_set;
+        const int fpg = m->tune.refine_fpg > 0 ? m->tune.refine_fpg : (narrow_cull_set && IP.n_frames > 4 ? 4 : 1);
+        const int rblock = prompt ? 64 : REFINE_BLOCK;
+        const int n_groups = (IP.n_frames + fpg - 1) / fpg;
+        const long long pairs = (long long)(items_hint > 0 ? items_hint + items_hint / 4 + 16 : 1024) * n_groups;
+        const int rwaves = rblock / 64;
         const int rgrid = (int)std::max<long long>(64, std::min<long long>(4096 * 4 / rwaves, (pairs + rwaves - 1) / rwaves));
         front_recorded = m->tune.ext_events && !m->profiling;
         if (front_recorded)  // the set's front_done event is the refinement kernel's own completion: no record packet behind it
-            hipExtLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(REFINE_BLOCK), 0, front, nullptr, bs.front_done, 0, IP, pyr, m->pyr_stride, (const WorkItem *)bs.items,
-                                  (const FrameBox *)bs.boxes, (const int *)(bs.cand_count + COUNT_ITEMS), m->items_capacity, bs.cells, m->refine_off ? 1 : 0);
+            hipExtLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, nullptr, bs.front_done, 0, IP, pyr, m->pyr_stride, (const WorkItem *)bs.items,
+                                  (const FrameBox *)bs.boxes, (const int *)(bs.cand_count + COUNT_ITEMS), m->items_capacity, bs.cells, m->refine_off ? 1 : 0, fpg);
         else
-        hipLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(REFINE_BLOCK), 0, front, IP, pyr, m->pyr_stride, bs.items, bs.boxes, bs.cand_count + COUNT_ITEMS,
-                           m->items_capacity, bs.cells, m->refine_off ? 1 : 0);
+        hipLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, IP, pyr, m->pyr_stride, bs.items, bs.boxes, bs.cand_count + COUNT_ITEMS,
+                           m->items_capacity, bs.cells, m->refine_off ? 1 : 0, fpg);
     }
     if (!front_recorded) HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     }
@@ -595,7 +627,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const long long units = (long long)total * wpc;
         constexpr int WPB = Geom<N, 4>::WPB;
         long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * wpc + WPB - 1) / WPB : (long long)Geom<N, 4>::GRID;
-        if (m->tune.persistent_grid) blocks = (long long)Geom<N, 4>::GRID;
+        if (m->tune.persistent_grid) blocks = m->tune.persistent_grid == 1 ? (long long)Geom<N, 4>::GRID : 256ll * m->tune.persistent_grid * (4 / WPB);
         blocks = std::min<long long>(blocks, (units + WPB - 1) / WPB);
         // Two granularities in one launch: the last seventh of the (cost-ordered) items at 2 voxels per lane -- units of half the length
         // where the launch drains -- when the launch is long enough to have a tail worth shortening (>= 2 rounds of the chip).  The
@@ -1141,8 +1173,11 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
         m->refine_always = atoi(e) == 2;
     }
     if (const char *e = getenv("CHISEL_HIP_VPL")) m->tune.force_vpl = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 0);
-    if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) m->tune.force_cull_waves = atoi(e) == 4 ? 4 : 16;
-    if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) m->tune.persistent_grid = atoi(e) != 0;
+    if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) m->tune.force_cull_waves = atoi(e) == 4 ? 4 : (atoi(e) == 1 ? 1 : 16);
+    if (const char *e = getenv("CHISEL_HIP_REFINE_PROMPT")) m->tune.refine_prompt = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("CHISEL_HIP_REFINE_FPG")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) m->tune.refine_fpg = v; }
+    if (const char *e = getenv("CHISEL_HIP_CULL_CONTIG")) m->tune.force_cull_contig = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) m->tune.persistent_grid = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = getenv("CHISEL_HIP_TAIL_PERCENT")) m->tune.tail_percent = atoi(e);
     if (const char *e = getenv("CHISEL_HIP_FINE_BELOW")) m->tune.fine_below = atoi(e);
     if (const char *e = getenv("CHISEL_HIP_DIRECT_MAX")) m->tune.direct_items_max = atoi(e);

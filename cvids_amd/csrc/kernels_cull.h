@@ -415,35 +415,42 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
 #define REFINE_TEXELS 4
 #endif
 #ifndef REFINE_BLOCK
-#define REFINE_BLOCK 256   // threads per workgroup of refine_kernel (one wave per (item, frame) pair; the waves of a workgroup never meet)
+#define REFINE_BLOCK 256   // threads per workgroup of refine_kernel at most (the waves of a workgroup never meet; the host picks 64 or this per launch)
 #endif
 template <int N>
 __global__ __launch_bounds__(256) void refine_kernel(IntegrateParams P, PyramidView pyr, int pyr_stride,
                                                      const WorkItem *__restrict__ items, const FrameBox *__restrict__ boxes, const int *__restrict__ work_count,
-                                                     int max_items, CellRec *__restrict__ cells, int full) {
+                                                     int max_items, CellRec *__restrict__ cells, int full, int fpg) {
+    // fpg = frames per wave (1, 2, 4, ... a power of two): a wave takes the frames g * fpg ... of a work item one after the other, skipping
+    // the ones outside the item's mask; lane j keeps frame g * fpg + j's record and the wave stores them together.  1 = one wave per
+    // (item, frame) pair, the shortest chain; 4 for launches whose frames look at different parts of the space (of four consecutive
+    // frames of interleaved agents one, seldom two, are in an item's mask: a quarter of the waves, each as long as before).
     constexpr int CELL = N / 4;
     const IntegratorParams &ip = P.ip;
     const int n_frames = P.n_frames;
     const int lane = threadIdx.x & 63;
     int n_items = *work_count;
     if (n_items > max_items) n_items = max_items;
-    const int n_pairs = n_items * n_frames;
+    const int n_groups = (n_frames + fpg - 1) / fpg;
+    const int n_pairs = n_items * n_groups;
     const int waves = (int)gridDim.x * (int)(blockDim.x >> 6);
     for (int p = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); p < n_pairs; p += waves) {
-        const int it = p / n_frames, k = p - it * n_frames;
+        const int it = p / n_groups, k0 = (p - it * n_groups) * fpg;
         const WorkItem wi = items[it];
         const unsigned fmask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
+        const int row = __builtin_amdgcn_readfirstlane(wi.box);
+        const bool mine = lane < fpg && k0 + lane < n_frames;  // this lane keeps a frame's record
         CellRec out;
         out.need = 0ull;
         out.flags = 0;
         out.pad = 0;
-        if ((fmask >> k) & 1u) {  // wave-uniform
-            const int row = __builtin_amdgcn_readfirstlane(wi.box);
-            const int flags = boxes[(size_t)row * n_frames + k].flags;
-            out.flags = __builtin_amdgcn_readfirstlane(flags);
-            if (full) {
-                out.need = ~0ull;
-            } else {
+        if (mine && ((fmask >> (k0 + lane)) & 1u)) out.flags = boxes[(size_t)row * n_frames + k0 + lane].flags;
+        unsigned gm = (fmask >> k0) & (fpg >= 32 ? 0xffffffffu : ((1u << fpg) - 1u));
+        while (gm) {  // wave-uniform
+            const int j = __builtin_ctz(gm), k = k0 + j;
+            gm &= gm - 1u;
+            unsigned long long b = ~0ull;
+            if (!full) {
                 const int slot = __builtin_amdgcn_readfirstlane(wi.slot);
                 const unsigned inband_before = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.inband_mask) & ((1u << k) - 1u);
                 const bool resident = slot >= 0 || slot == SLOT_LOOKUP || inband_before != 0u;
@@ -471,10 +478,11 @@ __global__ __launch_bounds__(256) void refine_kernel(IntegrateParams P, PyramidV
                         }
                     }
                 }
-                out.need = __ballot(need);
+                b = __ballot(need);
             }
+            if (lane == j) out.need = b;
         }
-        if (lane == 0) cells[(size_t)it * n_frames + k] = out;
+        if (mine) cells[(size_t)it * n_frames + k0 + lane] = out;
     }
 }
 
@@ -589,8 +597,13 @@ struct CullGeom {
 };
 template <int N, int KL, bool INLINE, int WV>
 __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *counts,
-                                                        int max_cands, MapView M, uint64_t *my_pending, ItemSync *sync, CellRec *cells) {
+                                                        int max_cands, MapView M, uint64_t *my_pending, ItemSync *sync, CellRec *cells, int contig) {
     constexpr int WAVES = CullGeom<KL, WV>::WAVES, FPW = CullGeom<KL, WV>::FPW;
+    // which frames a wave takes when it takes several: k, k + WAVES, ... or (contig) k * FPW, k * FPW + 1, ...  The host picks the one
+    // that gives a wave frames looking at DIFFERENT parts of the space: of a wave's frames few then survive the range test for any one
+    // block of ids, and the survivors of a block are spread over its waves instead of queueing up in one of them (interleaved agents,
+    // frame i from agent i mod 4: strided hands wave k the four frames of agent k -- four cull_post in a row in one wave, three waves idle)
+
     int *cand_count = counts + (INLINE ? COUNT_ITEMS : COUNT_CANDS);
     __shared__ int s_flags[KL][64];
     __shared__ int s_pos[64];
@@ -609,13 +622,13 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
         have_id = ix < P.range_dim[0] && iy < P.range_dim[1] && iz < P.range_dim[2];
     }
     const bool mine = have_id && chunk_owner(cx, cy, cz, P.ip.n_shards, P.ip.shard_block) == P.ip.shard_rank;
-    FrameBox fbs[FPW];
-    int fls[FPW];
+    constexpr int UNROLL = FPW <= 4 ? FPW : 1;
     bool any_flag = false;
-#pragma unroll
+    // (the verdicts live in LDS: a wave of the one-wave form takes all KL frames, one after the other -- no unrolling, no register arrays)
+#pragma unroll UNROLL
     for (int j = 0; j < FPW; j++) {
-        const int kf = k + j * WAVES;
-        FrameBox &fb = fbs[j];
+        const int kf = (FPW > 1 && contig) ? k * FPW + j : k + j * WAVES;
+        FrameBox fb;
         fb.flags = 0;
         int fl = 0;
         CullPre pre;
@@ -628,8 +641,6 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
             if (__any(alive && box_needs_whole_image(pre.su0, pre.sv0, pre.su1, pre.sv1))) whole = whole_image_minmax(pyr, pyr.data + (size_t)kf * P.pyr_stride);
             if (alive) fl = cull_post<N>(P.ip, P.f[kf], pyr, pyr.data + (size_t)kf * P.pyr_stride, whole, cx, cy, cz, pre, fb);
         }
-        fb.flags = fl;
-        fls[j] = fl;
         s_flags[kf][lane] = fl;
         any_flag = any_flag || fl != 0;
     }
@@ -709,17 +720,20 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
     }
     __syncthreads();
     const int pos = s_pos[lane];
-#pragma unroll
+#pragma unroll UNROLL
     for (int j = 0; j < FPW; j++) {
-        const int kf = k + j * WAVES;
+        const int kf = (FPW > 1 && contig) ? k * FPW + j : k + j * WAVES;
         if (pos >= 0 && kf < P.n_frames) {
-            boxes[(size_t)pos * P.n_frames + kf] = fbs[j];
+            const int fl = s_flags[kf][lane];
+            FrameBox fb;
+            fb.flags = fl;
+            boxes[(size_t)pos * P.n_frames + kf] = fb;
             // INLINE with `cells`: the candidate list is the work-list and the launch is not worth refining (one frame, a caller that
             // waits): every cell of a frame that can touch the chunk counts as needed, and no refine_kernel is launched
             if (INLINE && cells) {
                 CellRec cr;
-                cr.need = fls[j] ? ~0ull : 0ull;
-                cr.flags = fls[j];
+                cr.need = fl ? ~0ull : 0ull;
+                cr.flags = fl;
                 cr.pad = 0;
                 cells[(size_t)pos * P.n_frames + kf] = cr;
             }

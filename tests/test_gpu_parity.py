@@ -503,16 +503,16 @@ def test_launch_statistics_account_for_every_launch_set(oracle_mod, monkeypatch)
 
 
 @pytest.mark.parametrize("chunk", [8, 16, 32])
-@pytest.mark.parametrize("mode", ["vpl2", "vpl4", "persistent", "growing", "cull4", "cull16"])
+@pytest.mark.parametrize("mode", ["vpl2", "vpl4", "persistent", "growing", "cull1", "cull4", "cull16"])
 def test_integration_schedules(oracle_mod, chunk, mode, monkeypatch):
     """The integration kernel's two granularities (2 / 4 voxels per lane, normally picked per launch from the item count a
     recent launch reported) and its two ways of handing out units (one unit per wave with a grid sized from that count;
     persistent waves pulling from the queue heads) give the same map: each forced over a stream with batches of 1..8 frames,
     colour, carving.  "growing": the reported count is far too small for the next launch (a small wall, then the whole room),
-    so most units come from the queue heads of a small grid.  "cull4" / "cull16": the cull kernel's two workgroup shapes (four waves of
-    several frames each, picked by the host for launches whose frames look at different parts of the space; one wave per frame),
-    each forced over the two-agent stream."""
-    if mode in ("cull4", "cull16"):
+    so most units come from the queue heads of a small grid.  "cull1" / "cull4" / "cull16": the cull kernel's three workgroup shapes (one wave that takes
+    every frame, or four waves of several frames each, picked by the host for launches whose frames look at different parts of the space; one
+    wave per frame), each forced over the two-agent stream."""
+    if mode in ("cull1", "cull4", "cull16"):
         monkeypatch.setenv("CHISEL_HIP_CULL_WAVES", mode[4:])
     if mode == "vpl2":
         monkeypatch.setenv("CHISEL_HIP_VPL", "2")
