@@ -572,7 +572,7 @@ class Chisel:
         return {k: {"ms": ms[i], "launches": int(n[i])} for i, k in enumerate(capi.KERNEL_NAMES)}
 
     LAUNCH_STATS = ("integrate_2_per_lane", "integrate_4_per_lane", "integrate_4_with_2_tail", "cull_4_waves", "cull_wave_per_frame",
-                    "unordered_worklists", "single_stream_sets", "launch_sets")
+                    "unordered_worklists", "single_stream_sets", "launch_sets", "behind_unseen_recompute", "replayed")
 
     def launch_stats(self, reset=False):
         """which shapes the launch heuristics picked (chisel_hip_get_launch_stats)"""

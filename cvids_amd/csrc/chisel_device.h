@@ -91,6 +91,10 @@ struct MapView {
 // "absent" verdict for ids outside it: ChunkManager::InterpolateColor's eight look-ups (ChunkManager.cpp:506-520) take integer VOXEL
 // indices for metric positions and land hundreds of chunks away, where one compare answers what was a hash probe per vertex.
 constexpr int MC_BBOX = 136;
+// mesh_ctl[MC_LATCH] != 0: the recompute in front did not fit its triangle list or its arena and will be emitted again from the voxels AS THEY
+// ARE -- set by mesh_triangle_kernel, read by integrate_kernel (every wave leaves at once: the map stays as the recompute saw it), cleared by
+// the host when it emits again and then replays the launches that left (host_mesh.h: check_mesh_totals)
+constexpr int MC_LATCH = 5;
 __device__ inline void bbox_include(int *mesh_ctl, int x, int y, int z) {
     if (!mesh_ctl) return;
     int *b = mesh_ctl + MC_BBOX;

@@ -189,7 +189,12 @@ struct chisel_hip_map {
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
         hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's work-list (and with it its pending set) is complete
         hipEvent_t back_done = nullptr;   // recorded on the map's stream after the set's integration
+        // what launch_back needs to launch the set's integration again (a set queued behind a recompute that then did not fit: deferred_set)
+        IntegrateParams replay_ip;
+        bool replay_color = false, replay_inline = false;
+        int replay_total = 0;
     } sets[CHISEL_FRONT_SETS];
+    int deferred_set = -1;               // the set whose integration was queued behind a recompute the host has not sized yet (launch_back), or -1
     uint64_t *pending_ring[CHISEL_PENDING_RING] = {};  // [PENDING_CAPACITY + 1] each: the set, then its overflow flag
     hipStream_t aux = nullptr, aux2 = nullptr, aux3 = nullptr;  // the front halves of consecutive batches take them in turn (aux3: CHISEL_FRONT_SETS >= 4 only)
     hipEvent_t call_event = nullptr;     // caller-provided stream: orders the front after the caller's producers
@@ -216,6 +221,8 @@ struct chisel_hip_map {
         int force_cull_waves = 0;               // CHISEL_HIP_CULL_WAVES=1|4|16
         int refine_prompt = -1;                 // CHISEL_HIP_REFINE_PROMPT=0|1: single-wave workgroups for refine_kernel (default: launches of frames that look apart)
         int refine_fpg = 0;                     // CHISEL_HIP_REFINE_FPG=1|2|4|8|16: frames per wave of refine_kernel (default 1, 4 for such launches)
+        int defer_totals = 1;                   // CHISEL_HIP_DEFER_TOTALS=0: every integration launch waits for the totals of the recompute in front of it; 2 (test hook): a
+                                                // launch is queued unseen even when the totals are already there
         int force_cull_contig = -1;             // CHISEL_HIP_CULL_CONTIG=0|1: which frames a wave of the four-wave cull takes (default: by the frames' ranges)
         int persistent_grid = 0;                // CHISEL_HIP_PERSISTENT=n: a resident grid of n workgroups per SIMD (1 = the build's INTEGRATE_BLOCKS_PER_CU) pulling units from the queue heads
         bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
@@ -449,6 +456,140 @@ int ensure_pyramid(chisel_hip_map *m, int W, int H) {
 
 int check_mesh_totals(chisel_hip_map *m);  // host_mesh.h
 void give_up_job_list(chisel_hip_map *m);  // host_mesh.h
+// First thing in every entry point that looks at the map or queues work on it (the depth-integration calls see to it themselves, in
+// launch_back): a launch set that was queued behind a recompute the host had not sized yet is settled -- the totals are read, and had
+// the recompute not fitted it is emitted again and the set's integration replayed -- before anybody can observe the difference.
+inline int settle(chisel_hip_map *m) { return (m && m->deferred_set >= 0) ? check_mesh_totals(m) : CHISEL_HIP_OK; }
+#define SETTLE(m) do { const int rc_settle_ = settle(m); if (rc_settle_) return rc_settle_; } while (0)
+
+bool mesh_totals_published(const chisel_hip_map *m);  // host_mesh.h
+// The back half of a launch set: the integration kernel on the map's stream.  replay: the launch again, for a set whose first launch
+// left the map alone (MC_LATCH; check_mesh_totals).
+template <int N>
+int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const IntegrateParams &IP, bool color, int total, bool inline_resolve, bool replay) {
+    RoctxRange back_range("chisel_hip back half: integrate");
+    // ---- back half: the map's stream.  A mesh recompute still in flight must have been sized first (it may have to be
+    // emitted again from the voxels as they are now); its front-half work above did not depend on that.
+    bool recompute_in_flight = m->pending_meshes.unchecked;
+    if (!replay) {
+        // A recompute whose totals the host has not seen yet.  Waiting for them here (the triangle kernel publishes them when it STARTS)
+        // put the host into the device's loop once per recompute: the launch below reached the queue 10-30 us after that kernel had ended.
+        // Instead the launch is queued behind it unseen -- ONE launch set, of frames whose integration reads nothing of the caller's
+        // (bs.replay_*) -- and protected on the device: a recompute that did not fit sets MC_LATCH, every wave of the integration kernel
+        // leaves at once, and the host, when it next looks (any entry point: settle()), emits again from the untouched map and replays the
+        // launch.  Otherwise the totals are looked at as before (by now they are usually there).
+        bool same_cam_all = color;
+        for (int k = 0; k < IP.n_frames; k++) same_cam_all = same_cam_all && IP.f[k].same_cam;
+        const bool may_defer = recompute_in_flight && m->tune.defer_totals && m->deferred_set < 0 && m->cfg.n_shards <= 1 && (!color || same_cam_all) &&
+                               (m->tune.defer_totals == 2 || !mesh_totals_published(m));
+        if (may_defer) {
+            m->deferred_set = (int)(&bs - m->sets);
+            bs.replay_ip = IP;
+            bs.replay_color = color;
+            bs.replay_total = total;
+            bs.replay_inline = inline_resolve;
+            m->launch_stats[8]++;
+            recompute_in_flight = false;  // (nothing was waited for: no reason to poll for the front half either)
+        } else {
+            int rc_m = check_mesh_totals(m);
+            if (rc_m) return rc_m;
+        }
+    }
+    if (!inline_resolve && !replay) {
+        // A front half that has already finished needs no wait packet in front of the integration kernel (the packet is only looked at
+        // once the kernel in front of it has ended, and the dispatch behind it only once the packet has retired).  With a recompute
+        // in flight the host has just waited for its triangle kernel to START (check_mesh_totals), that kernel has another 15-25 us
+        // to run and this batch's front half, queued before that wait, is over or about to be: worth a short look.  (Default window
+        // 87.8 -> 89.9 k frames/s; nothing on streams without recomputes, where the host runs batches ahead of the device.)
+        const bool never = m->tune.always_wait_packet;
+        bool done = !never && hipEventQuery(bs.front_done) == hipSuccess;
+        if (!done && !never && recompute_in_flight) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!(done = hipEventQuery(bs.front_done) == hipSuccess) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) {}
+        }
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+        if (!done) HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
+    }
+    int *wc = bs.cand_count + COUNT_ITEMS;
+    {
+        ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
+        // Grid.  One unit per wave and the hardware's in-order workgroup dispatch over the cost-ordered work-list is the
+        // schedule that works best (the SIMDs issue from their oldest wave first: a persistent wave that pulls a second unit keeps
+        // its age and starves the younger waves' first units).  The number of work items is only known on the device, so the grid
+        // is sized from the count a recent launch of this map reported (pinned word [2] beside the error flags, written by the
+        // integration kernel; it lags by the launches in flight) plus 1/8; surplus workgroups find no unit and leave, a shortfall
+        // is pulled from the queue heads by the workgroups as they finish.  Without a report yet: what the chip holds at once.
+        // The same figure picks the granularity: 2 voxels per lane for launches of several frames below INTEGRATE_FINE_BELOW items
+        // (about three rounds of the chip at 4 voxels per lane), 4 otherwise (kernels_integrate.h).
+        const long long hint = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[2];
+        const long long pairs = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[3];  // (item, frame) pairs of that launch, 0 = unknown
+        int vpl = (IP.n_frames >= 4 && hint > 0 && hint * (long long)(N * N * N) < (long long)m->tune.fine_below * 4096 &&
+                   (pairs == 0 || pairs >= (long long)m->tune.fine_min_frames_per_item * hint)) ? 2 : 4;
+        if (m->tune.force_vpl) vpl = m->tune.force_vpl;
+        const int wpc = vpl == 2 ? Geom<N, 2>::WPC : Geom<N, 4>::WPC;
+        const int step = vpl == 2 ? Geom<N, 2>::GRID_STEP : Geom<N, 4>::GRID_STEP;
+        const long long units = (long long)total * wpc;
+        constexpr int WPB = Geom<N, 4>::WPB;
+        long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * wpc + WPB - 1) / WPB : (long long)Geom<N, 4>::GRID;
+        if (m->tune.persistent_grid) blocks = m->tune.persistent_grid == 1 ? (long long)Geom<N, 4>::GRID : 256ll * m->tune.persistent_grid * (4 / WPB);
+        blocks = std::min<long long>(blocks, (units + WPB - 1) / WPB);
+        // Two granularities in one launch: the last seventh of the (cost-ordered) items at 2 voxels per lane -- units of half the length
+        // where the launch drains -- when the launch is long enough to have a tail worth shortening (>= 2 rounds of the chip).  The
+        // kernel takes the split only if the grid covers every unit (it knows the true item count), so the grid is sized for it.
+        int split = -1;
+        if (vpl == 4 && hint > 0 && hint * (long long)Geom<N, 4>::WPC >= 2ll * Geom<N, 4>::GRID * WPB) {
+            const int tail_percent = m->tune.tail_percent;  // (driver window, round 3: 97.8 us without, 95.7 with 15 %, 98.9 with 25 %, 104 with 50 %; no effect late in the stream)
+            if (tail_percent > 0) {
+                const long long n_est = hint + hint / 8 + 8;
+                split = (int)std::max<long long>(0, hint - hint * tail_percent / 100);
+                const long long u0 = ((split + 7) / 8) * (long long)Geom<N, 4>::WPC + ((n_est + 7) / 8 - (split + 7) / 8) * (long long)Geom<N, 2>::WPC;
+                const long long need = 8 * ((u0 + WPB - 1) / WPB);
+                if (need <= (long long)INTEGRATE_GRID_CAP) blocks = std::max(blocks, need);
+                else split = -1;
+            }
+        }
+        blocks = std::min<long long>(blocks, (long long)INTEGRATE_GRID_CAP);
+        const int grid = (int)std::max<long long>(step, (blocks + step - 1) / step * step);
+        m->launch_stats[vpl == 2 ? 0 : (split >= 0 ? 2 : 1)]++;
+        m->launch_stats[7]++;
+        if (inline_resolve) m->launch_stats[6]++;
+        int *queues = bs.cand_count + COUNT_QUEUE0;
+        bool same_cam = color;
+        for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
+        const bool back_recorded = m->tune.ext_events && !m->profiling;  // back_done = the integration kernel's own completion
+#define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
+    do {                                                                                                                             \
+        if (back_recorded)                                                                                                           \
+            hipExtLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, nullptr, bs.back_done, 0, IP, m->view, \
+                                  (const MapView *)m->view_dev, (const WorkItem *)bs.items, (const CellRec *)bs.cells, bs.sync, (const int *)wc, queues,       \
+                                  m->items_capacity, split);                                                                         \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
+                               bs.cells, bs.sync, wc, queues, m->items_capacity, split);                                             \
+    } while (0)
+        if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
+            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);
+            else CHISEL_LAUNCH_INTEGRATE(true, true, 4);
+        } else if (color) {
+            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, false, 2);
+            else CHISEL_LAUNCH_INTEGRATE(true, false, 4);
+        } else {
+            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(false, false, 2);
+            else CHISEL_LAUNCH_INTEGRATE(false, false, 4);
+        }
+#undef CHISEL_LAUNCH_INTEGRATE
+    }
+    HIP_TRY(hipGetLastError());
+    m->mesh_totals_clean = true;  // (integrate_kernel's first thread zeroes the next recompute's totals)
+    if (!(m->tune.ext_events && !m->profiling)) HIP_TRY(hipEventRecord(bs.back_done, m->stream));
+    if (replay) return CHISEL_HIP_OK;
+    m->batch_seq++;
+    if (m->cfg.n_shards <= 1) {  // (the shards of a group are issued by a thread each: one unsynchronised timer would only record their race)
+        g_host_timer.lap(5);
+        if (g_host_timer.on) g_host_timer.calls++;
+    }
+    return CHISEL_HIP_OK;
+}
 
 // The launch set of one batch.  Front half on the auxiliary stream, back half on the map's stream (see BatchSet).
 template <int N>
@@ -583,107 +724,18 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     if (!front_recorded) HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
     }
     g_host_timer.lap(4);
-    RoctxRange back_range("chisel_hip back half: integrate");
-    // ---- back half: the map's stream.  A mesh recompute still in flight must have been sized first (it may have to be
-    // emitted again from the voxels as they are now); its front-half work above did not depend on that.
-    const bool recompute_in_flight = m->pending_meshes.unchecked;
-    {
-        int rc_m = check_mesh_totals(m);
-        if (rc_m) return rc_m;
+    return launch_back<N>(m, bs, IP, color, total, inline_resolve, false);
+}
+
+// the integration of a set that was queued behind a recompute which then did not fit: its kernel left at once (MC_LATCH), here it is again
+int replay_deferred_set(chisel_hip_map *m, int set) {
+    chisel_hip_map::BatchSet &bs = m->sets[set];
+    m->launch_stats[9]++;
+    switch (m->N) {
+        case 8: return launch_back<8>(m, bs, bs.replay_ip, bs.replay_color, bs.replay_total, bs.replay_inline, true);
+        case 16: return launch_back<16>(m, bs, bs.replay_ip, bs.replay_color, bs.replay_total, bs.replay_inline, true);
+        default: return launch_back<32>(m, bs, bs.replay_ip, bs.replay_color, bs.replay_total, bs.replay_inline, true);
     }
-    if (!inline_resolve) {
-        // A front half that has already finished needs no wait packet in front of the integration kernel (the packet is only looked at
-        // once the kernel in front of it has ended, and the dispatch behind it only once the packet has retired).  With a recompute
-        // in flight the host has just waited for its triangle kernel to START (check_mesh_totals), that kernel has another 15-25 us
-        // to run and this batch's front half, queued before that wait, is over or about to be: worth a short look.  (Default window
-        // 87.8 -> 89.9 k frames/s; nothing on streams without recomputes, where the host runs batches ahead of the device.)
-        const bool never = m->tune.always_wait_packet;
-        bool done = !never && hipEventQuery(bs.front_done) == hipSuccess;
-        if (!done && !never && recompute_in_flight) {
-            const auto t0 = std::chrono::steady_clock::now();
-            while (!(done = hipEventQuery(bs.front_done) == hipSuccess) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) {}
-        }
-        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        if (!done) HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
-    }
-    int *wc = bs.cand_count + COUNT_ITEMS;
-    {
-        ProfScope ps(m, CHISEL_HIP_KERNEL_INTEGRATE);
-        // Grid.  One unit per wave and the hardware's in-order workgroup dispatch over the cost-ordered work-list is the
-        // schedule that works best (the SIMDs issue from their oldest wave first: a persistent wave that pulls a second unit keeps
-        // its age and starves the younger waves' first units).  The number of work items is only known on the device, so the grid
-        // is sized from the count a recent launch of this map reported (pinned word [2] beside the error flags, written by the
-        // integration kernel; it lags by the launches in flight) plus 1/8; surplus workgroups find no unit and leave, a shortfall
-        // is pulled from the queue heads by the workgroups as they finish.  Without a report yet: what the chip holds at once.
-        // The same figure picks the granularity: 2 voxels per lane for launches of several frames below INTEGRATE_FINE_BELOW items
-        // (about three rounds of the chip at 4 voxels per lane), 4 otherwise (kernels_integrate.h).
-        const long long hint = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[2];
-        const long long pairs = (long long)reinterpret_cast<volatile int *>(m->error_flag_host)[3];  // (item, frame) pairs of that launch, 0 = unknown
-        int vpl = (IP.n_frames >= 4 && hint > 0 && hint * (long long)(N * N * N) < (long long)m->tune.fine_below * 4096 &&
-                   (pairs == 0 || pairs >= (long long)m->tune.fine_min_frames_per_item * hint)) ? 2 : 4;
-        if (m->tune.force_vpl) vpl = m->tune.force_vpl;
-        const int wpc = vpl == 2 ? Geom<N, 2>::WPC : Geom<N, 4>::WPC;
-        const int step = vpl == 2 ? Geom<N, 2>::GRID_STEP : Geom<N, 4>::GRID_STEP;
-        const long long units = (long long)total * wpc;
-        constexpr int WPB = Geom<N, 4>::WPB;
-        long long blocks = hint > 0 ? ((hint + hint / 8 + 8) * wpc + WPB - 1) / WPB : (long long)Geom<N, 4>::GRID;
-        if (m->tune.persistent_grid) blocks = m->tune.persistent_grid == 1 ? (long long)Geom<N, 4>::GRID : 256ll * m->tune.persistent_grid * (4 / WPB);
-        blocks = std::min<long long>(blocks, (units + WPB - 1) / WPB);
-        // Two granularities in one launch: the last seventh of the (cost-ordered) items at 2 voxels per lane -- units of half the length
-        // where the launch drains -- when the launch is long enough to have a tail worth shortening (>= 2 rounds of the chip).  The
-        // kernel takes the split only if the grid covers every unit (it knows the true item count), so the grid is sized for it.
-        int split = -1;
-        if (vpl == 4 && hint > 0 && hint * (long long)Geom<N, 4>::WPC >= 2ll * Geom<N, 4>::GRID * WPB) {
-            const int tail_percent = m->tune.tail_percent;  // (driver window, round 3: 97.8 us without, 95.7 with 15 %, 98.9 with 25 %, 104 with 50 %; no effect late in the stream)
-            if (tail_percent > 0) {
-                const long long n_est = hint + hint / 8 + 8;
-                split = (int)std::max<long long>(0, hint - hint * tail_percent / 100);
-                const long long u0 = ((split + 7) / 8) * (long long)Geom<N, 4>::WPC + ((n_est + 7) / 8 - (split + 7) / 8) * (long long)Geom<N, 2>::WPC;
-                const long long need = 8 * ((u0 + WPB - 1) / WPB);
-                if (need <= (long long)INTEGRATE_GRID_CAP) blocks = std::max(blocks, need);
-                else split = -1;
-            }
-        }
-        blocks = std::min<long long>(blocks, (long long)INTEGRATE_GRID_CAP);
-        const int grid = (int)std::max<long long>(step, (blocks + step - 1) / step * step);
-        m->launch_stats[vpl == 2 ? 0 : (split >= 0 ? 2 : 1)]++;
-        m->launch_stats[7]++;
-        if (inline_resolve) m->launch_stats[6]++;
-        int *queues = bs.cand_count + COUNT_QUEUE0;
-        bool same_cam = color;
-        for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
-        const bool back_recorded = m->tune.ext_events && !m->profiling;  // back_done = the integration kernel's own completion
-#define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
-    do {                                                                                                                             \
-        if (back_recorded)                                                                                                           \
-            hipExtLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, nullptr, bs.back_done, 0, IP, m->view, \
-                                  (const MapView *)m->view_dev, (const WorkItem *)bs.items, (const CellRec *)bs.cells, bs.sync, (const int *)wc, queues,       \
-                                  m->items_capacity, split);                                                                         \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
-                               bs.cells, bs.sync, wc, queues, m->items_capacity, split);                                             \
-    } while (0)
-        if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
-            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);
-            else CHISEL_LAUNCH_INTEGRATE(true, true, 4);
-        } else if (color) {
-            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, false, 2);
-            else CHISEL_LAUNCH_INTEGRATE(true, false, 4);
-        } else {
-            if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(false, false, 2);
-            else CHISEL_LAUNCH_INTEGRATE(false, false, 4);
-        }
-#undef CHISEL_LAUNCH_INTEGRATE
-    }
-    HIP_TRY(hipGetLastError());
-    m->mesh_totals_clean = true;  // (integrate_kernel's first thread zeroes the next recompute's totals)
-    if (!(m->tune.ext_events && !m->profiling)) HIP_TRY(hipEventRecord(bs.back_done, m->stream));
-    m->batch_seq++;
-    if (m->cfg.n_shards <= 1) {  // (the shards of a group are issued by a thread each: one unsynchronised timer would only record their race)
-        g_host_timer.lap(5);
-        if (g_host_timer.on) g_host_timer.calls++;
-    }
-    return CHISEL_HIP_OK;
 }
 
 int check_frame(chisel_hip_map *m, const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c) {
@@ -1176,6 +1228,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) m->tune.force_cull_waves = atoi(e) == 4 ? 4 : (atoi(e) == 1 ? 1 : 16);
     if (const char *e = getenv("CHISEL_HIP_REFINE_PROMPT")) m->tune.refine_prompt = atoi(e) ? 1 : 0;
     if (const char *e = getenv("CHISEL_HIP_REFINE_FPG")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) m->tune.refine_fpg = v; }
+    if (const char *e = getenv("CHISEL_HIP_DEFER_TOTALS")) m->tune.defer_totals = atoi(e);
     if (const char *e = getenv("CHISEL_HIP_CULL_CONTIG")) m->tune.force_cull_contig = atoi(e) ? 1 : 0;
     if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) m->tune.persistent_grid = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = getenv("CHISEL_HIP_TAIL_PERCENT")) m->tune.tail_percent = atoi(e);
@@ -1308,6 +1361,7 @@ int chisel_hip_set_integrator(chisel_hip_map *m, const chisel_hip_integrator *in
 }
 
 int chisel_hip_set_stream(chisel_hip_map *m, void *s) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a group runs on the streams of its shards (one set per GPU): order device frames with chisel_hip_wait_event / record_event");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     int rc = sync_all(m);
@@ -1328,6 +1382,7 @@ int chisel_hip_wait_event(chisel_hip_map *m, void *ev) {
 }
 
 int chisel_hip_record_event(chisel_hip_map *m, void *ev) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "one event cannot be recorded on the streams of several GPUs: chisel_hip_synchronize the group instead");
     if (!m || !ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -1336,6 +1391,7 @@ int chisel_hip_record_event(chisel_hip_map *m, void *ev) {
 }
 
 int chisel_hip_synchronize(chisel_hip_map *m) {
+    SETTLE(m);
     if (m && m->is_group) return group::for_all(m, [](chisel_hip_map *s) { return chisel_hip_synchronize(s); });
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
@@ -1369,6 +1425,7 @@ int chisel_hip_integrate_batch(chisel_hip_map *m, int n, const chisel_hip_depth_
 // chunk, the return value "some voxel changed".  The chunk must be resident (the reference's caller holds a Chunk object); the frame
 // goes through the ordinary launch set with the candidate range pinned to that id.
 int chisel_hip_integrate_chunk(chisel_hip_map *m, const int id[3], const chisel_hip_depth_frame *f, const chisel_hip_color_frame *c, int *updated) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_integrate_chunk(group::owner_map(m, id), id, f, c, updated) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id || !f) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank) return fail(CHISEL_HIP_ERR_INVALID, "this shard does not own the chunk");
@@ -1393,6 +1450,7 @@ int chisel_hip_integrate_chunk(chisel_hip_map *m, const int id[3], const chisel_
 }
 
 int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
+    SETTLE(m);
     if (m && m->is_group) return group::garbage_collect(m, ids, n);
     if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
     if (n == 0) return CHISEL_HIP_OK;
@@ -1433,6 +1491,7 @@ int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
 }
 
 int chisel_hip_num_chunks(chisel_hip_map *m, int64_t *out) {
+    SETTLE(m);
     if (m && m->is_group) {
         if (!out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
         *out = 0;
@@ -1454,6 +1513,7 @@ int chisel_hip_num_chunks(chisel_hip_map *m, int64_t *out) {
 }
 
 int chisel_hip_list_chunks(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    SETTLE(m);
     if (m && m->is_group) {
         std::vector<int> all;
         const int rc = group::gather_ids(m, chisel_hip_list_chunks, false, all);
@@ -1472,6 +1532,7 @@ int chisel_hip_list_chunks(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t
 }
 
 int chisel_hip_has_chunk(chisel_hip_map *m, const int id[3], int *out) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_has_chunk(group::owner_map(m, id), id, out) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -1483,6 +1544,7 @@ int chisel_hip_has_chunk(chisel_hip_map *m, const int id[3], int *out) {
 }
 
 int chisel_hip_download_chunk(chisel_hip_map *m, const int id[3], float *sdf, float *weight, uint8_t *rgbw) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_download_chunk(group::owner_map(m, id), id, sdf, weight, rgbw) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -1688,6 +1750,7 @@ int chisel_hip_depth_filter_read(chisel_hip_depth_filter *f, int which, double *
 }
 
 int chisel_hip_export_chunks(chisel_hip_map *m, const int *ids, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_export_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
@@ -1720,6 +1783,7 @@ int chisel_hip_export_chunks(chisel_hip_map *m, const int *ids, int n, float *sd
 
 int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, const float *sdf, const float *weight, const uint8_t *rgbw,
                                    const int *found, int on_device) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_import_ghost_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
@@ -1760,6 +1824,7 @@ int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, con
 }
 
 int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_drop_ghost_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     if (m->ghost_packed) {
@@ -1824,6 +1889,7 @@ int stage_shell_items(chisel_hip_map *m, const int *items, int n, long long *tot
 }  // namespace
 
 int chisel_hip_dirty_ids_device(chisel_hip_map *m, int *out_dev, int capacity) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m || !out_dev || capacity < 0) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -1852,6 +1918,7 @@ int chisel_hip_dirty_ids_device(chisel_hip_map *m, int *out_dev, int capacity) {
 }
 
 int chisel_hip_export_shells(chisel_hip_map *m, const int *items, int n, float *sdf, float *weight, uint8_t *rgbw, int *found, int on_device) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m || n < 0 || (n > 0 && (!items || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
@@ -1893,6 +1960,7 @@ int chisel_hip_export_shells(chisel_hip_map *m, const int *items, int n, float *
 
 int chisel_hip_import_ghost_shells(chisel_hip_map *m, const int *items, int n, const float *sdf, const float *weight, const uint8_t *rgbw,
                                    const int *found, int on_device) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m || n < 0 || (n > 0 && (!items || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
@@ -1992,6 +2060,7 @@ int ensure_shell_plan(chisel_hip_map *m, int jobset_capacity, int send_capacity)
 // out[4 + 2 p], out[5 + 2 p] = (items, voxels) sent to p, out[4 + 2 W + 2 p], ... = received from p.  The call waits for these figures:
 // the one host wait of a sharded recompute.  A buffer that was ready behind an event: chisel_hip_wait_event first.
 int chisel_hip_shell_plan_device(chisel_hip_map *m, const int *gathered_dev, int world, int cap, int64_t *out) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m || !gathered_dev || !out || cap < 1 || world < 1 || world != m->cfg.n_shards || world > SHELL_MAX_SHARDS) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -2056,6 +2125,7 @@ int64_t chisel_hip_shell_segment_bytes(chisel_hip_map *m, int64_t items, int64_t
 // Step 3, owner side: the segments of the latest plan -- one per peer, in rank order, back to back -- into `out_dev` (`bytes` = their
 // sum: checked).  Nothing is waited for (chisel_hip_record_event orders the collective behind it).
 int chisel_hip_export_shells_packed(chisel_hip_map *m, void *out_dev, int64_t bytes) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m || (bytes > 0 && !out_dev)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -2079,6 +2149,7 @@ int chisel_hip_export_shells_packed(chisel_hip_map *m, void *out_dev, int64_t by
 // buffers leaves) become ghost chunks.  The buffer must stay as it is until chisel_hip_drop_ghost_chunks has been queued (the ghosts are
 // dropped by the ids it holds).  A buffer that is ready behind an event: chisel_hip_wait_event first.
 int chisel_hip_import_shells_packed(chisel_hip_map *m, const void *in_dev, int64_t bytes) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m || (bytes > 0 && !in_dev)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -2203,6 +2274,7 @@ int chisel_hip_mesh_shell_plan(const int *entries, int64_t n_entries, int n_shar
 int64_t chisel_hip_shell_volume(int box, int chunk_edge) { return (int64_t)shell_volume(box, chunk_edge); }
 
 int chisel_hip_save_map(chisel_hip_map *m, const char *path) {
+    SETTLE(m);
     if (m && m->is_group) return group::save_map(m, path);
     if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -2277,6 +2349,7 @@ int chisel_hip_load_map(chisel_hip_map *m, const char *path) {
 }
 
 int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf, const float *weight, const uint8_t *rgbw) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_upload_chunk(group::owner_map(m, id), id, sdf, weight, rgbw) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id || !sdf || !weight) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)
@@ -2307,6 +2380,7 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
 }
 
 int chisel_hip_meshes_to_update(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    SETTLE(m);
     if (m && m->is_group) {
         std::vector<int> all;
         const int rc = group::gather_ids(m, chisel_hip_meshes_to_update, true, all);
@@ -2336,6 +2410,7 @@ int chisel_hip_meshes_to_update(chisel_hip_map *m, int *ids, int64_t max_ids, in
 // 27-neighbourhoods (Chisel.h:175-189) here, plus the entries kept on the host for chunks that were removed while dirty.
 constexpr int DIRTY_TAIL_CAP = 16384;
 int chisel_hip_meshes_to_update_since(chisel_hip_map *m, uint64_t cursor[2], int *ids, int64_t max_ids, int64_t *count, int *cleared) {
+    SETTLE(m);
     if (!m || !cursor || !count || !cleared || max_ids < 0 || (max_ids > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (m->is_group) {  // (a group's shards keep a list each: the whole set every time)
         *cleared = 1;
@@ -2392,6 +2467,7 @@ int chisel_hip_meshes_to_update_since(chisel_hip_map *m, uint64_t cursor[2], int
 // handed over) without waiting: the caller's own wait for that integration (chisel_hip_synchronize: the reference's calls are synchronous)
 // then covers the listing too, and the _since call that follows finds its result.  Nothing happens for a cursor of another epoch.
 int chisel_hip_meshes_to_update_prefetch(chisel_hip_map *m, const uint64_t cursor[2]) {
+    SETTLE(m);
     if (!m || !cursor) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (m->is_group) return CHISEL_HIP_OK;
     if ((cursor[0] >> 32) != (uint64_t)m->dirty_epoch + 1u) return CHISEL_HIP_OK;  // (the set was emptied since: the _since call starts over)
@@ -2409,6 +2485,7 @@ int chisel_hip_meshes_to_update_prefetch(chisel_hip_map *m, const uint64_t curso
 }
 
 int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters) {
+    SETTLE(m);
     if (m && m->is_group) return out ? group::get_counters(m, out, reset_counters) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -2580,6 +2657,7 @@ int chisel_hip_get_launch_stats(chisel_hip_map *m, int64_t *out, int reset_stats
 }
 
 int chisel_hip_memory_statistics(chisel_hip_map *m, chisel_hip_statistics *out) {
+    SETTLE(m);
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     memset(out, 0, sizeof(*out));
     for (int a = 0; a < 3; a++) {
@@ -2626,6 +2704,7 @@ int chisel_hip_memory_statistics(chisel_hip_map *m, chisel_hip_statistics *out) 
 }
 
 int chisel_hip_topology_epoch(chisel_hip_map *m, uint64_t *out) {
+    SETTLE(m);
     if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     *out = m->topology_epoch;
     if (m->is_group)
@@ -2678,6 +2757,7 @@ int chisel_hip_candidates(const float corners[24], const float planes[24], const
 }
 
 int chisel_hip_shade_vertices(chisel_hip_map *m, const float *vertices, int64_t n, float *normals, float *colors, int stages) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_shade_vertices reads the voxels around every vertex: ask the shard that owns them (a group's meshes are shaded by chisel_hip_update_meshes)");
     if (!m || n < 0 || (n > 0 && !vertices)) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
@@ -2790,6 +2870,7 @@ int chisel_hip_kat_color_fresh(unsigned *mismatches) {
 }
 // diagnostics of the last cloud: listed chunks, (unit, point) pairs, rays of the largest unit, units with rays
 int chisel_hip_debug_cloud_stats(chisel_hip_map *m, int64_t out[4]) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "per-shard read-out");
     if (!m || !m->cloud.view.ctl) return fail(CHISEL_HIP_ERR_INVALID, "no cloud yet");
     HIP_TRY(hipSetDevice(m->device));

@@ -127,6 +127,7 @@ int cloud_setup(chisel_hip_map *m, const chisel_hip_pointcloud *cloud, CloudPara
 }  // namespace
 
 extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_hip_pointcloud *cloud) {
+    SETTLE(m);
     if (m && m->is_group) return group::integrate_cloud(m, cloud);
     if (!m || !cloud) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (cloud->n_points < 0 || (cloud->n_points > 0 && !cloud->points)) return fail(CHISEL_HIP_ERR_INVALID, "bad point list");
@@ -172,6 +173,7 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
 // the segments point -+ truncation along the viewing rays pass through -- the listing step of the call above on its own (the same
 // kernel), ids in ascending order (the reference's order is that of an unordered_map).  A shard lists the chunks it owns.
 extern "C" int chisel_hip_cloud_candidates(chisel_hip_map *m, const chisel_hip_pointcloud *cloud, int *ids, int64_t max_ids, int64_t *count) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "per-shard read-out");
     if (!m || !cloud || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (cloud->n_points < 0 || (cloud->n_points > 0 && !cloud->points)) return fail(CHISEL_HIP_ERR_INVALID, "bad point list");

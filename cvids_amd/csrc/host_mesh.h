@@ -150,6 +150,7 @@ void release_mesh_ref(chisel_hip_map *m, MeshRef &ref) {
 void clear_meshes(chisel_hip_map *m) {
     m->pending_meshes.active = false;
     m->pending_meshes.unchecked = false;
+    m->deferred_set = -1;  // (whatever was queued behind an unseen recompute is void with the map; reset_map_kernel clears MC_LATCH)
     for (MeshArena &A : m->arenas) free_arena(m, A);
     m->arenas.clear();
     m->meshes.clear();
@@ -249,9 +250,15 @@ int recompute_meshes(chisel_hip_map *m) {
 // The totals of the recompute in flight: sizes the arena's contents, emits again when the batch outgrew the triangle
 // list or the arena.  Must run before anything else changes the map (a second emission reads the voxels): every entry
 // point that queues map-changing work calls it first; it waits for the count kernel only, not for the stream.
+bool mesh_totals_published(const chisel_hip_map *m) { return ((volatile const int *)m->mesh_totals_host)[5] == m->mesh_seq; }
+int replay_deferred_set(chisel_hip_map *m, int set);  // chisel_hip.hip
 int check_mesh_totals(chisel_hip_map *m) {
     if (!m->pending_meshes.unchecked) return CHISEL_HIP_OK;
     m->pending_meshes.unchecked = false;
+    // a launch set queued behind this recompute before its totals were seen (launch_back): if the recompute is emitted again below, that
+    // set's integration kernel has left the map alone (MC_LATCH) and is launched again afterwards
+    const int deferred = m->deferred_set;
+    m->deferred_set = -1;
     MeshBuffers &B = m->mesh_buf;
     int *d_totals = mesh_totals(m);
     const bool color = m->cfg.use_color != 0;
@@ -269,6 +276,7 @@ int check_mesh_totals(chisel_hip_map *m) {
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
+    const bool device_unfit = m->mesh_totals_host[4] != 0;  // the triangle kernel's own verdict (what MC_LATCH was set by)
     const unsigned packed_jobs = (unsigned)m->mesh_totals_host[2];
     int totals[4] = {m->mesh_totals_host[0], m->mesh_totals_host[1], (int)(packed_jobs >> 31), (int)(packed_jobs & 0x7fffffffu)};
     // A chunk of an earlier batch could not be allocated (word [0] of the map's error flags: pool / hash; cloud reports live in
@@ -315,18 +323,27 @@ int check_mesh_totals(chisel_hip_map *m) {
         A.nv = nv;
         A.ng = ng;
         A.color = color;
+        if (redo ? !device_unfit : (A.floats() > A.capacity) != device_unfit)  // (the device's verdict is what a deferred launch went by)
+            return fail(CHISEL_HIP_ERR_HIP, "mesh recompute: host and device disagree on whether it fitted");
         if (redo || A.floats() > A.capacity) {
             // did not fit (or was listed again): emit once more into a buffer of the right size
             HIP_TRY(hipStreamSynchronize(m->stream));
+            HIP_TRY(hipMemsetAsync(mesh_totals(m) + MC_LATCH, 0, sizeof(int), m->stream));  // (in front of the replay below)
             if (A.floats() > A.capacity) {
                 m->arena_pool.emplace_back(A.dev, A.capacity);
                 A.dev = nullptr;
                 int rc_a = take_arena_buffer(m, A.floats(), &A.dev, &A.capacity);
                 if (rc_a) return rc_a;
             }
-            ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
-            launch_mesh_triangles(m, P, A.dev, A.capacity);
+            {
+                ProfScope ps(m, CHISEL_HIP_KERNEL_MESH);
+                launch_mesh_triangles(m, P, A.dev, A.capacity);
+            }
             HIP_TRY(hipGetLastError());
+            if (deferred >= 0) {
+                int rc_r = replay_deferred_set(m, deferred);
+                if (rc_r) return rc_r;
+            }
         }
         m->mesh_need_hint = A.floats();
         if (nv + ng == 0) {
@@ -482,6 +499,7 @@ std::vector<uint64_t> sorted_mesh_keys(const chisel_hip_map *m) {
 extern "C" {
 
 int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
+    SETTLE(m);
     if (m && m->is_group) return group::update_meshes(m, force);
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     if (m->cfg.n_shards > 1)
@@ -515,6 +533,7 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
 }
 
 int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_update_meshes_of is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
     HIP_TRY(hipSetDevice(m->device));
@@ -543,6 +562,7 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
 
 // Step 5 of a sharded recompute: the jobs of the latest plan (chisel_hip_shell_plan_device) -- a list that never left the device.
 int chisel_hip_update_meshes_planned(chisel_hip_map *m) {
+    SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m || !m->shell_plan.my_jobs) return fail(CHISEL_HIP_ERR_INVALID, "no plan: chisel_hip_shell_plan_device first");
     HIP_TRY(hipSetDevice(m->device));
@@ -569,6 +589,7 @@ int chisel_hip_update_meshes_planned(chisel_hip_map *m) {
 // ChunkManager::RecomputeMesh(chunkID, mutex) (ChunkManager.cpp:91-128): the mesh of one chunk into allMeshes; meshesToUpdate is the
 // caller's business there (Chisel::UpdateMeshes clears it, Chisel.cpp:57), so nothing of it is touched here
 int chisel_hip_recompute_mesh(chisel_hip_map *m, const int id[3]) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_recompute_mesh(group::owner_map(m, id), id) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     m->mesh_detached = true;
@@ -581,6 +602,7 @@ int chisel_hip_recompute_mesh(chisel_hip_map *m, const int id[3]) {
 // chunk (mesh_one_cube_kernel): up to 15 vertices and as many (face) normals; *occupied = a grid entry belongs to the cube.
 int chisel_hip_mesh_cube(chisel_hip_map *m, const int id[3], const int voxel[3], const float coords[3], float *vertices, float *normals, int *n_vertices,
                          int *occupied) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_mesh_cube(group::owner_map(m, id), id, voxel, coords, vertices, normals, n_vertices, occupied)
                                     : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id || !voxel || !coords || !n_vertices || !occupied) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
@@ -616,6 +638,7 @@ int chisel_hip_mesh_cube(chisel_hip_map *m, const int id[3], const int voxel[3],
 // off, its result is copied out and the map's own mesh entry of the chunk (if any) is put back.
 int chisel_hip_generate_mesh(chisel_hip_map *m, const int id[3], int stages, int64_t capacity_vertices, int64_t capacity_grids, float *vertices,
                              float *normals, float *colors, float *grids, int64_t *n_vertices, int64_t *n_grids) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_generate_mesh(group::owner_map(m, id), id, stages, capacity_vertices, capacity_grids, vertices, normals, colors, grids, n_vertices, n_grids)
                                     : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id || !n_vertices || !n_grids) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
@@ -673,6 +696,7 @@ int chisel_hip_generate_mesh(chisel_hip_map *m, const int id[3], int stages, int
 }
 
 int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) {
+    SETTLE(m);
     if (m && m->is_group) {
         if (!out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
         *out = 0;
@@ -693,6 +717,7 @@ int chisel_hip_num_meshes(chisel_hip_map *m, int64_t *out) {
 }
 
 int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t *count) {
+    SETTLE(m);
     if (m && m->is_group) return group::list_meshes(m, ids, max_ids, count);
     if (!m || !count) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -706,6 +731,7 @@ int chisel_hip_list_meshes(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t
 }
 
 int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_t *ng) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_mesh_size(group::owner_map(m, id), id, nv, ng) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -719,6 +745,7 @@ int chisel_hip_mesh_size(chisel_hip_map *m, const int id[3], int64_t *nv, int64_
 }
 
 int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float *n, float *c, float *g) {
+    SETTLE(m);
     if (m && m->is_group) return id ? chisel_hip_download_mesh(group::owner_map(m, id), id, v, n, c, g) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !id) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
@@ -738,12 +765,14 @@ int chisel_hip_download_mesh(chisel_hip_map *m, const int id[3], float *v, float
 }
 
 int chisel_hip_get_sdf(chisel_hip_map *m, const float pos[3], double *dist, int *found) {
+    SETTLE(m);
     if (m && m->is_group) return pos ? group::get_sdf(m, pos, dist, found) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !pos) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     return query_sdf(m, pos, 0, dist, nullptr, found);
 }
 
 int chisel_hip_get_sdf_and_gradient(chisel_hip_map *m, const float pos[3], double *dist, float grad[3], int *found) {
+    SETTLE(m);
     if (m && m->is_group) return pos ? group::get_sdf_and_gradient(m, pos, dist, grad, found) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !pos) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     return query_sdf(m, pos, 1, dist, grad, found);
@@ -802,6 +831,7 @@ extern "C" {
 // formatting (operator<< of float / int).  The reference concatenates the meshes in the iteration order of its
 // std::unordered_map (unspecified); here chunks are written in ascending id order.
 int chisel_hip_save_ply(chisel_hip_map *m, const char *path) {
+    SETTLE(m);
     if (m && m->is_group) return path ? group::save_ply(m, path) : fail(CHISEL_HIP_ERR_INVALID, "null argument");
     if (!m || !path) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     std::ofstream stream(path);

@@ -229,7 +229,11 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
     const int nb = (int)gridDim.x;  // multiple of 8 and of 2 * WPC
     const int xcd = (int)blockIdx.x & 7;
     const int local_unit = ((int)blockIdx.x >> 3) * G::WPB + wave;  // this wave among its XCD's
+    // The recompute in front of this launch will be emitted again (chisel_device.h: MC_LATCH): the launch leaves the map alone and the host
+    // replays it afterwards.  (Requested together with the item count: one scalar wait for both.)
+    const int latch = M.mesh_ctl ? M.mesh_ctl[MC_LATCH] : 0;
     int n_items = *work_count;
+    if (latch) return;
     if (n_items > max_items) n_items = max_items;
     const int total = n_items * G::WPC;
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void reset_map_kernel(MapView M, int V, int al
         M.slot_dirty[2 * (size_t)M.max_chunks] = 0;  // the list of dirty slots is empty
         if (M.mesh_ctl) {
             M.mesh_ctl[4] = 0;                       // and so is the job list
+            M.mesh_ctl[MC_LATCH] = 0;                // (a recompute that did not fit: void with the map)
             for (int a = 0; a < 3; a++) {            // the box of created ids: empty
                 M.mesh_ctl[MC_BBOX + a] = INT32_MAX;
                 M.mesh_ctl[MC_BBOX + 3 + a] = INT32_MIN;

@@ -317,6 +317,7 @@ constexpr int MESH_PARTS = 64;  // partitions of the unordered record lists
 // from [8] on MESH_PARTS 64-bit cursors (triangles | cubes << 32).  [0..2] and the cursors start every recompute at zero.
 enum { MC_TRIS = 0, MC_GRIDS = 1, MC_OVERFLOW = 2, MC_JOBS = 3, MC_KEPT = 4, MC_CURSORS = 8, MC_INTS = MC_BBOX + 8 };  // (MC_BBOX: chisel_device.h)
 static_assert(MC_BBOX == MC_CURSORS + 2 * MESH_PARTS, "the created-id box sits behind the cursors");
+static_assert(MC_LATCH > MC_KEPT && MC_LATCH < MC_CURSORS, "a free word in front of the cursors");
 static_assert(MC_CURSORS == 8 && MESH_PARTS == 64 && MC_KEPT == 4, "kernels_integrate.h / kernels_map.h address these words by number");
 
 #ifndef MESH_COUNT_WAVES
@@ -700,6 +701,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         *reinterpret_cast<uint4 *>(const_cast<int *>(host_flags)) = v;
         // what the host polls is a second copy of the sequence number behind a system-scope fence: that the 16 bytes above arrive
         // as one piece is how the bus behaves, not a guarantee (this thread alone pays the few hundred nanoseconds)
+        host_flags[4] = (totals[MC_OVERFLOW] == 0 && (size_t)n_tris * 9 * (P.use_color ? 3 : 2) + (size_t)totals[MC_GRIDS] * 3 <= arena_floats) ? 0 : 1;  // (`fits`, below)
         __threadfence_system();
         host_flags[5] = seq;
         // the job list the integration kernels keep has been consumed by the count kernel (its number is in totals[3]): empty again
@@ -708,6 +710,8 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     const size_t nv3 = (size_t)n_tris * 9, ng3 = (size_t)totals[MC_GRIDS] * 3;
     // a triangle list that overflowed (totals[2]) is incomplete: nothing is emitted, the host lists and emits again
     const bool fits = totals[MC_OVERFLOW] == 0 && nv3 * (P.use_color ? 3 : 2) + ng3 <= arena_floats;
+    // ... and an integration launch the host has queued behind this recompute without waiting for its totals must not touch the map
+    if ((publish & 1) && !fits && blockIdx.x == 0 && threadIdx.x == 0 && M.mesh_ctl) M.mesh_ctl[MC_LATCH] = 1;
     if (blockIdx.x == 0) {
         const int *src = reinterpret_cast<const int *>(info);
         const int n = min(n_jobs, max_jobs) * 8;

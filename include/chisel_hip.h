@@ -449,8 +449,9 @@ int chisel_hip_raycast(const float start[3], const float end[3], const int min_x
 /* Which shapes the launch heuristics picked since the map was created / last reset of these figures (no reference counterpart: a
  * diagnostic beside chisel_hip_get_profile): out[0..7] = integration launches at 2 voxels per lane, at 4, at 4 with a 2-voxel tail;
  * cull launches with four waves per workgroup, with one wave per frame; launch sets without an order kernel; launch sets in the
- * short single-stream form; launch sets in all.  A group handle sums its shards. */
-#define CHISEL_HIP_NUM_LAUNCH_STATS 8
+ * short single-stream form; launch sets in all; out[8..9] = launch sets queued behind a mesh recompute whose totals the host had not seen
+ * yet, and the ones of them that had to be replayed because that recompute did not fit.  A group handle sums its shards. */
+#define CHISEL_HIP_NUM_LAUNCH_STATS 10
 int chisel_hip_get_launch_stats(chisel_hip_map *map, int64_t *out, int reset_stats);
 /* owner shard of a chunk id under (n_shards, shard_block); pure function, same on every rank */
 int chisel_hip_chunk_owner(const int id_xyz[3], int n_shards, int shard_block);

@@ -231,6 +231,46 @@ def test_recompute_that_outgrows_its_buffers(oracle_mod, monkeypatch):
     assert n > 10 and nv > 1000
 
 
+def test_integration_queued_behind_an_unseen_recompute_is_replayed(oracle_mod, monkeypatch):
+    """An integration call right after UpdateMeshes() is queued behind the recompute before the host has seen whether that fitted its
+    buffers; one that did not fit sets a word on the device, the integration kernel leaves the map alone, and the host -- when it next
+    looks -- emits the recompute again from the untouched map and replays the launch.  Forced here for every recompute
+    (CHISEL_HIP_MESH_TINY: nothing ever fits; CHISEL_HIP_DEFER_TOTALS=2: queued unseen even when the totals are there): meshes after
+    every step and voxels at the end equal the oracle's, and the statistics say the replays happened."""
+    monkeypatch.setenv("CHISEL_HIP_MESH_TINY", "1")
+    monkeypatch.setenv("CHISEL_HIP_DEFER_TOTALS", "2")
+    om, gm, integ = _mk(oracle_mod, 16, 0.04, True, max_chunks=4096)
+    W, H = 160, 120
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    color = synth.render_color(W, H, 3)
+    frames = make_frames("sphere_room", 20, W, H)
+    for lo in range(0, len(frames), 5):
+        part = frames[lo:lo + 5]
+        for d, p in part:
+            om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+        gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        om.update_meshes(force=True)
+        gm.UpdateMeshes(force=True)
+        if lo == 10:
+            _compare_meshes(om, gm, True)  # (a reader in the middle: settles what is queued, then reads)
+    st = gm.launch_stats()
+    assert st["behind_unseen_recompute"] >= 2 and st["replayed"] >= 2, st  # (steps 2 and 3; step 4 follows a reader, which settled everything)
+    from tests.common import compare_fields
+    compare_fields(om.fields(), gm.fields(), om.V, True)
+    n, nv = _compare_meshes(om, gm, True)
+    assert n > 10 and nv > 1000
+    # the same stream with the totals looked at before every launch gives the same map (and no replays)
+    monkeypatch.setenv("CHISEL_HIP_DEFER_TOTALS", "0")
+    _, gm0, integ0 = _mk(oracle_mod, 16, 0.04, True, max_chunks=4096)
+    for lo in range(0, len(frames), 5):
+        part = frames[lo:lo + 5]
+        gm0.IntegrateBatch(integ0, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        gm0.UpdateMeshes(force=True)
+    assert gm0.launch_stats()["behind_unseen_recompute"] == 0
+    compare_fields(gm0.fields(), gm.fields(), om.V, True)
+
+
 def test_mesh_color_lookup_near_origin(oracle_mod):
     """10 cm voxels: InterpolateColor's integer-index lookups (ChunkManager.cpp:506-520) land inside the map"""
     om, gm, integ = _mk(oracle_mod, 8, 0.10, True, trunc=("constant", 0.3), max_chunks=8192)
