@@ -545,6 +545,25 @@ def test_integration_schedules(oracle_mod, chunk, mode, monkeypatch):
     compare_fields(om.fields(), gm.fields(), om.V, True)
 
 
+@pytest.mark.parametrize("agents", [3, 4])
+def test_chunks_seen_by_every_third_launch(oracle_mod, agents, monkeypatch):
+    """Agents that look in different directions, ONE frame per call, nothing waited for: a chunk only agent 0 sees is a candidate of
+    launch sets k, k + agents, ... and of none in between -- the front half of set k + 3 may look it up while the integration of set k
+    is still creating it.  The map must equal the oracle's all the same (no chunk created twice, none missed)."""
+    monkeypatch.setenv("CHISEL_HIP_FORCE_PIPELINE", "1")
+    om, gm, integ = _mk(oracle_mod, 16, 0.02, False, max_chunks=16384)
+    W, H = 320, 240
+    cam = small_camera(W, H)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    frames = make_frames("sphere_room", 8, W, H, agents=agents)
+    for d, p in frames:
+        om.integrate_depth(d, p, intr, cam.near_plane, cam.far_plane)
+    for d, p in frames:
+        gm.IntegrateBatch(integ, [(d, p, cam)])
+    assert om.num_chunks() == gm.NumChunks()
+    compare_fields(om.fields(), gm.fields(), om.V, False)
+
+
 def test_checkpoint_and_resume(oracle_mod, tmp_path):
     """chisel_hip_save_map / load_map: a map dumped in the middle of a stream and restored into a fresh map continues
     bit for bit like the uninterrupted run (and like the oracle); the dump itself reads back identically"""
