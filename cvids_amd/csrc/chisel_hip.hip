@@ -2524,6 +2524,12 @@ int chisel_hip_get_counters(chisel_hip_map *m, uint64_t *out, int reset_counters
             unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_phase), z, sizeof(z));
         }
+        if (hipMemcpyFromSymbol(mp, HIP_SYMBOL(g_tri_phase), sizeof(mp)) == hipSuccess && mp[7]) {
+            fprintf(stderr, "mesh_triangle_kernel, us per wave (lane 0): prefix + search %.2f | record, job row, position %.2f | corners, three vertices %.2f | gradient %.2f | colour %.2f | waves sampled %llu\n",
+                    mp[0] * 0.01 / mp[7], mp[1] * 0.01 / mp[7], mp[2] * 0.01 / mp[7], mp[3] * 0.01 / mp[7], mp[4] * 0.01 / mp[7], mp[7]);
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tri_phase), z, sizeof(z));
+        }
     }
     if (ph[15] && ph[17]) {  // where an executed frame's time goes (10 ns ticks summed over waves)
         uint64_t f[6] = {0, 0, 0, 0, 0, 0};

@@ -72,26 +72,41 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
     float mn = INFINITY, mx = -INFINITY;
     if (px0 < W && py0 < H) {
         const bool vec = ((W & 3) == 0) && (px0 + 3 < W);
+        if (vec) {
+            // the thread's rows requested two at a time (a row past the image reads the last one again and is dropped below): two round
+            // trips for the tile instead of four -- the kernel is one generation of waves, as long as its chain of dependent accesses.
+            // (All four at once take 39 registers: beside an integration kernel that leaves 32 per SIMD the kernel would wait for its drain.)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int py = py0 + r;
-            if (py >= H) break;
-            if (vec) {
-                float4 d = *reinterpret_cast<const float4 *>(depth + (size_t)py * W + px0);
-                float v[4] = {d.x, d.y, d.z, d.w};
-                PixelRec o[4];
+            for (int h = 0; h < 2; h++) {
+                float4 d4[2];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    o[c] = make_record(P.ip, v[c]);
-                    if (depth_valid(v[c], max_depth)) {
-                        mn = fminf(mn, v[c]);
-                        mx = fmaxf(mx, v[c]);
+                for (int r = 0; r < 2; r++) {
+                    const int py = py0 + 2 * h + r < H ? py0 + 2 * h + r : H - 1;
+                    d4[r] = *reinterpret_cast<const float4 *>(depth + (size_t)py * W + px0);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int py = py0 + 2 * h + r;
+                    if (py < H) {
+                        const float v[4] = {d4[r].x, d4[r].y, d4[r].z, d4[r].w};
+                        PixelRec o[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            o[c] = make_record(P.ip, v[c]);
+                            if (depth_valid(v[c], max_depth)) {
+                                mn = fminf(mn, v[c]);
+                                mx = fmaxf(mx, v[c]);
+                            }
+                        }
+                        float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)py * W + px0);
+                        dst[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                        dst[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
                     }
                 }
-                float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)py * W + px0);
-                dst[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
-                dst[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
-            } else {
+            }
+        } else {
+            for (int r = 0; r < 4 && py0 + r < H; r++) {
+                const int py = py0 + r;
                 for (int c = 0; c < 4 && px0 + c < W; c++) {
                     float v = depth[(size_t)py * W + px0 + c];
                     rec[(size_t)py * W + px0 + c] = make_record(P.ip, v);

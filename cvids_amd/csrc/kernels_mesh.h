@@ -364,6 +364,12 @@ __device__ unsigned long long g_mesh_phase[8];  // diagnostic: 10 ns ticks per s
 #else
 #define MSTAMP(i) do { } while (0)
 #endif
+#ifdef CHISEL_PHASES
+__device__ unsigned long long g_tri_phase[8];  // diagnostic: 10 ns ticks per stage of mesh_triangle_kernel (lane 0 of every 32nd wave), [6] = kernel start -> this wave's start, [7] = waves
+#define TSTAMP(i, dep) do { asm volatile("" ::"v"(dep)); if ((threadIdx.x & 63) == 0 && ((blockIdx.x * (MESH_TRI_BLOCK / 64) + (threadIdx.x >> 6)) & 31) == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_tri_phase[i], n_ - tt_); tt_ = n_; } } while (0)
+#else
+#define TSTAMP(i, dep) do { } while (0)
+#endif
 
 // info[j] = what the host keeps of job j: sizes and its first triangle / grid in the batch (the chunks' ranges follow one another in
 // completion order; within a chunk the order is the reference's).  ctl: see MC_*.  `ids` holds ids_capacity entries.
@@ -674,6 +680,10 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     // concatenation is this grid's i-th triangle: where the partitions begin in that numbering, once per workgroup.  (A partition per
     // workgroup -- no table, no search -- was 1-7 us slower: the workgroups that find nothing to do then sit between the others in dispatch order.)
     __shared__ int s_off[MESH_PARTS + 1];
+#ifdef CHISEL_PHASES
+    unsigned long long tt_ = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0 && ((blockIdx.x * (MESH_TRI_BLOCK / 64) + (threadIdx.x >> 6)) & 31) == 0) atomicAdd(&g_tri_phase[7], 1ull);
+#endif
     if (threadIdx.x < MESH_PARTS) {
         int v = totals[MC_CURSORS + 2 * threadIdx.x];
 #pragma unroll
@@ -734,6 +744,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     for (int o = MESH_PARTS / 2; o > 0; o >>= 1)
         if (s_off[part + o] <= i) part += o;
     i -= s_off[part];
+    TSTAMP(0, i);
     const TriRec rec = tris[(size_t)part * part_capacity + i];
     const MeshJob &job = jobs[rec.job];  // stays in memory (L1 / L2): its neighbour table is indexed per lane
     const int *nb = job.nb;
@@ -760,6 +771,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         }
     }
     const int vi = 3 * tri_pos + mine;
+    TSTAMP(1, vi);
     const unsigned long long row = c_mc_cases[index];
     const f3v origin = mk3((float)(N * jx) * P.res, (float)(N * jy) * P.res, (float)(N * jz) * P.res);  // Chunk.cpp:43
     // cube origin = centroid of voxel (x, y, z) + chunk origin (ChunkManager.cpp:61, :404)
@@ -789,6 +801,7 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
     vo[0] = pv.x;
     vo[1] = pv.y;
     vo[2] = pv.z;
+    TSTAMP(2, pv.x);
     f3v nrm = fn;
     double dist;
     f3v grad;
@@ -796,12 +809,14 @@ __global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M
         const float mag = sqrtf(sum3f(grad.x * grad.x, grad.y * grad.y, grad.z * grad.z));
         if ((double)mag > 1e-12) nrm = scl3(grad, 1.0f / mag);
     }
+    TSTAMP(3, nrm.x);
     no[0] = nrm.x;
     no[1] = nrm.y;
     no[2] = nrm.z;
     if (colors) {
         const f3v col = (P.stages & 2) ? interpolate_color<N>(M, P, pv, jx, jy, jz, nb) : mk3(0.0f, 0.0f, 0.0f);
         float *co = colors + 3 * (size_t)vi;
+        TSTAMP(4, col.x);
         co[0] = col.x;
         co[1] = col.y;
         co[2] = col.z;

@@ -422,13 +422,14 @@ class ShardedChisel:
                 head[0] = len(e)
                 head[1:1 + 4 * min(len(e), cap)] = e[:cap].reshape(-1)
                 buf.copy_(torch.from_numpy(head))
+            lap("dirty ids (issue)")
             if bounce:
                 host = torch.empty(gathered.shape, dtype=torch.int32)
                 dist.all_gather_into_tensor(host, buf.cpu())
                 gathered.copy_(host)
             else:
                 dist.all_gather_into_tensor(gathered, buf)
-            lap("dirty ids + all_gather (issue)")
+            lap("all_gather (issue)")
             if on_gpu:
                 self._order_map_after_collectives()
             plan = self.map.PlanShellsDevice(gathered, world, cap)  # the one host wait of a recompute

@@ -57,7 +57,7 @@ PY
     [ $# = 0 ] && set -- "--steps 200 --warmup 20 --batch 1 --mesh-every 0" "$W_200 --mesh-every 0 --batch 10" "$W_drv --mesh-every 0 --batch 10" "$W_sh8" "$W_4ag8"
     for a in "$@"; do echo "== $a"; python3 bench.py $a $Q --no-roofline --repeats 1 2>&1 | grep -v "^{" | tail -${PHASE_LINES:-5}; done ;;
   mesh-phases) # stage timers of mesh_count_kernel (diagnostic build; every 32nd wave stamps), 200 and drv
-    for a in "$W_200" "$W_drv"; do echo "== bench.py $a"; CHISEL_HIP_LIB=libchisel_hip_ph.so python3 bench.py $a $Q --no-roofline --repeats 1 2>&1 | grep "mesh_count_kernel, us per job\|working waves" | tail -2; done ;;
+    for a in "$W_200" "$W_drv"; do echo "== bench.py $a"; CHISEL_HIP_LIB=libchisel_hip_ph.so python3 bench.py $a $Q --no-roofline --repeats 1 2>&1 | grep "mesh_count_kernel, us per job\|mesh_triangle_kernel, us per wave\|working waves" | tail -3; done ;;
   host-issue) # host time to issue a launch set against its wall time (CHISEL_HIP_HOST_TIMING)
     for a in "$W_sh8" "$W_4ag8" "--mesh-every 0 --batch 16 --steps 320 --warmup 64" "$W_200"; do
       echo "== $a"; CHISEL_HIP_HOST_TIMING=1 python3 bench.py $a $Q --no-roofline --repeats 3 2>/tmp/err.txt | tail -1 | show "host issue"; grep "host us" /tmp/err.txt | tail -2
