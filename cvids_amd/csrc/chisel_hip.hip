@@ -104,6 +104,26 @@ struct HostTimer {
     }
 };
 HostTimer g_host_timer;
+// the same for chisel_hip_update_meshes of a single map: waiting for the previous recompute's totals / job records, the host's
+// bookkeeping of that recompute (which chunk's mesh is where), queueing the new one
+struct MeshHostTimer {
+    double acc[4] = {0, 0, 0, 0};
+    long calls = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { if (g_host_timer.on) t = std::chrono::steady_clock::now(); }
+    void lap(int i) {
+        if (!g_host_timer.on) return;
+        auto n = std::chrono::steady_clock::now();
+        acc[i] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+    ~MeshHostTimer() {
+        if (g_host_timer.on && calls)
+            fprintf(stderr, "chisel_hip host us/recompute: waiting for the previous one's totals %.2f, for its job records %.2f | bookkeeping %.2f | queueing %.2f (recomputes %ld)\n",
+                    acc[0] / calls, acc[1] / calls, acc[2] / calls, acc[3] / calls, calls);
+    }
+};
+MeshHostTimer g_mesh_timer;
 
 // roctx ranges (rocprofv3 --marker-trace) around the two halves of a launch set and the mesh recompute: CHISEL_HIP_ROCTX=1.  The
 // library is looked up at run time (libroctx64.so of the ROCm installation): no link-time dependency, nothing when the variable is unset.

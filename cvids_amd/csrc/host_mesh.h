@@ -387,6 +387,7 @@ int resolve_pending_meshes(chisel_hip_map *m) {
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
+    g_mesh_timer.lap(1);
     std::vector<JobInfo> tail;
     if (n > MESH_INFO_PREFETCH) {
         tail.resize((size_t)n - MESH_INFO_PREFETCH);
@@ -420,6 +421,7 @@ int resolve_pending_meshes(chisel_hip_map *m) {
     }
     if (g_host_timer.on) fprintf(stderr, "chisel_hip mesh recompute: %d jobs, %d with triangles\n", n, with_tris);
     if (arena_id >= 0 && m->arenas[arena_id].live == 0) free_arena(m, m->arenas[arena_id]);
+    g_mesh_timer.lap(2);
     return CHISEL_HIP_OK;
 }
 
@@ -517,10 +519,15 @@ int chisel_hip_update_meshes(chisel_hip_map *m, int force) {
         unpack_id(key, x, y, z);
         extra.push_back(x); extra.push_back(y); extra.push_back(z);
     }
-    rc = resolve_pending_meshes(m);  // the device buffers of the previous recompute are about to be reused
+    g_mesh_timer.start();
+    rc = check_mesh_totals(m);
+    g_mesh_timer.lap(0);
+    if (!rc) rc = resolve_pending_meshes(m);  // the device buffers of the previous recompute are about to be reused
     if (rc) return rc;
     rc = collect_mesh_ids(m, extra);
     if (!rc) rc = recompute_meshes(m);  // ends with meshesToUpdate.clear() (Chisel.cpp:57)
+    g_mesh_timer.lap(3);
+    g_mesh_timer.calls++;
     if (rc) {
         // the mark kernel may have flagged slots that no count kernel will now reset: a slot whose flag stays set could never
         // become a job again

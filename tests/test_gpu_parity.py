@@ -487,13 +487,14 @@ def test_launch_statistics_account_for_every_launch_set(oracle_mod, monkeypatch)
         gm.synchronize()
         return gm, gm.launch_stats()
 
+    forced = bool(os.environ.get("CHISEL_HIP_FORCE_PIPELINE"))  # (tools/stress_hooks.sh runs the suite under it: no single-stream form then)
     gm, st = run(wait=True)
-    assert st["launch_sets"] == 6 and st["single_stream_sets"] == 6
+    assert st["launch_sets"] == 6 and st["single_stream_sets"] == (0 if forced else 6)
     assert st["integrate_2_per_lane"] + st["integrate_4_per_lane"] + st["integrate_4_with_2_tail"] == 6
     assert st["cull_4_waves"] + st["cull_wave_per_frame"] == 6
     assert gm.launch_stats(reset=True)["launch_sets"] == 6 and gm.launch_stats()["launch_sets"] == 0
     _, st = run(wait=False)
-    assert st["launch_sets"] == 6 and 1 <= st["single_stream_sets"] <= 6  # (the first set finds the map idle; the rest depends on timing)
+    assert st["launch_sets"] == 6 and (st["single_stream_sets"] == 0 if forced else 1 <= st["single_stream_sets"] <= 6)  # (the first set finds the map idle; the rest depends on timing)
     monkeypatch.setenv("CHISEL_HIP_VPL", "2")
     _, st = run(wait=True)
     assert st["integrate_2_per_lane"] == 6
