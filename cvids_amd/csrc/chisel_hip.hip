@@ -1547,7 +1547,14 @@ int chisel_hip_list_chunks(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t
     rc = fetch_listed(m, false, all, nullptr);
     if (rc) return rc;
     *count = (int64_t)all.size() / 3;
-    if (ids && max_ids > 0) memcpy(ids, all.data(), (size_t)std::min<int64_t>(*count, max_ids) * 3 * sizeof(int));
+    if (ids && max_ids > 0) {
+        // ascending (x, then y, then z), like a group's listing and the mesh listings: the device lists in the order its atomics came in,
+        // and a caller that acts on "every n-th chunk" (tools/soak.py) should get the same chunks every time
+        std::vector<std::array<int, 3>> v((size_t)*count);
+        for (size_t j = 0; j < v.size(); j++) v[j] = {all[3 * j], all[3 * j + 1], all[3 * j + 2]};
+        std::sort(v.begin(), v.end());
+        for (size_t j = 0; j < v.size() && (int64_t)j < max_ids; j++) memcpy(ids + 3 * j, v[j].data(), 3 * sizeof(int));
+    }
     return CHISEL_HIP_OK;
 }
 

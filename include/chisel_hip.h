@@ -192,7 +192,8 @@ int chisel_hip_update_meshes(chisel_hip_map *map, int force);
 /* ---- queries (each synchronises) --------------------------------------------------------------------- */
 /* ChunkManager::GetChunks().size() ChunkManager.h:67-70 */
 int chisel_hip_num_chunks(chisel_hip_map *map, int64_t *out);
-/* ids of all resident chunks, 3 ints each; writes min(count, max_ids) ids, *count = total */
+/* ids of all resident chunks, 3 ints each, ascending (x, then y, then z; the reference: the order of an unordered_map); writes
+ * min(count, max_ids) ids, *count = total */
 int chisel_hip_list_chunks(chisel_hip_map *map, int *ids_xyz, int64_t max_ids, int64_t *count);
 /* ChunkManager::HasChunk ChunkManager.h:79-82 */
 int chisel_hip_has_chunk(chisel_hip_map *map, const int id_xyz[3], int *out);

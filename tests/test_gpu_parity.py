@@ -565,6 +565,17 @@ def test_chunks_seen_by_every_third_launch(oracle_mod, agents, monkeypatch):
     compare_fields(om.fields(), gm.fields(), om.V, False)
 
 
+def test_chunk_listing_is_in_ascending_order(oracle_mod):
+    """chisel_hip_list_chunks: ascending (x, y, z) whatever order the device compacted the slots in -- a caller that acts on every
+    n-th listed chunk (tools/soak.py's garbage collection) then removes the same chunks every time"""
+    _, gm, integ = _mk(oracle_mod, 16, 0.04, False, max_chunks=4096)
+    cam = small_camera(96, 72)
+    gm.IntegrateBatch(integ, [(d, p, cam) for d, p in make_frames("sphere_room", 6, 96, 72, agents=2)])
+    ids = np.asarray(gm.GetChunkIDs()).reshape(-1, 3)
+    assert len(ids) > 50
+    assert [tuple(r) for r in ids.tolist()] == sorted(tuple(r) for r in ids.tolist())
+
+
 def test_checkpoint_and_resume(oracle_mod, tmp_path):
     """chisel_hip_save_map / load_map: a map dumped in the middle of a stream and restored into a fresh map continues
     bit for bit like the uninterrupted run (and like the oracle); the dump itself reads back identically"""

@@ -49,4 +49,7 @@ warm = log[0][2] - log[min(3, len(log) - 1)][2]
 drift = log[min(3, len(log) - 1)][2] - log[-1][2]
 print("warm-up (arenas, pools, staging) first -> fourth checkpoint: %.1f MiB; drift fourth -> last checkpoint: %.1f MiB" % (warm, drift))
 assert abs(drift) < 16.0, "device memory keeps growing"
+# the stream repeats every 600 frames (and the listing the garbage collection picks from is in ascending id order): so do the counts
+for i in range(2, len(log)):
+    assert log[i][1] == log[i - 2][1], "chunk counts of identical stretches of the stream differ: %d vs %d after %d frames" % (log[i][1], log[i - 2][1], log[i][0])
 print("soak ok")
