@@ -387,9 +387,9 @@ def main():
         t0 = time.perf_counter()
         run(m, first_timed, len(bounds))
         t_issue = time.perf_counter() - t0  # host time to enqueue everything (no synchronisation yet)
+        m.synchronize()  # inside the timed region: a launch queued behind a recompute that did not fit is replayed by this call (and it surfaces pool exhaustion)
         fence()
         dt = time.perf_counter() - t0
-        m.synchronize()  # surfaces pool exhaustion
         prof = m.profile(reset=True) if instrumented else None
         if instrumented and m.px is not None:
             prof["allgather_us"] = m.px.measure(False)  # per batch, events on the communication stream
