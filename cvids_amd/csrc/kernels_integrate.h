@@ -231,7 +231,11 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
     const int local_unit = ((int)blockIdx.x >> 3) * G::WPB + wave;  // this wave among its XCD's
     // The recompute in front of this launch will be emitted again (chisel_device.h: MC_LATCH): the launch leaves the map alone and the host
     // replays it afterwards.  (Requested together with the item count: one scalar wait for both.)
+#ifdef CHISEL_NO_LATCH  // (A/B build only: what the word costs; CHISEL_HIP_DEFER_TOTALS=0 must go with it)
+    const int latch = 0;
+#else
     const int latch = M.mesh_ctl ? M.mesh_ctl[MC_LATCH] : 0;
+#endif
     int n_items = *work_count;
     if (latch) return;
     if (n_items > max_items) n_items = max_items;
