@@ -45,6 +45,16 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.ColorFrame) == 88
 
 
+def test_array_lengths_of_the_python_mirror_match_the_header():
+    """the arrays chisel_hip_get_launch_stats / get_counters / get_profile fill are sized by macros of the header: the Python mirror's
+    name lists must have those lengths (a list one short would let the library write past the ctypes buffer)"""
+    from cvids_amd import capi, chisel
+    txt = open(os.path.join(ROOT, "include", "chisel_hip.h")).read()
+    macro = lambda name: int(re.search(r"(?:#define\s+%s\s+|%s\s*=\s*)(\d+)" % (name, name), txt).group(1))  # (a macro or an enumerator)
+    assert len(chisel.Chisel.LAUNCH_STATS) == macro("CHISEL_HIP_NUM_LAUNCH_STATS")
+    assert capi.NUM_KERNELS == macro("CHISEL_HIP_NUM_KERNELS") == len(capi.KERNEL_NAMES)
+
+
 def test_create_fails_loudly_without_gpu(hip_lib):
     """No CPU fallback: on a box without a gfx950 device create() must fail, not emulate."""
     from cvids_amd import capi
