@@ -387,8 +387,8 @@ def main():
         t0 = time.perf_counter()
         run(m, first_timed, len(bounds))
         t_issue = time.perf_counter() - t0  # host time to enqueue everything (no synchronisation yet)
-        m.synchronize()  # inside the timed region: a launch queued behind a recompute that did not fit is replayed by this call (and it surfaces pool exhaustion)
         fence()
+        m.synchronize()  # inside the timed region: a launch queued behind a recompute that did not fit is replayed by this call (normally the map's stream is idle by now: a few microseconds); it also surfaces pool exhaustion
         dt = time.perf_counter() - t0
         prof = m.profile(reset=True) if instrumented else None
         if instrumented and m.px is not None:
