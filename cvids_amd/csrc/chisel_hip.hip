@@ -213,6 +213,7 @@ struct chisel_hip_map {
         IntegrateParams replay_ip;
         bool replay_color = false, replay_inline = false;
         int replay_total = 0;
+        bool staged = false;             // host frames of this set were copied with hipMemcpyAsync (not read over the bus, not on the device)
     } sets[CHISEL_FRONT_SETS];
     int deferred_set = -1;               // the set whose integration was queued behind a recompute the host has not sized yet (launch_back), or -1
     uint64_t *pending_ring[CHISEL_PENDING_RING] = {};  // [PENDING_CAPACITY + 1] each: the set, then its overflow flag
@@ -247,7 +248,7 @@ struct chisel_hip_map {
         int persistent_grid = 0;                // CHISEL_HIP_PERSISTENT=n: a resident grid of n workgroups per SIMD (1 = the build's INTEGRATE_BLOCKS_PER_CU) pulling units from the queue heads
         bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
         bool always_wait_packet = false;
-        bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: sharded maps        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
+        bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: on        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
     } tune;
     int64_t launch_stats[CHISEL_HIP_NUM_LAUNCH_STATS] = {};  // chisel_hip_get_launch_stats
     bool refine_always = false;          // test / A-B hook (CHISEL_HIP_REFINE=2): also one-frame launches of the short form are refined
@@ -577,7 +578,7 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
-        const bool back_recorded = m->tune.ext_events && !m->profiling;  // back_done = the integration kernel's own completion
+        const bool back_recorded = m->tune.ext_events && !m->profiling && !bs.staged;  // back_done = the integration kernel's own completion
 #define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
     do {                                                                                                                             \
         if (back_recorded)                                                                                                           \
@@ -602,7 +603,7 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
     }
     HIP_TRY(hipGetLastError());
     m->mesh_totals_clean = true;  // (integrate_kernel's first thread zeroes the next recompute's totals)
-    if (!(m->tune.ext_events && !m->profiling)) HIP_TRY(hipEventRecord(bs.back_done, m->stream));
+    if (!(m->tune.ext_events && !m->profiling && !bs.staged)) HIP_TRY(hipEventRecord(bs.back_done, m->stream));
     if (replay) return CHISEL_HIP_OK;
     m->batch_seq++;
     if (m->cfg.n_shards <= 1) {  // (the shards of a group are issued by a thread each: one unsynchronised timer would only record their race)
@@ -734,7 +735,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const long long pairs = (long long)(items_hint > 0 ? items_hint + items_hint / 4 + 16 : 1024) * n_groups;
         const int rwaves = rblock / 64;
         const int rgrid = (int)std::max<long long>(64, std::min<long long>(4096 * 4 / rwaves, (pairs + rwaves - 1) / rwaves));
-        front_recorded = m->tune.ext_events && !m->profiling;
+        front_recorded = m->tune.ext_events && !m->profiling && !bs.staged;
         if (front_recorded)  // the set's front_done event is the refinement kernel's own completion: no record packet behind it
             hipExtLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, nullptr, bs.front_done, 0, IP, pyr, m->pyr_stride, (const WorkItem *)bs.items,
                                   (const FrameBox *)bs.boxes, (const int *)(bs.cand_count + COUNT_ITEMS), m->items_capacity, bs.cells, m->refine_off ? 1 : 0, fpg);
@@ -806,6 +807,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     PP.H = H;
     chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq % CHISEL_FRONT_SETS];
     bs.pending = m->pending_ring[m->batch_seq & (CHISEL_PENDING_RING - 1u)];
+    bs.staged = false;
     PP.rec_stride = (int)npx + 2;
     PP.pyr_stride = m->pyr_stride;
     PP.rec = bs.rec_data + 2;
@@ -906,6 +908,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
                 float *dst = bs.depth_stage + (size_t)k * m->depth_stage_elems;
                 HIP_TRY(hipMemcpyAsync(dst, f->depth, npx * sizeof(float), hipMemcpyHostToDevice, front));
                 PP.depth[k] = dst;
+                bs.staged = true;
             }
         }
         F.rec = PP.rec + (size_t)k * PP.rec_stride;
@@ -920,6 +923,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
                 uint8_t *dst = bs.color_stage + (size_t)k * m->color_stage_bytes;
                 HIP_TRY(hipMemcpyAsync(dst, c->color, (size_t)c->width * c->height * c->channels, hipMemcpyHostToDevice, front));
                 F.color = dst;
+                bs.staged = true;
             }
         }
         hostmath::FrustumRange fr = hostmath::frustum_range(f->pose, f->near_plane, f->far_plane, f->fy, f->cy, W, H, m->N,
@@ -1257,9 +1261,12 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     if (const char *e = getenv("CHISEL_HIP_DIRECT_MAX")) m->tune.direct_items_max = atoi(e);
     m->tune.no_zero_copy = getenv("CHISEL_HIP_NO_ZERO_COPY") != nullptr;
     m->tune.always_wait_packet = getenv("CHISEL_HIP_ALWAYS_WAIT_PACKET") != nullptr;
-    // (measured at the end of round 4, tools/ab_ext_events.sh: one rank of eight 404 -> 419 k and 259 -> 265 k frames/s, two runtime calls and
-    // two barrier packets fewer per launch set; nothing on a single map: on by default for the shards of a map only)
-    m->tune.ext_events = cfg->n_shards > 1;
+    // (two runtime calls and two barrier packets fewer per launch set.  Round 4: one rank of eight 404 -> 419 k and 259 -> 265 k frames/s,
+    // nothing on the two headline windows -- the shards of a map only; round 5, with the host out of the device's loop: one frame per call
+    // 31 -> 37 k, 640x480 @ 2 cm depth only 208 -> 227 k, 16 frames per call 247 -> 254 k, driver's window + 1 %, nothing lost anywhere:
+    // every map.  Not for a launch set whose host frames are copied with hipMemcpyAsync: a caller that waits after every frame got them
+    // 11 us later, 97 -> 108 us per page-locked frame whose colour image is staged -- BatchSet::staged)
+    m->tune.ext_events = true;
     if (const char *e = getenv("CHISEL_HIP_EXT_EVENTS")) m->tune.ext_events = atoi(e) != 0;
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
