@@ -866,14 +866,20 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         // the front half may start as soon as the batch that last used this buffer set (CHISEL_FRONT_SETS batches ago) has been integrated;
         // only its resolve step waits for the previous batch's (launch_group).  The previous front half may have run on the map's
         // stream (short form): what it wrote must be complete before this one's kernels read the candidates' neighbours' state
-        HIP_TRY(hipStreamWaitEvent(front, bs.back_done, 0));
+        // (a wait on what is already over is skipped: a barrier packet on the front stream costs its kernels 5-10 us)
+        const auto wait_unless_over = [&](hipEvent_t ev) -> hipError_t {
+            if (!m->tune.always_wait_packet && hipEventQuery(ev) == hipSuccess) return hipSuccess;
+            (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+            return hipStreamWaitEvent(front, ev, 0);
+        };
+        HIP_TRY(wait_unless_over(bs.back_done));
         // this batch's pyramid kernel clears the pending buffer that the resolve step of batch b-2 still reads (as its b-4)
         // (with a pending ring of NSETS + 3 or more the buffer's last readers finished before the set came free: no such wait)
         if (m->batch_seq >= 2 && CHISEL_PENDING_RING < CHISEL_FRONT_SETS + 3)
             HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].front_done, 0));
         // a stream paced by integration + meshing gains nothing from a front half that starts a batch earlier (it only runs
         // beside more of the kernels that set the pace): the two-set rule for it
-        if (meshing && m->batch_seq >= 2) HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].back_done, 0));
+        if (meshing && m->batch_seq >= 2) HIP_TRY(wait_unless_over(m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].back_done));
         if (m->mutation_pending) HIP_TRY(hipStreamWaitEvent(front, m->mutation_event, 0));
     }
     m->mutation_pending = false;
