@@ -9,8 +9,9 @@ N=${1:-$(python3 -c "import torch; print(min(8, torch.cuda.device_count()))")}
 [ "$N" -ge 2 ] || { echo "first_contact: $N GPU visible, need >= 2"; exit 2; }
 step() { echo; echo "== $1"; shift; "$@" || { echo "first_contact: FAILED at: $*"; exit 1; }; }
 step "1. build + one-GPU smoke (known good on one GPU)" python3 -c "import __graft_entry__ as g; g.build(); g.smoke()"
-step "2. RCCL itself: the world-1 check with 2 ranks (frame all-gather on its own stream; first time two ranks meet)" \
-     python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/nccl_world1_check.py
+step "2. RCCL itself between two ranks: the three collectives of the N > 1 path on their own (first time two ranks meet)" \
+     python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/rccl_two_ranks.py
+step "2b. the RCCL code path of the frame exchange and the sharded mesher with one rank (known good on one GPU)" python3 tools/nccl_world1_check.py
 step "3. two RCCL ranks == one rank: voxel counters, meshes inside the timed region (first device all_to_all with non-empty payloads)" \
      python3 -m pytest tests/test_gpu_bench.py -q -m gpu -k "two_rccl_ranks or group_on_two_devices"
 step "4. the in-library group on devices 0,1 against one map, bit for bit (first hipMemcpyPeerAsync between two devices)" \
