@@ -232,7 +232,8 @@ struct chisel_hip_map {
         int fine_min_frames_per_item = 6;       // ... if its items see at least this many frames on average (chains worth shortening)
         int tail_percent = 15;                  // share of a large 4-voxel launch's cost-ordered work-list (the cheap end) that runs at 2 voxels per lane
         double narrow_cull_ratio = 1.5;         // frames look at different parts of space (union id range > ratio x the largest frame's): cull with four waves per workgroup ...
-        int narrow_cull_max_shards = 2;         // ... on maps of at most this many shards (a shard's cull is an n-th of it: no gain measured at 8)
+        int narrow_cull_max_shards = 1 << 30;   // ... on maps of at most this many shards (round 4: 2 -- only the cull changed then, no gain at 8; round 5, with the
+                                                // refinement's shape going with it: one rank of 2 / 4 / 8 on the 4-agent stream + 3 / + 16 / + 1 %)
         int direct_items_max = 1 << 30;         // work-lists up to this size are not cost-ordered: no order_kernel launch.  Round 3: 256 (a list that fits the chip
                                                 // in one go); round 4: every list -- with bricks and per-unit frame masks a unit's cost no longer follows from its
                                                 // chunk's frame count, and the launch saved is worth more than the order (default window 97.6 -> 100.3 k frames/s,
@@ -657,7 +658,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // and `waves` by the ids their ranges have in common: interleaved agents share less with their neighbour in the launch
         // ... and one wave per workgroup where the front half runs beside an integration kernel that refills every slot as it frees up: a
         // single-wave workgroup gets in at once, one of four waits for four free slots on ONE CU (tools/micro/beside.hip)
-        const bool cull_one_wave = m->tune.force_cull_waves ? m->tune.force_cull_waves == 1 : !inline_resolve;
+        const bool cull_one_wave = m->tune.force_cull_waves ? m->tune.force_cull_waves == 1 : (!inline_resolve && m->cfg.n_shards <= 1);  // (a shard's cull is an n-th of the map's: the one wave's chain is what is left of it -- one rank of eight 276 -> 206 k)
         int cull_contig = 0;
         if (narrow_cull && CP.n_frames > 4) {
             const int waves = 4, far = waves < CP.n_frames ? waves : CP.n_frames - 1;
