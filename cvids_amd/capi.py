@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CHISEL_HIP_LIB selects a diagnostic build (e.g. libchisel_hip_stamps.so); the default is the product library
 _LIB = os.path.join(_HERE, os.environ.get("CHISEL_HIP_LIB", "libchisel_hip.so"))
 
+ABI_VERSION = 2  # CHISEL_HIP_ABI_VERSION of include/chisel_hip.h this mirror was written against (tests/test_abi.py compares)
 NUM_COUNTERS = 9
 COUNTER_NAMES = ["sdf", "col", "col_sat", "probe", "carved", "work_chunks", "new_chunks", "updated_chunks", "frames"]
 NUM_KERNELS = 6
@@ -113,6 +114,8 @@ def load_library():
     except ImportError:
         pass
     L = C.CDLL(_LIB)
+    if L.chisel_hip_abi_version() != ABI_VERSION:  # array lengths and signatures below are this version's: no call into another
+        raise ChiselHipError(2, "%s has ABI version %d, these bindings are for %d: rebuild (`make -C cvids_amd/csrc`)" % (_LIB, L.chisel_hip_abi_version(), ABI_VERSION))
     vp, i32p, f32p, u8p, i64p = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
     L.chisel_hip_last_error.restype = C.c_char_p
     L.chisel_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]

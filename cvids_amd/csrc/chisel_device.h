@@ -59,6 +59,9 @@ __host__ __device__ inline int chunk_owner(int x, int y, int z, int n_shards, in
 //   [0] chunk pool (1) or chunk hash (2) exhausted: the map is incomplete from here on; stays set until chisel_hip_reset
 //   [1] a property of ONE point cloud (kernels_cloud.h: 3 = too many chunks / pairs, 4 = ray out of range): reported once, cleared
 // Plain stores: every writer of a word stores a nonzero code; the host reads them after a wait, without a copy.
+// Words [2], [3]: the work items / (item, frame) pairs of the latest integration launch (grid sizing hints).  Words [4], [5]: progress of the
+// map's stream -- [4] the number of the latest integration launch that has STARTED (its first thread), [5] the number of the latest launch
+// known to be OVER (stored by the count kernel of the recompute queued behind it) -- which the host reads instead of querying events.
 __device__ inline void raise_error(int *flag, int code) { reinterpret_cast<volatile int *>(flag)[code >= 3 ? 1 : 0] = code; }
 
 struct MapView {

@@ -208,12 +208,14 @@ struct chisel_hip_map {
         uint64_t *pending = nullptr;     // chunks this batch may create: one of pending_ring (assigned per batch)
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
         hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's work-list (and with it its pending set) is complete
-        hipEvent_t back_done = nullptr;   // recorded on the map's stream after the set's integration
         // what launch_back needs to launch the set's integration again (a set queued behind a recompute that then did not fit: deferred_set)
         IntegrateParams replay_ip;
         bool replay_color = false, replay_inline = false;
         int replay_total = 0;
         bool staged = false;             // host frames of this set were copied with hipMemcpyAsync (not read over the bus, not on the device)
+        unsigned lseq = 0;               // launch number of the set's integration (chisel_hip_map::launch_seq), 0 = never launched
+        bool caller_color = false;       // a colour image of the set lies in the caller's device memory (not staged)
+        bool front_inline = false;       // the set's front half ran on the map's stream, in front of its integration: no front_done event
     } sets[CHISEL_FRONT_SETS];
     int deferred_set = -1;               // the set whose integration was queued behind a recompute the host has not sized yet (launch_back), or -1
     uint64_t *pending_ring[CHISEL_PENDING_RING] = {};  // [PENDING_CAPACITY + 1] each: the set, then its overflow flag
@@ -249,6 +251,7 @@ struct chisel_hip_map {
         int persistent_grid = 0;                // CHISEL_HIP_PERSISTENT=n: a resident grid of n workgroups per SIMD (1 = the build's INTEGRATE_BLOCKS_PER_CU) pulling units from the queue heads
         bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
         bool always_wait_packet = false;
+        int front_poll_after_publish_us = 18;   // CHISEL_HIP_FRONT_POLL_US: how long after a recompute's triangle kernel has started the host keeps looking for the front half's end before it queues a wait packet (launch_back)
         bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: on        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
     } tune;
     int64_t launch_stats[CHISEL_HIP_NUM_LAUNCH_STATS] = {};  // chisel_hip_get_launch_stats
@@ -256,6 +259,13 @@ struct chisel_hip_map {
     bool refine_off = false;             // test / A-B hook (CHISEL_HIP_REFINE=0 at creation): every cell of every frame of an item's mask counts as needed
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % CHISEL_FRONT_SETS] and pending_ring[b % CHISEL_PENDING_RING]
+    // How far the map's stream has come, WITHOUT events on it: a kernel that carries an event (or an event record, or a wait packet) holds the
+    // kernel behind it back by 5-6 us (rocprofv3 timelines of the driver's window with and without them: 309 -> 294 us).  Every integration
+    // launch has a number (launch_seq, from 1); its first thread stores it into pinned word [4] (PROGRESS_STARTED: this launch has started, so
+    // everything queued before it on the stream is complete -- its own front half when that ran on the map's stream, and the launch before it),
+    // the count kernel of a recompute stores the number of the launch in front of it into word [5] (PROGRESS_DONE).  complete_seq: what the
+    // host itself has seen complete (a wait for the stream).
+    unsigned launch_seq = 0, complete_seq = 0;
     unsigned recomputes = 0, recomputes_seen = 0;  // mesh recomputes issued / as of the previous batch (front-stream choice)
     int items_capacity = 0;
     int pyr_w = 0, pyr_h = 0, pyr_stride = 0;
@@ -341,12 +351,49 @@ int sync_all(chisel_hip_map *m) {
         if (m->aux3) HIP_TRY(hipStreamSynchronize(m->aux3));
         if (!pass) HIP_TRY(hipStreamSynchronize(m->stream));
     }
+    m->complete_seq = m->launch_seq;  // (note_stream_idle, declared below)
+    return CHISEL_HIP_OK;
+}
+
+// ---- progress of the map's stream (chisel_hip_map::launch_seq) ---------------------------------------------------------------------------
+constexpr int PROGRESS_STARTED = 4, PROGRESS_DONE = 5;  // words of the pinned error-flag block (chisel_device.h)
+inline void note_stream_idle(chisel_hip_map *m) { m->complete_seq = m->launch_seq; }  // the host has just waited for the map's stream
+// has integration launch L started / ended?  (pinned words the kernels store into; no runtime call, nothing queued)
+inline bool integrate_started(chisel_hip_map *m, unsigned L) {
+    if (L <= m->complete_seq) return true;
+    volatile int *w = reinterpret_cast<volatile int *>(m->error_flag_host);
+    const unsigned started = (unsigned)w[PROGRESS_STARTED], done = (unsigned)w[PROGRESS_DONE];
+    if (started > L && started - 1 > m->complete_seq && started <= m->launch_seq) m->complete_seq = started - 1;
+    if (done > m->complete_seq && done <= m->launch_seq) m->complete_seq = done;
+    return L <= m->complete_seq || started >= L;
+}
+inline bool integrate_done(chisel_hip_map *m, unsigned L) {
+    if (L <= m->complete_seq) return true;
+    (void)integrate_started(m, L);  // (refreshes complete_seq)
+    return L <= m->complete_seq;
+}
+// The host waits (polling the pinned words) until launch L has started (ended): back-pressure for a caller that runs more than the buffer
+// sets ahead of the device, and the order between an inline front half and the next batch's resolve step.  Everything waited for here has
+// been queued and needs nothing more from the host; should the words never move (a failed launch) the stream is waited for instead.
+int wait_integrate(chisel_hip_map *m, unsigned L, bool until_done) {
+    if (L == 0) return CHISEL_HIP_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++) {
+        if (until_done ? integrate_done(m, L) : integrate_started(m, L)) return CHISEL_HIP_OK;
+        if ((spin & 63u) == 63u) {
+            if (until_done && L == m->launch_seq) break;  // nothing queued behind it can report its end: ask the stream
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    note_stream_idle(m);
     return CHISEL_HIP_OK;
 }
 
 // the chunk hash was changed on the map's stream outside the integration path: the next batch's front half must see it
 hipError_t note_map_mutation(chisel_hip_map *m) {
     m->mutation_pending = true;
+    m->dirty_tail_queued = false;  // (a prefetched listing of meshesToUpdate predates what this change dirtied or removed)
     return hipEventRecord(m->mutation_event, m->stream);
 }
 
@@ -421,6 +468,7 @@ hipError_t wait_stream_spinning(hipStream_t st) {
 // lands in pinned memory and the wait polls) and reports a chunk that could not be allocated.
 int check_device_error(chisel_hip_map *m) {
     HIP_TRY(wait_stream_spinning(m->stream));
+    note_stream_idle(m);
     std::atomic_thread_fence(std::memory_order_acquire);
     volatile int *flags = m->error_flag_host;  // written by the device (raise_error): no copy
     const int cloud = flags[1];
@@ -485,6 +533,17 @@ inline int settle(chisel_hip_map *m) { return (m && m->deferred_set >= 0) ? chec
 #define SETTLE(m) do { const int rc_settle_ = settle(m); if (rc_settle_) return rc_settle_; } while (0)
 
 bool mesh_totals_published(const chisel_hip_map *m);  // host_mesh.h
+// `stream` is about to read what the front half of set `ps` (an earlier batch) wrote -- its pending set, its work-list buffers: ordered behind
+// it.  A front half that ran on an auxiliary stream has its event (no wait packet for what is over); one that ran on the map's stream in
+// front of its integration (the short form) is over once that integration has started: the host looks at the progress words, and waits the
+// few microseconds itself in the rare case that it got here first.
+int wait_for_front_of(chisel_hip_map *m, chisel_hip_map::BatchSet &ps, hipStream_t stream) {
+    if (ps.front_inline) return stream == m->stream ? CHISEL_HIP_OK : wait_integrate(m, ps.lseq, false);
+    if (!m->tune.always_wait_packet && hipEventQuery(ps.front_done) == hipSuccess) return CHISEL_HIP_OK;
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+    HIP_TRY(hipStreamWaitEvent(stream, ps.front_done, 0));
+    return CHISEL_HIP_OK;
+}
 // The back half of a launch set: the integration kernel on the map's stream.  replay: the launch again, for a set whose first launch
 // left the map alone (MC_LATCH; check_mesh_totals).
 template <int N>
@@ -493,6 +552,30 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
     // ---- back half: the map's stream.  A mesh recompute still in flight must have been sized first (it may have to be
     // emitted again from the voxels as they are now); its front-half work above did not depend on that.
     bool recompute_in_flight = m->pending_meshes.unchecked;
+    if (!inline_resolve && !replay) {
+        // A front half that has already finished needs no wait packet in front of the integration kernel (the packet is only looked at
+        // once the kernel in front of it has ended, and the dispatch behind it only once the packet has retired: 5-6 us of idle chip).
+        // With a recompute in flight the map's stream has its count and triangle kernels to chew on (40-50 us) and the host nothing
+        // else to do: it looks until the front half is over -- or until the triangle kernel has been running for a while (its first thread
+        // publishes the totals: then the integration kernel must get into the queue, with a wait packet if need be).  Without a recompute
+        // the host runs batches ahead of the device and the packet is the cheaper wait.
+        const bool never = m->tune.always_wait_packet;
+        bool done = !never && hipEventQuery(bs.front_done) == hipSuccess;
+        if (!done && !never && recompute_in_flight) {
+            const auto t0 = std::chrono::steady_clock::now();
+            auto t_pub = t0;
+            bool published = false;
+            for (;;) {
+                if ((done = hipEventQuery(bs.front_done) == hipSuccess)) break;
+                const auto now = std::chrono::steady_clock::now();
+                if (!published && mesh_totals_published(m)) { published = true; t_pub = now; }
+                if (published && now - t_pub > std::chrono::microseconds(m->tune.front_poll_after_publish_us)) break;
+                if (now - t0 > std::chrono::microseconds(300)) break;
+            }
+        }
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
+        if (!done) HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
+    }
     if (!replay) {
         // A recompute whose totals the host has not seen yet.  Waiting for them here (the triangle kernel publishes them when it STARTS)
         // put the host into the device's loop once per recompute: the launch below reached the queue 10-30 us after that kernel had ended.
@@ -502,7 +585,11 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
         // launch.  Otherwise the totals are looked at as before (by now they are usually there).
         bool same_cam_all = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam_all = same_cam_all && IP.f[k].same_cam;
-        const bool may_defer = recompute_in_flight && m->tune.defer_totals && m->deferred_set < 0 && m->cfg.n_shards <= 1 && (!color || same_cam_all) &&
+        // (a replay reads the frames' colour images again.  Staged copies are the library's own; images in the caller's device memory are
+        // safe as long as the caller cannot know the integration is over without passing an entry point that settles first -- true on the
+        // map's own stream (chisel_hip_synchronize / record_event), not on a stream of the caller's, where it may overwrite them in stream order)
+        const bool caller_may_overwrite = color && bs.caller_color && m->stream != m->own_stream;
+        const bool may_defer = recompute_in_flight && m->tune.defer_totals && m->deferred_set < 0 && m->cfg.n_shards <= 1 && (!color || same_cam_all) && !caller_may_overwrite &&
                                (m->tune.defer_totals == 2 || !mesh_totals_published(m));
         if (may_defer) {
             m->deferred_set = (int)(&bs - m->sets);
@@ -511,27 +598,10 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
             bs.replay_total = total;
             bs.replay_inline = inline_resolve;
             m->launch_stats[8]++;
-            // (the short look for the front half below stays: a wait packet in front of the integration kernel costs 7-12 us once the
-            // recompute has ended, the host has nothing else to do meanwhile -- driver's window 63.6 -> 65 k frames/s)
         } else {
             int rc_m = check_mesh_totals(m);
             if (rc_m) return rc_m;
         }
-    }
-    if (!inline_resolve && !replay) {
-        // A front half that has already finished needs no wait packet in front of the integration kernel (the packet is only looked at
-        // once the kernel in front of it has ended, and the dispatch behind it only once the packet has retired).  With a recompute
-        // in flight the host has just waited for its triangle kernel to START (check_mesh_totals), that kernel has another 15-25 us
-        // to run and this batch's front half, queued before that wait, is over or about to be: worth a short look.  (Default window
-        // 87.8 -> 89.9 k frames/s; nothing on streams without recomputes, where the host runs batches ahead of the device.)
-        const bool never = m->tune.always_wait_packet;
-        bool done = !never && hipEventQuery(bs.front_done) == hipSuccess;
-        if (!done && !never && recompute_in_flight) {
-            const auto t0 = std::chrono::steady_clock::now();
-            while (!(done = hipEventQuery(bs.front_done) == hipSuccess) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) {}
-        }
-        (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-        if (!done) HIP_TRY(hipStreamWaitEvent(m->stream, bs.front_done, 0));
     }
     int *wc = bs.cand_count + COUNT_ITEMS;
     {
@@ -579,17 +649,11 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
-        const bool back_recorded = m->tune.ext_events && !m->profiling && !bs.staged;  // back_done = the integration kernel's own completion
+        bs.lseq = ++m->launch_seq;
+        const int lseq = (int)bs.lseq;
 #define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
-    do {                                                                                                                             \
-        if (back_recorded)                                                                                                           \
-            hipExtLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, nullptr, bs.back_done, 0, IP, m->view, \
-                                  (const MapView *)m->view_dev, (const WorkItem *)bs.items, (const CellRec *)bs.cells, bs.sync, (const int *)wc, queues,       \
-                                  m->items_capacity, split);                                                                         \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
-                               bs.cells, bs.sync, wc, queues, m->items_capacity, split);                                             \
-    } while (0)
+    hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
+                       bs.cells, bs.sync, wc, queues, m->items_capacity, split, lseq)
         if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
             if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);
             else CHISEL_LAUNCH_INTEGRATE(true, true, 4);
@@ -604,7 +668,6 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
     }
     HIP_TRY(hipGetLastError());
     m->mesh_totals_clean = true;  // (integrate_kernel's first thread zeroes the next recompute's totals)
-    if (!(m->tune.ext_events && !m->profiling && !bs.staged)) HIP_TRY(hipEventRecord(bs.back_done, m->stream));
     if (replay) return CHISEL_HIP_OK;
     m->batch_seq++;
     if (m->cfg.n_shards <= 1) {  // (the shards of a group are issued by a thread each: one unsynchronised timer would only record their race)
@@ -699,9 +762,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const unsigned b = m->batch_seq;
         const uint64_t *prev_pending = (b >= 1 || m->force_uncertain) ? m->pending_ring[(b + CHISEL_PENDING_RING - 1u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
         const uint64_t *prev2_pending = b >= 2 ? m->pending_ring[(b + CHISEL_PENDING_RING - 2u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
-        if (b >= 1 && hipEventQuery(m->sets[(b + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS].front_done) != hipSuccess) {  // (no wait packet for what is over: below)
-            (void)hipGetLastError();
-            HIP_TRY(hipStreamWaitEvent(front, m->sets[(b + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS].front_done, 0));
+        if (b >= 1) {
+            int rc_w = wait_for_front_of(m, m->sets[(b + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS], front);
+            if (rc_w) return rc_w;
         }
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
         const int *force_flag = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : nullptr;
@@ -736,7 +799,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         const long long pairs = (long long)(items_hint > 0 ? items_hint + items_hint / 4 + 16 : 1024) * n_groups;
         const int rwaves = rblock / 64;
         const int rgrid = (int)std::max<long long>(64, std::min<long long>(4096 * 4 / rwaves, (pairs + rwaves - 1) / rwaves));
-        front_recorded = m->tune.ext_events && !m->profiling && !bs.staged;
+        front_recorded = m->tune.ext_events && !m->profiling && !bs.staged && !inline_resolve;
         if (front_recorded)  // the set's front_done event is the refinement kernel's own completion: no record packet behind it
             hipExtLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, nullptr, bs.front_done, 0, IP, pyr, m->pyr_stride, (const WorkItem *)bs.items,
                                   (const FrameBox *)bs.boxes, (const int *)(bs.cand_count + COUNT_ITEMS), m->items_capacity, bs.cells, m->refine_off ? 1 : 0, fpg);
@@ -744,7 +807,11 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         hipLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, IP, pyr, m->pyr_stride, bs.items, bs.boxes, bs.cand_count + COUNT_ITEMS,
                            m->items_capacity, bs.cells, m->refine_off ? 1 : 0, fpg);
     }
-    if (!front_recorded) HIP_TRY(hipEventRecord(bs.front_done, front));  // also in the short form: the next batch's front half may run on the other stream
+    // The short form has no event: its kernels sit in front of the set's integration on the map's stream, and a later batch's front half on
+    // another stream learns that they are over from the progress words (wait_for_front_of) -- an event carried by (or recorded behind) the
+    // last of them would hold the integration kernel back by 5 us, on every frame of a caller that waits after each.
+    bs.front_inline = inline_resolve;
+    if (!front_recorded && !inline_resolve) HIP_TRY(hipEventRecord(bs.front_done, front));
     }
     g_host_timer.lap(4);
     return launch_back<N>(m, bs, IP, color, total, inline_resolve, false);
@@ -809,6 +876,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     chisel_hip_map::BatchSet &bs = m->sets[m->batch_seq % CHISEL_FRONT_SETS];
     bs.pending = m->pending_ring[m->batch_seq & (CHISEL_PENDING_RING - 1u)];
     bs.staged = false;
+    bs.caller_color = false;
     PP.rec_stride = (int)npx + 2;
     PP.pyr_stride = m->pyr_stride;
     PP.rec = bs.rec_data + 2;
@@ -853,8 +921,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
     m->recomputes_seen = m->recomputes;
     {
         const chisel_hip_map::BatchSet &prev = m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS];  // the previous batch's (integrations complete in order)
-        const bool idle = (m->batch_seq == 0 || hipEventQuery(prev.back_done) == hipSuccess) && !m->pending_meshes.unchecked &&
-                          !m->force_pipeline;
+        const bool idle = (m->batch_seq == 0 || integrate_done(m, prev.lseq)) && !m->pending_meshes.unchecked && !m->force_pipeline;
         // Two auxiliary streams, taken in turn, double the rate of the front halves -- which is what a stream without meshing
         // hangs on (98 -> 122 k frames/s) -- but a stream that recomputes meshes between its batches is paced by integration +
         // meshing on the map's stream, and a second front half beside them only takes 3 % from it: one stream then.
@@ -867,20 +934,24 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         // the front half may start as soon as the batch that last used this buffer set (CHISEL_FRONT_SETS batches ago) has been integrated;
         // only its resolve step waits for the previous batch's (launch_group).  The previous front half may have run on the map's
         // stream (short form): what it wrote must be complete before this one's kernels read the candidates' neighbours' state
-        // (a wait on what is already over is skipped: a barrier packet on the front stream costs its kernels 5-10 us)
-        const auto wait_unless_over = [&](hipEvent_t ev) -> hipError_t {
-            if (!m->tune.always_wait_packet && hipEventQuery(ev) == hipSuccess) return hipSuccess;
-            (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-            return hipStreamWaitEvent(front, ev, 0);
-        };
-        HIP_TRY(wait_unless_over(bs.back_done));
+        // (the integration that last read this buffer set, CHISEL_FRONT_SETS batches ago: the HOST waits -- a caller that far ahead of the
+        // device has nothing to gain from queueing more, and the map's stream carries no event for it, see chisel_hip_map::launch_seq)
+        if (m->batch_seq >= (unsigned)CHISEL_FRONT_SETS) {
+            rc = wait_integrate(m, bs.lseq, true);
+            if (rc) return rc;
+        }
         // this batch's pyramid kernel clears the pending buffer that the resolve step of batch b-2 still reads (as its b-4)
         // (with a pending ring of NSETS + 3 or more the buffer's last readers finished before the set came free: no such wait)
-        if (m->batch_seq >= 2 && CHISEL_PENDING_RING < CHISEL_FRONT_SETS + 3)
-            HIP_TRY(hipStreamWaitEvent(front, m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].front_done, 0));
+        if (m->batch_seq >= 2 && CHISEL_PENDING_RING < CHISEL_FRONT_SETS + 3) {
+            rc = wait_for_front_of(m, m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS], front);
+            if (rc) return rc;
+        }
         // a stream paced by integration + meshing gains nothing from a front half that starts a batch earlier (it only runs
         // beside more of the kernels that set the pace): the two-set rule for it
-        if (meshing && m->batch_seq >= 2) HIP_TRY(wait_unless_over(m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].back_done));
+        if (meshing && m->batch_seq >= 2) {
+            rc = wait_integrate(m, m->sets[(m->batch_seq + CHISEL_FRONT_SETS - 2u) % CHISEL_FRONT_SETS].lseq, true);
+            if (rc) return rc;
+        }
         if (m->mutation_pending) HIP_TRY(hipStreamWaitEvent(front, m->mutation_event, 0));
     }
     m->mutation_pending = false;
@@ -926,6 +997,7 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
             F.same_cam = memcmp(&F.cam, &F.ccam, sizeof(CameraParams)) == 0 ? 1 : 0;
             if (c->on_device) {
                 F.color = c->color;
+                bs.caller_color = true;
             } else {
                 uint8_t *dst = bs.color_stage + (size_t)k * m->color_stage_bytes;
                 HIP_TRY(hipMemcpyAsync(dst, c->color, (size_t)c->width * c->height * c->channels, hipMemcpyHostToDevice, front));
@@ -1238,9 +1310,16 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipHostGetDevicePointer((void **)&m->mesh_info_dev, m->mesh_info_host, 0));
     static_assert(sizeof(JobInfo) == 8 * sizeof(int), "the triangle kernel moves the records to the host as ints");
     HIP_TRY_C(hipEventCreateWithFlags(&m->call_event, hipEventDisableTiming));
+    // A launch set's two events order kernels of ONE device across its streams: the agent-scope release every kernel ends with is all they
+    // need.  Without hipEventDisableSystemFence the kernel that carries the event (hipExtLaunchKernelGGL's stop event) ends with a
+    // system-scope release -- the L2s written back for the host's sake -- and the kernel behind it starts 5 us later (rocprofv3 timeline
+    // of the driver's window: refine -> integrate 5.3 us, integrate -> mesh_count 4.9 us, against 0.1 us between kernels without an event).
+    // What the host reads of the device travels through pinned memory behind the kernels' own system-scope fences or through copies.
+    // CHISEL_HIP_EVENT_FENCE=system: the events as they were (A/B).
+    const char *ev_fence = getenv("CHISEL_HIP_EVENT_FENCE");
+    const unsigned set_event_flags = hipEventDisableTiming | ((ev_fence && !strcmp(ev_fence, "system")) ? 0u : (unsigned)hipEventDisableSystemFence);
     for (auto &bs : m->sets) {
-        HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, hipEventDisableTiming));
-        HIP_TRY_C(hipEventCreateWithFlags(&bs.back_done, hipEventDisableTiming));
+        HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, set_event_flags));
         HIP_TRY_C(hipMalloc(&bs.cand_count, COUNT_INTS * sizeof(int)));
         HIP_TRY_C(hipMemsetAsync(bs.cand_count, 0, COUNT_INTS * sizeof(int), m->own_stream));
     }
@@ -1275,6 +1354,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     // 11 us later, 97 -> 108 us per page-locked frame whose colour image is staged -- BatchSet::staged)
     m->tune.ext_events = true;
     if (const char *e = getenv("CHISEL_HIP_EXT_EVENTS")) m->tune.ext_events = atoi(e) != 0;
+    if (const char *e = getenv("CHISEL_HIP_FRONT_POLL_US")) m->tune.front_poll_after_publish_us = atoi(e);
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
         const int one = 1;
@@ -1295,8 +1375,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     HIP_TRY_C(hipMalloc(&v.counters, 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMalloc(&v.block_counters, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long)));
     HIP_TRY_C(hipMemsetAsync(v.block_counters, 0, (size_t)INTEGRATE_MAX_GRID * 32 * sizeof(unsigned long long), m->stream));
-    HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, 4 * sizeof(int), hipHostMallocDefault));
-    m->error_flag_host[0] = m->error_flag_host[1] = m->error_flag_host[2] = m->error_flag_host[3] = 0;
+    HIP_TRY_C(hipHostMalloc((void **)&m->error_flag_host, 16 * sizeof(int), hipHostMallocDefault));
+    memset(m->error_flag_host, 0, 16 * sizeof(int));
     HIP_TRY_C(hipHostGetDevicePointer((void **)&v.error_flag, m->error_flag_host, 0));
     HIP_TRY_C(hipMemsetAsync(v.counters, 0, CHISEL_HIP_NUM_COUNTERS * sizeof(unsigned long long), m->stream));
     // the mesh recompute's job list, kept by the integration kernels (kernels_map.h: mesh_expand_dirty): a flag per slot, the ids of the
@@ -1342,7 +1422,6 @@ int chisel_hip_destroy(chisel_hip_map *m) {
         for (void *p : bp)
             if (p) (void)hipFree(p);
         if (bs.front_done) (void)hipEventDestroy(bs.front_done);
-        if (bs.back_done) (void)hipEventDestroy(bs.back_done);
     }
     for (auto &pr : m->pending_ring)
         if (pr) (void)hipFree(pr);
@@ -1377,7 +1456,7 @@ int chisel_hip_reset(chisel_hip_map *m) {
     if (m && m->is_group) return group::for_all(m, [](chisel_hip_map *s) { return chisel_hip_reset(s); });
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
-    m->topology_epoch++;
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
     hipLaunchKernelGGL(reset_map_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->V, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(note_map_mutation(m));
@@ -1490,7 +1569,7 @@ int chisel_hip_garbage_collect(chisel_hip_map *m, const int *ids, int n) {
     if (!m || n < 0 || (n > 0 && !ids)) return fail(CHISEL_HIP_ERR_INVALID, "bad id list");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
-    m->topology_epoch++;
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
     {
         int rc_m = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
         if (rc_m) return rc_m;
@@ -1850,7 +1929,7 @@ int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, con
     if (!m || n < 0 || (n > 0 && (!ids || !sdf || !weight))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
-    m->topology_epoch++;
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
     int rc = check_mesh_totals(m);
     if (rc) return rc;
     for (int j = 0; j < n; j++)
@@ -1892,7 +1971,7 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     if (m->ghost_packed) {
         // the ghosts of chisel_hip_import_shells_packed: named by the items of the received segments, which the caller still holds
         HIP_TRY(hipSetDevice(m->device));
-        m->topology_epoch++;
+        { m->topology_epoch++; m->dirty_tail_queued = false; }
         int rc_p = check_mesh_totals(m);  // a recompute in flight may still read them
         if (rc_p) return rc_p;
         if (m->ghost_packed_items > 0)
@@ -1904,7 +1983,7 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     }
     if (m->ghost_ids.empty()) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
-    m->topology_epoch++;
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
     int rc = check_mesh_totals(m);  // a recompute in flight may still read them
     if (rc) return rc;
     const int n = (int)(m->ghost_ids.size() / 3);
@@ -2027,7 +2106,7 @@ int chisel_hip_import_ghost_shells(chisel_hip_map *m, const int *items, int n, c
     if (!m || n < 0 || (n > 0 && (!items || !sdf || !weight || !found))) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     if (n == 0) return CHISEL_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
-    m->topology_epoch++;
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
     int rc = check_mesh_totals(m);
     if (rc) return rc;
     // the distinct ghosts (several boxes may belong to one), each with the item whose `found` decides whether it is created
@@ -2228,7 +2307,7 @@ int chisel_hip_import_shells_packed(chisel_hip_map *m, const void *in_dev, int64
     G.off[m->cfg.n_shards] = off;
     G.first_item[m->cfg.n_shards] = items;
     if (off != bytes) return fail(CHISEL_HIP_ERR_INVALID, "chisel_hip_import_shells_packed: the buffer is not the size the plan gives");
-    m->topology_epoch++;
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
     int rc = check_mesh_totals(m);
     if (rc) return rc;
     if (m->input_event) {
@@ -2417,7 +2496,7 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
     if (chunk_owner(id[0], id[1], id[2], m->cfg.n_shards, m->cfg.shard_block) != m->cfg.shard_rank)
         return fail(CHISEL_HIP_ERR_INVALID, "chunk belongs to another shard");
     HIP_TRY(hipSetDevice(m->device));
-    m->topology_epoch++;
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
     int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
     if (rc) return rc;
     rc = ensure_scratch(m, 16);

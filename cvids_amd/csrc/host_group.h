@@ -430,10 +430,15 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
             if (F.rccl.group_start() != 0) return fail(CHISEL_HIP_ERR_HIP, "ncclGroupStart failed");
             for (int d = 0; d < ND; d++) {
                 DeviceStage &D = F.dev[(size_t)d];
-                if (F.rccl.broadcast(R.depth[fb], D.depth[fb], (size_t)n * F.depth_elems, /* ncclFloat32 */ 7, root, D.comm, D.copy) != 0)
+                // (a failed call must not leave the group open: every later RCCL call of the process would join it)
+                if (F.rccl.broadcast(R.depth[fb], D.depth[fb], (size_t)n * F.depth_elems, /* ncclFloat32 */ 7, root, D.comm, D.copy) != 0) {
+                    (void)F.rccl.group_end();
                     return fail(CHISEL_HIP_ERR_HIP, "ncclBroadcast (depth) failed");
-                if (colors && F.rccl.broadcast(R.color[fb], D.color[fb], (size_t)n * F.color_bytes, /* ncclUint8 */ 1, root, D.comm, D.copy) != 0)
+                }
+                if (colors && F.rccl.broadcast(R.color[fb], D.color[fb], (size_t)n * F.color_bytes, /* ncclUint8 */ 1, root, D.comm, D.copy) != 0) {
+                    (void)F.rccl.group_end();
                     return fail(CHISEL_HIP_ERR_HIP, "ncclBroadcast (colour) failed");
+                }
             }
             if (F.rccl.group_end() != 0) return fail(CHISEL_HIP_ERR_HIP, "ncclGroupEnd failed");
         }
@@ -650,30 +655,44 @@ int update_meshes(chisel_hip_map *g, int force) {
         return CHISEL_HIP_OK;
     };
     std::vector<std::array<int64_t, 4 + 4 * SHELL_MAX_SHARDS>> plan((size_t)W);
+    // Every shard's events and copy stream exist before the first fan-out, and a list that must grow is grown here, on the calling thread:
+    // the shard threads below read each other's handles (MS.copy[o], MS.of[o].listed), which must not be coming into being meanwhile.
+    for (int i = 0; i < W; i++) {
+        HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
+        int rc0 = make_events(MS.of[(size_t)i]);
+        if (rc0) return rc0;
+        if (!MS.copy[(size_t)i]) HIP_TRY(hipStreamCreateWithFlags(&MS.copy[(size_t)i], hipStreamNonBlocking));
+    }
     for (;;) {
         const int cap = MS.cap, blk = 1 + 4 * cap;
-        // ---- A
-        int rc = run_shards(g, [&](int i) -> int {
-            chisel_hip_map *sh = g->shards[(size_t)i];
-            MeshStage &S = MS.of[(size_t)i];
-            HIP_TRY(hipSetDevice(sh->device));
-            int rc2 = make_events(S);
-            if (rc2) return rc2;
-            if (!MS.copy[(size_t)i]) HIP_TRY(hipStreamCreateWithFlags(&MS.copy[(size_t)i], hipStreamNonBlocking));
-            if (S.cap < cap) {
-                rc2 = chisel_hip_synchronize(sh);  // (the previous recompute's plan kernels have read the old list; the other shards' copies out of it too: below)
-                if (rc2) return rc2;
-                for (int r = 0; r < W; r++)
-                    if (MS.copy[(size_t)r]) {
-                        HIP_TRY(hipSetDevice(g->shards[(size_t)r]->device));
-                        HIP_TRY(hipStreamSynchronize(MS.copy[(size_t)r]));
-                    }
-                HIP_TRY(hipSetDevice(sh->device));
+        bool grow = false;
+        for (int i = 0; i < W; i++) grow = grow || MS.of[(size_t)i].cap < cap;
+        if (grow) {
+            // (the previous recompute's plan kernels have read the old lists, the other shards' copies out of them too)
+            for (int i = 0; i < W; i++) {
+                int rc0 = chisel_hip_synchronize(g->shards[(size_t)i]);
+                if (rc0) return rc0;
+            }
+            for (int r = 0; r < W; r++) {
+                HIP_TRY(hipSetDevice(g->shards[(size_t)r]->device));
+                HIP_TRY(hipStreamSynchronize(MS.copy[(size_t)r]));
+            }
+            for (int i = 0; i < W; i++) {
+                MeshStage &S = MS.of[(size_t)i];
+                if (S.cap >= cap) continue;
+                HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
                 if (S.gathered) HIP_TRY(hipFree(S.gathered));
                 S.gathered = nullptr;
                 HIP_TRY(hipMalloc(&S.gathered, (size_t)W * blk * sizeof(int)));
                 S.cap = cap;
             }
+        }
+        // ---- A
+        int rc = run_shards(g, [&](int i) -> int {
+            chisel_hip_map *sh = g->shards[(size_t)i];
+            MeshStage &S = MS.of[(size_t)i];
+            HIP_TRY(hipSetDevice(sh->device));
+            int rc2;
             rc2 = chisel_hip_dirty_ids_device(sh, S.gathered + (size_t)i * blk, cap);
             if (rc2) return rc2;
             return chisel_hip_record_event(sh, S.listed);

@@ -181,10 +181,11 @@ void launch_mesh_count(chisel_hip_map *m) {
     const long long units = (long long)(m->mesh_jobs_hint > 0 ? m->mesh_jobs_hint + m->mesh_jobs_hint / 4 + 8 : 1024) * mesh_subjobs(m);
     const dim3 grid((unsigned)(std::min<long long>(std::max<long long>(units, 2048), 1 << 17) + 7) / 8 * 8);
     const int part = B.tri_capacity / MESH_PARTS, keep = m->mesh_detached ? 1 : 0;
+    const int done_seq = (int)m->launch_seq;  // (every integration launched so far sits in front of this kernel on the map's stream)
     switch (m->N) {
-        case 8: hipLaunchKernelGGL(mesh_count_kernel_8, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep); break;
-        case 16: hipLaunchKernelGGL(mesh_count_kernel_16, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep); break;
-        case 32: hipLaunchKernelGGL(mesh_count_kernel_32, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep); break;
+        case 8: hipLaunchKernelGGL(mesh_count_kernel_8, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep, done_seq); break;
+        case 16: hipLaunchKernelGGL(mesh_count_kernel_16, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep, done_seq); break;
+        case 32: hipLaunchKernelGGL(mesh_count_kernel_32, grid, dim3(64), 0, m->stream, m->view, ids, ids_capacity, B.jobs, n_jobs, B.info, d_totals, B.cnt, B.job_acc, B.tris, B.corners, part, B.flags, keep, done_seq); break;
     }
 }
 
@@ -277,6 +278,20 @@ int check_mesh_totals(chisel_hip_map *m) {
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     const bool device_unfit = m->mesh_totals_host[4] != 0;  // the triangle kernel's own verdict (what MC_LATCH was set by)
+    // From here on MC_LATCH is known to be set (device_unfit) and the deferred set's kernel to have left the map alone: whatever way this
+    // function ends -- also through one of the error returns below -- the latch is cleared and that integration launched again; a frame
+    // must not be lost, and no later launch find the latch still up, because a mesh buffer could not be grown.
+    struct LatchGuard {
+        chisel_hip_map *m;
+        int deferred;
+        bool armed, settled = false;
+        ~LatchGuard() {
+            if (!armed || settled) return;
+            (void)hipStreamSynchronize(m->stream);
+            (void)hipMemsetAsync(mesh_totals(m) + MC_LATCH, 0, sizeof(int), m->stream);
+            if (deferred >= 0) (void)replay_deferred_set(m, deferred);
+        }
+    } latch_guard{m, deferred, device_unfit};
     const unsigned packed_jobs = (unsigned)m->mesh_totals_host[2];
     int totals[4] = {m->mesh_totals_host[0], m->mesh_totals_host[1], (int)(packed_jobs >> 31), (int)(packed_jobs & 0x7fffffffu)};
     // A chunk of an earlier batch could not be allocated (word [0] of the map's error flags: pool / hash; cloud reports live in
@@ -340,6 +355,7 @@ int check_mesh_totals(chisel_hip_map *m) {
                 launch_mesh_triangles(m, P, A.dev, A.capacity);
             }
             HIP_TRY(hipGetLastError());
+            latch_guard.settled = true;
             if (deferred >= 0) {
                 int rc_r = replay_deferred_set(m, deferred);
                 if (rc_r) return rc_r;

@@ -50,6 +50,9 @@ __device__ inline PixelRec make_record(const IntegratorParams &ip, float d) {
 
 // grid: (ceil(W/64), ceil(H/64), n_frames), block 256: thread = one 4x4 pixel block of a 64x64 tile
 // Also resets the batch's counters (COUNT_* below) and empties its pending set.
+#ifndef PYRAMID_NT
+#define PYRAMID_NT 0
+#endif
 __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, PyramidView pyr, int *counts, uint64_t *pending) {
     __shared__ float2 red[256];
     const int tid = threadIdx.x;
@@ -82,7 +85,15 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     const int py = py0 + 2 * h + r < H ? py0 + 2 * h + r : H - 1;
+#if PYRAMID_NT
+                    {
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(depth + (size_t)py * W + px0));
+                        d4[r] = make_float4(t.x, t.y, t.z, t.w);
+                    }
+#else
                     d4[r] = *reinterpret_cast<const float4 *>(depth + (size_t)py * W + px0);
+#endif
                 }
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
@@ -99,8 +110,16 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
                             }
                         }
                         float4 *dst = reinterpret_cast<float4 *>(rec + (size_t)py * W + px0);
+#if PYRAMID_NT
+                        // streaming stores: the records of a batch that is built BESIDE the integration of the batch before it must not push
+                        // that batch's records (what its voxels gather) out of the XCDs' L2s
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store((v4f){o[0].x, o[0].y, o[1].x, o[1].y}, reinterpret_cast<v4f *>(dst));
+                        __builtin_nontemporal_store((v4f){o[2].x, o[2].y, o[3].x, o[3].y}, reinterpret_cast<v4f *>(dst) + 1);
+#else
                         dst[0] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
                         dst[1] = make_float4(o[2].x, o[2].y, o[3].x, o[3].y);
+#endif
                     }
                 }
             }

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                                                                           const WorkItem *__restrict__ items,
                                                                           const CellRec *__restrict__ cells, ItemSync *sync,
                                                                           const int *__restrict__ work_count, int *queues,
-                                                                          int max_items, int split) {
+                                                                          int max_items, int split, int lseq) {
     using G = Geom<N, VPL0>;   // the launch's own granularity: what the grid and the queue heads are laid out for
     using GF = Geom<N, 2>;     // the fine one (2 voxels per lane) of the items behind `split`
     const int lane = threadIdx.x & 63;
@@ -237,6 +237,9 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
     const int latch = M.mesh_ctl ? M.mesh_ctl[MC_LATCH] : 0;
 #endif
     int n_items = *work_count;
+    // this launch has started: everything queued in front of it on the map's stream is over (the host's substitute for events on that
+    // stream, chisel_hip.hip: launch_seq; pinned memory, one thread -- also of a launch that leaves at once)
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<volatile int *>(M.error_flag)[4] = lseq;
     if (latch) return;
     if (n_items > max_items) n_items = max_items;
     const int total = n_items * G::WPC;

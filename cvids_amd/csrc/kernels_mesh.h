@@ -376,7 +376,7 @@ __device__ unsigned long long g_tri_phase[8];  // diagnostic: 10 ns ticks per st
 template <int N>
 __device__ __forceinline__ void mesh_count_body(const MapView &M, const int *__restrict__ ids, int ids_capacity, MeshJob *jobs, const int *__restrict__ n_jobs,
                                                 JobInfo *info, int *ctl, unsigned *cnt, unsigned long long *job_acc, TriRec *tris, CubeCorners *corners,
-                                                int part_capacity, unsigned *mesh_flag, int keep_dirty) {
+                                                int part_capacity, unsigned *mesh_flag, int keep_dirty, int done_seq) {
     using G = MeshGeom<N>;
     __shared__ __attribute__((aligned(16))) float s_tile[G::TILE];
     __shared__ unsigned s_list[G::MAXC];  // occupied cubes of the sub-job in traversal order: cube | case << 10 | first triangle (relative) << 18
@@ -387,6 +387,8 @@ __device__ __forceinline__ void mesh_count_body(const MapView &M, const int *__r
     int n = *n_jobs;  // the job count stays on the device: the grid is persistent
     if (n > ids_capacity) n = ids_capacity;  // (the kept list never gets there: the host gives it up first)
     if (blockIdx.x == 0 && lane == 0) ctl[MC_JOBS] = n;  // where the kernels behind this one (and a second emission) read it
+    // every integration launch queued before this recompute is over (pinned word [5]: the host's substitute for an event on the map's stream)
+    if (blockIdx.x == 0 && lane == 2 && done_seq > 0) reinterpret_cast<volatile int *>(M.error_flag)[5] = done_seq;
     // the list of dirty slots has been consumed -- also when none of them became a job (every listed chunk removed since)
     if (blockIdx.x == 0 && lane == 1 && !keep_dirty) M.slot_dirty[2 * (size_t)M.max_chunks] = 0u;
     s_counts[lane] = reinterpret_cast<const unsigned *>(c_mc_counts)[lane];
@@ -636,8 +638,8 @@ __device__ __forceinline__ void mesh_count_body(const MapView &M, const int *__r
 #define CHISEL_MESH_COUNT_KERNEL(NN, VGPRS, WAVES)                                                                                                    \
     __global__ __launch_bounds__(64, WAVES) __attribute__((amdgpu_num_vgpr(VGPRS))) void mesh_count_kernel_##NN(                                 \
         MapView M, const int *__restrict__ ids, int ids_capacity, MeshJob *jobs, const int *__restrict__ n_jobs, JobInfo *info, int *ctl, unsigned *cnt, \
-        unsigned long long *job_acc, TriRec *tris, CubeCorners *corners, int part_capacity, unsigned *mesh_flag, int keep_dirty) {              \
-        mesh_count_body<NN>(M, ids, ids_capacity, jobs, n_jobs, info, ctl, cnt, job_acc, tris, corners, part_capacity, mesh_flag, keep_dirty);   \
+        unsigned long long *job_acc, TriRec *tris, CubeCorners *corners, int part_capacity, unsigned *mesh_flag, int keep_dirty, int done_seq) { \
+        mesh_count_body<NN>(M, ids, ids_capacity, jobs, n_jobs, info, ctl, cnt, job_acc, tris, corners, part_capacity, mesh_flag, keep_dirty, done_seq); \
     }
 CHISEL_MESH_COUNT_KERNEL(8, MESH_COUNT_VGPRS, MESH_COUNT_WAVES)
 CHISEL_MESH_COUNT_KERNEL(16, MESH_COUNT_VGPRS, MESH_COUNT_WAVES)

@@ -87,6 +87,12 @@ class ColorVoxel {  // ColorVoxel.h:33-100
 inline void hip_check(int rc) {
     if (rc != CHISEL_HIP_OK) throw std::runtime_error(std::string("chisel_hip: ") + chisel_hip_last_error());
 }
+// the library on the loader's path must be the one these headers were written against (array lengths and signatures are the version's)
+inline void hip_check_abi() {
+    if (chisel_hip_abi_version() != CHISEL_HIP_ABI_VERSION)
+        throw std::runtime_error("chisel_hip: libchisel_hip.so has ABI version " + std::to_string(chisel_hip_abi_version()) + ", these headers " +
+                                 std::to_string(CHISEL_HIP_ABI_VERSION));
+}
 
 namespace hipfacade {  // the C structs of the boundary from the facade's value types
 inline void Pose12(const Transform &T, float out[12]) {
@@ -319,6 +325,7 @@ class ProjectionIntegrator {  // ProjectionIntegrator.h:36-232 (Integrate / Inte
         cfg.max_chunks = 8;
         cfg.n_shards = 1;
         chisel_hip_map *tmp = nullptr;
+        hip_check_abi();
         hip_check(chisel_hip_create(&cfg, &tmp));
         const size_t V = chunk->GetTotalNumVoxels();
         std::vector<float> sdf(V), w(V);
@@ -365,6 +372,7 @@ class ChunkManager {  // ChunkManager.h:57-216 over one chisel_hip_map
         cfg.use_color = color ? 1 : 0;
         cfg.device_id = -1;
         cfg.n_shards = 1;
+        hip_check_abi();
         hip_check(chisel_hip_create(&cfg, &map));
         owned = std::shared_ptr<chisel_hip_map>(map, [](chisel_hip_map *m) { chisel_hip_destroy(m); });  // copies of the manager share the map
         CacheCentroids();
@@ -743,6 +751,7 @@ class Chisel {  // Chisel.h:38-230
                 p = (*end == ',') ? end + 1 : end;
             }
         }
+        hip_check_abi();
         if (devices.size() > 1) hip_check(chisel_hip_create_group(&cfg, devices.data(), (int)devices.size(), &map));
         else {
             if (devices.size() == 1) cfg.device_id = devices[0];

@@ -36,7 +36,13 @@
 extern "C" {
 #endif
 
-#define CHISEL_HIP_ABI_VERSION 1
+/* Bumped whenever an export is removed or re-typed, a struct of this header changes its layout, or one of the array-length macros below
+ * (CHISEL_HIP_NUM_*) grows: a client built against another value must not call into the library (chisel_hip_abi_version() tells; the
+ * facade's chisel::Chisel constructor and cvids_amd/capi.py refuse a mismatch).
+ *   1  rounds 1-4
+ *   2  round 5-6: chisel_hip_mesh_shell_plan_all removed, CHISEL_HIP_NUM_LAUNCH_STATS 8 -> 10, the device-plan and incremental
+ *      meshesToUpdate entries added */
+#define CHISEL_HIP_ABI_VERSION 2
 
 typedef struct chisel_hip_map chisel_hip_map; /* opaque: one TSDF map (or one shard of it) on one GPU */
 

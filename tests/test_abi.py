@@ -21,7 +21,8 @@ def test_header_symbols_exported(hip_lib):
     for s in syms:
         assert hasattr(hip_lib, s), "libchisel_hip.so does not export %s" % s
     assert sorted(capi.EXPORTS) == syms, "cvids_amd/capi.py EXPORTS out of sync with include/chisel_hip.h"
-    assert hip_lib.chisel_hip_abi_version() == 1
+    txt = open(os.path.join(ROOT, "include", "chisel_hip.h")).read()
+    assert hip_lib.chisel_hip_abi_version() == capi.ABI_VERSION == int(re.search(r"#define\s+CHISEL_HIP_ABI_VERSION\s+(\d+)", txt).group(1))
 
 
 def test_every_exported_symbol_is_declared(hip_lib):
