@@ -199,12 +199,11 @@ struct chisel_hip_map {
         PixelRec *rec_data = nullptr;    // [KMAX][2 + W*H]: per frame two all-NaN records, then the image
         float *depth_stage = nullptr;    // [KMAX][depth_stage_elems]: host frames are copied here
         uint8_t *color_stage = nullptr;  // [KMAX][color_stage_bytes]
-        WorkItem *cands = nullptr;       // [items_capacity]
-        FrameBox *boxes = nullptr;       // [items_capacity][KMAX]
+        FrameBox *boxes = nullptr;       // [items_capacity][KMAX]: the cull kernel's flags of every (work item, frame), in work-list order
+        unsigned short *brick_masks = nullptr;  // [items_capacity][bricks per chunk]: the frames that can touch each brick of a work item (cull_kernel's brick phase)
         int *cand_count = nullptr;       // [COUNT_INTS] device counters of the batch (COUNT_* in kernels_cull.h)
         WorkItem *items = nullptr;       // [items_capacity]: the work-list
         ItemSync *sync = nullptr;        // [items_capacity]: chunk-level state of the work items while the integration kernel runs
-        CellRec *cells = nullptr;        // [items_capacity][KMAX]: per (work item, frame) the cells the frame can touch + the cull flags (refine_kernel)
         uint64_t *pending = nullptr;     // chunks this batch may create: one of pending_ring (assigned per batch)
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
         hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's work-list (and with it its pending set) is complete
@@ -236,15 +235,9 @@ struct chisel_hip_map {
         double narrow_cull_ratio = 1.5;         // frames look at different parts of space (union id range > ratio x the largest frame's): cull with four waves per workgroup ...
         int narrow_cull_max_shards = 1 << 30;   // ... on maps of at most this many shards (round 4: 2 -- only the cull changed then, no gain at 8; round 5, with the
                                                 // refinement's shape going with it: one rank of 2 / 4 / 8 on the 4-agent stream + 3 / + 16 / + 1 %)
-        int direct_items_max = 1 << 30;         // work-lists up to this size are not cost-ordered: no order_kernel launch.  Round 3: 256 (a list that fits the chip
-                                                // in one go); round 4: every list -- with bricks and per-unit frame masks a unit's cost no longer follows from its
-                                                // chunk's frame count, and the launch saved is worth more than the order (default window 97.6 -> 100.3 k frames/s,
-                                                // 4 agents 65.5 -> 67.2 k, driver's and late windows unchanged; CHISEL_HIP_DIRECT_MAX=256 restores the ordering)
         // test / A-B hooks (environment, at creation)
         int force_vpl = 0;                      // CHISEL_HIP_VPL=2|4
         int force_cull_waves = 0;               // CHISEL_HIP_CULL_WAVES=1|4|16
-        int refine_prompt = -1;                 // CHISEL_HIP_REFINE_PROMPT=0|1: single-wave workgroups for refine_kernel (default: launches of frames that look apart)
-        int refine_fpg = 0;                     // CHISEL_HIP_REFINE_FPG=1|2|4|8|16: frames per wave of refine_kernel (default 1, 4 for such launches)
         int defer_totals = 1;                   // CHISEL_HIP_DEFER_TOTALS=0: every integration launch waits for the totals of the recompute in front of it; 2 (test hook): a
                                                 // launch is queued unseen even when the totals are already there
         int force_cull_contig = -1;             // CHISEL_HIP_CULL_CONTIG=0|1: which frames a wave of the four-wave cull takes (default: by the frames' ranges)
@@ -255,7 +248,6 @@ struct chisel_hip_map {
         bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: on        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
     } tune;
     int64_t launch_stats[CHISEL_HIP_NUM_LAUNCH_STATS] = {};  // chisel_hip_get_launch_stats
-    bool refine_always = false;          // test / A-B hook (CHISEL_HIP_REFINE=2): also one-frame launches of the short form are refined
     bool refine_off = false;             // test / A-B hook (CHISEL_HIP_REFINE=0 at creation): every cell of every frame of an item's mask counts as needed
     bool force_uncertain = false;        // test hook (CHISEL_HIP_FORCE_UNCERTAIN at creation): every candidate without a slot takes the SLOT_LOOKUP path
     unsigned batch_seq = 0;              // batches issued so far: batch b uses sets[b % CHISEL_FRONT_SETS] and pending_ring[b % CHISEL_PENDING_RING]
@@ -653,7 +645,7 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
         const int lseq = (int)bs.lseq;
 #define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
     hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
-                       bs.cells, bs.sync, wc, queues, m->items_capacity, split, lseq)
+                       bs.boxes, bs.sync, wc, queues, m->items_capacity, split, lseq, bs.brick_masks)
         if (color && same_cam) {  // CVIDS: depth and colour share one camera (sample.launch:19-20)
             if (vpl == 2) CHISEL_LAUNCH_INTEGRATE(true, true, 2);
             else CHISEL_LAUNCH_INTEGRATE(true, true, 4);
@@ -692,22 +684,33 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     const bool inline_resolve = front == m->stream;
     bool front_recorded = false;
     bool narrow_cull_set = false;  // this launch's frames look at different parts of the space (decided where the cull kernel is launched)
-    bool skip_refine = false;  // the short form of a one-frame launch: the cull kernel fills the CellRecs itself (4 us of launch for 2 us of integration)
+    const bool skip_bricks = IP.n_frames == 1 && !m->refine_off;  // a one-frame launch: the cull kernel fills the brick masks itself (4 us of launch + 9 of kernel for 4 us of integration)
     {
-    RoctxRange front_range("chisel_hip front half: pyramid, cull, resolve, order");
+    RoctxRange front_range("chisel_hip front half: pyramid, cull, bricks");
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_PYRAMID, front);
         dim3 grid((PP.W + 63) / 64, (PP.H + 63) / 64, IP.n_frames);
         hipLaunchKernelGGL(depth_pyramid_kernel, grid, dim3(256), 0, front, PP, pyr, bs.cand_count, bs.pending);
     }
     g_host_timer.lap(3);
+    // the chunks the batches in flight may create: the pending sets of the previous two (complete once the previous batch's cull kernel
+    // is through: the one wait between consecutive front halves).  Nothing in flight in the short form.
+    const unsigned b = m->batch_seq;
+    const uint64_t *prev_pending = nullptr, *prev2_pending = nullptr;
+    if (!inline_resolve) {
+        prev_pending = (b >= 1 || m->force_uncertain) ? m->pending_ring[(b + CHISEL_PENDING_RING - 1u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
+        prev2_pending = b >= 2 ? m->pending_ring[(b + CHISEL_PENDING_RING - 2u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
+        if (b >= 1) {
+            int rc_w = wait_for_front_of(m, m->sets[(b + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS], front);
+            if (rc_w) return rc_w;
+        }
+    }
     {
         ProfScope ps(m, CHISEL_HIP_KERNEL_CULL, front);
         const CullSpace cspace(CP);
         static_assert(CULL_BLOCK * CULL_BLOCK * CULL_BLOCK == 64, "one wave per block of ids");
         const dim3 cgrid = cspace.sharded ? dim3((total + 63) / 64) : dim3(cspace.nsb[2], cspace.nsb[1], cspace.nsb[0]);
         // frames that look at different parts of the space (several agents in one launch): four waves per workgroup (kernels_cull.h)
-        skip_refine = inline_resolve && IP.n_frames == 1 && !m->refine_always;
         bool narrow_cull = false;
         {
             double vmax = 0.0;
@@ -715,7 +718,6 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
             narrow_cull = m->cfg.n_shards <= m->tune.narrow_cull_max_shards && (double)CP.range_dim[0] * CP.range_dim[1] * CP.range_dim[2] > m->tune.narrow_cull_ratio * vmax;
             if (m->tune.force_cull_waves) narrow_cull = m->tune.force_cull_waves != 16;
             m->launch_stats[(narrow_cull && IP.n_frames > 4) ? 3 : 4]++;
-            narrow_cull_set = narrow_cull;
         }
         // a wave of the four-wave form takes several frames: the ones that share least (kernels_cull.h).  Frames 0 and 1 against frames 0
         // and `waves` by the ids their ranges have in common: interleaved agents share less with their neighbour in the launch
@@ -725,10 +727,10 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         int cull_contig = 0;
         if (narrow_cull && CP.n_frames > 4) {
             const int waves = 4, far = waves < CP.n_frames ? waves : CP.n_frames - 1;
-            const auto common = [&](const CullFrame &a, const CullFrame &b) {
+            const auto common = [&](const CullFrame &a, const CullFrame &b2) {
                 double v = 1.0;
                 for (int ax = 0; ax < 3; ax++) {
-                    const int lo = std::max(a.range_min[ax], b.range_min[ax]), hi = std::min(a.range_min[ax] + a.range_dim[ax], b.range_min[ax] + b.range_dim[ax]);
+                    const int lo = std::max(a.range_min[ax], b2.range_min[ax]), hi = std::min(a.range_min[ax] + a.range_dim[ax], b2.range_min[ax] + b2.range_dim[ax]);
                     v *= hi > lo ? (double)(hi - lo) : 0.0;
                 }
                 return v;
@@ -736,76 +738,44 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
             cull_contig = common(CP.f[0], CP.f[1]) < common(CP.f[0], CP.f[far]) ? 1 : 0;
             if (m->tune.force_cull_contig >= 0) cull_contig = m->tune.force_cull_contig;
         }
-#define CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, WV)                                                                                   \
-    hipLaunchKernelGGL((cull_kernel<N, KLV, INL, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, OUT, bs.boxes, bs.cand_count, \
-                       m->items_capacity, m->view, bs.pending, bs.sync, skip_refine ? bs.cells : nullptr, cull_contig)
-#define CHISEL_LAUNCH_CULL(KLV, INL, OUT) do { if (narrow_cull && cull_one_wave) CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 1); else if (narrow_cull) CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 4); else CHISEL_LAUNCH_CULL_W(KLV, INL, OUT, 16); } while (0)
-        if (inline_resolve) {
-            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, true, bs.items, 16);
-            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL_W(2, true, bs.items, 16);
-            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL_W(4, true, bs.items, 16);
-            else if (IP.n_frames <= 8) CHISEL_LAUNCH_CULL(8, true, bs.items);
-            else CHISEL_LAUNCH_CULL(16, true, bs.items);
-        } else {
-            if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, false, bs.cands, 16);
-            else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL_W(2, false, bs.cands, 16);
-            else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL_W(4, false, bs.cands, 16);
-            else if (IP.n_frames <= 8) CHISEL_LAUNCH_CULL(8, false, bs.cands);
-            else CHISEL_LAUNCH_CULL(16, false, bs.cands);
-        }
+        const int *force_flag = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : nullptr;
+        front_recorded = false;
+#define CHISEL_LAUNCH_CULL_W(KLV, WV)                                                                                                          \
+    hipLaunchKernelGGL((cull_kernel<N, KLV, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, bs.items, bs.boxes, bs.cand_count, \
+                       m->items_capacity, m->view, prev_pending, prev2_pending, force_flag, bs.pending, bs.sync, cull_contig, skip_bricks ? bs.brick_masks : nullptr)
+#define CHISEL_LAUNCH_CULL(KLV) do { if (narrow_cull && cull_one_wave) CHISEL_LAUNCH_CULL_W(KLV, 1); else if (narrow_cull) CHISEL_LAUNCH_CULL_W(KLV, 4); else CHISEL_LAUNCH_CULL_W(KLV, 16); } while (0)
+        if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, 16);
+        else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL_W(2, 16);
+        else if (IP.n_frames <= 4) CHISEL_LAUNCH_CULL_W(4, 16);
+        else if (IP.n_frames <= 8) CHISEL_LAUNCH_CULL(8);
+        else CHISEL_LAUNCH_CULL(16);
 #undef CHISEL_LAUNCH_CULL_W
 #undef CHISEL_LAUNCH_CULL
+        m->launch_stats[5]++;
+        narrow_cull_set = narrow_cull;
     }
-    if (!inline_resolve) {
-        // the chunks the batches in flight may create: the pending sets of the previous two (complete once the previous batch's
-        // resolve step is through: the one wait between consecutive front halves)
-        const unsigned b = m->batch_seq;
-        const uint64_t *prev_pending = (b >= 1 || m->force_uncertain) ? m->pending_ring[(b + CHISEL_PENDING_RING - 1u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
-        const uint64_t *prev2_pending = b >= 2 ? m->pending_ring[(b + CHISEL_PENDING_RING - 2u) & (CHISEL_PENDING_RING - 1u)] : nullptr;
-        if (b >= 1) {
-            int rc_w = wait_for_front_of(m, m->sets[(b + CHISEL_FRONT_SETS - 1u) % CHISEL_FRONT_SETS], front);
-            if (rc_w) return rc_w;
-        }
-        ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
-        const int *force_flag = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : nullptr;
-        const dim3 rgrid((total + RESOLVE_BLOCK - 1) / RESOLVE_BLOCK);
-        // one frame: nothing to order; and a work-list that fits the chip in one go (<= 256 items by the count a recent launch
-        // reported: every unit starts at once, whatever its place in the list) is not worth a launch of its own either -- the
-        // shards of a multi-GPU map are in this regime, where the front half is what a rank's rate hangs on
-        const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
-        const bool direct = IP.n_frames == 1 || (items_hint > 0 && items_hint <= m->tune.direct_items_max);
-        skip_refine = IP.n_frames == 1 && !m->refine_always;  // (a one-frame launch: the resolve kernel fills the CellRecs itself)
-        hipLaunchKernelGGL(resolve_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, m->view, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, IP.n_frames,
-                           prev_pending, prev2_pending, force_flag, bs.pending, direct ? bs.items : nullptr, bs.sync, bs.boxes, skip_refine ? bs.cells : nullptr);
-        if (direct) m->launch_stats[5]++;
-        if (!direct)
-            hipLaunchKernelGGL(order_kernel, rgrid, dim3(RESOLVE_BLOCK), 0, front, bs.cands, bs.cand_count, bs.cand_count, m->items_capacity, bs.items, bs.sync);
-    }
-    if (!skip_refine) {
-        // per (work item, frame): which cells of the chunk the frame can touch (the cull test again at cell scale, kernels_cull.h).
-        // A persistent grid over the (item, frame) pairs: their number is only known on the device.
+    if (!skip_bricks) {
+        // per work item: which frames can touch which of its bricks (the cull test again at the scale of what a wave of the integration kernel
+        // owns, kernels_cull.h).  One wave per item; their number is only known on the device: a persistent grid sized from a recent launch.
         ProfScope ps(m, CHISEL_HIP_KERNEL_RESOLVE, front);
         const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
         // Shape.  Beside an integration kernel (80 registers, six single-wave workgroups per SIMD, every slot refilled the moment it frees up)
         // a workgroup of four waves waits for four free slots on ONE CU, i.e. for that kernel to drain (tools/micro/beside.hip: 145 us
         // instead of 17); single-wave workgroups get in at once -- and take the slots from the integration kernel for as long as they run.
-        // Worth it when the front half is what the stream waits for: launches whose frames look at different parts of the space (the
-        // interleaved agents of one map: each integration waited 50 us for a refinement that could not start before the previous
-        // integration drained).  Those also take four frames per wave (kernels_cull.h).
-        const bool prompt = m->tune.refine_prompt >= 0 ? m->tune.refine_prompt != 0 : narrow_cull_set;
-        const int fpg = m->tune.refine_fpg > 0 ? m->tune.refine_fpg : (narrow_cull_set && IP.n_frames > 4 ? 4 : 1);
-        const int rblock = prompt ? 64 : REFINE_BLOCK;
-        const int n_groups = (IP.n_frames + fpg - 1) / fpg;
-        const long long pairs = (long long)(items_hint > 0 ? items_hint + items_hint / 4 + 16 : 1024) * n_groups;
+        // Worth it when the front half is what the stream waits for: launches whose frames look at different parts of the space.
+        const int rblock = narrow_cull_set ? 64 : BRICK_BLOCK;
         const int rwaves = rblock / 64;
-        const int rgrid = (int)std::max<long long>(64, std::min<long long>(4096 * 4 / rwaves, (pairs + rwaves - 1) / rwaves));
+        const long long want = items_hint > 0 ? items_hint + items_hint / 4 + 16 : 2048;
+        const int rgrid = (int)std::max<long long>(64, std::min<long long>(8192 / rwaves, (want + rwaves - 1) / rwaves));
+        // The brick kernel is the front half's last: in the pipelined form its completion IS the set's front_done event (no record packet
+        // behind it); the short form has no event at all (launch_seq).
         front_recorded = m->tune.ext_events && !m->profiling && !bs.staged && !inline_resolve;
-        if (front_recorded)  // the set's front_done event is the refinement kernel's own completion: no record packet behind it
-            hipExtLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, nullptr, bs.front_done, 0, IP, pyr, m->pyr_stride, (const WorkItem *)bs.items,
-                                  (const FrameBox *)bs.boxes, (const int *)(bs.cand_count + COUNT_ITEMS), m->items_capacity, bs.cells, m->refine_off ? 1 : 0, fpg);
+        if (front_recorded)
+            hipExtLaunchKernelGGL((brick_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, nullptr, bs.front_done, 0, IP, pyr, m->pyr_stride, (const WorkItem *)bs.items,
+                                  (const int *)(bs.cand_count + COUNT_ITEMS), m->items_capacity, bs.brick_masks, m->refine_off ? 1 : 0);
         else
-        hipLaunchKernelGGL((refine_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, IP, pyr, m->pyr_stride, bs.items, bs.boxes, bs.cand_count + COUNT_ITEMS,
-                           m->items_capacity, bs.cells, m->refine_off ? 1 : 0, fpg);
+            hipLaunchKernelGGL((brick_kernel<N>), dim3(rgrid), dim3(rblock), 0, front, IP, pyr, m->pyr_stride, bs.items, bs.cand_count + COUNT_ITEMS, m->items_capacity,
+                               bs.brick_masks, m->refine_off ? 1 : 0);
     }
     // The short form has no event: its kernels sit in front of the set's integration on the map's stream, and a later batch's front half on
     // another stream learns that they are over from the progress words (wait_for_front_of) -- an event carried by (or recorded behind) the
@@ -1038,21 +1008,18 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         int cap = std::max(1 << 17, m->items_capacity);
         while (cap < total) cap *= 2;
         for (auto &b2 : m->sets) {
-            if (b2.cands) HIP_TRY(hipFree(b2.cands));
             if (b2.boxes) HIP_TRY(hipFree(b2.boxes));
+            if (b2.brick_masks) HIP_TRY(hipFree(b2.brick_masks));
+            b2.brick_masks = nullptr;
             if (b2.items) HIP_TRY(hipFree(b2.items));
             if (b2.sync) HIP_TRY(hipFree(b2.sync));
-            if (b2.cells) HIP_TRY(hipFree(b2.cells));
-            b2.cells = nullptr;
-            b2.cands = nullptr;
             b2.boxes = nullptr;
             b2.items = nullptr;
             b2.sync = nullptr;
-            HIP_TRY(hipMalloc(&b2.cands, (size_t)cap * sizeof(WorkItem)));
             HIP_TRY(hipMalloc(&b2.items, (size_t)cap * sizeof(WorkItem)));
             HIP_TRY(hipMalloc(&b2.sync, (size_t)cap * sizeof(ItemSync)));
             HIP_TRY(hipMalloc(&b2.boxes, (size_t)cap * KMAX * sizeof(FrameBox)));
-            HIP_TRY(hipMalloc(&b2.cells, (size_t)cap * KMAX * sizeof(CellRec)));
+            HIP_TRY(hipMalloc(&b2.brick_masks, (size_t)cap * (m->N / 8) * (m->N / 8) * (m->N / 4) * sizeof(unsigned short)));
         }
         m->items_capacity = cap;
     }
@@ -1333,18 +1300,14 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     m->force_uncertain = getenv("CHISEL_HIP_FORCE_UNCERTAIN") != nullptr;
     if (const char *e = getenv("CHISEL_HIP_REFINE")) {
         m->refine_off = atoi(e) == 0;
-        m->refine_always = atoi(e) == 2;
     }
     if (const char *e = getenv("CHISEL_HIP_VPL")) m->tune.force_vpl = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 0);
     if (const char *e = getenv("CHISEL_HIP_CULL_WAVES")) m->tune.force_cull_waves = atoi(e) == 4 ? 4 : (atoi(e) == 1 ? 1 : 16);
-    if (const char *e = getenv("CHISEL_HIP_REFINE_PROMPT")) m->tune.refine_prompt = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("CHISEL_HIP_REFINE_FPG")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) m->tune.refine_fpg = v; }
     if (const char *e = getenv("CHISEL_HIP_DEFER_TOTALS")) m->tune.defer_totals = atoi(e);
     if (const char *e = getenv("CHISEL_HIP_CULL_CONTIG")) m->tune.force_cull_contig = atoi(e) ? 1 : 0;
     if (const char *e = getenv("CHISEL_HIP_PERSISTENT")) m->tune.persistent_grid = atoi(e) > 0 ? atoi(e) : 0;
     if (const char *e = getenv("CHISEL_HIP_TAIL_PERCENT")) m->tune.tail_percent = atoi(e);
     if (const char *e = getenv("CHISEL_HIP_FINE_BELOW")) m->tune.fine_below = atoi(e);
-    if (const char *e = getenv("CHISEL_HIP_DIRECT_MAX")) m->tune.direct_items_max = atoi(e);
     m->tune.no_zero_copy = getenv("CHISEL_HIP_NO_ZERO_COPY") != nullptr;
     m->tune.always_wait_packet = getenv("CHISEL_HIP_ALWAYS_WAIT_PACKET") != nullptr;
     // (two runtime calls and two barrier packets fewer per launch set.  Round 4: one rank of eight 404 -> 419 k and 259 -> 265 k frames/s,
@@ -1418,7 +1381,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &bs : m->sets) {
-        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.cands, bs.boxes, bs.cand_count, bs.items, bs.sync, bs.cells};
+        void *bp[] = {bs.pyr_data, bs.rec_data, bs.depth_stage, bs.color_stage, bs.boxes, bs.brick_masks, bs.cand_count, bs.items, bs.sync};
         for (void *p : bp)
             if (p) (void)hipFree(p);
         if (bs.front_done) (void)hipEventDestroy(bs.front_done);

@@ -196,15 +196,20 @@ __device__ inline void truncation_range(int kind, float param, float d0, float d
 template <int T = 3>
 __device__ inline void pyramid_minmax(const PyramidView &pyr, const float2 *__restrict__ pdata, float2 whole, int u0, int v0, int u1,
                                       int v1, float &dmin, float &dmax) {
-    int l = PYR_LEVELS - 1;
+    // (the level's offset and width are carried along as selects between the view's scalars: an index into the view's arrays that differs per
+    // lane would have to go through memory)
+    int l = PYR_LEVELS - 1, loff = pyr.off[PYR_LEVELS - 1], lw = pyr.w[PYR_LEVELS - 1];
 #pragma unroll
     for (int k = PYR_LEVELS - 2; k >= 0; k--) {
         const int s = PYR_L0 + k;
-        if (((u1 >> s) - (u0 >> s)) <= T - 1 && ((v1 >> s) - (v0 >> s)) <= T - 1) l = k;
+        if (((u1 >> s) - (u0 >> s)) <= T - 1 && ((v1 >> s) - (v0 >> s)) <= T - 1) {
+            l = k;
+            loff = pyr.off[k];
+            lw = pyr.w[k];
+        }
     }
     const int s = PYR_L0 + l;
-    const float2 *lvl = pdata + pyr.off[l];
-    const int lw = pyr.w[l];
+    const float2 *lvl = pdata + loff;
     const int tx0 = u0 >> s, ty0 = v0 >> s, tx1 = u1 >> s, ty1 = v1 >> s;
     dmin = INFINITY;
     dmax = -INFINITY;
@@ -315,6 +320,45 @@ __device__ inline bool cell_pre(const IntegratorParams &ip, const CameraParams &
     if (zs0 > 0.25f * ip.res) {
         const float i0 = __builtin_amdgcn_rcpf(zs0) * 1.00001f, i1 = __builtin_amdgcn_rcpf(zs1) * 0.99999f;
         const float xl = px - hx, xh = px + hx, yl = py - hy, yh = py + hy;
+        const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
+        const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
+        const float fu0 = floorf(ul) - 2.0f, fu1 = floorf(uh) + 2.0f, fv0 = floorf(vl) - 2.0f, fv1 = floorf(vh) + 2.0f;
+        if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1)) return false;  // off the image
+        pre.su0 = (int)fmaxf(fu0, 0.0f); pre.sv0 = (int)fmaxf(fv0, 0.0f);
+        pre.su1 = (int)fminf(fu1, (float)(C.W - 1)); pre.sv1 = (int)fminf(fv1, (float)(C.H - 1));
+    }
+    pre.zs0 = zs0; pre.zs1 = zs1; pre.slack = slack;
+    return true;
+}
+// A BRICK of the integration kernel (kernels_integrate.h: a unit = one wave = 8 x 8 x 4 voxels at 4 voxels per lane): the same bound for
+// the centres of its voxels -- a box of half-extents (3.5, 3.5, 1.5) voxels around their centre (vx0, vy0, vz0 = the brick's first voxel,
+// counted from the world origin) --, per camera axis i the exact extent of the rotated box, sum_j |R_ji| h_j.
+constexpr int BRICK_X = 8, BRICK_Y = 8, BRICK_Z = 4;
+template <int N>
+struct BrickGrid {
+    static constexpr int NBX = N / BRICK_X, NBY = N / BRICK_Y, NBZ = N / BRICK_Z, PER_CHUNK = NBX * NBY * NBZ;  // 2 (8^3), 16 (16^3), 128 (32^3)
+    static_assert(NBX >= 1 && NBY >= 1 && NBZ >= 1, "bricks tile the chunk");
+};
+__device__ inline bool brick_pre(const IntegratorParams &ip, const CameraParams &C, int vx0, int vy0, int vz0, CullPre &pre) {
+    const float hx = 0.5f * (float)(BRICK_X - 1) * ip.res, hy = 0.5f * (float)(BRICK_Y - 1) * ip.res, hz = 0.5f * (float)(BRICK_Z - 1) * ip.res;
+    // centre of the voxel centres: (v0 + (B - 1) / 2 + 0.5) res
+    const float wx = ((float)vx0 * ip.res + (hx + ip.half_res)) - C.t[0], wy = ((float)vy0 * ip.res + (hy + ip.half_res)) - C.t[1],
+                wz = ((float)vz0 * ip.res + (hz + ip.half_res)) - C.t[2];
+    const float px = C.R[0] * wx + C.R[3] * wy + C.R[6] * wz;
+    const float py = C.R[1] * wx + C.R[4] * wy + C.R[7] * wz;
+    const float pz = C.R[2] * wx + C.R[5] * wy + C.R[8] * wz;
+    // rounding: as cell_pre (1e-4 relative is three orders of magnitude more than the integration kernel's own coordinates carry)
+    const float slack = 1e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + (hx + hy + hz)) + 1e-6f;
+    const float ex = (fabsf(C.R[0]) * hx + fabsf(C.R[3]) * hy + fabsf(C.R[6]) * hz) * 1.001f + slack;
+    const float ey = (fabsf(C.R[1]) * hx + fabsf(C.R[4]) * hy + fabsf(C.R[7]) * hz) * 1.001f + slack;
+    const float ez = (fabsf(C.R[2]) * hx + fabsf(C.R[5]) * hy + fabsf(C.R[8]) * hz) * 1.001f + slack;
+    const float zs1 = pz + ez;
+    if (zs1 < 0.0f) return false;  // every voxel has z < 0 (ProjectionIntegrator.h:68)
+    const float zs0 = pz - ez;
+    pre.su0 = 0; pre.sv0 = 0; pre.su1 = C.W - 1; pre.sv1 = C.H - 1;
+    if (zs0 > 0.25f * ip.res) {
+        const float i0 = __builtin_amdgcn_rcpf(zs0) * 1.00001f, i1 = __builtin_amdgcn_rcpf(zs1) * 0.99999f;
+        const float xl = px - ex, xh = px + ex, yl = py - ey, yh = py + ey;
         const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
         const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
         const float fu0 = floorf(ul) - 2.0f, fu1 = floorf(uh) + 2.0f, fv0 = floorf(vl) - 2.0f, fv1 = floorf(vh) + 2.0f;
@@ -436,87 +480,93 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
            (inside ? WI_INSIDE : 0);
 }
 
-// The cull kernel's depth test again, per CELL of a work item (4 x 4 x 4 cells of N/4 voxels on a side) -> CellRec, in work-list order.
-// The chunk-level test looks at the depth range under the whole chunk's pixel box (40-60 pixels wide at 1 cm / 2 m, fetched as
-// 3 x 3 texels of a pyramid level that covers more than that): its camera-z bounds let 40-45 % more voxel-frames into the integration
-// kernel than take the band or the carve branch.  A cell's box is a quarter of that on a side; the depth range under it is tight, and the
-// integration kernel's waves own whole cells (a unit = 8 x 8 x 4 or 4 x 8 x 4 voxels), so "does this frame touch my cells" is one AND.
-// One wave per (work item, frame of its mask), lane = cell.  A cell is needed by frame k if one of its voxels may integrate, or may take
-// the carve test while the chunk is resident: resident now, or (conservatively, as resolve_kernel has it) created by an earlier
-// frame of the launch; SLOT_LOOKUP items count as resident (the integration kernel drops what it must once it knows).
-// `full` (launches not worth refining, test hook): every cell of every frame of the mask.
+// The depth test again at the scale of a 4 x 4 x 4-voxel sub-box is the first step of every unit of the integration kernel
+// (kernels_integrate.h; until round 5 refine_kernel here, one wave per (work item, frame), wrote a CellRec per pair).
 #ifndef REFINE_TEXELS
 #define REFINE_TEXELS 4
 #endif
-#ifndef REFINE_BLOCK
-#define REFINE_BLOCK 256   // threads per workgroup of refine_kernel at most (the waves of a workgroup never meet; the host picks 64 or this per launch)
+
+// Which frames of the launch can touch which BRICK of every work item -> brick_masks[item][brick] (16 bits: the frames), in work-list order.
+// The chunk-level test of the cull kernel looks at the depth range under the whole chunk's pixel box (40-60 pixels wide at 1 cm / 2 m): its
+// bounds let 40-45 % more voxel-frames into the integration kernel than take the band or the carve branch.  A brick's box is half of that on
+// a side and the depth range under it tight, and a brick is exactly what one wave of the integration kernel owns: its mask is what that wave
+// walks.  (Rounds 4-5: refine_kernel, one wave per (work item, frame) pair, lane = one of 64 cells, a 64-bit cell mask per pair -- four
+// times the tests, a wave per pair; 14 us on the driver's window.)  Here ONE WAVE PER WORK ITEM: lane = (brick, frame group), the frames of
+// a group one after the other (16^3 chunks: 16 bricks x 4 groups, 16 frames in four rounds; a round is one round trip to the pyramid), the
+// groups' verdicts merged by shuffles.  A brick is needed by frame k if one of its voxels may integrate, or may take the carve test while
+// the chunk is resident: resident now, or (conservatively, as the cull kernel has it) created by an earlier frame of the launch; SLOT_LOOKUP
+// items count as resident (the integration kernel drops what it must once it knows).  `full` (test hook): every brick takes its item's mask.
+#ifndef BRICK_BLOCK
+#define BRICK_BLOCK 256   // threads per workgroup of brick_kernel at most (its waves never meet; the host picks 64 or this per launch)
 #endif
 template <int N>
-__global__ __launch_bounds__(256) void refine_kernel(IntegrateParams P, PyramidView pyr, int pyr_stride,
-                                                     const WorkItem *__restrict__ items, const FrameBox *__restrict__ boxes, const int *__restrict__ work_count,
-                                                     int max_items, CellRec *__restrict__ cells, int full, int fpg) {
-    // fpg = frames per wave (1, 2, 4, ... a power of two): a wave takes the frames g * fpg ... of a work item one after the other, skipping
-    // the ones outside the item's mask; lane j keeps frame g * fpg + j's record and the wave stores them together.  1 = one wave per
-    // (item, frame) pair, the shortest chain; 4 for launches whose frames look at different parts of the space (of four consecutive
-    // frames of interleaved agents one, seldom two, are in an item's mask: a quarter of the waves, each as long as before).
-    constexpr int CELL = N / 4;
+__global__ __launch_bounds__(256) void brick_kernel(IntegrateParams P, PyramidView pyr, int pyr_stride, const WorkItem *__restrict__ items,
+                                                    const int *__restrict__ work_count, int max_items, unsigned short *__restrict__ brick_masks, int full) {
+    constexpr int BPC = BrickGrid<N>::PER_CHUNK;
+    constexpr int BR = BPC > 64 ? BPC / 64 : 1;   // bricks per lane (32^3 chunks: two)
+    constexpr int G = BPC >= 64 ? 1 : 64 / BPC;   // frame groups: lane = group * BPC + brick
     const IntegratorParams &ip = P.ip;
     const int n_frames = P.n_frames;
     const int lane = threadIdx.x & 63;
+    const int g = BPC >= 64 ? 0 : lane / BPC;
     int n_items = *work_count;
     if (n_items > max_items) n_items = max_items;
-    const int n_groups = (n_frames + fpg - 1) / fpg;
-    const int n_pairs = n_items * n_groups;
     const int waves = (int)gridDim.x * (int)(blockDim.x >> 6);
-    for (int p = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); p < n_pairs; p += waves) {
-        const int it = p / n_groups, k0 = (p - it * n_groups) * fpg;
+    for (int it = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); it < n_items; it += waves) {
         const WorkItem wi = items[it];
         const unsigned fmask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
-        const int row = __builtin_amdgcn_readfirstlane(wi.box);
-        const bool mine = lane < fpg && k0 + lane < n_frames;  // this lane keeps a frame's record
-        CellRec out;
-        out.need = 0ull;
-        out.flags = 0;
-        out.pad = 0;
-        if (mine && ((fmask >> (k0 + lane)) & 1u)) out.flags = boxes[(size_t)row * n_frames + k0 + lane].flags;
-        unsigned gm = (fmask >> k0) & (fpg >= 32 ? 0xffffffffu : ((1u << fpg) - 1u));
-        while (gm) {  // wave-uniform
-            const int j = __builtin_ctz(gm), k = k0 + j;
-            gm &= gm - 1u;
-            unsigned long long b = ~0ull;
-            if (!full) {
-                const int slot = __builtin_amdgcn_readfirstlane(wi.slot);
-                const unsigned inband_before = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.inband_mask) & ((1u << k) - 1u);
-                const bool resident = slot >= 0 || slot == SLOT_LOOKUP || inband_before != 0u;
-                const CameraParams &C = P.f[k].cam;
-                const float ar[3] = {fabsf(C.R[0]) + fabsf(C.R[3]) + fabsf(C.R[6]), fabsf(C.R[1]) + fabsf(C.R[4]) + fabsf(C.R[7]),
-                                     fabsf(C.R[2]) + fabsf(C.R[5]) + fabsf(C.R[8])};
-                const int cx = 4 * __builtin_amdgcn_readfirstlane(wi.x) + (lane & 3), cy = 4 * __builtin_amdgcn_readfirstlane(wi.y) + ((lane >> 2) & 3),
-                          cz = 4 * __builtin_amdgcn_readfirstlane(wi.z) + (lane >> 4);
-                CullPre pre;
-                bool need = false;
-                if (cell_pre<CELL>(ip, C, ar, cx, cy, cz, pre)) {
-                    if (box_needs_whole_image(pre.su0, pre.sv0, pre.su1, pre.sv1)) {
-                        need = true;  // (a cell next to the camera: not worth the reduction over the image)
-                    } else {
-                        float dmin, dmax;
-                        pyramid_minmax<REFINE_TEXELS>(pyr, pyr.data + (size_t)k * pyr_stride, make_float2(INFINITY, -INFINITY), pre.su0, pre.sv0, pre.su1, pre.sv1, dmin, dmax);
-                        if (dmin <= dmax) {
-                            float tmin, tmax;
-                            truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
-                            const float zlo = fmaxf(pre.zs0, 0.0f) - pre.slack;
-                            const float band = tmax + ip.diag;
-                            const bool inband = (dmin - band < pre.zs1) && (dmax + band > zlo);
-                            const bool carve = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
-                            need = inband || (carve && resident);
+        const int slot = __builtin_amdgcn_readfirstlane(wi.slot);
+        const unsigned inband_all = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.inband_mask);
+        const int cxi = __builtin_amdgcn_readfirstlane(wi.x), cyi = __builtin_amdgcn_readfirstlane(wi.y), czi = __builtin_amdgcn_readfirstlane(wi.z);
+        unsigned m[BR];
+#pragma unroll
+        for (int h = 0; h < BR; h++) m[h] = 0u;
+        if (full) {
+#pragma unroll
+            for (int h = 0; h < BR; h++) m[h] = fmask;
+        } else {
+            for (int j = 0; j * G < n_frames; j++) {  // (a round; lanes of one group share the frame, a group whose frame is not in the mask idles)
+                const int kf = g + j * G;
+                if (kf >= n_frames || !((fmask >> kf) & 1u)) continue;
+                const CameraParams &C = P.f[kf].cam;
+                const bool resident = slot >= 0 || slot == SLOT_LOOKUP || (inband_all & ((1u << kf) - 1u)) != 0u;
+#pragma unroll
+                for (int h = 0; h < BR; h++) {
+                    const int b = (BPC >= 64 ? lane : lane % BPC) + 64 * h;
+                    const int bx = b % BrickGrid<N>::NBX, by = (b / BrickGrid<N>::NBX) % BrickGrid<N>::NBY, bz = b / (BrickGrid<N>::NBX * BrickGrid<N>::NBY);
+                    CullPre pre;
+                    bool need = false;
+                    if (brick_pre(ip, C, N * cxi + bx * BRICK_X, N * cyi + by * BRICK_Y, N * czi + bz * BRICK_Z, pre)) {
+                        if (box_needs_whole_image(pre.su0, pre.sv0, pre.su1, pre.sv1)) {
+                            need = true;  // (a brick next to the camera: not worth the reduction over the image)
+                        } else {
+                            float dmin, dmax;
+                            pyramid_minmax<REFINE_TEXELS>(pyr, pyr.data + (size_t)kf * pyr_stride, make_float2(INFINITY, -INFINITY), pre.su0, pre.sv0, pre.su1, pre.sv1, dmin, dmax);
+                            if (dmin <= dmax) {
+                                float tmin, tmax;
+                                truncation_range(ip.trunc_kind, ip.trunc_param, dmin, dmax, tmin, tmax);
+                                const float zlo = fmaxf(pre.zs0, 0.0f) - pre.slack;
+                                const float band = tmax + ip.diag;
+                                const bool inb = (dmin - band < pre.zs1) && (dmax + band > zlo);
+                                const bool crv = ip.carving && (dmax - zlo > tmin + ip.carving_dist - 1e-6f);
+                                need = inb || (crv && resident);
+                            }
                         }
                     }
+                    m[h] |= need ? (1u << kf) : 0u;
                 }
-                b = __ballot(need);
             }
-            if (lane == j) out.need = b;
+            // the groups' verdicts on one brick meet in the group-0 lane
+#pragma unroll
+            for (int o = 32; o >= BPC && o > 0; o >>= 1) {
+#pragma unroll
+                for (int h = 0; h < BR; h++) m[h] |= (unsigned)__shfl_xor((int)m[h], o);
+            }
         }
-        if (mine) cells[(size_t)it * n_frames + k0 + lane] = out;
+        if (BPC >= 64 || lane < BPC) {
+#pragma unroll
+            for (int h = 0; h < BR; h++) brick_masks[(size_t)it * BPC + lane + 64 * h] = (unsigned short)m[h];
+        }
     }
 }
 
@@ -629,16 +679,18 @@ struct CullGeom {
     static constexpr int WAVES = KL < WV ? KL : WV;
     static constexpr int FPW = KL / WAVES;  // frames per wave
 };
-template <int N, int KL, bool INLINE, int WV>
-__global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *cands, FrameBox *boxes, int *counts,
-                                                        int max_cands, MapView M, uint64_t *my_pending, ItemSync *sync, CellRec *cells, int contig) {
+template <int N, int KL, int WV>
+__global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(CullParams P, PyramidView pyr, WorkItem *items, FrameBox *boxes, int *counts,
+                                                        int max_items, MapView M, const uint64_t *__restrict__ prev_pending,
+                                                        const uint64_t *__restrict__ prev2_pending, const int *__restrict__ force_uncertain,
+                                                        uint64_t *my_pending, ItemSync *sync, int contig, unsigned short *brick_masks) {
     constexpr int WAVES = CullGeom<KL, WV>::WAVES, FPW = CullGeom<KL, WV>::FPW;
     // which frames a wave takes when it takes several: k, k + WAVES, ... or (contig) k * FPW, k * FPW + 1, ...  The host picks the one
     // that gives a wave frames looking at DIFFERENT parts of the space: of a wave's frames few then survive the range test for any one
     // block of ids, and the survivors of a block are spread over its waves instead of queueing up in one of them (interleaved agents,
     // frame i from agent i mod 4: strided hands wave k the four frames of agent k -- four cull_post in a row in one wave, three waves idle)
 
-    int *cand_count = counts + (INLINE ? COUNT_ITEMS : COUNT_CANDS);
+    int *item_count = counts + COUNT_ITEMS;
     __shared__ int s_flags[KL][64];
     __shared__ int s_pos[64];
     const int lane = threadIdx.x & 63;
@@ -691,7 +743,7 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
 #endif
     __syncthreads();
     if (k == 0) {
-        // ---- merge the frames of each chunk, compact the candidates ----------------------------------------------
+        // ---- merge the frames of each chunk; look the survivors up; compact them into the work-list ---------------------------------
         unsigned inband = 0, carve = 0;
 #pragma unroll
         for (int j = 0; j < KL; j++) {
@@ -701,41 +753,64 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
         }
         bool keep = (inband | carve) != 0u;
         int slot = -1;
-        unsigned mask = inband | (carve << 16);
-        if (INLINE && keep) {
-            // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82); the map is at rest
-            const uint64_t key = pack_id(cx, cy, cz);
-            const uint64_t h0 = chunk_hash(cx, cy, cz), h = h0 & M.hash_mask;
-            for (uint64_t i = 0; i <= M.hash_mask; i++) {
-                const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
-                if (kk == key) {
-                    slot = M.hash_vals[(h + i) & M.hash_mask];
-                    break;
+        unsigned mask = 0u;
+        if (__any(keep)) {  // wave-uniform: most blocks of ids hold nothing
+            // a pending set of the batches in flight is incomplete (its overflow flag sits behind its last bucket), or the test hook
+            const bool forced = force_uncertain && *force_uncertain != 0;  // (test hook: everything through the look-up path of the integration kernel)
+            const bool all_uncertain = forced || (prev_pending && prev_pending[PENDING_CAPACITY] != 0) || (prev2_pending && prev2_pending[PENDING_CAPACITY] != 0);
+            if (keep) {
+                // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82)
+                const uint64_t key = pack_id(cx, cy, cz);
+                const uint64_t h0 = chunk_hash(cx, cy, cz), h = h0 & M.hash_mask;
+                for (uint64_t i = 0; i <= M.hash_mask; i++) {
+                    const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
+                    if (kk == key) {
+                        slot = M.hash_vals[(h + i) & M.hash_mask];
+                        break;
+                    }
+                    if (kk == KEY_EMPTY) break;
                 }
-                if (kk == KEY_EMPTY) break;
-            }
-            // a frame can only matter if it may integrate, or may carve a chunk that is resident by then
-            bool resident = slot >= 0;
-            mask = 0;
+                // While the batches before this one are being integrated a key can already be visible whose slot value is not (create_chunk
+                // writes key, then value, then slot_key[slot]): a lookup result that does not check out against slot_key only counts for
+                // chunks those batches cannot be creating.  One that does check out is final, whoever is in flight -- the value read IS the
+                // slot that holds this key -- and such a chunk is resident for good: without this, a chunk created by some batch stayed
+                // "uncertain" for as long as it stayed in view (an uncertain item has no slot here, so it went into this batch's pending
+                // set and was uncertain again for the next two: most items of a steady stream were looked up again by every one of their
+                // units in the integration kernel, 4 us of dependent round trips at the head of each).
+                const bool verified = !forced && slot >= 0 && slot < M.max_chunks && M.slot_key[slot] == key;
+                if (!verified && slot >= 0) slot = -1;
+                const bool uncertain = !verified && (all_uncertain || (prev_pending && pending_contains(prev_pending, key, h0)) ||
+                                                     (prev2_pending && pending_contains(prev2_pending, key, h0)));
+                if (uncertain) {
+                    // the batches in flight may be creating this chunk: the integration kernel looks it up itself, when they are over
+                    slot = SLOT_LOOKUP;
+                    mask = inband | carve;
+                } else {
+                    // a frame can only matter if it may integrate, or may carve a chunk that is resident by then
+                    // (resident now, or created by an earlier frame of this batch)
+                    bool resident = slot >= 0;
 #pragma unroll
-            for (int j = 0; j < KL; j++) {
-                const bool in = (inband >> j) & 1u;
-                if (in || (((carve >> j) & 1u) && resident)) mask |= 1u << j;
-                resident |= in;
+                    for (int j = 0; j < KL; j++) {
+                        const bool in = (inband >> j) & 1u;
+                        if (in || (((carve >> j) & 1u) && resident)) mask |= 1u << j;
+                        resident |= in;
+                    }
+                }
+                keep = mask != 0u;
+                // the chunks this batch may create: what the next two batches' look-ups must not trust
+                if (keep && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) my_pending[PENDING_CAPACITY] = 1;
             }
-            keep = mask != 0;
-            if (keep && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) my_pending[PENDING_CAPACITY] = 1;
         }
         // wave64 compaction: ballot + prefix popcount, one atomic per wave
         const unsigned long long bal = __ballot(keep);
         int pos = -1;
         if (bal) {
             int base = 0;
-            if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(cand_count, __popcll(bal));
+            if (lane == (int)__builtin_ctzll(bal)) base = atomicAdd(item_count, __popcll(bal));
             base = __shfl(base, (int)__builtin_ctzll(bal));
             if (keep) {
                 pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pos < max_cands) {
+                if (pos < max_items) {
                     WorkItem wi;
                     wi.x = cx; wi.y = cy; wi.z = cz;
                     wi.slot = slot;
@@ -743,8 +818,13 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
                     wi.box = pos;
                     wi.inband_mask = inband;
                     wi.pad = 0;
-                    cands[pos] = wi;
-                    if (INLINE) item_sync_init(sync + pos);  // the candidate list is the work-list
+                    items[pos] = wi;
+                    item_sync_init(sync + pos);
+                    // one-frame launches are not worth brick_kernel (a launch for a kernel's worth of nothing): every brick takes the item's mask
+                    if (brick_masks) {
+                        constexpr int BPC = BrickGrid<N>::PER_CHUNK;
+                        for (int b = 0; b < BPC; b++) brick_masks[(size_t)pos * BPC + b] = (unsigned short)mask;
+                    }
                 } else {
                     pos = -1;
                 }
@@ -753,182 +833,16 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
         s_pos[lane] = pos;
     }
     __syncthreads();
+    // the flags of every (work item, frame), in work-list order: lane k of a unit of the integration kernel reads frame k's
     const int pos = s_pos[lane];
 #pragma unroll UNROLL
     for (int j = 0; j < FPW; j++) {
         const int kf = (FPW > 1 && contig) ? k * FPW + j : k + j * WAVES;
         if (pos >= 0 && kf < P.n_frames) {
-            const int fl = s_flags[kf][lane];
             FrameBox fb;
-            fb.flags = fl;
+            fb.flags = s_flags[kf][lane];
             boxes[(size_t)pos * P.n_frames + kf] = fb;
-            // INLINE with `cells`: the candidate list is the work-list and the launch is not worth refining (one frame, a caller that
-            // waits): every cell of a frame that can touch the chunk counts as needed, and no refine_kernel is launched
-            if (INLINE && cells) {
-                CellRec cr;
-                cr.need = fl ? ~0ull : 0ull;
-                cr.flags = fl;
-                cr.pad = 0;
-                cells[(size_t)pos * P.n_frames + kf] = cr;
-            }
         }
-    }
-}
-
-// Candidates -> work-list, in two passes over the candidates (both on the auxiliary stream, one thread per candidate,
-// block 256).
-//   resolve_kernel : hash lookup, frame mask; the verdict is written back into the candidate (frame_mask == 0: dropped)
-//                    and counted per cost class in counts[COUNT_CLASS0 + class].
-//   order_kernel   : places the surviving candidates into the work-list class by class, most expensive first (class by
-//                    the number of frames that touch the chunk, cost_class()): the integration kernel's last workgroups then run the
-//                    short items, which shortens the stretch where the chip drains.
-//   prev_pending / prev_overflow : the chunks the previous batch may create (nullptr: there is none in flight).  The
-//                                  chunk hash is read while that batch may still be inserting exactly those chunks, so
-//                                  for them the lookup result is ignored and the item is marked SLOT_LOOKUP; every
-//                                  other key of the hash is stable (inserted before, removal never overlaps a batch).
-//                                  *prev_overflow != 0: that set is incomplete -- every candidate is marked SLOT_LOOKUP.
-//   my_pending / counts[COUNT_OVERFLOW] : receives the chunks this batch may create.
-
-// `counts_in` is `counts` again, read-only: the values read through it were written by earlier kernels, and a read-only
-// pointer lets them travel through the scalar cache instead of every wave asking the same L2 line.
-// cost class of a work item: 0 = touched by (nearly) all of the batch's frames ... 7 = by one or two
-__device__ inline int cost_class(unsigned frame_mask) { return (KMAX - __popc(frame_mask)) >> 1; }
-
-// items != nullptr: single-frame launch sets -- every work item is touched by exactly one frame, there is nothing to order,
-// so the survivors go straight into the work-list (one returning atomic per wave) and order_kernel is not launched.
-__global__ __launch_bounds__(RESOLVE_BLOCK) void resolve_kernel(MapView M, WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
-                                                       int max_cands, int n_frames, const uint64_t *__restrict__ prev_pending,
-                                                       const uint64_t *__restrict__ prev2_pending, const int *__restrict__ force_uncertain,
-                                                       uint64_t *my_pending, WorkItem *items, ItemSync *sync, const FrameBox *__restrict__ boxes, CellRec *cells) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * RESOLVE_BLOCK + threadIdx.x;
-    int n = counts_in[COUNT_CANDS];
-    if (n > max_cands) n = max_cands;
-    if ((int)(blockIdx.x * RESOLVE_BLOCK) >= n) return;
-    // a pending set of the batches in flight is incomplete (its overflow flag sits behind its last bucket), or the test hook
-    const bool all_uncertain = (force_uncertain && *force_uncertain != 0) || (prev_pending && prev_pending[PENDING_CAPACITY] != 0) ||
-                               (prev2_pending && prev2_pending[PENDING_CAPACITY] != 0);
-    int cls = -1;
-    if (c < n) {
-        WorkItem wi = cands[c];
-        const uint64_t key = pack_id(wi.x, wi.y, wi.z);
-        const uint64_t h0 = chunk_hash(wi.x, wi.y, wi.z);
-        // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82)
-        const uint64_t h = h0 & M.hash_mask;
-        int slot = -1;
-        for (uint64_t i = 0; i <= M.hash_mask; i++) {
-            const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
-            if (kk == key) {
-                slot = M.hash_vals[(h + i) & M.hash_mask];
-                break;
-            }
-            if (kk == KEY_EMPTY) break;
-        }
-        const unsigned inband = wi.frame_mask & 0xffffu, carve = wi.frame_mask >> 16;
-        // While the previous batches are being integrated a key can already be visible whose slot value is not (create_chunk writes
-        // key, then value, then slot_key[slot]): a lookup result that does not check out against slot_key only counts for chunks
-        // those batches cannot be creating.  One that does check out is final, whoever is in flight -- the value read IS the slot
-        // that holds this key -- and such a chunk is resident for good: without this, a chunk created by some batch stayed
-        // "uncertain" for as long as it stayed in view (an uncertain item has no slot here, so it went into this batch's pending set and
-        // was uncertain again for the next two: most items of a steady stream were looked up again by every one of their units in the
-        // integration kernel, 4 us of dependent round trips at the head of each).
-        const bool forced = force_uncertain && *force_uncertain != 0;  // (test hook: everything through the look-up path of the integration kernel)
-        const bool verified = !forced && slot >= 0 && slot < M.max_chunks && M.slot_key[slot] == key;
-        if (!verified && slot >= 0) slot = -1;
-        const bool uncertain = !verified &&
-                               (all_uncertain || (prev_pending && pending_contains(prev_pending, key, h0)) ||
-                                (prev2_pending && pending_contains(prev2_pending, key, h0)));
-        unsigned mask = 0;
-        if (uncertain) {
-            slot = SLOT_LOOKUP;
-            mask = inband | carve;
-        } else {
-            // a frame can only matter if it may integrate, or may carve a chunk that is resident by then
-            // (resident now, or created by an earlier frame of this batch)
-            bool resident = slot >= 0;
-            for (int j = 0; j < n_frames; j++) {
-                const bool in = (inband >> j) & 1u;
-                if (in || (((carve >> j) & 1u) && resident)) mask |= 1u << j;
-                resident |= in;
-            }
-        }
-        wi.slot = slot;
-        wi.frame_mask = mask;
-        if (!items) {
-            cands[c].slot = slot;
-            cands[c].frame_mask = mask;
-        }
-        if (mask) cls = cost_class(mask);
-        if (mask && slot < 0 && inband != 0u && !pending_insert(my_pending, key, h0)) my_pending[PENDING_CAPACITY] = 1;
-        if (items) {  // (a wave takes this branch as a whole only in its active lanes; the ballot below counts them)
-            const unsigned long long bal = __ballot(mask != 0u);
-            if (mask) {
-                int base = 0;
-                const int leader = (int)__builtin_ctzll(bal);
-                if (lane == leader) base = atomicAdd(&counts[COUNT_ITEMS], __popcll(bal));
-                base = __shfl(base, leader);
-                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                items[pos] = wi;
-                item_sync_init(sync + pos);
-                // one-frame launch sets are not refined (a launch for a kernel's worth of nothing): every cell of the frame counts
-                if (cells) {
-                    CellRec cr;
-                    cr.need = ~0ull;
-                    cr.flags = boxes[(size_t)wi.box * n_frames].flags;
-                    cr.pad = 0;
-                    cells[(size_t)pos * n_frames] = cr;
-                }
-            }
-        }
-    }
-    if (items) return;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const unsigned long long bal = __ballot(cls == k);
-        if (bal && lane == (int)__builtin_ctzll(bal)) atomicAdd(&counts[COUNT_CLASS0 + k], __popcll(bal));
-    }
-}
-
-__global__ __launch_bounds__(RESOLVE_BLOCK) void order_kernel(const WorkItem *__restrict__ cands, const int *__restrict__ counts_in, int *counts,
-                                                     int max_cands, WorkItem *__restrict__ items, ItemSync *sync) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * RESOLVE_BLOCK + threadIdx.x;
-    int n = counts_in[COUNT_CANDS];
-    if (n > max_cands) n = max_cands;
-    if ((int)(blockIdx.x * RESOLVE_BLOCK) >= n && blockIdx.x != 0) return;
-    int start[8];
-    int total = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        start[k] = total;
-        total += counts_in[COUNT_CLASS0 + k];
-    }
-    if (c == 0) counts[COUNT_ITEMS] = total;
-    WorkItem wi;
-    int cls = -1;
-    if (c < n) {
-        wi = cands[c];
-        if (wi.frame_mask) cls = cost_class(wi.frame_mask);
-    }
-    // one returning atomic per (wave, class), all of a wave's classes in the same instruction: the first lane of each class
-    // reserves the range for its class
-    unsigned long long mine = 0;  // lanes of this wave in my class
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const unsigned long long bal = __ballot(cls == k);
-        if (cls == k) mine = bal;
-    }
-    if (cls >= 0) {
-        const int leader = (int)__builtin_ctzll(mine);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&counts[COUNT_CURSOR0 + cls], __popcll(mine));
-        base = __shfl(base, leader);
-        int first = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) first = (cls == k) ? start[k] : first;
-        const int pos = first + base + __popcll(mine & ((1ull << lane) - 1ull));
-        items[pos] = wi;  // items holds max_cands entries
-        item_sync_init(sync + pos);
     }
 }
 

@@ -216,9 +216,9 @@ template <int N, bool COLOR, bool SAMECAM, int VPL0>
 #endif
 __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 : INTEGRATE_WAVES)) INTEGRATE_SGPR_ATTR void integrate_kernel(IntegrateParams P, MapView M, const MapView *__restrict__ Mc,
                                                                           const WorkItem *__restrict__ items,
-                                                                          const CellRec *__restrict__ cells, ItemSync *sync,
+                                                                          const FrameBox *__restrict__ boxes, ItemSync *sync,
                                                                           const int *__restrict__ work_count, int *queues,
-                                                                          int max_items, int split, int lseq) {
+                                                                          int max_items, int split, int lseq, const unsigned short *__restrict__ brick_masks) {
     using G = Geom<N, VPL0>;   // the launch's own granularity: what the grid and the queue heads are laid out for
     using GF = Geom<N, 2>;     // the fine one (2 voxels per lane) of the items behind `split`
     const int lane = threadIdx.x & 63;
@@ -309,30 +309,21 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             using QuadU = QuadUT<VPL>;
             PHASE0(1, n_items);
             const WorkItem wi = items[it];
-            // lane k: what frame k needs of this chunk (refine_kernel), requested together with the work item
-            CellRec cr;
-            cr.need = 0ull;
-            cr.flags = 0;
-            if (lane < P.n_frames) cr = cells[(size_t)it * P.n_frames + lane];
+            // lane k: the cull kernel's flags of (chunk, frame k), requested together with the work item
+            int cr_flags = 0;
+            if (lane < P.n_frames) cr_flags = boxes[(size_t)it * P.n_frames + lane].flags;
             const int cxi = __builtin_amdgcn_readfirstlane(wi.x), cyi = __builtin_amdgcn_readfirstlane(wi.y),
                       czi = __builtin_amdgcn_readfirstlane(wi.z);
             int slot = __builtin_amdgcn_readfirstlane(wi.slot);
             unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
-            // the brick of this unit, the lane's quad in it, and the cells they lie in: bit (cz * 4 + cy) * 4 + cx of a 64-bit mask, of
-            // which a brick occupies one 32-bit half (its layers span at most two cell layers cz, and those are 2j, 2j + 1)
+            // the brick of this unit and the lane's quad in it
             const int bx = wq % G::NBX, by = (wq / G::NBX) % G::NBY, bz = wq / (G::NBX * G::NBY);  // wave-uniform
             const int vx0 = bx * G::BX + (lane & 1) * VPL, vy = by * G::BY + ((lane >> 1) & 7), vz = bz * G::BZ + (lane >> 4);
-            const int cell_half = ((bz * G::BZ) / G::CELL) >> 1;  // wave-uniform
-            unsigned lane_cells;  // this lane's cells (one, or two when the quad straddles a cell boundary: 8^3 chunks at 4 voxels per lane)
-            {
-                const int crow = ((vz / G::CELL) * 4 + vy / G::CELL) * 4 - 32 * cell_half;
-                lane_cells = (1u << (crow + vx0 / G::CELL)) | (1u << (crow + (vx0 + VPL - 1) / G::CELL));
-            }
-            unsigned unit_cells = lane_cells;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) unit_cells |= (unsigned)__shfl_xor((int)unit_cells, o);
-            const unsigned need_half = cell_half ? (unsigned)(cr.need >> 32) : (unsigned)cr.need;  // lane k: frame k's cells of this brick's half
-            const unsigned unit_frames = (unsigned)__ballot((need_half & unit_cells) != 0u);  // frames that can touch this brick (lanes >= n_frames hold 0)
+            // the frames that can touch THIS brick: the cull kernel's depth test at brick scale (kernels_cull.h, "the brick phase"), requested
+            // together with the work item.  At 2 voxels per lane a unit is one half of such a brick and takes its mask.
+            constexpr int B4X = (VPL == 4) ? 1 : 2;  // units per brick along x
+            const int brick = (bz * G::NBY + by) * (G::NBX / B4X) + bx / B4X;
+            const unsigned unit_frames = (unsigned)__builtin_amdgcn_readfirstlane((int)brick_masks[(size_t)it * BrickGrid<N>::PER_CHUNK + brick]);
             PHASE0(2, (int)unit_frames);
             if (slot >= 0 && (mask & unit_frames) == 0u) return;  // a resident chunk, and no frame of the launch can touch this brick
             if (slot == SLOT_LOOKUP) {
@@ -406,7 +397,6 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             // nothing of it depends on the voxels' state.  apply(): verdicts and updates, in frame order.  INTEGRATE_PIPE: the records of
             // frame k + 1 are requested before frame k is applied, so that their round trip runs beside frame k's arithmetic (for launches
             // that do not fill the chip: what such a launch takes is the length of its units' chains, and registers are not scarce there).
-            const int cr_flags = cr.flags;  // lane k: the cull kernel's flags of (chunk, frame k)
             struct Proj {
                 int k, flags;         // wave-uniform
                 bool need;            // this lane's cell can be touched by the frame
@@ -424,7 +414,6 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
 #endif
                 const int flags = __builtin_amdgcn_readlane(cr_flags, k);
                 pj.flags = flags;
-                const unsigned frame_cells = (unsigned)__builtin_amdgcn_readlane((int)need_half, k);
                 const FrameCam &F = P.f[k];
                 const CameraParams &C = F.cam;
                 // inCamera = R^T * (voxelCenter - t) (ProjectionIntegrator.h:64), row i of R^T summed as a0 + (a1 + a2)
@@ -437,7 +426,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
                     dx[j] = wx[j] - C.t[0];
                     pcz[j] = C.R[2] * dx[j] + s2;
                 }
-                const bool need = (frame_cells & lane_cells) != 0u;
+                const bool need = true;  // (every lane of a unit that visits a frame looks its pixels up: the brick is the unit of the depth test)
                 pj.need = need;
                 FSTAMP(0, (int)need);
                 // the quad's state, at the first frame that can touch it (straight into the tuples: no use, no wait)
