@@ -574,6 +574,12 @@ class Chisel:
     LAUNCH_STATS = ("integrate_2_per_lane", "integrate_4_per_lane", "integrate_4_with_2_tail", "cull_4_waves", "cull_wave_per_frame",
                     "unordered_worklists", "single_stream_sets", "launch_sets", "behind_unseen_recompute", "replayed")
 
+    def pool_info(self):
+        """chisel_hip_pool_info: chunks committed now, the pool's limit, times it has grown, whether it can"""
+        out = (C.c_int64 * 4)()
+        check(self.L.chisel_hip_pool_info(self.h, out))
+        return {"committed": int(out[0]), "limit": int(out[1]), "grown": int(out[2]), "growable": bool(out[3])}
+
     def launch_stats(self, reset=False):
         """which shapes the launch heuristics picked (chisel_hip_get_launch_stats)"""
         out = (C.c_int64 * len(self.LAUNCH_STATS))()

@@ -80,7 +80,9 @@ struct MapView {
     unsigned long long *counters;  // CHISEL_HIP_NUM_COUNTERS (filled by reduce_counters_kernel)
     unsigned long long *block_counters;  // [INTEGRATE_MAX_GRID][16] per-workgroup partial sums
     int *error_flag;         // two words in pinned host memory, see raise_error
-    int max_chunks;
+    int max_chunks;          // slots the per-slot arrays and the hash are laid out for (fixed at creation: the pool's upper limit)
+    int committed;           // slots whose voxel payload has memory behind it, <= max_chunks: only these are ever on the free list (a growable
+                             // pool commits more as it fills up, chisel_hip.hip: grow_pool; a fixed one has committed == max_chunks)
     // meshesToUpdate as a job list kept on the device while integrating (kernels_mesh.h: mesh_expand_dirty): the wave that first dirties
     // a slot appends the resident chunks of its 27-neighbourhood (Chisel.h:175-189), so that a recompute starts with its count kernel
     unsigned *mesh_flag;     // [max_chunks] "this slot is in the job list"

@@ -258,6 +258,20 @@ struct chisel_hip_map {
     // the count kernel of a recompute stores the number of the launch in front of it into word [5] (PROGRESS_DONE).  complete_seq: what the
     // host itself has seen complete (a wait for the stream).
     unsigned launch_seq = 0, complete_seq = 0;
+    // A pool that grows with the scene, as the reference's unordered_map of heap chunks does (ChunkManager.h:40-55, ChunkManager.cpp:171-174).
+    // The voxel arrays are address ranges reserved for view.max_chunks slots (hipMemAddressReserve) of which view.committed have physical
+    // memory mapped (hipMemCreate / hipMemMap, in steps of the allocation granularity); the per-slot arrays and the hash (76 bytes per slot
+    // against 48 KiB of voxels) are allocated for max_chunks at once, so nothing is ever moved or rehashed.  When the free slots fall under a
+    // low-water mark -- checked at launch-set boundaries from the count the integration kernels report in pinned word [7] -- grow_pool() maps
+    // more memory and two small kernels on the map's stream give the new slots default voxels and push them onto the free list.
+    bool growable = false;
+    struct PoolArray {
+        char *base = nullptr;
+        size_t reserved = 0, mapped = 0;  // bytes
+        std::vector<hipMemGenericAllocationHandle_t> handles;
+    } pool_mem[3];                        // sdf, wgt, rgbw
+    size_t vmm_granularity = 0;
+    int64_t grow_events = 0;              // (chisel_hip_pool_info)
     unsigned recomputes = 0, recomputes_seen = 0;  // mesh recomputes issued / as of the previous batch (front-stream choice)
     int items_capacity = 0;
     int pyr_w = 0, pyr_h = 0, pyr_stride = 0;
@@ -380,6 +394,93 @@ int wait_integrate(chisel_hip_map *m, unsigned L, bool until_done) {
     HIP_TRY(hipStreamSynchronize(m->stream));
     note_stream_idle(m);
     return CHISEL_HIP_OK;
+}
+
+// ---- growable pool (chisel_hip_map::growable) ---------------------------------------------------------------------------------------------
+constexpr int PROGRESS_USED = 7;  // pinned word: committed - free slots as the latest integration launch found them when it started
+// physical memory behind the first `bytes` of a reserved array
+int pool_map_upto(chisel_hip_map *m, chisel_hip_map::PoolArray &A, size_t bytes) {
+    bytes = (bytes + m->vmm_granularity - 1) / m->vmm_granularity * m->vmm_granularity;
+    if (bytes > A.reserved) bytes = A.reserved;
+    if (bytes <= A.mapped) return CHISEL_HIP_OK;
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = m->device;
+    const size_t add = bytes - A.mapped;
+    hipMemGenericAllocationHandle_t h;
+    HIP_TRY(hipMemCreate(&h, add, &prop, 0));
+    hipError_t e = hipMemMap(A.base + A.mapped, add, 0, h, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc;
+        memset(&acc, 0, sizeof(acc));
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        // (over everything mapped so far, from the reservation's base: on this driver the call fails now and then -- "invalid argument" --
+        // for a range that begins behind an earlier mapping, never for one that begins at the base: tools/micro/vmm_probe.hip)
+        e = hipMemSetAccess(A.base, A.mapped + add, &acc, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(A.base + A.mapped, add);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemRelease(h);
+        return fail(CHISEL_HIP_ERR_HIP, std::string("growing the chunk pool: ") + hipGetErrorString(e));
+    }
+    A.handles.push_back(h);
+    A.mapped = bytes;
+    return CHISEL_HIP_OK;
+}
+void pool_release(chisel_hip_map::PoolArray &A) {
+    if (!A.base) return;
+    if (A.mapped) (void)hipMemUnmap(A.base, A.mapped);
+    for (auto h : A.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(A.base, A.reserved);
+    A = chisel_hip_map::PoolArray();
+}
+// more committed slots (up to `want`, at most view.max_chunks): memory, default voxels, free list -- queued on the map's stream, nothing waited for
+int grow_pool(chisel_hip_map *m, int64_t want) {
+    MapView &v = m->view;
+    if (!m->growable || v.committed >= v.max_chunks) return CHISEL_HIP_OK;
+    const size_t per_chunk = (size_t)m->V * sizeof(float);  // (floats and packed colours alike: 4 bytes per voxel)
+    int64_t step = (int64_t)std::max<size_t>(1, m->vmm_granularity / per_chunk);  // whole mapping granules
+    int64_t target = std::min<int64_t>(v.max_chunks, (std::max<int64_t>(want, v.committed + 1) + step - 1) / step * step);
+    for (int a = 0; a < 3; a++) {
+        if (a == 2 && !m->cfg.use_color) continue;
+        int rc = pool_map_upto(m, m->pool_mem[a], (size_t)target * per_chunk);
+        if (rc) return rc;
+    }
+    const int first = v.committed, n = (int)(target - v.committed);
+    hipLaunchKernelGGL(grow_pool_kernel, dim3(std::min(n, 4096)), dim3(256), 0, m->stream, m->view, m->V, first, n);
+    hipLaunchKernelGGL(grow_commit_kernel, dim3(1), dim3(1), 0, m->stream, m->view, n);
+    HIP_TRY(hipGetLastError());
+    v.committed = (int)target;
+    HIP_TRY(hipMemcpyAsync(&m->view_dev->committed, &v.committed, sizeof(int), hipMemcpyHostToDevice, m->stream));
+    m->grow_events++;
+    return CHISEL_HIP_OK;
+}
+// Called where chunks are about to be created: grows the pool when what is left of it -- by the latest report of an integration launch,
+// less what the launches queued since may have taken -- is less than a quarter of the pool, or than `expect_new` with room to spare.
+int maybe_grow(chisel_hip_map *m, int64_t expect_new) {
+    if (!m->growable || m->view.committed >= m->view.max_chunks) return CHISEL_HIP_OK;
+    volatile int *w = reinterpret_cast<volatile int *>(m->error_flag_host);
+    const int64_t used = w[PROGRESS_USED];
+    const unsigned started = (unsigned)w[PROGRESS_STARTED];
+    const int64_t in_flight = (int64_t)(m->launch_seq > started ? m->launch_seq - started : 0) + 1;  // launches whose allocations the report does not hold
+    const int64_t free_est = (int64_t)m->view.committed - used - in_flight * expect_new;
+    if (free_est >= (int64_t)m->view.committed / 4 && free_est >= 2 * expect_new) return CHISEL_HIP_OK;
+    return grow_pool(m, std::max<int64_t>(2 * (int64_t)m->view.committed, (int64_t)m->view.committed + 4 * in_flight * expect_new));
+}
+
+// ... and for the entry points that create chunks outside the integration path and wait for the stream anyway (point clouds, uploads): the
+// free list's true height, at least `n` free slots afterwards (or the pool at its limit)
+int ensure_free_exact(chisel_hip_map *m, int64_t n) {
+    if (!m->growable || m->view.committed >= m->view.max_chunks) return CHISEL_HIP_OK;
+    int top = 0;
+    HIP_TRY(hipMemcpyAsync(&top, m->view.free_top, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    note_stream_idle(m);
+    if ((int64_t)top >= n + (int64_t)m->view.committed / 8) return CHISEL_HIP_OK;
+    return grow_pool(m, std::max<int64_t>(2 * (int64_t)m->view.committed, (int64_t)m->view.committed + 2 * n));
 }
 
 // the chunk hash was changed on the map's stream outside the integration path: the next batch's front half must see it
@@ -1023,6 +1124,12 @@ int integrate_group(chisel_hip_map *m, int n, const chisel_hip_depth_frame *fram
         }
         m->items_capacity = cap;
     }
+    {
+        // (a launch set creates at most its work items' worth of chunks; the hint is a recent launch's count)
+        const int items_hint = reinterpret_cast<volatile int *>(m->error_flag_host)[2];
+        rc = maybe_grow(m, std::max<int64_t>(256, 2 * (int64_t)items_hint));
+        if (rc) return rc;
+    }
     switch (m->N) {
         case 8: return launch_group<8>(m, bs, PP, CP, IP, color);
         case 16: return launch_group<16>(m, bs, PP, CP, IP, color);
@@ -1225,10 +1332,27 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     m->V = N * N * N;
     m->device = dev;
     const size_t bytes_per_chunk = (size_t)m->V * (8 + (cfg->use_color ? 4 : 0));
-    int64_t C = cfg->max_chunks;
-    if (C <= 0) C = (int64_t)((6ull << 30) / bytes_per_chunk);
-    if (C > (1 << 30)) C = 1 << 30;
+    // max_chunks > 0: a pool of exactly that many chunks (exhaustion = CHISEL_HIP_ERR_POOL_FULL); 0: the default size, growing with the scene;
+    // < 0: -max_chunks to begin with, growing.  A growing pool is laid out for 16 times its first size, or for what three quarters of
+    // the device's memory hold, whichever is less (C_max); CHISEL_HIP_GROW=0 keeps every pool at its first size.
+    int64_t C0 = cfg->max_chunks;
+    bool growable = C0 <= 0 && !(getenv("CHISEL_HIP_GROW") && atoi(getenv("CHISEL_HIP_GROW")) == 0);
+    if (C0 == 0) C0 = (int64_t)((6ull << 30) / bytes_per_chunk);
+    else if (C0 < 0) C0 = -C0;
+    if (C0 > (1 << 30)) C0 = 1 << 30;
+    int64_t C = C0;  // C_max
+    if (growable) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
+        const int64_t by_memory = (int64_t)((double)total_b * 0.75 / (double)bytes_per_chunk);
+        const int64_t step = std::max<int64_t>(1, ((int64_t)2 << 20) / ((int64_t)m->V * 4));  // chunks per 2 MiB page of a voxel array: what the pool grows in
+        C0 = (C0 + step - 1) / step * step;
+        C = std::max<int64_t>(C0, std::min<int64_t>(std::max<int64_t>(16 * C0, 8 * step), by_memory));
+        if (C > (1 << 30)) C = 1 << 30;
+        if (C == C0) growable = false;
+    }
     m->cfg.max_chunks = C;
+    m->growable = growable;
     uint64_t hc = 1024;
     while (hc < (uint64_t)C * 2) hc <<= 1;
     m->hash_capacity = hc;
@@ -1325,14 +1449,63 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     }
     MapView &v = m->view;
     v.max_chunks = (int)C;
+    v.committed = (int)C0;
     v.hash_mask = hc - 1;
-    HIP_TRY_C(hipMalloc(&v.sdf, (size_t)C * m->V * sizeof(float)));
-    HIP_TRY_C(hipMalloc(&v.wgt, (size_t)C * m->V * sizeof(float)));
-    if (cfg->use_color) HIP_TRY_C(hipMalloc(&v.rgbw, (size_t)C * m->V * sizeof(uchar4)));
+    if (m->growable) {
+        // the voxel arrays as reserved address ranges, the first C0 slots mapped (a device without the virtual-memory calls gets a fixed pool)
+        hipMemAllocationProp prop;
+        memset(&prop, 0, sizeof(prop));
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) {
+            (void)hipGetLastError();
+            m->growable = false;
+        } else {
+            // (the device reports 4 KiB, but mappings of that size behaved erratically -- hipMemSetAccess on a range behind an earlier mapping
+            // failed now and then, tools/micro/vmm_probe.hip --: the pool maps whole 2 MiB pages, as the driver's own allocator does)
+            gran = std::max<size_t>(gran, (size_t)2 << 20);
+            m->vmm_granularity = gran;
+            const size_t per_chunk = (size_t)m->V * sizeof(float);
+            const int64_t step = (int64_t)std::max<size_t>(1, gran / per_chunk);
+            v.committed = (int)std::min<int64_t>(C, (C0 + step - 1) / step * step);
+            const size_t reserve = ((size_t)C * per_chunk + gran - 1) / gran * gran;
+            for (int a = 0; a < 3 && m->growable; a++) {
+                if (a == 2 && !cfg->use_color) continue;
+                void *base = nullptr;
+                if (hipMemAddressReserve(&base, reserve, gran, nullptr, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    m->growable = false;
+                    break;
+                }
+                m->pool_mem[a].base = static_cast<char *>(base);
+                m->pool_mem[a].reserved = reserve;
+                if (pool_map_upto(m, m->pool_mem[a], (size_t)v.committed * per_chunk) != CHISEL_HIP_OK) m->growable = false;
+            }
+            if (!m->growable)
+                for (auto &A : m->pool_mem) pool_release(A);
+        }
+        if (m->growable) {
+            v.sdf = reinterpret_cast<float *>(m->pool_mem[0].base);
+            v.wgt = reinterpret_cast<float *>(m->pool_mem[1].base);
+            if (cfg->use_color) v.rgbw = reinterpret_cast<uchar4 *>(m->pool_mem[2].base);
+        } else {
+            // no growth on this device: the pool is its first size, as with max_chunks > 0 (hash and per-slot arrays keep the larger layout)
+            v.committed = (int)C0;
+        }
+    }
+    if (!m->growable) {
+        HIP_TRY_C(hipMalloc(&v.sdf, (size_t)v.committed * m->V * sizeof(float)));
+        HIP_TRY_C(hipMalloc(&v.wgt, (size_t)v.committed * m->V * sizeof(float)));
+        if (cfg->use_color) HIP_TRY_C(hipMalloc(&v.rgbw, (size_t)v.committed * m->V * sizeof(uchar4)));
+    }
     HIP_TRY_C(hipMalloc(&v.hash_keys, hc * sizeof(uint64_t)));
     HIP_TRY_C(hipMalloc(&v.hash_vals, hc * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.slot_key, (size_t)C * sizeof(uint64_t)));
+    HIP_TRY_C(hipMemsetAsync(v.slot_key, 0xff, (size_t)C * sizeof(uint64_t), m->stream));  // KEY_EMPTY: also the slots a growable pool has not committed yet
     HIP_TRY_C(hipMalloc(&v.slot_dirty, (3 * (size_t)C + SLOT_SUMMARY_PAD) * sizeof(uint32_t)));  // flags, list of dirty slots, its length; sign summaries
+    HIP_TRY_C(hipMemsetAsync(v.slot_dirty, 0, (3 * (size_t)C + SLOT_SUMMARY_PAD) * sizeof(uint32_t), m->stream));
     HIP_TRY_C(hipMalloc(&v.free_list, (size_t)C * sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.free_top, sizeof(int)));
     HIP_TRY_C(hipMalloc(&v.counters, 32 * sizeof(unsigned long long)));
@@ -1376,6 +1549,10 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     (void)hipSetDevice(m->device);
     if (m->stream) (void)sync_all(m);
     MapView &v = m->view;
+    if (m->pool_mem[0].base) {  // (a growable pool: mapped ranges, not allocations)
+        for (auto &A : m->pool_mem) pool_release(A);
+        v.sdf = nullptr; v.wgt = nullptr; v.rgbw = nullptr;
+    }
     void *ptrs[] = {v.sdf, v.wgt, v.rgbw, v.hash_keys, v.hash_vals, v.slot_key, v.slot_dirty, v.free_list, v.free_top,
                     v.counters, v.block_counters, m->view_dev, m->scratch_i, m->shell_items_dev, m->shell_offs_dev, m->shell_first_dev, v.mesh_jobs};
     for (void *p : ptrs)
@@ -1585,7 +1762,7 @@ int chisel_hip_num_chunks(chisel_hip_map *m, int64_t *out) {
     if (rc) return rc;
     int top = 0;
     HIP_TRY(hipMemcpy(&top, m->view.free_top, sizeof(int), hipMemcpyDeviceToHost));
-    *out = (int64_t)m->view.max_chunks - top;
+    *out = (int64_t)m->view.committed - top;
     return CHISEL_HIP_OK;
 }
 
@@ -1895,6 +2072,8 @@ int chisel_hip_import_ghost_chunks(chisel_hip_map *m, const int *ids, int n, con
     { m->topology_epoch++; m->dirty_tail_queued = false; }
     int rc = check_mesh_totals(m);
     if (rc) return rc;
+    rc = maybe_grow(m, n);  // (ghosts take slots of this shard's pool until they are dropped again)
+    if (rc) return rc;
     for (int j = 0; j < n; j++)
         if ((!found || found[j]) && chunk_owner(ids[3 * j], ids[3 * j + 1], ids[3 * j + 2], m->cfg.n_shards, m->cfg.shard_block) == m->cfg.shard_rank)
             return fail(CHISEL_HIP_ERR_INVALID, "a ghost chunk must belong to another shard");
@@ -2072,6 +2251,8 @@ int chisel_hip_import_ghost_shells(chisel_hip_map *m, const int *items, int n, c
     { m->topology_epoch++; m->dirty_tail_queued = false; }
     int rc = check_mesh_totals(m);
     if (rc) return rc;
+    rc = maybe_grow(m, n);  // (ghosts take slots of this shard's pool until they are dropped again)
+    if (rc) return rc;
     // the distinct ghosts (several boxes may belong to one), each with the item whose `found` decides whether it is created
     std::unordered_set<uint64_t, IdHash> seen;
     std::vector<int> first;
@@ -2168,7 +2349,7 @@ int chisel_hip_shell_plan_device(chisel_hip_map *m, const int *gathered_dev, int
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m || !gathered_dev || !out || cap < 1 || world < 1 || world != m->cfg.n_shards || world > SHELL_MAX_SHARDS) return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
-    int rc = ensure_mesh_jobs(m, m->view.max_chunks);
+    int rc = ensure_mesh_jobs(m, m->view.committed);
     if (rc) return rc;
     if (m->input_event) {
         HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
@@ -2278,6 +2459,8 @@ int chisel_hip_import_shells_packed(chisel_hip_map *m, const void *in_dev, int64
         m->input_event = nullptr;
     }
     if (items > 0) {
+        rc = maybe_grow(m, items);  // (ghosts take slots of this shard's pool until they are dropped again)
+        if (rc) return rc;
         const unsigned char *in = static_cast<const unsigned char *>(in_dev);
         hipLaunchKernelGGL(shell_ensure_ghosts_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, m->stream, m->view, in, G, m->cfg.n_shards, items,
                            reinterpret_cast<unsigned long long *>(m->shell_plan.ctl + 16 + 4 * SHELL_MAX_SHARDS));
@@ -2435,6 +2618,8 @@ int chisel_hip_load_map(chisel_hip_map *m, const char *path) {
     if (h.n_chunks < 0 || h.n_chunks > m->view.max_chunks) return fail(CHISEL_HIP_ERR_POOL_FULL, "map file holds more chunks than max_chunks");
     int rc = chisel_hip_reset(m);
     if (rc) return rc;
+    rc = ensure_free_exact(m, h.n_chunks);  // (a growable pool: room for the file's chunks)
+    if (rc) return rc;
     const size_t V = (size_t)m->V;
     std::vector<float> sdf(V), wgt(V);
     std::vector<uint8_t> col(h.has_color ? 4 * V : 0);
@@ -2463,6 +2648,8 @@ int chisel_hip_upload_chunk(chisel_hip_map *m, const int id[3], const float *sdf
     int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
     if (rc) return rc;
     rc = ensure_scratch(m, 16);
+    if (rc) return rc;
+    rc = ensure_free_exact(m, 1);
     if (rc) return rc;
     hipLaunchKernelGGL(ensure_chunk_kernel, dim3(1), dim3(1), 0, m->stream, m->view, id[0], id[1], id[2], m->scratch_i);
     int slot = -1;
@@ -2747,6 +2934,24 @@ int chisel_hip_raycast(const float start[3], const float end[3], const int min_x
     (void)hipFree(d_in); (void)hipFree(d_cells); (void)hipFree(d_count);
     if (e != hipSuccess) return fail(CHISEL_HIP_ERR_HIP, std::string("chisel_hip_raycast: ") + hipGetErrorString(e));
     *count = c;
+    return CHISEL_HIP_OK;
+}
+
+int chisel_hip_pool_info(chisel_hip_map *m, int64_t out[4]) {
+    if (!m || !out) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (m->is_group)
+        return group::for_all(m, [&](chisel_hip_map *s) {
+            int64_t v[4];
+            const int rc = chisel_hip_pool_info(s, v);
+            for (int k = 0; k < 3; k++) out[k] += v[k];
+            out[3] = std::max(out[3], v[3]);
+            return rc;
+        });
+    out[0] = m->view.committed;
+    out[1] = m->growable ? m->view.max_chunks : m->view.committed;
+    out[2] = m->grow_events;
+    out[3] = m->growable ? 1 : 0;
     return CHISEL_HIP_OK;
 }
 

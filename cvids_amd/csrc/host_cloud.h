@@ -137,6 +137,8 @@ extern "C" int chisel_hip_integrate_pointcloud(chisel_hip_map *m, const chisel_h
     HIP_TRY(hipSetDevice(m->device));
     int rc = check_mesh_totals(m);  // a recompute in flight reads the voxels as they are
     if (rc) return rc;
+    rc = ensure_free_exact(m, CLOUD_MAX_LISTED);  // (a growable pool: a cloud creates at most the chunks it can list)
+    if (rc) return rc;
     CloudParams P;
     CloudView C;
     rc = cloud_setup(m, cloud, P, C);

@@ -74,8 +74,8 @@ hipError_t zero_mesh_counters(chisel_hip_map *m) {
 // the device (mesh_ctl[4], copied to the totals by the count kernel); nothing here waits for the stream unless `extra` is used.
 int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
     MeshBuffers &B = m->mesh_buf;
-    const int C = m->view.max_chunks;
-    int rc = ensure_mesh_jobs(m, C);  // (MeshJob / JobInfo records: worst case every resident chunk)
+    const int C = m->view.committed;
+    int rc = ensure_mesh_jobs(m, C);  // (MeshJob / JobInfo records: worst case every resident chunk -- every slot that has memory)
     if (rc) return rc;
     int *n_jobs = mesh_totals(m) + MC_KEPT;
     B.n_jobs = n_jobs;

@@ -239,7 +239,10 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
     int n_items = *work_count;
     // this launch has started: everything queued in front of it on the map's stream is over (the host's substitute for events on that
     // stream, chisel_hip.hip: launch_seq; pinned memory, one thread -- also of a launch that leaves at once)
-    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<volatile int *>(M.error_flag)[4] = lseq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<volatile int *>(M.error_flag)[4] = lseq;
+        reinterpret_cast<volatile int *>(M.error_flag)[7] = M.committed - *M.free_top;  // slots in use (what a growable pool's host looks at)
+    }
     if (latch) return;
     if (n_items > max_items) n_items = max_items;
     const int total = n_items * G::WPC;

@@ -33,17 +33,18 @@ __global__ __launch_bounds__(256) void reset_map_kernel(MapView M, int V, int al
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = gid; i <= M.hash_mask; i += stride) M.hash_keys[i] = KEY_EMPTY;
-    for (uint64_t i = gid; i < (uint64_t)M.max_chunks; i += stride) {
+    // (only the committed slots have voxel memory, hold chunks and sit on the free list: MapView::committed)
+    for (uint64_t i = gid; i < (uint64_t)M.committed; i += stride) {
         M.slot_dirty[i] = 0;
         slot_summary(M)[i] = 0;
         if (M.mesh_flag) M.mesh_flag[i] = 0;
-        M.free_list[i] = M.max_chunks - 1 - (int)i;  // slot 0 is popped first
+        M.free_list[i] = M.committed - 1 - (int)i;  // slot 0 is popped first
     }
-    for (long long base = 0; base < (long long)M.max_chunks; base += (long long)gridDim.x * 256) {
+    for (long long base = 0; base < (long long)M.committed; base += (long long)gridDim.x * 256) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
         const long long slot = base + (long long)threadIdx.x * gridDim.x + blockIdx.x;
-        if (slot < (long long)M.max_chunks) {
+        if (slot < (long long)M.committed) {
             const bool used = all_slots || M.slot_key[slot] != KEY_EMPTY;
             M.slot_key[slot] = KEY_EMPTY;
             if (used) s_list[atomicAdd(&s_n, 1)] = (int)slot;
@@ -63,11 +64,30 @@ __global__ __launch_bounds__(256) void reset_map_kernel(MapView M, int V, int al
                 M.mesh_ctl[MC_BBOX + 3 + a] = INT32_MIN;
             }
         }
-        *M.free_top = M.max_chunks;
+        *M.free_top = M.committed;
         M.error_flag[0] = 0;
         M.error_flag[1] = 0;
     }
 }
+
+// A growable pool has just committed the slots [first, first + n) (chisel_hip.hip: grow_pool; M.committed is still `first`): default voxels
+// into their fresh memory (the pool invariant), their per-slot state cleared, and onto the free list -- the highest on top, as after a reset.
+// On the map's stream: no other kernel that pops or pushes slots runs beside it.
+__global__ __launch_bounds__(256) void grow_pool_kernel(MapView M, int V, int first, int n) {
+    for (int s = blockIdx.x; s < n; s += gridDim.x) {
+        const int slot = first + s;
+        fill_default_chunk(M, slot, V);
+        if (threadIdx.x == 0) {
+            M.slot_key[slot] = KEY_EMPTY;
+            M.slot_dirty[slot] = 0;
+            slot_summary(M)[slot] = 0;
+            if (M.mesh_flag) M.mesh_flag[slot] = 0;
+            M.free_list[*M.free_top + (n - 1 - s)] = slot;  // (free_top is raised by grow_commit_kernel, behind this kernel: stable here)
+        }
+    }
+}
+// ... and then, behind it on the stream, the free list's top (one thread)
+__global__ void grow_commit_kernel(MapView M, int n) { *M.free_top += n; }
 
 __device__ inline int hash_find(const MapView &M, int x, int y, int z, uint64_t *where = nullptr) {
     const uint64_t key = pack_id(x, y, z);
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(256) void census_kernel(MapView M, int V, CensusOut
     __shared__ unsigned s_cnt[4][3];
     __shared__ double s_w[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int slot = blockIdx.x; slot < M.max_chunks; slot += gridDim.x) {
+    for (int slot = blockIdx.x; slot < M.committed; slot += gridDim.x) {
         const uint64_t key = M.slot_key[slot];  // block-uniform
         if (key == KEY_EMPTY) continue;
         unsigned unknown = 0, inside = 0, outside = 0;
@@ -274,7 +294,7 @@ __global__ void list_slots_kernel(MapView M, int *ids, int *slots, int max_out, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     uint64_t key = KEY_EMPTY;
-    if (i < M.max_chunks) {
+    if (i < M.committed) {  // (slots without voxel memory hold no chunk)
         key = M.slot_key[i];
         keep = key != KEY_EMPTY && (!DIRTY_ONLY || M.slot_dirty[i] != 0);
     }

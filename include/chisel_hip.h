@@ -50,7 +50,7 @@ typedef enum {
     CHISEL_HIP_OK = 0,
     CHISEL_HIP_ERR_INVALID = 1,     /* bad argument (null, non-cubic chunk, bad channel count ...)        */
     CHISEL_HIP_ERR_HIP = 2,         /* a HIP runtime call failed / no gfx950 device                        */
-    CHISEL_HIP_ERR_POOL_FULL = 3,   /* chunk pool or hash exhausted: raise chisel_hip_config.max_chunks    */
+    CHISEL_HIP_ERR_POOL_FULL = 3,   /* chunk pool or hash exhausted (a fixed pool, or a growing one at its limit) */
     CHISEL_HIP_ERR_NOT_FOUND = 4,   /* chunk / mesh absent (the reference throws std::out_of_range)        */
     CHISEL_HIP_ERR_UNSUPPORTED = 5, /* feature outside the supported envelope                             */
     CHISEL_HIP_ERR_IO = 6           /* file could not be written                                          */
@@ -70,7 +70,10 @@ typedef struct {
     float voxel_resolution;  /* metres                                                                  */
     int use_color;           /* allocate RGBW voxels (ColorVoxel.h:95-98)                               */
     int device_id;           /* HIP device ordinal, -1 = current device                                 */
-    int64_t max_chunks;      /* chunk-pool capacity, 0 = default (about 6 GiB of voxel payload)         */
+    int64_t max_chunks;      /* chunk pool: > 0 = exactly that many chunks (more: CHISEL_HIP_ERR_POOL_FULL); 0 = about 6 GiB of
+                              * voxel payload to begin with, GROWING with the scene as the reference's unordered_map of heap chunks
+                              * does (ChunkManager.h:40-55; up to 16 times that or three quarters of the device's memory); < 0 =
+                              * -max_chunks chunks to begin with, growing likewise.  See chisel_hip_pool_info.  */
     int n_shards;            /* spatial sharding of the chunk hash over GPUs: number of shards (>=1)    */
     int shard_rank;          /* this map's shard, 0 <= shard_rank < n_shards                            */
     int shard_block;         /* ownership super-block edge in chunks, 0 = default (2)                   */
@@ -460,6 +463,11 @@ int chisel_hip_raycast(const float start[3], const float end[3], const int min_x
  * yet, and the ones of them that had to be replayed because that recompute did not fit.  A group handle sums its shards. */
 #define CHISEL_HIP_NUM_LAUNCH_STATS 10
 int chisel_hip_get_launch_stats(chisel_hip_map *map, int64_t *out, int reset_stats);
+/* The chunk pool (no reference counterpart: ChunkManager's map has no capacity): out[0] = chunks with voxel memory behind them now,
+ * out[1] = the most the pool can grow to (== out[0] for a fixed pool), out[2] = times it has grown, out[3] = 1 if it can grow.  A growing
+ * pool commits more memory when its free slots fall under a quarter (checked when a launch set is queued, from the figures the integration
+ * kernels report: nothing is waited for, nothing is moved, ids and slots stay what they are); a group handle reports its shards' sums. */
+int chisel_hip_pool_info(chisel_hip_map *map, int64_t out[4]);
 /* owner shard of a chunk id under (n_shards, shard_block); pure function, same on every rank */
 int chisel_hip_chunk_owner(const int id_xyz[3], int n_shards, int shard_block);
 

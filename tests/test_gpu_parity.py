@@ -354,6 +354,43 @@ def test_pool_exhaustion_is_reported(oracle_mod):
     assert e.value.code == 3
 
 
+def test_growing_pool_integrates_past_its_first_size(oracle_mod):
+    """max_chunks < 0: a pool that starts small and grows like the reference's map of heap chunks (ChunkManager.h:40-55): a stream that needs
+    many times the first commitment integrates bit for bit like the oracle, without CHISEL_HIP_ERR_POOL_FULL, in launch sets of several
+    frames queued back to back (the growth is decided from lagging reports) and with a reset in between (the grown pool stays)."""
+    om, gm, integ = _mk(oracle_mod, 16, 0.02, True, max_chunks=-16)  # (commits whole 2 MiB pages: 128 chunks of 16^3 to begin with)
+    info0 = gm.pool_info()
+    assert info0["growable"] and info0["limit"] > info0["committed"] >= 16
+    cam = small_camera(96, 72)
+    color = synth.render_color(96, 72, 3)
+    frames = make_frames("sphere_room", 12, 96, 72)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy)
+    for rnd in range(2):
+        for lo in range(0, 12, 3):
+            part = frames[lo:lo + 3]
+            for d, p in part:
+                om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
+            gm.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
+        gm.synchronize()
+        assert om.num_chunks() == gm.NumChunks()
+        compare_fields(om.fields(), gm.fields(), om.V, True)
+        info = gm.pool_info()
+        assert info["committed"] >= gm.NumChunks() and (info["grown"] >= 1 or info0["committed"] >= om.num_chunks())
+        if rnd == 0:
+            gm.Reset()
+            om = _mk(oracle_mod, 16, 0.02, True)[0]
+    assert gm.pool_info()["grown"] >= 1 and om.num_chunks() > info0["committed"]  # (the scene needs more than the first commitment: the test is one)
+    # a saved map loaded into a pool that has to grow for it
+    _, g2, _ = _mk(oracle_mod, 16, 0.02, True, max_chunks=-16)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.bin")
+        gm.SaveMap(path)
+        g2.LoadMap(path)
+    assert g2.NumChunks() == gm.NumChunks() and g2.pool_info()["committed"] >= gm.NumChunks()
+    compare_fields(gm.fields(), g2.fields(), om.V, True)
+
+
 def test_device_resident_frames_and_batch(oracle_mod):
     """Frames already in HBM (torch tensors) through integrate_batch == frame-by-frame host frames."""
     import torch
