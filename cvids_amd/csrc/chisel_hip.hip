@@ -866,7 +866,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         // Worth it when the front half is what the stream waits for: launches whose frames look at different parts of the space.
         const int rblock = narrow_cull_set ? 64 : BRICK_BLOCK;
         const int rwaves = rblock / 64;
-        const long long want = items_hint > 0 ? items_hint + items_hint / 4 + 16 : 2048;
+        const long long want = (items_hint > 0 ? items_hint + items_hint / 4 + 16 : 2048) * (IP.n_frames > 8 ? 2 : 1);  // (two waves per item for launches of more than eight frames)
         const int rgrid = (int)std::max<long long>(64, std::min<long long>(8192 / rwaves, (want + rwaves - 1) / rwaves));
         // The brick kernel is the front half's last: in the pipelined form its completion IS the set's front_done event (no record packet
         // behind it); the short form has no event at all (launch_seq).

@@ -512,7 +512,15 @@ __global__ __launch_bounds__(256) void brick_kernel(IntegrateParams P, PyramidVi
     int n_items = *work_count;
     if (n_items > max_items) n_items = max_items;
     const int waves = (int)gridDim.x * (int)(blockDim.x >> 6);
-    for (int it = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); it < n_items; it += waves) {
+    // launches of more than eight frames give an item two waves, frames 0-7 and 8-15 (a wave's chain is its rounds: at most two then); each
+    // writes its byte of the bricks' 16-bit masks
+    const int halves = n_frames > 8 ? 2 : 1;
+    for (int p = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6); p < n_items * halves; p += waves) {
+        const int it = halves == 2 ? p >> 1 : p, hh = halves == 2 ? (p & 1) : 0;
+        const int k_lo = 8 * hh, k_hi = halves == 2 ? (hh ? n_frames : 8) : n_frames;  // this wave's frames
+        // (the first round's camera is requested beside the work item, the next round's while this one's texels are under way: the
+        // cameras come from the argument segment with a per-lane index, i.e. through the vector memory path)
+        CameraParams Cn = P.f[min(k_lo + g, n_frames - 1)].cam;
         const WorkItem wi = items[it];
         const unsigned fmask = (unsigned)__builtin_amdgcn_readfirstlane((int)wi.frame_mask);
         const int slot = __builtin_amdgcn_readfirstlane(wi.slot);
@@ -525,10 +533,11 @@ __global__ __launch_bounds__(256) void brick_kernel(IntegrateParams P, PyramidVi
 #pragma unroll
             for (int h = 0; h < BR; h++) m[h] = fmask;
         } else {
-            for (int j = 0; j * G < n_frames; j++) {  // (a round; lanes of one group share the frame, a group whose frame is not in the mask idles)
-                const int kf = g + j * G;
-                if (kf >= n_frames || !((fmask >> kf) & 1u)) continue;
-                const CameraParams &C = P.f[kf].cam;
+            for (int j = 0; k_lo + j * G < k_hi; j++) {  // (a round; lanes of one group share the frame, a group whose frame is not in the mask idles)
+                const int kf = k_lo + g + j * G;
+                const CameraParams C = Cn;
+                if (k_lo + (j + 1) * G < k_hi) Cn = P.f[min(kf + G, n_frames - 1)].cam;
+                if (kf >= k_hi || !((fmask >> kf) & 1u)) continue;
                 const bool resident = slot >= 0 || slot == SLOT_LOOKUP || (inband_all & ((1u << kf) - 1u)) != 0u;
 #pragma unroll
                 for (int h = 0; h < BR; h++) {
@@ -565,7 +574,10 @@ __global__ __launch_bounds__(256) void brick_kernel(IntegrateParams P, PyramidVi
         }
         if (BPC >= 64 || lane < BPC) {
 #pragma unroll
-            for (int h = 0; h < BR; h++) brick_masks[(size_t)it * BPC + lane + 64 * h] = (unsigned short)m[h];
+            for (int h = 0; h < BR; h++) {
+                if (halves == 2) reinterpret_cast<unsigned char *>(brick_masks)[2 * ((size_t)it * BPC + lane + 64 * h) + hh] = (unsigned char)((m[h] >> (8 * hh)) & 0xffu);
+                else brick_masks[(size_t)it * BPC + lane + 64 * h] = (unsigned short)m[h];
+            }
         }
     }
 }
