@@ -69,7 +69,7 @@ EXPORTS = [
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
     "chisel_hip_depth_filter_create", "chisel_hip_depth_filter_destroy", "chisel_hip_depth_filter_update", "chisel_hip_depth_filter_read",
     "chisel_hip_get_counters", "chisel_hip_memory_statistics", "chisel_hip_topology_epoch", "chisel_hip_candidates", "chisel_hip_cloud_candidates", "chisel_hip_mesh_cube", "chisel_hip_write_mesh_ply", "chisel_hip_shade_vertices", "chisel_hip_generate_mesh", "chisel_hip_recompute_mesh", "chisel_hip_integrate_chunk", "chisel_hip_dirty_ids_device", "chisel_hip_mesh_shell_plan",
-    "chisel_hip_shell_volume", "chisel_hip_export_shells", "chisel_hip_import_ghost_shells", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_get_launch_stats", "chisel_hip_pool_info", "chisel_hip_mc_tables", "chisel_hip_mesh_cube_values", "chisel_hip_interpolate_vertex", "chisel_hip_raycast", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_create_group",
+    "chisel_hip_shell_volume", "chisel_hip_export_shells", "chisel_hip_import_ghost_shells", "chisel_hip_set_profiling", "chisel_hip_get_profile", "chisel_hip_get_launch_stats", "chisel_hip_pool_info", "chisel_hip_mc_tables", "chisel_hip_mesh_cube_values", "chisel_hip_interpolate_vertex", "chisel_hip_raycast", "chisel_hip_chunk_owner", "chisel_hip_frustum", "chisel_hip_frustum_from_vectors", "chisel_hip_create_group",
 ]
 # the device self-tests and debug read-outs include/chisel_hip_selftest.h declares
 SELFTEST_EXPORTS = [

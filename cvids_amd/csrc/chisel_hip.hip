@@ -1394,8 +1394,8 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     }
     m->stream = m->own_stream;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
-    HIP_TRY_C(hipHostMalloc((void **)&m->mesh_totals_host, 8 * sizeof(int), hipHostMallocDefault));
-    memset(m->mesh_totals_host, 0, 8 * sizeof(int));
+    HIP_TRY_C(hipHostMalloc((void **)&m->mesh_totals_host, 16 * sizeof(int), hipHostMallocDefault));  // ([8..]: staging of small host values that are copied to the device asynchronously)
+    memset(m->mesh_totals_host, 0, 16 * sizeof(int));
     HIP_TRY_C(hipHostGetDevicePointer((void **)&m->mesh_totals_dev, m->mesh_totals_host, 0));
     HIP_TRY_C(hipHostMalloc((void **)&m->mesh_info_host, (size_t)MESH_INFO_PREFETCH * sizeof(JobInfo), hipHostMallocDefault));
     HIP_TRY_C(hipHostGetDevicePointer((void **)&m->mesh_info_dev, m->mesh_info_host, 0));
@@ -3281,6 +3281,20 @@ int chisel_hip_frustum(const float pose[12], float fy, float cy, int width, int 
         // far face, near face, connecting edges (Frustum.cpp:190-217)
         static const int idx[24] = {0, 1, 3, 2, 1, 3, 2, 0, 4, 7, 6, 5, 5, 7, 6, 4, 0, 5, 1, 6, 2, 7, 3, 4};
         for (int i = 0; i < 24; i++) memcpy(lines + 3 * i, fr.corners + 3 * idx[i], 3 * sizeof(float));
+    }
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_frustum_from_vectors(const float forward[3], const float pos[3], const float right[3], const float up[3], float near_plane, float far_plane,
+                                    float fov, float aspect, float *corners, float *lines, float *planes) {
+    if (!forward || !pos || !right || !up) return fail(CHISEL_HIP_ERR_INVALID, "bad frustum arguments");
+    float pl[24], co[24];
+    hostmath::frustum_from_vectors(hostmath::mk(forward[0], forward[1], forward[2]), hostmath::mk(pos[0], pos[1], pos[2]), hostmath::mk(right[0], right[1], right[2]),
+                                   hostmath::mk(up[0], up[1], up[2]), near_plane, far_plane, fov, aspect, pl, co);
+    if (corners) memcpy(corners, co, sizeof(co));
+    if (planes) memcpy(planes, pl, sizeof(pl));
+    if (lines) {
+        static const int idx[24] = {0, 1, 3, 2, 1, 3, 2, 0, 4, 7, 6, 5, 5, 7, 6, 4, 0, 5, 1, 6, 2, 7, 3, 4};  // Frustum.cpp:190-217
+        for (int i = 0; i < 24; i++) memcpy(lines + 3 * i, co + 3 * idx[i], 3 * sizeof(float));
     }
     return CHISEL_HIP_OK;
 }

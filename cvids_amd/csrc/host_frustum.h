@@ -55,16 +55,9 @@ struct FrustumRange {
     float corners[24];
 };
 
-// pose: row-major 3x4 camera->world
-inline FrustumRange frustum_range(const float *pose, float nearDist, float farDist, float fy, float cy, int W, int H,
-                                  int chunk_n, float res) {
-    const f3 rightVec = mk(pose[0], pose[4], pose[8]);
-    const f3 up = mk(-pose[1], -pose[5], -pose[9]);
-    const f3 forward = mk(pose[2], pose[6], pose[10]);
-    const f3 pos = mk(pose[3], pose[7], pose[11]);
-    const float imgWidth = (float)W, imgHeight = (float)H;
-    const float aspect = (fy * imgWidth) / (fy * imgHeight);
-    const float fov = (float)(::atan2((double)cy, (double)fy) + ::atan2((double)(imgHeight - cy), (double)fy));
+// Frustum::SetFromVectors (Frustum.cpp:155-219): corners (Frustum::GetCorners' order) and the six planes (far, near, top, bottom, left, right)
+inline void frustum_from_vectors(const f3 &forward, const f3 &pos, const f3 &rightVec, const f3 &up, float nearDist, float farDist, float fov, float aspect,
+                                 float planes[24], float corners_out[24]) {
     const float angleTangent = (float)::tan((double)(fov / 2));
     const float heightFar = angleTangent * farDist;
     const float widthFar = heightFar * aspect;
@@ -88,21 +81,36 @@ inline FrustumRange frustum_range(const float *pose, float nearDist, float farDi
         plane_from_points(nearBotRight, farBotLeft, nearBotLeft),     // bottom
         plane_from_points(farTopLeft, nearTopLeft, farBotLeft),       // left
         plane_from_points(nearTopRight, farTopRight, nearBotRight)};  // right
-    FrustumRange out;
     for (int i = 0; i < 6; i++) {
-        out.planes[4 * i] = pl[i].n.v[0];
-        out.planes[4 * i + 1] = pl[i].n.v[1];
-        out.planes[4 * i + 2] = pl[i].n.v[2];
-        out.planes[4 * i + 3] = pl[i].d;
+        planes[4 * i] = pl[i].n.v[0];
+        planes[4 * i + 1] = pl[i].n.v[1];
+        planes[4 * i + 2] = pl[i].n.v[2];
+        planes[4 * i + 3] = pl[i].d;
     }
     const f3 corners[8] = {farTopLeft, farTopRight, farBotLeft, farBotRight, nearBotRight, nearTopLeft, nearTopRight, nearBotLeft};
+    for (int i = 0; i < 8; i++)
+        for (int k = 0; k < 3; k++) corners_out[3 * i + k] = corners[i].v[k];
+}
+
+// pose: row-major 3x4 camera->world.  Frustum::SetFromParams (Frustum.cpp:143-153: cx unused; PinholeCamera::SetupFrustum passes fy twice)
+inline FrustumRange frustum_range(const float *pose, float nearDist, float farDist, float fy, float cy, int W, int H,
+                                  int chunk_n, float res) {
+    const f3 rightVec = mk(pose[0], pose[4], pose[8]);
+    const f3 up = mk(-pose[1], -pose[5], -pose[9]);
+    const f3 forward = mk(pose[2], pose[6], pose[10]);
+    const f3 pos = mk(pose[3], pose[7], pose[11]);
+    const float imgWidth = (float)W, imgHeight = (float)H;
+    const float aspect = (fy * imgWidth) / (fy * imgHeight);
+    const float fov = (float)(::atan2((double)cy, (double)fy) + ::atan2((double)(imgHeight - cy), (double)fy));
+    FrustumRange out;
+    frustum_from_vectors(forward, pos, rightVec, up, nearDist, farDist, fov, aspect, out.planes, out.corners);
     float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
     float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
     for (int i = 0; i < 8; i++)
         for (int k = 0; k < 3; k++) {
-            out.corners[3 * i + k] = corners[i].v[k];
-            mn[k] = corners[i].v[k] < mn[k] ? corners[i].v[k] : mn[k];
-            mx[k] = corners[i].v[k] > mx[k] ? corners[i].v[k] : mx[k];
+            const float c = out.corners[3 * i + k];
+            mn[k] = c < mn[k] ? c : mn[k];
+            mx[k] = c > mx[k] ? c : mx[k];
         }
     const float roundingFactor = 1.0f / ((float)chunk_n * res);
     for (int k = 0; k < 3; k++) {

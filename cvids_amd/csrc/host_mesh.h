@@ -97,7 +97,7 @@ int collect_mesh_ids(chisel_hip_map *m, const std::vector<int> &extra) {
         if (rc) return rc;
         int *d_slots = nullptr;
         HIP_TRY(hipMalloc(&d_slots, (size_t)ne * sizeof(int)));
-        HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), (size_t)ne * sizeof(int), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpy(d_slots, slots.data(), (size_t)ne * sizeof(int), hipMemcpyHostToDevice));  // (pageable source, rare path: a blocking copy; lookup_slots has waited for the stream already)
         hipLaunchKernelGGL(mesh_append_kernel, dim3((ne + 255) / 256), dim3(256), 0, m->stream, m->view, B.flags, (const int *)d_slots, ne, m->view.mesh_jobs, n_jobs);
         HIP_TRY(hipStreamSynchronize(m->stream));
         HIP_TRY(hipFree(d_slots));
@@ -319,7 +319,10 @@ int check_mesh_totals(chisel_hip_map *m) {
             HIP_TRY(zero_mesh_counters(m));
             // (the kept job list's counter has been emptied by the first emission; its entries are untouched -- nothing has integrated since --
             // and their number is in the totals)
-            if (B.n_jobs) HIP_TRY(hipMemcpyAsync(B.n_jobs, &n_again, sizeof(int), hipMemcpyHostToDevice, m->stream));
+            if (B.n_jobs) {
+                m->mesh_totals_host[8] = n_again;  // (page-locked: an asynchronous copy must not read a local of this function)
+                HIP_TRY(hipMemcpyAsync(B.n_jobs, &m->mesh_totals_host[8], sizeof(int), hipMemcpyHostToDevice, m->stream));
+            }
             launch_mesh_count(m);
             if (B.n_jobs) HIP_TRY(hipMemsetAsync(B.n_jobs, 0, sizeof(int), m->stream));
             HIP_TRY(hipMemcpyAsync(totals, d_totals, 4 * sizeof(int), hipMemcpyDeviceToHost, m->stream));

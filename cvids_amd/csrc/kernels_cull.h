@@ -774,13 +774,22 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
                 // hash lookup (ChunkManager::HasChunk ChunkManager.h:79-82)
                 const uint64_t key = pack_id(cx, cy, cz);
                 const uint64_t h0 = chunk_hash(cx, cy, cz), h = h0 & M.hash_mask;
-                for (uint64_t i = 0; i <= M.hash_mask; i++) {
-                    const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
-                    if (kk == key) {
-                        slot = M.hash_vals[(h + i) & M.hash_mask];
-                        break;
+                // (the home bucket's value is requested with its key: most probes end there, and the wave waits once instead of twice)
+                {
+                    const uint64_t k0 = M.hash_keys[h];
+                    const int v0 = M.hash_vals[h];
+                    if (k0 == key) {
+                        slot = v0;
+                    } else if (k0 != KEY_EMPTY) {
+                        for (uint64_t i = 1; i <= M.hash_mask; i++) {
+                            const uint64_t kk = M.hash_keys[(h + i) & M.hash_mask];
+                            if (kk == key) {
+                                slot = M.hash_vals[(h + i) & M.hash_mask];
+                                break;
+                            }
+                            if (kk == KEY_EMPTY) break;
+                        }
                     }
-                    if (kk == KEY_EMPTY) break;
                 }
                 // While the batches before this one are being integrated a key can already be visible whose slot value is not (create_chunk
                 // writes key, then value, then slot_key[slot]): a lookup result that does not check out against slot_key only counts for
@@ -789,7 +798,9 @@ __global__ __launch_bounds__((64 * CullGeom<KL, WV>::WAVES)) void cull_kernel(Cu
                 // "uncertain" for as long as it stayed in view (an uncertain item has no slot here, so it went into this batch's pending
                 // set and was uncertain again for the next two: most items of a steady stream were looked up again by every one of their
                 // units in the integration kernel, 4 us of dependent round trips at the head of each).
-                const bool verified = !forced && slot >= 0 && slot < M.max_chunks && M.slot_key[slot] == key;
+                // (nothing in flight -- the short form: no pending sets --: the map is at rest and every value read is final, no third round trip)
+                const bool at_rest = !forced && !prev_pending && !prev2_pending;
+                const bool verified = !forced && slot >= 0 && slot < M.max_chunks && (at_rest || M.slot_key[slot] == key);
                 if (!verified && slot >= 0) slot = -1;
                 const bool uncertain = !verified && (all_uncertain || (prev_pending && pending_contains(prev_pending, key, h0)) ||
                                                      (prev2_pending && pending_contains(prev2_pending, key, h0)));

@@ -111,6 +111,11 @@ struct MatT {
     float &operator()(int r, int c) { return m[N * r + c]; }
     const float &operator()(int r, int c) const { return m[N * r + c]; }
     static MatT Identity() { return MatT(); }
+    static MatT Zero() {
+        MatT z;
+        for (int i = 0; i < N * N; i++) z.m[i] = 0.0f;
+        return z;
+    }
 };
 struct Matrix3f : MatT<3> {
     Matrix3f inverse() const {  // cofactors over the determinant

@@ -123,6 +123,44 @@ int main() {
         Frustum fr;
         cam.SetupFrustum(T, &fr);
         CHECK(fr.Contains(Vec3(0.0f, 0.0f, 1.0f)) == fr.Contains(Vec3(0.0f, 0.0f, 1.0f)));
+        {
+            // Frustum::SetFromVectors on the vectors SetFromParams derives (Frustum.cpp:143-153) is the same frustum; and
+            // SetFromOpenGLViewProjection (:124-141) of a view / projection pair that encodes them
+            const Mat3x3 R = T.linear();
+            const float fy = cam.GetIntrinsics().GetFy(), cyp = cam.GetIntrinsics().GetCy(), W = (float)cam.GetWidth(), H = (float)cam.GetHeight();
+            const float aspect = (fy * W) / (fy * H), fov = (float)(std::atan2((double)cyp, (double)fy) + std::atan2((double)(H - cyp), (double)fy));
+            Frustum fv;
+            fv.SetFromVectors(Vec3(R(0, 2), R(1, 2), R(2, 2)), T.translation(), Vec3(R(0, 0), R(1, 0), R(2, 0)), Vec3(-R(0, 1), -R(1, 1), -R(2, 1)),
+                              cam.GetNearPlane(), cam.GetFarPlane(), fov, aspect);
+            for (int i = 0; i < 8; i++) CHECK(fv.GetCorners()[i] == fr.GetCorners()[i]);
+            for (int i = 0; i < 24; i++) CHECK(fv.GetLines()[i] == fr.GetLines()[i]);
+            CHECK(fv.GetFarPlane().distance == fr.GetFarPlane().distance && fv.GetLeftPlane().normal == fr.GetLeftPlane().normal);
+            Mat4x4 view = Mat4x4::Zero(), proj = Mat4x4::Zero();
+            for (int k = 0; k < 3; k++) {
+                view(0, k) = R(k, 0);
+                view(1, k) = -R(k, 1);
+                view(2, k) = -R(k, 2);
+                view(k, 3) = T.translation()(k);
+            }
+            view(3, 3) = 1.0f;
+            const float nearD = 0.5f, farD = 4.0f, kk = farD / nearD;
+            proj(1, 1) = 1.0f / std::tan(0.5f * fov);
+            proj(0, 0) = proj(1, 1) / aspect;
+            proj(2, 2) = (1.0f + kk) / (1.0f - kk);     // (cc - 1) / (cc + 1) = kk
+            proj(2, 3) = 2.0f * kk * nearD / (1.0f - kk);  // dd (1 - kk) / (2 kk) = n
+            Frustum fo;
+            fo.SetFromOpenGLViewProjection(view, proj);
+            // (what :124-141 derive from the two matrices, handed to SetFromVectors directly: the same frustum bit for bit; and its far
+            // plane's corners lie farD in front of the camera, up to the rounding of the matrix entries)
+            const float bb = proj(1, 1), cc = proj(2, 2), dd = proj(2, 3), k2 = (cc - 1.0f) / (cc + 1.0f), n2 = (dd * (1.0f - k2)) / (2.0f * k2);
+            Frustum fe;
+            fe.SetFromVectors(Vec3(R(0, 2), R(1, 2), R(2, 2)), T.translation(), Vec3(R(0, 0), R(1, 0), R(2, 0)), Vec3(-R(0, 1), -R(1, 1), -R(2, 1)), n2, k2 * n2,
+                              (float)(2.0f * std::atan((double)(1.0f / bb))), bb / proj(0, 0));
+            for (int i = 0; i < 8; i++) CHECK(fo.GetCorners()[i] == fe.GetCorners()[i]);
+            CHECK(fo.GetNearPlane().distance == fe.GetNearPlane().distance && fo.GetTopPlane().normal == fe.GetTopPlane().normal);
+            const Vec3 far_centre = (fo.GetCorners()[0] + fo.GetCorners()[1] + fo.GetCorners()[2] + fo.GetCorners()[3]) * 0.25f;
+            CHECK((far_centre - T * Vec3(0.0f, 0.0f, farD)).norm() < 1e-3f);
+        }
         ChunkIDList ids;
         cm.GetChunkIDsIntersecting(fr, &ids);
         AABB box;

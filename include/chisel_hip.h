@@ -338,6 +338,10 @@ int chisel_hip_create_group(const chisel_hip_config *cfg, const int *device_ids,
  * Any of the three outputs may be NULL. */
 int chisel_hip_frustum(const float pose_c2w[12], float fy, float cy, int width, int height, float near_plane, float far_plane,
                        float *corners, float *lines, float *planes);
+/* Frustum::SetFromVectors (src/geometry/Frustum.cpp:155-219) itself, for a caller that has its own view vectors (what
+ * Frustum::SetFromOpenGLViewProjection, :124-141, ends in): same outputs, same fp32 operation order. */
+int chisel_hip_frustum_from_vectors(const float forward[3], const float pos[3], const float right[3], const float up[3], float near_plane,
+                                    float far_plane, float fov, float aspect, float *corners, float *lines, float *planes);
 
 /* ---- meshing a sharded map with shells -----------------------------------------------------------------
  * What a chunk's mesh reads of a neighbour chunk is a shell one or two voxels thick (cube corners, gradients around the vertices, the

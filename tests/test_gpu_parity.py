@@ -297,6 +297,16 @@ def test_meshes_to_update_kept_incrementally(oracle_mod):
             for v in victims:
                 om.remove_chunk(v)
             step()
+        if k == 6:
+            # a listing prefetched behind the integration, then something ELSE dirties chunks before the caller reads the set (the facade's
+            # order IntegrateDepthScan, IntegratePointCloud, GetMeshesToUpdate): the prefetched listing is stale and must not be served
+            gm.PrefetchMeshesToUpdate(cursor)
+            gm.synchronize()
+            pose = synth.trajectory_pose(40)
+            pts = synth.depth_to_cloud(synth.render_depth("sphere_room", pose, synth.intrinsics(32, 24), 32, 24), synth.intrinsics(32, 24), 0.6)
+            om.integrate_pointcloud(pts, pose, None, 0.1, 5.0)
+            gm.IntegratePointCloud(integ, (pts, None), pose, 0.1, 5.0)
+            step()
         if k == 8:
             gm.UpdateMeshes(force=True)
             om.update_meshes()

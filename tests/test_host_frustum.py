@@ -80,3 +80,31 @@ def test_candidates_export_equals_the_oracles_enumeration(hip_lib, oracle_mod):
             assert hip_lib.chisel_hip_candidates(fp(corners), fp(planes), ip(cs), res, ip(ids), n.value, C.byref(n)) == 0
             want = om.candidates(pose, intr, W, H, near, far)
             assert np.array_equal(ids, want), (W, H, N, len(ids), len(want))
+
+
+def test_frustum_from_vectors_equals_set_from_params(hip_lib):
+    """Frustum::SetFromParams is SetFromVectors on the vectors it derives from the pose (Frustum.cpp:143-153): the export of the latter
+    (chisel_hip_frustum_from_vectors, what the facade's Frustum::SetFromVectors / SetFromOpenGLViewProjection call) reproduces the former
+    bit for bit."""
+    import ctypes as C
+    import math
+    f32 = C.c_float
+    hip_lib.chisel_hip_frustum_from_vectors.argtypes = [C.POINTER(f32)] * 4 + [f32] * 4 + [C.POINTER(f32)] * 3
+    hip_lib.chisel_hip_frustum.argtypes = [C.POINTER(f32), f32, f32, C.c_int, C.c_int, f32, f32] + [C.POINTER(f32)] * 3
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        a = rng.normal(size=(3, 3))
+        q, _r = np.linalg.qr(a)
+        pose = np.zeros((3, 4), np.float32)
+        pose[:, :3] = q.astype(np.float32)
+        pose[:, 3] = rng.uniform(-3, 3, 3).astype(np.float32)
+        W, H, fy, cy, near, far = 640, 480, np.float32(525.0), np.float32(239.5), np.float32(0.05), np.float32(5.0)
+        c0, l0, p0 = (f32 * 24)(), (f32 * 72)(), (f32 * 24)()
+        flat = (f32 * 12)(*pose.reshape(-1).tolist())
+        assert hip_lib.chisel_hip_frustum(flat, fy, cy, W, H, near, far, c0, l0, p0) == 0
+        vec = lambda v: (f32 * 3)(*[float(x) for x in v])
+        aspect = np.float32(np.float32(fy * np.float32(W)) / np.float32(fy * np.float32(H)))
+        fov = np.float32(math.atan2(float(cy), float(fy)) + math.atan2(float(np.float32(H) - cy), float(fy)))
+        c1, l1, p1 = (f32 * 24)(), (f32 * 72)(), (f32 * 24)()
+        assert hip_lib.chisel_hip_frustum_from_vectors(vec(pose[:, 2]), vec(pose[:, 3]), vec(pose[:, 0]), vec(-pose[:, 1]), near, far, fov, aspect, c1, l1, p1) == 0
+        assert bytes(c0) == bytes(c1) and bytes(l0) == bytes(l1) and bytes(p0) == bytes(p1)
