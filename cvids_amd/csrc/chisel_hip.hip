@@ -244,6 +244,7 @@ struct chisel_hip_map {
         int persistent_grid = 0;                // CHISEL_HIP_PERSISTENT=n: a resident grid of n workgroups per SIMD (1 = the build's INTEGRATE_BLOCKS_PER_CU) pulling units from the queue heads
         bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
         bool always_wait_packet = false;
+        bool bricks_for_one_frame = false;      // CHISEL_HIP_BRICKS_K1=1 (A/B hook): one-frame launch sets of the short form run brick_kernel too (a caller that waits after every frame: 48.7 / 53.6 us per frame with, 50.3 / 48.8 without)
         int front_poll_after_publish_us = 18;   // CHISEL_HIP_FRONT_POLL_US: how long after a recompute's triangle kernel has started the host keeps looking for the front half's end before it queues a wait packet (launch_back)
         bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: on        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
     } tune;
@@ -785,7 +786,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     const bool inline_resolve = front == m->stream;
     bool front_recorded = false;
     bool narrow_cull_set = false;  // this launch's frames look at different parts of the space (decided where the cull kernel is launched)
-    const bool skip_bricks = IP.n_frames == 1 && !m->refine_off;  // a one-frame launch: the cull kernel fills the brick masks itself (4 us of launch + 9 of kernel for 4 us of integration)
+    const bool skip_bricks = IP.n_frames == 1 && !m->refine_off && !(inline_resolve && m->tune.bricks_for_one_frame);
     {
     RoctxRange front_range("chisel_hip front half: pyramid, cull, bricks");
     {
@@ -1442,6 +1443,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     m->tune.ext_events = true;
     if (const char *e = getenv("CHISEL_HIP_EXT_EVENTS")) m->tune.ext_events = atoi(e) != 0;
     if (const char *e = getenv("CHISEL_HIP_FRONT_POLL_US")) m->tune.front_poll_after_publish_us = atoi(e);
+    if (const char *e = getenv("CHISEL_HIP_BRICKS_K1")) m->tune.bricks_for_one_frame = atoi(e) != 0;
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
         const int one = 1;
