@@ -206,7 +206,9 @@ struct chisel_hip_map {
         ItemSync *sync = nullptr;        // [items_capacity]: chunk-level state of the work items while the integration kernel runs
         uint64_t *pending = nullptr;     // chunks this batch may create: one of pending_ring (assigned per batch)
         hipStream_t front_stream = nullptr;  // where this batch's front half runs: aux, or the map's stream when nothing is in flight
-        hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's work-list (and with it its pending set) is complete
+        hipEvent_t front_done = nullptr;  // recorded on the front stream after the set's front half (work-list, brick masks) is complete
+        hipEvent_t cull_done = nullptr;   // ... and after its cull kernel: the set's pending set is complete (what the NEXT batch's cull kernel waits for: it need not
+                                          // wait for this batch's brick kernel too -- one rank of eight on the 4-agent stream 253 -> 28x k frames/s)
         // what launch_back needs to launch the set's integration again (a set queued behind a recompute that then did not fit: deferred_set)
         IntegrateParams replay_ip;
         bool replay_color = false, replay_inline = false;
@@ -633,9 +635,9 @@ bool mesh_totals_published(const chisel_hip_map *m);  // host_mesh.h
 // few microseconds itself in the rare case that it got here first.
 int wait_for_front_of(chisel_hip_map *m, chisel_hip_map::BatchSet &ps, hipStream_t stream) {
     if (ps.front_inline) return stream == m->stream ? CHISEL_HIP_OK : wait_integrate(m, ps.lseq, false);
-    if (!m->tune.always_wait_packet && hipEventQuery(ps.front_done) == hipSuccess) return CHISEL_HIP_OK;
+    if (!m->tune.always_wait_packet && hipEventQuery(ps.cull_done) == hipSuccess) return CHISEL_HIP_OK;
     (void)hipGetLastError();  // (hipErrorNotReady is not an error)
-    HIP_TRY(hipStreamWaitEvent(stream, ps.front_done, 0));
+    HIP_TRY(hipStreamWaitEvent(stream, ps.cull_done, 0));
     return CHISEL_HIP_OK;
 }
 // The back half of a launch set: the integration kernel on the map's stream.  replay: the launch again, for a set whose first launch
@@ -842,9 +844,19 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         }
         const int *force_flag = m->force_uncertain ? m->sets[0].cand_count + COUNT_ONE : nullptr;
         front_recorded = false;
+        // (pipelined form: the cull kernel's completion is the set's cull_done event -- what the next batch's cull kernel waits for)
+        const bool cull_recorded = m->tune.ext_events && !m->profiling && !bs.staged && !inline_resolve;
 #define CHISEL_LAUNCH_CULL_W(KLV, WV)                                                                                                          \
-    hipLaunchKernelGGL((cull_kernel<N, KLV, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, bs.items, bs.boxes, bs.cand_count, \
-                       m->items_capacity, m->view, prev_pending, prev2_pending, force_flag, bs.pending, bs.sync, cull_contig, skip_bricks ? bs.brick_masks : nullptr)
+    do {                                                                                                                                       \
+        if (cull_recorded)                                                                                                                     \
+            hipExtLaunchKernelGGL((cull_kernel<N, KLV, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, nullptr, bs.cull_done, 0, CP, pyr, bs.items, \
+                                  bs.boxes, bs.cand_count, m->items_capacity, m->view, prev_pending, prev2_pending, force_flag, bs.pending, bs.sync, \
+                                  cull_contig, skip_bricks ? bs.brick_masks : nullptr);                                                        \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((cull_kernel<N, KLV, WV>), cgrid, dim3(64 * CullGeom<KLV, WV>::WAVES), 0, front, CP, pyr, bs.items, bs.boxes, bs.cand_count, \
+                               m->items_capacity, m->view, prev_pending, prev2_pending, force_flag, bs.pending, bs.sync, cull_contig,        \
+                               skip_bricks ? bs.brick_masks : nullptr);                                                                       \
+    } while (0)
 #define CHISEL_LAUNCH_CULL(KLV) do { if (narrow_cull && cull_one_wave) CHISEL_LAUNCH_CULL_W(KLV, 1); else if (narrow_cull) CHISEL_LAUNCH_CULL_W(KLV, 4); else CHISEL_LAUNCH_CULL_W(KLV, 16); } while (0)
         if (IP.n_frames <= 1) CHISEL_LAUNCH_CULL_W(1, 16);
         else if (IP.n_frames <= 2) CHISEL_LAUNCH_CULL_W(2, 16);
@@ -856,6 +868,7 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
         m->launch_stats[5]++;
         narrow_cull_set = narrow_cull;
     }
+    if (!inline_resolve && !(m->tune.ext_events && !m->profiling && !bs.staged)) HIP_TRY(hipEventRecord(bs.cull_done, front));  // the set's pending set is complete (wait_for_front_of)
     if (!skip_bricks) {
         // per work item: which frames can touch which of its bricks (the cull test again at the scale of what a wave of the integration kernel
         // owns, kernels_cull.h).  One wave per item; their number is only known on the device: a persistent grid sized from a recent launch.
@@ -1412,6 +1425,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     const unsigned set_event_flags = hipEventDisableTiming | ((ev_fence && !strcmp(ev_fence, "system")) ? 0u : (unsigned)hipEventDisableSystemFence);
     for (auto &bs : m->sets) {
         HIP_TRY_C(hipEventCreateWithFlags(&bs.front_done, set_event_flags));
+        HIP_TRY_C(hipEventCreateWithFlags(&bs.cull_done, set_event_flags));
         HIP_TRY_C(hipMalloc(&bs.cand_count, COUNT_INTS * sizeof(int)));
         HIP_TRY_C(hipMemsetAsync(bs.cand_count, 0, COUNT_INTS * sizeof(int), m->own_stream));
     }
@@ -1564,6 +1578,7 @@ int chisel_hip_destroy(chisel_hip_map *m) {
         for (void *p : bp)
             if (p) (void)hipFree(p);
         if (bs.front_done) (void)hipEventDestroy(bs.front_done);
+        if (bs.cull_done) (void)hipEventDestroy(bs.cull_done);
     }
     for (auto &pr : m->pending_ring)
         if (pr) (void)hipFree(pr);
