@@ -96,7 +96,7 @@ def parse():
     ap.add_argument("--no-e2e-leg", action="store_true", help="skip the end-to-end pass (per-frame depth AND colour from page-locked host buffers, `e2e`, 1 GPU only)")
     args = ap.parse_args()
     given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
-    preset = {2: {"res": 0.02, "no_color": True, "mesh_every": 0},
+    preset = {2: {"res": 0.02, "no_color": True, "mesh_every": 0, "batch": 16},  # (16 frames per call: at 2 cm a launch is as long as its frames' chain, the front half per launch the rest)
               3: {},
               4: {"agents": 4},
               5: {"width": 1280, "height": 720, "res": 0.005, "mesh_every": 0, "batch": 16, "max_chunks": 1 << 18}}[args.config]

@@ -368,6 +368,8 @@ def test_growing_pool_integrates_past_its_first_size(oracle_mod):
     """max_chunks < 0: a pool that starts small and grows like the reference's map of heap chunks (ChunkManager.h:40-55): a stream that needs
     many times the first commitment integrates bit for bit like the oracle, without CHISEL_HIP_ERR_POOL_FULL, in launch sets of several
     frames queued back to back (the growth is decided from lagging reports) and with a reset in between (the grown pool stays)."""
+    if os.environ.get("CHISEL_HIP_GROW") == "0":
+        pytest.skip("CHISEL_HIP_GROW=0: every pool keeps its first size (tools/stress_hooks.sh runs the suite under it)")
     om, gm, integ = _mk(oracle_mod, 16, 0.02, True, max_chunks=-16)  # (commits whole 2 MiB pages: 128 chunks of 16^3 to begin with)
     info0 = gm.pool_info()
     assert info0["growable"] and info0["limit"] > info0["committed"] >= 16
