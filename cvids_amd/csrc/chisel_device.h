@@ -219,7 +219,7 @@ struct PyramidParams {
 };
 
 // A candidate (written by cull_kernel: geometry only, the map is not consulted) and a work item (written by
-// resolve_kernel: the candidates that can change the map, with their pool slot) share this layout.
+// its first wave's look-up: the candidates that can change the map, with their pool slot) share this layout.
 struct WorkItem {
     int x, y, z;             // chunk id
     int slot;                // pool slot, -1 = not resident (allocated if any voxel is integrated); candidates: -1;
@@ -235,17 +235,7 @@ constexpr int SLOT_LOOKUP = -2;
 constexpr unsigned PENDING_CAPACITY = 1u << 14;
 struct FrameBox {            // one per (candidate, frame): the cull kernel's verdict (WI_* flags; 0 = the frame cannot touch the chunk).
     int flags;               // (Until round 3 also the chunk's pixel box and camera-z bounds, which the integration kernel staged and
-};                           // pre-tested with; since round 4 its units read CellRec -- cell masks -- and the box went.)
-// What a unit (wave) of the integration kernel needs to know about one (work item, frame) pair, in work-list order (written by
-// refine_kernel, kernels_cull.h): which of the chunk's 4 x 4 x 4 CELLS (N/4 voxels on a side; bit (cz * 4 + cy) * 4 + cx) hold a voxel that
-// the frame may integrate or carve-test -- the cull kernel's conservative test repeated at cell scale, where the depth range under
-// the (much smaller) pixel box is tight -- and the cull kernel's flags for the chunk.  A unit visits a frame only if one of its own
-// cells is set, and a lane fetches a pixel record only if its own cell is.
-struct alignas(16) CellRec {
-    unsigned long long need;
-    int flags;
-    int pad;
-};
+};                           // pre-tested with; since round 4 its units read need masks -- per cell, since round 6 per brick: brick_kernel -- and the box went.)
 constexpr int WI_INBAND = 1;   // some voxel may take the in-band branch
 constexpr int WI_CARVE = 2;    // some voxel may take the carve test (only matters while the chunk is resident)
 constexpr int WI_TILE = 4;     // u0..v1 is a valid bounding box (else: gather from the whole image)

@@ -187,7 +187,7 @@ struct chisel_hip_map {
     chisel_hip_integrator integ{CHISEL_HIP_TRUNC_INVERSE, 8.0f, 1.0f, 1, 0.05f};  // ChiselNode.cpp:54-64 defaults
     // A batch (up to KMAX frames) is handled by one launch set in two halves:
     //   front (auxiliary stream): host->device staging, depth_pyramid_kernel, cull_kernel (these read the frames only),
-    //         resolve_kernel (reads the chunk hash; tolerates the previous batch's insertions, see kernels_cull.h)
+    //         (which also reads the chunk hash; it tolerates the previous batches' insertions, see kernels_cull.h), brick_kernel
     //   back  (the map's stream): integrate_kernel
     // The fronts of batches b+1 and b+2 run while the back of batch b is still executing -- on two auxiliary streams, so that
     // consecutive fronts overlap each other too (each is a chain of four short kernels: one stream runs them at half the rate the
@@ -247,6 +247,7 @@ struct chisel_hip_map {
         bool no_zero_copy = false;              // CHISEL_HIP_NO_ZERO_COPY: page-locked host frames are copied like pageable ones
         bool always_wait_packet = false;
         bool bricks_for_one_frame = false;      // CHISEL_HIP_BRICKS_K1=1 (A/B hook): one-frame launch sets of the short form run brick_kernel too (a caller that waits after every frame: 48.7 / 53.6 us per frame with, 50.3 / 48.8 without)
+        int mesh_stage_mask = 3;                // CHISEL_HIP_MESH_STAGES=0..3 (timing diagnostic, wrong normals / colours): which of ComputeNormalsFromGradients (1) and ColorizeMesh (2) the triangle kernel runs
         int front_poll_after_publish_us = 18;   // CHISEL_HIP_FRONT_POLL_US: how long after a recompute's triangle kernel has started the host keeps looking for the front half's end before it queues a wait packet (launch_back)
         bool ext_events = false;                // CHISEL_HIP_EXT_EVENTS=0|1: a set's events ride on its last kernels (hipExtLaunchKernelGGL's stop event) instead of separate records; default: on        // CHISEL_HIP_ALWAYS_WAIT_PACKET: no event query before a stream wait
     } tune;
@@ -1458,6 +1459,7 @@ int chisel_hip_create(const chisel_hip_config *cfg, chisel_hip_map **out) {
     if (const char *e = getenv("CHISEL_HIP_EXT_EVENTS")) m->tune.ext_events = atoi(e) != 0;
     if (const char *e = getenv("CHISEL_HIP_FRONT_POLL_US")) m->tune.front_poll_after_publish_us = atoi(e);
     if (const char *e = getenv("CHISEL_HIP_BRICKS_K1")) m->tune.bricks_for_one_frame = atoi(e) != 0;
+    if (const char *e = getenv("CHISEL_HIP_MESH_STAGES")) m->tune.mesh_stage_mask = atoi(e) & 3;
     m->force_pipeline = m->force_uncertain || getenv("CHISEL_HIP_FORCE_PIPELINE") != nullptr;
     {
         const int one = 1;

@@ -13,7 +13,7 @@ MeshParams mesh_params(const chisel_hip_map *m) {
     P.rf_chunk = 1.0f / ((float)m->N * m->cfg.voxel_resolution);    // ChunkManager.h:138-140
     P.rf_voxel = 1.0f / m->cfg.voxel_resolution;                    // Chunk.cpp:74
     P.use_color = m->cfg.use_color ? 1 : 0;
-    P.stages = m->mesh_stages;
+    P.stages = m->mesh_stages & m->tune.mesh_stage_mask;
     return P;
 }
 

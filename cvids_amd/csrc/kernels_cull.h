@@ -14,12 +14,14 @@
 //                          prefix popcount (one atomic per wave).  Reads the frames only, never the map,
 //                          so it runs (with the pyramid) on the auxiliary stream while the previous
 //                          batch is still being integrated.
-//   resolve_kernel       : one thread per candidate: chunk-hash lookup (ChunkManager::HasChunk), drops the
-//                          candidates that could only carve a chunk that is not resident, compacts the
-//                          rest into the work-list.  Also runs while the previous batch is being
-//                          integrated: the chunks that batch may still create are known (its work items
-//                          without a slot, kept in a small "pending" set), and a candidate found there is
-//                          passed on with slot = SLOT_LOOKUP for the integration kernel to look up itself.
+//                          Since round 6 the first wave of every block also looks its survivors up (ChunkManager::HasChunk),
+//                          drops the candidates that could only carve a chunk that is not resident, and compacts the rest
+//                          straight into the work-list (rounds 2-5: resolve_kernel / order_kernel).  In the pipelined form it runs
+//                          while the previous batch is being integrated: the chunks that batch may still create are known (its
+//                          work items without a slot, kept in a small "pending" set), and a candidate found there is passed on
+//                          with slot = SLOT_LOOKUP for the integration kernel to look up itself.
+//   brick_kernel         : one wave per work item: which frames can touch which 8 x 8 x 4-voxel brick of the chunk (what a wave of
+//                          the integration kernel owns) -> a 16-bit frame mask per brick (rounds 4-5: refine_kernel, per cell)
 //
 // Dropping a (chunk, frame) pair is parity-safe only when no voxel of the chunk can change in that
 // frame: untouched new chunks are erased again by the reference (Chisel.h:202-207) and untouched
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void depth_pyramid_kernel(PyramidParams P, Pyr
     const float max_depth = P.ip.max_depth;
     const int bx = tid & 15, by = tid >> 4;
     const int px0 = blockIdx.x * 64 + bx * 4, py0 = blockIdx.y * 64 + by * 4;
-    {  // consumed by cull_kernel / resolve_kernel (next launches)
+    {  // consumed by cull_kernel / brick_kernel (next launches)
         const unsigned gid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256u + tid;
         const unsigned n_threads = gridDim.x * gridDim.y * gridDim.z * 256u;
         for (unsigned i = gid; i < (unsigned)COUNT_INTS; i += n_threads)
@@ -192,7 +194,7 @@ __device__ inline void truncation_range(int kind, float param, float d0, float d
 
 // min / max of the valid depth over pixel box (u0, v0) .. (u1, v1): the finest pyramid level that covers the box with
 // at most 3 x 3 texels, read as nine unconditional (clamped, possibly repeated) loads so that they are in flight together
-// (T = texels per side, 3 for the chunks of the cull kernel; the cells of refine_kernel take 4: a finer level, a tighter range)
+// (T = texels per side, 3 for the chunks of the cull kernel; the bricks of brick_kernel take 4: a finer level, a tighter range)
 template <int T = 3>
 __device__ inline void pyramid_minmax(const PyramidView &pyr, const float2 *__restrict__ pdata, float2 whole, int u0, int v0, int u1,
                                       int v1, float &dmin, float &dmax) {
@@ -257,7 +259,7 @@ struct CullPre {
     int su0, sv0, su1, sv1;   // pixel box under the bounding sphere (the whole image when the sphere reaches behind the camera)
     float zs0, zs1, slack;    // camera-z interval of the sphere, rounding slack
 };
-// the geometric part for the axis-aligned box of N^3 voxels with index (cx, cy, cz) in units of N voxels: a chunk, or (refine_kernel) a cell
+// the geometric part for the axis-aligned box of N^3 voxels with index (cx, cy, cz) in units of N voxels: a chunk
 template <int N>
 __device__ inline bool box_pre(const IntegratorParams &ip, const CameraParams &C, int cx, int cy, int cz, CullPre &pre);
 template <int N>
@@ -296,43 +298,10 @@ __device__ inline bool box_pre(const IntegratorParams &ip, const CameraParams &C
     pre.zs0 = zs0; pre.zs1 = zs1; pre.slack = slack;
     return true;
 }
-// The same for a CELL of refine_kernel: what has to be bounded are the CENTRES of its voxels -- a box of half-extent h = (E - 1) / 2 voxels
-// around the cell's centre -- and the box is bounded per camera axis (half-extent along camera axis i = h * sum_j |R_ji|: the exact
-// extent of the rotated box; `ar` = those three sums, wave-uniform) instead of by its bounding sphere: at 4 voxels per cell the sphere
-// around the whole cell is 3.5 voxels, this 1.5 to 2.6.
-template <int E>
-__device__ inline bool cell_pre(const IntegratorParams &ip, const CameraParams &C, const float (&ar)[3], int cx, int cy, int cz, CullPre &pre) {
-    const float h = 0.5f * (float)(E - 1) * ip.res;
-    // centre of the voxel centres: ((E c + (E - 1) / 2) + 0.5) res
-    const float wx = ((float)(cx * E) * ip.res + (h + ip.half_res)) - C.t[0], wy = ((float)(cy * E) * ip.res + (h + ip.half_res)) - C.t[1],
-                wz = ((float)(cz * E) * ip.res + (h + ip.half_res)) - C.t[2];
-    const float px = C.R[0] * wx + C.R[3] * wy + C.R[6] * wz;
-    const float py = C.R[1] * wx + C.R[4] * wy + C.R[7] * wz;
-    const float pz = C.R[2] * wx + C.R[5] * wy + C.R[8] * wz;
-    // rounding: the integration kernel builds its camera coordinates from products of magnitude <= |p| + h (a few ulp each), and the
-    // voxel centres themselves carry an ulp or two of (id * res): 1e-4 relative is three orders of magnitude more than that
-    const float slack = 1e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + 3.0f * h) + 1e-6f;
-    const float hx = h * ar[0] * 1.001f + slack, hy = h * ar[1] * 1.001f + slack, hz = h * ar[2] * 1.001f + slack;
-    const float zs1 = pz + hz;
-    if (zs1 < 0.0f) return false;  // every voxel has z < 0 (ProjectionIntegrator.h:68)
-    const float zs0 = pz - hz;
-    pre.su0 = 0; pre.sv0 = 0; pre.su1 = C.W - 1; pre.sv1 = C.H - 1;
-    if (zs0 > 0.25f * ip.res) {
-        const float i0 = __builtin_amdgcn_rcpf(zs0) * 1.00001f, i1 = __builtin_amdgcn_rcpf(zs1) * 0.99999f;
-        const float xl = px - hx, xh = px + hx, yl = py - hy, yh = py + hy;
-        const float ul = C.fx * xl * (xl < 0.0f ? i0 : i1) + C.cx, uh = C.fx * xh * (xh < 0.0f ? i1 : i0) + C.cx;
-        const float vl = C.fy * yl * (yl < 0.0f ? i0 : i1) + C.cy, vh = C.fy * yh * (yh < 0.0f ? i1 : i0) + C.cy;
-        const float fu0 = floorf(ul) - 2.0f, fu1 = floorf(uh) + 2.0f, fv0 = floorf(vl) - 2.0f, fv1 = floorf(vh) + 2.0f;
-        if (fu1 < 0.0f || fv1 < 0.0f || fu0 > (float)(C.W - 1) || fv0 > (float)(C.H - 1)) return false;  // off the image
-        pre.su0 = (int)fmaxf(fu0, 0.0f); pre.sv0 = (int)fmaxf(fv0, 0.0f);
-        pre.su1 = (int)fminf(fu1, (float)(C.W - 1)); pre.sv1 = (int)fminf(fv1, (float)(C.H - 1));
-    }
-    pre.zs0 = zs0; pre.zs1 = zs1; pre.slack = slack;
-    return true;
-}
 // A BRICK of the integration kernel (kernels_integrate.h: a unit = one wave = 8 x 8 x 4 voxels at 4 voxels per lane): the same bound for
 // the centres of its voxels -- a box of half-extents (3.5, 3.5, 1.5) voxels around their centre (vx0, vy0, vz0 = the brick's first voxel,
-// counted from the world origin) --, per camera axis i the exact extent of the rotated box, sum_j |R_ji| h_j.
+// counted from the world origin) --, per camera axis i the exact extent of the rotated box, sum_j |R_ji| h_j (a bounding sphere around the
+// brick would be 5.1 voxels, this 1.5 to 3.5 per axis).
 constexpr int BRICK_X = 8, BRICK_Y = 8, BRICK_Z = 4;
 template <int N>
 struct BrickGrid {
@@ -480,8 +449,6 @@ __device__ inline int cull_post(const IntegratorParams &ip, const CullFrame &F, 
            (inside ? WI_INSIDE : 0);
 }
 
-// The depth test again at the scale of a 4 x 4 x 4-voxel sub-box is the first step of every unit of the integration kernel
-// (kernels_integrate.h; until round 5 refine_kernel here, one wave per (work item, frame), wrote a CellRec per pair).
 #ifndef REFINE_TEXELS
 #define REFINE_TEXELS 4
 #endif
@@ -604,9 +571,6 @@ __device__ inline bool pending_insert(uint64_t *set, uint64_t key, uint64_t h) {
 // anyway), here in blocks of 4 x 4 x 4 ids per wave.  Sharded: only the ids this shard owns -- chunk_owner() is (bx + 3 by + 5 bz) mod n on
 // super-blocks of b^3 chunks, so for each (by, bz) the owned bx are one residue class: slot j of (by, bz) is the j-th owned bx
 // at or after the range's first super-block.  (Before, every shard walked the whole range with n - 1 of n lanes idle.)
-#ifndef RESOLVE_BLOCK
-#define RESOLVE_BLOCK 256   // threads per workgroup of resolve_kernel / order_kernel (they use wave-level primitives only)
-#endif
 constexpr int CULL_BLOCK = 4;
 #ifndef CULL_EARLY_EXIT
 #define CULL_EARLY_EXIT 1
@@ -677,7 +641,6 @@ struct CullSpace {
 
 // One wave per frame of the batch over the same 64 chunk ids (block = 64 * KL threads, KL = frames rounded up to a
 // power of two): every per-frame constant is wave-uniform (scalar loads), the per-frame verdicts meet in LDS.
-// INLINE (the map is idle: nothing to run beside, the caller is waiting): the k == 0 wave also does resolve_kernel's job
 // for its survivors -- hash lookup, frame mask, compaction straight into the work-list -- and one launch set is three
 // kernels on one stream instead of five on two.
 // WV = waves per workgroup at most; a launch of more frames gives each wave several (k, k + WV, ...).  One wave per frame (WV = 16) is

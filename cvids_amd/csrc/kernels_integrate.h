@@ -97,7 +97,7 @@ struct Geom {
     static_assert(QUADS % 64 == 0, "whole waves");
     // A unit is a BRICK of 2 quads x 8 rows x 4 layers (8 x 8 x 4 voxels at 4 per lane, 4 x 8 x 4 at 2): compact in every direction, so
     // that the band shell cuts few of them whatever the viewing direction (a z-layer of 16 x 16 x 1 is cut by every frame that looks
-    // along x or y), and a union of whole cells of the refine kernel's per-cell test (CellRec; cells are N/4 voxels on a side).
+    // along x or y), and the unit of brick_kernel's depth test (kernels_cull.h: BRICK_X / _Y / _Z).
     // Lanes 2i, 2i + 1 hold 2 * VPL * 4 contiguous bytes of one x-row per array.
     static constexpr int BX = 2 * VPL, BY = 8, BZ = 4;
     static constexpr int NBX = N / BX, NBY = N / BY, NBZ = N / BZ;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * INTEGRATE_WPB, (VPL0 == 2 ? INTEGRATE_WAVES2 :
             unsigned bm = 0u, cm = 0u;  // frames in which this wave integrated / changed a voxel (wave-uniform)
             int carve_v = 0;            // lane k: this wave's carve tests of frame k (items without a slot)
 
-            // Frames of the mask: each can touch one of this brick's cells (refine_kernel's conservative test).  A lane whose own cell
+            // Frames of the mask: each can touch this brick (brick_kernel's conservative test).  A lane whose own cell
             // it cannot touch reads the all-NaN record instead of a pixel and fails every test.
             // A frame has two halves.  project(): the lane's voxels in the frame's camera, their pixel records requested -- geometry only,
             // nothing of it depends on the voxels' state.  apply(): verdicts and updates, in frame order.  INTEGRATE_PIPE: the records of

@@ -106,6 +106,9 @@ __device__ inline bool get_sdf(const MapView &M, const MeshParams &P, f3v posf, 
 // ChunkManager::GetSDFAndGradient (ChunkManager.cpp:449-474).  The reference makes the seven GetSDF calls one after
 // the other and gives up at the first failure; here the seven voxel addresses are resolved first and their weights and
 // distances requested together (14 independent loads instead of a chain of 14), then judged in the reference's order.
+#ifndef MESH_GRAD_X3
+#define MESH_GRAD_X3 1  // (round 6: triangle kernel 26.2 -> 24.6 us on the driver's window, 20.9 -> 20.4 on the default)
+#endif
 template <int N>
 __device__ inline bool get_sdf_and_gradient(const MapView &M, const MeshParams &P, f3v pos, int hx, int hy, int hz, const int *nb,
                                             double &dist, f3v &grad) {
@@ -121,6 +124,38 @@ __device__ inline bool get_sdf_and_gradient(const MapView &M, const MeshParams &
     q[6] = sub3(posf, mk3(0, 0, r));
     float w[7], d[7];
     bool ok[7];
+#if MESH_GRAD_X3
+    // The three voxels along x (-x, centre, +x: q[4], q[0], q[1]) are neighbours in memory whenever the reference's own index
+    // arithmetic puts them into one row of one chunk: then ONE 12-byte access per array fetches them (the kernel's time is the
+    // number of scattered lane accesses its gathers make, not their bytes).  The indices are the reference's, computed as before;
+    // only the access is merged.
+    size_t offs[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        f3v origin;
+        const int slot = chunk_at<N>(M, P, q[i], hx, hy, hz, nb, origin);
+        const f3v rel = sub3(q[i], origin);
+        const int cx = (int)floorf(rel.x * P.rf_voxel), cy = (int)floorf(rel.y * P.rf_voxel), cz = (int)floorf(rel.z * P.rf_voxel);
+        const int id = (cz * N + cy) * N + cx;
+        ok[i] = slot >= 0 && id >= 0 && id < N * N * N;  // GetSDF: chunk present, linear voxel id in range (Chunk.h:81-84)
+        offs[i] = ok[i] ? (size_t)slot * (N * N * N) + id : 0;
+    }
+    struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+    const bool row = ok[0] && ok[1] && ok[4] && offs[1] == offs[0] + 1 && offs[4] + 1 == offs[0];
+    if (row) {
+        const F3 w3 = *reinterpret_cast<const F3 *>(M.wgt + offs[4]), d3 = *reinterpret_cast<const F3 *>(M.sdf + offs[4]);
+        w[4] = w3.a; w[0] = w3.b; w[1] = w3.c;
+        d[4] = d3.a; d[0] = d3.b; d[1] = d3.c;
+    } else {
+        w[0] = M.wgt[offs[0]]; d[0] = M.sdf[offs[0]];
+        w[1] = M.wgt[offs[1]]; d[1] = M.sdf[offs[1]];
+        w[4] = M.wgt[offs[4]]; d[4] = M.sdf[offs[4]];
+    }
+    w[2] = M.wgt[offs[2]]; d[2] = M.sdf[offs[2]];
+    w[3] = M.wgt[offs[3]]; d[3] = M.sdf[offs[3]];
+    w[5] = M.wgt[offs[5]]; d[5] = M.sdf[offs[5]];
+    w[6] = M.wgt[offs[6]]; d[6] = M.sdf[offs[6]];
+#else
 #pragma unroll
     for (int i = 0; i < 7; i++) {
         f3v origin;
@@ -133,6 +168,7 @@ __device__ inline bool get_sdf_and_gradient(const MapView &M, const MeshParams &
         w[i] = M.wgt[off];
         d[i] = M.sdf[off];
     }
+#endif
 #pragma unroll
     for (int i = 0; i < 7; i++)
         if (!(ok[i] && (double)w[i] > 1e-12)) return false;
@@ -328,6 +364,9 @@ static_assert(MC_CURSORS == 8 && MESH_PARTS == 64 && MC_KEPT == 4, "kernels_inte
                              // spends 151 registers
 #endif
 constexpr int MESH_TRI_BLOCK = 256;  // per-triangle kernel
+#ifndef MESH_TRI_WAVES
+#define MESH_TRI_WAVES 1  // waves per SIMD the triangle kernel is compiled for (1 = whatever its registers allow: six)
+#endif
 
 // What the host needs to know about a job after a recompute (one 32-byte record, fetched in one copy)
 struct JobInfo {
@@ -673,7 +712,7 @@ template <int N>
 // Housekeeping that rides along (an extra kernel, copy or event on the map's stream would sit on the critical path in front of the
 // next integration): workgroup 0 writes the per-job records into pinned host memory (`host_info`, at most max_jobs of them; the
 // host needs them at the next recompute) and then `seq` into host_flags[6].
-__global__ __launch_bounds__(MESH_TRI_BLOCK) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
+__global__ __launch_bounds__(MESH_TRI_BLOCK, MESH_TRI_WAVES) void mesh_triangle_kernel(MapView M, MeshParams P, const MeshJob *__restrict__ jobs,
                                                                     const JobInfo *__restrict__ info, const TriRec *__restrict__ tris,
                                                                     const CubeCorners *__restrict__ corners, const int *__restrict__ totals,
                                                                     const unsigned *__restrict__ cnt, int part_capacity, float *arena, size_t arena_floats, int *host_info,
