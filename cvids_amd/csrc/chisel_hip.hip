@@ -369,18 +369,21 @@ int sync_all(chisel_hip_map *m) {
 constexpr int PROGRESS_STARTED = 4, PROGRESS_DONE = 5;  // words of the pinned error-flag block (chisel_device.h)
 inline void note_stream_idle(chisel_hip_map *m) { m->complete_seq = m->launch_seq; }  // the host has just waited for the map's stream
 // has integration launch L started / ended?  (pinned words the kernels store into; no runtime call, nothing queued)
+// (launch numbers are compared through their signed difference: a map that lives through 2^32 launches keeps working)
+inline bool seq_le(unsigned a, unsigned b) { return (int)(a - b) <= 0; }
 inline bool integrate_started(chisel_hip_map *m, unsigned L) {
-    if (L <= m->complete_seq) return true;
+    if (seq_le(L, m->complete_seq)) return true;
     volatile int *w = reinterpret_cast<volatile int *>(m->error_flag_host);
     const unsigned started = (unsigned)w[PROGRESS_STARTED], done = (unsigned)w[PROGRESS_DONE];
-    if (started > L && started - 1 > m->complete_seq && started <= m->launch_seq) m->complete_seq = started - 1;
-    if (done > m->complete_seq && done <= m->launch_seq) m->complete_seq = done;
-    return L <= m->complete_seq || started >= L;
+    // (a word counts only if it names a launch of this map that is not already known to be over: they start at zero)
+    if (seq_le(started, m->launch_seq) && !seq_le(started - 1u, m->complete_seq)) m->complete_seq = started - 1u;
+    if (seq_le(done, m->launch_seq) && !seq_le(done, m->complete_seq)) m->complete_seq = done;
+    return seq_le(L, m->complete_seq) || (seq_le(started, m->launch_seq) && seq_le(L, started));
 }
 inline bool integrate_done(chisel_hip_map *m, unsigned L) {
-    if (L <= m->complete_seq) return true;
+    if (seq_le(L, m->complete_seq)) return true;
     (void)integrate_started(m, L);  // (refreshes complete_seq)
-    return L <= m->complete_seq;
+    return seq_le(L, m->complete_seq);
 }
 // The host waits (polling the pinned words) until launch L has started (ended): back-pressure for a caller that runs more than the buffer
 // sets ahead of the device, and the order between an inline front half and the next batch's resolve step.  Everything waited for here has
@@ -469,7 +472,7 @@ int maybe_grow(chisel_hip_map *m, int64_t expect_new) {
     volatile int *w = reinterpret_cast<volatile int *>(m->error_flag_host);
     const int64_t used = w[PROGRESS_USED];
     const unsigned started = (unsigned)w[PROGRESS_STARTED];
-    const int64_t in_flight = (int64_t)(m->launch_seq > started ? m->launch_seq - started : 0) + 1;  // launches whose allocations the report does not hold
+    const int64_t in_flight = (int64_t)((int)(m->launch_seq - started) > 0 ? (int)(m->launch_seq - started) : 0) + 1;  // launches whose allocations the report does not hold
     const int64_t free_est = (int64_t)m->view.committed - used - in_flight * expect_new;
     if (free_est >= (int64_t)m->view.committed / 4 && free_est >= 2 * expect_new) return CHISEL_HIP_OK;
     return grow_pool(m, std::max<int64_t>(2 * (int64_t)m->view.committed, (int64_t)m->view.committed + 4 * in_flight * expect_new));
@@ -746,7 +749,8 @@ int launch_back(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const Integrate
         int *queues = bs.cand_count + COUNT_QUEUE0;
         bool same_cam = color;
         for (int k = 0; k < IP.n_frames; k++) same_cam = same_cam && IP.f[k].same_cam;
-        bs.lseq = ++m->launch_seq;
+        if (++m->launch_seq == 0u) { m->launch_seq = 1u; m->complete_seq = 0u; }  // (0 means "never launched"; the wait in integrate_group for a buffer set's last launch has long passed)
+        bs.lseq = m->launch_seq;
         const int lseq = (int)bs.lseq;
 #define CHISEL_LAUNCH_INTEGRATE(COLOR, SAMECAM, VPL)                                                                                 \
     hipLaunchKernelGGL((integrate_kernel<N, COLOR, SAMECAM, VPL>), dim3(grid), dim3(64 * WPB), 0, m->stream, IP, m->view, m->view_dev, bs.items, \
