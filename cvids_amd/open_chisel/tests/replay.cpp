@@ -230,34 +230,22 @@ class Server {
         colorCamera.cameraModel.SetupFrustum(colorCamera.lastPose, &frustum);
         colorCamera.frustumPublisher.publish(CreateFrustumMarker(frustum));
     }
+    // what the markers take from the library: the frustum's 24 line end points, the pose's translation and rotation, the chunk
+    // boxes' centres (marker types, scales and colours are rviz business with no chisel:: call in them)
     visualization_msgs::Marker CreateFrustumMarker(const chisel::Frustum &frustum) {
         visualization_msgs::Marker marker;
-        marker.type = visualization_msgs::Marker::LINE_LIST;
-        marker.scale.x = marker.scale.y = marker.scale.z = 0.01;
         const chisel::Vec3 *lines = frustum.GetLines();
-        for (int i = 0; i < 24; i++) {
-            const chisel::Vec3 &linePoint = lines[i];
-            geometry_msgs::Point pt;
-            pt.x = linePoint.x();
-            pt.y = linePoint.y();
-            pt.z = linePoint.z();
-            marker.points.push_back(pt);
-        }
+        for (int i = 0; i < 24; i++) marker.points.push_back(point_of(lines[i]));
         return marker;
     }
     // :136-180
     void PublishPose(RosCameraTopic &cam) {
-        chisel::Transform lastPose = cam.lastPose;
         geometry_msgs::PoseStamped pose;
         pose.header.stamp = cam.lastImageTimestamp;
-        pose.pose.position.x = lastPose.translation()(0);
-        pose.pose.position.y = lastPose.translation()(1);
-        pose.pose.position.z = lastPose.translation()(2);
-        chisel::Quaternion quat(lastPose.rotation());
-        pose.pose.orientation.x = quat.x();
-        pose.pose.orientation.y = quat.y();
-        pose.pose.orientation.z = quat.z();
-        pose.pose.orientation.w = quat.w();
+        pose.pose.position = point_of(cam.lastPose.translation());
+        const chisel::Quaternion quat(cam.lastPose.rotation());
+        pose.pose.orientation.x = quat.x(); pose.pose.orientation.y = quat.y();
+        pose.pose.orientation.z = quat.z(); pose.pose.orientation.w = quat.w();
         cam.lastPosePublisher.publish(pose);
     }
     void PublishDepthPose() { PublishPose(depthCamera); }
@@ -267,37 +255,15 @@ class Server {
     void PublishLatestChunkBoxes() {
         const chisel::ChunkManager &chunkManager = chiselMap->GetChunkManager();
         visualization_msgs::Marker marker;
-        marker.type = visualization_msgs::Marker::CUBE_LIST;
         marker.scale.x = chunkManager.GetChunkSize()(0) * chunkManager.GetResolution();
-        marker.scale.y = chunkManager.GetChunkSize()(1) * chunkManager.GetResolution();
-        marker.scale.z = chunkManager.GetChunkSize()(2) * chunkManager.GetResolution();
-        const chisel::ChunkSet &latest = chiselMap->GetMeshesToUpdate();
-        for (const std::pair<const chisel::ChunkID, bool> &id : latest) {
-            if (chunkManager.HasChunk(id.first)) {
-                chisel::AABB aabb = chunkManager.GetChunk(id.first)->ComputeBoundingBox();
-                chisel::Vec3 center = aabb.GetCenter();
-                geometry_msgs::Point pt;
-                pt.x = center.x();
-                pt.y = center.y();
-                pt.z = center.z();
-                marker.points.push_back(pt);
-            }
-        }
+        for (const std::pair<const chisel::ChunkID, bool> &id : chiselMap->GetMeshesToUpdate())
+            if (chunkManager.HasChunk(id.first)) marker.points.push_back(point_of(chunkManager.GetChunk(id.first)->ComputeBoundingBox().GetCenter()));
         latestChunkPublisher.publish(marker);
     }
     void PublishChunkBoxes() {
-        const chisel::ChunkManager &chunkManager = chiselMap->GetChunkManager();
         visualization_msgs::Marker marker;
-        marker.type = visualization_msgs::Marker::CUBE_LIST;
-        for (const std::pair<const chisel::ChunkID, chisel::ChunkPtr> &pair : chunkManager.GetChunks()) {
-            chisel::AABB aabb = pair.second->ComputeBoundingBox();
-            chisel::Vec3 center = aabb.GetCenter();
-            geometry_msgs::Point pt;
-            pt.x = center.x();
-            pt.y = center.y();
-            pt.z = center.z();
-            marker.points.push_back(pt);
-        }
+        for (const std::pair<const chisel::ChunkID, chisel::ChunkPtr> &pair : chiselMap->GetChunkManager().GetChunks())
+            marker.points.push_back(point_of(pair.second->ComputeBoundingBox().GetCenter()));
         chunkBoxPublisher.publish(marker);
     }
     // :607-716: what the mesh markers take from the library -- GetAllMeshes() and, per mesh, grids / vertices / HasColors() ? colors :

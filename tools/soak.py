@@ -1,5 +1,5 @@
 """Soak: a long stream with recomputes, garbage collection, mesh downloads and resets; free device memory and pool state must settle.
-python3 tools/soak.py [frames] [group shards]"""
+python3 tools/soak.py [frames] [group shards] [grow]     grow: the pool starts at 128 chunks and grows on demand (chisel_hip_config.max_chunks < 0)"""
 import os
 import sys
 import time
@@ -10,12 +10,13 @@ from cvids_amd import chisel as ch, synth
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 n_group = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # > 0: an in-library group of that many shards on device 0
+grow = len(sys.argv) > 3 and sys.argv[3] == "grow"
 W, H, N, res = 320, 240, 16, 0.02
 intr = synth.intrinsics(W, H)
 cam = ch.PinholeCamera(*intr, W, H, 0.05, 5.0)
 integ = ch.ProjectionIntegrator(ch.InverseTruncator(2.0), ch.ConstantWeighter(1.0), 0.05, True)
 color = synth.render_color(W, H, 3)
-m = ch.Chisel((N,) * 3, res, True, max_chunks=1 << 14, **({"devices": [0] * n_group} if n_group else {}))
+m = ch.Chisel((N,) * 3, res, True, max_chunks=-128 if grow else 1 << 14, **({"devices": [0] * n_group} if n_group else {}))
 frames = list(synth.stream("sphere_room", 300, W, H, agents=2))
 dev = torch.device("cuda:0")
 free0 = None
@@ -52,4 +53,8 @@ assert abs(drift) < 16.0, "device memory keeps growing"
 # the stream repeats every 600 frames (and the listing the garbage collection picks from is in ascending id order): so do the counts
 for i in range(2, len(log)):
     assert log[i][1] == log[i - 2][1], "chunk counts of identical stretches of the stream differ: %d vs %d after %d frames" % (log[i][1], log[i - 2][1], log[i][0])
+if grow and not n_group:
+    info = m.pool_info()
+    print("pool:", info)
+    assert info["growable"] and info["committed"] > 128 and info["grown"] > 0, "the pool never grew"
 print("soak ok")
