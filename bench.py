@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--mesh-every", type=int, default=None,
                     help="marching-cubes recompute (UpdateMeshes) every M frames inside the timed region; default: 10 at 1 GPU (the "
                          "reference's keyframe cadence, Chisel.cpp:54 -- BASELINE config 3), 0 = off (N > 1: a sharded map is not meshed yet)")
+    ap.add_argument("--blocking-mesh", action="store_true",
+                    help="N > 1: the sharded recompute in its blocking form (the host reads the plan's sizes in the middle of it) instead of the "
+                         "wait-free one (cvids_amd/sharded.py: ShardedChisel._recompute_wait_free)")
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per chisel_hip_integrate_batch call (<= 16 share one launch set); default: the keyframe interval when "
                          "meshing (10 frames = one launch set, the recompute falls exactly on every 10th frame), else 8")
@@ -330,7 +333,7 @@ def main():
     def update_meshes(m, ids=None):
         mesh_stats["recomputes"] += 1
         if world > 1:
-            mesh_stats["ghost_bytes"] += m.sharded.UpdateMeshes(force=True, ids=ids) or 0
+            mesh_stats["ghost_bytes"] += m.sharded.UpdateMeshes(force=True, ids=ids, wait_free=not args.blocking_mesh) or 0
         elif ids is None:
             m.UpdateMeshes(force=True)
         else:
@@ -358,6 +361,8 @@ def main():
             n, fa, ca = calls_ref[0][b]
             if world > 1:
                 m.px.exchange(b, stack[b], meta[b], color_slots)  # RCCL all-gather on the communication stream; the map waits for its event
+            if world > 1:
+                m.sharded.Settle()  # a wait-free recompute in flight: its status (by now on the host) before the map changes again
             rc = L.chisel_hip_integrate_batch(h, n, fa, ca)
             if rc:
                 capi.check(rc)
@@ -367,6 +372,8 @@ def main():
                 update_meshes(m)
         if args.config == 5 and b_hi == len(bounds) and b_hi > b_lo:
             finish_config5(m)
+        if world > 1:
+            m.sharded.Settle()
 
     def fence():
         if world > 1:
@@ -589,6 +596,7 @@ def main():
                "source": "every frame's depth and colour image ((u + k, v, u + v + k) mod 256) copied from page-locked host memory into one of two "
                          "device buffer sets on a copy stream, overlapped with the previous batch's integration (events, no host wait)"}
     sharded_totals = (getattr(m.sharded, "shell_bytes", 0), getattr(m.sharded, "whole_chunk_bytes", 0)) if world > 1 else (0, 0)
+    wait_free_totals = (getattr(m.sharded, "wait_free_recomputes", 0), getattr(m.sharded, "wait_free_aborts", 0), getattr(m.sharded, "wire_bytes", 0), {str(k): v for k, v in getattr(m.sharded, "abort_bits", {}).items()}, getattr(m.sharded, "last_abort_status", None), getattr(m.sharded, "_est", None)) if world > 1 else (0, 0, 0, {}, None, None)
     m.close()
 
     if rank == 0:
@@ -618,7 +626,11 @@ def main():
             out["sharded_meshing"] = {"recomputes": mesh_stats["recomputes"],
                                       "ghost_bytes_per_recompute_rank0": mesh_stats["ghost_bytes"] / max(1, mesh_stats["recomputes"]),
                                       "whole_ghost_chunks_would_be": sharded_totals[1] / max(1, mesh_stats["recomputes"]),
-                                      "shells_over_whole_chunks": sharded_totals[0] / max(1, sharded_totals[1])}
+                                      "shells_over_whole_chunks": sharded_totals[0] / max(1, sharded_totals[1]),
+                                      # (of the last timed pass) recomputes queued without a host wait, how many of them were called off on the
+                                      # device and made again the blocking way, and the fixed-size segments they sent per recompute
+                                      "wait_free": {"recomputes": wait_free_totals[0], "called_off": wait_free_totals[1], "called_off_by_status_bits": wait_free_totals[3], "last_called_off_status": wait_free_totals[4], "sizes_now": wait_free_totals[5],
+                                                    "wire_bytes_per_recompute_rank0": wait_free_totals[2] / max(1, wait_free_totals[0])}}
             if getattr(m.sharded, "phase_us", None):  # CHISEL_HIP_HOST_TIMING=1: rank 0's host time per sharded recompute, by phase
                 n_rc = max(1, m.sharded.phase_us.get("recomputes", 1))
                 out["sharded_meshing"]["host_us_per_recompute_rank0"] = {k: round(v / n_rc, 1) for k, v in m.sharded.phase_us.items() if k != "recomputes"}

@@ -384,6 +384,23 @@ class Chisel:
         check(self.L.chisel_hip_import_shells_packed(self.h, buf.data_ptr() if buf.numel() else None, int(buf.numel())))
         self._packed_keep = getattr(self, "_packed_keep", []) + [buf]
 
+    # ---- ... and its wait-free form (chisel_hip.h: chisel_hip_shell_plan_queue ...): every tensor below stays the caller's until ShellCommit
+    def PlanShellsQueue(self, gathered, world, cap, stride, status):
+        """queues the plan and this rank's status (int32 CUDA tensor of SHELL_STATUS_INTS entries); nothing is waited for"""
+        check(self.L.chisel_hip_shell_plan_queue(self.h, gathered.data_ptr(), int(world), int(cap), int(stride), status.data_ptr()))
+
+    def ExportShellsFixed(self, out, stride):
+        check(self.L.chisel_hip_export_shells_fixed(self.h, out.data_ptr(), int(stride)))
+
+    def ImportShellsFixed(self, buf, stride, status, jobs_hint=0, items_hint=0):
+        """buf: the received segments; status: the ALL-REDUCED status vector (word 0 != 0: nothing below happens on the device)"""
+        check(self.L.chisel_hip_import_shells_fixed(self.h, buf.data_ptr(), int(stride), status.data_ptr(), int(jobs_hint), int(items_hint)))
+
+    def ShellCommit(self, aborted):
+        check(self.L.chisel_hip_shell_commit(self.h, int(bool(aborted))))
+
+    SHELL_STATUS_INTS = 8
+
     def UpdateMeshesPlanned(self):
         check(self.L.chisel_hip_update_meshes_planned(self.h))
         self._imports_fenced = True
@@ -455,6 +472,14 @@ class Chisel:
     def record_event(self, hip_event):
         """record the hipEvent_t behind everything queued on the map: after it the frames of earlier calls have been read"""
         check(self.L.chisel_hip_record_event(self.h, C.c_void_p(hip_event)))
+
+    def order_stream_after_map(self, hip_stream):
+        """whatever the hipStream_t is given next starts after what the map has queued so far (one call, the map's own event)"""
+        check(self.L.chisel_hip_order_stream_after_map(self.h, C.c_void_p(hip_stream)))
+
+    def order_map_after_stream(self, hip_stream):
+        """the map's next call starts after what the hipStream_t has been given so far"""
+        check(self.L.chisel_hip_order_map_after_stream(self.h, C.c_void_p(hip_stream)))
 
     def NumChunks(self):
         n = C.c_int64(0)

@@ -313,6 +313,13 @@ struct chisel_hip_map {
     const unsigned char *ghost_packed = nullptr;                       // the received segments the current ghosts came from (chisel_hip_import_shells_packed): dropped from there
     ShellSegments ghost_segments{};
     int ghost_packed_items = 0;
+    // the wait-free form (chisel_hip_shell_plan_queue ...): the segments' stride, the all-reduced status word on the device, whether a drop
+    // is queued that leaves the ghosts alone while the mesh step has to be emitted again (check_mesh_totals launches it again), whether the
+    // recompute's host-side bookkeeping (pending_mesh_ids) waits for chisel_hip_shell_commit
+    hipEvent_t order_events[2] = {nullptr, nullptr};  // chisel_hip_order_stream_after_map / chisel_hip_order_map_after_stream
+    int64_t shell_stride = 0;
+    const int *shell_abort_dev = nullptr;
+    bool shell_fixed_ghosts = false, shell_redrop = false, shell_uncommitted = false;
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
     uint64_t pending_version = 1;                                      // bumped when entries join pending_mesh_ids (chisel_hip_meshes_to_update_since)
     uint32_t dirty_epoch = 0;                                          // bumped when the device's dirty list is emptied (recompute, reset)
@@ -1588,6 +1595,8 @@ int chisel_hip_destroy(chisel_hip_map *m) {
     }
     for (auto &pr : m->pending_ring)
         if (pr) (void)hipFree(pr);
+    for (hipEvent_t e : m->order_events)
+        if (e) (void)hipEventDestroy(e);
     if (m->call_event) (void)hipEventDestroy(m->call_event);
     if (m->mutation_event) (void)hipEventDestroy(m->mutation_event);
     if (m->aux && m->aux != m->own_stream) (void)hipStreamDestroy(m->aux);
@@ -1664,6 +1673,29 @@ int chisel_hip_record_event(chisel_hip_map *m, void *ev) {
     if (!m || !ev) return fail(CHISEL_HIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipEventRecord((hipEvent_t)ev, m->stream));
+    return CHISEL_HIP_OK;
+}
+
+// The two orderings a caller with a stream of its own needs around the map (collectives on the communication library's stream, cvids_amd/sharded.py),
+// each as ONE call with events the map keeps: `stream` continues after what the map has queued so far / the map's next call starts after what
+// `stream` has been given so far.  Nothing is waited for.
+int chisel_hip_order_stream_after_map(chisel_hip_map *m, void *stream) {
+    SETTLE(m);
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "one event cannot be recorded on the streams of several GPUs: chisel_hip_synchronize the group instead");
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->order_events[0]) HIP_TRY(hipEventCreateWithFlags(&m->order_events[0], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->order_events[0], m->stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, m->order_events[0], 0));
+    return CHISEL_HIP_OK;
+}
+int chisel_hip_order_map_after_stream(chisel_hip_map *m, void *stream) {
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a group takes an event of the caller's: chisel_hip_wait_event");
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->order_events[1]) HIP_TRY(hipEventCreateWithFlags(&m->order_events[1], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->order_events[1], (hipStream_t)stream));
+    m->input_event = m->order_events[1];  // (as chisel_hip_wait_event: the next call that queues work makes its streams wait)
     return CHISEL_HIP_OK;
 }
 
@@ -2133,7 +2165,19 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
     SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "chisel_hip_drop_ghost_chunks is a call between the shards of a map: a group makes it itself (chisel_hip_update_meshes)");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
-    if (m->ghost_packed) {
+    if (m->ghost_packed && m->shell_fixed_ghosts) {
+        // the wait-free form: nothing is waited for.  The recompute in flight may have to be emitted again (its totals are not known yet):
+        // then the kernel leaves the ghosts where they are (MC_LATCH) and check_mesh_totals launches it again behind the second emission.
+        HIP_TRY(hipSetDevice(m->device));
+        { m->topology_epoch++; m->dirty_tail_queued = false; }
+        hipLaunchKernelGGL(shell_drop_ghosts_fixed_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, m->cfg.n_shards, m->V,
+                           m->shell_abort_dev, (const int *)(m->view.mesh_ctl ? m->view.mesh_ctl + MC_LATCH : nullptr));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(note_map_mutation(m));
+        m->shell_redrop = m->pending_meshes.unchecked;  // (ghost_packed stays: the buffer is the caller's until its next recompute)
+        m->shell_fixed_ghosts = false;
+        if (!m->shell_redrop) m->ghost_packed = nullptr;
+    } else if (m->ghost_packed) {
         // the ghosts of chisel_hip_import_shells_packed: named by the items of the received segments, which the caller still holds
         HIP_TRY(hipSetDevice(m->device));
         { m->topology_epoch++; m->dirty_tail_queued = false; }
@@ -2217,7 +2261,8 @@ int chisel_hip_dirty_ids_device(chisel_hip_map *m, int *out_dev, int capacity) {
         head.push_back(x); head.push_back(y); head.push_back(z); head.push_back(1);
         stored++;
     }
-    HIP_TRY(hipMemcpyAsync(out_dev, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    if (head.size() == 1 && head[0] == 0) HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(int), m->stream));  // (the common case: no copy from pageable memory)
+    else HIP_TRY(hipMemcpyAsync(out_dev, head.data(), head.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
     hipLaunchKernelGGL(list_dirty_ids_kernel, dim3(256), dim3(256), 0, m->stream, m->view, out_dev, capacity);
     HIP_TRY(hipGetLastError());
     return CHISEL_HIP_OK;
@@ -2449,7 +2494,7 @@ int chisel_hip_export_shells_packed(chisel_hip_map *m, void *out_dev, int64_t by
         m->input_event = nullptr;
     }
     hipLaunchKernelGGL(shell_export_kernel, dim3((unsigned)std::max(1, m->shell_send_items)), dim3(256), 0, m->stream, m->view, m->shell_plan, m->N, m->cfg.n_shards,
-                       static_cast<unsigned char *>(out_dev));
+                       static_cast<unsigned char *>(out_dev), 0ll);
     HIP_TRY(hipGetLastError());
     return CHISEL_HIP_OK;
 }
@@ -2495,6 +2540,104 @@ int chisel_hip_import_shells_packed(chisel_hip_map *m, const void *in_dev, int64
         m->ghost_packed_items = items;
     }
     return CHISEL_HIP_OK;
+}
+
+// ---- the wait-free form of the same recompute (kernels_map.h: "the wait-free form"; include/chisel_hip.h) ----------------------------------
+// Step 2 without the host: the plan's kernels and, behind them, this rank's status vector into `status_dev` (SHELL_STATUS_INTS ints, the
+// caller's: it all-reduces them with MAX in front of the exchange).  The plan's buffers keep the sizes the last chisel_hip_shell_plan_device
+// grew them to; a plan that outgrows them is one of the things the status reports.
+int chisel_hip_shell_plan_queue(chisel_hip_map *m, const int *gathered_dev, int world, int cap, int64_t seg_stride, int *status_dev) {
+    SETTLE(m);
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || !gathered_dev || !status_dev || cap < 1 || world < 1 || world != m->cfg.n_shards || world > SHELL_MAX_SHARDS || seg_stride < 16 || (seg_stride & 15))
+        return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = check_mesh_totals(m);  // (the recompute before this one: its second emission, if any, and the drop behind it come first)
+    if (rc) return rc;
+    rc = ensure_mesh_jobs(m, m->view.committed);
+    if (rc) return rc;
+    if (m->input_event) {
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    rc = ensure_shell_plan(m, std::max(m->shell_plan.jobset_capacity, 1 << 15), std::max(m->shell_plan.send_capacity, 1 << 15));
+    if (rc) return rc;
+    ShellPlan &S = m->shell_plan;
+    if (!S.my_jobs || S.max_jobs < m->mesh_buf.capacity) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (S.my_jobs) HIP_TRY(hipFree(S.my_jobs));
+        S.my_jobs = nullptr;
+        HIP_TRY(hipMalloc(&S.my_jobs, (size_t)m->mesh_buf.capacity * 3 * sizeof(int)));
+        S.max_jobs = m->mesh_buf.capacity;
+    }
+    HIP_TRY(hipMemsetAsync(S.jobset, 0xff, (size_t)S.jobset_capacity * sizeof(unsigned long long), m->stream));
+    HIP_TRY(hipMemsetAsync(S.ctl, 0, (16 + 4 * SHELL_MAX_SHARDS) * sizeof(int), m->stream));
+    const long long threads = 27ll * cap * world;
+    hipLaunchKernelGGL(shell_jobs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, gathered_dev, world, cap, S, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
+    hipLaunchKernelGGL(shell_items_kernel, dim3((unsigned)(S.jobset_capacity / 8)), dim3(256), 0, m->stream, S, m->N, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
+    hipLaunchKernelGGL(shell_status_kernel, dim3(1), dim3(64), 0, m->stream, S, cap, (long long)seg_stride, m->view.rgbw != nullptr ? 1 : 0, m->cfg.n_shards, status_dev);
+    HIP_TRY(hipGetLastError());
+    m->shell_stride = seg_stride;
+    return CHISEL_HIP_OK;
+}
+// Step 3, owner side: `world` segments of `seg_stride` bytes each into out_dev (the stride of the plan just queued).  A segment that does not fit
+// carries a head that says so; the status said it before.
+int chisel_hip_export_shells_fixed(chisel_hip_map *m, void *out_dev, int64_t seg_stride) {
+    SETTLE(m);
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || !out_dev || seg_stride != m->shell_stride || seg_stride < 16) return fail(CHISEL_HIP_ERR_INVALID, "bad argument (the stride is the one of chisel_hip_shell_plan_queue)");
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->input_event) {
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    hipLaunchKernelGGL(shell_export_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->shell_plan, m->N, m->cfg.n_shards, static_cast<unsigned char *>(out_dev),
+                       (long long)seg_stride);
+    HIP_TRY(hipGetLastError());
+    return CHISEL_HIP_OK;
+}
+// Steps 4-6 behind the exchange: ghosts from the received segments, the plan's jobs meshed, the ghosts dropped -- all of it queued, none of
+// it done if word 0 of the all-reduced status (`status_dev`, which stays the caller's until chisel_hip_shell_commit) is not zero.
+// jobs_hint / items_hint: what the previous recompute had (grid sizes, pool growth); 0 = unknown.
+int chisel_hip_import_shells_fixed(chisel_hip_map *m, const void *in_dev, int64_t seg_stride, const int *status_dev, int jobs_hint, int items_hint) {
+    SETTLE(m);
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m || !in_dev || !status_dev || seg_stride != m->shell_stride || !m->shell_plan.my_jobs) return fail(CHISEL_HIP_ERR_INVALID, "bad argument (chisel_hip_shell_plan_queue first)");
+    HIP_TRY(hipSetDevice(m->device));
+    { m->topology_epoch++; m->dirty_tail_queued = false; }
+    if (m->input_event) {
+        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
+        m->input_event = nullptr;
+    }
+    int rc = maybe_grow(m, std::max(256, 2 * items_hint));  // (ghosts take slots of this shard's pool until they are dropped again)
+    if (rc) return rc;
+    const unsigned char *in = static_cast<const unsigned char *>(in_dev);
+    hipLaunchKernelGGL(shell_ensure_ghosts_fixed_kernel, dim3(64), dim3(256), 0, m->stream, m->view, in, (long long)seg_stride, m->cfg.n_shards, status_dev,
+                       reinterpret_cast<unsigned long long *>(m->shell_plan.ctl + 16 + 4 * SHELL_MAX_SHARDS));
+    hipLaunchKernelGGL(shell_import_fixed_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, in, (long long)seg_stride, m->cfg.n_shards, m->N, status_dev);
+    hipLaunchKernelGGL(shell_abort_kernel, dim3(1), dim3(64), 0, m->stream, status_dev, m->shell_plan.ctl);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(note_map_mutation(m));
+    m->ghost_packed = in;
+    m->shell_fixed_ghosts = true;
+    m->shell_abort_dev = status_dev;
+    m->shell_jobs = jobs_hint;
+    m->shell_uncommitted = true;
+    return CHISEL_HIP_OK;
+}
+// The host's look at a wait-free recompute, once it has read the all-reduced status: the totals of its mesh step are settled (a second
+// emission, and the drop behind it, if it did not fit) and, unless the recompute was called off, the bookkeeping that chisel_hip_update_meshes_planned
+// left open is closed.  aborted != 0: nothing happened on the device; the caller makes the recompute again with chisel_hip_shell_plan_device.
+int chisel_hip_shell_commit(chisel_hip_map *m, int aborted) {
+    SETTLE(m);
+    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
+    if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
+    HIP_TRY(hipSetDevice(m->device));
+    const int rc = check_mesh_totals(m);
+    if (m->shell_uncommitted && !aborted) m->pending_mesh_ids.clear();
+    m->shell_uncommitted = false;
+    m->shell_abort_dev = nullptr;
+    return rc;
 }
 
 // The plan of one rank for a recompute of a sharded map (pure host arithmetic, the same on every rank for the same entries -- so

@@ -359,6 +359,9 @@ int check_mesh_totals(chisel_hip_map *m) {
             }
             HIP_TRY(hipGetLastError());
             latch_guard.settled = true;
+            if (m->shell_redrop && m->ghost_packed)  // the ghosts of a wait-free sharded recompute: their drop kernel left them for this emission
+                hipLaunchKernelGGL(shell_drop_ghosts_fixed_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, m->cfg.n_shards, m->V,
+                                   m->shell_abort_dev, (const int *)nullptr);
             if (deferred >= 0) {
                 int rc_r = replay_deferred_set(m, deferred);
                 if (rc_r) return rc_r;
@@ -369,6 +372,10 @@ int check_mesh_totals(chisel_hip_map *m) {
             free_arena(m, A);
             arena_id = -1;
         }
+    }
+    if (m->shell_redrop) {
+        m->shell_redrop = false;
+        m->ghost_packed = nullptr;
     }
     m->mesh_jobs_hint = n;
     if (n != 0) {
@@ -578,7 +585,7 @@ int chisel_hip_update_meshes_of(chisel_hip_map *m, const int *ids, int n) {
     HIP_TRY(hipMemsetAsync(mesh_totals(m) + MC_CURSORS, 0, 2 * MESH_PARTS * sizeof(int), m->stream));
     m->mesh_jobs_hint = n;
     if (n) HIP_TRY(hipMemcpyAsync(B.ids, ids, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, m->stream));
-    if (!m->mesh_detached) hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    if (!m->mesh_detached) hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view, (const int *)nullptr);
     HIP_TRY(hipGetLastError());
     rc = recompute_meshes(m);
     if (rc) return rc;
@@ -604,11 +611,16 @@ int chisel_hip_update_meshes_planned(chisel_hip_map *m) {
     HIP_TRY(zero_mesh_counters(m));
     m->mesh_totals_clean = false;
     m->mesh_jobs_hint = m->shell_jobs;
-    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view);
+    // (the wait-free form: a recompute that was called off on the device keeps its dirty flags, and the host-held ids until chisel_hip_shell_commit)
+    hipLaunchKernelGGL(clear_dirty_kernel, dim3((m->view.max_chunks + 255) / 256), dim3(256), 0, m->stream, m->view, m->shell_uncommitted ? m->shell_abort_dev : (const int *)nullptr);
     HIP_TRY(hipGetLastError());
     rc = recompute_meshes(m);
     if (rc) return rc;
-    m->pending_mesh_ids.clear();
+    if (m->shell_uncommitted && m->shell_abort_dev) {
+        hipLaunchKernelGGL(shell_abort_relist_kernel, dim3(1), dim3(64), 0, m->stream, m->view, m->shell_abort_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!m->shell_uncommitted) m->pending_mesh_ids.clear();
     return CHISEL_HIP_OK;
 }
 

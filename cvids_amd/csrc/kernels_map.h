@@ -602,50 +602,96 @@ __global__ __launch_bounds__(256) void shell_items_kernel(ShellPlan S, int N, in
     }
 }
 // where segment `peer` begins in a buffer of consecutive segments, and its counts (cur: items | voxels << 32 per peer)
-__device__ inline long long shell_segment_at(const unsigned long long *cur, int peer, bool color, int &items, long long &voxels) {
-    long long off = 0;
-    for (int p = 0; p < peer; p++) off += shell_segment_bytes((long long)(cur[p] & 0xffffffffull), (long long)(cur[p] >> 32), color);
+// (stride > 0: the wait-free form -- every segment has `stride` bytes to itself, whatever the others hold)
+__device__ inline long long shell_segment_at(const unsigned long long *cur, int peer, bool color, int &items, long long &voxels, long long stride = 0) {
+    long long off = stride * peer;
+    for (int p = 0; p < peer && stride == 0; p++) off += shell_segment_bytes((long long)(cur[p] & 0xffffffffull), (long long)(cur[p] >> 32), color);
     items = (int)(cur[peer] & 0xffffffffull);
     voxels = (long long)(cur[peer] >> 32);
     return off;
 }
-// step 3 (owner): one workgroup per send item packs its box into the destination's segment; workgroup 0 also writes the segment heads
-__global__ __launch_bounds__(256) void shell_export_kernel(MapView M, ShellPlan S, int N, int n_shards, unsigned char *out) {
+// ---- the wait-free form of a sharded recompute (round 6) ------------------------------------------------------------------------------
+// The host reads nothing of the plan: the segments have a FIXED size agreed on beforehand (from what the previous recompute needed), the
+// exchange is an all-to-all of equal splits, and everything the steps behind the plan need to know they read on the device -- the export
+// kernel the plan's cursors, the import / drop kernels the heads of the received segments.  What can go wrong is written into a STATUS
+// vector by every rank right after its plan, all-reduced (MAX) in front of the exchange, and looked at
+//   * by the kernels behind the exchange (`abort` = word 0 of the reduced vector): if any rank's list, plan or segment did not fit, NO rank
+//     creates a ghost, meshes a job or clears a dirty flag -- the recompute has not happened and is made again the old way (with the host
+//     reading the plan) from an untouched map;
+//   * by the host when it next enters the map (ShardedChisel.Settle), which also takes the next recompute's sizes from it.
+// status: [0] abort bits (1: a rank's dirty list was cut off, 2: job set / job list / item list overflow, 4: a segment exceeds the stride),
+// [1] largest dirty count, [2] bytes of this rank's largest segment, [3] its jobs, [4] items it receives, [5] items it sends, [6] voxels it receives, [7] ghost chunks its earlier recomputes created (a running total, for the record)
+constexpr int SHELL_STATUS_INTS = 8;
+__global__ void shell_status_kernel(ShellPlan S, int cap, long long stride, int color, int n_shards, int *status) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    long long largest = 0, recv_items = 0, recv_voxels = 0;
+    for (int p = 0; p < n_shards; p++) {
+        largest = max(largest, shell_segment_bytes((long long)(S.send_cur[p] & 0xffffffffull), (long long)(S.send_cur[p] >> 32), color != 0));
+        recv_items += (long long)(S.recv_cnt[p] & 0xffffffffull);
+        recv_voxels += (long long)(S.recv_cnt[p] >> 32);
+    }
+    const bool plan_over = S.ctl[1] != 0 || S.ctl[3] > S.send_capacity;
+    status[0] = (S.ctl[2] > cap ? 1 : 0) | (plan_over ? 2 : 0) | ((stride > 0 && largest > stride) ? 4 : 0);
+    status[1] = S.ctl[2];
+    status[2] = (int)min(largest, 0x7fffffffll);
+    status[3] = S.ctl[0];
+    status[4] = (int)min(recv_items, 0x7fffffffll);
+    status[5] = S.ctl[3];
+    status[6] = (int)min(recv_voxels, 0x7fffffffll);
+    status[7] = (int)min((long long)*reinterpret_cast<const unsigned long long *>(S.ctl + 16 + 4 * SHELL_MAX_SHARDS), 0x7fffffffll);  // ghost chunks this rank's earlier recomputes created (for the record)
+}
+// in front of the mesh step: a recompute that was called off has no jobs
+__global__ void shell_abort_kernel(const int *abort, int *ctl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *abort) ctl[0] = 0;
+}
+// ... and behind it: the count kernel has emptied the LIST of dirty slots (it does so whatever it meshed), their flags are all still up
+// (clear_dirty_kernel left them) -- a list that says "overflowed" makes the next listing go by the flags (list_dirty_ids_kernel, mesh_mark_kernel)
+__global__ void shell_abort_relist_kernel(MapView M, const int *abort) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *abort) M.slot_dirty[2 * (size_t)M.max_chunks] = (unsigned)M.max_chunks + 1u;
+}
+// step 3 (owner): one workgroup per send item (or several items per workgroup: the wait-free form launches a fixed grid) packs its box
+// into the destination's segment; workgroup 0 also writes the segment heads.  stride > 0: a segment that exceeds it carries a head that
+// says so ({0, 0, 1, 0}) and nothing else.
+__global__ __launch_bounds__(256) void shell_export_kernel(MapView M, ShellPlan S, int N, int n_shards, unsigned char *out, long long stride) {
     __shared__ int s_slot;
     const bool color = M.rgbw != nullptr;
     if (blockIdx.x == 0 && threadIdx.x < n_shards) {
         int items;
         long long voxels;
-        const long long off = shell_segment_at(S.send_cur, threadIdx.x, color, items, voxels);
+        const long long off = shell_segment_at(S.send_cur, threadIdx.x, color, items, voxels, stride);
+        const bool fits = stride == 0 || shell_segment_bytes(items, voxels, color) <= stride;
         int *head = reinterpret_cast<int *>(out + off);
-        head[0] = items; head[1] = (int)voxels; head[2] = 0; head[3] = 0;
+        head[0] = fits ? items : 0; head[1] = fits ? (int)voxels : 0; head[2] = fits ? 0 : 1; head[3] = 0;
     }
-    const int j = blockIdx.x;
-    if (j >= min(S.ctl[3], S.send_capacity)) return;
-    const int *it = S.send_items + 8 * (size_t)j;
-    int items;
-    long long voxels;
-    const long long off = shell_segment_at(S.send_cur, it[4], color, items, voxels);
-    if (threadIdx.x == 0) {
-        s_slot = hash_find(M, it[0], it[1], it[2]);
-        int *rec = reinterpret_cast<int *>(out + off + 16 + 32 * (long long)it[5]);
-        rec[0] = it[0]; rec[1] = it[1]; rec[2] = it[2]; rec[3] = it[3]; rec[4] = s_slot >= 0 ? 1 : 0; rec[5] = it[6]; rec[6] = 0; rec[7] = 0;
-    }
-    __syncthreads();
-    const int slot = s_slot, box = it[3];
-    if (slot < 0) return;  // (an absent chunk: the receiver skips the item, its voxels stay unwritten)
-    const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
-    const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
-    float *sdf = reinterpret_cast<float *>(out + off + 16 + 32 * (long long)items) + it[6];
-    float *wgt = sdf + voxels;
-    unsigned *col = reinterpret_cast<unsigned *>(wgt + voxels);
-    const size_t src = (size_t)slot * N * N * N;
-    for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
-        const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
-        const size_t i = src + (size_t)(z * N + y) * N + x;
-        sdf[v] = M.sdf[i];
-        wgt[v] = M.wgt[i];
-        if (color) col[v] = reinterpret_cast<const unsigned *>(M.rgbw)[i];
+    const int n = min(S.ctl[3], S.send_capacity);
+    for (int j = blockIdx.x; j < n; j += gridDim.x) {
+        const int *it = S.send_items + 8 * (size_t)j;
+        int items;
+        long long voxels;
+        const long long off = shell_segment_at(S.send_cur, it[4], color, items, voxels, stride);
+        if (stride > 0 && shell_segment_bytes(items, voxels, color) > stride) continue;  // (wave-uniform, workgroup-uniform)
+        __syncthreads();  // (s_slot of the item before)
+        if (threadIdx.x == 0) {
+            s_slot = hash_find(M, it[0], it[1], it[2]);
+            int *rec = reinterpret_cast<int *>(out + off + 16 + 32 * (long long)it[5]);
+            rec[0] = it[0]; rec[1] = it[1]; rec[2] = it[2]; rec[3] = it[3]; rec[4] = s_slot >= 0 ? 1 : 0; rec[5] = it[6]; rec[6] = 0; rec[7] = 0;
+        }
+        __syncthreads();
+        const int slot = s_slot, box = it[3];
+        if (slot < 0) continue;  // (an absent chunk: the receiver skips the item, its voxels stay unwritten)
+        const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
+        const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
+        float *sdf = reinterpret_cast<float *>(out + off + 16 + 32 * (long long)items) + it[6];
+        float *wgt = sdf + voxels;
+        unsigned *col = reinterpret_cast<unsigned *>(wgt + voxels);
+        const size_t src = (size_t)slot * N * N * N;
+        for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
+            const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
+            const size_t i = src + (size_t)(z * N + y) * N + x;
+            sdf[v] = M.sdf[i];
+            wgt[v] = M.wgt[i];
+            if (color) col[v] = reinterpret_cast<const unsigned *>(M.rgbw)[i];
+        }
     }
 }
 // The received buffer: consecutive segments, one per owner (empty for this rank itself), at byte offsets seg[peer].
@@ -660,11 +706,7 @@ __device__ inline const int *shell_received_item(const unsigned char *in, const 
 }
 // step 4a (requester): a ghost chunk for every received item whose chunk was found at its owner -- several items may name one ghost, the
 // thread whose compare-and-swap enters the key creates it.  (The ids are absent before: ghosts are dropped after every recompute.)
-__global__ void shell_ensure_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int n_items, unsigned long long *ghosts_created) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_items) return;
-    int peer;
-    const int *it = shell_received_item(in, G, n_shards, j, peer);
+__device__ inline void shell_ensure_ghost(const MapView &M, const int *it, unsigned long long *ghosts_created) {
     if (!it[4]) return;
     const int x = it[0], y = it[1], z = it[2];
     const uint64_t key = pack_id(x, y, z);
@@ -696,19 +738,23 @@ __global__ void shell_ensure_ghosts_kernel(MapView M, const unsigned char *__res
     }
     raise_error(M.error_flag, 2);
 }
-// step 4b (the next launch): one workgroup per received item writes its box into the ghost
-__global__ __launch_bounds__(256) void shell_import_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int N) {
-    __shared__ int s_slot;
+__global__ void shell_ensure_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int n_items, unsigned long long *ghosts_created) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_items) return;
     int peer;
-    const int *it = shell_received_item(in, G, n_shards, blockIdx.x, peer);
-    if (!it[4]) return;
-    if (threadIdx.x == 0) s_slot = hash_find(M, it[0], it[1], it[2]);
+    shell_ensure_ghost(M, shell_received_item(in, G, n_shards, j, peer), ghosts_created);
+}
+// step 4b (the next launch): one workgroup per received item writes its box into the ghost (s_slot: a word of LDS; the workgroup's threads
+// arrive together and leave together)
+__device__ inline void shell_import_item(const MapView &M, const unsigned char *__restrict__ in, long long seg_off, const int *it, int N, int *s_slot) {
+    __syncthreads();  // (a workgroup that takes several items: s_slot of the one before)
+    if (threadIdx.x == 0) *s_slot = it[4] ? hash_find(M, it[0], it[1], it[2]) : -1;
     __syncthreads();
-    const int slot = s_slot, box = it[3];
+    const int slot = *s_slot, box = it[3];
     if (slot < 0) return;
-    const int *head = reinterpret_cast<const int *>(in + G.off[peer]);
+    const int *head = reinterpret_cast<const int *>(in + seg_off);
     const long long items = head[0], voxels = head[1];
-    const float *sdf = reinterpret_cast<const float *>(in + G.off[peer] + 16 + 32 * items) + it[5];
+    const float *sdf = reinterpret_cast<const float *>(in + seg_off + 16 + 32 * items) + it[5];
     const float *wgt = sdf + voxels;
     const unsigned *col = reinterpret_cast<const unsigned *>(wgt + voxels);
     const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
@@ -723,17 +769,20 @@ __global__ __launch_bounds__(256) void shell_import_kernel(MapView M, const unsi
         if (M.rgbw) reinterpret_cast<unsigned *>(M.rgbw)[i] = col[v];
     }
 }
-// step 6: the ghosts go again -- one workgroup per received item; of the items that name one ghost the one whose swap takes the key out
-// frees the slot (as remove_chunks_kernel does for a list with duplicates)
-__global__ __launch_bounds__(256) void shell_drop_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int V) {
+__global__ __launch_bounds__(256) void shell_import_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int N) {
     __shared__ int s_slot;
     int peer;
     const int *it = shell_received_item(in, G, n_shards, blockIdx.x, peer);
-    if (!it[4]) return;
+    shell_import_item(M, in, G.off[peer], it, N, &s_slot);
+}
+// step 6: the ghosts go again -- one workgroup per received item; of the items that name one ghost the one whose swap takes the key out
+// frees the slot (as remove_chunks_kernel does for a list with duplicates)
+__device__ inline void shell_drop_item(const MapView &M, const int *it, int V, int *s_slot) {
+    __syncthreads();
     if (threadIdx.x == 0) {
-        s_slot = -1;
+        *s_slot = -1;
         uint64_t where = 0;
-        const int slot = hash_find(M, it[0], it[1], it[2], &where);
+        const int slot = it[4] ? hash_find(M, it[0], it[1], it[2], &where) : -1;
         if (slot >= 0) {
             const uint64_t key = pack_id(it[0], it[1], it[2]);
             if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) == key) {
@@ -741,12 +790,12 @@ __global__ __launch_bounds__(256) void shell_drop_ghosts_kernel(MapView M, const
                 M.slot_dirty[slot] = 0;
                 slot_summary(M)[slot] = 0;
                 if (M.mesh_flag) M.mesh_flag[slot] = 0;
-                s_slot = slot;
+                *s_slot = slot;
             }
         }
     }
     __syncthreads();
-    const int slot = s_slot;
+    const int slot = *s_slot;
     if (slot < 0) return;
     fill_default_chunk(M, slot, V);
     __syncthreads();
@@ -754,6 +803,64 @@ __global__ __launch_bounds__(256) void shell_drop_ghosts_kernel(MapView M, const
         __threadfence();
         const int pos = atomicAdd(M.free_top, 1);
         M.free_list[pos] = slot;
+    }
+}
+__global__ __launch_bounds__(256) void shell_drop_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int V) {
+    __shared__ int s_slot;
+    int peer;
+    shell_drop_item(M, shell_received_item(in, G, n_shards, blockIdx.x, peer), V, &s_slot);
+}
+// ---- the same three steps in the wait-free form: segments `stride` bytes apart, their item counts in their heads (a head that says
+// "did not fit" counts as empty), a fixed grid whose workgroups take the items in turn, and nothing at all when the recompute was called off
+// (`abort`: word 0 of the all-reduced status) -- or, for the drop, while the mesh step in front of it is still to be emitted again
+// (`latch`: mesh_ctl[MC_LATCH]: the second emission reads the ghosts; check_mesh_totals launches the drop again behind it) ---------------
+__device__ inline void shell_segments_fixed(const unsigned char *__restrict__ in, long long stride, int n_shards, ShellSegments *G) {
+    if (threadIdx.x == 0) {
+        int items = 0;
+        for (int p = 0; p < n_shards; p++) {
+            const int *head = reinterpret_cast<const int *>(in + stride * p);
+            G->off[p] = stride * p;
+            G->first_item[p] = items;
+            items += head[2] ? 0 : head[0];
+        }
+        G->off[n_shards] = stride * n_shards;
+        G->first_item[n_shards] = items;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void shell_ensure_ghosts_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, const int *abort,
+                                                                        unsigned long long *ghosts_created) {
+    __shared__ ShellSegments G;
+    if (abort && *abort) return;
+    shell_segments_fixed(in, stride, n_shards, &G);
+    const int total = G.first_item[n_shards];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        int peer;
+        shell_ensure_ghost(M, shell_received_item(in, G, n_shards, j, peer), ghosts_created);
+    }
+}
+__global__ __launch_bounds__(256) void shell_import_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, int N, const int *abort) {
+    __shared__ ShellSegments G;
+    __shared__ int s_slot;
+    if (abort && *abort) return;
+    shell_segments_fixed(in, stride, n_shards, &G);
+    const int total = G.first_item[n_shards];
+    for (int j = blockIdx.x; j < total; j += gridDim.x) {
+        int peer;
+        const int *it = shell_received_item(in, G, n_shards, j, peer);
+        shell_import_item(M, in, G.off[peer], it, N, &s_slot);
+    }
+}
+__global__ __launch_bounds__(256) void shell_drop_ghosts_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, int V, const int *abort,
+                                                                      const int *latch) {
+    __shared__ ShellSegments G;
+    __shared__ int s_slot;
+    if ((abort && *abort) || (latch && *latch)) return;
+    shell_segments_fixed(in, stride, n_shards, &G);
+    const int total = G.first_item[n_shards];
+    for (int j = blockIdx.x; j < total; j += gridDim.x) {
+        int peer;
+        shell_drop_item(M, shell_received_item(in, G, n_shards, j, peer), V, &s_slot);
     }
 }
 
@@ -804,7 +911,8 @@ __global__ __launch_bounds__(256) void list_dirty_tail_kernel(MapView M, unsigne
         out[0] = (int)listed;
     }
 }
-__global__ void clear_dirty_kernel(MapView M) {
+__global__ void clear_dirty_kernel(MapView M, const int *abort) {  // (abort: a sharded recompute that was called off keeps its dirty flags)
+    if (abort && *abort) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M.max_chunks) {
         M.slot_dirty[i] = 0;

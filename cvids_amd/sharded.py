@@ -262,12 +262,58 @@ class LocalShardGroup:
         for s_ in self.shards:
             s_.IntegratePointCloud(integrator, cloud, extrinsic, truncation, max_dist)
 
-    def UpdateMeshes(self, force=False):
-        """the protocol of ShardedChisel.UpdateMeshes with the two collectives done by copies between the shards' buffers"""
+    def UpdateMeshes(self, force=False, wait_free=False, stride=None):
+        """the protocol of ShardedChisel.UpdateMeshes with the two collectives done by copies between the shards' buffers.
+        wait_free: its wait-free form (fixed segments of `stride` bytes -- default: half as much again as the largest segment of the
+        previous recompute --, nothing read between the steps; a recompute that does not fit is called off on the device and made again
+        the blocking way).  -> the all-reduced status of a wait-free recompute, else None"""
         import torch
         self.calls += 1
         if not force and (self.calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
-            return
+            return None
+        if wait_free and (stride or getattr(self, "_seg_need", 0)):
+            return self._update_wait_free(stride or (self._seg_need + self._seg_need // 2 + 4096 + 15) // 16 * 16)
+        return self._update_blocking()
+
+    def _update_wait_free(self, stride):
+        import torch
+        W = self.world
+        dev = torch.device("cuda", torch.cuda.current_device())
+        cap = getattr(self, "_dirty_cap", 1 << 12)
+        gathered = torch.zeros((W, 1 + 4 * cap), dtype=torch.int32, device=dev)
+        status = torch.zeros((W, 8), dtype=torch.int32, device=dev)
+        send = [torch.zeros((W * stride,), dtype=torch.uint8, device=dev) for _ in range(W)]
+        torch.cuda.current_stream().synchronize()
+        for r, s_ in enumerate(self.shards):
+            s_.DirtyIdsDevice(gathered[r])
+            s_.synchronize()  # (stands for the all-gather's event)
+        for r, s_ in enumerate(self.shards):
+            s_.PlanShellsQueue(gathered.view(-1), W, cap, stride, status[r])
+            s_.ExportShellsFixed(send[r], stride)
+            s_.synchronize()  # (... for the events in front of the all-reduce and the all-to-all)
+        reduced = status.max(dim=0).values.contiguous()  # the all-reduce (MAX)
+        recv = [torch.cat([send[o][r * stride:(r + 1) * stride] for o in range(W)]) for r in range(W)]  # the all-to-all of equal splits
+        torch.cuda.current_stream().synchronize()
+        for r, s_ in enumerate(self.shards):
+            s_.ImportShellsFixed(recv[r], stride, reduced)
+            s_.UpdateMeshesPlanned()
+            s_.DropGhostChunks()
+        self._keep = (gathered, status, reduced, send, recv)  # (the device reads them until the commit below has settled the mesh step)
+        st = [int(v) for v in reduced.tolist()]  # (a host wait here: this class is a test vehicle; ShardedChisel reads it in Settle())
+        for s_ in self.shards:
+            s_.ShellCommit(st[0] != 0)
+        self.last_status = st
+        self._seg_need = st[2]
+        self.ghost_bytes = st[6] * (12 if self.shards[0].use_color else 8)
+        if st[0] & 1:
+            self._dirty_cap = 2 * st[1]
+        if st[0]:
+            self.wait_free_aborts = getattr(self, "wait_free_aborts", 0) + 1
+            self._update_blocking()
+        return st
+
+    def _update_blocking(self):
+        import torch
         W = self.world
         dev = torch.device("cuda", torch.cuda.current_device())
         cap = getattr(self, "_dirty_cap", 1 << 12)
@@ -291,6 +337,7 @@ class LocalShardGroup:
             s_.ExportShellsPacked(buf)
             s_.synchronize()
             send.append((buf, np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)))
+            self._seg_need = max([getattr(self, "_seg_need", 0) if r else 0] + sizes)
         self.ghost_bytes = 0
         for r, s_ in enumerate(self.shards):
             sizes = [s_.ShellSegmentBytes(*plans[r]["recv"][o]) for o in range(W)]
@@ -317,6 +364,7 @@ class ShardedChisel:
     def IntegrateBatch(self, local_depth, local_poses, local_cameras, local_color=None):
         """Every rank passes the frames it ingested (x.per of them); all ranks integrate the whole batch in frame order."""
         torch = self.x.torch
+        self.Settle()
         # This is the simple, synchronous form (PipelinedExchange is the overlapped one): the map's streams may still be reading
         # the receive / colour buffer and the temporaries of the call before last, which the exchange below refills on the
         # communication library's stream -- wait for the map first.
@@ -338,6 +386,7 @@ class ShardedChisel:
         pass None), it is broadcast over RCCL and every rank updates the chunks it owns -- no other exchange is needed, the
         update of a chunk depends on the cloud and that chunk only."""
         torch, dist = self.x.torch, self.x.dist
+        self.Settle()
         rank = dist.get_rank()
         head = [None]
         if rank == src:
@@ -363,12 +412,12 @@ class ShardedChisel:
         dist = self.x.dist
         if dist.get_backend() == "gloo" and inp.is_cuda:
             o = self.x.torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.cpu(), n_recv, n_send)
+            dist.all_to_all_single(o, inp.cpu(), n_recv, n_send)  # (no sizes: equal splits)
             out.copy_(o)
         else:
             dist.all_to_all_single(out, inp, n_recv, n_send)
 
-    def UpdateMeshes(self, force=False, ids=None):
+    def UpdateMeshes(self, force=False, ids=None, wait_free=False):
         """Chisel::UpdateMeshes of the sharded map: every rank ends up with the meshes of the chunks it owns.
 
         1. every rank lists the chunks it has updated since the last recompute as a device int array (chisel_hip_dirty_ids_device) and
@@ -380,60 +429,105 @@ class ShardedChisel:
            ghost chunks; map stream and collective stream are ordered by events (record_event / wait_event);
         4. every rank recomputes its jobs (a list that never left the device) and drops the ghosts.
         ids: mesh these chunks (every rank passes ids of its own choice, the union is meshed) instead of meshesToUpdate.
-        -> bytes of ghost voxels this rank received"""
+        wait_free: the form in which the host reads NOTHING in between (_recompute_wait_free): everything is queued, the segments have a
+        size the ranks agreed on at the previous recompute, and a recompute that did not fit them is called off on the device and made
+        again the way above -- when the host next looks (Settle(): call it, or any method of this class, before touching self.map).
+        -> bytes of ghost voxels this rank received (wait_free: of the rank that received most, at the previous recompute)"""
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
             return 0
-        torch, dist, world, rank, dev = self.x.torch, self.x.dist, self.x.world, self.x.rank, self.x.device
-        if world == 1 and not getattr(self, "force_collectives", False):  # (force_collectives: tools/nccl_world1_check.py runs the N > 1 code on one rank)
+        self.Settle()
+        if self.x.world == 1 and not getattr(self, "force_collectives", False):  # (force_collectives: tools/nccl_world1_check.py runs the N > 1 code on one rank)
             if ids is None:
                 self.map.UpdateMeshes(force=True)
             else:
                 self.map.UpdateMeshesOf(np.asarray(ids, np.int32).reshape(-1, 3))
             return 0
-        on_gpu = dev.type == "cuda"
-        bounce = dist.get_backend() == "gloo" and on_gpu  # functional check only: gloo has no device collectives
+        if wait_free and ids is None and getattr(self, "_est", None) is not None and hasattr(self.map, "PlanShellsQueue"):
+            return self._recompute_wait_free()
+        return self._recompute_blocking(ids, post_sizes=wait_free)
+
+    def _lap(self, name):
+        """CHISEL_HIP_HOST_TIMING=1: host phases of a sharded recompute, summed in self.phase_us"""
         import os
         import time
-        timing = bool(os.environ.get("CHISEL_HIP_HOST_TIMING"))  # host phases of a sharded recompute, summed in self.phase_us
-        t_prev = [time.perf_counter()]
-        def lap(name):
-            if timing:
-                now = time.perf_counter()
-                self.phase_us = getattr(self, "phase_us", {})
-                self.phase_us[name] = self.phase_us.get(name, 0.0) + (now - t_prev[0]) * 1e6
-                t_prev[0] = now
+        if getattr(self, "_timing", None) is None:
+            self._timing = bool(os.environ.get("CHISEL_HIP_HOST_TIMING"))
+        now = time.perf_counter()
+        if self._timing and name is not None:
+            self.phase_us = getattr(self, "phase_us", {})
+            self.phase_us[name] = self.phase_us.get(name, 0.0) + (now - self._t_prev) * 1e6
+        self._t_prev = now
+
+    def _mesh_buffers(self, cap):
+        """the two int tensors of step 1 (kept between recomputes) and the status vectors of the wait-free form"""
+        torch, world, dev = self.x.torch, self.x.world, self.x.device
+        key = (cap, world)
+        if getattr(self, "_mesh_bufs_key", None) != key:
+            self._mesh_bufs_key = key
+            self._dirty_buf = torch.zeros((1 + 4 * cap,), dtype=torch.int32, device=dev)
+            self._gathered = torch.zeros((world * (1 + 4 * cap),), dtype=torch.int32, device=dev)
+            if dev.type == "cuda":
+                self._order_map_after_collectives()  # (torch's allocator hands out memory its own stream may still be using)
+        if getattr(self, "_status", None) is None:
+            self._status = torch.zeros((8,), dtype=torch.int32, device=dev)
+            self._status_host = torch.zeros((8,), dtype=torch.int32, pin_memory=dev.type == "cuda")
+            self._status_event = torch.cuda.Event() if dev.type == "cuda" else None
+        return self._dirty_buf, self._gathered
+
+    def _list_dirty(self, buf, ids):
+        on_gpu = self.x.device.type == "cuda"
+        cap = (buf.numel() - 1) // 4
+        if ids is None and on_gpu:
+            self.map.DirtyIdsDevice(buf)  # (writes the count itself; the buffer's last reader, the previous recompute's all-gather, is long through)
+            self._order_after_map()
+        else:
+            e = np.asarray(self.map.DirtyEntries(), np.int32).reshape(-1, 4) if ids is None else \
+                np.concatenate([np.asarray(ids, np.int32).reshape(-1, 3), np.ones((len(np.asarray(ids).reshape(-1, 3)), 1), np.int32)], axis=1)
+            head = np.zeros(1 + 4 * cap, np.int32)
+            head[0] = len(e)
+            head[1:1 + 4 * min(len(e), cap)] = e[:cap].reshape(-1)
+            buf.copy_(self.x.torch.from_numpy(head))
+
+    def _gather_dirty(self, gathered, buf):
+        torch, dist = self.x.torch, self.x.dist
+        if dist.get_backend() == "gloo" and buf.is_cuda:  # functional check only: gloo has no device collectives
+            host = torch.empty(gathered.shape, dtype=torch.int32)
+            dist.all_gather_into_tensor(host, buf.cpu())
+            gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(gathered, buf)
+
+    def _reduce_status(self):
+        """the ranks' status vectors -> their element-wise maximum on every rank, and on its way to the host (Settle reads it)"""
+        torch, dist = self.x.torch, self.x.dist
+        st = self._status
+        if dist.get_backend() == "gloo" and st.is_cuda:
+            host = st.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX)
+            st.copy_(host)
+        else:
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        self._status_host.copy_(st, non_blocking=True)
+        if self._status_event is not None:
+            self._status_event.record(torch.cuda.current_stream())
+
+    def _recompute_blocking(self, ids, post_sizes=False):
+        torch, dist, world, rank, dev = self.x.torch, self.x.dist, self.x.world, self.x.rank, self.x.device
+        on_gpu = dev.type == "cuda"
+        self._lap(None)
         # ---- 1. the ranks' dirty chunks, 2. the plan
         while True:
             cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 12)  # (entries per rank in the gathered tensor; doubled below when a rank has more)
-            key = (cap, world)
-            if getattr(self, "_mesh_bufs_key", None) != key:  # the two int tensors of step 1, kept between recomputes
-                self._mesh_bufs_key = key
-                self._dirty_buf = torch.zeros((1 + 4 * cap,), dtype=torch.int32, device=dev)
-                self._gathered = torch.zeros((world * (1 + 4 * cap),), dtype=torch.int32, device=dev)
-            buf, gathered = self._dirty_buf, self._gathered
-            if ids is None and on_gpu:
-                self.map.DirtyIdsDevice(buf)  # (writes the count itself; the buffer's last reader, the previous recompute's all-gather, is long through)
-                self._order_after_map()
-            else:
-                e = np.asarray(self.map.DirtyEntries(), np.int32).reshape(-1, 4) if ids is None else \
-                    np.concatenate([np.asarray(ids, np.int32).reshape(-1, 3), np.ones((len(np.asarray(ids).reshape(-1, 3)), 1), np.int32)], axis=1)
-                head = np.zeros(1 + 4 * cap, np.int32)
-                head[0] = len(e)
-                head[1:1 + 4 * min(len(e), cap)] = e[:cap].reshape(-1)
-                buf.copy_(torch.from_numpy(head))
-            lap("dirty ids (issue)")
-            if bounce:
-                host = torch.empty(gathered.shape, dtype=torch.int32)
-                dist.all_gather_into_tensor(host, buf.cpu())
-                gathered.copy_(host)
-            else:
-                dist.all_gather_into_tensor(gathered, buf)
-            lap("all_gather (issue)")
+            buf, gathered = self._mesh_buffers(cap)
+            self._list_dirty(buf, ids)
+            self._lap("dirty ids (issue)")
+            self._gather_dirty(gathered, buf)
+            self._lap("all_gather (issue)")
             if on_gpu:
                 self._order_map_after_collectives()
             plan = self.map.PlanShellsDevice(gathered, world, cap)  # the one host wait of a recompute
-            lap("plan (device) + wait")
+            self._lap("plan (device) + wait")
             if plan["max_count"] <= cap:
                 break
             self._dirty_cap = 2 * plan["max_count"]  # (every rank sees the same counts and takes the same turn)
@@ -444,28 +538,31 @@ class ShardedChisel:
         # the two byte buffers are kept between recomputes and only ever grow (their last readers -- the previous recompute's
         # all-to-all and its drop kernel -- finished before the plan's wait above returned)
         need = (sum(s_bytes), sum(r_bytes))
-        if getattr(self, "_seg_cap", (0, 0))[0] < need[0] or self._seg_cap[1] < need[1]:
-            self._seg_cap = (max(2 * need[0], 1 << 20), max(2 * need[1], 1 << 20))
-            self._seg_send = torch.empty((self._seg_cap[0],), dtype=torch.uint8, device=dev)
-            self._seg_recv = torch.empty((self._seg_cap[1],), dtype=torch.uint8, device=dev)
-            if on_gpu:
-                self._order_map_after_collectives()  # (torch's allocator hands out memory its own stream may still be using)
+        self._segment_buffers(need[0], need[1])
         send, recv = self._seg_send[:need[0]], self._seg_recv[:need[1]]
         self.map.ExportShellsPacked(send)
         if on_gpu:
             self._order_after_map()
-        lap("export (issue)")
+        self._lap("export (issue)")
         self._all_to_all(recv, send, r_bytes, s_bytes)
-        lap("all_to_all (issue)")
+        self._lap("all_to_all (issue)")
         if on_gpu:
             self._order_map_after_collectives()
         self.map.ImportShellsPacked(recv)
-        lap("import (issue)")
+        self._lap("import (issue)")
         # ---- 4.
         self.map.UpdateMeshesPlanned()
         self.map.DropGhostChunks()
-        lap("recompute + drop (issue)")
-        if timing:
+        self._lap("recompute + drop (issue)")
+        # what the next recompute may size its fixed segments from (the wait-free form): the ranks' needs, reduced like its status
+        if post_sizes and ids is None and hasattr(self.map, "PlanShellsQueue"):
+            mine = np.array([0, plan["max_count"], max(s_bytes) if s_bytes else 0, plan["jobs"], int(plan["recv"][:, 0].sum()), plan["send_items"],
+                             min(int(plan["recv"][:, 1].sum()), 2**31 - 1), 0], np.int32)
+            self._status.copy_(torch.from_numpy(mine))
+            self._reduce_status()
+            self._pending = "sizes"
+            self._lap("sizes for the next one (issue)")
+        if getattr(self, "_timing", False):
             self.phase_us["recomputes"] = self.phase_us.get("recomputes", 0) + 1
         per_voxel = 12 if getattr(self.map, "use_color", False) else 8
         total = int(plan["recv"][:, 1].sum())
@@ -478,9 +575,101 @@ class ShardedChisel:
         self.last_plan = plan
         return int(total * per_voxel)
 
+    def _segment_buffers(self, n_send, n_recv):
+        torch, dev = self.x.torch, self.x.device
+        if getattr(self, "_seg_cap", (0, 0))[0] < n_send or self._seg_cap[1] < n_recv:
+            self._seg_cap = (max(2 * n_send, 1 << 20), max(2 * n_recv, 1 << 20))
+            self._seg_send = torch.empty((self._seg_cap[0],), dtype=torch.uint8, device=dev)
+            self._seg_recv = torch.empty((self._seg_cap[1],), dtype=torch.uint8, device=dev)
+            if dev.type == "cuda":
+                self._order_map_after_collectives()  # (torch's allocator hands out memory its own stream may still be using)
+
+    def _recompute_wait_free(self):
+        """The recompute as ONE burst of queued work -- the host reads nothing until Settle():
+             dirty ids -> all_gather -> plan + status + export (map stream) -> all_reduce(status, MAX) + all_to_all of EQUAL splits (collective
+             stream) -> import + mesh + drop (map stream).
+        The segments' size comes from the previous recompute (the largest segment any rank sent, plus a half); a rank whose list, plan or
+        segment does not fit says so in its status, the all-reduce tells everybody, and the kernels behind the exchange do nothing at all:
+        Settle() then makes the recompute again the blocking way, from a map nobody has touched."""
+        torch, dist, world, dev = self.x.torch, self.x.dist, self.x.world, self.x.device
+        on_gpu = dev.type == "cuda"
+        est = self._est
+        self._lap(None)
+        if 2 * est["max_count"] > getattr(self, "_dirty_cap", 1 << 12):
+            self._dirty_cap = 4 * est["max_count"]  # (the same figures, the same turn on every rank)
+        cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 12)
+        stride = (est["seg_bytes"] + est["seg_bytes"] // 2 + 4096 + 15) // 16 * 16
+        self._last_stride = stride
+        buf, gathered = self._mesh_buffers(cap)
+        self._segment_buffers(world * stride, world * stride)
+        send, recv = self._seg_send[:world * stride], self._seg_recv[:world * stride]
+        self._list_dirty(buf, None)
+        self._lap("dirty ids (issue)")
+        self._gather_dirty(gathered, buf)
+        self._lap("all_gather (issue)")
+        if on_gpu:
+            self._order_map_after_collectives()
+        self.map.PlanShellsQueue(gathered, world, cap, stride, self._status)
+        self.map.ExportShellsFixed(send, stride)
+        if on_gpu:
+            self._order_after_map()
+        self._lap("plan + export (issue)")
+        self._reduce_status()
+        self._all_to_all(recv, send, None, None)
+        self._lap("all_reduce + all_to_all (issue)")
+        if on_gpu:
+            self._order_map_after_collectives()
+        self.map.ImportShellsFixed(recv, stride, self._status, est["jobs"], est["recv_items"])
+        self._lap("import (issue)")
+        self.map.UpdateMeshesPlanned()
+        self.map.DropGhostChunks()
+        self._lap("recompute + drop (issue)")
+        self._pending = "recompute"
+        self.wire_bytes = getattr(self, "wire_bytes", 0) + (world - 1) * stride
+        self.wait_free_recomputes = getattr(self, "wait_free_recomputes", 0) + 1
+        if getattr(self, "_timing", False):
+            self.phase_us["recomputes"] = self.phase_us.get("recomputes", 0) + 1
+        per_voxel = 12 if getattr(self.map, "use_color", False) else 8
+        return int(est["recv_voxels"]) * per_voxel
+
+    def Settle(self):
+        """The host's look at what UpdateMeshes left in flight -- before it (or anybody who goes to self.map directly) changes or reads the
+        map again.  After a blocking recompute: the sizes the ranks exchanged for the next one.  After a wait-free one: its all-reduced
+        status; the mesh step's totals are settled (chisel_hip_shell_commit), and a recompute that was called off is made again, blocking."""
+        pending = getattr(self, "_pending", None)
+        if not pending:
+            return
+        self._pending = None
+        self._lap(None)
+        if self._status_event is not None:
+            self._status_event.synchronize()
+        st = [int(v) for v in self._status_host.tolist()]
+        self._lap("settle (wait)")
+        self._est = {"max_count": st[1], "seg_bytes": st[2], "jobs": st[3], "recv_items": st[4], "send_items": st[5], "recv_voxels": st[6]}
+        if __import__("os").environ.get("CHISEL_HIP_WF_DEBUG") and self.x.rank == 0:
+            print("settle", pending, "stride", getattr(self, "_last_stride", None), "status", st, file=__import__("sys").stderr, flush=True)
+        if pending == "recompute":
+            self.map.ShellCommit(st[0] != 0)
+            per_voxel = 12 if getattr(self.map, "use_color", False) else 8
+            self.shell_bytes = getattr(self, "_shell_bytes_all", 0)
+            self.whole_chunk_bytes = st[7] * int(self.map.chunk_size[0]) ** 3 * per_voxel  # (as in the blocking form: both cover the recomputes before this one)
+            if st[0] == 0:
+                self._shell_bytes_all = self.shell_bytes + st[6] * per_voxel  # (of the rank that received most)
+            else:
+                self.wait_free_aborts = getattr(self, "wait_free_aborts", 0) + 1
+                self.last_abort = st[0]
+                self.abort_bits = getattr(self, "abort_bits", {})
+                self.abort_bits[st[0]] = self.abort_bits.get(st[0], 0) + 1
+                self.last_abort_status = st
+                self._recompute_blocking(None, post_sizes=True)
+            self._lap("settle (commit)")
+
     def _order_after_map(self):
         """the collective queued next on torch's current stream starts after what the map has queued so far (an event, no host wait)"""
         torch = self.x.torch
+        if hasattr(self.map, "order_stream_after_map"):  # one call into the library instead of three through torch (19 -> 4 us)
+            self.map.order_stream_after_map(torch.cuda.current_stream().cuda_stream)
+            return
         ev = self._ev = getattr(self, "_ev", None) or torch.cuda.Event()
         ev.record(torch.cuda.current_stream())  # (a first record creates the hipEvent_t behind the torch object)
         self.map.record_event(ev.cuda_event)
@@ -489,18 +678,23 @@ class ShardedChisel:
     def _order_map_after_collectives(self):
         """the map's next call starts after the collectives queued on torch's current stream"""
         torch = self.x.torch
+        if hasattr(self.map, "order_map_after_stream"):
+            self.map.order_map_after_stream(torch.cuda.current_stream().cuda_stream)
+            return
         ev = self._ev2 = getattr(self, "_ev2", None) or torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.map.wait_event(ev.cuda_event)
 
     def NumChunks(self):
         torch, dist = self.x.torch, self.x.dist
+        self.Settle()
         n = torch.tensor([self.map.NumChunks()], dtype=torch.int64, device=self.x.recv[0].device)
         if self.x.world > 1:
             dist.all_reduce(n)
         return int(n.item())
 
     def GatherChunkIDs(self):
+        self.Settle()
         ids = np.asarray(self.map.GetChunkIDs(), np.int32).reshape(-1, 3)
         if self.x.world == 1:
             return ids

@@ -99,4 +99,4 @@ def test_rccl_code_path_with_one_rank():
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1_check.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "nccl world-1 check ok" in out.stdout and "sharded mesher over nccl, one rank" in out.stdout
+    assert "nccl world-1 check ok" in out.stdout and "sharded mesher over nccl, one rank" in out.stdout and "wait-free form over nccl, one rank" in out.stdout

@@ -71,8 +71,9 @@ def test_mesh_chunk_sizes(oracle_mod, N, res, W, H):
     assert n > 0 and nv > 0
 
 
+@pytest.mark.parametrize("wait_free", [False, True])
 @pytest.mark.parametrize("n_shards", [2, 4, 8])
-def test_sharded_map_meshes_equal_the_unsharded_map(oracle_mod, n_shards):
+def test_sharded_map_meshes_equal_the_unsharded_map(oracle_mod, n_shards, wait_free):
     """SURVEY.md 8e "meshing across shards": every shard meshes the chunks it owns with its neighbours' chunks imported as
     ghosts (export_chunks / import_ghost_chunks / update_meshes_of / drop_ghost_chunks, cvids_amd/sharded.py).  The union
     of the shards' meshes equals the oracle's meshes of the whole map element for element, two recomputes in a row, and
@@ -94,7 +95,10 @@ def test_sharded_map_meshes_equal_the_unsharded_map(oracle_mod, n_shards):
         def GetMesh(self, cid):
             return shards[ch.chunk_owner(cid, n_shards, 2)].GetMesh(cid)
 
-    for start, count in ((0, 4), (4, 3)):
+    # wait_free: the first recompute has nothing to size its segments from and takes the blocking form; the second is the wait-free form
+    # (chisel_hip_shell_plan_queue ...: fixed segments, nothing read in between); the third gets segments of 64 bytes: called off on the
+    # device -- no ghost, no mesh, no dirty flag cleared, on any shard -- and made again the blocking way
+    for turn, (start, count) in enumerate(((0, 4), (4, 3), (7, 2)) if wait_free else ((0, 4), (4, 3))):
         part = make_frames("sphere_room", count, 64, 48, start=start)
         for d, p in part:
             om.integrate_depth_color(d, p, intr, color, near=cam.near_plane, far=cam.far_plane)
@@ -102,7 +106,10 @@ def test_sharded_map_meshes_equal_the_unsharded_map(oracle_mod, n_shards):
             s_.IntegrateBatch(integ, [(d, p, cam) for d, p in part], [(color, p, cam) for _, p in part])
         before = [s_.NumChunks() for s_ in shards]
         om.update_meshes(force=True)
-        group.UpdateMeshes(force=True)
+        st = group.UpdateMeshes(force=True, wait_free=wait_free, stride=64 if turn == 2 else None)
+        if wait_free:
+            assert (st is None) if turn == 0 else (st[0] == (4 if turn == 2 else 0) and st[3] > 0 and st[4] > 0 and st[2] > 64)
+            assert getattr(group, "wait_free_aborts", 0) == (1 if turn == 2 else 0)
         n, nv = _compare_meshes(om, Union(), True)
         assert n > 20 and nv > 3000
         assert [s_.NumChunks() for s_ in shards] == before  # ghosts dropped

@@ -200,11 +200,12 @@ class MeshRecordingMap(RecordingMap):
         from cvids_amd.sharded import segment_bytes
         return segment_bytes(int(items), int(voxels), False)
 
-    def ExportShellsPacked(self, out):
+    def _segments(self):
+        """one byte segment per peer, as the device's export kernel lays them out"""
         from cvids_amd.sharded import pack_segment, shell_box_coords
         res = self._resident()
         _, send, _ = self._plan
-        blob = b""
+        segs = []
         rng = np.random.default_rng(self.rank)
         for p in range(self.world):
             items = list(send.get(p, []))
@@ -220,9 +221,64 @@ class MeshRecordingMap(RecordingMap):
             seg = bytearray(pack_segment(np.array(items, np.int32).reshape(-1, 4), np.array(found, np.int32), sdf, sdf + np.float32(0.5), None))
             rec = np.frombuffer(seg, np.int32, 8 * len(items), 16).reshape(-1, 8)
             rec[:, 5] = first
-            blob += bytes(seg)
+            segs.append(bytes(seg))
+        return segs
+
+    def ExportShellsPacked(self, out):
+        blob = b"".join(self._segments())
         assert len(blob) == out.numel()
         out.copy_(__import__("torch").from_numpy(np.frombuffer(blob, np.uint8).copy()))
+
+    # ---- the wait-free form (chisel_hip_shell_plan_queue ...) restated: fixed strides, a status vector, and nothing at all behind the
+    # exchange when the all-reduced status calls the recompute off
+    force_overflow = False  # a test's way to make ONE rank report a segment that does not fit
+
+    def PlanShellsQueue(self, gathered, world, cap, stride, status):
+        from cvids_amd.sharded import segment_bytes
+        plan = self.PlanShellsDevice(gathered, world, cap)
+        cut = plan["max_count"] > cap
+        if cut:
+            self._plan = ([], {}, {})
+        largest = max(segment_bytes(int(i), int(v), False) for i, v in plan["send"])
+        flags = (1 if cut else 0) | (4 if (largest > stride or self.force_overflow) else 0)
+        vals = [flags, plan["max_count"], largest, plan["jobs"], int(plan["recv"][:, 0].sum()), plan["send_items"], int(plan["recv"][:, 1].sum()), 0]
+        status.copy_(__import__("torch").tensor(vals, dtype=status.dtype))
+        self.queued_plans = getattr(self, "queued_plans", 0) + 1
+
+    def ExportShellsFixed(self, out, stride):
+        blob = b""
+        for seg in self._segments():
+            if len(seg) > stride:
+                seg = np.array([0, 0, 1, 0], np.int32).tobytes()
+            blob += seg + bytes(stride - len(seg))
+        assert len(blob) == out.numel() == self.world * stride
+        out.copy_(__import__("torch").from_numpy(np.frombuffer(blob, np.uint8).copy()))
+
+    def ImportShellsFixed(self, buf, stride, status, jobs_hint=0, items_hint=0):
+        from cvids_amd.sharded import segment_bytes, shell_box_coords, unpack_segment
+        self._called_off = int(status[0]) != 0
+        if self._called_off:
+            return
+        self.ghosts_created = getattr(self, "ghosts_created", 0)
+        raw = np.asarray(buf)
+        _, _, recv = self._plan
+        for o in range(self.world):
+            seg = raw[o * stride:(o + 1) * stride]
+            head = np.frombuffer(seg.tobytes()[:16], np.int32)
+            assert head[2] == 0  # (the status would have called the recompute off)
+            rec, sdf, wgt, _ = unpack_segment(seg[:segment_bytes(int(head[0]), int(head[1]), False)], False)
+            assert sorted(map(tuple, rec[:, :4].tolist())) == sorted(recv.get(o, []))
+            for x, y, z, code, found, first, _, _ in rec.tolist():
+                if not found:
+                    continue
+                cells = self.ghosts.setdefault((x, y, z), {})
+                for k, v in enumerate(shell_box_coords(code, self.EDGE)):
+                    cells[v] = (float(sdf[first + k]), float(wgt[first + k]))
+
+    def ShellCommit(self, aborted):
+        self.commits = getattr(self, "commits", []) + [bool(aborted)]
+        assert bool(aborted) == getattr(self, "_called_off", False)
+        self._called_off = False
 
     def ImportShellsPacked(self, buf):
         from cvids_amd.sharded import segment_bytes, shell_box_coords, unpack_segment
@@ -245,12 +301,17 @@ class MeshRecordingMap(RecordingMap):
         assert at == len(raw)
 
     def UpdateMeshesPlanned(self):
+        if getattr(self, "_called_off", False):
+            return
+        self.mesh_steps = getattr(self, "mesh_steps", 0) + 1
         self.meshed = (list(self._plan[0]), dict(self.ghosts))
 
     def UpdateMeshesOf(self, ids):
         self.meshed = ([tuple(int(v) for v in i) for i in np.asarray(ids).reshape(-1, 3)], dict(self.ghosts))
 
     def DropGhostChunks(self):
+        if getattr(self, "_called_off", False):
+            return
         self.dropped += 1
         self.ghosts = {}
 
@@ -335,6 +396,81 @@ def test_sharded_update_meshes_protocol_world2(hip_lib, dirty_cap):
         assert nbytes < 0.7 * 8 * E ** 3 * n_ghost_ids  # less than whole ghost chunks would take, even with two shards, 8^3 chunks and unmerged boxes
         assert all(chunk_owner(g, world, 2) != rank for g in ghosts)
     assert all_jobs == union
+
+
+def _wait_free_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from cvids_amd.sharded import FrameExchange, ShardedChisel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = FrameExchange(W, H, K, torch.device("cpu"), dist, channels=0)
+        local = MeshRecordingMap(rank, world)
+        sm = ShardedChisel(local, x, integrator=None)
+        snap = lambda: (sorted(local.meshed[0]), {g: dict(c) for g, c in local.meshed[1].items()})
+        log = {}
+        # 1. nothing to size the segments from yet: the blocking form, which leaves the ranks' sizes behind
+        sm.UpdateMeshes(force=True, wait_free=True)
+        assert getattr(sm, "wait_free_recomputes", 0) == 0 and local.mesh_steps == 1
+        first = snap()
+        sm.Settle()
+        assert sm._est["seg_bytes"] > 0 and sm._est["jobs"] > 0
+        # 2. the wait-free form: the same meshes from the same ghosts, nothing read in between, one commit
+        nbytes = sm.UpdateMeshes(force=True, wait_free=True)
+        assert sm.wait_free_recomputes == 1 and local.queued_plans == 1 and local.mesh_steps == 2 and nbytes > 0
+        sm.Settle()
+        assert snap() == first and local.commits == [False] and local.dropped == 2 and not local.ghosts
+        # 3. segments far too small on every rank: called off (no mesh step, no ghost, no drop), then made again the blocking way by Settle
+        sm._est["seg_bytes"] = 64
+        sm.UpdateMeshes(force=True, wait_free=True)
+        assert sm.wait_free_recomputes == 2 and local.mesh_steps == 2 and local.dropped == 2 and not local.ghosts
+        sm.NumChunks()  # (any method of the sharded map settles first)
+        assert sm.wait_free_aborts == 1 and sm.last_abort == 4 and local.commits == [False, True] and local.mesh_steps == 3 and snap() == first
+        # 4. ONE rank whose segment does not fit: the all-reduce tells the other, both call the recompute off and make it again
+        sm.Settle()
+        assert sm._est["seg_bytes"] > 64
+        local.force_overflow = rank == 1
+        sm.UpdateMeshes(force=True, wait_free=True)
+        assert sm.wait_free_recomputes == 3 and local.mesh_steps == 3
+        local.force_overflow = False
+        sm.Settle()
+        assert sm.wait_free_aborts == 2 and local.mesh_steps == 4 and snap() == first and local.commits == [False, True, True]
+        # 5. a dirty list that outgrows the gathered tensor: called off as well, and the blocking form grows the tensor
+        sm.Settle()
+        sm._dirty_cap = 4
+        sm._est["max_count"] = 1
+        sm.UpdateMeshes(force=True, wait_free=True)
+        sm.Settle()
+        assert sm.wait_free_aborts == 3 and (sm.last_abort & 1) and sm._dirty_cap > 4 and snap() == first
+        # 6. and on it goes
+        sm.Settle()
+        sm.UpdateMeshes(force=True, wait_free=True)
+        sm.Settle()
+        assert sm.wait_free_recomputes == 5 and sm.wait_free_aborts == 3 and snap() == first
+        out.put((rank, True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_wait_free_sharded_recompute_world2(hip_lib):
+    """ShardedChisel.UpdateMeshes(wait_free=True) between two processes (gloo), against the blocking form: same jobs, same ghosts, same
+    values; a recompute whose segments (on both ranks, on one rank only) or whose dirty list do not fit is called off on every rank before
+    anything has happened and made again by Settle()."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wait_free_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=170) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
 
 
 def test_mesh_shell_plan_is_consistent_across_ranks(hip_lib):

@@ -62,6 +62,27 @@ for cid in ids_a:
         assert np.array_equal(np.asarray(a[key]).view(np.uint32), np.asarray(b[key]).view(np.uint32)), (cid, key)
     nv += len(a["vertices"])
 print("sharded mesher over nccl, one rank: %d meshes, %d vertices identical" % (len(ids_a), nv))
+# ... and its wait-free form (fixed segments, all_reduce of the status, all_to_all of equal splits, nothing read in between): a second
+# stretch of frames into both maps, the first recompute above left the sizes behind
+moved = sh.UpdateMeshes(force=True, wait_free=True)  # (the blocking form once more: it is the one that posts the sizes)
+ref.UpdateMeshes(force=True)
+for b in range(4):
+    for mm in (ref, m):
+        mm.IntegrateBatch(integ, [(torch.from_numpy(frames[(b * K + j + 3) % len(frames)][0]).to(dev), frames[(b * K + j + 3) % len(frames)][1], cam) for j in range(K)])
+sh.Settle()
+assert sh._est is not None
+sh.UpdateMeshes(force=True, wait_free=True)
+ref.UpdateMeshes(force=True)
+assert sh.wait_free_recomputes == 1
+sh.Settle()
+assert getattr(sh, "wait_free_aborts", 0) == 0 and len(m.GetMeshesToUpdate()) == 0
+ids_a, ids_b = sorted(map(tuple, ref.GetMeshIDs().tolist())), sorted(map(tuple, m.GetMeshIDs().tolist()))
+assert ids_a == ids_b and len(ids_a) > 20, (len(ids_a), len(ids_b))
+for cid in ids_a:
+    a, b = ref.GetMesh(cid), m.GetMesh(cid)
+    for key in ("vertices", "normals", "grids"):
+        assert np.array_equal(np.asarray(a[key]).view(np.uint32), np.asarray(b[key]).view(np.uint32)), (cid, key)
+print("wait-free form over nccl, one rank: %d meshes identical, status %s" % (len(ids_a), sh._est))
 t = torch.tensor([1.0], device=dev)
 dist.all_reduce(t)
 dist.barrier()
