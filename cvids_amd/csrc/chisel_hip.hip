@@ -2177,7 +2177,7 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
         m->shell_redrop = m->pending_meshes.unchecked;  // (ghost_packed stays: the buffer is the caller's until its next recompute)
         m->shell_fixed_ghosts = false;
         if (!m->shell_redrop) m->ghost_packed = nullptr;
-    } else if (m->ghost_packed) {
+    } else if (m->ghost_packed && !m->shell_redrop) {
         // the ghosts of chisel_hip_import_shells_packed: named by the items of the received segments, which the caller still holds
         HIP_TRY(hipSetDevice(m->device));
         { m->topology_epoch++; m->dirty_tail_queued = false; }
@@ -2538,6 +2538,7 @@ int chisel_hip_import_shells_packed(chisel_hip_map *m, const void *in_dev, int64
         m->ghost_packed = in;
         m->ghost_segments = G;
         m->ghost_packed_items = items;
+        m->shell_fixed_ghosts = m->shell_redrop = false;
     }
     return CHISEL_HIP_OK;
 }

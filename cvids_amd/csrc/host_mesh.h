@@ -151,6 +151,10 @@ void clear_meshes(chisel_hip_map *m) {
     m->pending_meshes.active = false;
     m->pending_meshes.unchecked = false;
     m->deferred_set = -1;  // (whatever was queued behind an unseen recompute is void with the map; reset_map_kernel clears MC_LATCH)
+    m->ghost_packed = nullptr;  // (... and so are the ghosts of a sharded recompute and what its wait-free form left open)
+    m->ghost_packed_items = 0;
+    m->shell_fixed_ghosts = m->shell_redrop = m->shell_uncommitted = false;
+    m->shell_abort_dev = nullptr;
     for (MeshArena &A : m->arenas) free_arena(m, A);
     m->arenas.clear();
     m->meshes.clear();
