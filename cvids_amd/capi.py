@@ -63,7 +63,7 @@ EXPORTS = [
     "chisel_hip_synchronize", "chisel_hip_wait_event", "chisel_hip_record_event", "chisel_hip_order_stream_after_map", "chisel_hip_order_map_after_stream", "chisel_hip_integrate_depth", "chisel_hip_integrate_depth_color",
     "chisel_hip_integrate_batch", "chisel_hip_integrate_pointcloud", "chisel_hip_garbage_collect", "chisel_hip_update_meshes", "chisel_hip_num_chunks",
     "chisel_hip_list_chunks", "chisel_hip_has_chunk", "chisel_hip_download_chunk", "chisel_hip_upload_chunk",
-    "chisel_hip_meshes_to_update", "chisel_hip_meshes_to_update_since", "chisel_hip_meshes_to_update_prefetch", "chisel_hip_shell_plan_device", "chisel_hip_shell_segment_bytes", "chisel_hip_export_shells_packed", "chisel_hip_import_shells_packed", "chisel_hip_update_meshes_planned", "chisel_hip_shell_plan_queue", "chisel_hip_export_shells_fixed", "chisel_hip_import_shells_fixed", "chisel_hip_shell_commit", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
+    "chisel_hip_meshes_to_update", "chisel_hip_meshes_to_update_since", "chisel_hip_meshes_to_update_prefetch", "chisel_hip_shell_plan_device", "chisel_hip_shell_segment_bytes", "chisel_hip_export_shells_packed", "chisel_hip_import_shells_packed", "chisel_hip_update_meshes_planned", "chisel_hip_shell_plan_queue", "chisel_hip_import_shells_fixed", "chisel_hip_shell_commit", "chisel_hip_num_meshes", "chisel_hip_list_meshes", "chisel_hip_mesh_size",
     "chisel_hip_download_mesh", "chisel_hip_get_sdf", "chisel_hip_get_sdf_and_gradient", "chisel_hip_save_ply",
     "chisel_hip_save_map", "chisel_hip_load_map", "chisel_hip_export_chunks", "chisel_hip_import_ghost_chunks",
     "chisel_hip_drop_ghost_chunks", "chisel_hip_update_meshes_of", "chisel_hip_condition_depth", "chisel_hip_condition_color", "chisel_hip_publish_cloud",
@@ -181,8 +181,7 @@ def load_library():
         L.chisel_hip_export_shells_packed.argtypes = [vp, vp, C.c_int64]
         L.chisel_hip_import_shells_packed.argtypes = [vp, vp, C.c_int64]
         L.chisel_hip_update_meshes_planned.argtypes = [vp]
-        L.chisel_hip_shell_plan_queue.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, vp]
-        L.chisel_hip_export_shells_fixed.argtypes = [vp, vp, C.c_int64]
+        L.chisel_hip_shell_plan_queue.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, vp, vp, C.c_int]
         L.chisel_hip_import_shells_fixed.argtypes = [vp, vp, C.c_int64, vp, C.c_int, C.c_int]
         L.chisel_hip_shell_commit.argtypes = [vp, C.c_int]
         L.chisel_hip_mesh_shell_plan.argtypes = [i32p, C.c_int64, C.c_int, C.c_int, C.c_int, i32p, C.c_int64, i64p, i32p, C.c_int64, i64p]

@@ -385,12 +385,10 @@ class Chisel:
         self._packed_keep = getattr(self, "_packed_keep", []) + [buf]
 
     # ---- ... and its wait-free form (chisel_hip.h: chisel_hip_shell_plan_queue ...): every tensor below stays the caller's until ShellCommit
-    def PlanShellsQueue(self, gathered, world, cap, stride, status):
-        """queues the plan and this rank's status (int32 CUDA tensor of SHELL_STATUS_INTS entries); nothing is waited for"""
-        check(self.L.chisel_hip_shell_plan_queue(self.h, gathered.data_ptr(), int(world), int(cap), int(stride), status.data_ptr()))
-
-    def ExportShellsFixed(self, out, stride):
-        check(self.L.chisel_hip_export_shells_fixed(self.h, out.data_ptr(), int(stride)))
+    def PlanShellsQueue(self, gathered, world, cap, stride, status, out, send_items_hint=0):
+        """queues the plan, the export of `world` segments of `stride` bytes into `out` (uint8 CUDA tensor) and this rank's status (int32 CUDA
+        tensor of SHELL_STATUS_INTS entries); nothing is waited for"""
+        check(self.L.chisel_hip_shell_plan_queue(self.h, gathered.data_ptr(), int(world), int(cap), int(stride), status.data_ptr(), out.data_ptr(), int(send_items_hint)))
 
     def ImportShellsFixed(self, buf, stride, status, jobs_hint=0, items_hint=0):
         """buf: the received segments; status: the ALL-REDUCED status vector (word 0 != 0: nothing below happens on the device)"""

@@ -318,6 +318,7 @@ struct chisel_hip_map {
     // recompute's host-side bookkeeping (pending_mesh_ids) waits for chisel_hip_shell_commit
     hipEvent_t order_events[2] = {nullptr, nullptr};  // chisel_hip_order_stream_after_map / chisel_hip_order_map_after_stream
     int64_t shell_stride = 0;
+    unsigned shell_items_grid = 2048;
     const int *shell_abort_dev = nullptr;
     bool shell_fixed_ghosts = false, shell_redrop = false, shell_uncommitted = false;
     std::unordered_set<uint64_t, IdHash> pending_mesh_ids;             // meshesToUpdate entries whose source chunk is gone
@@ -914,6 +915,13 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
     return launch_back<N>(m, bs, IP, color, total, inline_resolve, false);
 }
 
+// the ghosts of a wait-free sharded recompute go (kernels_map.h: the drop in two passes); latch: leave them while the mesh step has to be emitted again
+void launch_fixed_drop(chisel_hip_map *m, const int *latch) {
+    hipLaunchKernelGGL(shell_reset_boxes_fixed_kernel, dim3(m->shell_items_grid), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, m->cfg.n_shards, m->N,
+                       m->shell_abort_dev, latch);
+    hipLaunchKernelGGL(shell_remove_ghosts_fixed_kernel, dim3((m->shell_items_grid + 255) / 256), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride,
+                       m->cfg.n_shards, m->shell_abort_dev, latch);
+}
 // the integration of a set that was queued behind a recompute which then did not fit: its kernel left at once (MC_LATCH), here it is again
 int replay_deferred_set(chisel_hip_map *m, int set) {
     chisel_hip_map::BatchSet &bs = m->sets[set];
@@ -2170,8 +2178,7 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
         // then the kernel leaves the ghosts where they are (MC_LATCH) and check_mesh_totals launches it again behind the second emission.
         HIP_TRY(hipSetDevice(m->device));
         { m->topology_epoch++; m->dirty_tail_queued = false; }
-        hipLaunchKernelGGL(shell_drop_ghosts_fixed_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, m->cfg.n_shards, m->V,
-                           m->shell_abort_dev, (const int *)(m->view.mesh_ctl ? m->view.mesh_ctl + MC_LATCH : nullptr));
+        launch_fixed_drop(m, m->view.mesh_ctl ? m->view.mesh_ctl + MC_LATCH : nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(note_map_mutation(m));
         m->shell_redrop = m->pending_meshes.unchecked;  // (ghost_packed stays: the buffer is the caller's until its next recompute)
@@ -2494,7 +2501,7 @@ int chisel_hip_export_shells_packed(chisel_hip_map *m, void *out_dev, int64_t by
         m->input_event = nullptr;
     }
     hipLaunchKernelGGL(shell_export_kernel, dim3((unsigned)std::max(1, m->shell_send_items)), dim3(256), 0, m->stream, m->view, m->shell_plan, m->N, m->cfg.n_shards,
-                       static_cast<unsigned char *>(out_dev), 0ll);
+                       static_cast<unsigned char *>(out_dev), 0ll, 0, (int *)nullptr);
     HIP_TRY(hipGetLastError());
     return CHISEL_HIP_OK;
 }
@@ -2544,13 +2551,15 @@ int chisel_hip_import_shells_packed(chisel_hip_map *m, const void *in_dev, int64
 }
 
 // ---- the wait-free form of the same recompute (kernels_map.h: "the wait-free form"; include/chisel_hip.h) ----------------------------------
-// Step 2 without the host: the plan's kernels and, behind them, this rank's status vector into `status_dev` (SHELL_STATUS_INTS ints, the
-// caller's: it all-reduces them with MAX in front of the exchange).  The plan's buffers keep the sizes the last chisel_hip_shell_plan_device
-// grew them to; a plan that outgrows them is one of the things the status reports.
-int chisel_hip_shell_plan_queue(chisel_hip_map *m, const int *gathered_dev, int world, int cap, int64_t seg_stride, int *status_dev) {
+// Steps 2 and 3 without the host: the plan's kernels and, behind them, the export into `world` segments of `seg_stride` bytes each (out_dev), whose
+// first workgroup also writes this rank's status vector into `status_dev` (SHELL_STATUS_INTS ints, the caller's: it all-reduces them with MAX
+// in front of the exchange).  A segment that does not fit carries a head that says so; the status says it too.  The plan's buffers keep the
+// sizes the last chisel_hip_shell_plan_device grew them to; a plan that outgrows them is one of the things the status reports.
+// send_items_hint: what the previous recompute sent (grid size); 0 = unknown.
+int chisel_hip_shell_plan_queue(chisel_hip_map *m, const int *gathered_dev, int world, int cap, int64_t seg_stride, int *status_dev, void *out_dev, int send_items_hint) {
     SETTLE(m);
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
-    if (!m || !gathered_dev || !status_dev || cap < 1 || world < 1 || world != m->cfg.n_shards || world > SHELL_MAX_SHARDS || seg_stride < 16 || (seg_stride & 15))
+    if (!m || !gathered_dev || !status_dev || !out_dev || cap < 1 || world < 1 || world != m->cfg.n_shards || world > SHELL_MAX_SHARDS || seg_stride < 16 || (seg_stride & 15))
         return fail(CHISEL_HIP_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(m->device));
     int rc = check_mesh_totals(m);  // (the recompute before this one: its second emission, if any, and the drop behind it come first)
@@ -2576,25 +2585,11 @@ int chisel_hip_shell_plan_queue(chisel_hip_map *m, const int *gathered_dev, int 
     const long long threads = 27ll * cap * world;
     hipLaunchKernelGGL(shell_jobs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, gathered_dev, world, cap, S, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
     hipLaunchKernelGGL(shell_items_kernel, dim3((unsigned)(S.jobset_capacity / 8)), dim3(256), 0, m->stream, S, m->N, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
-    hipLaunchKernelGGL(shell_status_kernel, dim3(1), dim3(64), 0, m->stream, S, cap, (long long)seg_stride, m->view.rgbw != nullptr ? 1 : 0, m->cfg.n_shards, status_dev);
+    // (a workgroup per item when the hint holds, several items per workgroup when there are more)
+    const unsigned egrid = (unsigned)std::min<long long>(16384, std::max<long long>(256, (long long)send_items_hint + send_items_hint / 4 + 64));
+    hipLaunchKernelGGL(shell_export_kernel, dim3(egrid), dim3(256), 0, m->stream, m->view, S, m->N, m->cfg.n_shards, static_cast<unsigned char *>(out_dev), (long long)seg_stride, cap, status_dev);
     HIP_TRY(hipGetLastError());
     m->shell_stride = seg_stride;
-    return CHISEL_HIP_OK;
-}
-// Step 3, owner side: `world` segments of `seg_stride` bytes each into out_dev (the stride of the plan just queued).  A segment that does not fit
-// carries a head that says so; the status said it before.
-int chisel_hip_export_shells_fixed(chisel_hip_map *m, void *out_dev, int64_t seg_stride) {
-    SETTLE(m);
-    if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
-    if (!m || !out_dev || seg_stride != m->shell_stride || seg_stride < 16) return fail(CHISEL_HIP_ERR_INVALID, "bad argument (the stride is the one of chisel_hip_shell_plan_queue)");
-    HIP_TRY(hipSetDevice(m->device));
-    if (m->input_event) {
-        HIP_TRY(hipStreamWaitEvent(m->stream, m->input_event, 0));
-        m->input_event = nullptr;
-    }
-    hipLaunchKernelGGL(shell_export_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->shell_plan, m->N, m->cfg.n_shards, static_cast<unsigned char *>(out_dev),
-                       (long long)seg_stride);
-    HIP_TRY(hipGetLastError());
     return CHISEL_HIP_OK;
 }
 // Steps 4-6 behind the exchange: ghosts from the received segments, the plan's jobs meshed, the ghosts dropped -- all of it queued, none of
@@ -2613,10 +2608,10 @@ int chisel_hip_import_shells_fixed(chisel_hip_map *m, const void *in_dev, int64_
     int rc = maybe_grow(m, std::max(256, 2 * items_hint));  // (ghosts take slots of this shard's pool until they are dropped again)
     if (rc) return rc;
     const unsigned char *in = static_cast<const unsigned char *>(in_dev);
-    hipLaunchKernelGGL(shell_ensure_ghosts_fixed_kernel, dim3(64), dim3(256), 0, m->stream, m->view, in, (long long)seg_stride, m->cfg.n_shards, status_dev,
-                       reinterpret_cast<unsigned long long *>(m->shell_plan.ctl + 16 + 4 * SHELL_MAX_SHARDS));
-    hipLaunchKernelGGL(shell_import_fixed_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, in, (long long)seg_stride, m->cfg.n_shards, m->N, status_dev);
-    hipLaunchKernelGGL(shell_abort_kernel, dim3(1), dim3(64), 0, m->stream, status_dev, m->shell_plan.ctl);
+    m->shell_items_grid = (unsigned)std::min<long long>(16384, std::max<long long>(256, (long long)items_hint + items_hint / 4 + 64));  // (a workgroup per item when the hint holds)
+    hipLaunchKernelGGL(shell_ensure_ghosts_fixed_kernel, dim3((m->shell_items_grid + 255) / 256), dim3(256), 0, m->stream, m->view, in, (long long)seg_stride, m->cfg.n_shards, status_dev,
+                       reinterpret_cast<unsigned long long *>(m->shell_plan.ctl + 16 + 4 * SHELL_MAX_SHARDS), m->shell_plan.ctl);
+    hipLaunchKernelGGL(shell_import_fixed_kernel, dim3(m->shell_items_grid), dim3(256), 0, m->stream, m->view, in, (long long)seg_stride, m->cfg.n_shards, m->N, status_dev);
     HIP_TRY(hipGetLastError());
     HIP_TRY(note_map_mutation(m));
     m->ghost_packed = in;

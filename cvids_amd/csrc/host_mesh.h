@@ -257,6 +257,7 @@ int recompute_meshes(chisel_hip_map *m) {
 // point that queues map-changing work calls it first; it waits for the count kernel only, not for the stream.
 bool mesh_totals_published(const chisel_hip_map *m) { return ((volatile const int *)m->mesh_totals_host)[5] == m->mesh_seq; }
 int replay_deferred_set(chisel_hip_map *m, int set);  // chisel_hip.hip
+void launch_fixed_drop(chisel_hip_map *m, const int *latch);  // chisel_hip.hip
 int check_mesh_totals(chisel_hip_map *m) {
     if (!m->pending_meshes.unchecked) return CHISEL_HIP_OK;
     m->pending_meshes.unchecked = false;
@@ -364,8 +365,7 @@ int check_mesh_totals(chisel_hip_map *m) {
             HIP_TRY(hipGetLastError());
             latch_guard.settled = true;
             if (m->shell_redrop && m->ghost_packed)  // the ghosts of a wait-free sharded recompute: their drop kernel left them for this emission
-                hipLaunchKernelGGL(shell_drop_ghosts_fixed_kernel, dim3(2048), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, m->cfg.n_shards, m->V,
-                                   m->shell_abort_dev, (const int *)nullptr);
+                launch_fixed_drop(m, nullptr);
             if (deferred >= 0) {
                 int rc_r = replay_deferred_set(m, deferred);
                 if (rc_r) return rc_r;

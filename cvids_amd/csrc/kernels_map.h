@@ -619,14 +619,14 @@ __device__ inline long long shell_segment_at(const unsigned long long *cur, int 
 //     creates a ghost, meshes a job or clears a dirty flag -- the recompute has not happened and is made again the old way (with the host
 //     reading the plan) from an untouched map;
 //   * by the host when it next enters the map (ShardedChisel.Settle), which also takes the next recompute's sizes from it.
-// status: [0] abort bits (1: a rank's dirty list was cut off, 2: job set / job list / item list overflow, 4: a segment exceeds the stride),
+// status (written by the export kernel's first workgroup): [0] abort bits (1: a rank's dirty list was cut off, 2: job set / job list / item list overflow, 4: a segment exceeds the stride),
 // [1] largest dirty count, [2] bytes of this rank's largest segment, [3] its jobs, [4] items it receives, [5] items it sends, [6] voxels it receives, [7] ghost chunks its earlier recomputes created (a running total, for the record)
 constexpr int SHELL_STATUS_INTS = 8;
-__global__ void shell_status_kernel(ShellPlan S, int cap, long long stride, int color, int n_shards, int *status) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// (one thread, behind the plan's kernels: the first workgroup of the export kernel)
+__device__ inline void shell_write_status(const ShellPlan &S, int cap, long long stride, bool color, int n_shards, int *status) {
     long long largest = 0, recv_items = 0, recv_voxels = 0;
     for (int p = 0; p < n_shards; p++) {
-        largest = max(largest, shell_segment_bytes((long long)(S.send_cur[p] & 0xffffffffull), (long long)(S.send_cur[p] >> 32), color != 0));
+        largest = max(largest, shell_segment_bytes((long long)(S.send_cur[p] & 0xffffffffull), (long long)(S.send_cur[p] >> 32), color));
         recv_items += (long long)(S.recv_cnt[p] & 0xffffffffull);
         recv_voxels += (long long)(S.recv_cnt[p] >> 32);
     }
@@ -640,11 +640,7 @@ __global__ void shell_status_kernel(ShellPlan S, int cap, long long stride, int 
     status[6] = (int)min(recv_voxels, 0x7fffffffll);
     status[7] = (int)min((long long)*reinterpret_cast<const unsigned long long *>(S.ctl + 16 + 4 * SHELL_MAX_SHARDS), 0x7fffffffll);  // ghost chunks this rank's earlier recomputes created (for the record)
 }
-// in front of the mesh step: a recompute that was called off has no jobs
-__global__ void shell_abort_kernel(const int *abort, int *ctl) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && *abort) ctl[0] = 0;
-}
-// ... and behind it: the count kernel has emptied the LIST of dirty slots (it does so whatever it meshed), their flags are all still up
+// behind the mesh step of a recompute that was called off: the count kernel has emptied the LIST of dirty slots (it does so whatever it meshed), their flags are all still up
 // (clear_dirty_kernel left them) -- a list that says "overflowed" makes the next listing go by the flags (list_dirty_ids_kernel, mesh_mark_kernel)
 __global__ void shell_abort_relist_kernel(MapView M, const int *abort) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && *abort) M.slot_dirty[2 * (size_t)M.max_chunks] = (unsigned)M.max_chunks + 1u;
@@ -652,9 +648,10 @@ __global__ void shell_abort_relist_kernel(MapView M, const int *abort) {
 // step 3 (owner): one workgroup per send item (or several items per workgroup: the wait-free form launches a fixed grid) packs its box
 // into the destination's segment; workgroup 0 also writes the segment heads.  stride > 0: a segment that exceeds it carries a head that
 // says so ({0, 0, 1, 0}) and nothing else.
-__global__ __launch_bounds__(256) void shell_export_kernel(MapView M, ShellPlan S, int N, int n_shards, unsigned char *out, long long stride) {
+__global__ __launch_bounds__(256) void shell_export_kernel(MapView M, ShellPlan S, int N, int n_shards, unsigned char *out, long long stride, int cap, int *status) {
     __shared__ int s_slot;
     const bool color = M.rgbw != nullptr;
+    if (status && blockIdx.x == 0 && threadIdx.x == 64) shell_write_status(S, cap, stride, color, n_shards, status);  // (the wait-free form)
     if (blockIdx.x == 0 && threadIdx.x < n_shards) {
         int items;
         long long voxels;
@@ -812,7 +809,7 @@ __global__ __launch_bounds__(256) void shell_drop_ghosts_kernel(MapView M, const
 }
 // ---- the same three steps in the wait-free form: segments `stride` bytes apart, their item counts in their heads (a head that says
 // "did not fit" counts as empty), a fixed grid whose workgroups take the items in turn, and nothing at all when the recompute was called off
-// (`abort`: word 0 of the all-reduced status) -- or, for the drop, while the mesh step in front of it is still to be emitted again
+// (`abort`: word 0 of the all-reduced status) -- or, for the drop (two kernels, below), while the mesh step in front of it is still to be emitted again
 // (`latch`: mesh_ctl[MC_LATCH]: the second emission reads the ghosts; check_mesh_totals launches the drop again behind it) ---------------
 __device__ inline void shell_segments_fixed(const unsigned char *__restrict__ in, long long stride, int n_shards, ShellSegments *G) {
     if (threadIdx.x == 0) {
@@ -829,9 +826,12 @@ __device__ inline void shell_segments_fixed(const unsigned char *__restrict__ in
     __syncthreads();
 }
 __global__ __launch_bounds__(256) void shell_ensure_ghosts_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, const int *abort,
-                                                                        unsigned long long *ghosts_created) {
+                                                                        unsigned long long *ghosts_created, int *plan_ctl) {
     __shared__ ShellSegments G;
-    if (abort && *abort) return;
+    if (abort && *abort) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) plan_ctl[0] = 0;  // a recompute that was called off has no jobs (the mesh step behind this kernel reads the count)
+        return;
+    }
     shell_segments_fixed(in, stride, n_shards, &G);
     const int total = G.first_item[n_shards];
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
@@ -851,7 +851,11 @@ __global__ __launch_bounds__(256) void shell_import_fixed_kernel(MapView M, cons
         shell_import_item(M, in, G.off[peer], it, N, &s_slot);
     }
 }
-__global__ __launch_bounds__(256) void shell_drop_ghosts_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, int V, const int *abort,
+// The drop in two passes.  A ghost holds default voxels everywhere but in the boxes that were written into it, so only those are restored
+// (a sixth of the chunk on average; the one-pass kernel above restores all of it, from the one workgroup that wins the ghost's key, while the
+// workgroups of its other items wait for nothing: 40 us per recompute against 12 + 5): pass 1, one workgroup per item, puts the item's box
+// back to default voxels; pass 2, one thread per item, takes the keys out and frees the slots.
+__global__ __launch_bounds__(256) void shell_reset_boxes_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, int N, const int *abort,
                                                                       const int *latch) {
     __shared__ ShellSegments G;
     __shared__ int s_slot;
@@ -860,7 +864,46 @@ __global__ __launch_bounds__(256) void shell_drop_ghosts_fixed_kernel(MapView M,
     const int total = G.first_item[n_shards];
     for (int j = blockIdx.x; j < total; j += gridDim.x) {
         int peer;
-        shell_drop_item(M, shell_received_item(in, G, n_shards, j, peer), V, &s_slot);
+        const int *it = shell_received_item(in, G, n_shards, j, peer);
+        __syncthreads();
+        if (threadIdx.x == 0) s_slot = it[4] ? hash_find(M, it[0], it[1], it[2]) : -1;
+        __syncthreads();
+        const int slot = s_slot, box = it[3];
+        if (slot < 0) continue;
+        const int cx = box & 3, cy = (box >> 2) & 3, cz = (box >> 4) & 3;
+        const int lx = shell_len(cx, N), ly = shell_len(cy, N), lz = shell_len(cz, N);
+        const size_t dst = (size_t)slot * N * N * N;
+        for (int v = threadIdx.x; v < lx * ly * lz; v += 256) {
+            const int x = shell_coord(cx, v % lx, N), y = shell_coord(cy, (v / lx) % ly, N), z = shell_coord(cz, v / (lx * ly), N);
+            const size_t i = dst + (size_t)(z * N + y) * N + x;
+            M.sdf[i] = 99999.0f;  // (fill_default_chunk's values)
+            M.wgt[i] = 0.0f;
+            if (M.rgbw) reinterpret_cast<unsigned *>(M.rgbw)[i] = 0u;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void shell_remove_ghosts_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, const int *abort,
+                                                                        const int *latch) {
+    __shared__ ShellSegments G;
+    if ((abort && *abort) || (latch && *latch)) return;
+    shell_segments_fixed(in, stride, n_shards, &G);
+    const int total = G.first_item[n_shards];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        int peer;
+        const int *it = shell_received_item(in, G, n_shards, j, peer);
+        if (!it[4]) continue;
+        uint64_t where = 0;
+        const int slot = hash_find(M, it[0], it[1], it[2], &where);
+        if (slot < 0) continue;
+        const uint64_t key = pack_id(it[0], it[1], it[2]);
+        if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) != key) continue;  // (another item of the same ghost)
+        M.slot_key[slot] = KEY_EMPTY;
+        M.slot_dirty[slot] = 0;
+        slot_summary(M)[slot] = 0;
+        if (M.mesh_flag) M.mesh_flag[slot] = 0;
+        __threadfence();
+        const int pos = atomicAdd(M.free_top, 1);
+        M.free_list[pos] = slot;
     }
 }
 

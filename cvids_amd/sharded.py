@@ -288,8 +288,7 @@ class LocalShardGroup:
             s_.DirtyIdsDevice(gathered[r])
             s_.synchronize()  # (stands for the all-gather's event)
         for r, s_ in enumerate(self.shards):
-            s_.PlanShellsQueue(gathered.view(-1), W, cap, stride, status[r])
-            s_.ExportShellsFixed(send[r], stride)
+            s_.PlanShellsQueue(gathered.view(-1), W, cap, stride, status[r], send[r])
             s_.synchronize()  # (... for the events in front of the all-reduce and the all-to-all)
         reduced = status.max(dim=0).values.contiguous()  # the all-reduce (MAX)
         recv = [torch.cat([send[o][r * stride:(r + 1) * stride] for o in range(W)]) for r in range(W)]  # the all-to-all of equal splits
@@ -609,8 +608,7 @@ class ShardedChisel:
         self._lap("all_gather (issue)")
         if on_gpu:
             self._order_map_after_collectives()
-        self.map.PlanShellsQueue(gathered, world, cap, stride, self._status)
-        self.map.ExportShellsFixed(send, stride)
+        self.map.PlanShellsQueue(gathered, world, cap, stride, self._status, send, est["send_items"])
         if on_gpu:
             self._order_after_map()
         self._lap("plan + export (issue)")

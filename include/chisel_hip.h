@@ -386,20 +386,21 @@ int chisel_hip_update_meshes_planned(chisel_hip_map *map);
 /* The same recompute with NO host wait (round 6; ShardedChisel.UpdateMeshes(wait_free=True)).  The host reads nothing of the plan: every
  * (sender, receiver) segment has `seg_stride` bytes to itself (a multiple of 16, agreed between the ranks beforehand -- from what the previous
  * recompute needed), the exchange is an all-to-all of equal splits, and the steps behind it read the heads of the received segments.
- *   chisel_hip_shell_plan_queue    queues the plan and, behind it, this rank's STATUS into status_dev (CHISEL_HIP_SHELL_STATUS_INTS ints on the
- *                                  device): [0] bits that call the recompute off (1: a rank's dirty list exceeds `capacity`, 2: the plan's
+ *   chisel_hip_shell_plan_queue    queues the plan and, behind it, the export of `world` segments of seg_stride bytes into out_dev, whose first
+ *                                  workgroup also writes this rank's STATUS into status_dev (CHISEL_HIP_SHELL_STATUS_INTS ints on the device):
+ *                                  [0] bits that call the recompute off (1: a rank's dirty list exceeds `capacity`, 2: the plan's
  *                                  tables overflowed, 4: a segment exceeds seg_stride), [1] largest per-rank dirty count, [2] bytes of this
- *                                  rank's largest segment, [3] its jobs, [4] items it receives, [5] items it sends, [6] voxels it receives, [7] ghost chunks its earlier recomputes created.  The caller all-reduces
- *                                  the vector with MAX (in place) in front of the exchange.
- *   chisel_hip_export_shells_fixed `world` segments of seg_stride bytes into out_dev
+ *                                  rank's largest segment, [3] its jobs, [4] items it receives, [5] items it sends, [6] voxels it receives,
+ *                                  [7] ghost chunks its earlier recomputes created.  The caller all-reduces the vector with MAX (in place)
+ *                                  in front of the exchange.  send_items_hint: [5] of the previous recompute (a grid size; 0 = unknown)
  *   chisel_hip_import_shells_fixed ghosts from the received segments; then chisel_hip_update_meshes_planned and chisel_hip_drop_ghost_chunks
  *                                  as before -- all of it queued, and all of it a no-op ON THE DEVICE if word 0 of the all-reduced status
  *                                  is not zero (no ghost, no mesh, no dirty flag cleared: on every rank alike)
  *   chisel_hip_shell_commit        once the host has read the all-reduced status (any time before it next changes the map): settles the mesh
  *                                  step; aborted != 0: the recompute did not happen -- make it again with chisel_hip_shell_plan_device */
 #define CHISEL_HIP_SHELL_STATUS_INTS 8
-int chisel_hip_shell_plan_queue(chisel_hip_map *map, const int *gathered_dev, int world, int capacity, int64_t seg_stride, int *status_dev);
-int chisel_hip_export_shells_fixed(chisel_hip_map *map, void *out_dev, int64_t seg_stride);
+int chisel_hip_shell_plan_queue(chisel_hip_map *map, const int *gathered_dev, int world, int capacity, int64_t seg_stride, int *status_dev, void *out_dev,
+                                int send_items_hint);
 int chisel_hip_import_shells_fixed(chisel_hip_map *map, const void *in_dev, int64_t seg_stride, const int *status_dev, int jobs_hint, int items_hint);
 int chisel_hip_shell_commit(chisel_hip_map *map, int aborted);
 int64_t chisel_hip_shell_volume(int box, int chunk_edge);

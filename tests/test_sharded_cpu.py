@@ -233,7 +233,7 @@ class MeshRecordingMap(RecordingMap):
     # exchange when the all-reduced status calls the recompute off
     force_overflow = False  # a test's way to make ONE rank report a segment that does not fit
 
-    def PlanShellsQueue(self, gathered, world, cap, stride, status):
+    def PlanShellsQueue(self, gathered, world, cap, stride, status, out, send_items_hint=0):
         from cvids_amd.sharded import segment_bytes
         plan = self.PlanShellsDevice(gathered, world, cap)
         cut = plan["max_count"] > cap
@@ -244,8 +244,6 @@ class MeshRecordingMap(RecordingMap):
         vals = [flags, plan["max_count"], largest, plan["jobs"], int(plan["recv"][:, 0].sum()), plan["send_items"], int(plan["recv"][:, 1].sum()), 0]
         status.copy_(__import__("torch").tensor(vals, dtype=status.dtype))
         self.queued_plans = getattr(self, "queued_plans", 0) + 1
-
-    def ExportShellsFixed(self, out, stride):
         blob = b""
         for seg in self._segments():
             if len(seg) > stride:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # everything DESIGN.md's measurement section / profiles/<tag>_* is made of, on one box; pieces by name:
-#   bash tools/round.sh <tag> tests | profile | diag | table | shards | lines | group | ranks
+#   bash tools/round.sh <tag> tests | profile | diag | table | shards | lines | group | ranks | hosttime | soak
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 TAG=$1; shift
 prune() { find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -delete; find gpurun_out -name "*.db" -delete; find gpurun_out -name "*agent_info.csv" -delete; }
@@ -27,6 +27,16 @@ for piece in "$@"; do
       python3 bench.py --config 2 > gpurun_out/${TAG}_config2_line.json 2> /dev/null ;;
     group) bash tools/group_bench.sh > gpurun_out/${TAG}_group_bench.txt 2>&1 ;;
     ranks) bash tools/n_ranks_one_gpu.sh > gpurun_out/${TAG}_n_ranks_one_gpu_gloo.txt 2>&1 ;;
+    hosttime)
+      export TMPDIR=/tmp
+      for n in 2 8; do
+        python3 tools/sharded_host_time.py $n 2>&1 | grep -v "mesh recompute\|amdgpu.ids" > gpurun_out/${TAG}_sharded_host_time_$n.txt
+        rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/shk_$n -o t -- python3 tools/sharded_host_time.py $n > /dev/null 2>&1
+        python3 tools/sharded_kernel_time.py gpurun_out/shk_$n $n 11 >> gpurun_out/${TAG}_sharded_host_time_$n.txt 2>&1
+      done; prune ;;
+    soak)
+      python3 tools/soak.py 6000 > gpurun_out/${TAG}_soak.txt 2>&1
+      python3 tools/soak.py 3000 0 grow > gpurun_out/${TAG}_soak_grow.txt 2>&1 ;;
   esac
 done
 du -sh gpurun_out
