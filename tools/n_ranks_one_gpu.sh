@@ -13,7 +13,7 @@ import sys, json
 d = json.loads(sys.stdin.read())
 s = d.get('sharded_meshing', {})
 h = s.get('host_us_per_recompute_rank0', {})
-coll = sum(v for k, v in h.items() if 'all_' in k)
+coll = sum(v for k, v in h.items() if 'all_' in k or k.startswith('sizes'))  # (the sizes travel by an all_reduce: under gloo a blocking one)
 print('   %8.0f frames/s  ms/step %.4f | recomputes %s, wait-free %s, called off %s | host us per recompute: %.0f outside the collectives (+ %.0f inside gloo)' % (
     d['value'], d['ms_per_step'], s.get('recomputes'), s.get('wait_free', {}).get('recomputes'), s.get('wait_free', {}).get('called_off'), sum(h.values()) - coll, coll))
 print('            ' + json.dumps(h))
