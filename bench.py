@@ -433,7 +433,7 @@ def main():
         # (N > 1: a fixed number of passes -- every rank must take the same turn, their clocks do not agree)
         if (world == 1 and time.perf_counter() - t_warm > 1.0) or (world > 1 and warm_passes >= 3):
             break
-        m.Reset()
+        (m.sharded or m).Reset()
     fence()
     # ---- passes C (1 GPU, meshing on): the same stream without the mesh recomputes, for reference ----------------
     no_mesh = None
@@ -441,7 +441,7 @@ def main():
         every, args.mesh_every = args.mesh_every, 0
         ts = []
         for _ in range(min(repeats, 5)):
-            m.Reset()
+            (m.sharded or m).Reset()
             ts.append(timed(m)[0])
         args.mesh_every = every
         no_mesh = {"value": args.steps / median(ts), "unit": "frames/s", "ms_per_step": median(ts) / args.steps * 1e3, "repeats": len(ts)}
@@ -449,7 +449,7 @@ def main():
     # ---- passes A: the timed region ---------------------------------------------------------------------
     ts, issues = [], []
     for _ in range(repeats):
-        m.Reset()
+        (m.sharded or m).Reset()
         dt_r, t_issue_r, cnt, n_chunks, _ = timed(m)
         ts.append(dt_r)
         issues.append(t_issue_r)
@@ -470,7 +470,7 @@ def main():
     if not args.no_roofline:
         avgs, others, dts_b = [], [], []
         for _ in range(min(repeats, 5)):
-            m.Reset()
+            (m.sharded or m).Reset()
             dt_b, _, cb, _, prof = timed(m, instrumented=True)
             k = prof["integrate"]
             avgs.append(k["ms"] / max(k["launches"], 1))
@@ -513,7 +513,7 @@ def main():
         calls_ref[0] = calls_d
         ts_d = []
         for _ in range(min(repeats, 3)):
-            m.Reset()
+            (m.sharded or m).Reset()
             ts_d.append(timed(m)[0])
         calls_ref[0] = saved
         pcie = {"value": args.steps / median(ts_d), "unit": "frames/s", "ms_per_step": median(ts_d) / args.steps * 1e3,
@@ -570,7 +570,7 @@ def main():
 
         ts_e = []
         for _ in range(min(repeats, 3)):
-            m.Reset()
+            (m.sharded or m).Reset()
             run_e2e(m, 0, first_timed)
             m.synchronize()
             fence()

@@ -637,7 +637,14 @@ void give_up_job_list(chisel_hip_map *m);  // host_mesh.h
 // First thing in every entry point that looks at the map or queues work on it (the depth-integration calls see to it themselves, in
 // launch_back): a launch set that was queued behind a recompute the host had not sized yet is settled -- the totals are read, and had
 // the recompute not fitted it is emitted again and the set's integration replayed -- before anybody can observe the difference.
-inline int settle(chisel_hip_map *m) { return (m && m->deferred_set >= 0) ? check_mesh_totals(m) : CHISEL_HIP_OK; }
+namespace group {
+int settle(chisel_hip_map *g);  // host_group.h: a group's wait-free recompute in flight -- its status, the shards' commits
+void forget_recompute(chisel_hip_map *g);
+}
+inline int settle(chisel_hip_map *m) {
+    if (m && m->is_group) return group::settle(m);
+    return (m && m->deferred_set >= 0) ? check_mesh_totals(m) : CHISEL_HIP_OK;
+}
 #define SETTLE(m) do { const int rc_settle_ = settle(m); if (rc_settle_) return rc_settle_; } while (0)
 
 bool mesh_totals_published(const chisel_hip_map *m);  // host_mesh.h
@@ -1633,7 +1640,10 @@ int chisel_hip_destroy(chisel_hip_map *m) {
 }
 
 int chisel_hip_reset(chisel_hip_map *m) {
-    if (m && m->is_group) return group::for_all(m, [](chisel_hip_map *s) { return chisel_hip_reset(s); });
+    if (m && m->is_group) {
+        group::forget_recompute(m);  // (a wait-free recompute in flight is void with the maps, and so are the sizes the next one would have gone by)
+        return group::for_all(m, [](chisel_hip_map *s) { return chisel_hip_reset(s); });
+    }
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
     { m->topology_epoch++; m->dirty_tail_queued = false; }
@@ -2629,7 +2639,7 @@ int chisel_hip_shell_commit(chisel_hip_map *m, int aborted) {
     if (m && m->is_group) return fail(CHISEL_HIP_ERR_UNSUPPORTED, "a call between the shards of a map");
     if (!m) return fail(CHISEL_HIP_ERR_INVALID, "null map");
     HIP_TRY(hipSetDevice(m->device));
-    const int rc = check_mesh_totals(m);
+    const int rc = check_mesh_totals(m);  // (the mesh step's totals: a second emission and the drop behind it, if it did not fit)
     if (m->shell_uncommitted && !aborted) m->pending_mesh_ids.clear();
     m->shell_uncommitted = false;
     m->shell_abort_dev = nullptr;

@@ -139,11 +139,20 @@ struct MeshStage {
     long long send_cap = 0, recv_cap = 0;
     hipEvent_t listed = nullptr, gathered_ev = nullptr, exported = nullptr, copied = nullptr, imported = nullptr;
     bool armed = false;                        // `copied` / `imported` have been recorded at least once
+    int *status = nullptr;                     // the wait-free form: [W + 2][8] ints -- row 0 the all-reduced vector, row 1 this shard's own (its export kernel writes it), rows 2.. every shard's, copied here
 };
 struct MeshStages {
     std::vector<MeshStage> of;                 // [shard]
     std::vector<hipStream_t> copy;             // [r]: the peer copies that bring the other shards' lists and segments to shard r
     int cap = 1 << 12;                         // entries per shard in the gathered list (doubled when a shard has more)
+    // the wait-free form of the recompute (update_meshes_wait_free): what the previous recompute needed (all shards' maximum), whether one is
+    // in flight whose status the host has not looked at (settle), where shard 0's all-reduced status reaches the host
+    bool have_sizes = false, unsettled = false;
+    int64_t need_max_count = 0, need_seg_bytes = 0, need_jobs = 0, need_recv_items = 0, need_send_items = 0;
+    long long stride = 0;
+    int *status_host = nullptr;                // pinned [8]
+    hipEvent_t status_ev = nullptr;
+    int wait_free_recomputes = 0, called_off = 0;
 };
 
 inline int n_shards(const chisel_hip_map *g) { return (int)g->shards.size(); }
@@ -276,7 +285,7 @@ int destroy(chisel_hip_map *g) {
         for (int i = 0; i < W; i++) {
             MeshStage &S = MS->of[(size_t)i];
             (void)hipSetDevice(g->shards[(size_t)i]->device);
-            for (void *p : {(void *)S.gathered, (void *)S.send, (void *)S.recv})
+            for (void *p : {(void *)S.gathered, (void *)S.send, (void *)S.recv, (void *)S.status})
                 if (p) (void)hipFree(p);
             for (hipEvent_t e : {S.listed, S.gathered_ev, S.exported, S.copied, S.imported})
                 if (e) (void)hipEventDestroy(e);
@@ -286,6 +295,8 @@ int destroy(chisel_hip_map *g) {
                 (void)hipSetDevice(g->shards[r]->device);
                 (void)hipStreamDestroy(MS->copy[(size_t)r]);
             }
+        if (MS->status_host) (void)hipHostFree(MS->status_host);
+        if (MS->status_ev) (void)hipEventDestroy(MS->status_ev);
         delete MS;
         g->mesh_stages_group = nullptr;
     }
@@ -545,6 +556,10 @@ int integrate_set(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames
 // frames in order; consecutive frames of one image size go out KMAX at a time (as integrate_frames cuts them for one map)
 int integrate(chisel_hip_map *g, int n, const chisel_hip_depth_frame *frames, const chisel_hip_color_frame *colors) {
     if (n < 0 || (n > 0 && !frames)) return fail(CHISEL_HIP_ERR_INVALID, "bad frame list");
+    {
+        const int rc_s = settle(g);  // (a wait-free recompute in flight: its status before the maps change)
+        if (rc_s) return rc_s;
+    }
     // chisel_hip_wait_event on the group: the event covers every frame of this call, so every launch set arms its shards with it
     const hipEvent_t call_input = g->input_event;
     g->input_event = nullptr;
@@ -634,10 +649,40 @@ int emit_ids(const std::vector<int> &all, int *ids, int64_t max_ids, int64_t *co
 //   C  every OWNER packs its segments (chisel_hip_export_shells_packed) and records `exported`;
 //   D  every MESHING shard copies its segments out of the owners' buffers (behind their `exported`), installs the ghosts, recomputes
 //      its jobs, drops the ghosts and records `imported`, behind which the next recompute's copies into the same buffer are ordered.
-int update_meshes(chisel_hip_map *g, int force) {
-    if (!force && (g->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;  // Chisel.cpp:53-58: every 10th call
+// the shards' gathered lists at MS.cap entries per shard (a list that must grow is grown here, on the calling thread, after everything that
+// reads the old one: the previous recompute's plan kernels, the other shards' copies out of it)
+int grow_lists(chisel_hip_map *g, MeshStages &MS) {
+    const int W = n_shards(g), cap = MS.cap, blk = 1 + 4 * cap;
+    bool grow = false;
+    for (int i = 0; i < W; i++) grow = grow || MS.of[(size_t)i].cap < cap;
+    if (!grow) return CHISEL_HIP_OK;
+    for (int i = 0; i < W; i++) {
+        int rc0 = chisel_hip_synchronize(g->shards[(size_t)i]);
+        if (rc0) return rc0;
+    }
+    for (int r = 0; r < W; r++) {
+        HIP_TRY(hipSetDevice(g->shards[(size_t)r]->device));
+        HIP_TRY(hipStreamSynchronize(MS.copy[(size_t)r]));
+    }
+    for (int i = 0; i < W; i++) {
+        MeshStage &S = MS.of[(size_t)i];
+        if (S.cap >= cap) continue;
+        HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
+        if (S.gathered) HIP_TRY(hipFree(S.gathered));
+        S.gathered = nullptr;
+        HIP_TRY(hipMalloc(&S.gathered, (size_t)W * blk * sizeof(int)));
+        S.cap = cap;
+    }
+    return CHISEL_HIP_OK;
+}
+inline int make_stage_events(MeshStage &S) {
+    if (S.listed) return CHISEL_HIP_OK;
+    for (hipEvent_t *e : {&S.listed, &S.gathered_ev, &S.exported, &S.copied, &S.imported}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return CHISEL_HIP_OK;
+}
+
+int update_meshes_blocking(chisel_hip_map *g) {
     const int W = n_shards(g);
-    if (W == 1) return chisel_hip_update_meshes(g->shards[0], 1);
     MeshStages &MS = *static_cast<MeshStages *>(g->mesh_stages_group);
     const bool timing = g_host_timer.on;
     auto t_prev = std::chrono::steady_clock::now();
@@ -665,27 +710,9 @@ int update_meshes(chisel_hip_map *g, int force) {
     }
     for (;;) {
         const int cap = MS.cap, blk = 1 + 4 * cap;
-        bool grow = false;
-        for (int i = 0; i < W; i++) grow = grow || MS.of[(size_t)i].cap < cap;
-        if (grow) {
-            // (the previous recompute's plan kernels have read the old lists, the other shards' copies out of them too)
-            for (int i = 0; i < W; i++) {
-                int rc0 = chisel_hip_synchronize(g->shards[(size_t)i]);
-                if (rc0) return rc0;
-            }
-            for (int r = 0; r < W; r++) {
-                HIP_TRY(hipSetDevice(g->shards[(size_t)r]->device));
-                HIP_TRY(hipStreamSynchronize(MS.copy[(size_t)r]));
-            }
-            for (int i = 0; i < W; i++) {
-                MeshStage &S = MS.of[(size_t)i];
-                if (S.cap >= cap) continue;
-                HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
-                if (S.gathered) HIP_TRY(hipFree(S.gathered));
-                S.gathered = nullptr;
-                HIP_TRY(hipMalloc(&S.gathered, (size_t)W * blk * sizeof(int)));
-                S.cap = cap;
-            }
+        {
+            int rc0 = grow_lists(g, MS);
+            if (rc0) return rc0;
         }
         // ---- A
         int rc = run_shards(g, [&](int i) -> int {
@@ -803,7 +830,218 @@ int update_meshes(chisel_hip_map *g, int force) {
         fprintf(stderr, "chisel_hip group recompute, host us: dirty lists %.0f | list copies + plan (device) + wait %.0f | exports %.0f | copies + imports + recompute + drop %.0f\n",
                 t_phase[0], t_phase[1], t_phase[2], t_phase[3]);
     for (uint64_t v : moved) g->ghost_bytes += v;
+    if (!rc) {  // what the next recompute may lay its fixed segments out from (update_meshes_wait_free)
+        MS.have_sizes = true;
+        MS.need_max_count = MS.need_seg_bytes = MS.need_jobs = MS.need_recv_items = MS.need_send_items = 0;
+        for (int r = 0; r < W; r++) {
+            MS.need_max_count = std::max(MS.need_max_count, plan[(size_t)r][2]);
+            MS.need_jobs = std::max(MS.need_jobs, plan[(size_t)r][0]);
+            MS.need_send_items = std::max(MS.need_send_items, plan[(size_t)r][3]);
+            int64_t items = 0;
+            for (int o = 0; o < W; o++) {
+                items += plan[(size_t)r][4 + 2 * W + 2 * o];
+                MS.need_seg_bytes = std::max<int64_t>(MS.need_seg_bytes, seg(o, r));
+            }
+            MS.need_recv_items = std::max(MS.need_recv_items, items);
+        }
+    }
     return rc;
+}
+
+
+// The same recompute with nothing read in between (kernels_map.h: "the wait-free form"; cvids_amd/sharded.py: _recompute_wait_free is its
+// multi-process twin): every (owner, meshing shard) segment has MS.stride bytes to itself -- half as much again as the largest segment of the
+// previous recompute --, the owners' export kernels leave their status vectors, every meshing shard copies the slots AND the status vectors of
+// all owners and reduces the latter itself (shell_status_max_kernel: the all-reduce), and its import / mesh / drop kernels do nothing if the
+// reduced word 0 says that anybody's list, plan or segment did not fit.  The host looks at shard 0's copy of that vector when the group is
+// next entered (settle): a recompute that was called off is then made again by update_meshes_blocking, from maps nobody has touched.
+// Three fan-outs (an event must have been recorded before another thread makes a stream wait for it), no host wait.
+int update_meshes_wait_free(chisel_hip_map *g) {
+    const int W = n_shards(g);
+    MeshStages &MS = *static_cast<MeshStages *>(g->mesh_stages_group);
+    const bool timing = g_host_timer.on;
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_phase[4] = {0, 0, 0, 0};
+    auto lap = [&](int i) {
+        if (!timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        t_phase[i] += std::chrono::duration<double, std::micro>(n - t_prev).count();
+        t_prev = n;
+    };
+    if (2 * MS.need_max_count > MS.cap) MS.cap = (int)std::min<int64_t>(4 * MS.need_max_count, 1 << 26);
+    const long long stride = ((long long)MS.need_seg_bytes + MS.need_seg_bytes / 2 + 4096 + 15) / 16 * 16;
+    const long long bytes = stride * W;
+    for (int i = 0; i < W; i++) {
+        HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
+        int rc0 = make_stage_events(MS.of[(size_t)i]);
+        if (rc0) return rc0;
+        if (!MS.copy[(size_t)i]) HIP_TRY(hipStreamCreateWithFlags(&MS.copy[(size_t)i], hipStreamNonBlocking));
+    }
+    {
+        int rc0 = grow_lists(g, MS);
+        if (rc0) return rc0;
+    }
+    // buffers that must grow: after everything that reads the old ones (rare: the slots are laid out with room to spare)
+    bool grow = false;
+    for (int i = 0; i < W; i++) grow = grow || MS.of[(size_t)i].send_cap < bytes || MS.of[(size_t)i].recv_cap < bytes || !MS.of[(size_t)i].status;
+    if (grow || !MS.status_host) {
+        for (int i = 0; i < W; i++) {
+            int rc0 = chisel_hip_synchronize(g->shards[(size_t)i]);
+            if (rc0) return rc0;
+        }
+        for (int r = 0; r < W; r++) {
+            HIP_TRY(hipSetDevice(g->shards[(size_t)r]->device));
+            HIP_TRY(hipStreamSynchronize(MS.copy[(size_t)r]));
+        }
+        for (int i = 0; i < W; i++) {
+            MeshStage &S = MS.of[(size_t)i];
+            HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
+            if (S.send_cap < bytes) {
+                if (S.send) HIP_TRY(hipFree(S.send));
+                S.send = nullptr;
+                S.send_cap = std::max<long long>(bytes + bytes / 2, 1 << 20);
+                HIP_TRY(hipMalloc(&S.send, (size_t)S.send_cap));
+            }
+            if (S.recv_cap < bytes) {
+                if (S.recv) HIP_TRY(hipFree(S.recv));
+                S.recv = nullptr;
+                S.recv_cap = std::max<long long>(bytes + bytes / 2, 1 << 20);
+                HIP_TRY(hipMalloc(&S.recv, (size_t)S.recv_cap));
+            }
+            if (!S.status) {
+                HIP_TRY(hipMalloc(&S.status, (size_t)(W + 2) * SHELL_STATUS_INTS * sizeof(int)));
+                HIP_TRY(hipMemset(S.status, 0, (size_t)(W + 2) * SHELL_STATUS_INTS * sizeof(int)));
+            }
+        }
+        HIP_TRY(hipSetDevice(g->shards[0]->device));
+        if (!MS.status_host) HIP_TRY(hipHostMalloc((void **)&MS.status_host, SHELL_STATUS_INTS * sizeof(int), hipHostMallocDefault));
+        if (!MS.status_ev) HIP_TRY(hipEventCreateWithFlags(&MS.status_ev, hipEventDisableTiming));
+    }
+    const int cap = MS.cap, blk = 1 + 4 * cap;
+    lap(0);
+    // ---- A: the dirty lists
+    int rc = run_shards(g, [&](int i) -> int {
+        chisel_hip_map *sh = g->shards[(size_t)i];
+        MeshStage &S = MS.of[(size_t)i];
+        HIP_TRY(hipSetDevice(sh->device));
+        int rc2 = chisel_hip_dirty_ids_device(sh, S.gathered + (size_t)i * blk, cap);
+        if (rc2) return rc2;
+        return chisel_hip_record_event(sh, S.listed);
+    });
+    if (rc) return rc;
+    lap(1);
+    // ---- B: the other shards' lists, the plan, the export into fixed slots, this shard's status
+    rc = run_shards(g, [&](int r) -> int {
+        chisel_hip_map *sh = g->shards[(size_t)r];
+        MeshStage &S = MS.of[(size_t)r];
+        HIP_TRY(hipSetDevice(sh->device));
+        hipStream_t cs = MS.copy[(size_t)r];
+        for (int o = 0; o < W; o++) {
+            if (o == r) continue;
+            HIP_TRY(hipStreamWaitEvent(cs, MS.of[(size_t)o].listed, 0));
+            HIP_TRY(hipMemcpyPeerAsync(S.gathered + (size_t)o * blk, sh->device, MS.of[(size_t)o].gathered + (size_t)o * blk, g->shards[(size_t)o]->device, (size_t)blk * sizeof(int), cs));
+        }
+        HIP_TRY(hipEventRecord(S.gathered_ev, cs));
+        // the previous recompute's readers of the send buffer and of this shard's status row: the copies of every meshing shard
+        for (int q = 0; q < W; q++)
+            if (MS.of[(size_t)q].armed) HIP_TRY(hipStreamWaitEvent(sh->stream, MS.of[(size_t)q].copied, 0));
+        int rc2 = chisel_hip_wait_event(sh, S.gathered_ev);
+        if (rc2) return rc2;
+        rc2 = chisel_hip_shell_plan_queue(sh, S.gathered, W, cap, stride, S.status + SHELL_STATUS_INTS, S.send, (int)MS.need_send_items);
+        if (rc2) return rc2;
+        return chisel_hip_record_event(sh, S.exported);
+    });
+    if (rc) return rc;
+    lap(2);
+    // ---- D: the slots and the status vectors of all owners, their maximum, ghosts, meshes, drop
+    rc = run_shards(g, [&](int r) -> int {
+        chisel_hip_map *dst = g->shards[(size_t)r];
+        MeshStage &S = MS.of[(size_t)r];
+        HIP_TRY(hipSetDevice(dst->device));
+        hipStream_t cs = MS.copy[(size_t)r];
+        if (S.armed) HIP_TRY(hipStreamWaitEvent(cs, S.imported, 0));  // the previous recompute's import and drop have read the buffer
+        for (int o = 0; o < W; o++) {
+            HIP_TRY(hipStreamWaitEvent(cs, MS.of[(size_t)o].exported, 0));
+            if (o != r)  // (a shard owes itself nothing: its own slot only needs its head)
+                HIP_TRY(hipMemcpyPeerAsync(S.recv + (size_t)o * stride, dst->device, MS.of[(size_t)o].send + (size_t)r * stride, g->shards[(size_t)o]->device, (size_t)stride, cs));
+            else
+                HIP_TRY(hipMemcpyAsync(S.recv + (size_t)o * stride, MS.of[(size_t)o].send + (size_t)r * stride, 16, hipMemcpyDeviceToDevice, cs));
+            HIP_TRY(hipMemcpyPeerAsync(S.status + (size_t)(2 + o) * SHELL_STATUS_INTS, dst->device, MS.of[(size_t)o].status + SHELL_STATUS_INTS, g->shards[(size_t)o]->device,
+                                       SHELL_STATUS_INTS * sizeof(int), cs));
+        }
+        HIP_TRY(hipEventRecord(S.copied, cs));
+        HIP_TRY(hipStreamWaitEvent(dst->stream, S.copied, 0));
+        hipLaunchKernelGGL(shell_status_max_kernel, dim3(1), dim3(64), 0, dst->stream, (const int *)(S.status + 2 * SHELL_STATUS_INTS), W, S.status);
+        HIP_TRY(hipGetLastError());
+        if (r == 0) {
+            HIP_TRY(hipMemcpyAsync(MS.status_host, S.status, SHELL_STATUS_INTS * sizeof(int), hipMemcpyDeviceToHost, dst->stream));
+            HIP_TRY(hipEventRecord(MS.status_ev, dst->stream));
+        }
+        int rc2 = chisel_hip_import_shells_fixed(dst, S.recv, stride, S.status, (int)MS.need_jobs, (int)MS.need_recv_items);
+        if (rc2) return rc2;
+        rc2 = chisel_hip_update_meshes_planned(dst);
+        if (rc2) return rc2;
+        rc2 = chisel_hip_drop_ghost_chunks(dst);
+        if (rc2) return rc2;
+        rc2 = chisel_hip_record_event(dst, S.imported);
+        if (rc2) return rc2;
+        S.armed = true;
+        return CHISEL_HIP_OK;
+    });
+    lap(3);
+    if (timing)
+        fprintf(stderr, "chisel_hip group recompute (wait-free), host us: buffers %.0f | dirty lists %.0f | list copies + plan + export %.0f | slot copies + import + recompute + drop %.0f\n",
+                t_phase[0], t_phase[1], t_phase[2], t_phase[3]);
+    MS.stride = stride;
+    MS.unsettled = true;  // (also after a failure: whatever was queued is settled before the maps are entered again)
+    MS.wait_free_recomputes++;
+    return rc;
+}
+
+// The host's look at a wait-free recompute, first thing when the group is entered again (chisel_hip.hip: settle): the all-reduced status,
+// the shards' commits, and the recompute made again if it was called off.
+int settle(chisel_hip_map *g) {
+    MeshStages *MSp = static_cast<MeshStages *>(g->mesh_stages_group);
+    if (!MSp || !MSp->unsettled) return CHISEL_HIP_OK;
+    MeshStages &MS = *MSp;
+    MS.unsettled = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(g->shards[0]->device));
+    HIP_TRY(hipEventSynchronize(MS.status_ev));
+    const auto t1 = std::chrono::steady_clock::now();
+    int st[SHELL_STATUS_INTS];
+    for (int k = 0; k < SHELL_STATUS_INTS; k++) st[k] = reinterpret_cast<volatile int *>(MS.status_host)[k];
+    MS.need_max_count = st[1]; MS.need_seg_bytes = st[2]; MS.need_jobs = st[3]; MS.need_recv_items = st[4]; MS.need_send_items = st[5];
+    const int W = n_shards(g);
+    int rc = CHISEL_HIP_OK;
+    for (int i = 0; i < W && !rc; i++) rc = chisel_hip_shell_commit(g->shards[(size_t)i], st[0] != 0);
+    if (g_host_timer.on)
+        fprintf(stderr, "chisel_hip group settle, host us: status %.0f | commits %.0f | status %d\n", std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(), st[0]);
+    if (rc) return rc;
+    if (st[0] == 0) {
+        g->ghost_bytes += (uint64_t)st[6] * (g->cfg.use_color ? 12 : 8) * (uint64_t)W;  // (the shard that received most, times the shards)
+        return CHISEL_HIP_OK;
+    }
+    MS.called_off++;
+    if (st[0] & 1) MS.cap = (int)std::min<int64_t>(2 * (int64_t)st[1], 1 << 26);
+    return update_meshes_blocking(g);
+}
+
+void forget_recompute(chisel_hip_map *g) {
+    if (MeshStages *MS = static_cast<MeshStages *>(g->mesh_stages_group)) MS->unsettled = MS->have_sizes = false;
+}
+
+int update_meshes(chisel_hip_map *g, int force) {
+    if (!force && (g->update_meshes_calls++ % 10) != 0) return CHISEL_HIP_OK;  // Chisel.cpp:53-58: every 10th call
+    const int W = n_shards(g);
+    if (W == 1) return chisel_hip_update_meshes(g->shards[0], 1);
+    int rc = settle(g);
+    if (rc) return rc;
+    MeshStages &MS = *static_cast<MeshStages *>(g->mesh_stages_group);
+    static const bool blocking_only = getenv("CHISEL_HIP_GROUP_BLOCKING_MESH") != nullptr;  // A/B hook: the form of rounds 5 (two host waits per shard)
+    if (MS.have_sizes && !blocking_only) return update_meshes_wait_free(g);
+    return update_meshes_blocking(g);
 }
 
 int list_meshes(chisel_hip_map *g, int *ids, int64_t max_ids, int64_t *count) {

@@ -640,6 +640,13 @@ __device__ inline void shell_write_status(const ShellPlan &S, int cap, long long
     status[6] = (int)min(recv_voxels, 0x7fffffffll);
     status[7] = (int)min((long long)*reinterpret_cast<const unsigned long long *>(S.ctl + 16 + 4 * SHELL_MAX_SHARDS), 0x7fffffffll);  // ghost chunks this rank's earlier recomputes created (for the record)
 }
+// the all-reduce of the in-library group (host_group.h): every shard has the other shards' status vectors copied beside its own
+__global__ void shell_status_max_kernel(const int *all, int world, int *reduced) {
+    if (blockIdx.x != 0 || threadIdx.x >= SHELL_STATUS_INTS) return;
+    int v = all[threadIdx.x];
+    for (int r = 1; r < world; r++) v = max(v, all[r * SHELL_STATUS_INTS + threadIdx.x]);
+    reduced[threadIdx.x] = v;
+}
 // behind the mesh step of a recompute that was called off: the count kernel has emptied the LIST of dirty slots (it does so whatever it meshed), their flags are all still up
 // (clear_dirty_kernel left them) -- a list that says "overflowed" makes the next listing go by the flags (list_dirty_ids_kernel, mesh_mark_kernel)
 __global__ void shell_abort_relist_kernel(MapView M, const int *abort) {

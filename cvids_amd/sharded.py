@@ -683,6 +683,13 @@ class ShardedChisel:
         ev.record(torch.cuda.current_stream())
         self.map.wait_event(ev.cuda_event)
 
+    def Reset(self):
+        """Chisel::Reset of this rank's shard (every rank calls it): what the last recompute left in flight is settled first, and the sizes the
+        wait-free form would have gone by are forgotten with the map they described (its next recompute takes the blocking form)"""
+        self.Settle()
+        self.map.Reset()
+        self._est = None
+
     def NumChunks(self):
         torch, dist = self.x.torch, self.x.dist
         self.Settle()
