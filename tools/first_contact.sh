@@ -16,7 +16,8 @@ step "3. two RCCL ranks == one rank: voxel counters, meshes inside the timed reg
      python3 -m pytest tests/test_gpu_bench.py -q -m gpu -k "two_rccl_ranks or group_on_two_devices"
 step "4. the in-library group on devices 0,1 against one map, bit for bit (first hipMemcpyPeerAsync between two devices)" \
      env CHISEL_HIP_TEST_DEVICES=0,1 python3 -m pytest tests/test_gpu_group.py -q -m gpu
-step "5. the headline line at N = 2 (small: 40 frames)" python3 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline
+step "5. the headline line at N = 2 (small: 40 frames), the sharded recompute in its blocking form (the host reads the plan in the middle of it)" python3 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline --blocking-mesh
+step "5b. the same with the wait-free recompute (first all_reduce of the status, first all_to_all of equal splits between two devices; sharded_meshing.wait_free.called_off should stay 0)" python3 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline
 step "6. the scaling curve the driver records" bash -c "for n in 1 2 4 8; do [ \$n -le $N ] && python3 bench.py --gpus \$n --no-cpu-baseline | tail -1; done"
 step "6b. the same curve without the sharded recomputes (what the shard tables of DESIGN.md section 6 predict)" bash -c "for n in 1 2 4 8; do [ \$n -le $N ] && python3 bench.py --gpus \$n --mesh-every 0 --batch 16 --steps 320 --warmup 64 --no-cpu-baseline | tail -1; done"
 step "7. the same map in ONE process (chisel_ros' shape): group of $N" python3 bench.py --group "$N" --agents 4 --batch 16 --steps 320 --warmup 64 --no-cpu-baseline
