@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--mesh-every", type=int, default=None,
                     help="marching-cubes recompute (UpdateMeshes) every M frames inside the timed region; default: 10 at 1 GPU (the "
                          "reference's keyframe cadence, Chisel.cpp:54 -- BASELINE config 3), 0 = off (N > 1: a sharded map is not meshed yet)")
+    ap.add_argument("--mesh-checksum", action="store_true",
+                    help="after the last pass: meshes, vertices and a checksum over every mesh array of the final map (summed over the ranks), as "
+                         "`mesh_checksum` -- equal at every N when the sharded mesher is right (tests/test_gpu_bench.py)")
     ap.add_argument("--blocking-mesh", action="store_true",
                     help="N > 1: the sharded recompute in its blocking form (the host reads the plan's sizes in the middle of it) instead of the "
                          "wait-free one (cvids_amd/sharded.py: ShardedChisel._recompute_wait_free)")
@@ -595,6 +598,23 @@ def main():
                "pcie_copy_gb_per_s_measured": (64 << 20) / best / 1e9,
                "source": "every frame's depth and colour image ((u + k, v, u + v + k) mod 256) copied from page-locked host memory into one of two "
                          "device buffer sets on a copy stream, overlapped with the previous batch's integration (events, no host wait)"}
+    mesh_checksum = None
+    if args.mesh_checksum:
+        import zlib
+        if world > 1:
+            m.sharded.Settle()
+        acc = np.zeros(3, np.int64)
+        for cid in map(tuple, np.asarray(m.GetMeshIDs()).reshape(-1, 3).tolist()):  # (a rank lists the meshes of the chunks it owns)
+            mesh = m.GetMesh(cid)
+            h = zlib.crc32(np.asarray(cid, np.int32).tobytes())
+            for key in ("vertices", "normals", "colors", "grids"):
+                if mesh[key] is not None:
+                    h = zlib.crc32(np.ascontiguousarray(mesh[key]).tobytes(), h)
+            acc += np.array([1, len(mesh["vertices"]), h], np.int64)
+        t_sum = torch.from_numpy(acc).to(dev if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu"))
+        if world > 1:
+            dist.all_reduce(t_sum)
+        mesh_checksum = {"meshes": int(t_sum[0]), "vertices": int(t_sum[1]), "crc_sum": int(t_sum[2])}
     sharded_totals = (getattr(m.sharded, "shell_bytes", 0), getattr(m.sharded, "whole_chunk_bytes", 0)) if world > 1 else (0, 0)
     wait_free_totals = (getattr(m.sharded, "wait_free_recomputes", 0), getattr(m.sharded, "wait_free_aborts", 0), getattr(m.sharded, "wire_bytes", 0), {str(k): v for k, v in getattr(m.sharded, "abort_bits", {}).items()}, getattr(m.sharded, "last_abort_status", None), getattr(m.sharded, "_est", None)) if world > 1 else (0, 0, 0, {}, None, None)
     m.close()
@@ -620,6 +640,8 @@ def main():
                           "work_chunks": vals[6] / args.steps, "resident_chunks_end": vals[7]},
             "launch_shapes": cnt.get("launch_shapes"),
         }
+        if mesh_checksum is not None:
+            out["mesh_checksum"] = mesh_checksum
         if args.noise or args.nan_fraction:
             out["config"]["workload"] += " (depth noise 0.002 d^2: %s, NaN pixels: %g)" % ("yes" if args.noise else "no", args.nan_fraction)
         if world > 1:

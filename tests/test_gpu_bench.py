@@ -27,9 +27,16 @@ def _bench(*args, timeout=900):
 def test_two_ranks_launched_by_bench_itself_equal_one_rank():
     common = ["--steps", "20", "--warmup", "5", "--width", "320", "--height", "240", "--res", "0.02", "--no-cpu-baseline", "--no-roofline",
               "--repeats", "2"]
+    common = common + ["--mesh-checksum"]
     one = _bench("--gpus", "1", *common)
     two = _bench("--gpus", "2", "--dist-backend", "gloo", *common)
+    blocking = _bench("--gpus", "2", "--dist-backend", "gloo", "--blocking-mesh", *common)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    # every mesh array of the final map, summed over the ranks: the sharded mesher in its wait-free form (what --gpus N runs) and in its
+    # blocking form against the one map
+    assert one["mesh_checksum"]["meshes"] > 50 and one["mesh_checksum"]["vertices"] > 10000
+    assert two["mesh_checksum"] == one["mesh_checksum"] and blocking["mesh_checksum"] == one["mesh_checksum"]
+    assert two["sharded_meshing"]["wait_free"]["recomputes"] > 0 and blocking["sharded_meshing"]["wait_free"]["recomputes"] == 0
     assert two["config"]["mesh_every"] == 10 and one["config"]["mesh_every"] == 10  # meshes inside the timed region at every N
     assert two["sharded_meshing"]["recomputes"] > 0
     # shells, not whole ghost chunks (two shards are the worst case).  Since round 5 the denominator is the ghost chunks the owners actually
@@ -53,9 +60,11 @@ def test_two_rccl_ranks_equal_one_rank():
     world-2 gloo and the in-process group only."""
     common = ["--steps", "20", "--warmup", "5", "--width", "320", "--height", "240", "--res", "0.02", "--no-cpu-baseline", "--no-roofline",
               "--repeats", "2"]
+    common = common + ["--mesh-checksum"]
     one = _bench("--gpus", "1", *common)
     two = _bench("--gpus", "2", "--dist-backend", "nccl", *common)
     assert two["n_gpus"] == 2 and two["sharded_meshing"]["recomputes"] > 0
+    assert two["mesh_checksum"] == one["mesh_checksum"] and two["sharded_meshing"]["wait_free"]["recomputes"] > 0
     for k in ("voxel_updates", "n_sdf", "n_col", "n_probe", "n_carved", "resident_chunks_end"):
         assert one["per_frame"][k] == two["per_frame"][k], (k, one["per_frame"][k], two["per_frame"][k])
 
