@@ -447,6 +447,16 @@ def _wait_free_worker(rank, world, port, out):
         sm.UpdateMeshes(force=True, wait_free=True)
         sm.Settle()
         assert sm.wait_free_recomputes == 5 and sm.wait_free_aborts == 3 and snap() == first
+        # 7. Reset: the sizes go with the map they described -- the next recompute takes the blocking form again, the one after it the wait-free one
+        local.Reset = lambda: None
+        sm.Reset()
+        assert sm._est is None
+        plans = local.queued_plans
+        sm.UpdateMeshes(force=True, wait_free=True)
+        assert local.queued_plans == plans and sm.wait_free_recomputes == 5
+        sm.UpdateMeshes(force=True, wait_free=True)
+        sm.Settle()
+        assert local.queued_plans == plans + 1 and sm.wait_free_recomputes == 6 and sm.wait_free_aborts == 3 and snap() == first
         out.put((rank, True))
     finally:
         dist.destroy_process_group()
