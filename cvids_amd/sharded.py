@@ -190,9 +190,26 @@ def shell_box_coords(code, n):
     return [(x, y, z) for z in rng((code >> 4) & 3) for y in rng((code >> 2) & 3) for x in rng(code & 3)]
 
 
+def shell_item_covered(j, d, r, jobset, owner_of):
+    """job j of rank r reads box(d) of its neighbour g = j + d: is that box part of a box another job of r reads of g anyway?  A box holds
+    another when it is "all" wherever it differs: the job at g - d', d' = d with some (not all) of its non-zero components zeroed."""
+    g = (j[0] + d[0], j[1] + d[1], j[2] + d[2])
+    nz = [a for a in range(3) if d[a]]
+    for mask in range(1, (1 << len(nz)) - 1):
+        d2 = list(d)
+        for k, a in enumerate(nz):
+            if (mask >> k) & 1:
+                d2[a] = 0
+        j2 = (g[0] - d2[0], g[1] - d2[1], g[2] - d2[2])
+        if j2 in jobset and owner_of(j2) == r:
+            return True
+    return False
+
+
 def plan_shells_reference(entries, world, rank, owner_of):
     """entries: (n, 4) (x, y, z, flag) of ALL ranks.  -> (jobs: sorted ids this rank owns, send: {peer: [(x, y, z, box), ...]} -- what this
-    rank owns and the jobs of `peer` read --, recv: {owner: [(x, y, z, box), ...]}): one item per (job, direction), nothing merged."""
+    rank owns and the jobs of `peer` read --, recv: {owner: [(x, y, z, box), ...]}): one item per (job, direction), less the items whose box
+    is part of another item's of the same (rank, ghost) (shell_item_covered: an edge or corner box beside the face box that holds it)."""
     jobset = set()
     for x, y, z, flag in np.asarray(entries, np.int64).reshape(-1, 4).tolist():
         r = 0 if flag else 1
@@ -209,6 +226,8 @@ def plan_shells_reference(entries, world, rank, owner_of):
                     g = (j[0] + dx, j[1] + dy, j[2] + dz)
                     o = owner_of(g)
                     if o == r:
+                        continue
+                    if (o == rank or r == rank) and shell_item_covered(j, (dx, dy, dz), r, jobset, owner_of):
                         continue
                     item = g + (shell_box_of((dx, dy, dz)),)
                     if o == rank:
