@@ -41,7 +41,9 @@ extern "C" {
  * facade's chisel::Chisel constructor and cvids_amd/capi.py refuse a mismatch).
  *   1  rounds 1-4
  *   2  round 5-6: chisel_hip_mesh_shell_plan_all removed, CHISEL_HIP_NUM_LAUNCH_STATS 8 -> 10, the device-plan and incremental
- *      meshesToUpdate entries added */
+ *      meshesToUpdate entries added; later additions within 2 (nothing removed or re-typed): chisel_hip_pool_info,
+ *      chisel_hip_frustum_from_vectors, chisel_hip_order_stream_after_map / _map_after_stream, the wait-free sharded recompute
+ *      (chisel_hip_shell_plan_queue, _import_shells_fixed, _shell_commit) */
 #define CHISEL_HIP_ABI_VERSION 2
 
 typedef struct chisel_hip_map chisel_hip_map; /* opaque: one TSDF map (or one shard of it) on one GPU */
