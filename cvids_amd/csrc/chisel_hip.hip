@@ -2409,7 +2409,7 @@ int ensure_shell_plan(chisel_hip_map *m, int jobset_capacity, int send_capacity)
         HIP_TRY(hipStreamSynchronize(m->stream));
         if (S.jobset) HIP_TRY(hipFree(S.jobset));
         S.jobset = nullptr;
-        HIP_TRY(hipMalloc(&S.jobset, (size_t)jobset_capacity * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&S.jobset, 2 * (size_t)jobset_capacity * sizeof(unsigned long long)));  // (the set, then the list)
         S.jobset_capacity = jobset_capacity;
     }
     if (send_capacity > S.send_capacity) {
@@ -2456,7 +2456,7 @@ int chisel_hip_shell_plan_device(chisel_hip_map *m, const int *gathered_dev, int
         HIP_TRY(hipMemsetAsync(S.ctl, 0, (16 + 4 * SHELL_MAX_SHARDS) * sizeof(int), m->stream));
         const long long threads = 27ll * cap * world;
         hipLaunchKernelGGL(shell_jobs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, gathered_dev, world, cap, S, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
-        hipLaunchKernelGGL(shell_items_kernel, dim3((unsigned)(S.jobset_capacity / 8)), dim3(256), 0, m->stream, S, m->N, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
+        hipLaunchKernelGGL(shell_items_kernel, dim3((unsigned)std::min(S.jobset_capacity / 8, 1024)), dim3(256), 0, m->stream, S, m->N, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(m->shell_plan_host_dev, S.ctl, (16 + 4 * SHELL_MAX_SHARDS + 4) * sizeof(int), hipMemcpyDeviceToDevice, m->stream));
         HIP_TRY(wait_stream_spinning(m->stream));
@@ -2594,7 +2594,7 @@ int chisel_hip_shell_plan_queue(chisel_hip_map *m, const int *gathered_dev, int 
     HIP_TRY(hipMemsetAsync(S.ctl, 0, (16 + 4 * SHELL_MAX_SHARDS) * sizeof(int), m->stream));
     const long long threads = 27ll * cap * world;
     hipLaunchKernelGGL(shell_jobs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, gathered_dev, world, cap, S, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
-    hipLaunchKernelGGL(shell_items_kernel, dim3((unsigned)(S.jobset_capacity / 8)), dim3(256), 0, m->stream, S, m->N, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
+    hipLaunchKernelGGL(shell_items_kernel, dim3((unsigned)std::min(S.jobset_capacity / 8, 1024)), dim3(256), 0, m->stream, S, m->N, m->cfg.n_shards, m->cfg.shard_rank, m->cfg.shard_block);
     // (a workgroup per item when the hint holds, several items per workgroup when there are more)
     const unsigned egrid = (unsigned)std::min<long long>(16384, std::max<long long>(256, (long long)send_items_hint + send_items_hint / 4 + 64));
     hipLaunchKernelGGL(shell_export_kernel, dim3(egrid), dim3(256), 0, m->stream, m->view, S, m->N, m->cfg.n_shards, static_cast<unsigned char *>(out_dev), (long long)seg_stride, cap, status_dev);

@@ -493,11 +493,11 @@ __global__ __launch_bounds__(256) void import_shells_kernel(MapView M, const int
 //     float sdf[voxels];  float weight[voxels];  [uint32 rgbw[voxels]]
 // The items sit in the order the sender's atomics produced: each one says where its voxels are, so the receiver needs no plan of its own.
 struct ShellPlan {
-    unsigned long long *jobset;    // [jobset_capacity] packed ids of all jobs (KEY_EMPTY = free)
+    unsigned long long *jobset;    // [2 * jobset_capacity]: a hash set of the packed ids of all jobs (KEY_EMPTY = free), then the same ids as a list (ctl[4] of them)
     int jobset_capacity;           // power of two
     int *my_jobs;                  // [max_jobs][3] the jobs this rank owns
     int max_jobs;
-    int *ctl;                      // [0] jobs of this rank, [1] overflow (job set / job list / item list), [2] largest per-rank entry count of the gathered list, [3] send items
+    int *ctl;                      // [0] jobs of this rank, [1] overflow (job set / job list / item list), [2] largest per-rank entry count of the gathered list, [3] send items, [4] jobs of all ranks
     unsigned long long *send_cur;  // [n_shards] items | voxels << 32 this rank sends to each peer
     unsigned long long *recv_cnt;  // [n_shards] ... and receives from each
     int *send_items;               // [send_capacity][8]: x, y, z, box, destination, index within the destination's segment, first voxel, 0
@@ -536,6 +536,7 @@ __global__ void shell_jobs_kernel(const int *__restrict__ gathered, int world, i
             const unsigned long long old = atomicCAS(&S.jobset[h], KEY_EMPTY, key);
             if (old == key) return;
             if (old != KEY_EMPTY) continue;  // (somebody else's id: next bucket)
+            S.jobset[(size_t)S.jobset_capacity + atomicAdd(&S.ctl[4], 1)] = key;  // the list beside the set (as many entries as the set holds, at most)
             if (chunk_owner(x, y, z, n_shards, shard_block) == shard_rank) {
                 const int pos = atomicAdd(&S.ctl[0], 1);
                 if (pos < S.max_jobs) {
@@ -578,23 +579,26 @@ __device__ inline bool shell_item_covered(const ShellPlan &S, int gx, int gy, in
     }
     return false;
 }
-// step 2: the items.  32 threads per bucket of the job set (26 directions); counts and positions are reserved per workgroup in LDS,
-// then once per (workgroup, peer) in memory.
+// step 2: the items.  32 threads per job (26 directions), eight jobs per workgroup and round; the jobs come from the LIST shell_jobs_kernel
+// keeps beside the set (a scan of the set's buckets -- 32 768 of them for a few thousand jobs -- was 17 us of a 25 us plan).  Counts and
+// positions are reserved per workgroup in LDS, then once per (workgroup, peer) in memory.
 __global__ __launch_bounds__(256) void shell_items_kernel(ShellPlan S, int N, int n_shards, int shard_rank, int shard_block) {
     __shared__ unsigned long long s_send[SHELL_MAX_SHARDS], s_recv[SHELL_MAX_SHARDS], s_base[SHELL_MAX_SHARDS];
     __shared__ int s_n, s_pos;
-    if (threadIdx.x < SHELL_MAX_SHARDS) s_send[threadIdx.x] = s_recv[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const int bucket = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
-    bool sends = false;
-    int gx = 0, gy = 0, gz = 0, box = 0, dest = 0, local = 0;
-    unsigned long long mine = 0ull;
-    if (bucket < S.jobset_capacity && d < 26) {
-        const unsigned long long key = S.jobset[bucket];
-        if (key != KEY_EMPTY) {
+    const int n_all = min(S.ctl[4], S.jobset_capacity);
+    const unsigned long long *joblist = S.jobset + S.jobset_capacity;
+    for (int first = blockIdx.x * 8; first < n_all; first += gridDim.x * 8) {
+        __syncthreads();  // (the round before has read its bases)
+        if (threadIdx.x < SHELL_MAX_SHARDS) s_send[threadIdx.x] = s_recv[threadIdx.x] = 0ull;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const int job = first + (threadIdx.x >> 5), d = threadIdx.x & 31;
+        bool sends = false;
+        int gx = 0, gy = 0, gz = 0, box = 0, dest = 0, local = 0;
+        unsigned long long mine = 0ull;
+        if (job < n_all && d < 26) {
             int jx, jy, jz;
-            unpack_id(key, jx, jy, jz);
+            unpack_id(joblist[job], jx, jy, jz);
             const int dd = d < 13 ? d : d + 1;  // (skip the job itself)
             const int dx = dd % 3 - 1, dy = (dd / 3) % 3 - 1, dz = dd / 9 - 1;
             gx = jx + dx; gy = jy + dy; gz = jz + dz;
@@ -612,22 +616,22 @@ __global__ __launch_bounds__(256) void shell_items_kernel(ShellPlan S, int N, in
                 }
             }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < n_shards) {
-        if (s_send[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&S.send_cur[threadIdx.x], s_send[threadIdx.x]);
-        if (s_recv[threadIdx.x]) atomicAdd(&S.recv_cnt[threadIdx.x], s_recv[threadIdx.x]);
-    }
-    if (threadIdx.x == 0 && s_n) s_pos = atomicAdd(&S.ctl[3], s_n);
-    __syncthreads();
-    if (sends) {
-        const unsigned long long at = s_base[dest] + mine;
-        const int pos = s_pos + local;
-        if (pos < S.send_capacity) {
-            int *it = S.send_items + 8 * (size_t)pos;
-            it[0] = gx; it[1] = gy; it[2] = gz; it[3] = box; it[4] = dest; it[5] = (int)(at & 0xffffffffull); it[6] = (int)(at >> 32); it[7] = 0;
-        } else {
-            S.ctl[1] = 1;
+        __syncthreads();
+        if (threadIdx.x < n_shards) {
+            if (s_send[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&S.send_cur[threadIdx.x], s_send[threadIdx.x]);
+            if (s_recv[threadIdx.x]) atomicAdd(&S.recv_cnt[threadIdx.x], s_recv[threadIdx.x]);
+        }
+        if (threadIdx.x == 0 && s_n) s_pos = atomicAdd(&S.ctl[3], s_n);
+        __syncthreads();
+        if (sends) {
+            const unsigned long long at = s_base[dest] + mine;
+            const int pos = s_pos + local;
+            if (pos < S.send_capacity) {
+                int *it = S.send_items + 8 * (size_t)pos;
+                it[0] = gx; it[1] = gy; it[2] = gz; it[3] = box; it[4] = dest; it[5] = (int)(at & 0xffffffffull); it[6] = (int)(at >> 32); it[7] = 0;
+            } else {
+                S.ctl[1] = 1;
+            }
         }
     }
 }
