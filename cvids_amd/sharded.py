@@ -616,7 +616,11 @@ class ShardedChisel:
         if 2 * est["max_count"] > getattr(self, "_dirty_cap", 1 << 12):
             self._dirty_cap = 4 * est["max_count"]  # (the same figures, the same turn on every rank)
         cap = self._dirty_cap = getattr(self, "_dirty_cap", 1 << 12)
-        stride = (est["seg_bytes"] + est["seg_bytes"] // 2 + 4096 + 15) // 16 * 16
+        # Room beyond the previous recompute's largest segment: a half (CHISEL_HIP_SHELL_SLACK_PERCENT: A/B).  The need mostly shrinks or holds
+        # from one recompute to the next and jumps when the camera turns towards new space -- without warning: sizing by the last step's
+        # growth called off as many recomputes as a fixed quarter (EXPERIMENTS.md).  Every rank computes this from the same figures.
+        slack = int(__import__("os").environ.get("CHISEL_HIP_SHELL_SLACK_PERCENT", "50"))
+        stride = (est["seg_bytes"] + est["seg_bytes"] * slack // 100 + 4096 + 15) // 16 * 16
         self._last_stride = stride
         buf, gathered = self._mesh_buffers(cap)
         self._segment_buffers(world * stride, world * stride)
