@@ -651,7 +651,7 @@ def main():
                                       "shells_over_whole_chunks": sharded_totals[0] / max(1, sharded_totals[1]),
                                       # (of the last timed pass) recomputes queued without a host wait, how many of them were called off on the
                                       # device and made again the blocking way, and the fixed-size segments they sent per recompute
-                                      "wait_free": {"recomputes": wait_free_totals[0], "called_off": wait_free_totals[1], "called_off_by_status_bits": wait_free_totals[3], "last_called_off_status": wait_free_totals[4], "sizes_now": wait_free_totals[5],
+                                      "wait_free": {"recomputes": wait_free_totals[0], "called_off": wait_free_totals[1], "made_again_wait_free": getattr(m.sharded, "wait_free_retries", 0), "called_off_by_status_bits": wait_free_totals[3], "last_called_off_status": wait_free_totals[4], "sizes_now": wait_free_totals[5],
                                                     "wire_bytes_per_recompute_rank0": wait_free_totals[2] / max(1, wait_free_totals[0])}}
             if getattr(m.sharded, "phase_us", None):  # CHISEL_HIP_HOST_TIMING=1: rank 0's host time per sharded recompute, by phase
                 n_rc = max(1, m.sharded.phase_us.get("recomputes", 1))

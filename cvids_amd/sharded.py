@@ -620,6 +620,8 @@ class ShardedChisel:
         # from one recompute to the next and jumps when the camera turns towards new space -- without warning: sizing by the last step's
         # growth called off as many recomputes as a fixed quarter (EXPERIMENTS.md).  Every rank computes this from the same figures.
         slack = int(__import__("os").environ.get("CHISEL_HIP_SHELL_SLACK_PERCENT", "50"))
+        if getattr(self, "_exact_retry", False):
+            slack = 0  # (Settle's second go at a recompute whose slots were too small: est holds what THIS recompute needs)
         stride = (est["seg_bytes"] + est["seg_bytes"] * slack // 100 + 4096 + 15) // 16 * 16
         self._last_stride = stride
         buf, gathered = self._mesh_buffers(cap)
@@ -656,7 +658,8 @@ class ShardedChisel:
     def Settle(self):
         """The host's look at what UpdateMeshes left in flight -- before it (or anybody who goes to self.map directly) changes or reads the
         map again.  After a blocking recompute: the sizes the ranks exchanged for the next one.  After a wait-free one: its all-reduced
-        status; the mesh step's totals are settled (chisel_hip_shell_commit), and a recompute that was called off is made again, blocking."""
+        status; the mesh step's totals are settled (chisel_hip_shell_commit), and a recompute that was called off is made again -- in slots of
+        exactly the size its status reported when only they were too small, in the blocking form otherwise."""
         pending = getattr(self, "_pending", None)
         if not pending:
             return
@@ -682,7 +685,18 @@ class ShardedChisel:
                 self.abort_bits = getattr(self, "abort_bits", {})
                 self.abort_bits[st[0]] = self.abort_bits.get(st[0], 0) + 1
                 self.last_abort_status = st
-                self._recompute_blocking(None, post_sizes=True)
+                if st[0] == 4 and not getattr(self, "_exact_retry", False):
+                    # only the slots were too small, and the status says by how much: the same recompute again (the map is as it was, so is
+                    # the plan) in slots that hold exactly this -- still without reading the plan; settled right away, it cannot fail the same way
+                    self._exact_retry = True
+                    try:
+                        self._recompute_wait_free()
+                        self.wait_free_retries = getattr(self, "wait_free_retries", 0) + 1
+                        self.Settle()
+                    finally:
+                        self._exact_retry = False
+                else:
+                    self._recompute_blocking(None, post_sizes=True)
             self._lap("settle (commit)")
 
     def _order_after_map(self):

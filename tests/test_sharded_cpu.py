@@ -420,43 +420,43 @@ def _wait_free_worker(rank, world, port, out):
         assert sm.wait_free_recomputes == 1 and local.queued_plans == 1 and local.mesh_steps == 2 and nbytes > 0
         sm.Settle()
         assert snap() == first and local.commits == [False] and local.dropped == 2 and not local.ghosts
-        # 3. segments far too small on every rank: called off (no mesh step, no ghost, no drop), then made again the blocking way by Settle
+        # 3. segments far too small on every rank: called off (no mesh step, no ghost, no drop); Settle makes it again, still wait-free, in
+        # slots of exactly the size the status reported
         sm._est["seg_bytes"] = 64
         sm.UpdateMeshes(force=True, wait_free=True)
         assert sm.wait_free_recomputes == 2 and local.mesh_steps == 2 and local.dropped == 2 and not local.ghosts
         sm.NumChunks()  # (any method of the sharded map settles first)
-        assert sm.wait_free_aborts == 1 and sm.last_abort == 4 and local.commits == [False, True] and local.mesh_steps == 3 and snap() == first
+        assert sm.wait_free_aborts == 1 and sm.last_abort == 4 and sm.wait_free_retries == 1 and sm.wait_free_recomputes == 3
+        assert local.commits == [False, True, False] and local.mesh_steps == 3 and local.dropped == 3 and snap() == first
         # 4. ONE rank whose segment does not fit: the all-reduce tells the other, both call the recompute off and make it again
-        sm.Settle()
         assert sm._est["seg_bytes"] > 64
         local.force_overflow = rank == 1
         sm.UpdateMeshes(force=True, wait_free=True)
-        assert sm.wait_free_recomputes == 3 and local.mesh_steps == 3
+        assert sm.wait_free_recomputes == 4 and local.mesh_steps == 3
         local.force_overflow = False
         sm.Settle()
-        assert sm.wait_free_aborts == 2 and local.mesh_steps == 4 and snap() == first and local.commits == [False, True, True]
-        # 5. a dirty list that outgrows the gathered tensor: called off as well, and the blocking form grows the tensor
-        sm.Settle()
+        assert sm.wait_free_aborts == 2 and sm.wait_free_retries == 2 and local.mesh_steps == 4 and snap() == first and local.commits == [False, True, False, True, False]
+        # 5. a dirty list that outgrows the gathered tensor: called off as well, and made again in the blocking form, which grows the tensor
         sm._dirty_cap = 4
         sm._est["max_count"] = 1
         sm.UpdateMeshes(force=True, wait_free=True)
         sm.Settle()
-        assert sm.wait_free_aborts == 3 and (sm.last_abort & 1) and sm._dirty_cap > 4 and snap() == first
+        assert sm.wait_free_aborts == 3 and (sm.last_abort & 1) and sm.wait_free_retries == 2 and sm._dirty_cap > 4 and snap() == first
         # 6. and on it goes
         sm.Settle()
         sm.UpdateMeshes(force=True, wait_free=True)
         sm.Settle()
-        assert sm.wait_free_recomputes == 5 and sm.wait_free_aborts == 3 and snap() == first
+        assert sm.wait_free_recomputes == 7 and sm.wait_free_aborts == 3 and snap() == first
         # 7. Reset: the sizes go with the map they described -- the next recompute takes the blocking form again, the one after it the wait-free one
         local.Reset = lambda: None
         sm.Reset()
         assert sm._est is None
         plans = local.queued_plans
         sm.UpdateMeshes(force=True, wait_free=True)
-        assert local.queued_plans == plans and sm.wait_free_recomputes == 5
+        assert local.queued_plans == plans and sm.wait_free_recomputes == 7
         sm.UpdateMeshes(force=True, wait_free=True)
         sm.Settle()
-        assert local.queued_plans == plans + 1 and sm.wait_free_recomputes == 6 and sm.wait_free_aborts == 3 and snap() == first
+        assert local.queued_plans == plans + 1 and sm.wait_free_recomputes == 8 and sm.wait_free_aborts == 3 and snap() == first
         out.put((rank, True))
     finally:
         dist.destroy_process_group()
