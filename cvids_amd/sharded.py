@@ -449,7 +449,8 @@ class ShardedChisel:
         ids: mesh these chunks (every rank passes ids of its own choice, the union is meshed) instead of meshesToUpdate.
         wait_free: the form in which the host reads NOTHING in between (_recompute_wait_free): everything is queued, the segments have a
         size the ranks agreed on at the previous recompute, and a recompute that did not fit them is called off on the device and made
-        again the way above -- when the host next looks (Settle(): call it, or any method of this class, before touching self.map).
+        again -- in segments of the right size, or the way above if a list or table overflowed -- when the host next looks (Settle(): call
+        it, or any method of this class, before touching self.map).
         -> bytes of ghost voxels this rank received (wait_free: of the rank that received most, at the previous recompute)"""
         self._mesh_calls = getattr(self, "_mesh_calls", 0) + 1
         if not force and (self._mesh_calls - 1) % 10:  # Chisel.cpp:53-58: every 10th call
