@@ -869,7 +869,9 @@ int update_meshes_wait_free(chisel_hip_map *g) {
         t_prev = n;
     };
     if (2 * MS.need_max_count > MS.cap) MS.cap = (int)std::min<int64_t>(4 * MS.need_max_count, 1 << 26);
-    const long long stride = ((long long)MS.need_seg_bytes + MS.need_seg_bytes / 2 + 4096 + 15) / 16 * 16;
+    long long stride = ((long long)MS.need_seg_bytes + MS.need_seg_bytes / 2 + 4096 + 15) / 16 * 16;
+    static const bool tiny_slots = getenv("CHISEL_HIP_GROUP_TINY_SLOTS") != nullptr;  // test hook: every other wait-free recompute gets slots of 64 bytes -- called off on the device, made again by settle()
+    if (tiny_slots && (MS.wait_free_recomputes & 1)) stride = 64;
     const long long bytes = stride * W;
     for (int i = 0; i < W; i++) {
         HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
