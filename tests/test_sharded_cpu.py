@@ -611,10 +611,11 @@ def test_cull_space_enumerates_exactly_the_owned_ids(hip_lib):
 
 
 def test_unmerged_device_plan_covers_what_the_merging_host_planner_asks_for(hip_lib):
-    """The plan of round 5 (cvids_amd.sharded.plan_shells_reference = what chisel_hip_shell_plan_device computes: one item per (job,
-    direction), nothing merged) against chisel_hip_mesh_shell_plan (the host planner of rounds 3-4: a box another one contains is dropped,
-    the two ends of one axis become one box): the same jobs, the same ghosts per owner, and per ghost the same set of voxels -- the
-    unmerged items overlap, their union is what the merged boxes hold.  Scattered and contiguous dirty sets, entries of both flags."""
+    """The plan of rounds 5-6 (cvids_amd.sharded.plan_shells_reference = what chisel_hip_shell_plan_device computes: one item per (job,
+    direction), less -- since round 6 -- the items whose box is part of another item's of the same (rank, ghost)) against
+    chisel_hip_mesh_shell_plan (the host planner of rounds 3-4: a box another one contains is dropped, the two ends of one axis become one
+    box): the same jobs, the same ghosts per owner, and per ghost the same set of voxels -- the items that are left may still overlap,
+    their union is what the merged boxes hold, and none of them lies inside another.  Scattered and contiguous dirty sets, entries of both flags."""
     from cvids_amd.chisel import chunk_owner, mesh_shell_plan
     from cvids_amd.sharded import plan_shells_reference, shell_box_coords
     rng = np.random.default_rng(11)
@@ -638,6 +639,14 @@ def test_unmerged_device_plan_covers_what_the_merging_host_planner_asks_for(hip_
                     for x, y, z, box in items:
                         plain.setdefault((o, x, y, z), set()).update(shell_box_coords(box, E))
                 assert merged == plain, (world, r)
+                # no item of a ghost lies inside another item of the same ghost (what shell_item_covered leaves out)
+                per_ghost = {}
+                for o, items in recv.items():
+                    for x, y, z, box in items:
+                        per_ghost.setdefault((x, y, z), []).append(set(shell_box_coords(box, E)))
+                for boxes in per_ghost.values():
+                    for a in range(len(boxes)):
+                        assert not any(a != b and boxes[a] <= boxes[b] for b in range(len(boxes)))
                 # what r plans to receive from o is what o plans to send r
                 for o in range(world):
                     if o != r:
