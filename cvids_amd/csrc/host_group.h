@@ -147,7 +147,7 @@ struct MeshStages {
     int cap = 1 << 12;                         // entries per shard in the gathered list (doubled when a shard has more)
     // the wait-free form of the recompute (update_meshes_wait_free): what the previous recompute needed (all shards' maximum), whether one is
     // in flight whose status the host has not looked at (settle), where shard 0's all-reduced status reaches the host
-    bool have_sizes = false, unsettled = false;
+    bool have_sizes = false, unsettled = false, retrying = false;
     int64_t need_max_count = 0, need_seg_bytes = 0, need_jobs = 0, need_recv_items = 0, need_send_items = 0;
     long long stride = 0;
     int *status_host = nullptr;                // pinned [8]
@@ -856,7 +856,7 @@ int update_meshes_blocking(chisel_hip_map *g) {
 // reduced word 0 says that anybody's list, plan or segment did not fit.  The host looks at shard 0's copy of that vector when the group is
 // next entered (settle): a recompute that was called off is then made again by update_meshes_blocking, from maps nobody has touched.
 // Three fan-outs (an event must have been recorded before another thread makes a stream wait for it), no host wait.
-int update_meshes_wait_free(chisel_hip_map *g) {
+int update_meshes_wait_free(chisel_hip_map *g, bool exact = false) {  // exact: settle()'s second go at a recompute whose slots were too small -- MS.need_* is what THIS recompute needs
     const int W = n_shards(g);
     MeshStages &MS = *static_cast<MeshStages *>(g->mesh_stages_group);
     const bool timing = g_host_timer.on;
@@ -869,9 +869,9 @@ int update_meshes_wait_free(chisel_hip_map *g) {
         t_prev = n;
     };
     if (2 * MS.need_max_count > MS.cap) MS.cap = (int)std::min<int64_t>(4 * MS.need_max_count, 1 << 26);
-    long long stride = ((long long)MS.need_seg_bytes + MS.need_seg_bytes / 2 + 4096 + 15) / 16 * 16;
+    long long stride = ((long long)MS.need_seg_bytes + (exact ? 0 : MS.need_seg_bytes / 2) + 4096 + 15) / 16 * 16;
     static const bool tiny_slots = getenv("CHISEL_HIP_GROUP_TINY_SLOTS") != nullptr;  // test hook: every other wait-free recompute gets slots of 64 bytes -- called off on the device, made again by settle()
-    if (tiny_slots && (MS.wait_free_recomputes & 1)) stride = 64;
+    if (tiny_slots && !exact && (MS.wait_free_recomputes & 1)) stride = 64;
     const long long bytes = stride * W;
     for (int i = 0; i < W; i++) {
         HIP_TRY(hipSetDevice(g->shards[(size_t)i]->device));
@@ -1026,6 +1026,15 @@ int settle(chisel_hip_map *g) {
         return CHISEL_HIP_OK;
     }
     MS.called_off++;
+    if (st[0] == 4 && !MS.retrying) {
+        // only the slots were too small, and the status says by how much: the same recompute again (the maps are as they were, so are the
+        // plans), still without reading a plan, in slots that hold exactly this; settled right away -- it cannot fail the same way
+        MS.retrying = true;
+        rc = update_meshes_wait_free(g, true);
+        if (!rc) rc = settle(g);
+        MS.retrying = false;
+        return rc;
+    }
     if (st[0] & 1) MS.cap = (int)std::min<int64_t>(2 * (int64_t)st[1], 1 << 26);
     return update_meshes_blocking(g);
 }
