@@ -924,9 +924,9 @@ int launch_group(chisel_hip_map *m, chisel_hip_map::BatchSet &bs, const PyramidP
 
 // the ghosts of a wait-free sharded recompute go (kernels_map.h: the drop in two passes); latch: leave them while the mesh step has to be emitted again
 void launch_fixed_drop(chisel_hip_map *m, const int *latch) {
-    hipLaunchKernelGGL(shell_reset_boxes_fixed_kernel, dim3(m->shell_items_grid), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, m->cfg.n_shards, m->N,
-                       m->shell_abort_dev, latch);
-    hipLaunchKernelGGL(shell_remove_ghosts_fixed_kernel, dim3((m->shell_items_grid + 255) / 256), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride,
+    hipLaunchKernelGGL(shell_reset_boxes_kernel, dim3(m->shell_items_grid), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, ShellSegments{}, m->cfg.n_shards,
+                       m->N, m->shell_abort_dev, latch);
+    hipLaunchKernelGGL(shell_remove_ghosts_kernel, dim3((m->shell_items_grid + 255) / 256), dim3(256), 0, m->stream, m->view, m->ghost_packed, (long long)m->shell_stride, ShellSegments{},
                        m->cfg.n_shards, m->shell_abort_dev, latch);
 }
 // the integration of a set that was queued behind a recompute which then did not fit: its kernel left at once (MC_LATCH), here it is again
@@ -2200,8 +2200,12 @@ int chisel_hip_drop_ghost_chunks(chisel_hip_map *m) {
         { m->topology_epoch++; m->dirty_tail_queued = false; }
         int rc_p = check_mesh_totals(m);  // a recompute in flight may still read them
         if (rc_p) return rc_p;
-        if (m->ghost_packed_items > 0)
-            hipLaunchKernelGGL(shell_drop_ghosts_kernel, dim3((unsigned)m->ghost_packed_items), dim3(256), 0, m->stream, m->view, m->ghost_packed, m->ghost_segments, m->cfg.n_shards, m->V);
+        if (m->ghost_packed_items > 0) {  // (the two passes of kernels_map.h, over segments that lie back to back)
+            hipLaunchKernelGGL(shell_reset_boxes_kernel, dim3((unsigned)m->ghost_packed_items), dim3(256), 0, m->stream, m->view, m->ghost_packed, 0ll, m->ghost_segments, m->cfg.n_shards,
+                               m->N, (const int *)nullptr, (const int *)nullptr);
+            hipLaunchKernelGGL(shell_remove_ghosts_kernel, dim3((unsigned)(m->ghost_packed_items + 255) / 256), dim3(256), 0, m->stream, m->view, m->ghost_packed, 0ll, m->ghost_segments,
+                               m->cfg.n_shards, (const int *)nullptr, (const int *)nullptr);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(note_map_mutation(m));
         m->ghost_packed = nullptr;

@@ -813,41 +813,7 @@ __global__ __launch_bounds__(256) void shell_import_kernel(MapView M, const unsi
     const int *it = shell_received_item(in, G, n_shards, blockIdx.x, peer);
     shell_import_item(M, in, G.off[peer], it, N, &s_slot);
 }
-// step 6: the ghosts go again -- one workgroup per received item; of the items that name one ghost the one whose swap takes the key out
-// frees the slot (as remove_chunks_kernel does for a list with duplicates)
-__device__ inline void shell_drop_item(const MapView &M, const int *it, int V, int *s_slot) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *s_slot = -1;
-        uint64_t where = 0;
-        const int slot = it[4] ? hash_find(M, it[0], it[1], it[2], &where) : -1;
-        if (slot >= 0) {
-            const uint64_t key = pack_id(it[0], it[1], it[2]);
-            if (atomicCAS((unsigned long long *)&M.hash_keys[where], (unsigned long long)key, (unsigned long long)KEY_TOMB) == key) {
-                M.slot_key[slot] = KEY_EMPTY;
-                M.slot_dirty[slot] = 0;
-                slot_summary(M)[slot] = 0;
-                if (M.mesh_flag) M.mesh_flag[slot] = 0;
-                *s_slot = slot;
-            }
-        }
-    }
-    __syncthreads();
-    const int slot = *s_slot;
-    if (slot < 0) return;
-    fill_default_chunk(M, slot, V);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const int pos = atomicAdd(M.free_top, 1);
-        M.free_list[pos] = slot;
-    }
-}
-__global__ __launch_bounds__(256) void shell_drop_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, ShellSegments G, int n_shards, int V) {
-    __shared__ int s_slot;
-    int peer;
-    shell_drop_item(M, shell_received_item(in, G, n_shards, blockIdx.x, peer), V, &s_slot);
-}
+// step 6: the ghosts go again: shell_reset_boxes_kernel + shell_remove_ghosts_kernel below (both forms of the recompute)
 // ---- the same three steps in the wait-free form: segments `stride` bytes apart, their item counts in their heads (a head that says
 // "did not fit" counts as empty), a fixed grid whose workgroups take the items in turn, and nothing at all when the recompute was called off
 // (`abort`: word 0 of the all-reduced status) -- or, for the drop (two kernels, below), while the mesh step in front of it is still to be emitted again
@@ -893,15 +859,21 @@ __global__ __launch_bounds__(256) void shell_import_fixed_kernel(MapView M, cons
     }
 }
 // The drop in two passes.  A ghost holds default voxels everywhere but in the boxes that were written into it, so only those are restored
-// (a sixth of the chunk on average; the one-pass kernel above restores all of it, from the one workgroup that wins the ghost's key, while the
-// workgroups of its other items wait for nothing: 40 us per recompute against 12 + 5): pass 1, one workgroup per item, puts the item's box
+// (a sixth of the chunk on average; the one-pass kernel of round 5 restored all of it, from the one workgroup that won the ghost's key, while the
+// workgroups of its other items waited for nothing: 40 us per recompute against 12 + 5): pass 1, one workgroup per item, puts the item's box
 // back to default voxels; pass 2, one thread per item, takes the keys out and frees the slots.
-__global__ __launch_bounds__(256) void shell_reset_boxes_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, int N, const int *abort,
-                                                                      const int *latch) {
+// (stride == 0: the blocking form -- the segments lie back to back where `packed` says, as the host laid them out from the plan's counts)
+__global__ __launch_bounds__(256) void shell_reset_boxes_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, ShellSegments packed, int n_shards, int N,
+                                                                const int *abort, const int *latch) {
     __shared__ ShellSegments G;
     __shared__ int s_slot;
     if ((abort && *abort) || (latch && *latch)) return;
-    shell_segments_fixed(in, stride, n_shards, &G);
+    if (stride > 0) {
+        shell_segments_fixed(in, stride, n_shards, &G);
+    } else {
+        if (threadIdx.x == 0) G = packed;
+        __syncthreads();
+    }
     const int total = G.first_item[n_shards];
     for (int j = blockIdx.x; j < total; j += gridDim.x) {
         int peer;
@@ -923,11 +895,16 @@ __global__ __launch_bounds__(256) void shell_reset_boxes_fixed_kernel(MapView M,
         }
     }
 }
-__global__ __launch_bounds__(256) void shell_remove_ghosts_fixed_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, int n_shards, const int *abort,
-                                                                        const int *latch) {
+__global__ __launch_bounds__(256) void shell_remove_ghosts_kernel(MapView M, const unsigned char *__restrict__ in, long long stride, ShellSegments packed, int n_shards,
+                                                                  const int *abort, const int *latch) {
     __shared__ ShellSegments G;
     if ((abort && *abort) || (latch && *latch)) return;
-    shell_segments_fixed(in, stride, n_shards, &G);
+    if (stride > 0) {
+        shell_segments_fixed(in, stride, n_shards, &G);
+    } else {
+        if (threadIdx.x == 0) G = packed;
+        __syncthreads();
+    }
     const int total = G.first_item[n_shards];
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
         int peer;

@@ -6,7 +6,7 @@ from collections import defaultdict
 out, shards, recomputes = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 steps = [("dirty ids", ("list_dirty_ids_kernel",)), ("plan", ("shell_jobs_kernel", "shell_items_kernel")), ("export + status", ("shell_export_kernel",)),
          ("import", ("shell_ensure_ghosts_fixed_kernel", "shell_import_fixed_kernel")),
-         ("mesh", ("clear_dirty_kernel", "mesh_count_kernel_16", "mesh_triangle_kernel", "shell_abort_relist_kernel")), ("drop", ("shell_reset_boxes_fixed_kernel", "shell_remove_ghosts_fixed_kernel"))]
+         ("mesh", ("clear_dirty_kernel", "mesh_count_kernel_16", "mesh_triangle_kernel", "shell_abort_relist_kernel")), ("drop", ("shell_reset_boxes_kernel", "shell_remove_ghosts_kernel"))]
 agg = defaultdict(list)
 for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
