@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--mesh-every", type=int, default=None,
                     help="marching-cubes recompute (UpdateMeshes) every M frames inside the timed region; default: 10 at 1 GPU (the "
                          "reference's keyframe cadence, Chisel.cpp:54 -- BASELINE config 3), 0 = off (N > 1: a sharded map is not meshed yet)")
+    ap.add_argument("--shard-block", type=int, default=0,
+                    help="N > 1 / --sim-shards: edge of the ownership blocks in chunks (chunk_owner; 0 = the library's 2).  Larger blocks: fewer "
+                         "shells cross between ranks when the map is meshed, coarser balance of the integration")
     ap.add_argument("--mesh-checksum", action="store_true",
                     help="after the last pass: meshes, vertices and a checksum over every mesh array of the final map (summed over the ranks), as "
                          "`mesh_checksum` -- equal at every N when the sharded mesher is right (tests/test_gpu_bench.py)")
@@ -325,7 +328,7 @@ def main():
         else:
             m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
                        n_shards=args.sim_shards if (args.sim_shards and world == 1) else world,
-                       shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank)
+                       shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank, shard_block=args.shard_block)
         m._use(integ)
         m.px = PipelinedExchange(xch, m) if world > 1 else None  # RCCL -> integrate ordering: events, no host wait
         m.sharded = ShardedChisel(m, xch, integ) if world > 1 else None  # Chisel::UpdateMeshes of the sharded map
