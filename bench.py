@@ -68,8 +68,9 @@ def parse():
                     help="marching-cubes recompute (UpdateMeshes) every M frames inside the timed region; default: 10 at 1 GPU (the "
                          "reference's keyframe cadence, Chisel.cpp:54 -- BASELINE config 3), 0 = off (N > 1: a sharded map is not meshed yet)")
     ap.add_argument("--shard-block", type=int, default=0,
-                    help="N > 1 / --sim-shards: edge of the ownership blocks in chunks (chunk_owner; 0 = the library's 2).  Larger blocks: fewer "
-                         "shells cross between ranks when the map is meshed, coarser balance of the integration")
+                    help="N > 1 / --sim-shards: edge of the ownership blocks in chunks (chunk_owner; 0 = 8 between two ranks, where every edge "
+                         "balances alike, else the library's 2).  Larger blocks: fewer shells cross between ranks when the map is meshed, coarser "
+                         "balance of the integration from four ranks on (tools/shard_balance.py)")
     ap.add_argument("--mesh-checksum", action="store_true",
                     help="after the last pass: meshes, vertices and a checksum over every mesh array of the final map (summed over the ranks), as "
                          "`mesh_checksum` -- equal at every N when the sharded mesher is right (tests/test_gpu_bench.py)")
@@ -326,9 +327,14 @@ def main():
         if group_devices:
             m = Chisel((args.chunk,) * 3, args.res, use_color, max_chunks=args.max_chunks, devices=group_devices)
         else:
+            ns = args.sim_shards if (args.sim_shards and world == 1) else world
+            # ownership blocks: between TWO ranks the owner is the parity of bx + by + bz -- a 3-D checkerboard that deals every launch set
+            # evenly whatever the blocks' edge (tools/shard_balance.py: max / mean 1.00), so the largest edge measured is taken there: a
+            # quarter of the shells cross between the ranks per recompute.  From four ranks on larger blocks cost more than they save.
+            blk = args.shard_block or (8 if ns == 2 else 0)
             m = Chisel((args.chunk,) * 3, args.res, use_color, device_id=local_rank, max_chunks=args.max_chunks,
-                       n_shards=args.sim_shards if (args.sim_shards and world == 1) else world,
-                       shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank, shard_block=args.shard_block)
+                       n_shards=ns,
+                       shard_rank=(args.sim_rank % args.sim_shards) if (args.sim_shards and world == 1) else rank, shard_block=blk)
         m._use(integ)
         m.px = PipelinedExchange(xch, m) if world > 1 else None  # RCCL -> integrate ordering: events, no host wait
         m.sharded = ShardedChisel(m, xch, integ) if world > 1 else None  # Chisel::UpdateMeshes of the sharded map
